@@ -1,0 +1,304 @@
+"""
+CPU oracle for the DenseMatcher matching hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a NumPy float64 restatement of the
+reference's algorithm.  It may be imported by `tests/`, by
+`__graft_entry__.smoke()` and by the `cpu_baseline` leg of `bench.py` as the
+*checker* / the *timed CPU baseline*.  It is never imported by the product
+package `densematcher_amd` (which fails loudly when its HIP library is missing).
+
+Parity pinning: the reference has no tests or golden vectors on this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, generated in the build container by `tools/make_golden.py` (which
+imports `/root/reference`) and committed under `tests/golden/`.
+`tests/test_oracle_golden.py` checks every function below against them.
+
+Every function cites the reference file:line it restates (paths relative to
+`/root/reference/densematcher/`).
+
+Conventions:
+    Phi1 (N1,k1), Phi2 (N2,k2)   mass-orthonormal Laplace-Beltrami eigenvectors
+    lam1 (k1,),  lam2 (k2,)      eigenvalues
+    a1 (N1,),    a2 (N2,)        diagonal of the lumped mass matrices A1, A2
+    F1 (N1,D),   F2 (N2,D)       per-vertex descriptors
+    C (k2,k1)                    functional map: basis-1 coefficients -> basis-2
+    p2p_21 (N2,)                 for each vertex of mesh 2, a vertex of mesh 1
+"""
+import numpy as np
+import scipy.linalg
+import scipy.optimize
+
+
+# --------------------------------------------------------------------------- #
+# spectral projection
+# --------------------------------------------------------------------------- #
+def project(phi, mass, F):
+    """Phi^T (a * F)   -- pyFM/optimize/base_functions.py:526-532
+    (`evects.T @ A @ descr`, A = dense diag(mass); eta == 1) and
+    pyFM/mesh/trimesh.py:533-556 (`TriMesh.project`)."""
+    phi = np.asarray(phi, dtype=np.float64)
+    F = np.asarray(F, dtype=np.float64)
+    mass = np.asarray(mass, dtype=np.float64)
+    return phi.T @ (mass[:, None] * F)
+
+
+def ev_sqdiff(lam1, lam2):
+    """((lam1[None,:] - lam2[:,None]) / scale)^2, scale = max(lam1.max, lam2.max)
+    -- pyFM/functional.py:404-405.  Note: the reference divides each term by
+    `scale` before subtracting; kept in that order."""
+    lam1 = np.asarray(lam1, dtype=np.float64)
+    lam2 = np.asarray(lam2, dtype=np.float64)
+    scale = max(lam1.max(), lam2.max())
+    return np.square(lam1[None, :] / scale - lam2[:, None] / scale)
+
+
+def get_x0(k1, k2, phi1_00, phi2_00, area1, area2, optinit="zeros", rng=None):
+    """Initial functional map with the hand-set first column
+    -- pyFM/functional.py:629-660."""
+    if optinit == "random":
+        rng = np.random if rng is None else rng
+        x0 = rng.random((k2, k1))
+        x0 = x0 / x0.sum()
+    elif optinit == "identity":
+        x0 = np.eye(k2, k1)
+    elif optinit == "zeros":
+        x0 = np.zeros((k2, k1))
+    else:
+        raise ValueError(f"optinit arg should be 'random', 'identity' or 'zeros', not {optinit}")
+    ev_sign = np.sign(phi1_00 * phi2_00)
+    area_ratio = np.sqrt(area2 / area1)
+    x0[:, 0] = np.zeros(k2)
+    x0[0, 0] = ev_sign * area_ratio
+    return x0
+
+
+# --------------------------------------------------------------------------- #
+# energy, gradient, minimiser
+# --------------------------------------------------------------------------- #
+def energy(C, A, B, ev, w_descr, w_lap):
+    """w_descr * 0.5 ||C A - B||^2 + w_lap * 0.5 sum(C^2 * ev)
+    -- pyFM/optimize/base_functions.py:49 (descr_preservation), :95
+    (LB_commutation), :534-544 (weights)."""
+    return w_descr * 0.5 * np.square(C @ A - B).sum() + w_lap * 0.5 * (np.square(C) * ev).sum()
+
+
+def grad_energy(C, A, B, ev, w_descr, w_lap):
+    """w_descr (C A - B) A^T + w_lap C * ev with column 0 zeroed
+    -- pyFM/optimize/base_functions.py:58-76, :105-121, :759."""
+    g = w_descr * (C @ A - B) @ A.T + w_lap * C * ev
+    g[:, 0] = 0
+    return g
+
+
+def fmap_fit_lbfgs(A, B, ev, x0, w_descr, w_lap, maxiter=100000):
+    """float64 L-BFGS-B on the reference energy with its analytic gradients
+    -- pyFM/functional.py:477 (scipy.optimize.minimize) driven in float64
+    instead of the fp32 torch autograd energy.  Tight tolerances so that it
+    converges to the minimiser that `fmap_solve` gives in closed form."""
+    k2, k1 = x0.shape
+
+    def f(x):
+        return energy(x.reshape(k2, k1), A, B, ev, w_descr, w_lap)
+
+    def g(x):
+        return grad_energy(x.reshape(k2, k1), A, B, ev, w_descr, w_lap).ravel()
+
+    res = scipy.optimize.minimize(f, x0.ravel(), jac=g, method="L-BFGS-B",
+                                  options={"maxiter": maxiter, "maxfun": 10 * maxiter,
+                                           "ftol": 1e-20, "gtol": 1e-12, "maxcor": 30})
+    return res.x.reshape(k2, k1), res
+
+
+def fmap_solve(A, B, lam1, lam2, x0, w_descr, w_lap):
+    """Closed-form minimiser of `energy` with column 0 pinned to x0[:,0]
+    (SURVEY.md Appendix A.5).  Rows decouple:
+        (P[f,f] + w_lap diag(ev[i,f])) C[i,f] = Q[i,f] - P[f,0] x0[i,0],
+    P = w_descr A A^T, Q = w_descr B A^T, f = 1..k1-1.
+    This is what any optimiser applied to base_functions.py:480-763 converges
+    to when only w_descr and w_lap are non-zero."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    k1, k2 = A.shape[0], B.shape[0]
+    ev = ev_sqdiff(lam1, lam2)
+    P = w_descr * (A @ A.T)
+    Q = w_descr * (B @ A.T)
+    C = np.zeros((k2, k1))
+    C[:, 0] = x0[:, 0]
+    Pff = P[1:, 1:]
+    for i in range(k2):
+        M = Pff + w_lap * np.diag(ev[i, 1:])
+        rhs = Q[i, 1:] - P[1:, 0] * x0[i, 0]
+        C[i, 1:] = scipy.linalg.solve(M, rhs, assume_a="pos")
+    return C
+
+
+def fit(phi1, phi2, lam1, lam2, a1, a2, F1, F2, w_descr, w_lap, optinit="zeros"):
+    """FunctionalMapping.fit restated (w_descr / w_lap terms only)
+    -- pyFM/functional.py:352-487.  Returns C (k2,k1) float64."""
+    k1, k2 = phi1.shape[1], phi2.shape[1]
+    A = project(phi1, a1, F1)
+    B = project(phi2, a2, F2)
+    x0 = get_x0(k1, k2, float(phi1[0, 0]), float(phi2[0, 0]),
+                float(np.asarray(a1, dtype=np.float64).sum()),
+                float(np.asarray(a2, dtype=np.float64).sum()), optinit)
+    return fmap_solve(A, B, lam1, lam2, x0, w_descr, w_lap)
+
+
+# --------------------------------------------------------------------------- #
+# functional map <-> point-to-point map
+# --------------------------------------------------------------------------- #
+def knn_query(X, Y, chunk=2048):
+    """For every row of Y the index of the nearest row of X (k = 1)
+    -- pyFM/spectral/nn_utils.py:4-38 (sklearn kd-tree, exact Euclidean NN).
+    Restated as the brute-force argmin of |x|^2 - 2 <x,y>, lowest index on
+    ties.  Agrees with the kd-tree wherever the nearest neighbour is unique."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    nx = np.einsum("ij,ij->i", X, X)
+    out = np.empty(Y.shape[0], dtype=np.int64)
+    for s in range(0, Y.shape[0], chunk):
+        d = nx[None, :] - 2.0 * (Y[s:s + chunk] @ X.T)
+        out[s:s + chunk] = d.argmin(axis=1)
+    return out
+
+
+def fm_to_p2p(C, phi1, phi2, a1, with_indicator=True):
+    """FM_to_p2p -- pyFM/spectral/convert.py:96-147.
+    Returns (p2p_21 (N2,), p2p_12 (N1,), mapped_indicator (N2,N1) or None).
+    Eigenvectors are sliced to the map's size (the fork's unsliced :144 only
+    works when they already are)."""
+    k2, k1 = C.shape
+    assert k1 <= phi1.shape[1], f"At least {k1} should be provided, here only {phi1.shape[1]} are given"
+    assert k2 <= phi2.shape[1], f"At least {k2} should be provided, here only {phi2.shape[1]} are given"
+    e1 = np.asarray(phi1[:, :k1], dtype=np.float64)
+    e2 = np.asarray(phi2[:, :k2], dtype=np.float64)
+    # convert.py:134-136  tree = Phi2 C, query = Phi1
+    p2p_12 = knn_query(e2 @ C, e1)
+    # convert.py:138-140  tree = Phi1 C^T, query = Phi2
+    p2p_21 = knn_query(e1 @ C.T, e2)
+    ind = None
+    if with_indicator:
+        # convert.py:144  Phi2 C Phi1^T A1, A1 diagonal
+        ind = ((e2 @ C) @ e1.T) * np.asarray(a1, dtype=np.float64)[None, :]
+    return p2p_21, p2p_12, ind
+
+
+def indicator_argmax(ind, eta=None):
+    """functional_map.py:49-50: argmax over axis 1 and axis 0 of
+    mapped_indicator * eta[:,None] (eta == 1 after fit, functional.py:483)."""
+    if eta is not None:
+        ind = ind * eta[..., None]
+    return ind.argmax(axis=1), ind.argmax(axis=0)
+
+
+def fm_to_p2p_all(C, phi1, phi2, a1, chunk=1024):
+    """All four integer maps of one pair without materialising the indicator
+    at once (same arithmetic as fm_to_p2p + indicator_argmax, row-chunked).
+    Returns (knn21, knn12, ind21, ind12)."""
+    k2, k1 = C.shape
+    e1 = np.asarray(phi1[:, :k1], dtype=np.float64)
+    e2 = np.asarray(phi2[:, :k2], dtype=np.float64)
+    a1 = np.asarray(a1, dtype=np.float64)
+    knn12 = knn_query(e2 @ C, e1)
+    knn21 = knn_query(e1 @ C.T, e2)
+    emb2 = e2 @ C
+    N2, N1 = e2.shape[0], e1.shape[0]
+    ind21 = np.empty(N2, dtype=np.int64)
+    colbest = np.full(N1, -np.inf)
+    ind12 = np.zeros(N1, dtype=np.int64)
+    for s in range(0, N2, chunk):
+        blk = (emb2[s:s + chunk] @ e1.T) * a1[None, :]
+        ind21[s:s + chunk] = blk.argmax(axis=1)
+        r = blk.argmax(axis=0)
+        v = blk[r, np.arange(N1)]
+        upd = v > colbest          # strict: earlier chunk wins ties (first index)
+        colbest[upd] = v[upd]
+        ind12[upd] = r[upd] + s
+    return knn21, knn12, ind21, ind12
+
+
+def p2p_to_fm(p2p_21, phi1, phi2, a2=None):
+    """p2p_to_FM -- pyFM/spectral/convert.py:14-51.
+    With a2: Phi2^T (a2 * Phi1[p2p_21])  (:41-48); without: least squares (:51)."""
+    e1 = np.asarray(phi1, dtype=np.float64)
+    e2 = np.asarray(phi2, dtype=np.float64)
+    pb = e1[np.asarray(p2p_21), :]
+    if a2 is not None:
+        a2 = np.asarray(a2, dtype=np.float64)
+        if a2.shape[0] != e2.shape[0]:
+            raise ValueError("Can't compute exact pseudo inverse with subsampled eigenvectors")
+        return e2.T @ (a2[:, None] * pb)
+    return scipy.linalg.lstsq(e2, pb)[0]
+
+
+# --------------------------------------------------------------------------- #
+# refinement
+# --------------------------------------------------------------------------- #
+def zoomout_refine(C, phi1, phi2, nit, step=1, a2=None, return_p2p=False, trajectory=None):
+    """ZoomOut -- pyFM/refine/zoomout.py:7-44 (iteration), :47-115 (loop),
+    with upstream-pyFM FM_to_p2p semantics (the fork's call at :40/:112 is
+    broken): p2p_21 = NN(tree = Phi1[:, :k1] C^T,
+    query = Phi2[:, :k2])."""
+    k2_0, k1_0 = C.shape
+    try:
+        step1, step2 = step
+    except TypeError:
+        step1 = step2 = step
+    assert k1_0 + nit * step1 <= phi1.shape[1], \
+        f"Not enough eigenvectors on source : {k1_0 + nit * step1} are needed when {phi1.shape[1]} are provided"
+    assert k2_0 + nit * step2 <= phi2.shape[1], \
+        f"Not enough eigenvectors on target : {k2_0 + nit * step2} are needed when {phi2.shape[1]} are provided"
+    e1 = np.asarray(phi1, dtype=np.float64)
+    e2 = np.asarray(phi2, dtype=np.float64)
+    C = np.array(C, dtype=np.float64)
+    for _ in range(nit):
+        k2, k1 = C.shape
+        p21 = knn_query(e1[:, :k1] @ C.T, e2[:, :k2])           # zoomout.py:40
+        C = p2p_to_fm(p21, e1[:, :k1 + step1], e2[:, :k2 + step2], a2)   # zoomout.py:42
+        if trajectory is not None:
+            trajectory.append((p21, C))
+    if return_p2p:
+        k2, k1 = C.shape
+        p21 = knn_query(e1[:, :k1] @ C.T, e2[:, :k2])           # zoomout.py:111-113
+        return C, p21
+    return C
+
+
+def icp_refine(C, phi1, phi2, nit=10):
+    """ICP -- pyFM/refine/icp.py:10-40 (iteration), :43-107 (loop, fixed nit).
+    p2p_21 -> least-squares map (no mass, convert.py:51) -> U eye V^T."""
+    k2, k1 = C.shape
+    e1 = np.asarray(phi1[:, :k1], dtype=np.float64)
+    e2 = np.asarray(phi2[:, :k2], dtype=np.float64)
+    C = np.array(C, dtype=np.float64)
+    for _ in range(nit):
+        p21 = knn_query(e1 @ C.T, e2)
+        Ch = scipy.linalg.lstsq(e2, e1[p21, :])[0]
+        U, _, VT = scipy.linalg.svd(Ch)
+        C = U @ np.eye(k2, k1) @ VT
+    return C
+
+
+# --------------------------------------------------------------------------- #
+# feature-similarity nearest neighbour (BASELINE.json config 3)
+# --------------------------------------------------------------------------- #
+def simnn(F_tgt, F_src, chunk=2048):
+    """nn[i] = argmax_j <F_tgt[i], F_src[j]>, lowest index on ties.
+    No reference symbol exists for this: parity is
+    unpinned by the reference; this float64 statement is the definition."""
+    T = np.asarray(F_tgt, dtype=np.float64)
+    S = np.asarray(F_src, dtype=np.float64)
+    out = np.empty(T.shape[0], dtype=np.int64)
+    for s in range(0, T.shape[0], chunk):
+        out[s:s + chunk] = (T[s:s + chunk] @ S.T).argmax(axis=1)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# one pair end to end (what bench.py's cpu_baseline times)
+# --------------------------------------------------------------------------- #
+def match_pair(phi1, phi2, lam1, lam2, a1, a2, F1, F2, w_descr=1e4, w_lap=1e3):
+    """project -> closed-form fit -> four integer maps, for one pair."""
+    C = fit(phi1, phi2, lam1, lam2, a1, a2, F1, F2, w_descr, w_lap)
+    knn21, knn12, ind21, ind12 = fm_to_p2p_all(C, phi1, phi2, a1)
+    return C, knn21, knn12, ind21, ind12

@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def fx_cfg1():
+    return load_golden("fx_cfg1.npz")
+
+
+@pytest.fixture(scope="session")
+def fx_ties():
+    return load_golden("fx_ties.npz")
+
+
+@pytest.fixture(scope="session")
+def fx_cfg2():
+    fx = load_golden("fx_cfg2.npz")
+    from densematcher_amd import synth
+    n = fx["Phi1"].shape[0]
+    s1, s2 = (int(x) for x in fx["feat_seeds"])
+    F1, F2, _ = synth.feature_pair(n, n, int(fx["D"]), s1, s2, sigma=float(fx["feat_sigma"]), perm="identity")
+    assert synth.sha256_of(F1, F2) == str(fx["feat_sha256"]), "regenerated descriptors differ from the fixture's"
+    fx["F1"], fx["F2"] = F1, F2
+    return fx

@@ -1,0 +1,151 @@
+"""
+CPU: pin the oracle (oracle/dm_oracle.py) against the golden vectors that
+tools/make_golden.py produced by running the reference itself.
+"""
+import numpy as np
+import pytest
+
+from oracle import dm_oracle as orc
+
+
+def _f64(fx, *names):
+    return [np.asarray(fx[n], dtype=np.float64) for n in names]
+
+
+@pytest.mark.parametrize("fxname", ["fx_cfg1", "fx_cfg2"])
+def test_fit_matches_reference(fxname, request):
+    fx = request.getfixturevalue(fxname)
+    phi1, phi2, a1, a2 = _f64(fx, "Phi1", "Phi2", "a1", "a2")
+    k = int(fx["k"])
+    phi1, phi2 = phi1[:, :k], phi2[:, :k]
+    lam1, lam2 = fx["lam1"][:k], fx["lam2"][:k]
+    C = orc.fit(phi1, phi2, lam1, lam2, a1, a2, fx["F1"], fx["F2"], float(fx["w_descr"]), float(fx["w_lap"]))
+    # closed form == float64 L-BFGS-B over the reference's analytic gradients
+    assert np.abs(C - fx["C_f64"]).max() < 2e-6
+    # distance to the reference's fp32-autograd fit(): its own noise floor
+    assert np.abs(C - fx["C_fit"]).max() < 2e-3
+    # pinned first column (functional.py:654-658, base_functions.py:759)
+    assert np.array_equal(C[:, 0], fx["C_fit"][:, 0])
+
+
+def test_pieces_cfg1(fx_cfg1):
+    fx = fx_cfg1
+    k = int(fx["k"])
+    phi1, phi2, a1, a2 = _f64(fx, "Phi1", "Phi2", "a1", "a2")
+    phi1k, phi2k = phi1[:, :k], phi2[:, :k]
+    A = orc.project(phi1k, a1, fx["F1"])
+    B = orc.project(phi2k, a2, fx["F2"])
+    assert np.abs(A - fx["A_f64"]).max() < 1e-12
+    assert np.abs(B - fx["B_f64"]).max() < 1e-12
+    assert np.abs(A - fx["A_f32"]).max() < 1e-5 * np.abs(A).max() + 1e-7      # reference computes these in fp32
+    ev = orc.ev_sqdiff(fx["lam1"][:k], fx["lam2"][:k])
+    assert np.array_equal(ev, fx["ev_sqdiff"])
+    x0 = orc.get_x0(k, k, phi1[0, 0], phi2[0, 0], a1.sum(), a2.sum())
+    assert np.allclose(x0, fx["x0"], rtol=1e-15, atol=0)
+    # energy/gradient: the minimiser has zero free gradient
+    g = orc.grad_energy(fx["C_f64"], A, B, ev, float(fx["w_descr"]), float(fx["w_lap"]))
+    assert np.abs(g).max() < 1e-4 * float(fx["w_descr"]) * np.abs(A @ A.T).max()
+    Cl, res = orc.fmap_fit_lbfgs(A, B, ev, x0, float(fx["w_descr"]), float(fx["w_lap"]))
+    assert np.abs(Cl - fx["C_f64"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("fxname,pre", [("fx_cfg1", ""), ("fx_cfg2", ""), ("fx_cfg2", "f64_")])
+def test_maps_bit_exact(fxname, pre, request):
+    fx = request.getfixturevalue(fxname)
+    k = int(fx["k"])
+    phi1, phi2, a1 = _f64(fx, "Phi1", "Phi2", "a1")
+    C = fx["C_f64"] if pre else fx["C_fit"]
+    p21, p12, ind = orc.fm_to_p2p(C, phi1[:, :k], phi2[:, :k], a1)
+    i21, i12 = orc.indicator_argmax(ind, np.ones(ind.shape[0]))
+    assert np.array_equal(p21, fx[pre + "knn21"])
+    assert np.array_equal(p12, fx[pre + "knn12"])
+    assert np.array_equal(i21, fx[pre + "ind21"])
+    assert np.array_equal(i12, fx[pre + "ind12"])
+    q = orc.fm_to_p2p_all(C, phi1[:, :k], phi2[:, :k], a1, chunk=300)
+    for got, name in zip(q, ["knn21", "knn12", "ind21", "ind12"]):
+        assert np.array_equal(got, fx[pre + name])
+    if fxname == "fx_cfg1":
+        assert np.allclose(ind[fx["ind_row_ids"]], fx["ind_rows"], rtol=1e-12, atol=1e-14)
+
+
+def test_ties(fx_ties):
+    fx = fx_ties
+    phi1, phi2, a1 = _f64(fx, "Phi1", "Phi2", "a1")
+    p21, p12, ind = orc.fm_to_p2p(fx["C"], phi1, phi2, a1)
+    i21, i12 = orc.indicator_argmax(ind)
+    # np.argmax is first-index: the indicator maps are pinned bit-exactly, ties included
+    assert np.array_equal(i21, fx["ind21"])
+    assert np.array_equal(i12, fx["ind12"])
+    # the kd-tree breaks exact ties by traversal order, not by index: where the
+    # reference differs from the lowest-index rule it must be an exact tie.
+    e1 = phi1 @ fx["C"].T
+    for got, ref, tree, query in [(p21, fx["knn21"], e1, phi2), (p12, fx["knn12"], phi2 @ fx["C"], phi1)]:
+        diff = np.nonzero(got != ref)[0]
+        for i in diff:
+            assert np.array_equal(tree[got[i]], tree[ref[i]]), "mismatch that is not an exact duplicate"
+            assert got[i] < ref[i]
+        assert len(diff) <= 80
+
+
+def test_p2p_to_fm(fx_cfg1):
+    fx = fx_cfg1
+    k = int(fx["k"])
+    phi1, phi2, a2 = _f64(fx, "Phi1", "Phi2", "a2")
+    C = orc.p2p_to_fm(fx["knn21"], phi1[:, :k], phi2[:, :k], a2)
+    assert np.abs(C - fx["C_from_p2p"]).max() < 1e-13
+    C = orc.p2p_to_fm(fx["knn21"], phi1[:, :k], phi2[:, :k])
+    assert np.abs(C - fx["C_from_p2p_lstsq"]).max() < 1e-10
+
+
+def test_zoomout(fx_cfg1, fx_cfg2):
+    fx = fx_cfg1
+    phi1, phi2, a2 = _f64(fx, "Phi1", "Phi2", "a2")
+    C, p = orc.zoomout_refine(fx["C20"], phi1, phi2, nit=20, step=1, a2=a2, return_p2p=True)
+    assert C.shape == (40, 40)
+    assert np.array_equal(p, fx["p21_zo"])
+    assert np.abs(C - fx["C_zo"]).max() < 1e-12
+    C, p = orc.zoomout_refine(fx["C20"], phi1, phi2, nit=6, step=4, a2=a2, return_p2p=True)
+    assert C.shape == (44, 44)
+    assert np.array_equal(p, fx["p21_zo4"])
+    assert np.abs(C - fx["C_zo4"]).max() < 1e-12
+    fx = fx_cfg2
+    phi1, phi2, a2 = _f64(fx, "Phi1", "Phi2", "a2")
+    C, p = orc.zoomout_refine(fx["C_fit"], phi1, phi2, nit=3, step=4, a2=a2, return_p2p=True)
+    assert np.array_equal(p, fx["p21_zo"])
+    assert np.abs(C - fx["C_zo"]).max() < 1e-12
+    with pytest.raises(AssertionError):
+        orc.zoomout_refine(fx["C_fit"], phi1, phi2, nit=4, step=4, a2=a2)
+
+
+def test_icp(fx_cfg1):
+    fx = fx_cfg1
+    k = int(fx["k"])
+    phi1, phi2, a1 = _f64(fx, "Phi1", "Phi2", "a1")
+    C = orc.icp_refine(fx["C_fit"], phi1[:, :k], phi2[:, :k], nit=10)
+    assert np.abs(C - fx["C_icp"]).max() < 1e-9
+    q = orc.fm_to_p2p_all(fx["C_icp"], phi1[:, :k], phi2[:, :k], a1)
+    for got, name in zip(q, ["icp_knn21", "icp_knn12", "icp_ind21", "icp_ind12"]):
+        assert np.array_equal(got, fx[name])
+
+
+def test_compute_surface_map_tuple(fx_cfg1):
+    """The 14-tuple's integer slots equal the piecewise reference outputs
+    (functional_map.py:48-50,75-77,81)."""
+    fx = fx_cfg1
+    assert np.array_equal(fx["csm_p2p_21"], fx["ind21"])
+    assert np.array_equal(fx["csm_p2p_12"], fx["ind12"])
+    assert np.array_equal(fx["csm_p2p_21_adjoint"], fx["knn21"])
+    assert np.array_equal(fx["csm_p2p_12_adjoint"], fx["knn12"])
+    assert np.array_equal(fx["csm_p2p_21_icp"], fx["icp_ind21"])
+    assert np.array_equal(fx["csm_p2p_21_icp_adjoint"], fx["icp_knn21"])
+    assert np.abs(fx["csm_FM_base"] - fx["C_fit"]).max() == 0.0
+
+
+def test_simnn_definition():
+    rng = np.random.default_rng(0)
+    S = rng.standard_normal((64, 32)).astype(np.float16)
+    T = S[rng.permutation(64)][:40]
+    nn = orc.simnn(T, S)
+    assert np.array_equal(S[nn], T)
+    S2 = np.concatenate([S, S[:5]])            # duplicates: lowest index wins
+    assert np.array_equal(orc.simnn(T, S2), nn)
