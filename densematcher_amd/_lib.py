@@ -1,0 +1,75 @@
+"""
+ctypes binding of libdensematch.so (include/densematch.h).
+
+The product path has NO fallback: if the library is missing or a call fails,
+an exception is raised.  (The NumPy oracle under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdensematch.so")
+
+DM_OK, DM_EINVAL, DM_ENOMEM, DM_EHIP, DM_ESINGULAR = 0, -1, -2, -3, -4
+DM_F16, DM_F32 = 0, 1
+
+_p = C.c_void_p
+_i = C.c_int
+_d = C.c_double
+
+# name -> (restype, argtypes); exactly the symbols include/densematch.h declares
+SIGNATURES = {
+    "dm_create": (_i, [_i, _p, C.POINTER(_p)]),
+    "dm_destroy": (_i, [_p]),
+    "dm_last_error": (C.c_char_p, [_p]),
+    "dm_version": (C.c_char_p, []),
+    "dm_workspace_bytes": (C.c_size_t, [_p]),
+    "dm_profile_kernel": (_i, [_p, C.c_char_p]),
+    "dm_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(_d)]),
+    "dm_simnn_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "dm_project": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
+    "dm_fmap_c00": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
+    "dm_fmap_solve": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _d, _d, _p, _p]),
+    "dm_fm_to_p2p": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "dm_p2p_to_fm": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
+    "dm_zoomout": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdensematch.so (built in-tree by `python -m densematcher_amd._build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library has not been built. "
+            "Run `python -m densematcher_amd._build` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class DenseMatchError(RuntimeError):
+    pass
+
+
+def raise_for(rc, lib, ctx):
+    if rc == DM_OK:
+        return
+    msg = lib.dm_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    if rc == DM_EINVAL:
+        raise ValueError(msg or "invalid argument")
+    if rc == DM_ENOMEM:
+        raise MemoryError(msg or "device workspace allocation failed")
+    if rc == DM_ESINGULAR:
+        raise DenseMatchError(msg or "system not positive definite")
+    raise DenseMatchError(msg or f"HIP failure (status {rc})")

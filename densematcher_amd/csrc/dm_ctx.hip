@@ -1,0 +1,117 @@
+// Context, error reporting, scratch arena and per-kernel event timing.
+#include <stdarg.h>
+
+#include "dm_internal.h"
+
+int dm_fail(dm_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" int dm_create(int device, void* hip_stream, dm_ctx** out) {
+    if (!out) return DM_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DM_EHIP;
+    if (hipSetDevice(device) != hipSuccess) return DM_EHIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DM_EHIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DM_EHIP;   // kernels exist for gfx950 only
+    dm_ctx* ctx = new dm_ctx();
+    ctx->device = device;
+    ctx->stream = (hipStream_t)hip_stream;
+    *out = ctx;
+    return DM_OK;
+}
+
+extern "C" int dm_destroy(dm_ctx* ctx) {
+    if (!ctx) return DM_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    delete ctx;
+    return DM_OK;
+}
+
+extern "C" const char* dm_last_error(const dm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" const char* dm_version(void) { return DM_VERSION_STRING; }
+extern "C" size_t dm_workspace_bytes(const dm_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+int dm_ws_reserve(dm_ctx* ctx, size_t total_bytes) {
+    ctx->ws_off = 0;
+    total_bytes = dm_align_up(total_bytes + 4096, 1 << 20);
+    if (total_bytes <= ctx->ws_bytes) return DM_OK;
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->ws) {
+        DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // nothing in flight may still use the old block
+        DM_CHECK_HIP(ctx, hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, total_bytes) != hipSuccess)
+        return dm_fail(ctx, DM_ENOMEM, "workspace allocation of %zu bytes failed", total_bytes);
+    ctx->ws = (char*)p;
+    ctx->ws_bytes = total_bytes;
+    return DM_OK;
+}
+
+void* dm_ws_take(dm_ctx* ctx, size_t bytes) {
+    size_t off = dm_align_up(ctx->ws_off);
+    if (off + bytes > ctx->ws_bytes) return nullptr;   // callers reserve exactly what they take
+    ctx->ws_off = off + bytes;
+    return ctx->ws + off;
+}
+
+// ---- per-kernel timing -------------------------------------------------------
+extern "C" int dm_profile_kernel(dm_ctx* ctx, const char* name) {
+    if (!ctx) return DM_EINVAL;
+    DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_name = name ? name : "";
+    ctx->prof_used = 0;
+    return DM_OK;
+}
+
+int dm_prof_begin(dm_ctx* ctx, const char* name) {
+    if (ctx->prof_name.empty() || ctx->prof_name != name) return -1;
+    if (ctx->prof_used + 2 > ctx->prof_events.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            ctx->prof_events.push_back(e);
+        }
+    }
+    int tok = (int)ctx->prof_used;
+    (void)hipEventRecord(ctx->prof_events[tok], ctx->stream);
+    ctx->prof_used += 2;
+    return tok;
+}
+
+int dm_prof_end(dm_ctx* ctx, int token) {
+    if (token < 0) return 0;
+    (void)hipEventRecord(ctx->prof_events[token + 1], ctx->stream);
+    return 0;
+}
+
+extern "C" int dm_profile_read(dm_ctx* ctx, int* launches, double* total_ms) {
+    if (!ctx || !launches || !total_ms) return DM_EINVAL;
+    DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        float ms = 0.f;
+        DM_CHECK_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
+        tot += ms;
+        ++n;
+    }
+    *launches = n;
+    *total_ms = tot;
+    ctx->prof_used = 0;
+    return DM_OK;
+}

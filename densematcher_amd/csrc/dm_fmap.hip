@@ -1,0 +1,267 @@
+// Spectral projection (dm_project) and the functional-map solve (dm_fmap_solve).
+//
+// Reference arithmetic reproduced (oracle/dm_oracle.py: project, ev_sqdiff, fmap_solve):
+//   A = Phi1^T (a1 * F1), B = Phi2^T (a2 * F2)                 pyFM/optimize/base_functions.py:526-532
+//   ev_ij = (lam1_j / s - lam2_i / s)^2, s = max(lam1, lam2)   pyFM/functional.py:404-405
+//   minimiser of w_d/2 |C A - B|^2 + w_l/2 sum C^2 ev with column 0 pinned (base_functions.py:49,95,759):
+//   for every row i:  (P[f,f] + w_l diag(ev[i,f])) C[i,f] = Q[i,f] - P[f,0] C[i,0],
+//   P = w_d A A^T, Q = w_d B A^T, f = 1..k1-1   
+#include "dm_gemm_f64.h"
+#include "dm_internal.h"
+
+// =================================================================================================
+// dm_project:  Ared[b] = Phi[b][:, :k]^T (mass[b] * F[b])
+// =================================================================================================
+struct OutProj {
+    float* direct;        // (B, k, D) when nsplit == 1
+    double* partial;      // (nsplit, B, k, D) otherwise
+    int B, k, D;
+    __device__ __forceinline__ void store(int b, int split, int m, int c, double v) const {
+        if (direct) direct[((long long)b * k + m) * D + c] = (float)v;
+        else partial[(((long long)split * B + b) * k + m) * D + c] = v;
+    }
+};
+
+__global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const double* __restrict__ partial, int nsplit,
+                                                                long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += partial[(long long)q * n + i];
+    out[i] = (float)s;
+}
+
+static int pick_split(int wgs_unsplit, int K, int bk) {
+    int nsplit = 1;
+    while (wgs_unsplit * nsplit < 1024 && nsplit < 16 && K / (nsplit * 2) >= 8 * bk) nsplit *= 2;
+    return nsplit;
+}
+
+extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass,
+                          const void* F, int f_dtype, float* Ared) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N > 0 && D > 0 && k > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi && mass && F && Ared, "null pointer");
+    DM_REQUIRE(ctx, ld >= k, "eigenvector row stride smaller than k");
+    DM_REQUIRE(ctx, f_dtype == DM_F16 || f_dtype == DM_F32, "f_dtype must be DM_F16 or DM_F32");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const int tiles = dm_cdiv(k, TN_T) * dm_cdiv(D, TN_T);
+    const int nsplit = pick_split(tiles * B, N, TN_BK);
+    const int kchunk = dm_cdiv(dm_cdiv(N, nsplit), TN_BK) * TN_BK;
+    double* partial = nullptr;
+    if (nsplit > 1) {
+        int rc = dm_ws_reserve(ctx, (size_t)nsplit * B * k * D * 8);
+        if (rc) return rc;
+        partial = (double*)dm_ws_take(ctx, (size_t)nsplit * B * k * D * 8);
+    }
+    // the mass multiplies the descriptor rows, as in the reference (A @ descr), the basis stays unscaled
+    RowsF32Scaled opx{Phi, (long long)N * ld, ld, k, nullptr, 0};
+    OutProj out{nsplit > 1 ? nullptr : Ared, partial, B, k, D};
+    dim3 grid(tiles, nsplit, B);
+    if (f_dtype == DM_F16) {
+        RowsF16Scaled opy{(const _Float16*)F, (long long)N * D, D, D, mass, (long long)N};
+        DM_LAUNCH(ctx, "project_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF16Scaled, OutProj>), grid, dim3(256), 0, opx,
+                  opy, out, k, D, N, kchunk);
+    } else {
+        RowsF32Scaled opy{(const float*)F, (long long)N * D, D, D, mass, (long long)N};
+        DM_LAUNCH(ctx, "project_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF32Scaled, OutProj>), grid, dim3(256), 0, opx,
+                  opy, out, k, D, N, kchunk);
+    }
+    if (nsplit > 1) {
+        const long long n = (long long)B * k * D;
+        DM_LAUNCH(ctx, "splitk_reduce", splitk_reduce_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                  partial, nsplit, n, Ared);
+    }
+    return DM_OK;
+}
+
+// =================================================================================================
+// dm_fmap_c00: sign(Phi1[0,0] Phi2[0,0]) sqrt(area2 / area1)          pyFM/functional.py:654-658
+// =================================================================================================
+__global__ __launch_bounds__(256) void c00_kernel(const float* __restrict__ Phi1, long long s1, const float* __restrict__ Phi2,
+                                                  long long s2, const float* __restrict__ mass1, const float* __restrict__ mass2,
+                                                  int N1, int N2, double* __restrict__ c00) {
+    __shared__ double red[2][4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = t; i < N1; i += 256) a1 += (double)mass1[(long long)b * N1 + i];
+    for (int i = t; i < N2; i += 256) a2 += (double)mass2[(long long)b * N2 + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a1 += __shfl_xor(a1, off);
+        a2 += __shfl_xor(a2, off);
+    }
+    if ((t & 63) == 0) { red[0][t >> 6] = a1; red[1][t >> 6] = a2; }
+    __syncthreads();
+    if (t == 0) {
+        const double area1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const double area2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double pr = (double)Phi1[b * s1] * (double)Phi2[b * s2];
+        const double sgn = (pr > 0.0) ? 1.0 : ((pr < 0.0) ? -1.0 : 0.0);      // np.sign
+        c00[b] = sgn * sqrt(area2 / area1);
+    }
+}
+
+extern "C" int dm_fmap_c00(dm_ctx* ctx, int B, int N1, int N2, const float* Phi1, int ld1, const float* Phi2, int ld2,
+                           const float* mass1, const float* mass2, double* c00) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && ld1 > 0 && ld2 > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && mass2 && c00, "null pointer");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    DM_LAUNCH(ctx, "c00", c00_kernel, dim3(B), dim3(256), 0, Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2,
+              N1, N2, c00);
+    return DM_OK;
+}
+
+// =================================================================================================
+// Gram matrices  PQ[b] = w_d [A; Bm] A^T    ((k1 + k2) x k1, float64)
+// =================================================================================================
+struct KRowsStackedF32 {
+    const float* A; const float* Bm; int k1, k2, D;
+    __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
+        const float* r = nullptr;
+        if (row < k1) r = A + ((long long)b * k1 + row) * D;
+        else if (row < k1 + k2) r = Bm + ((long long)b * k2 + (row - k1)) * D;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (r && k0 + e < D) ? (double)r[k0 + e] : 0.0;
+    }
+};
+struct OutScaled {
+    double* p; long long stride_b; int ld; double scale;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const {
+        p[b * stride_b + (long long)i * ld + j] = scale * v;
+    }
+};
+
+// =================================================================================================
+// Row-wise SPD solves.  One workgroup per (pair b, row i).  The (n+1) x n augmented lower triangle
+// [M_i ; rhs_i^T] (n = k1 - 1) lives in LDS, packed row-major; a right-looking Cholesky turns the
+// last row into y = L^-1 rhs, then L^T x = y is solved backwards.
+// =================================================================================================
+__device__ __forceinline__ int tri(int r) { return r * (r + 1) / 2; }
+
+__global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restrict__ PQ, const double* __restrict__ lam1,
+                                                         const double* __restrict__ lam2, const double* __restrict__ c00,
+                                                         double w_lap, int k1, int k2, double* __restrict__ C,
+                                                         int32_t* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = k1 - 1;
+    double* M = sm;                         // tri(n + 1) entries
+    double* col = sm + tri(n + 1);          // max(n + 1, 4)
+    double* red = col + max(n + 1, 4);      // 2: [0] = eigenvalue scale, [1] = failure flag
+    const int b = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+    const double* P = PQ + (long long)b * (k1 + k2) * k1;
+    const double* Q = P + (long long)k1 * k1;
+    const double* l1 = lam1 + (long long)b * k1;
+    const double* l2 = lam2 + (long long)b * k2;
+
+    // scale = max(lam1.max(), lam2.max())   (functional.py:404)
+    double mx = -DM_INF_F64;
+    for (int q = t; q < k1; q += 256) mx = fmax(mx, l1[q]);
+    for (int q = t; q < k2; q += 256) mx = fmax(mx, l2[q]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if ((t & 63) == 0) col[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+        red[0] = fmax(fmax(col[0], col[1]), fmax(col[2], col[3]));
+        red[1] = 0.0;
+    }
+    __syncthreads();
+    const double scale = red[0];
+    const double ci0 = (i == 0) ? c00[b] : 0.0;           // get_x0: column 0 is (c00, 0, ..., 0)^T
+    const double l2i = l2[i] / scale;
+
+    // load [M ; rhs]
+    for (int r = t >> 4; r <= n; r += 16) {
+        for (int c = t & 15; c <= r && c < n; c += 16) {
+            double v;
+            if (r < n) {
+                v = P[(long long)(r + 1) * k1 + (c + 1)];
+                if (r == c) {
+                    const double d = l1[c + 1] / scale - l2i;
+                    v += w_lap * (d * d);
+                }
+            } else {
+                v = Q[(long long)i * k1 + (c + 1)] - P[(long long)(c + 1) * k1] * ci0;
+            }
+            M[tri(r) + c] = v;
+        }
+    }
+    __syncthreads();
+
+    for (int j = 0; j < n; ++j) {
+        const double piv = M[tri(j) + j];
+        if (!(piv > 0.0)) {                      // uniform: every thread reads the same LDS word
+            if (t == 0) red[1] = 1.0;
+            break;
+        }
+        const double inv = 1.0 / sqrt(piv);
+        for (int r = j + 1 + t; r <= n; r += 256) {
+            const double x = M[tri(r) + j] * inv;
+            M[tri(r) + j] = x;
+            col[r] = x;
+        }
+        __syncthreads();
+        if (t == 0) M[tri(j) + j] = sqrt(piv);
+        for (int r = j + 1 + (t >> 4); r <= n; r += 16) {
+            const double lr = col[r];
+            const int cend = min(r, n - 1);
+            for (int c = j + 1 + (t & 15); c <= cend; c += 16) M[tri(r) + c] -= lr * col[c];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (red[1] != 0.0) {
+        if (t == 0) atomicMax(&info[b], i + 1);
+        for (int c = t; c < k1; c += 256) C[((long long)b * k2 + i) * k1 + c] = (c == 0) ? ci0 : 0.0;
+        return;
+    }
+    // back substitution L^T x = y, y = M[n][0..n-1]
+    double* y = M + tri(n);
+    for (int j = n - 1; j >= 0; --j) {
+        const double xj = y[j] / M[tri(j) + j];
+        __syncthreads();
+        if (t == 0) y[j] = xj;
+        for (int c = t; c < j; c += 256) y[c] -= M[tri(j) + c] * xj;
+        __syncthreads();
+    }
+    double* Crow = C + ((long long)b * k2 + i) * k1;
+    if (t == 0) Crow[0] = ci0;
+    for (int c = t; c < n; c += 256) Crow[c + 1] = y[c];
+}
+
+extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const float* A, const float* Bm,
+                             const double* lam1, const double* lam2, const double* c00, double w_descr, double w_lap,
+                             double* C, int32_t* info) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && k1 > 0 && k2 > 0 && D > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, A && Bm && lam1 && lam2 && c00 && C && info, "null pointer");
+    DM_REQUIRE(ctx, k1 <= 200, "k1 > 200 does not fit the in-LDS solver");
+    DM_REQUIRE(ctx, w_descr >= 0.0 && w_lap >= 0.0 && (w_descr > 0.0 || w_lap > 0.0), "weights must be >= 0 and not both 0");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pq_bytes = (size_t)B * (k1 + k2) * k1 * 8;
+    int rc = dm_ws_reserve(ctx, pq_bytes);
+    if (rc) return rc;
+    double* PQ = (double*)dm_ws_take(ctx, pq_bytes);
+    DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
+
+    KRowsStackedF32 opa{A, Bm, k1, k2, D};
+    KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
+    OutScaled out{PQ, (long long)(k1 + k2) * k1, k1, w_descr};
+    dim3 grid(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
+    DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutScaled>), grid, dim3(256), 0, opa, opb, out,
+              k1 + k2, k1, D);
+
+    const int n = k1 - 1;
+    const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 4 ? 4 : n + 1) + 2) * sizeof(double);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)fmap_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)lds));
+        lds_set = lds;
+    }
+    DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_kernel, dim3(k2, B), dim3(256), lds, PQ, lam1, lam2, c00, w_lap, k1, k2,
+              C, info);
+    return DM_OK;
+}

@@ -1,0 +1,110 @@
+// Internal declarations shared by the libdensematch translation units.
+// gfx950 (MI355X / CDNA4) only: wave64, f16/f32/f64 MFMA, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "densematch.h"
+
+#define DM_VERSION_STRING "densematch 0.1.0 (gfx950)"
+
+struct dm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scratch arena: one allocation, bump-pointer per call, grown lazily
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t ws_off = 0;
+
+    // kernel timing
+    std::string prof_name;
+    std::vector<hipEvent_t> prof_events;   // pairs (start, stop)
+    size_t prof_used = 0;                  // events used so far
+};
+
+int dm_fail(dm_ctx* ctx, int code, const char* fmt, ...);
+
+#define DM_CHECK_HIP(ctx, expr)                                                        \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return dm_fail(ctx, DM_EHIP, "%s failed: %s (%s:%d)", #expr,               \
+                           hipGetErrorString(_e), __FILE__, __LINE__);                 \
+    } while (0)
+
+#define DM_REQUIRE(ctx, cond, msg)                                                     \
+    do {                                                                               \
+        if (!(cond)) return dm_fail(ctx, DM_EINVAL, "%s: requirement failed: %s (%s)", \
+                                    __func__, #cond, msg);                             \
+    } while (0)
+
+// ---- workspace arena -------------------------------------------------------
+// A call first declares the total it needs (dm_ws_reserve: may reallocate, which
+// synchronises the stream so that no in-flight kernel still reads the old
+// block), then carves aligned pieces with dm_ws_take.
+int dm_ws_reserve(dm_ctx* ctx, size_t total_bytes);
+void* dm_ws_take(dm_ctx* ctx, size_t bytes);
+static inline size_t dm_align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---- launch bookkeeping -----------------------------------------------------
+// DM_LAUNCH(ctx, "name", kernel, grid, block, shmem, args...) launches on the
+// ctx stream, brackets with events when `name` is being profiled, and returns
+// DM_EHIP from the enclosing function on a launch error.
+int dm_prof_begin(dm_ctx* ctx, const char* name);
+int dm_prof_end(dm_ctx* ctx, int token);
+
+#define DM_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                          \
+    do {                                                                               \
+        int _tok = dm_prof_begin(ctx, name);                                           \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);    \
+        hipError_t _le = hipGetLastError();                                            \
+        if (_le != hipSuccess)                                                         \
+            return dm_fail(ctx, DM_EHIP, "launch of %s failed: %s", name,              \
+                           hipGetErrorString(_le));                                    \
+        dm_prof_end(ctx, _tok);                                                        \
+    } while (0)
+
+static inline int dm_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- internal building blocks (each in its own .hip) -------------------------
+// K-major float64 copy of the first k columns of Phi:  out[b][c][i] = Phi[b][i][c]
+// (c < k), zero for padded entries; out is (B, kpad, Npad).
+int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld,
+                   double* out, int kpad, int Npad);
+
+// embT[b][r][j] = sum_m Cm[b][r][m] * Phi[b][j][m]   (r < kr, m < km), K-major f64
+// (B, krpad, Npad); nrm[b][j] = sum_r embT[b][r][j]^2 (nullable).  Only entries (r < kr, j < N)
+// are written; zero_first clears the whole buffer before (padding must read as 0).
+// Cm is (B, kr, km) f64 with row stride ldc; if transC, Cm[b][m][r] is read instead.
+int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld,
+                    const double* Cm, int ldc, long long strideC, int transC,
+                    double* embT, int krpad, int Npad, double* nrm, int zero_first);
+
+// Fused G = A^T B tile kernel with the arg-reductions (see dm_p2p.hip).
+struct dm_gred_args {
+    int B, N2, N1;                    // G is N2 x N1
+    int Kloop;                        // contraction depth actually traversed (multiple of 16, <= Kpad)
+    const double* AT; int N2pad;      // (B, Kpad, N2pad)  rows = Phi2^T
+    const double* BT; int N1pad;      // (B, Kpad, N1pad)  rows = emb1^T
+    int Kpad;
+    const double* n1;                 // (B, N1pad) |emb1_j|^2          (knn21)
+    const double* n2;                 // (B, N2pad) |Phi2_i C|^2        (knn12)
+    const float* mass1;               // (B, N1)                        (ind21, ind12)
+    int32_t* knn21; int32_t* knn12; int32_t* ind21; int32_t* ind12;   // any nullable
+};
+int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a);
+size_t dm_gred_ws_bytes(int B, int N2, int N1);
+
+// C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
+int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,
+                        const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass2,
+                        double* C, int ldc, long long strideC);
+size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2);

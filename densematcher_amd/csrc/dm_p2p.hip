@@ -1,0 +1,417 @@
+// Functional map -> vertex maps (dm_fm_to_p2p) and its building blocks.
+//
+//   G = Phi2[:, :k2] C Phi1[:, :k1]^T  is produced 128x128 tile by tile on the float64
+//   matrix cores (v_mfma_f64_16x16x4_f64) and consumed in registers by four fused
+//   arg-reductions; it never reaches memory.  Operands are staged K-major in float64
+//   (AT = Phi2^T, BT = (Phi1 C^T)^T) by two small pre-kernels so that every LDS fragment
+//   read is a conflict-free ds_read_b64.
+//
+// Reference arithmetic reproduced (oracle/dm_oracle.py: fm_to_p2p, indicator_argmax):
+//   knn21[i] = argmin_j  n1_j - 2 G_ij      n1_j = |C Phi1_j|^2      pyFM/spectral/convert.py:138-140
+//   knn12[j] = argmin_i  n2_i - 2 G_ij      n2_i = |Phi2_i C|^2      pyFM/spectral/convert.py:134-136
+//   ind21[i] = argmax_j  G_ij a1_j                                   convert.py:144, functional_map.py:49
+//   ind12[j] = argmax_i  G_ij a1_j                                   convert.py:144, functional_map.py:50
+// lowest index on ties (NumPy argmax/argmin).
+#include "dm_gemm_f64.h"
+#include "dm_internal.h"
+
+// =================================================================================================
+// K-major float64 copy of Phi:  out[b][c][i] = Phi[b][i][c]
+// =================================================================================================
+__global__ __launch_bounds__(256) void phiT_kernel(const float* __restrict__ Phi, int N, int k, int ld,
+                                                   double* __restrict__ out, int kpad, int Npad) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const float* P = Phi + (long long)b * N * ld;
+    double* O = out + (long long)b * kpad * Npad;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int i = i0 + r, c = c0 + tx;
+        tile[r][tx] = (i < N && c < k) ? P[(long long)i * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, i = i0 + tx;
+        if (c < kpad && i < Npad) O[(long long)c * Npad + i] = (double)tile[tx][r];
+    }
+}
+
+int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld, double* out, int kpad, int Npad) {
+    dim3 grid(dm_cdiv(Npad, 64), dm_cdiv(kpad, 64), B);
+    DM_LAUNCH(ctx, "phiT", phiT_kernel, grid, dim3(256), 0, Phi, N, k, ld, out, kpad, Npad);
+    return DM_OK;
+}
+
+// =================================================================================================
+// embT[b][r][j] = sum_m Cm[b][r][m] Phi[b][j][m]; column norms
+// =================================================================================================
+struct OutKMajor {
+    double* p; long long stride_b; int ld;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const {
+        p[b * stride_b + (long long)i * ld + j] = v;
+    }
+};
+
+// nrm[b][j] = sum_r embT[b][r][j]^2 over r < kr (fixed ascending order: deterministic)
+__global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__ embT, int kr, int krpad, int Npad,
+                                                      double* __restrict__ nrm) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Npad) return;
+    const double* E = embT + (long long)b * krpad * Npad;
+    double s = 0.0;
+    for (int r = 0; r < kr; ++r) {
+        const double x = E[(long long)r * Npad + j];
+        s += x * x;
+    }
+    nrm[(long long)b * Npad + j] = s;
+}
+
+int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld, const double* Cm, int ldc,
+                    long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first) {
+    // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
+    if (zero_first)
+        DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
+    KRowsF64 opa{Cm, strideC, ldc, kr, km, transC};
+    KRowsF32 opb{Phi, (long long)N * ld, ld, N, km};
+    OutKMajor out{embT, (long long)krpad * Npad, Npad};
+    dim3 grid(dm_cdiv(kr, NT_T) * dm_cdiv(N, NT_T), 1, B);
+    DM_LAUNCH(ctx, "embed_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF32, OutKMajor>), grid, dim3(256), 0, opa, opb, out, kr,
+              N, km);
+    if (nrm) {
+        dim3 g2(dm_cdiv(Npad, 256), B);
+        DM_LAUNCH(ctx, "colnorm", colnorm_kernel, g2, dim3(256), 0, embT, kr, krpad, Npad, nrm);
+    }
+    return DM_OK;
+}
+
+// =================================================================================================
+// fused G tile + arg-reductions
+// =================================================================================================
+constexpr int GT = 128;    // G tile (rows and columns) per workgroup
+constexpr int GBK = 16;    // contraction depth per LDS stage
+constexpr int GLD = 144;   // LDS row stride (f64): 288 dwords = 32 (mod 64)
+
+struct gred_params {
+    const double* AT; const double* BT;
+    const double* n1; const double* n2; const float* mass1;
+    // per-tile partial results
+    double* rv_knn; int32_t* rj_knn; double* rv_ind; int32_t* rj_ind;   // (B, tilesN, N2pad)
+    double* cv_knn; int32_t* ci_knn; double* cv_ind; int32_t* ci_ind;   // (B, tilesM, N1pad)
+    int N2, N1, N2pad, N1pad, Kpad, Kloop, tilesM, tilesN, total;
+    int want_rows_knn, want_rows_ind, want_cols_knn, want_cols_ind;
+};
+
+__global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
+    __shared__ double smem[2 * 2 * GBK * GLD];   // As[2][GBK][GLD] | Bs[2][GBK][GLD]   (73,728 B)
+    double* As = smem;
+    double* Bs = smem + 2 * GBK * GLD;
+
+    const int id = xcd_remap(blockIdx.x, p.total);
+    const int tiles = p.tilesM * p.tilesN;
+    const int b = id / tiles;
+    const int tmn = id - b * tiles;
+    const int tm = tmn / p.tilesN, tn = tmn - tm * p.tilesN;
+    const int i0 = tm * GT, j0 = tn * GT;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const double* AT = p.AT + (long long)b * p.Kpad * p.N2pad + i0;
+    const double* BT = p.BT + (long long)b * p.Kpad * p.N1pad + j0;
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    // stage = GBK rows x 128 f64 per operand; pass q: row q*4 + t/64, 16 B per lane, one 1 KiB row per wave
+    const int srow = t >> 6, scol = (t & 63) * 2;
+    f64x2 ra[4], rb[4];
+    // (macros, not lambdas: by-reference lambda captures of the staging arrays end up in scratch)
+#define GRED_FETCH(s_)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
+        const int kr = (s_) * GBK + q * 4 + srow;                                                    \
+        ra[q] = *reinterpret_cast<const f64x2*>(AT + (long long)kr * p.N2pad + scol);              \
+        rb[q] = *reinterpret_cast<const f64x2*>(BT + (long long)kr * p.N1pad + scol);              \
+    }
+#define GRED_STASH(buf_)                                                                             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                  \
+        const int off = (buf_) * GBK * GLD + (q * 4 + srow) * GLD + scol;                            \
+        *reinterpret_cast<f64x2*>(As + off) = ra[q];                                               \
+        *reinterpret_cast<f64x2*>(Bs + off) = rb[q];                                               \
+    }
+
+    const int ns = p.Kloop / GBK;
+    GRED_FETCH(0)
+    GRED_STASH(0)
+    __syncthreads();
+    for (int s = 0; s < ns; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < ns) { GRED_FETCH(s + 1) }
+        const double* A_ = As + buf * GBK * GLD + wm * 64 + (lane & 15);
+        const double* B_ = Bs + buf * GBK * GLD + wn * 64 + (lane & 15);
+#pragma unroll
+        for (int ks = 0; ks < GBK / 4; ++ks) {
+            const int kk = ks * 4 + (lane >> 4);
+            double a[4], bb[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[mt] = A_[kk * GLD + mt * 16];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bb[nt] = B_[kk * GLD + nt * 16];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
+        }
+        if (s + 1 < ns) { GRED_STASH(buf ^ 1) }
+        __syncthreads();
+    }
+#undef GRED_FETCH
+#undef GRED_STASH
+
+    // ---------------- epilogue: reductions over the 128x128 tile held in registers ----------------
+    // acc[mt][nt][r] = G[row = i0 + wm*64 + mt*16 + (lane>>4) + 4r][col = j0 + wn*64 + nt*16 + (lane&15)]
+    // LDS is free now (the loop ended with a barrier): reuse it for the cross-wave merges.
+    double* sv = smem;                                            // [4 kinds][2 waves][128]
+    int* sj = reinterpret_cast<int*>(smem + 4 * 2 * 128);         // [4 kinds][2 waves][128]
+
+    double a1[4], n1c[4];
+    bool cvalid[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int gj = j0 + wn * 64 + nt * 16 + (lane & 15);
+        cvalid[nt] = gj < p.N1;
+        a1[nt] = (cvalid[nt] && p.mass1) ? (double)p.mass1[(long long)b * p.N1 + gj] : 0.0;
+        n1c[nt] = p.n1 ? p.n1[(long long)b * p.N1pad + gj] : 0.0;
+    }
+
+    // column candidates, accumulated over this lane's 16 rows in ascending row order
+    double cbest_i[4], cbest_k[4];
+    int cidx_i[4], cidx_k[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        cbest_i[nt] = -DM_INF_F64; cbest_k[nt] = DM_INF_F64;
+        cidx_i[nt] = DM_IDX_NONE; cidx_k[nt] = DM_IDX_NONE;
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lrow = wm * 64 + mt * 16 + (lane >> 4) + 4 * r;
+            const int gi = i0 + lrow;
+            const bool rvalid = gi < p.N2;
+            const double n2r = (p.n2 && rvalid) ? p.n2[(long long)b * p.N2pad + gi] : 0.0;
+            double rb_i = -DM_INF_F64, rb_k = DM_INF_F64;
+            int rj_i = DM_IDX_NONE, rj_k = DM_IDX_NONE;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const double g = acc[mt][nt][r];
+                const int gj = j0 + wn * 64 + nt * 16 + (lane & 15);
+                const double vi = g * a1[nt];                  // (Phi2 C Phi1^T) @ A1, convert.py:144
+                const double vk = n1c[nt] - 2.0 * g;           // |x|^2 - 2 <x,y>
+                const double vk2 = n2r - 2.0 * g;
+                if (cvalid[nt]) {
+                    if (vi > rb_i) { rb_i = vi; rj_i = gj; }    // columns ascend with nt: strict keeps the lowest
+                    if (vk < rb_k) { rb_k = vk; rj_k = gj; }
+                }
+                if (rvalid) {
+                    if (vi > cbest_i[nt]) { cbest_i[nt] = vi; cidx_i[nt] = gi; }   // rows ascend with (mt, r)
+                    if (vk2 < cbest_k[nt]) { cbest_k[nt] = vk2; cidx_k[nt] = gi; }
+                }
+            }
+            // the 16 lanes that share (lane >> 4) hold the other columns of this row
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                if (p.want_rows_ind) {
+                    const double ov = __shfl_xor(rb_i, off);
+                    const int oj = __shfl_xor(rj_i, off);
+                    argmax_merge(rb_i, rj_i, ov, oj);
+                }
+                if (p.want_rows_knn) {
+                    const double ov = __shfl_xor(rb_k, off);
+                    const int oj = __shfl_xor(rj_k, off);
+                    argmin_merge(rb_k, rj_k, ov, oj);
+                }
+            }
+            if ((lane & 15) == 0) {
+                sv[(0 * 2 + wn) * 128 + lrow] = rb_i; sj[(0 * 2 + wn) * 128 + lrow] = rj_i;
+                sv[(1 * 2 + wn) * 128 + lrow] = rb_k; sj[(1 * 2 + wn) * 128 + lrow] = rj_k;
+            }
+        }
+    }
+    // the 4 lane groups (lane >> 4) hold different rows of the same column
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            if (p.want_cols_ind) {
+                const double ov = __shfl_xor(cbest_i[nt], off);
+                const int oi = __shfl_xor(cidx_i[nt], off);
+                argmax_merge(cbest_i[nt], cidx_i[nt], ov, oi);
+            }
+            if (p.want_cols_knn) {
+                const double ov = __shfl_xor(cbest_k[nt], off);
+                const int oi = __shfl_xor(cidx_k[nt], off);
+                argmin_merge(cbest_k[nt], cidx_k[nt], ov, oi);
+            }
+        }
+        if (lane < 16) {
+            const int lcol = wn * 64 + nt * 16 + lane;
+            sv[(2 * 2 + wm) * 128 + lcol] = cbest_i[nt]; sj[(2 * 2 + wm) * 128 + lcol] = cidx_i[nt];
+            sv[(3 * 2 + wm) * 128 + lcol] = cbest_k[nt]; sj[(3 * 2 + wm) * 128 + lcol] = cidx_k[nt];
+        }
+    }
+    __syncthreads();
+    // merge the two waves that share a row (wn = 0, 1) / a column (wm = 0, 1); lower half first
+    if (t < 128) {
+        const int gi = i0 + t;
+        if (gi < p.N2) {
+            const long long o = ((long long)b * p.tilesN + tn) * p.N2pad + gi;
+            if (p.want_rows_ind) {
+                double v = sv[(0 * 2 + 0) * 128 + t]; int j = sj[(0 * 2 + 0) * 128 + t];
+                argmax_merge(v, j, sv[(0 * 2 + 1) * 128 + t], sj[(0 * 2 + 1) * 128 + t]);
+                p.rv_ind[o] = v; p.rj_ind[o] = j;
+            }
+            if (p.want_rows_knn) {
+                double v = sv[(1 * 2 + 0) * 128 + t]; int j = sj[(1 * 2 + 0) * 128 + t];
+                argmin_merge(v, j, sv[(1 * 2 + 1) * 128 + t], sj[(1 * 2 + 1) * 128 + t]);
+                p.rv_knn[o] = v; p.rj_knn[o] = j;
+            }
+        }
+    } else {
+        const int c = t - 128;
+        const int gj = j0 + c;
+        if (gj < p.N1) {
+            const long long o = ((long long)b * p.tilesM + tm) * p.N1pad + gj;
+            if (p.want_cols_ind) {
+                double v = sv[(2 * 2 + 0) * 128 + c]; int i = sj[(2 * 2 + 0) * 128 + c];
+                argmax_merge(v, i, sv[(2 * 2 + 1) * 128 + c], sj[(2 * 2 + 1) * 128 + c]);
+                p.cv_ind[o] = v; p.ci_ind[o] = i;
+            }
+            if (p.want_cols_knn) {
+                double v = sv[(3 * 2 + 0) * 128 + c]; int i = sj[(3 * 2 + 0) * 128 + c];
+                argmin_merge(v, i, sv[(3 * 2 + 1) * 128 + c], sj[(3 * 2 + 1) * 128 + c]);
+                p.cv_knn[o] = v; p.ci_knn[o] = i;
+            }
+        }
+    }
+}
+
+// final merge over tiles, ascending tile order, strict comparison (lower tile = lower index wins ties)
+__global__ __launch_bounds__(256) void gred_merge_kernel(const double* __restrict__ pv, const int32_t* __restrict__ pj,
+                                                         int ntiles, int n, int npad, int is_max,
+                                                         int32_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v = is_max ? -DM_INF_F64 : DM_INF_F64;
+    int j = DM_IDX_NONE;
+    for (int tIdx = 0; tIdx < ntiles; ++tIdx) {
+        const long long o = ((long long)b * ntiles + tIdx) * npad + i;
+        const double ov = pv[o];
+        const int oj = pj[o];
+        if (is_max) argmax_merge(v, j, ov, oj); else argmin_merge(v, j, ov, oj);
+    }
+    out[(long long)b * n + i] = (j == DM_IDX_NONE) ? 0 : j;
+}
+
+static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+
+size_t dm_gred_ws_bytes(int B, int N2, int N1) {
+    const int N2pad = pad_to(N2, GT), N1pad = pad_to(N1, GT);
+    const size_t tilesM = N2pad / GT, tilesN = N1pad / GT;
+    const size_t rows = (size_t)B * tilesN * N2pad, cols = (size_t)B * tilesM * N1pad;
+    return 2 * (dm_align_up(rows * 8) + dm_align_up(rows * 4)) + 2 * (dm_align_up(cols * 8) + dm_align_up(cols * 4)) + 4096;
+}
+
+int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a) {
+    gred_params p;
+    memset(&p, 0, sizeof(p));
+    p.AT = a.AT; p.BT = a.BT; p.n1 = a.n1; p.n2 = a.n2; p.mass1 = a.mass1;
+    p.N2 = a.N2; p.N1 = a.N1; p.N2pad = a.N2pad; p.N1pad = a.N1pad; p.Kpad = a.Kpad; p.Kloop = a.Kloop;
+    p.tilesM = a.N2pad / GT; p.tilesN = a.N1pad / GT;
+    p.total = a.B * p.tilesM * p.tilesN;
+    p.want_rows_knn = a.knn21 != nullptr; p.want_rows_ind = a.ind21 != nullptr;
+    p.want_cols_knn = a.knn12 != nullptr; p.want_cols_ind = a.ind12 != nullptr;
+    if ((p.want_rows_knn && !a.n1) || (p.want_cols_knn && !a.n2) || ((p.want_rows_ind || p.want_cols_ind) && !a.mass1))
+        return dm_fail(ctx, DM_EINVAL, "gred: missing norms / mass for a requested reduction");
+    if (a.N2pad % GT || a.N1pad % GT || a.Kpad % GBK || a.Kloop % GBK || a.Kloop < GBK || a.Kloop > a.Kpad)
+        return dm_fail(ctx, DM_EINVAL, "gred: operand padding must be a multiple of the tile (%d) / stage (%d)", GT, GBK);
+    const size_t rows = (size_t)a.B * p.tilesN * a.N2pad, cols = (size_t)a.B * p.tilesM * a.N1pad;
+    p.rv_knn = (double*)dm_ws_take(ctx, rows * 8); p.rj_knn = (int32_t*)dm_ws_take(ctx, rows * 4);
+    p.rv_ind = (double*)dm_ws_take(ctx, rows * 8); p.rj_ind = (int32_t*)dm_ws_take(ctx, rows * 4);
+    p.cv_knn = (double*)dm_ws_take(ctx, cols * 8); p.ci_knn = (int32_t*)dm_ws_take(ctx, cols * 4);
+    p.cv_ind = (double*)dm_ws_take(ctx, cols * 8); p.ci_ind = (int32_t*)dm_ws_take(ctx, cols * 4);
+    if (!p.rv_knn || !p.rj_knn || !p.rv_ind || !p.rj_ind || !p.cv_knn || !p.ci_knn || !p.cv_ind || !p.ci_ind)
+        return dm_fail(ctx, DM_ENOMEM, "gred: workspace not reserved");
+    DM_LAUNCH(ctx, "gred_f64", gred_kernel, dim3(p.total), dim3(256), 0, p);
+    if (a.knn21) {
+        DM_LAUNCH(ctx, "gred_merge", gred_merge_kernel, dim3(dm_cdiv(a.N2, 256), a.B), dim3(256), 0, p.rv_knn, p.rj_knn,
+                  p.tilesN, a.N2, a.N2pad, 0, a.knn21);
+    }
+    if (a.ind21) {
+        DM_LAUNCH(ctx, "gred_merge", gred_merge_kernel, dim3(dm_cdiv(a.N2, 256), a.B), dim3(256), 0, p.rv_ind, p.rj_ind,
+                  p.tilesN, a.N2, a.N2pad, 1, a.ind21);
+    }
+    if (a.knn12) {
+        DM_LAUNCH(ctx, "gred_merge", gred_merge_kernel, dim3(dm_cdiv(a.N1, 256), a.B), dim3(256), 0, p.cv_knn, p.ci_knn,
+                  p.tilesM, a.N1, a.N1pad, 0, a.knn12);
+    }
+    if (a.ind12) {
+        DM_LAUNCH(ctx, "gred_merge", gred_merge_kernel, dim3(dm_cdiv(a.N1, 256), a.B), dim3(256), 0, p.cv_ind, p.ci_ind,
+                  p.tilesM, a.N1, a.N1pad, 1, a.ind12);
+    }
+    return DM_OK;
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,
+                            const float* Phi2, int ld2, const float* mass1, const double* C, int32_t* knn21,
+                            int32_t* knn12, int32_t* ind21, int32_t* ind12) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi1 && Phi2 && C, "null input");
+    DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
+    DM_REQUIRE(ctx, (!ind21 && !ind12) || mass1, "mass1 is needed for the indicator maps");
+    if (!knn21 && !knn12 && !ind21 && !ind12) return DM_OK;
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+
+    const int N1pad = pad_to(N1, GT), N2pad = pad_to(N2, GT);
+    const int Kpad = pad_to(k2, GBK);          // contraction of G = Phi2 (k2) . emb1 (k2)
+    const int K1pad = pad_to(k1, GBK);
+    const size_t bytes_AT = (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;
+    const size_t bytes_E2 = knn12 ? (size_t)B * K1pad * N2pad * 8 : 0;
+    const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + dm_align_up(bytes_E2) +
+                        dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2pad * 8) +
+                        dm_gred_ws_bytes(B, N2, N1);
+    int rc = dm_ws_reserve(ctx, need);
+    if (rc) return rc;
+    double* AT = (double*)dm_ws_take(ctx, bytes_AT);
+    double* BT = (double*)dm_ws_take(ctx, bytes_BT);
+    double* E2 = bytes_E2 ? (double*)dm_ws_take(ctx, bytes_E2) : nullptr;
+    double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
+    double* n2 = (double*)dm_ws_take(ctx, (size_t)B * N2pad * 8);
+
+    // AT = Phi2[:, :k2]^T (K-major f64)
+    rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad);
+    if (rc) return rc;
+    // BT = emb1^T, emb1 = Phi1[:, :k1] C^T (N1 x k2): emb1T[c][j] = sum_m C[c][m] Phi1[j][m];  n1_j = |emb1_j|^2
+    rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, C, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 1);
+    if (rc) return rc;
+    if (knn12) {
+        // emb2 = Phi2[:, :k2] C (N2 x k1): emb2T[m][i] = sum_c C[c][m] Phi2[i][c];  only n2_i = |emb2_i|^2 is used
+        rc = dm_launch_embed(ctx, B, N2, k1, k2, Phi2, ld2, C, k1, (long long)k2 * k1, 1, E2, K1pad, N2pad, n2, 1);
+        if (rc) return rc;
+    }
+    dm_gred_args a;
+    a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = Kpad;
+    a.AT = AT; a.N2pad = N2pad; a.BT = BT; a.N1pad = N1pad; a.Kpad = Kpad;
+    a.n1 = n1; a.n2 = knn12 ? n2 : nullptr; a.mass1 = mass1;
+    a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
+    return dm_launch_gred(ctx, a);
+}

@@ -1,0 +1,229 @@
+"""
+MatchEngine: batched matching hot path on one MI355X, bound to libdensematch through ctypes.
+
+PyTorch is used for device memory and streams only: every method takes / returns
+torch tensors that live on the engine's GPU and hands their `data_ptr()` to the
+C ABI (include/densematch.h).  All arithmetic of the path runs in the HIP kernels.
+
+Batch layout (B pairs; pairs are independent):
+    Phi1 (B,N1,ld1) f32   Phi2 (B,N2,ld2) f32    eigenvectors (first k columns are used)
+    lam1 (B,k1) f64       lam2 (B,k2) f64        eigenvalues
+    a1 (B,N1) f32         a2 (B,N2) f32          lumped masses
+    F1 (B,N1,D) f16|f32   F2 (B,N2,D) f16|f32    descriptors
+    C  (B,k2,k1) f64                              functional maps
+    maps int32 on the device
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class MatchEngine:
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("MatchEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
+                                   (device if isinstance(device, int) else torch.device(device).index or 0))
+        self.stream = torch.cuda.current_stream(self.device)
+        ctx = C.c_void_p()
+        rc = self.lib.dm_create(self.device.index, C.c_void_p(self.stream.cuda_stream), C.byref(ctx))
+        if rc != 0:
+            raise _lib.DenseMatchError(f"dm_create failed with status {rc} (is this a gfx950 device?)")
+        self.ctx = ctx
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.dm_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _chk(self, rc):
+        _lib.raise_for(rc, self.lib, self.ctx)
+
+    def _dev(self, t, dtype, name):
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t)
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=dtype).contiguous()
+        return t
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def workspace_bytes(self):
+        return int(self.lib.dm_workspace_bytes(self.ctx))
+
+    def profile_kernel(self, name):
+        self._chk(self.lib.dm_profile_kernel(self.ctx, name.encode() if name else None))
+
+    def profile_read(self):
+        n, ms = C.c_int(0), C.c_double(0.0)
+        self._chk(self.lib.dm_profile_read(self.ctx, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # ------------------------------------------------------------------ ops
+    def simnn(self, Ftgt, Fsrc, return_scores=False):
+        """nn[b,i] = argmax_j <Ftgt[b,i], Fsrc[b,j]> (float64-exact, lowest index on ties)."""
+        Ftgt = self._dev(Ftgt, torch.float16, "Ftgt")
+        Fsrc = self._dev(Fsrc, torch.float16, "Fsrc")
+        if Ftgt.dim() != 3 or Fsrc.dim() != 3 or Ftgt.shape[0] != Fsrc.shape[0] or Ftgt.shape[2] != Fsrc.shape[2]:
+            raise ValueError("simnn expects Ftgt (B,N2,D) and Fsrc (B,N1,D)")
+        B, N2, D = Ftgt.shape
+        N1 = Fsrc.shape[1]
+        nn = torch.empty((B, N2), dtype=torch.int32, device=self.device)
+        best = torch.empty((B, N2), dtype=torch.float32, device=self.device) if return_scores else None
+        margin = torch.empty((B, N2), dtype=torch.float32, device=self.device) if return_scores else None
+        self._chk(self.lib.dm_simnn_f16(self.ctx, B, N2, N1, D, _ptr(Ftgt), _ptr(Fsrc), _ptr(nn), _ptr(best), _ptr(margin)))
+        return (nn, best, margin) if return_scores else nn
+
+    def project(self, Phi, mass, F, k=None, out=None):
+        """Phi[:, :k]^T (mass * F)  ->  (B,k,D) f32."""
+        Phi = self._dev(Phi, torch.float32, "Phi")
+        mass = self._dev(mass, torch.float32, "mass")
+        if not isinstance(F, torch.Tensor):
+            F = torch.as_tensor(F)
+        fdt = torch.float16 if F.dtype == torch.float16 else torch.float32
+        F = self._dev(F, fdt, "F")
+        B, N, ld = Phi.shape
+        k = ld if k is None else k
+        if F.shape[:2] != (B, N) or mass.shape != (B, N):
+            raise ValueError("project: Phi (B,N,ld), mass (B,N), F (B,N,D) do not agree")
+        D = F.shape[2]
+        if out is None:
+            out = torch.empty((B, k, D), dtype=torch.float32, device=self.device)
+        self._chk(self.lib.dm_project(self.ctx, B, N, D, k, _ptr(Phi), ld, _ptr(mass), _ptr(F),
+                                      _lib.DM_F16 if fdt == torch.float16 else _lib.DM_F32, _ptr(out)))
+        return out
+
+    def c00(self, Phi1, Phi2, a1, a2):
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        a1 = self._dev(a1, torch.float32, "a1")
+        a2 = self._dev(a2, torch.float32, "a2")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        out = torch.empty((B,), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_fmap_c00(self.ctx, B, N1, N2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(a2), _ptr(out)))
+        return out
+
+    def fmap_solve(self, A, Bm, lam1, lam2, c00, w_descr, w_lap, check=True):
+        """Closed-form minimiser of the w_descr / w_lap energy -> C (B,k2,k1) f64."""
+        A = self._dev(A, torch.float32, "A")
+        Bm = self._dev(Bm, torch.float32, "Bm")
+        lam1 = self._dev(lam1, torch.float64, "lam1")
+        lam2 = self._dev(lam2, torch.float64, "lam2")
+        c00 = self._dev(c00, torch.float64, "c00")
+        B, k1, D = A.shape
+        k2 = Bm.shape[1]
+        if Bm.shape[0] != B or Bm.shape[2] != D or lam1.shape != (B, k1) or lam2.shape != (B, k2) or c00.shape != (B,):
+            raise ValueError("fmap_solve: shapes do not agree")
+        Cm = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        info = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_fmap_solve(self.ctx, B, k1, k2, D, _ptr(A), _ptr(Bm), _ptr(lam1), _ptr(lam2), _ptr(c00),
+                                         float(w_descr), float(w_lap), _ptr(Cm), _ptr(info)))
+        if check:
+            bad = torch.nonzero(info).flatten()
+            if bad.numel():
+                raise _lib.DenseMatchError(
+                    f"functional-map system not positive definite for pairs {bad.tolist()[:8]} "
+                    f"(row {int(info[bad[0]]) - 1}): descriptors are rank deficient in the basis and w_lap cannot fix it")
+        return Cm
+
+    def fm_to_p2p(self, Phi1, Phi2, a1, Cm, k1=None, k2=None, knn=True, ind=True):
+        """Returns dict with knn21, knn12 (kd-tree maps of the reference) and ind21, ind12 (indicator arg-max)."""
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        Cm = self._dev(Cm, torch.float64, "C")
+        a1 = self._dev(a1, torch.float32, "a1") if a1 is not None else None
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        k2_, k1_ = Cm.shape[1], Cm.shape[2]
+        if (k1 is not None and k1 != k1_) or (k2 is not None and k2 != k2_) or Cm.shape[0] != B:
+            raise ValueError("fm_to_p2p: C must be (B,k2,k1)")
+        if k1_ > ld1 or k2_ > ld2:
+            raise AssertionError(f"At least {k1_}/{k2_} eigenvectors should be provided, here only {ld1}/{ld2} are given")
+        mk = lambda n: torch.empty((B, n), dtype=torch.int32, device=self.device)
+        out = {"knn21": mk(N2) if knn else None, "knn12": mk(N1) if knn else None,
+               "ind21": mk(N2) if ind else None, "ind12": mk(N1) if ind else None}
+        self._chk(self.lib.dm_fm_to_p2p(self.ctx, B, N1, N2, k1_, k2_, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(Cm),
+                                        _ptr(out["knn21"]), _ptr(out["knn12"]), _ptr(out["ind21"]), _ptr(out["ind12"])))
+        return out
+
+    def p2p_to_fm(self, p21, Phi1, Phi2, a2, k1, k2):
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        a2 = self._dev(a2, torch.float32, "a2")
+        p21 = self._dev(p21, torch.int32, "p21")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        if p21.shape != (B, N2):
+            raise ValueError("p2p_to_fm: p21 must be (B,N2)")
+        Cm = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_p2p_to_fm(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2), _ptr(Cm)))
+        return Cm
+
+    def zoomout(self, Phi1, Phi2, a2, C0, nit, step=1, return_p2p=False):
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        a2 = self._dev(a2, torch.float32, "a2")
+        C0 = self._dev(C0, torch.float64, "C0")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        if C0.dim() != 3 or C0.shape[0] != B or C0.shape[1] != C0.shape[2]:
+            raise ValueError("zoomout: C0 must be (B,k0,k0)")
+        k0 = C0.shape[1]
+        kf = k0 + nit * step
+        assert kf <= ld1, f"Not enough eigenvectors on source : {kf} are needed when {ld1} are provided"
+        assert kf <= ld2, f"Not enough eigenvectors on target : {kf} are needed when {ld2} are provided"
+        Cout = torch.empty((B, kf, kf), dtype=torch.float64, device=self.device)
+        p21 = torch.empty((B, N2), dtype=torch.int32, device=self.device) if return_p2p else None
+        self._chk(self.lib.dm_zoomout(self.ctx, B, N1, N2, k0, nit, step, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2),
+                                      _ptr(C0), _ptr(Cout), _ptr(p21)))
+        return (Cout, p21) if return_p2p else Cout
+
+    # ------------------------------------------------------------------ the hot path, one batch
+    def match(self, batch, k=None, w_descr=1e4, w_lap=1e3, knn=True, ind=True, check=False):
+        """project -> pinned column -> solve -> vertex maps for a batch of pairs (BASELINE config 2).
+
+        `batch` is a dict with Phi1, Phi2, lam1, lam2, a1, a2, F1, F2 (device tensors).
+        Returns dict(C, knn21, knn12, ind21, ind12).  No host synchronisation inside
+        (unless check=True)."""
+        Phi1, Phi2 = batch["Phi1"], batch["Phi2"]
+        k1 = k if k is not None else batch["lam1"].shape[1]
+        k2 = k if k is not None else batch["lam2"].shape[1]
+        A = self.project(Phi1, batch["a1"], batch["F1"], k1)
+        Bm = self.project(Phi2, batch["a2"], batch["F2"], k2)
+        c00 = self.c00(Phi1, Phi2, batch["a1"], batch["a2"])
+        lam1 = batch["lam1"][:, :k1].contiguous()
+        lam2 = batch["lam2"][:, :k2].contiguous()
+        Cm = self.fmap_solve(A, Bm, lam1, lam2, c00, w_descr, w_lap, check=check)
+        out = self.fm_to_p2p(Phi1, Phi2, batch["a1"], Cm, knn=knn, ind=ind)
+        out["C"] = Cm
+        return out
+
+
+_default_engines = {}
+
+
+def default_engine(device=None):
+    """One engine per (device, current stream), created on first use."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("densematcher_amd needs a ROCm GPU (gfx950); there is no CPU fallback")
+    dev = torch.cuda.current_device() if device is None else (device if isinstance(device, int) else torch.device(device).index or 0)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _default_engines:
+        _default_engines[key] = MatchEngine(dev)
+    return _default_engines[key]

@@ -1,0 +1,145 @@
+/*
+ * densematch.h -- C ABI of libdensematch (MI355X / gfx950 native).
+ *
+ * The drop-in boundary for DenseMatcher's matching hot path.  The reference
+ * has no FFI on this path: the seam is the Python call level
+ * (densematcher/functional_map.py:9 `compute_surface_map` and the
+ * densematcher/pyFM functions it calls).  Each entry point below replaces the
+ * arithmetic of one of those reference functions; the Python mirror in
+ * `densematcher_amd/` keeps the reference signatures and binds these symbols
+ * with ctypes (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - every array argument is a DEVICE pointer owned by the caller (hipMalloc /
+ *     torch tensor.data_ptr()), row-major, batch-major, contiguous unless an
+ *     `ld` (row stride in elements) is given.  The library never frees or
+ *     retains caller pointers past return.
+ *   - B = number of mesh pairs in the batch.  Pairs are independent.
+ *   - mesh 1 = source, mesh 2 = target.  Phi1 (N1 x ld1) / Phi2 (N2 x ld2) are
+ *     mass-orthonormal Laplace-Beltrami eigenvectors, mass1/mass2 the diagonals
+ *     of the lumped mass matrices, C is (k2 x k1) and maps basis-1
+ *     coefficients to basis 2 (reference convention, pyFM/functional.py:482).
+ *   - integer maps are int32 on the device (the Python layer widens to int64).
+ *   - calls are asynchronous on the context's stream; the caller synchronises
+ *     the stream before reading results.  A context is not thread-safe;
+ *     contexts are independent of one another.
+ *   - return value: DM_OK or a negative dm_status; no exceptions cross the ABI.
+ */
+#ifndef DENSEMATCH_H
+#define DENSEMATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dm_ctx dm_ctx;
+
+typedef enum dm_status {
+    DM_OK = 0,
+    DM_EINVAL = -1,     /* bad argument (shape, null pointer, unsupported size)  -> Python ValueError   */
+    DM_ENOMEM = -2,     /* workspace allocation failed                           -> Python MemoryError  */
+    DM_EHIP = -3,       /* a HIP runtime call failed (see dm_last_error)         -> Python RuntimeError */
+    DM_ESINGULAR = -4   /* a linear system was not positive definite (info[] says which pair) */
+} dm_status;
+
+/* feature dtypes for dm_project */
+enum { DM_F16 = 0, DM_F32 = 1 };
+
+/* ---- context ---------------------------------------------------------- */
+/* One context per (device, stream).  hip_stream may be NULL (default stream). */
+int dm_create(int device, void* hip_stream, dm_ctx** out);
+int dm_destroy(dm_ctx* ctx);
+/* ctx-owned string describing the last failure; valid until the next call on ctx. */
+const char* dm_last_error(const dm_ctx* ctx);
+const char* dm_version(void);
+/* bytes of ctx-owned scratch currently allocated (grown lazily, never shrunk). */
+size_t dm_workspace_bytes(const dm_ctx* ctx);
+
+/* ---- kernel timing (HIP events on the ctx stream) ----------------------- */
+/* Bracket every launch of the kernel called `name` (see DESIGN.md for names)
+ * with a hipEvent pair.  Pass NULL to stop.  dm_profile_read synchronises the
+ * stream and returns the number of launches and their summed duration since
+ * the last dm_profile_kernel call. */
+int dm_profile_kernel(dm_ctx* ctx, const char* name);
+int dm_profile_read(dm_ctx* ctx, int* launches, double* total_ms);
+
+/* ---- config 3: feature-similarity nearest neighbour ---------------------
+ * nn21[b,i] = argmax_j <Ftgt[b,i,:], Fsrc[b,j,:]>   (lowest j on ties)
+ * No reference symbol; defined by oracle/dm_oracle.py:simnn.
+ * The products are exact (fp16 x fp16 in fp32), accumulated in fp32 on the
+ * matrix cores; rows whose top-2 margin is within the fp32 accumulation bound
+ * are re-evaluated in float64, so nn21 equals the float64 argmax.
+ * Ftgt (B,N2,D), Fsrc (B,N1,D) fp16.  best/margin (B,N2) fp32 are optional
+ * (fp32-accumulated best score and best - second best). */
+int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D,
+                 const void* Ftgt, const void* Fsrc,
+                 int32_t* nn21, float* best /*nullable*/, float* margin /*nullable*/);
+
+/* ---- spectral projection ------------------------------------------------
+ * Ared[b] = Phi[b][:, :k]^T (mass[b] * F[b])        (k x D), fp32 out.
+ * Replaces pyFM/optimize/base_functions.py:526-532 (descr{1,2}_red) and
+ * pyFM/mesh/trimesh.py:533-556 (TriMesh.project).
+ * Phi (B,N,ld) fp32, mass (B,N) fp32, F (B,N,D) fp16 or fp32 (f_dtype). */
+int dm_project(dm_ctx* ctx, int B, int N, int D, int k,
+               const float* Phi, int ld, const float* mass,
+               const void* F, int f_dtype, float* Ared /* B*k*D */);
+
+/* ---- pinned first column ---------------------------------------------------
+ * c00[b] = sign(Phi1[b][0,0] * Phi2[b][0,0]) * sqrt(sum(mass2[b]) / sum(mass1[b]))
+ * Replaces FunctionalMapping.get_x0 (pyFM/functional.py:654-658; mesh.area =
+ * A.sum(), pyFM/mesh/trimesh.py:206-221): the only non-zero entry of column 0
+ * of the initial map, which the optimiser never changes (base_functions.py:759). */
+int dm_fmap_c00(dm_ctx* ctx, int B, int N1, int N2,
+                const float* Phi1, int ld1, const float* Phi2, int ld2,
+                const float* mass1, const float* mass2, double* c00 /* B */);
+
+/* ---- functional-map solve -----------------------------------------------
+ * Minimiser of  w_descr/2 |C A - Bm|^2 + w_lap/2 sum C_ij^2 ev_ij  with column
+ * 0 pinned to (c00, 0, ..., 0)^T, ev_ij = ((lam1_j - lam2_i)/max(lam))^2.
+ * Replaces the L-BFGS-B loop of pyFM/functional.py:352-487 over
+ * pyFM/optimize/base_functions.py:480-763 (w_descr / w_lap terms), i.e.
+ * FunctionalMapping.fit; c00 is get_x0()[0,0] (functional.py:654-658).
+ * A (B,k1,D), Bm (B,k2,D) fp32; lam1 (B,k1), lam2 (B,k2), c00 (B) fp64;
+ * C (B,k2,k1) fp64 out; info (B) int32 out, 0 = ok, r+1 = row r not SPD. */
+int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D,
+                  const float* A, const float* Bm,
+                  const double* lam1, const double* lam2, const double* c00,
+                  double w_descr, double w_lap, double* C, int32_t* info);
+
+/* ---- functional map -> vertex maps ---------------------------------------
+ * With G = Phi2[:, :k2] C Phi1[:, :k1]^T (never materialised):
+ *   knn21[i] = argmin_j |C Phi1_j|^2 - 2 G_ij      (pyFM/spectral/convert.py:138-140)
+ *   knn12[j] = argmin_i |Phi2_i C|^2 - 2 G_ij      (pyFM/spectral/convert.py:134-136)
+ *   ind21[i] = argmax_j G_ij mass1_j               (convert.py:144 + functional_map.py:49)
+ *   ind12[j] = argmax_i G_ij mass1_j               (convert.py:144 + functional_map.py:50)
+ * float64 arithmetic on the f64 matrix cores; lowest index on ties.
+ * Any of the four outputs may be NULL.  knn21/ind21 (B,N2); knn12/ind12 (B,N1). */
+int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                 const float* Phi1, int ld1, const float* Phi2, int ld2,
+                 const float* mass1, const double* C,
+                 int32_t* knn21, int32_t* knn12, int32_t* ind21, int32_t* ind12);
+
+/* ---- vertex map -> functional map -----------------------------------------
+ * C[b] = Phi2[b][:, :k2]^T (mass2[b] * Phi1[b][p21[b], :k1])   (k2 x k1) fp64.
+ * Replaces pyFM/spectral/convert.py:14-51 (p2p_to_FM, A2 given). */
+int dm_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                 const int32_t* p21, const float* Phi1, int ld1, const float* Phi2, int ld2,
+                 const float* mass2, double* C);
+
+/* ---- ZoomOut ----------------------------------------------------------------
+ * nit times: p21 = knn21(C_k); C_{k+step} = p2p_to_fm(p21) with k+step columns.
+ * Replaces pyFM/refine/zoomout.py:7-44,47-115 (with upstream FM_to_p2p
+ * semantics).  C0 (B,k0,k0); Cout (B,kf,kf), kf = k0+nit*step;
+ * p21_out (B,N2) optional = knn21(Cout).  Needs ld1, ld2 >= kf. */
+int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step,
+               const float* Phi1, int ld1, const float* Phi2, int ld2,
+               const float* mass2, const double* C0, double* Cout, int32_t* p21_out /*nullable*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENSEMATCH_H */

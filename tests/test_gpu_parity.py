@@ -1,0 +1,207 @@
+"""
+GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the
+reference-generated golden fixtures.  Integer maps must be bit-exact; C within 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+C_TOL = 1e-4          # BASELINE.json north_star: float C matrix within 1e-4
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from densematcher_amd.engine import MatchEngine
+    return MatchEngine()
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _b(x):
+    """add the batch axis"""
+    return np.ascontiguousarray(x)[None]
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("fxname", ["fx_cfg1", "fx_cfg2"])
+def test_project_and_solve(eng, fxname, request):
+    fx = request.getfixturevalue(fxname)
+    k = int(fx["k"])
+    wd, wl = float(fx["w_descr"]), float(fx["w_lap"])
+    A = _np(eng.project(_b(fx["Phi1"]), _b(fx["a1"]), _b(fx["F1"]), k))[0]
+    Bm = _np(eng.project(_b(fx["Phi2"]), _b(fx["a2"]), _b(fx["F2"]), k))[0]
+    A64 = orc.project(fx["Phi1"][:, :k], fx["a1"], fx["F1"])
+    B64 = orc.project(fx["Phi2"][:, :k], fx["a2"], fx["F2"])
+    assert np.abs(A - A64).max() <= 2e-7 * np.abs(A64).max() + 1e-12     # fp32 output rounding only
+    assert np.abs(Bm - B64).max() <= 2e-7 * np.abs(B64).max() + 1e-12
+    # fp32 descriptors take the other operand path
+    A32 = _np(eng.project(_b(fx["Phi1"]), _b(fx["a1"]), _b(fx["F1"].astype(np.float32)), k))[0]
+    assert np.array_equal(A32, A)
+
+    c00 = _np(eng.c00(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a1"]), _b(fx["a2"])))[0]
+    x0 = orc.get_x0(k, k, float(fx["Phi1"][0, 0]), float(fx["Phi2"][0, 0]),
+                    float(fx["a1"].astype(np.float64).sum()), float(fx["a2"].astype(np.float64).sum()))
+    assert abs(c00 - x0[0, 0]) <= 1e-14 * abs(x0[0, 0])
+
+    C = _np(eng.fmap_solve(_b(A), _b(Bm), _b(fx["lam1"][:k]), _b(fx["lam2"][:k]), np.array([c00]), wd, wl))[0]
+    err = np.abs(C - fx["C_f64"]).max()
+    print(f"{fxname}: |C_gpu - C_f64| = {err:.3e}   |C_gpu - C_fit(reference fp32 L-BFGS)| = {np.abs(C - fx['C_fit']).max():.3e}")
+    assert err <= C_TOL
+    assert err <= 1e-5                     # what this design actually delivers on these fixtures
+    assert np.array_equal(C[1:, 0], np.zeros(k - 1)) and C[0, 0] == c00
+    # solve fed with the oracle's float64 projections (rounded to f32): isolates the solver
+    C2 = _np(eng.fmap_solve(_b(A64.astype(np.float32)), _b(B64.astype(np.float32)), _b(fx["lam1"][:k]),
+                            _b(fx["lam2"][:k]), np.array([x0[0, 0]]), wd, wl))[0]
+    C2o = orc.fmap_solve(A64.astype(np.float32), B64.astype(np.float32), fx["lam1"][:k], fx["lam2"][:k], x0, wd, wl)
+    assert np.abs(C2 - C2o).max() <= 1e-9
+
+
+@pytest.mark.parametrize("fxname,pre,cname", [("fx_cfg1", "", "C_fit"), ("fx_cfg2", "", "C_fit"),
+                                              ("fx_cfg2", "f64_", "C_f64"), ("fx_cfg1", "icp_", "C_icp")])
+def test_fm_to_p2p_bit_exact(eng, fxname, pre, cname, request):
+    fx = request.getfixturevalue(fxname)
+    k = int(fx["k"])
+    out = eng.fm_to_p2p(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a1"]), _b(fx[cname]))
+    for name in ["knn21", "knn12", "ind21", "ind12"]:
+        got = _np(out[name])[0].astype(np.int64)
+        assert np.array_equal(got, fx[pre + name]), f"{fxname}/{name}: {(got != fx[pre + name]).sum()} mismatches"
+    # sliced eigenvectors (ld == k) give the same answer as ld > k
+    out2 = eng.fm_to_p2p(_b(fx["Phi1"][:, :k]), _b(fx["Phi2"][:, :k]), _b(fx["a1"]), _b(fx[cname]), knn=True, ind=False)
+    assert out2["ind21"] is None
+    assert np.array_equal(_np(out2["knn21"]), _np(out["knn21"]))
+
+
+def test_ties_lowest_index(eng, fx_ties):
+    fx = fx_ties
+    out = eng.fm_to_p2p(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a1"]), _b(fx["C"]))
+    # indicator maps: np.argmax first-index rule, pinned by the reference itself
+    assert np.array_equal(_np(out["ind21"])[0], fx["ind21"])
+    assert np.array_equal(_np(out["ind12"])[0], fx["ind12"])
+    # nearest-neighbour maps: equal to the lowest-index oracle (the kd-tree's own tie order is traversal dependent)
+    p21, p12, _ = orc.fm_to_p2p(fx["C"], fx["Phi1"].astype(np.float64), fx["Phi2"].astype(np.float64), fx["a1"],
+                                with_indicator=False)
+    assert np.array_equal(_np(out["knn21"])[0], p21)
+    assert np.array_equal(_np(out["knn12"])[0], p12)
+
+
+def test_p2p_to_fm(eng, fx_cfg1, fx_cfg2):
+    for fx, k in [(fx_cfg1, 30), (fx_cfg1, 48), (fx_cfg2, 128)]:
+        C = _np(eng.p2p_to_fm(_b(fx["knn21"].astype(np.int32)), _b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), k, k))[0]
+        Co = orc.p2p_to_fm(fx["knn21"], fx["Phi1"][:, :k], fx["Phi2"][:, :k], fx["a2"])
+        assert np.abs(C - Co).max() <= 1e-13 * max(1.0, np.abs(Co).max())
+    assert np.abs(C[:30, :30] - 0).max() > 0
+    C30 = _np(eng.p2p_to_fm(_b(fx_cfg1["knn21"].astype(np.int32)), _b(fx_cfg1["Phi1"]), _b(fx_cfg1["Phi2"]),
+                            _b(fx_cfg1["a2"]), 30, 30))[0]
+    assert np.abs(C30 - fx_cfg1["C_from_p2p"]).max() <= 1e-13
+    # rectangular map
+    C = _np(eng.p2p_to_fm(_b(fx_cfg1["knn21"].astype(np.int32)), _b(fx_cfg1["Phi1"]), _b(fx_cfg1["Phi2"]),
+                          _b(fx_cfg1["a2"]), 20, 40))[0]
+    Co = orc.p2p_to_fm(fx_cfg1["knn21"], fx_cfg1["Phi1"][:, :20], fx_cfg1["Phi2"][:, :40], fx_cfg1["a2"])
+    assert C.shape == (40, 20) and np.abs(C - Co).max() <= 1e-13
+
+
+def test_zoomout(eng, fx_cfg1, fx_cfg2):
+    fx = fx_cfg1
+    C, p = eng.zoomout(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), _b(fx["C20"]), nit=20, step=1, return_p2p=True)
+    assert np.array_equal(_np(p)[0], fx["p21_zo"])
+    assert np.abs(_np(C)[0] - fx["C_zo"]).max() <= 1e-11
+    C, p = eng.zoomout(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), _b(fx["C20"]), nit=6, step=4, return_p2p=True)
+    assert np.array_equal(_np(p)[0], fx["p21_zo4"])
+    assert np.abs(_np(C)[0] - fx["C_zo4"]).max() <= 1e-11
+    fx = fx_cfg2
+    C, p = eng.zoomout(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), _b(fx["C_fit"]), nit=3, step=4, return_p2p=True)
+    assert np.array_equal(_np(p)[0], fx["p21_zo"])
+    assert np.abs(_np(C)[0] - fx["C_zo"]).max() <= 1e-11
+    C0 = eng.zoomout(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), _b(fx["C_fit"]), nit=0)
+    assert np.array_equal(_np(C0)[0], fx["C_fit"])
+    with pytest.raises(AssertionError):
+        eng.zoomout(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), _b(fx["C_fit"]), nit=4, step=4)
+
+
+# --------------------------------------------------------------------------- #
+@pytest.mark.parametrize("B,N2,N1,D", [(1, 128, 128, 64), (2, 300, 517, 96), (3, 1000, 777, 384), (1, 2048, 2048, 768)])
+def test_simnn_random(eng, B, N2, N1, D):
+    rng = np.random.default_rng(B * 1000 + N2)
+    S = rng.standard_normal((B, N1, D)).astype(np.float16)
+    T = rng.standard_normal((B, N2, D)).astype(np.float16)
+    nn, best, margin = eng.simnn(T, S, return_scores=True)
+    nn = _np(nn)
+    for b in range(B):
+        ref = orc.simnn(T[b], S[b])
+        assert np.array_equal(nn[b], ref), f"{(nn[b] != ref).sum()} mismatches"
+        sc = (T[b].astype(np.float64) @ S[b].astype(np.float64).T)
+        srt = np.sort(sc, axis=1)
+        assert np.abs(_np(best)[b] - srt[:, -1]).max() <= 2e-4 * np.abs(srt).max()
+        assert np.abs(_np(margin)[b] - (srt[:, -1] - srt[:, -2])).max() <= 4e-4 * np.abs(srt).max()
+
+
+def test_simnn_ties_and_near_ties(eng):
+    rng = np.random.default_rng(5)
+    D, N1, N2 = 256, 640, 384
+    S = rng.standard_normal((N1, D)).astype(np.float16)
+    S[400:420] = S[10:30]                     # exact duplicates: lowest index must win
+    T = S[rng.integers(0, N1, size=N2)].copy()
+    # near ties: rows whose two best candidates differ in the last fp16 bit of one coordinate
+    S[500] = S[100]
+    S[500, 7] = np.nextafter(S[500, 7], np.float16(np.inf))
+    T[0] = S[100]
+    nn = _np(eng.simnn(T[None], S[None]))[0]
+    assert np.array_equal(nn, orc.simnn(T, S))
+    assert (nn[np.isin(nn, np.arange(10, 30))].size > 0) and not np.isin(nn, np.arange(400, 420)).any()
+
+
+def test_simnn_unit_norm_hard(eng):
+    """BASELINE config-3 recipe at reduced B: unit-norm rows, F2 = F1[perm] + sigma noise."""
+    from densematcher_amd import synth
+    for sigma in (0.1, 1.0):
+        F1, F2, perm = synth.feature_pair(2048, 2048, 768, 1000, 2000, sigma=sigma)
+        nn = _np(eng.simnn(F2[None], F1[None]))[0]
+        assert np.array_equal(nn, orc.simnn(F2, F1))
+        if sigma == 0.1:
+            assert np.array_equal(nn, perm)
+
+
+# --------------------------------------------------------------------------- #
+def test_match_batch_end_to_end(eng):
+    """project -> solve -> maps for a batch with distinct pairs; C within 1e-4 of the oracle,
+    maps bit-exact when the oracle consumes the same C, end-to-end agreement reported."""
+    from densematcher_amd import synth
+    B, k = 3, 40
+    batch = synth.make_pair_batch(B, 32, 16, 96, 56, sigma=0.5, n_distinct_meshes=2)
+    dev = {n: torch.as_tensor(v).to(eng.device) for n, v in batch.items()}
+    out = eng.match(dev, k=k, check=True)
+    agree = []
+    for b in range(B):
+        Co, k21, k12, i21, i12 = orc.match_pair(batch["Phi1"][b][:, :k], batch["Phi2"][b][:, :k], batch["lam1"][b][:k],
+                                                batch["lam2"][b][:k], batch["a1"][b], batch["a2"][b], batch["F1"][b],
+                                                batch["F2"][b])
+        Cg = _np(out["C"])[b]
+        assert np.abs(Cg - Co).max() <= C_TOL
+        same = orc.fm_to_p2p_all(Cg, batch["Phi1"][b][:, :k].astype(np.float64), batch["Phi2"][b][:, :k].astype(np.float64),
+                                 batch["a1"][b])
+        for got, name in zip(same, ["knn21", "knn12", "ind21", "ind12"]):
+            assert np.array_equal(_np(out[name])[b], got), name
+        agree.append(np.mean([(_np(out["knn21"])[b] == k21).mean(), (_np(out["ind21"])[b] == i21).mean()]))
+    print("end-to-end map agreement with the float64 oracle:", agree)
+    assert min(agree) >= 0.995
+
+
+def test_errors(eng):
+    z = np.zeros((1, 64, 8), np.float32)
+    with pytest.raises(ValueError):
+        eng.simnn(np.zeros((1, 8, 12), np.float16), np.zeros((1, 8, 12), np.float16))      # D % 8
+    with pytest.raises(ValueError):
+        eng.project(z, np.ones((1, 63), np.float32), np.zeros((1, 64, 4), np.float16), 8)
+    with pytest.raises(AssertionError):
+        eng.fm_to_p2p(z, z, np.ones((1, 64), np.float32), np.zeros((1, 9, 9)))
+    # rank-deficient descriptors and w_lap = 0: the system is singular and must be reported
+    from densematcher_amd._lib import DenseMatchError
+    A = np.zeros((1, 6, 16), np.float32)
+    with pytest.raises(DenseMatchError):
+        eng.fmap_solve(A, A, np.arange(6.0)[None], np.arange(6.0)[None], np.ones(1), 1.0, 0.0)
