@@ -48,6 +48,9 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP library has not been built. "
             "Run `python -m densematcher_amd._build` (needs hipcc). There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; import it first so that the
+    # library binds to the runtime that owns the tensors' device memory and streams.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol

@@ -13,15 +13,33 @@ int dm_fail(dm_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+// reason of the last context-less failure (dm_create), returned by dm_last_error(NULL)
+static thread_local std::string g_create_err = "null context";
+
+static int create_fail(const char* what, hipError_t e) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "dm_create: %s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    g_create_err = buf;
+    return DM_EHIP;
+}
+
 extern "C" int dm_create(int device, void* hip_stream, dm_ctx** out) {
     if (!out) return DM_EINVAL;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DM_EHIP;
-    if (hipSetDevice(device) != hipSuccess) return DM_EHIP;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess) return create_fail("hipGetDeviceCount failed", e);
+    if (ndev <= 0 || device < 0 || device >= ndev) return create_fail("no such HIP device", hipSuccess);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return create_fail("hipSetDevice failed", e);
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DM_EHIP;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DM_EHIP;   // kernels exist for gfx950 only
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return create_fail("hipGetDeviceProperties failed", e);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {                 // kernels exist for gfx950 only
+        char buf[300];
+        snprintf(buf, sizeof(buf), "device is %s, libdensematch is built for gfx950 only", prop.gcnArchName);
+        return create_fail(buf, hipSuccess);
+    }
     dm_ctx* ctx = new dm_ctx();
     ctx->device = device;
     ctx->stream = (hipStream_t)hip_stream;
@@ -39,7 +57,7 @@ extern "C" int dm_destroy(dm_ctx* ctx) {
     return DM_OK;
 }
 
-extern "C" const char* dm_last_error(const dm_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" const char* dm_last_error(const dm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" const char* dm_version(void) { return DM_VERSION_STRING; }
 extern "C" size_t dm_workspace_bytes(const dm_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
 

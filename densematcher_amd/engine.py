@@ -35,7 +35,7 @@ class MatchEngine:
         ctx = C.c_void_p()
         rc = self.lib.dm_create(self.device.index, C.c_void_p(self.stream.cuda_stream), C.byref(ctx))
         if rc != 0:
-            raise _lib.DenseMatchError(f"dm_create failed with status {rc} (is this a gfx950 device?)")
+            raise _lib.DenseMatchError(f"dm_create failed with status {rc}: {self.lib.dm_last_error(None).decode()}")
         self.ctx = ctx
 
     def close(self):
