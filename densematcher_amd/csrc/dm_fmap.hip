@@ -231,6 +231,211 @@ __global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restric
     for (int c = t; c < n; c += 256) Crow[c + 1] = y[c];
 }
 
+// =================================================================================================
+// Blocked variant (n <= 176): the matrix lives in LDS as 16x16 blocks, lower block triangle, each
+// block stored TRANSPOSED (T_IK[k][i] = A[I*16+i][K*16+k]) so that every f64-MFMA operand and
+// result access is a lane-contiguous, conflict-free ds_read/ds_write_b64.  Per block column J:
+//   (a) wave 0: Cholesky of the 16x16 diagonal block + W = L_JJ^-1 (the only serial part),
+//   (b) panel:   L_IJ = A_IJ L_JJ^-T        ==  T_IJ <- W T_IJ                    (MFMA)
+//   (c) update:  A_IK -= L_IJ L_KJ^T        ==  T_IK <- T_IK - L_KJ L_IJ^T        (MFMA)
+// the right-hand side is carried along (forward solve), then L^T x = y runs block-backwards with
+// the stored W_J.  Padding rows/columns (n..16*NB) are identity.
+// =================================================================================================
+__global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* __restrict__ PQ, const double* __restrict__ lam1,
+                                                                 const double* __restrict__ lam2, const double* __restrict__ c00,
+                                                                 double w_lap, int k1, int k2, int NB, double* __restrict__ C,
+                                                                 int32_t* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = k1 - 1;
+    const int nblk = NB * (NB + 1) / 2;
+    double* T = sm;                         // nblk blocks of 256
+    double* LT = T + nblk * 256;            // L_JJ^T scratch (row j = column j of L)
+    double* Ws = LT + 256;                  // W^T scratch:  Ws[m*16 + k] = W[k][m]
+    double* rhs = Ws + 256;                 // NB*16  (becomes y)
+    double* xv = rhs + NB * 16;             // NB*16
+    double* invp = xv + NB * 16;            // 16
+    double* red = invp + 16;                // 8: [0..3] wave maxima, [4] scale, [5] failure flag
+    const int b = blockIdx.y, i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const double* P = PQ + (long long)b * (k1 + k2) * k1;
+    const double* Q = P + (long long)k1 * k1;
+    const double* l1 = lam1 + (long long)b * k1;
+    const double* l2 = lam2 + (long long)b * k2;
+
+    double mx = -DM_INF_F64;
+    for (int q = t; q < k1; q += 256) mx = fmax(mx, l1[q]);
+    for (int q = t; q < k2; q += 256) mx = fmax(mx, l2[q]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    if (t == 0) {
+        red[4] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        red[5] = 0.0;
+    }
+    __syncthreads();
+    const double scale = red[4];
+    const double ci0 = (i == 0) ? c00[b] : 0.0;
+    const double l2i = l2[i] / scale;
+
+    // ---- load: T_IK[kk][ii] = M[I*16+ii][K*16+kk]; M symmetric, read P row (K*16+kk+1) so lanes (ii) are contiguous
+    {
+        const int kk = t >> 4, ii = t & 15;
+        for (int I = 0; I < NB; ++I)
+            for (int K = 0; K <= I; ++K) {
+                const int r = I * 16 + ii, c = K * 16 + kk;
+                double v;
+                if (r < n && c < n) {
+                    v = P[(long long)(c + 1) * k1 + (r + 1)];
+                    if (r == c) {
+                        const double d = l1[c + 1] / scale - l2i;
+                        v += w_lap * (d * d);
+                    }
+                } else {
+                    v = (r == c) ? 1.0 : 0.0;
+                }
+                T[(I * (I + 1) / 2 + K) * 256 + kk * 16 + ii] = v;
+            }
+        for (int c = t; c < NB * 16; c += 256)
+            rhs[c] = (c < n) ? Q[(long long)i * k1 + (c + 1)] - P[(long long)(c + 1) * k1] * ci0 : 0.0;
+    }
+    __syncthreads();
+
+    for (int J = 0; J < NB; ++J) {
+        double* S = T + (J * (J + 1) / 2 + J) * 256;
+        // ---- (a) diagonal block, wave 0 only.  Right-looking elimination of the 16x16 block S (kept as a full
+        // symmetric square so that every access is row-contiguous) carried out simultaneously on 16 identity rows and
+        // on the right-hand-side row: they end as L^-T (= W^T, exactly the layout the MFMA panel step wants) and as
+        // y_J = L^-1 rhs_J.  One wave: LDS operations retire in program order, no barrier inside.
+        if (wave == 0) {
+            const int c = lane & 15, rq = lane >> 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ws[(rq + 4 * e) * 16 + c] = (rq + 4 * e == c) ? 1.0 : 0.0;
+            if (rq == 0) xv[J * 16 + c] = rhs[J * 16 + c];
+            asm volatile("" ::: "memory");
+            bool ok = true;
+            for (int j = 0; j < 16; ++j) {
+                const double piv = S[j * 16 + j];
+                ok = ok && (piv > 0.0);
+                // 1/sqrt(piv): hardware seed + two Newton steps (full double precision for normal inputs)
+                double inv = __builtin_amdgcn_rsq(piv);
+                const double hp = 0.5 * piv;
+                inv = inv * (1.5 - hp * inv * inv);
+                inv = inv * (1.5 - hp * inv * inv);
+                const double lc = S[j * 16 + c] * inv;                 // L[c][j] for c > j
+                double lr[4], er[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lr[e] = S[j * 16 + rq + 4 * e] * inv;              // L[rq+4e][j]
+                    er[e] = Ws[(rq + 4 * e) * 16 + j] * inv;           // scaled column j of the identity rows
+                }
+                const double yr = xv[J * 16 + j] * inv;                // scaled entry j of the rhs row
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = rq + 4 * e;
+                    if (rr > j && c > j) S[rr * 16 + c] -= lr[e] * lc;
+                    if (c > j) Ws[rr * 16 + c] -= er[e] * lc;
+                    else if (c == j) Ws[rr * 16 + c] = er[e];
+                }
+                if (rq == 0) {
+                    if (c > j) xv[J * 16 + c] -= yr * lc;
+                    else if (c == j) xv[J * 16 + c] = yr;
+                }
+                asm volatile("" ::: "memory");
+            }
+            if (!ok && lane == 0) red[5] = 1.0;
+        }
+        __syncthreads();
+        if (red[5] != 0.0) break;
+        if (t < 16) rhs[J * 16 + t] = xv[J * 16 + t];
+        // ---- (b) panel: T_IJ <- W T_IJ for I > J, one block per wave at a time
+        for (int I = J + 1 + wave; I < NB; I += 4) {
+            double* Tij = T + (I * (I + 1) / 2 + J) * 256;
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            double bq[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bq[ks] = Tij[((lane >> 4) + 4 * ks) * 16 + (lane & 15)];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double a = Ws[((lane >> 4) + 4 * ks) * 16 + (lane & 15)];
+                acc = mfma_f64_16x16x4(a, bq[ks], acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tij[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+        }
+        __syncthreads();
+        // ---- (c) trailing update, right-hand-side update, and W_J parked in the (now free) diagonal slot
+        {
+            const int m = NB - 1 - J;                 // remaining block rows
+            const int nupd = m * (m + 1) / 2;
+            for (int u = wave; u < nupd; u += 4) {
+                // u -> (I, K) with J < K <= I < NB, row-major over the lower triangle
+                int a_ = 0;
+                while ((a_ + 1) * (a_ + 2) / 2 <= u) ++a_;
+                const int I = J + 1 + a_, K = J + 1 + (u - a_ * (a_ + 1) / 2);
+                double* Tik = T + (I * (I + 1) / 2 + K) * 256;
+                const double* Tij = T + (I * (I + 1) / 2 + J) * 256;
+                const double* Tkj = T + (K * (K + 1) / 2 + J) * 256;
+                f64x4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = Tik[((lane >> 4) + 4 * r) * 16 + (lane & 15)];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int o = ((lane >> 4) + 4 * ks) * 16 + (lane & 15);
+                    acc = mfma_f64_16x16x4(-Tkj[o], Tij[o], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tik[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+            }
+            // rhs_I -= L_IJ y_J   (row ii of block I: sum_k T_IJ[k][ii] y_J[k])
+            if (t < m * 16) {
+                const int I = J + 1 + (t >> 4), ii = t & 15;
+                const double* Tij = T + (I * (I + 1) / 2 + J) * 256;
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sacc += Tij[k * 16 + ii] * xv[J * 16 + k];
+                rhs[I * 16 + ii] -= sacc;
+            }
+            S[t] = Ws[t];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    double* Crow = C + ((long long)b * k2 + i) * k1;
+    if (red[5] != 0.0) {
+        if (t == 0) atomicMax(&info[b], i + 1);
+        for (int c = t; c < k1; c += 256) Crow[c] = (c == 0) ? ci0 : 0.0;
+        return;
+    }
+    // ---- back substitution  L^T x = y :  x_J = W_J^T (y_J - sum_{I>J} L_IJ^T x_I)
+    for (int J = NB - 1; J >= 0; --J) {
+        const double* Wt = T + (J * (J + 1) / 2 + J) * 256;     // Wt[m*16 + k] = W[k][m]
+        {
+            // x_J[k] = sum_m W[m][k] y[m] = sum_m Wt[k*16 + m] y[m]
+            const int k = t >> 4, m = t & 15;
+            double pr = Wt[k * 16 + m] * rhs[J * 16 + m];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) pr += __shfl_xor(pr, off);
+            if (m == 0) xv[J * 16 + k] = pr;
+        }
+        __syncthreads();
+        // y_K -= L_JK^T x_J for K < J:  (L_JK^T x)[k] = sum_i T_JK[k*16 + i] x_J[i]
+        for (int K = wave; K < J; K += 4) {
+            const double* Tjk = T + (J * (J + 1) / 2 + K) * 256;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = (lane >> 4) + 4 * e, ii = lane & 15;
+                double pr = Tjk[k * 16 + ii] * xv[J * 16 + ii];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) pr += __shfl_xor(pr, off);
+                if (ii == 0) rhs[K * 16 + k] -= pr;
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) Crow[0] = ci0;
+    for (int c = t; c < n; c += 256) Crow[c + 1] = xv[c];
+}
+
 extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const float* A, const float* Bm,
                              const double* lam1, const double* lam2, const double* c00, double w_descr, double w_lap,
                              double* C, int32_t* info) {
@@ -254,6 +459,20 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
               k1 + k2, k1, D);
 
     const int n = k1 - 1;
+    const int NB = (n + 15) / 16;
+    if (n >= 1 && NB <= 11) {
+        // blocked MFMA solver: NB(NB+1)/2 + 2 blocks of 2 KiB, vectors
+        const size_t lds = ((size_t)(NB * (NB + 1) / 2 + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);
+        static size_t lds_set_b = 0;
+        if (lds > lds_set_b) {
+            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)fmap_solve_blocked_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set_b = lds;
+        }
+        DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_blocked_kernel, dim3(k2, B), dim3(256), lds, PQ, lam1, lam2, c00, w_lap,
+                  k1, k2, NB, C, info);
+        return DM_OK;
+    }
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 4 ? 4 : n + 1) + 2) * sizeof(double);
     static size_t lds_set = 0;
     if (lds > lds_set) {

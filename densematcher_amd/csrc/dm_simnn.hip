@@ -34,6 +34,8 @@ __device__ __forceinline__ int lds_off_halves(int row, int chunk) {
 struct simnn_params {
     const _Float16* Ftgt; const _Float16* Fsrc;
     float* pb; int32_t* pj; float* ps;       // partials (B, tilesS, N2pad)
+    float* tnorm2;                           // (B, N2)  |t_i|^2, written by the workgroups of source tile 0
+    unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
 };
 
@@ -61,6 +63,12 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that
+    // own the first tile of the other operand (every row of T / S is seen exactly once that way)
+    const bool do_tn = (ts_ == 0) && (ws == 0);
+    const bool do_sn = (tt_ == 0) && (wt == 0);
+    float nrm_t[2] = {0.f, 0.f}, nrm_s[2] = {0.f, 0.f};
 
     const int lrow = t >> 3, lchunk = t & 7;
     uint4 rt[4], rs[4];
@@ -103,6 +111,18 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
                 fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(ws * 64 + x * 32 + (lane & 31), chunk));
                 ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wt * 64 + x * 32 + (lane & 31), chunk));
             }
+            if (do_tn) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) nrm_t[x] = fmaf((float)ft[x][e], (float)ft[x][e], nrm_t[x]);
+            }
+            if (do_sn) {
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) nrm_s[x] = fmaf((float)fs[x][e], (float)fs[x][e], nrm_s[x]);
+            }
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -114,6 +134,27 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
     }
 #undef SIMNN_FETCH
 #undef SIMNN_STASH
+
+    if (do_tn) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
+            const int gi = i0 + wt * 64 + x * 32 + (lane & 31);
+            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
+        }
+    }
+    if (do_sn) {
+        float m = 0.f;
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
+            const int gj = j0 + ws * 64 + x * 32 + (lane & 31);
+            if (gj < p.N1) m = fmaxf(m, v);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
+    }
 
     // acc[st][tt][r] = <src j, tgt i>,  j = j0 + ws*64 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
     //                                   i = i0 + wt*64 + tt*32 + (lane&31)
@@ -158,35 +199,12 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
     }
 }
 
-// row norms: one wave per row.  mode 0: out[row] = |F_row|; mode 1: atomicMax(out[b], |F_row|) as uint bits
-__global__ __launch_bounds__(256) void rownorm_f16_kernel(const _Float16* __restrict__ F, int N, int D, float* __restrict__ out,
-                                                          int mode) {
-    const int b = blockIdx.y;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= N) return;
-    const _Float16* r = F + ((long long)b * N + row) * D;
-    float s = 0.f;
-    for (int k = lane * 8; k < D; k += 512) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(r + k);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf((float)v[e], (float)v[e], s);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) {
-        const float nrm = sqrtf(s);
-        if (mode == 0) out[(long long)b * N + row] = nrm;
-        else atomicMax(reinterpret_cast<unsigned int*>(out) + b, __float_as_uint(nrm));
-    }
-}
-
 __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restrict__ pb, const int32_t* __restrict__ pj,
                                                           const float* __restrict__ ps, int tilesS, int N2, int N2pad,
-                                                          const float* __restrict__ tnorm, const float* __restrict__ smax,
+                                                          const float* __restrict__ tnorm2, const unsigned int* __restrict__ smax2,
                                                           float tau_scale, int32_t* __restrict__ nn, float* __restrict__ best,
                                                           float* __restrict__ margin, int32_t* __restrict__ flag_count,
-                                                          int32_t* __restrict__ flag_list) {
+                                                          int32_t* __restrict__ flag_list, float* __restrict__ flag_thr) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N2) return;
@@ -201,52 +219,63 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restric
     const float m = bv - sv;
     if (best) best[o] = bv;
     if (margin) margin[o] = m;
-    const float tau = tau_scale * tnorm[o] * smax[b];
+    const float tau = tau_scale * sqrtf(tnorm2[o] * __uint_as_float(smax2[b]));
     if (!(m > tau)) {
         const int pos = atomicAdd(flag_count, 1);
         flag_list[pos] = (int32_t)o;
+        flag_thr[pos] = bv - tau;          // candidates scoring below this (in fp32) cannot be the float64 argmax
     }
 }
 
-// float64 re-evaluation of the flagged rows: one workgroup per flagged row (grid-stride over the list)
+// float64 re-evaluation of the flagged rows: one workgroup per flagged row (grid-stride over the list).  Only the
+// source tiles whose fp32 tile maximum reaches (best - tau) can contain the float64 argmax (every fp32 score is
+// within tau/2 of the exact one); their 128 candidates are re-scored exactly: fp16 products are exact in f64.
 __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __restrict__ Ftgt, const _Float16* __restrict__ Fsrc,
-                                                          int N2, int N1, int D, const int32_t* __restrict__ flag_count,
-                                                          const int32_t* __restrict__ flag_list, int32_t* __restrict__ nn) {
-    extern __shared__ __attribute__((aligned(16))) double trow[];   // D doubles + 4 (value) + 4 (index as double slot)
+                                                          int N2, int N1, int D, const float* __restrict__ pb, int tilesS,
+                                                          int N2pad, const int32_t* __restrict__ flag_count,
+                                                          const int32_t* __restrict__ flag_list,
+                                                          const float* __restrict__ flag_thr, int32_t* __restrict__ nn) {
+    extern __shared__ __attribute__((aligned(16))) double trow[];   // D doubles + 4 (value) + 4 ints
     double* wv = trow + D;
     int* wj = reinterpret_cast<int*>(wv + 4);
     const int count = *flag_count;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = blockIdx.x; e < count; e += gridDim.x) {
         const int o = flag_list[e];
+        const float thr = flag_thr[e];
         const int b = o / N2, i = o - b * N2;
         const _Float16* tr = Ftgt + ((long long)b * N2 + i) * D;
         __syncthreads();
         for (int k = threadIdx.x; k < D; k += 256) trow[k] = (double)tr[k];
         __syncthreads();
-        const int chunk = (N1 + 3) / 4;
-        const int jbeg = wave * chunk, jend = min(N1, jbeg + chunk);
         double bv = -DM_INF_F64;
         int bj = DM_IDX_NONE;
-        for (int j = jbeg; j < jend; ++j) {
-            const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
-            double s = 0.0;
-            for (int k = lane * 8; k < D; k += 512) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(sr + k);
+        for (int ts = 0; ts < tilesS; ++ts) {
+            const float tb = pb[((long long)b * tilesS + ts) * N2pad + i];
+            if (!(tb >= thr)) continue;                       // uniform: every thread reads the same word
+            // wave w re-scores candidates [ts*128 + w*32, +32) in ascending order
+            for (int q = 0; q < 32; ++q) {
+                const int j = ts * ST + wave * 32 + q;
+                if (j >= N1) break;
+                const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
+                double s = 0.0;
+                for (int k = lane * 8; k < D; k += 512) {
+                    const f16x8 v = *reinterpret_cast<const f16x8*>(sr + k);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) s = fma((double)v[q], trow[k + q], s);
+                    for (int u = 0; u < 8; ++u) s = fma((double)v[u], trow[k + u], s);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                if (s > bv) { bv = s; bj = j; }               // ascending j within the wave: strict keeps the lowest
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            if (s > bv) { bv = s; bj = j; }       // ascending j, strict: lowest index wins ties
         }
         if (lane == 0) { wv[wave] = bv; wj[wave] = bj; }
         __syncthreads();
         if (threadIdx.x == 0) {
             double v = wv[0];
             int j = wj[0];
-            for (int w = 1; w < 4; ++w) argmax_merge(v, j, wv[w], wj[w]);
-            nn[o] = (j == DM_IDX_NONE) ? 0 : j;
+            for (int w = 1; w < 4; ++w) argmax_merge(v, j, wv[w], wj[w]);   // index tie-break: waves interleave tiles
+            if (j != DM_IDX_NONE) nn[o] = j;
         }
     }
 }
@@ -269,29 +298,26 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     p.tilesT = p.N2pad / ST; p.tilesS = dm_cdiv(N1, ST);
     p.total = B * p.tilesT * p.tilesS;
     const size_t np = (size_t)B * p.tilesS * p.N2pad;
-    const size_t need = 3 * dm_align_up(np * 4) + dm_align_up((size_t)B * N2 * 4) * 2 + dm_align_up((size_t)B * 4) + 8192;
+    const size_t need = 3 * dm_align_up(np * 4) + dm_align_up((size_t)B * N2 * 4) * 3 + dm_align_up((size_t)B * 4) + 8192;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     p.pb = (float*)dm_ws_take(ctx, np * 4);
     p.pj = (int32_t*)dm_ws_take(ctx, np * 4);
     p.ps = (float*)dm_ws_take(ctx, np * 4);
-    float* tnorm = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    p.tnorm2 = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* flag_list = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    float* smax = (float*)dm_ws_take(ctx, (size_t)B * 4);
+    float* flag_thr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    p.smax2 = (unsigned int*)dm_ws_take(ctx, (size_t)B * 4);
     int32_t* flag_count = (int32_t*)dm_ws_take(ctx, 256);
 
-    DM_CHECK_HIP(ctx, hipMemsetAsync(smax, 0, (size_t)B * 4, ctx->stream));
+    DM_CHECK_HIP(ctx, hipMemsetAsync(p.smax2, 0, (size_t)B * 4, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
-    DM_LAUNCH(ctx, "rownorm_f16", rownorm_f16_kernel, dim3(dm_cdiv(N2, 4), B), dim3(256), 0, (const _Float16*)Ftgt, N2, D,
-              tnorm, 0);
-    DM_LAUNCH(ctx, "rownorm_f16", rownorm_f16_kernel, dim3(dm_cdiv(N1, 4), B), dim3(256), 0, (const _Float16*)Fsrc, N1, D,
-              smax, 1);
     DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_kernel, dim3(p.total), dim3(256), 0, p);
     // twice the fp32 accumulation bound: D exact products, D (1 + 1/16) additions, unit roundoff 2^-23
     // (safe for round-to-nearest and for truncating adders), 1 % slack for the fp32 norms
     const float tau_scale = 2.0f * 1.01f * (float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f;
     DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb, p.pj, p.ps, p.tilesS, N2,
-              p.N2pad, tnorm, smax, tau_scale, nn21, best, margin, flag_count, flag_list);
+              p.N2pad, p.tnorm2, p.smax2, tau_scale, nn21, best, margin, flag_count, flag_list, flag_thr);
     const size_t lds = (size_t)D * 8 + 64;
     static size_t lds_set = 0;
     if (lds > 65536 && lds > lds_set) {
@@ -299,7 +325,7 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
                                               (int)lds));
         lds_set = lds;
     }
-    DM_LAUNCH(ctx, "simnn_fixup_f64", simnn_fixup_kernel, dim3(1024), dim3(256), lds, (const _Float16*)Ftgt,
-              (const _Float16*)Fsrc, N2, N1, D, flag_count, flag_list, nn21);
+    DM_LAUNCH(ctx, "simnn_fixup_f64", simnn_fixup_kernel, dim3(2048), dim3(256), lds, (const _Float16*)Ftgt,
+              (const _Float16*)Fsrc, N2, N1, D, p.pb, p.tilesS, p.N2pad, flag_count, flag_list, flag_thr, nn21);
     return DM_OK;
 }

@@ -205,3 +205,20 @@ def test_errors(eng):
     A = np.zeros((1, 6, 16), np.float32)
     with pytest.raises(DenseMatchError):
         eng.fmap_solve(A, A, np.arange(6.0)[None], np.arange(6.0)[None], np.ones(1), 1.0, 0.0)
+
+
+@pytest.mark.parametrize("k1,k2,D", [(2, 3, 16), (17, 17, 40), (50, 40, 96), (128, 128, 256), (177, 60, 200), (178, 20, 256), (200, 24, 256)])
+def test_solver_shapes(eng, k1, k2, D):
+    """blocked-MFMA Cholesky (n <= 176) and the packed fallback (n <= 199), square and rectangular maps"""
+    rng = np.random.default_rng(k1 * 7 + k2)
+    Bn = 2
+    A = rng.standard_normal((Bn, k1, D)).astype(np.float32) * 0.1
+    Bm = rng.standard_normal((Bn, k2, D)).astype(np.float32) * 0.1
+    lam1 = np.sort(rng.uniform(0, 50, (Bn, k1)), axis=1); lam1[:, 0] = 0
+    lam2 = np.sort(rng.uniform(0, 60, (Bn, k2)), axis=1); lam2[:, 0] = 0
+    c00 = np.array([1.0, -0.9])
+    C = _np(eng.fmap_solve(A, Bm, lam1, lam2, c00, 1e4, 1e3))
+    for b in range(Bn):
+        x0 = np.zeros((k2, k1)); x0[0, 0] = c00[b]
+        Co = orc.fmap_solve(A[b], Bm[b], lam1[b], lam2[b], x0, 1e4, 1e3)
+        assert np.abs(C[b] - Co).max() <= 1e-9 * max(1.0, np.abs(Co).max()), np.abs(C[b] - Co).max()
