@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdensematch.so")
 
 DM_OK, DM_EINVAL, DM_ENOMEM, DM_EHIP, DM_ESINGULAR = 0, -1, -2, -3, -4
-DM_F16, DM_F32 = 0, 1
+DM_F16, DM_F32, DM_PROJECT_F64 = 0, 1, 0x10
 
 _p = C.c_void_p
 _i = C.c_int

@@ -43,8 +43,11 @@ extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* 
     DM_REQUIRE(ctx, B > 0 && N > 0 && D > 0 && k > 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi && mass && F && Ared, "null pointer");
     DM_REQUIRE(ctx, ld >= k, "eigenvector row stride smaller than k");
-    DM_REQUIRE(ctx, f_dtype == DM_F16 || f_dtype == DM_F32, "f_dtype must be DM_F16 or DM_F32");
+    const int want_f64 = f_dtype & DM_PROJECT_F64;
+    f_dtype &= ~DM_PROJECT_F64;
+    DM_REQUIRE(ctx, f_dtype == DM_F16 || f_dtype == DM_F32, "f_dtype must be DM_F16 or DM_F32 (| DM_PROJECT_F64)");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (f_dtype == DM_F16 && !want_f64) return dm_project_f16split(ctx, B, N, D, k, Phi, ld, mass, F, Ared);
     const int tiles = dm_cdiv(k, TN_T) * dm_cdiv(D, TN_T);
     const int nsplit = pick_split(tiles * B, N, TN_BK);
     const int kchunk = dm_cdiv(dm_cdiv(N, nsplit), TN_BK) * TN_BK;
@@ -128,8 +131,16 @@ struct KRowsStackedF32 {
 };
 struct OutScaled {
     double* p; long long stride_b; int ld; double scale;
+    // optional second copy of P[1:,1:] in the blocked solver's LDS layout: 16x16 blocks of the lower block
+    // triangle, block (I,K) at (I(I+1)/2 + K) * 256, element [c & 15][r & 15] = P[r+1][c+1]  (see fmap_solve_blocked_kernel)
+    double* img; long long img_stride_b; int k1;
     __device__ __forceinline__ void store(int b, int i, int j, double v) const {
-        p[b * stride_b + (long long)i * ld + j] = scale * v;
+        const double x = scale * v;
+        p[b * stride_b + (long long)i * ld + j] = x;
+        if (img && i >= 1 && j >= 1 && i < k1) {
+            const int r = i - 1, c = j - 1, I = r >> 4, K = c >> 4;
+            if (I >= K) img[b * img_stride_b + (I * (I + 1) / 2 + K) * 256 + (c & 15) * 16 + (r & 15)] = x;
+        }
     }
 };
 
@@ -231,6 +242,64 @@ __global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restric
     for (int c = t; c < n; c += 256) Crow[c + 1] = y[c];
 }
 
+#ifdef DM_SOLVE_TIMING
+// phase cycle counters of workgroup (0,0), thread 0 (experiment builds only: tools/solve_timing.py)
+__device__ long long g_solve_dbg[16];
+extern "C" int dm_debug_solve_timing(long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solve_dbg), sizeof(long long) * 16) == hipSuccess ? 0 : -3;
+}
+#define DBG_T0() long long _t0 = clock64(); const bool _dbg = (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0);
+#define DBG_ACC(slot) { const long long _t1 = clock64(); if (_dbg) g_solve_dbg[slot] += _t1 - _t0; _t0 = _t1; }
+#else
+#define DBG_T0()
+#define DBG_ACC(slot)
+#endif
+
+// ---- register-resident factorisation of one 16x16 diagonal block (one wave) ------------------------------
+// Lane (r = lane & 15, g = lane >> 4) holds columns 4g..4g+3 of row r of the symmetric block S and of the identity
+// block E.  Step J eliminates column J in square-root-free form (S' = S - v v^T / piv: only a reciprocal sits on
+// the dependency chain), applied to E as row operations; scaling column J by piv^-1/2 turns E into L^-T (= W^T).
+// Row J reaches the lanes through DPP row_newbcast, column J through one ds_bpermute per operand.
+template <int J>
+__device__ __forceinline__ double dpp_row_bcast(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + J, 0xf, 0xf, false);   // v_mov_b32_dpp row_newbcast:J
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), srclane);
+    return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ void diag_step(double (&s)[4], double (&w)[4], int lane, bool& ok) {
+    constexpr int gj = J >> 2, ej = J & 3;
+    const double piv = readlane_f64(s[ej], J | (gj << 4));                  // S[J][J], wave uniform
+    ok = ok && (piv > 0.0);
+    double rp = __builtin_amdgcn_rcp(piv);                                   // 1 / piv   (seed + 2 Newton steps)
+    rp = fma(fma(-piv, rp, 1.0), rp, rp);
+    rp = fma(fma(-piv, rp, 1.0), rp, rp);
+    double inv = __builtin_amdgcn_rsq(piv);                                  // piv^-1/2  (off the critical chain)
+    const double hp = 0.5 * piv;
+    inv = inv * (1.5 - hp * inv * inv);
+    inv = inv * (1.5 - hp * inv * inv);
+    const int src = (lane & 15) | (gj << 4);
+    const double v = __shfl(s[ej], src);                                     // S[r][J]
+    const double z = __shfl(w[ej], src);                                     // E[r][J]
+    const double vr = -v * rp, zr = -z * rp;
+    // No column mask: for finished columns c < J the broadcast row entry S[J][c] is a rounding-level residue of
+    // its own elimination (S[r][c] (1 - piv rp)), so touching them perturbs the result by O(1e-16) only; column J
+    // itself is overwritten below.
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double t = dpp_row_bcast<J>(s[e]);                             // S[J][4g+e]
+        s[e] = fma(vr, t, s[e]);
+        w[e] = fma(zr, t, w[e]);
+    }
+    if ((lane >> 4) == gj) w[ej] = z * inv;                                  // column J of E is final: E[r][J] piv^-1/2
+}
+
 // =================================================================================================
 // Blocked variant (n <= 176): the matrix lives in LDS as 16x16 blocks, lower block triangle, each
 // block stored TRANSPOSED (T_IK[k][i] = A[I*16+i][K*16+k]) so that every f64-MFMA operand and
@@ -241,7 +310,8 @@ __global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restric
 // the right-hand side is carried along (forward solve), then L^T x = y runs block-backwards with
 // the stored W_J.  Padding rows/columns (n..16*NB) are identity.
 // =================================================================================================
-__global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* __restrict__ PQ, const double* __restrict__ lam1,
+__global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* __restrict__ PQ, const double* __restrict__ Timg,
+                                                                 const double* __restrict__ lam1,
                                                                  const double* __restrict__ lam2, const double* __restrict__ c00,
                                                                  double w_lap, int k1, int k2, int NB, double* __restrict__ C,
                                                                  int32_t* __restrict__ info) {
@@ -261,6 +331,7 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
     const double* l1 = lam1 + (long long)b * k1;
     const double* l2 = lam2 + (long long)b * k2;
 
+    DBG_T0()
     double mx = -DM_INF_F64;
     for (int q = t; q < k1; q += 256) mx = fmax(mx, l1[q]);
     for (int q = t; q < k2; q += 256) mx = fmax(mx, l2[q]);
@@ -276,77 +347,92 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
     const double scale = red[4];
     const double ci0 = (i == 0) ? c00[b] : 0.0;
     const double l2i = l2[i] / scale;
+    DBG_ACC(5)
+    // diagonal penalty w_lap ev[i][c+1], staged in LDS (LT is otherwise unused) so the block loop below has no
+    // dependent global loads
+    for (int c = t; c < n; c += 256) {
+        const double d = l1[c + 1] / scale - l2i;
+        LT[c] = w_lap * (d * d);
+    }
+    __syncthreads();
+    DBG_ACC(6)
 
-    // ---- load: T_IK[kk][ii] = M[I*16+ii][K*16+kk]; M symmetric, read P row (K*16+kk+1) so lanes (ii) are contiguous
+    // ---- load: the gram kernel left P[1:,1:] in exactly the LDS image layout (T_IK[kk][ii] = M[I*16+ii][K*16+kk]),
+    // so the copy is a contiguous, fully coalesced 16-byte stream; then the row's diagonal penalty is added and the
+    // padding rows/columns (>= n) are made identity.
     {
-        const int kk = t >> 4, ii = t & 15;
-        for (int I = 0; I < NB; ++I)
-            for (int K = 0; K <= I; ++K) {
-                const int r = I * 16 + ii, c = K * 16 + kk;
-                double v;
-                if (r < n && c < n) {
-                    v = P[(long long)(c + 1) * k1 + (r + 1)];
-                    if (r == c) {
-                        const double d = l1[c + 1] / scale - l2i;
-                        v += w_lap * (d * d);
-                    }
-                } else {
-                    v = (r == c) ? 1.0 : 0.0;
-                }
-                T[(I * (I + 1) / 2 + K) * 256 + kk * 16 + ii] = v;
+        const f64x2* src = reinterpret_cast<const f64x2*>(Timg + (long long)b * nblk * 256);
+        f64x2* dst = reinterpret_cast<f64x2*>(T);
+        const int nvec = nblk * 128;
+        for (int q0 = 0; q0 < nvec; q0 += 256 * 8) {
+            f64x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * 256 + t;
+                v[u] = (q < nvec) ? src[q] : f64x2{0.0, 0.0};
             }
+            DBG_ACC(8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * 256 + t;
+                if (q < nvec) dst[q] = v[u];
+            }
+        }
         for (int c = t; c < NB * 16; c += 256)
             rhs[c] = (c < n) ? Q[(long long)i * k1 + (c + 1)] - P[(long long)(c + 1) * k1] * ci0 : 0.0;
     }
     __syncthreads();
+    for (int c = t; c < NB * 16; c += 256) {
+        const int I = c >> 4;
+        double* dg = T + (I * (I + 1) / 2 + I) * 256 + (c & 15) * 17;
+        if (c < n) *dg += LT[c]; else *dg = 1.0;
+    }
+    __syncthreads();
+    // (u -> row, column) of a lower-triangular block enumeration, used by the trailing update; LT is free again
+    int* tri_rc = reinterpret_cast<int*>(LT);
+    for (int u = t; u < 128; u += 256) {
+        int a_ = 0;
+        while ((a_ + 1) * (a_ + 2) / 2 <= u) ++a_;
+        tri_rc[u] = (a_ << 8) | (u - a_ * (a_ + 1) / 2);
+    }
+    __syncthreads();
+    DBG_ACC(0)
 
     for (int J = 0; J < NB; ++J) {
         double* S = T + (J * (J + 1) / 2 + J) * 256;
-        // ---- (a) diagonal block, wave 0 only.  Right-looking elimination of the 16x16 block S (kept as a full
-        // symmetric square so that every access is row-contiguous) carried out simultaneously on 16 identity rows and
-        // on the right-hand-side row: they end as L^-T (= W^T, exactly the layout the MFMA panel step wants) and as
-        // y_J = L^-1 rhs_J.  One wave: LDS operations retire in program order, no barrier inside.
+        // ---- (a) diagonal block, wave 0 only, in registers (see diag_step)
         if (wave == 0) {
-            const int c = lane & 15, rq = lane >> 4;
+            const int r = lane & 15, g = lane >> 4;
+            double ds[4], dw[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Ws[(rq + 4 * e) * 16 + c] = (rq + 4 * e == c) ? 1.0 : 0.0;
-            if (rq == 0) xv[J * 16 + c] = rhs[J * 16 + c];
-            asm volatile("" ::: "memory");
-            bool ok = true;
-            for (int j = 0; j < 16; ++j) {
-                const double piv = S[j * 16 + j];
-                ok = ok && (piv > 0.0);
-                // 1/sqrt(piv): hardware seed + two Newton steps (full double precision for normal inputs)
-                double inv = __builtin_amdgcn_rsq(piv);
-                const double hp = 0.5 * piv;
-                inv = inv * (1.5 - hp * inv * inv);
-                inv = inv * (1.5 - hp * inv * inv);
-                const double lc = S[j * 16 + c] * inv;                 // L[c][j] for c > j
-                double lr[4], er[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lr[e] = S[j * 16 + rq + 4 * e] * inv;              // L[rq+4e][j]
-                    er[e] = Ws[(rq + 4 * e) * 16 + j] * inv;           // scaled column j of the identity rows
-                }
-                const double yr = xv[J * 16 + j] * inv;                // scaled entry j of the rhs row
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int rr = rq + 4 * e;
-                    if (rr > j && c > j) S[rr * 16 + c] -= lr[e] * lc;
-                    if (c > j) Ws[rr * 16 + c] -= er[e] * lc;
-                    else if (c == j) Ws[rr * 16 + c] = er[e];
-                }
-                if (rq == 0) {
-                    if (c > j) xv[J * 16 + c] -= yr * lc;
-                    else if (c == j) xv[J * 16 + c] = yr;
-                }
-                asm volatile("" ::: "memory");
+            for (int e = 0; e < 4; ++e) {
+                ds[e] = S[r * 16 + 4 * g + e];
+                dw[e] = (r == 4 * g + e) ? 1.0 : 0.0;
             }
+            bool ok = true;
+            diag_step<0>(ds, dw, lane, ok);   diag_step<1>(ds, dw, lane, ok);
+            diag_step<2>(ds, dw, lane, ok);   diag_step<3>(ds, dw, lane, ok);
+            diag_step<4>(ds, dw, lane, ok);   diag_step<5>(ds, dw, lane, ok);
+            diag_step<6>(ds, dw, lane, ok);   diag_step<7>(ds, dw, lane, ok);
+            diag_step<8>(ds, dw, lane, ok);   diag_step<9>(ds, dw, lane, ok);
+            diag_step<10>(ds, dw, lane, ok);  diag_step<11>(ds, dw, lane, ok);
+            diag_step<12>(ds, dw, lane, ok);  diag_step<13>(ds, dw, lane, ok);
+            diag_step<14>(ds, dw, lane, ok);  diag_step<15>(ds, dw, lane, ok);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ws[r * 16 + 4 * g + e] = dw[e];      // Ws[m][k] = W[k][m]
             if (!ok && lane == 0) red[5] = 1.0;
         }
         __syncthreads();
+        DBG_ACC(1)
         if (red[5] != 0.0) break;
-        if (t < 16) rhs[J * 16 + t] = xv[J * 16 + t];
+        // forward solve of this block of the right-hand side, y_J = W rhs_J (16 lanes of the last wave, beside the panel)
+        if (t >= 240) {
+            const int k = t - 240;
+            double y = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) y = fma(Ws[m * 16 + k], rhs[J * 16 + m], y);    // W[k][m]
+            xv[J * 16 + k] = y;              // parked in xv: the other lanes still read rhs_J
+        }
         // ---- (b) panel: T_IJ <- W T_IJ for I > J, one block per wave at a time
         for (int I = J + 1 + wave; I < NB; I += 4) {
             double* Tij = T + (I * (I + 1) / 2 + J) * 256;
@@ -363,29 +449,48 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
             for (int r = 0; r < 4; ++r) Tij[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
         }
         __syncthreads();
+        DBG_ACC(2)
+        if (t < 16) rhs[J * 16 + t] = xv[J * 16 + t];
         // ---- (c) trailing update, right-hand-side update, and W_J parked in the (now free) diagonal slot
         {
             const int m = NB - 1 - J;                 // remaining block rows
             const int nupd = m * (m + 1) / 2;
-            for (int u = wave; u < nupd; u += 4) {
-                // u -> (I, K) with J < K <= I < NB, row-major over the lower triangle
-                int a_ = 0;
-                while ((a_ + 1) * (a_ + 2) / 2 <= u) ++a_;
-                const int I = J + 1 + a_, K = J + 1 + (u - a_ * (a_ + 1) / 2);
-                double* Tik = T + (I * (I + 1) / 2 + K) * 256;
-                const double* Tij = T + (I * (I + 1) / 2 + J) * 256;
-                const double* Tkj = T + (K * (K + 1) / 2 + J) * 256;
-                f64x4 acc;
+            // four independent blocks per wave per pass: their LDS reads and MFMA chains overlap
+            for (int u0 = wave * 4; u0 < nupd; u0 += 16) {
+                f64x4 acc[4];
+                int off_ik[4], off_ij[4], off_kj[4];
+                const int o0 = (lane >> 4) * 16 + (lane & 15);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = Tik[((lane >> 4) + 4 * r) * 16 + (lane & 15)];
+                for (int q = 0; q < 4; ++q) {
+                    const int u = min(u0 + q, nupd - 1);
+                    const int rc = tri_rc[u];
+                    const int I = J + 1 + (rc >> 8), K = J + 1 + (rc & 255);             // J < K <= I < NB
+                    off_ik[q] = (I * (I + 1) / 2 + K) * 256 + o0;
+                    off_ij[q] = (I * (I + 1) / 2 + J) * 256 + o0;
+                    off_kj[q] = (K * (K + 1) / 2 + J) * 256 + o0;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int o = ((lane >> 4) + 4 * ks) * 16 + (lane & 15);
-                    acc = mfma_f64_16x16x4(-Tkj[o], Tij[o], acc);
+                    for (int r = 0; r < 4; ++r) acc[q][r] = T[off_ik[q] + r * 64];
                 }
+                double opa[4][4], opb[4][4];       // all LDS operand reads first: their latency overlaps the MFMA chains
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Tik[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        opa[q][ks] = -T[off_kj[q] + ks * 64];
+                        opb[q][ks] = T[off_ij[q] + ks * 64];
+                    }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = mfma_f64_16x16x4(opa[q][ks], opb[q][ks], acc[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (u0 + q < nupd) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T[off_ik[q] + r * 64] = acc[q][r];
+                    }
             }
+            DBG_ACC(7)
             // rhs_I -= L_IJ y_J   (row ii of block I: sum_k T_IJ[k][ii] y_J[k])
             if (t < m * 16) {
                 const int I = J + 1 + (t >> 4), ii = t & 15;
@@ -398,6 +503,7 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
             S[t] = Ws[t];
         }
         __syncthreads();
+        DBG_ACC(3)
     }
     __syncthreads();
     double* Crow = C + ((long long)b * k2 + i) * k1;
@@ -407,33 +513,37 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
         return;
     }
     // ---- back substitution  L^T x = y :  x_J = W_J^T (y_J - sum_{I>J} L_IJ^T x_I)
+    // one thread per output entry, serial 16-term dot products (no cross-lane reduction chains)
     for (int J = NB - 1; J >= 0; --J) {
         const double* Wt = T + (J * (J + 1) / 2 + J) * 256;     // Wt[m*16 + k] = W[k][m]
-        {
+        if (t < 16) {
             // x_J[k] = sum_m W[m][k] y[m] = sum_m Wt[k*16 + m] y[m]
-            const int k = t >> 4, m = t & 15;
-            double pr = Wt[k * 16 + m] * rhs[J * 16 + m];
+            double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) pr += __shfl_xor(pr, off);
-            if (m == 0) xv[J * 16 + k] = pr;
+            for (int m = 0; m < 16; m += 2) {
+                a0 = fma(Wt[t * 16 + m], rhs[J * 16 + m], a0);
+                a1 = fma(Wt[t * 16 + m + 1], rhs[J * 16 + m + 1], a1);
+            }
+            xv[J * 16 + t] = a0 + a1;
         }
         __syncthreads();
         // y_K -= L_JK^T x_J for K < J:  (L_JK^T x)[k] = sum_i T_JK[k*16 + i] x_J[i]
-        for (int K = wave; K < J; K += 4) {
+        if (t < J * 16) {
+            const int K = t >> 4, k = t & 15;
             const double* Tjk = T + (J * (J + 1) / 2 + K) * 256;
+            double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = (lane >> 4) + 4 * e, ii = lane & 15;
-                double pr = Tjk[k * 16 + ii] * xv[J * 16 + ii];
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) pr += __shfl_xor(pr, off);
-                if (ii == 0) rhs[K * 16 + k] -= pr;
+            for (int ii = 0; ii < 16; ii += 2) {
+                a0 = fma(Tjk[k * 16 + ii], xv[J * 16 + ii], a0);
+                a1 = fma(Tjk[k * 16 + ii + 1], xv[J * 16 + ii + 1], a1);
             }
+            rhs[K * 16 + k] -= a0 + a1;
         }
         __syncthreads();
     }
     if (t == 0) Crow[0] = ci0;
     for (int c = t; c < n; c += 256) Crow[c + 1] = xv[c];
+    DBG_ACC(4)
 }
 
 extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const float* A, const float* Bm,
@@ -446,21 +556,25 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     DM_REQUIRE(ctx, w_descr >= 0.0 && w_lap >= 0.0 && (w_descr > 0.0 || w_lap > 0.0), "weights must be >= 0 and not both 0");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t pq_bytes = (size_t)B * (k1 + k2) * k1 * 8;
-    int rc = dm_ws_reserve(ctx, pq_bytes);
+    const int n = k1 - 1;
+    const int NB = (n + 15) / 16;
+    const bool blocked = (n >= 1 && NB <= 11);
+    const size_t img_bytes = blocked ? (size_t)B * (NB * (NB + 1) / 2) * 256 * 8 : 0;
+    int rc = dm_ws_reserve(ctx, dm_align_up(pq_bytes) + img_bytes);
     if (rc) return rc;
     double* PQ = (double*)dm_ws_take(ctx, pq_bytes);
+    double* Timg = blocked ? (double*)dm_ws_take(ctx, img_bytes) : nullptr;
+    if (blocked) DM_CHECK_HIP(ctx, hipMemsetAsync(Timg, 0, img_bytes, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
 
     KRowsStackedF32 opa{A, Bm, k1, k2, D};
     KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
-    OutScaled out{PQ, (long long)(k1 + k2) * k1, k1, w_descr};
+    OutScaled out{PQ, (long long)(k1 + k2) * k1, k1, w_descr, Timg, (long long)(NB * (NB + 1) / 2) * 256, k1};
     dim3 grid(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
     DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutScaled>), grid, dim3(256), 0, opa, opb, out,
               k1 + k2, k1, D);
 
-    const int n = k1 - 1;
-    const int NB = (n + 15) / 16;
-    if (n >= 1 && NB <= 11) {
+    if (blocked) {
         // blocked MFMA solver: NB(NB+1)/2 + 2 blocks of 2 KiB, vectors
         const size_t lds = ((size_t)(NB * (NB + 1) / 2 + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);
         static size_t lds_set_b = 0;
@@ -469,8 +583,8 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set_b = lds;
         }
-        DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_blocked_kernel, dim3(k2, B), dim3(256), lds, PQ, lam1, lam2, c00, w_lap,
-                  k1, k2, NB, C, info);
+        DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_blocked_kernel, dim3(k2, B), dim3(256), lds, PQ, Timg, lam1, lam2, c00,
+                  w_lap, k1, k2, NB, C, info);
         return DM_OK;
     }
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 4 ? 4 : n + 1) + 2) * sizeof(double);

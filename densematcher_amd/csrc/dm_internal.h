@@ -108,3 +108,7 @@ int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, cons
                         const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass2,
                         double* C, int ldc, long long strideC);
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2);
+
+// fp16 split-operand MFMA projection (dm_project.hip); F must be fp16
+int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass,
+                        const void* F, float* Ared);

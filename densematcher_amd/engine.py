@@ -89,8 +89,9 @@ class MatchEngine:
         self._chk(self.lib.dm_simnn_f16(self.ctx, B, N2, N1, D, _ptr(Ftgt), _ptr(Fsrc), _ptr(nn), _ptr(best), _ptr(margin)))
         return (nn, best, margin) if return_scores else nn
 
-    def project(self, Phi, mass, F, k=None, out=None):
-        """Phi[:, :k]^T (mass * F)  ->  (B,k,D) f32."""
+    def project(self, Phi, mass, F, k=None, out=None, exact=False):
+        """Phi[:, :k]^T (mass * F)  ->  (B,k,D) f32.  fp16 descriptors use the fp16 matrix cores (split basis,
+        relative error ~1e-6); exact=True or fp32 descriptors use the float64 matrix cores."""
         Phi = self._dev(Phi, torch.float32, "Phi")
         mass = self._dev(mass, torch.float32, "mass")
         if not isinstance(F, torch.Tensor):
@@ -105,7 +106,8 @@ class MatchEngine:
         if out is None:
             out = torch.empty((B, k, D), dtype=torch.float32, device=self.device)
         self._chk(self.lib.dm_project(self.ctx, B, N, D, k, _ptr(Phi), ld, _ptr(mass), _ptr(F),
-                                      _lib.DM_F16 if fdt == torch.float16 else _lib.DM_F32, _ptr(out)))
+                                      (_lib.DM_F16 if fdt == torch.float16 else _lib.DM_F32) |
+                                      (_lib.DM_PROJECT_F64 if exact else 0), _ptr(out)))
         return out
 
     def c00(self, Phi1, Phi2, a1, a2):

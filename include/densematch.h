@@ -46,8 +46,8 @@ typedef enum dm_status {
     DM_ESINGULAR = -4   /* a linear system was not positive definite (info[] says which pair) */
 } dm_status;
 
-/* feature dtypes for dm_project */
-enum { DM_F16 = 0, DM_F32 = 1 };
+/* feature dtypes for dm_project; OR in DM_PROJECT_F64 to force the float64 matrix-core path */
+enum { DM_F16 = 0, DM_F32 = 1, DM_PROJECT_F64 = 0x10 };
 
 /* ---- context ---------------------------------------------------------- */
 /* One context per (device, stream).  hip_stream may be NULL (default stream). */
@@ -83,7 +83,10 @@ int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D,
  * Ared[b] = Phi[b][:, :k]^T (mass[b] * F[b])        (k x D), fp32 out.
  * Replaces pyFM/optimize/base_functions.py:526-532 (descr{1,2}_red) and
  * pyFM/mesh/trimesh.py:533-556 (TriMesh.project).
- * Phi (B,N,ld) fp32, mass (B,N) fp32, F (B,N,D) fp16 or fp32 (f_dtype). */
+ * Phi (B,N,ld) fp32, mass (B,N) fp32, F (B,N,D) fp16 or fp32 (f_dtype).
+ * fp16 descriptors run on the fp16 matrix cores with the basis split into two fp16 pieces (relative error
+ * ~1e-6, the class of the reference's own fp32 projection); fp32 descriptors, or f_dtype | DM_PROJECT_F64,
+ * run on the float64 matrix cores (error = the final fp32 rounding only). */
 int dm_project(dm_ctx* ctx, int B, int N, int D, int k,
                const float* Phi, int ld, const float* mass,
                const void* F, int f_dtype, float* Ared /* B*k*D */);

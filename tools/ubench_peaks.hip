@@ -62,6 +62,12 @@ int main() {
         CK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) printf("mfma_f16_32x32x16 : %.1f TFLOP/s\n", (double)G * 4 * ITER * 4 * 32768.0 / (ms * 1e-3) / 1e12);
     }
+    // one wave per SIMD (256 blocks x 256 threads), 4 independent accumulator chains: what a latency-bound kernel sees
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_f64<ITER>, dim3(256), dim3(256), 0, 0, (double*)buf); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("mfma_f64_16x16x4, 1 wave/SIMD x 4 chains: %.1f TFLOP/s  (%.1f cycles/MFMA at 2.4 GHz)\n", 256.0 * 4 * ITER * 4 * 2048.0 / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (ITER * 4.0));
+    }
     size_t nbytes = (size_t)2 << 30; void *a, *b; CK(hipMalloc(&a, nbytes)); CK(hipMalloc(&b, nbytes));
     CK(hipMemset(a, 1, nbytes));
     for (int rep = 0; rep < 3; ++rep) {
