@@ -40,3 +40,18 @@ __device__ __forceinline__ void argmax_merge(double& v, int& j, double ov, int o
 __device__ __forceinline__ void argmin_merge(double& v, int& j, double ov, int oj) {
     if (ov < v || (ov == v && oj < j)) { v = ov; j = oj; }
 }
+
+// DPP exchanges inside a 16-lane row: 0xB1 = quad_perm [1,0,3,2], 0x4E = quad_perm [2,3,0,1],
+// 0x141 = row_half_mirror, 0x140 = row_mirror.  Applied in this order with max/min they leave the
+// reduction over the 16 lanes in every lane (VALU speed, no LDS round trip).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int x) {
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
+}

@@ -12,6 +12,8 @@
 //   ind21[i] = argmax_j  G_ij a1_j                                   convert.py:144, functional_map.py:49
 //   ind12[j] = argmax_i  G_ij a1_j                                   convert.py:144, functional_map.py:50
 // lowest index on ties (NumPy argmax/argmin).
+#include <stdlib.h>
+
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
 
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld, const double* Cm, int ldc,
                     long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first) {
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
-    if (zero_first)
+    if (zero_first && (kr != krpad || N != Npad))
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
     KRowsF64 opa{Cm, strideC, ldc, kr, km, transC};
     KRowsF32 opb{Phi, (long long)N * ld, ld, N, km};
@@ -100,9 +102,169 @@ struct gred_params {
     double* rv_knn; int32_t* rj_knn; double* rv_ind; int32_t* rj_ind;   // (B, tilesN, N2pad)
     double* cv_knn; int32_t* ci_knn; double* cv_ind; int32_t* ci_ind;   // (B, tilesM, N1pad)
     int N2, N1, N2pad, N1pad, Kpad, Kloop, tilesM, tilesN, total;
-    int want_rows_knn, want_rows_ind, want_cols_knn, want_cols_ind;
+    int stagger;  // number of s_sleep(127) the odd-slot workgroups of the first round wait (0 = off)
+    int dbg;      // experiments only (env DM_GRED_DEBUG): 1 = skip the reduction epilogue, 2 = skip the MFMA main loop
 };
 
+// Reductions over the wave's 64x64 sub-tile, acc[mt][nt][r] = G[row = i0 + wm*64 + mt*16 + (lane>>4) + 4r]
+// [col = j0 + wn*64 + nt*16 + (lane&15)].  MASK = the tile crosses the matrix boundary (padded rows / columns must
+// not win); interior tiles take the mask-free instantiation.  ALL = all four reductions (dm_fm_to_p2p; n1, n2 and
+// mass1 are then always valid pointers), otherwise only the row arg-min knn21 (ZoomOut).  No run-time flags inside:
+// the whole epilogue is one basic block per instantiation.
+//  rows:    two passes per row slot: (A) extreme VALUE only (one v_max/v_min per element, DPP butterflies across
+//           the 16 lanes of a row), (B) lowest column whose value equals that extreme (32-bit min): the NumPy
+//           first-index rule without carrying (value, index) pairs through the butterfly.
+//  columns: (value, row) pairs tracked in-lane while sweeping the rows in ascending order, merged across the four
+//           16-lane groups at the end.
+template <bool MASK, bool ALL>
+__device__ __forceinline__ void gred_epilogue(const gred_params& p, const f64x4 (&acc)[4][4], double* sv, int* sj, int b,
+                                              int i0, int j0, int lane, int wm, int wn) {
+    const int cl = lane & 15, rg = lane >> 4;
+    // ---- sweep 1: row reductions -------------------------------------------------------------------------
+    {
+        double a1[4], n1c[4];
+        int gcol[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int gj = j0 + wn * 64 + nt * 16 + cl;
+            const bool cv = !MASK || gj < p.N1;
+            gcol[nt] = cv ? gj : DM_IDX_NONE;
+            a1[nt] = (ALL && cv) ? (double)p.mass1[(long long)b * p.N1 + gj] : 0.0;
+            n1c[nt] = p.n1[(long long)b * p.N1pad + gj];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int lrow = wm * 64 + mt * 16 + rg + 4 * r;
+                double vi[4], vk[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const double g = acc[mt][nt][r];
+                    vi[nt] = g * a1[nt];                           // (Phi2 C Phi1^T) @ A1, convert.py:144
+                    vk[nt] = n1c[nt] - 2.0 * g;                    // |x|^2 - 2 <x,y>
+                    if (MASK) {
+                        const bool cv = gcol[nt] != DM_IDX_NONE;
+                        vi[nt] = cv ? vi[nt] : -DM_INF_F64;
+                        vk[nt] = cv ? vk[nt] : DM_INF_F64;
+                    }
+                }
+                // pass A: row extremes over the 64 columns held by this wave
+                double mi = 0.0, mk;
+                int ji = DM_IDX_NONE, jk = DM_IDX_NONE;
+                if (ALL) {
+                    mi = fmax(fmax(vi[0], vi[1]), fmax(vi[2], vi[3]));
+                    mi = fmax(mi, dpp_f64<0xB1>(mi)); mi = fmax(mi, dpp_f64<0x4E>(mi));
+                    mi = fmax(mi, dpp_f64<0x141>(mi)); mi = fmax(mi, dpp_f64<0x140>(mi));
+                }
+                mk = fmin(fmin(vk[0], vk[1]), fmin(vk[2], vk[3]));
+                mk = fmin(mk, dpp_f64<0xB1>(mk)); mk = fmin(mk, dpp_f64<0x4E>(mk));
+                mk = fmin(mk, dpp_f64<0x141>(mk)); mk = fmin(mk, dpp_f64<0x140>(mk));
+                // pass B: lowest column that attains the extreme
+#pragma unroll
+                for (int nt = 3; nt >= 0; --nt) {                   // descending: the lowest matching column is kept
+                    if (ALL) ji = (vi[nt] == mi) ? gcol[nt] : ji;
+                    jk = (vk[nt] == mk) ? gcol[nt] : jk;
+                }
+                if (ALL) {
+                    ji = min(ji, dpp_i32<0xB1>(ji)); ji = min(ji, dpp_i32<0x4E>(ji));
+                    ji = min(ji, dpp_i32<0x141>(ji)); ji = min(ji, dpp_i32<0x140>(ji));
+                }
+                jk = min(jk, dpp_i32<0xB1>(jk)); jk = min(jk, dpp_i32<0x4E>(jk));
+                jk = min(jk, dpp_i32<0x141>(jk)); jk = min(jk, dpp_i32<0x140>(jk));
+                if (cl == 0) {
+                    if (ALL) { sv[(0 * 2 + wn) * 128 + lrow] = mi; sj[(0 * 2 + wn) * 128 + lrow] = ji; }
+                    sv[(1 * 2 + wn) * 128 + lrow] = mk; sj[(1 * 2 + wn) * 128 + lrow] = jk;
+                }
+                // one row slot at a time: without this the scheduler interleaves all 16 slots and spills
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (!ALL) return;
+    // ---- sweeps 2a / 2b: column reductions --------------------------------------------------------------------
+    // 2a: extreme VALUE per column over this lane's 16 rows, then across the four 16-lane groups;
+    // 2b: lowest row whose value equals it.  The values are recomputed with the same two operations as before
+    // (bit-identical) instead of being kept alive: the opaque asm statements stop the optimiser from re-using
+    // (and spilling) the 64 products of the previous sweep.
+    {
+        double a1[4], cmax_i[4], cmin_k[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int gj = j0 + wn * 64 + nt * 16 + cl;
+            a1[nt] = (!MASK || gj < p.N1) ? (double)p.mass1[(long long)b * p.N1 + gj] : 0.0;
+            asm volatile("" : "+v"(a1[nt]));
+            cmax_i[nt] = -DM_INF_F64; cmin_k[nt] = DM_INF_F64;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gi = i0 + wm * 64 + mt * 16 + rg + 4 * r;
+                const bool rvalid = !MASK || gi < p.N2;
+                const double n2r = p.n2[(long long)b * p.N2pad + gi];               // padded buffer: always in bounds
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const double g = acc[mt][nt][r];
+                    double vic = g * a1[nt];
+                    double vk2 = n2r - 2.0 * g;
+                    if (MASK) {
+                        vic = rvalid ? vic : -DM_INF_F64;
+                        vk2 = rvalid ? vk2 : DM_INF_F64;
+                    }
+                    cmax_i[nt] = fmax(cmax_i[nt], vic);
+                    cmin_k[nt] = fmin(cmin_k[nt], vk2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                cmax_i[nt] = fmax(cmax_i[nt], __shfl_xor(cmax_i[nt], off));
+                cmin_k[nt] = fmin(cmin_k[nt], __shfl_xor(cmin_k[nt], off));
+            }
+            asm volatile("" : "+v"(a1[nt]));
+        }
+        int ci[4], ck[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { ci[nt] = DM_IDX_NONE; ck[nt] = DM_IDX_NONE; }
+#pragma unroll
+        for (int mt = 3; mt >= 0; --mt) {
+#pragma unroll
+            for (int r = 3; r >= 0; --r) {                      // descending rows: the lowest matching row is kept
+                const int gi = i0 + wm * 64 + mt * 16 + rg + 4 * r;
+                const bool rvalid = !MASK || gi < p.N2;
+                const double n2r = p.n2[(long long)b * p.N2pad + gi];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const double g = acc[mt][nt][r];
+                    const double vic = g * a1[nt];
+                    const double vk2 = n2r - 2.0 * g;
+                    ci[nt] = (rvalid && vic == cmax_i[nt]) ? gi : ci[nt];
+                    ck[nt] = (rvalid && vk2 == cmin_k[nt]) ? gi : ck[nt];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                ci[nt] = min(ci[nt], __shfl_xor(ci[nt], off));
+                ck[nt] = min(ck[nt], __shfl_xor(ck[nt], off));
+            }
+            if (lane < 16) {
+                const int lcol = wn * 64 + nt * 16 + lane;
+                sv[(2 * 2 + wm) * 128 + lcol] = cmax_i[nt]; sj[(2 * 2 + wm) * 128 + lcol] = ci[nt];
+                sv[(3 * 2 + wm) * 128 + lcol] = cmin_k[nt]; sj[(3 * 2 + wm) * 128 + lcol] = ck[nt];
+            }
+        }
+    }
+}
+
+template <bool ALL>
 __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     __shared__ double smem[2 * 2 * GBK * GLD];   // As[2][GBK][GLD] | Bs[2][GBK][GLD]   (73,728 B)
     double* As = smem;
@@ -116,6 +278,16 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     const int i0 = tm * GT, j0 = tn * GT;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+
+    // Two workgroups share a CU.  Started together they stay in lock-step (both in the MFMA main loop, then both in
+    // the VALU epilogue) and the two pipes never overlap.  The second resident workgroup of the first dispatch
+    // round is delayed by about half a tile period once; the phase shift then persists for the whole launch.
+    if (p.stagger && blockIdx.x < 512) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;      // HW_ID.wave_id bit 0
+        if (slot) {
+            for (int q = 0; q < p.stagger; ++q) __builtin_amdgcn_s_sleep(127);
+        }
+    }
 
     const double* AT = p.AT + (long long)b * p.Kpad * p.N2pad + i0;
     const double* BT = p.BT + (long long)b * p.Kpad * p.N1pad + j0;
@@ -143,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
         *reinterpret_cast<f64x2*>(Bs + off) = rb[q];                                               \
     }
 
-    const int ns = p.Kloop / GBK;
+    const int ns = (p.dbg == 2) ? 1 : p.Kloop / GBK;
     GRED_FETCH(0)
     GRED_STASH(0)
     __syncthreads();
@@ -171,127 +343,49 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
 #undef GRED_FETCH
 #undef GRED_STASH
 
+    if (p.dbg == 1) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sacc += acc[a][c][0] + acc[a][c][1] + acc[a][c][2] + acc[a][c][3];
+        if (sacc == 1.2345) p.rv_knn[0] = sacc;
+        return;
+    }
     // ---------------- epilogue: reductions over the 128x128 tile held in registers ----------------
-    // acc[mt][nt][r] = G[row = i0 + wm*64 + mt*16 + (lane>>4) + 4r][col = j0 + wn*64 + nt*16 + (lane&15)]
     // LDS is free now (the loop ended with a barrier): reuse it for the cross-wave merges.
     double* sv = smem;                                            // [4 kinds][2 waves][128]
     int* sj = reinterpret_cast<int*>(smem + 4 * 2 * 128);         // [4 kinds][2 waves][128]
-
-    double a1[4], n1c[4];
-    bool cvalid[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int gj = j0 + wn * 64 + nt * 16 + (lane & 15);
-        cvalid[nt] = gj < p.N1;
-        a1[nt] = (cvalid[nt] && p.mass1) ? (double)p.mass1[(long long)b * p.N1 + gj] : 0.0;
-        n1c[nt] = p.n1 ? p.n1[(long long)b * p.N1pad + gj] : 0.0;
-    }
-
-    // column candidates, accumulated over this lane's 16 rows in ascending row order
-    double cbest_i[4], cbest_k[4];
-    int cidx_i[4], cidx_k[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        cbest_i[nt] = -DM_INF_F64; cbest_k[nt] = DM_INF_F64;
-        cidx_i[nt] = DM_IDX_NONE; cidx_k[nt] = DM_IDX_NONE;
-    }
-
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int lrow = wm * 64 + mt * 16 + (lane >> 4) + 4 * r;
-            const int gi = i0 + lrow;
-            const bool rvalid = gi < p.N2;
-            const double n2r = (p.n2 && rvalid) ? p.n2[(long long)b * p.N2pad + gi] : 0.0;
-            double rb_i = -DM_INF_F64, rb_k = DM_INF_F64;
-            int rj_i = DM_IDX_NONE, rj_k = DM_IDX_NONE;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const double g = acc[mt][nt][r];
-                const int gj = j0 + wn * 64 + nt * 16 + (lane & 15);
-                const double vi = g * a1[nt];                  // (Phi2 C Phi1^T) @ A1, convert.py:144
-                const double vk = n1c[nt] - 2.0 * g;           // |x|^2 - 2 <x,y>
-                const double vk2 = n2r - 2.0 * g;
-                if (cvalid[nt]) {
-                    if (vi > rb_i) { rb_i = vi; rj_i = gj; }    // columns ascend with nt: strict keeps the lowest
-                    if (vk < rb_k) { rb_k = vk; rj_k = gj; }
-                }
-                if (rvalid) {
-                    if (vi > cbest_i[nt]) { cbest_i[nt] = vi; cidx_i[nt] = gi; }   // rows ascend with (mt, r)
-                    if (vk2 < cbest_k[nt]) { cbest_k[nt] = vk2; cidx_k[nt] = gi; }
-                }
-            }
-            // the 16 lanes that share (lane >> 4) hold the other columns of this row
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                if (p.want_rows_ind) {
-                    const double ov = __shfl_xor(rb_i, off);
-                    const int oj = __shfl_xor(rj_i, off);
-                    argmax_merge(rb_i, rj_i, ov, oj);
-                }
-                if (p.want_rows_knn) {
-                    const double ov = __shfl_xor(rb_k, off);
-                    const int oj = __shfl_xor(rj_k, off);
-                    argmin_merge(rb_k, rj_k, ov, oj);
-                }
-            }
-            if ((lane & 15) == 0) {
-                sv[(0 * 2 + wn) * 128 + lrow] = rb_i; sj[(0 * 2 + wn) * 128 + lrow] = rj_i;
-                sv[(1 * 2 + wn) * 128 + lrow] = rb_k; sj[(1 * 2 + wn) * 128 + lrow] = rj_k;
-            }
-        }
-    }
-    // the 4 lane groups (lane >> 4) hold different rows of the same column
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-        for (int off = 16; off < 64; off <<= 1) {
-            if (p.want_cols_ind) {
-                const double ov = __shfl_xor(cbest_i[nt], off);
-                const int oi = __shfl_xor(cidx_i[nt], off);
-                argmax_merge(cbest_i[nt], cidx_i[nt], ov, oi);
-            }
-            if (p.want_cols_knn) {
-                const double ov = __shfl_xor(cbest_k[nt], off);
-                const int oi = __shfl_xor(cidx_k[nt], off);
-                argmin_merge(cbest_k[nt], cidx_k[nt], ov, oi);
-            }
-        }
-        if (lane < 16) {
-            const int lcol = wn * 64 + nt * 16 + lane;
-            sv[(2 * 2 + wm) * 128 + lcol] = cbest_i[nt]; sj[(2 * 2 + wm) * 128 + lcol] = cidx_i[nt];
-            sv[(3 * 2 + wm) * 128 + lcol] = cbest_k[nt]; sj[(3 * 2 + wm) * 128 + lcol] = cidx_k[nt];
-        }
-    }
+    if ((i0 + GT <= p.N2) && (j0 + GT <= p.N1)) gred_epilogue<false, ALL>(p, acc, sv, sj, b, i0, j0, lane, wm, wn);
+    else gred_epilogue<true, ALL>(p, acc, sv, sj, b, i0, j0, lane, wm, wn);
     __syncthreads();
     // merge the two waves that share a row (wn = 0, 1) / a column (wm = 0, 1); lower half first
     if (t < 128) {
         const int gi = i0 + t;
         if (gi < p.N2) {
             const long long o = ((long long)b * p.tilesN + tn) * p.N2pad + gi;
-            if (p.want_rows_ind) {
+            if (ALL) {
                 double v = sv[(0 * 2 + 0) * 128 + t]; int j = sj[(0 * 2 + 0) * 128 + t];
                 argmax_merge(v, j, sv[(0 * 2 + 1) * 128 + t], sj[(0 * 2 + 1) * 128 + t]);
                 p.rv_ind[o] = v; p.rj_ind[o] = j;
             }
-            if (p.want_rows_knn) {
+            {
                 double v = sv[(1 * 2 + 0) * 128 + t]; int j = sj[(1 * 2 + 0) * 128 + t];
                 argmin_merge(v, j, sv[(1 * 2 + 1) * 128 + t], sj[(1 * 2 + 1) * 128 + t]);
                 p.rv_knn[o] = v; p.rj_knn[o] = j;
             }
         }
-    } else {
+    } else if (ALL) {
         const int c = t - 128;
         const int gj = j0 + c;
         if (gj < p.N1) {
             const long long o = ((long long)b * p.tilesM + tm) * p.N1pad + gj;
-            if (p.want_cols_ind) {
+            {
                 double v = sv[(2 * 2 + 0) * 128 + c]; int i = sj[(2 * 2 + 0) * 128 + c];
                 argmax_merge(v, i, sv[(2 * 2 + 1) * 128 + c], sj[(2 * 2 + 1) * 128 + c]);
                 p.cv_ind[o] = v; p.ci_ind[o] = i;
             }
-            if (p.want_cols_knn) {
+            {
                 double v = sv[(3 * 2 + 0) * 128 + c]; int i = sj[(3 * 2 + 0) * 128 + c];
                 argmin_merge(v, i, sv[(3 * 2 + 1) * 128 + c], sj[(3 * 2 + 1) * 128 + c]);
                 p.cv_knn[o] = v; p.ci_knn[o] = i;
@@ -334,10 +428,12 @@ int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a) {
     p.N2 = a.N2; p.N1 = a.N1; p.N2pad = a.N2pad; p.N1pad = a.N1pad; p.Kpad = a.Kpad; p.Kloop = a.Kloop;
     p.tilesM = a.N2pad / GT; p.tilesN = a.N1pad / GT;
     p.total = a.B * p.tilesM * p.tilesN;
-    p.want_rows_knn = a.knn21 != nullptr; p.want_rows_ind = a.ind21 != nullptr;
-    p.want_cols_knn = a.knn12 != nullptr; p.want_cols_ind = a.ind12 != nullptr;
-    if ((p.want_rows_knn && !a.n1) || (p.want_cols_knn && !a.n2) || ((p.want_rows_ind || p.want_cols_ind) && !a.mass1))
-        return dm_fail(ctx, DM_EINVAL, "gred: missing norms / mass for a requested reduction");
+    { const char* e = getenv("DM_GRED_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    { const char* e = getenv("DM_GRED_STAGGER"); p.stagger = e ? atoi(e) : 2; }
+    // two instantiations: all four reductions (needs n1, n2, mass1) or the row arg-min knn21 alone (needs n1)
+    const bool all = a.knn12 || a.ind21 || a.ind12;
+    if (!a.n1 || (all && (!a.n2 || !a.mass1)))
+        return dm_fail(ctx, DM_EINVAL, "gred: missing norms / mass for the requested reductions");
     if (a.N2pad % GT || a.N1pad % GT || a.Kpad % GBK || a.Kloop % GBK || a.Kloop < GBK || a.Kloop > a.Kpad)
         return dm_fail(ctx, DM_EINVAL, "gred: operand padding must be a multiple of the tile (%d) / stage (%d)", GT, GBK);
     const size_t rows = (size_t)a.B * p.tilesN * a.N2pad, cols = (size_t)a.B * p.tilesM * a.N1pad;
@@ -347,7 +443,8 @@ int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a) {
     p.cv_ind = (double*)dm_ws_take(ctx, cols * 8); p.ci_ind = (int32_t*)dm_ws_take(ctx, cols * 4);
     if (!p.rv_knn || !p.rj_knn || !p.rv_ind || !p.rj_ind || !p.cv_knn || !p.ci_knn || !p.cv_ind || !p.ci_ind)
         return dm_fail(ctx, DM_ENOMEM, "gred: workspace not reserved");
-    DM_LAUNCH(ctx, "gred_f64", gred_kernel, dim3(p.total), dim3(256), 0, p);
+    if (all) DM_LAUNCH(ctx, "gred_f64", gred_kernel<true>, dim3(p.total), dim3(256), 0, p);
+    else DM_LAUNCH(ctx, "gred_f64", gred_kernel<false>, dim3(p.total), dim3(256), 0, p);
     if (a.knn21) {
         DM_LAUNCH(ctx, "gred_merge", gred_merge_kernel, dim3(dm_cdiv(a.N2, 256), a.B), dim3(256), 0, p.rv_knn, p.rj_knn,
                   p.tilesN, a.N2, a.N2pad, 0, a.knn21);
@@ -385,10 +482,11 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     const int Kpad = pad_to(k2, GBK);          // contraction of G = Phi2 (k2) . emb1 (k2)
     const int K1pad = pad_to(k1, GBK);
     const size_t bytes_AT = (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;
-    const size_t bytes_E2 = knn12 ? (size_t)B * K1pad * N2pad * 8 : 0;
+    const bool all = knn12 || ind21 || ind12;      // anything beyond knn21 takes the four-reduction kernel
+    const size_t bytes_E2 = all ? (size_t)B * K1pad * N2pad * 8 : 0;
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + dm_align_up(bytes_E2) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2pad * 8) +
-                        dm_gred_ws_bytes(B, N2, N1);
+                        dm_align_up((size_t)B * N1 * 4) + dm_gred_ws_bytes(B, N2, N1);
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bytes_AT);
@@ -403,7 +501,7 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     // BT = emb1^T, emb1 = Phi1[:, :k1] C^T (N1 x k2): emb1T[c][j] = sum_m C[c][m] Phi1[j][m];  n1_j = |emb1_j|^2
     rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, C, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 1);
     if (rc) return rc;
-    if (knn12) {
+    if (all) {
         // emb2 = Phi2[:, :k2] C (N2 x k1): emb2T[m][i] = sum_c C[c][m] Phi2[i][c];  only n2_i = |emb2_i|^2 is used
         rc = dm_launch_embed(ctx, B, N2, k1, k2, Phi2, ld2, C, k1, (long long)k2 * k1, 1, E2, K1pad, N2pad, n2, 1);
         if (rc) return rc;
@@ -411,7 +509,12 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     dm_gred_args a;
     a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = Kpad;
     a.AT = AT; a.N2pad = N2pad; a.BT = BT; a.N1pad = N1pad; a.Kpad = Kpad;
-    a.n1 = n1; a.n2 = knn12 ? n2 : nullptr; a.mass1 = mass1;
+    a.n1 = n1; a.n2 = all ? n2 : nullptr; a.mass1 = mass1;
+    if (all && !mass1) {                      // nearest-neighbour maps only: the indicator values are never read
+        float* ones = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
+        DM_CHECK_HIP(ctx, hipMemsetAsync(ones, 0, (size_t)B * N1 * 4, ctx->stream));
+        a.mass1 = ones;
+    }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
     return dm_launch_gred(ctx, a);
 }

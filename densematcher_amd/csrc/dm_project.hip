@@ -36,16 +36,33 @@ __device__ __forceinline__ f16x8 tr_frag(const _Float16* base, int row0, int col
     return r;
 }
 
-// max |mass[n] * Phi[n][m]| per pair -> power-of-two scale
+// max |mass[n] * Phi[n][m]| per pair -> power-of-two scale.  One 16-lane group per row, float4 per lane when the
+// layout allows it; many workgroups per pair so the 4 MB basis streams at HBM speed.
 __global__ __launch_bounds__(256) void proj_absmax_kernel(const float* __restrict__ Phi, const float* __restrict__ mass, int N,
                                                           int k, int ld, unsigned int* __restrict__ amax) {
     const int b = blockIdx.y;
     const float* P = Phi + (long long)b * N * ld;
     const float* a = mass + (long long)b * N;
+    const int sub = threadIdx.x & 15, rowl = threadIdx.x >> 4;          // 16 rows per pass per workgroup
+    const bool vec = ((ld & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0);
     float m = 0.f;
-    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4) {
+    for (int n = blockIdx.x * 16 + rowl; n < N; n += gridDim.x * 16) {
         const float an = fabsf(a[n]);
-        for (int c = threadIdx.x & 63; c < k; c += 64) m = fmaxf(m, an * fabsf(P[(long long)n * ld + c]));
+        const float* row = P + (long long)n * ld;
+        float rm = 0.f;
+        if (vec) {
+            for (int c = sub * 4; c < k; c += 64) {
+                if (c + 3 < k) {
+                    const float4 v = *reinterpret_cast<const float4*>(row + c);
+                    rm = fmaxf(fmaxf(rm, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
+                } else {
+                    for (int e = c; e < k; ++e) rm = fmaxf(rm, fabsf(row[e]));
+                }
+            }
+        } else {
+            for (int c = sub; c < k; c += 16) rm = fmaxf(rm, fabsf(row[c]));
+        }
+        m = fmaxf(m, an * rm);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -212,7 +229,7 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Ph
     unsigned int* amax = (unsigned int*)dm_ws_take(ctx, (size_t)B * 4);
     p.amax = amax;
     DM_CHECK_HIP(ctx, hipMemsetAsync(amax, 0, (size_t)B * 4, ctx->stream));
-    DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel, dim3(64, B), dim3(256), 0, Phi, mass, N, k, ld, amax);
+    DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel, dim3(min(64, dm_cdiv(N, 16)), B), dim3(256), 0, Phi, mass, N, k, ld, amax);
     DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel, dim3(p.tiles_m * p.tiles_d, nsplit, B), dim3(256), 0, p);
     const long long n = (long long)B * k * D;
     DM_LAUNCH(ctx, "project_reduce", proj_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.partial, nsplit, n,
