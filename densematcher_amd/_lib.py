@@ -32,7 +32,10 @@ SIGNATURES = {
     "dm_fmap_c00": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_fmap_solve": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _d, _d, _p, _p]),
     "dm_fm_to_p2p": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "dm_knn_query_f64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "dm_mapped_indicator": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_p2p_to_fm": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
+    "dm_icp": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_zoomout": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
 }
 

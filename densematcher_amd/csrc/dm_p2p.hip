@@ -17,20 +17,23 @@
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
 
+static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+
 // =================================================================================================
 // K-major float64 copy of Phi:  out[b][c][i] = Phi[b][i][c]
 // =================================================================================================
-__global__ __launch_bounds__(256) void phiT_kernel(const float* __restrict__ Phi, int N, int k, int ld,
+template <typename Tin>
+__global__ __launch_bounds__(256) void phiT_kernel(const Tin* __restrict__ Phi, int N, int k, int ld,
                                                    double* __restrict__ out, int kpad, int Npad) {
-    __shared__ float tile[64][65];
+    __shared__ Tin tile[64][65];
     const int b = blockIdx.z;
     const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const float* P = Phi + (long long)b * N * ld;
+    const Tin* P = Phi + (long long)b * N * ld;
     double* O = out + (long long)b * kpad * Npad;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) {
         const int i = i0 + r, c = c0 + tx;
-        tile[r][tx] = (i < N && c < k) ? P[(long long)i * ld + c] : 0.f;
+        tile[r][tx] = (i < N && c < k) ? P[(long long)i * ld + c] : (Tin)0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -41,7 +44,13 @@ __global__ __launch_bounds__(256) void phiT_kernel(const float* __restrict__ Phi
 
 int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld, double* out, int kpad, int Npad) {
     dim3 grid(dm_cdiv(Npad, 64), dm_cdiv(kpad, 64), B);
-    DM_LAUNCH(ctx, "phiT", phiT_kernel, grid, dim3(256), 0, Phi, N, k, ld, out, kpad, Npad);
+    DM_LAUNCH(ctx, "phiT", phiT_kernel<float>, grid, dim3(256), 0, Phi, N, k, ld, out, kpad, Npad);
+    return DM_OK;
+}
+
+static int launch_transpose_f64(dm_ctx* ctx, int B, int N, int k, const double* X, int ld, double* out, int kpad, int Npad) {
+    dim3 grid(dm_cdiv(Npad, 64), dm_cdiv(kpad, 64), B);
+    DM_LAUNCH(ctx, "phiT", phiT_kernel<double>, grid, dim3(256), 0, X, N, k, ld, out, kpad, Npad);
     return DM_OK;
 }
 
@@ -412,7 +421,6 @@ __global__ __launch_bounds__(256) void gred_merge_kernel(const double* __restric
     out[(long long)b * n + i] = (j == DM_IDX_NONE) ? 0 : j;
 }
 
-static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
 size_t dm_gred_ws_bytes(int B, int N2, int N1) {
     const int N2pad = pad_to(N2, GT), N1pad = pad_to(N1, GT);
@@ -517,4 +525,75 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
     return dm_launch_gred(ctx, a);
+}
+
+// ---- generic exact nearest neighbour (pyFM/spectral/nn_utils.py:4-38, k = 1) ---------------------------------
+// out[b][i] = argmin_j |X[b][j] - Y[b][i]|^2 = argmin_j |X_j|^2 - 2 <X_j, Y_i>   (lowest j on ties)
+extern "C" int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p, const double* X, const double* Y, int32_t* out) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && nx > 0 && ny > 0 && p > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, X && Y && out, "null pointer");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const int nxpad = pad_to(nx, GT), nypad = pad_to(ny, GT), Kpad = pad_to(p, GBK);
+    const size_t bA = (size_t)B * Kpad * nypad * 8, bB = (size_t)B * Kpad * nxpad * 8;
+    int rc = dm_ws_reserve(ctx, dm_align_up(bA) + dm_align_up(bB) + dm_align_up((size_t)B * nxpad * 8) + dm_gred_ws_bytes(B, ny, nx));
+    if (rc) return rc;
+    double* AT = (double*)dm_ws_take(ctx, bA);
+    double* BT = (double*)dm_ws_take(ctx, bB);
+    double* n1 = (double*)dm_ws_take(ctx, (size_t)B * nxpad * 8);
+    rc = launch_transpose_f64(ctx, B, ny, p, Y, p, AT, Kpad, nypad);
+    if (rc) return rc;
+    rc = launch_transpose_f64(ctx, B, nx, p, X, p, BT, Kpad, nxpad);
+    if (rc) return rc;
+    DM_LAUNCH(ctx, "colnorm", colnorm_kernel, dim3(dm_cdiv(nxpad, 256), B), dim3(256), 0, BT, p, Kpad, nxpad, n1);
+    dm_gred_args a;
+    a.B = B; a.N2 = ny; a.N1 = nx; a.Kloop = Kpad;
+    a.AT = AT; a.N2pad = nypad; a.BT = BT; a.N1pad = nxpad; a.Kpad = Kpad;
+    a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
+    a.knn21 = out; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
+    return dm_launch_gred(ctx, a);
+}
+
+// ---- dense mapped indicator (pyFM/spectral/convert.py:144) ------------------------------------------------------
+// M[b] = ((Phi2[:, :k2] C) Phi1[:, :k1]^T) * mass1[None, :]   (N2 x N1 float64), for callers that want the matrix
+// itself; the arg-max maps never need it (dm_fm_to_p2p).
+struct OutRowMajorF64 {
+    double* p; long long stride_b; int ld;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] = v; }
+};
+struct OutIndicator {
+    double* p; long long stride_b; int ld; const float* mass1; int N1;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const {
+        p[b * stride_b + (long long)i * ld + j] = v * (double)mass1[(long long)b * N1 + j];
+    }
+};
+extern "C" int dm_mapped_indicator(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,
+                                   const float* Phi2, int ld2, const float* mass1, const double* C, double* M) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && C && M, "null pointer");
+    DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bE = (size_t)B * N2 * k1 * 8;
+    int rc = dm_ws_reserve(ctx, bE);
+    if (rc) return rc;
+    double* E2 = (double*)dm_ws_take(ctx, bE);
+    // emb2[i][m] = sum_c Phi2[i][c] C[c][m]  ==  NT product of rows Phi2_i and rows (C^T)_m
+    {
+        KRowsF32 opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
+        KRowsF64 opb{C, (long long)k2 * k1, k1, k1, k2, 1};
+        OutRowMajorF64 out{E2, (long long)N2 * k1, k1};
+        dim3 grid(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
+        DM_LAUNCH(ctx, "emb2_nt_f64", (gemm_nt_f64<KRowsF32, KRowsF64, OutRowMajorF64>), grid, dim3(256), 0, opa, opb, out,
+                  N2, k1, k2);
+    }
+    {
+        KRowsF64 opa{E2, (long long)N2 * k1, k1, N2, k1, 0};
+        KRowsF32 opb{Phi1, (long long)N1 * ld1, ld1, N1, k1};
+        OutIndicator out{M, (long long)N2 * N1, N1, mass1, N1};
+        dim3 grid(dm_cdiv(N2, NT_T) * dm_cdiv(N1, NT_T), 1, B);
+        DM_LAUNCH(ctx, "indicator_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF32, OutIndicator>), grid, dim3(256), 0, opa, opb, out,
+                  N2, N1, k1);
+    }
+    return DM_OK;
 }

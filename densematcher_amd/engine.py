@@ -196,6 +196,47 @@ class MatchEngine:
                                       _ptr(C0), _ptr(Cout), _ptr(p21)))
         return (Cout, p21) if return_p2p else Cout
 
+    def icp(self, Phi1, Phi2, C0, nit=10, return_resid=False):
+        """Spectral ICP (reference pyFM/refine/icp.py) -> C (B,k2,k1) f64 with orthonormal columns."""
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        C0 = self._dev(C0, torch.float64, "C0")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        k2, k1 = C0.shape[1], C0.shape[2]
+        Cout = torch.empty_like(C0)
+        resid = torch.empty((B,), dtype=torch.float64, device=self.device)
+        info = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_icp(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(C0), int(nit), _ptr(Cout),
+                                  _ptr(resid), _ptr(info)))
+        return (Cout, resid, info) if return_resid else Cout
+
+    def knn_query(self, X, Y):
+        """For every row of Y the index of the nearest row of X (float64, exact, lowest index on ties)."""
+        X = self._dev(X, torch.float64, "X")
+        Y = self._dev(Y, torch.float64, "Y")
+        if X.dim() != 3 or Y.dim() != 3 or X.shape[0] != Y.shape[0] or X.shape[2] != Y.shape[2]:
+            raise ValueError("knn_query expects X (B,nx,p) and Y (B,ny,p)")
+        B, nx, p = X.shape
+        ny = Y.shape[1]
+        out = torch.empty((B, ny), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_knn_query_f64(self.ctx, B, nx, ny, p, _ptr(X), _ptr(Y), _ptr(out)))
+        return out
+
+    def mapped_indicator(self, Phi1, Phi2, a1, Cm):
+        """Dense (B,N2,N1) float64 indicator ((Phi2 C) Phi1^T) * a1 -- only for callers that want the matrix."""
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        a1 = self._dev(a1, torch.float32, "a1")
+        Cm = self._dev(Cm, torch.float64, "C")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        k2, k1 = Cm.shape[1], Cm.shape[2]
+        M = torch.empty((B, N2, N1), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_mapped_indicator(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1),
+                                               _ptr(Cm), _ptr(M)))
+        return M
+
     # ------------------------------------------------------------------ the hot path, one batch
     def match(self, batch, k=None, w_descr=1e4, w_lap=1e3, knn=True, ind=True, check=False):
         """project -> pinned column -> solve -> vertex maps for a batch of pairs (BASELINE config 2).

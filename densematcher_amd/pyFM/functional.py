@@ -1,0 +1,213 @@
+"""
+FunctionalMapping with the reference's interface (densematcher/pyFM/functional.py:19), restricted to what the
+matching hot path uses.  Arithmetic: libdensematch (HIP) through densematcher_amd.engine.
+"""
+import copy
+
+import numpy as np
+
+from . import refine, spectral
+
+_OPTIMIZERS = ("L-BFGS-B", "fmin_l_bfgs_b", "l-bfgs-b")
+
+
+class FunctionalMapping:
+    def __init__(self, mesh1, mesh2, partial=False, optimizer="fmin_l_bfgs_b"):
+        self.mesh1 = copy.deepcopy(mesh1)          # functional.py:58-59
+        self.mesh2 = copy.deepcopy(mesh2)
+        self.descr1 = None
+        self.descr2 = None
+        self._FM_type = 'classic'
+        self._FM_base = None
+        self._FM_icp = None
+        self._FM_zo = None
+        self._k1, self._k2 = None, None
+        self.optimizer = optimizer
+        self.partial = partial
+        self.eta = None
+        self.mapped_indicator = None
+
+    # ---------------------------------------------------------------- dimensions / state (functional.py:79-199)
+    @property
+    def k1(self):
+        if self._k1 is None and not self.preprocessed and not self.fitted:
+            raise ValueError('No information known about dimensions')
+        return self.FM.shape[1] if self.fitted else self._k1
+
+    @k1.setter
+    def k1(self, k1):
+        self._k1 = k1
+
+    @property
+    def k2(self):
+        if self._k2 is None and not self.preprocessed and not self.fitted:
+            raise ValueError('No information known about dimensions')
+        return self.FM.shape[0] if self.fitted else self._k2
+
+    @k2.setter
+    def k2(self, k2):
+        self._k2 = k2
+
+    @property
+    def FM_type(self):
+        return self._FM_type
+
+    @FM_type.setter
+    def FM_type(self, FM_type):
+        if FM_type.lower() not in ['classic', 'icp', 'zoomout']:
+            raise ValueError(f'FM_type can only be set to "classic", "icp" or "zoomout", not {FM_type}')
+        self._FM_type = FM_type
+
+    def change_FM_type(self, FM_type):
+        self.FM_type = FM_type
+
+    @property
+    def FM(self):
+        return {'classic': self._FM_base, 'icp': self._FM_icp, 'zoomout': self._FM_zo}[self.FM_type.lower()]
+
+    @FM.setter
+    def FM(self, FM):
+        self._FM_base = FM
+
+    @property
+    def preprocessed(self):
+        test_descr = (self.descr1 is not None) and (self.descr2 is not None)
+        test_evals = (self.mesh1.eigenvalues is not None) and (self.mesh2.eigenvalues is not None)
+        test_evects = (self.mesh1.eigenvectors is not None) and (self.mesh2.eigenvectors is not None)
+        return test_descr and test_evals and test_evects
+
+    @property
+    def fitted(self):
+        return self.FM is not None
+
+    # ---------------------------------------------------------------- preprocess (functional.py:264-350)
+    def preprocess(self, n_ev=(50, 50), n_descr=100, descr_type='WKS', landmarks=None, subsample_step=1, k_process=None,
+                   verbose=False, descr1=None, descr2=None):
+        self.k1, self.k2 = n_ev
+        if k_process is None:
+            k_process = 1
+        if landmarks is not None and len(landmarks) > 0:
+            raise NotImplementedError("landmark descriptors (HKS/WKS) are outside the matching path")
+        self.mesh1.process(max(self.k1, k_process), verbose=verbose, robust=True, intrinsic=False)
+        self.mesh2.process(max(self.k2, k_process), verbose=verbose, robust=True, intrinsic=False)
+        if descr1 is not None and descr2 is not None:
+            self.descr1, self.descr2 = descr1, descr2
+        elif descr_type in ('HKS', 'WKS'):
+            raise NotImplementedError(f"{descr_type} signatures are an alternative descriptor source, not the neural path")
+        else:
+            raise ValueError(f'Descriptor type "{descr_type}" not implemented')
+        self.descr1 = self.descr1[:, np.arange(0, self.descr1.shape[1], subsample_step)]      # functional.py:333-334
+        self.descr2 = self.descr2[:, np.arange(0, self.descr2.shape[1], subsample_step)]
+        return self                                                                          # no normalisation (:336-344)
+
+    # ---------------------------------------------------------------- fit (functional.py:352-487)
+    def fit(self, w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_orient=0, w_area=0, w_conformal=0, w_p2p=0, w_stochastic=0, w_ent=0,
+            w_range01=0, w_sumto1=0, w_area_difference=0, w_mumford_shah=0, mumford_shah_var=0.1, w_eta_entropy=0,
+            orient_reversing=False, optinit='zeros', verbose=False, maxiter=1000000, device=None):
+        """Minimiser of w_descr/2 |C A - B|^2 + w_lap/2 sum C^2 ev with the first column pinned: what the reference's
+        L-BFGS-B loop converges to, obtained in closed form.  Only the two quadratic
+        terms are on the GPU path; any other weight > 0 raises (SURVEY.md 'next #2')."""
+        from ..engine import default_engine
+        if optinit not in ['random', 'identity', 'zeros']:
+            raise ValueError(f"optinit arg should be 'random', 'identity' or 'zeros', not {optinit}")
+        if self.optimizer not in _OPTIMIZERS:
+            raise ValueError(f"Unknown solver {self.optimizer}")
+        if self.partial:
+            raise NotImplementedError()                                        # functional.py:480
+        others = dict(w_dcomm=w_dcomm, w_orient=w_orient, w_area=w_area, w_conformal=w_conformal, w_p2p=w_p2p,
+                      w_stochastic=w_stochastic, w_ent=w_ent, w_range01=w_range01, w_sumto1=w_sumto1,
+                      w_area_difference=w_area_difference, w_mumford_shah=w_mumford_shah, w_eta_entropy=w_eta_entropy)
+        live = [n for n, v in others.items() if v > 0]
+        if live:
+            raise NotImplementedError(f"energy terms {live} are not on the accelerated path (only w_descr, w_lap); pass 0")
+        if not (w_descr > 0 or w_lap > 0):
+            raise ValueError("every energy weight is 0")                       # base_functions.py:534,639 would fail too
+        if not self.preprocessed:
+            self.preprocess()
+        eng = default_engine()
+        m1, m2 = self.mesh1, self.mesh2
+        # like the reference (functional.py:412-413) fit uses every stored eigenvector column
+        Phi1 = np.ascontiguousarray(m1.eigenvectors, dtype=np.float32)[None]
+        Phi2 = np.ascontiguousarray(m2.eigenvectors, dtype=np.float32)[None]
+        a1 = np.ascontiguousarray(m1.A.diagonal(), dtype=np.float32)[None]
+        a2 = np.ascontiguousarray(m2.A.diagonal(), dtype=np.float32)[None]
+        d1, d2 = np.asarray(self.descr1), np.asarray(self.descr2)
+        fdt = np.float16 if (d1.dtype == np.float16 and d2.dtype == np.float16) else np.float32
+        batch = {"Phi1": Phi1, "Phi2": Phi2, "a1": a1, "a2": a2,
+                 "lam1": np.asarray(m1.eigenvalues, dtype=np.float64)[None], "lam2": np.asarray(m2.eigenvalues, dtype=np.float64)[None],
+                 "F1": np.ascontiguousarray(d1, dtype=fdt)[None], "F2": np.ascontiguousarray(d2, dtype=fdt)[None]}
+        dev = {n: eng._dev(v, {np.float16: __import__("torch").float16, np.float32: __import__("torch").float32,
+                               np.float64: __import__("torch").float64}[v.dtype.type], n) for n, v in batch.items()}
+        A = eng.project(dev["Phi1"], dev["a1"], dev["F1"])
+        B = eng.project(dev["Phi2"], dev["a2"], dev["F2"])
+        c00 = eng.c00(dev["Phi1"], dev["Phi2"], dev["a1"], dev["a2"])
+        C = eng.fmap_solve(A, B, dev["lam1"], dev["lam2"], c00, w_descr, w_lap, check=True)
+        self.FM = C[0].cpu().numpy()
+        self.eta = np.ones(m2.eigenvectors.shape[0])                           # functional.py:483
+        self._dev = dev
+
+    def get_x0(self, optinit="zeros"):
+        """functional.py:629-660"""
+        if optinit == 'random':
+            x0 = np.random.random((self.k2, self.k1))
+            x0 = x0 / x0.sum()
+        elif optinit == 'identity':
+            x0 = np.eye(self.k2, self.k1)
+        else:
+            x0 = np.zeros((self.k2, self.k1))
+        ev_sign = np.sign(self.mesh1.eigenvectors[0, 0] * self.mesh2.eigenvectors[0, 0])
+        area_ratio = np.sqrt(self.mesh2.area / self.mesh1.area)
+        x0[:, 0] = np.zeros(self.k2)
+        x0[0, 0] = ev_sign * area_ratio
+        return x0
+
+    # ---------------------------------------------------------------- maps and refinement
+    def get_p2p(self, use_adj=False, n_jobs=1):
+        """functional.py:201-219: returns the kd-tree maps (p2p_21, p2p_12) and sets self.mapped_indicator"""
+        p2p_21, p2p_12, self.mapped_indicator = spectral.mesh_FM_to_p2p(self.FM, self.mesh1, self.mesh2, use_adj=use_adj,
+                                                                       n_jobs=n_jobs)
+        return p2p_21, p2p_12
+
+    def icp_refine(self, nit=10, tol=None, use_adj=False, overwrite=True, verbose=False, n_jobs=1):
+        """functional.py:564-586"""
+        if not self.fitted:
+            raise ValueError("The Functional map must be fit before refining it")
+        self._FM_icp = refine.mesh_icp_refine(self.FM, self.mesh1, self.mesh2, nit=nit, tol=tol, return_p2p=False,
+                                              use_adj=use_adj, n_jobs=n_jobs, verbose=verbose)
+        if overwrite:
+            self.FM_type = 'icp'
+
+    def zoomout_refine(self, nit=10, step=1, subsample=None, overwrite=True, verbose=False):
+        """functional.py:588-617"""
+        if not self.fitted:
+            raise ValueError("The Functional map must be fit before refining it")
+        if subsample is not None and subsample != 0:
+            raise NotImplementedError("farthest-point subsampling is outside the matching path")
+        self._FM_zo = refine.mesh_zoomout_refine(self.FM, self.mesh1, self.mesh2, nit, step=step, subsample=None, verbose=verbose)
+        if overwrite:
+            self.FM_type = 'zoomout'
+
+    # ---------------------------------------------------------------- small helpers (functional.py:730-831)
+    def project(self, func, k=None, mesh_ind=1):
+        if mesh_ind == 1:
+            return self.mesh1.project(func, k=self.k1 if k is None else k)
+        elif mesh_ind == 2:
+            return self.mesh2.project(func, k=self.k2 if k is None else k)
+        raise ValueError(f'Only indices 1 or 2 are accepted, not {mesh_ind}')
+
+    def decode(self, encoded_func, mesh_ind=2):
+        if mesh_ind == 1:
+            return self.mesh1.decode(encoded_func)
+        elif mesh_ind == 2:
+            return self.mesh2.decode(encoded_func)
+        raise ValueError(f'Only indices 1 or 2 are accepted, not {mesh_ind}')
+
+    def transport(self, encoded_func, reverse=False):
+        if not self.preprocessed:
+            raise ValueError("The Functional map must be fit before transporting a function")
+        return np.linalg.pinv(self.FM) @ encoded_func if reverse else self.FM @ encoded_func
+
+    def transfer(self, func, reverse=False):
+        if not reverse:
+            return self.decode(self.transport(self.project(func)))
+        return self.decode(self.transport(self.project(func, mesh_ind=2), reverse=True), mesh_ind=1)

@@ -1,0 +1,139 @@
+"""
+TriMesh: the data carrier of the matching path (reference: densematcher/pyFM/mesh/trimesh.py:16).
+
+Only what the hot path consumes is kept: vertices / faces, the cotangent stiffness matrix W, the lumped
+(diagonal) mass matrix A, L = A^-1 W, the Laplace-Beltrami spectrum, `area`, `process`, `project`, `decode`.
+Producing the spectrum is an INPUT of the accelerated path ("next #4"): like the
+reference (trimesh.py:440-531 -> laplacian.py:143-182, SciPy/ARPACK) it runs on the host with SciPy.
+The reference's `robust=True` uses the external `robust_laplacian` wheel (tufted Laplacian); here the
+classical cotangent Laplacian with lumped masses is used for every mesh (identical on manifold meshes up
+to the mollification of degenerate triangles).
+"""
+import numpy as np
+import scipy.sparse as sparse
+
+from ... import synth
+
+
+class TriMesh:
+    def __init__(self, *args, **kwargs):
+        assert 0 < len(args) < 3, "Provide vertices / faces"
+        if isinstance(args[0], str):
+            raise NotImplementedError("mesh file loading is outside the matching path: pass (vertices, faces)")
+        self.W = None
+        self.A = None
+        self._L = None
+        self.eigenvalues = None
+        self.eigenvectors = None
+        self.vertlist = args[0]
+        self.facelist = args[1] if len(args) > 1 else None
+
+    # ------------------------------------------------------------- geometry
+    @property
+    def vertlist(self):
+        return self._vertlist
+
+    @vertlist.setter
+    def vertlist(self, vertlist):
+        vertlist = np.asarray(vertlist, dtype=float)          # trimesh.py:118 (float64 copy)
+        if vertlist.ndim != 2:
+            raise ValueError('Vertex list has to be 2D')
+        elif vertlist.shape[1] != 3:
+            raise ValueError('Vertex list requires 3D coordinates')
+        self._vertlist = vertlist.copy()
+        self.W = self.A = self._L = self.eigenvalues = self.eigenvectors = None
+
+    @property
+    def facelist(self):
+        return self._facelist
+
+    @facelist.setter
+    def facelist(self, facelist):
+        if facelist is not None:
+            facelist = np.asarray(facelist)
+            if facelist.ndim != 2:
+                raise ValueError('Faces list has to be 2D')
+            elif facelist.shape[1] != 3:
+                raise ValueError('Each face is made of 3 points')
+            self._facelist = facelist.astype(np.int64).copy()
+        else:
+            self._facelist = None
+
+    vertices = property(lambda self: self._vertlist)
+    faces = property(lambda self: self._facelist)
+    n_vertices = property(lambda self: self._vertlist.shape[0])
+    n_faces = property(lambda self: 0 if self._facelist is None else self._facelist.shape[0])
+
+    @property
+    def area(self):
+        """trimesh.py:206-221: A.sum() once the Laplacian exists, else the sum of the face areas."""
+        if self.A is None:
+            if self.facelist is None:
+                return None
+            v = self.vertlist
+            f = self.facelist
+            return 0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1).sum()
+        return self.A.sum()
+
+    @property
+    def L(self):
+        """A^-1 W (trimesh.py:482); built lazily, the matching path never needs it densified."""
+        if self._L is None and self.W is not None:
+            self._L = sparse.diags(1.0 / self.A.diagonal()).tocsr() @ self.W
+        return self._L
+
+    @L.setter
+    def L(self, value):
+        self._L = value
+
+    # ------------------------------------------------------------- spectrum (host side input of the path)
+    def laplacian_spectrum(self, k, intrinsic=False, return_spectrum=True, robust=False, verbose=False):
+        if self.facelist is None:
+            raise NotImplementedError("point-cloud Laplacians are outside the matching path")
+        self.W, mass = synth.cotan_laplacian(self.vertlist, self.facelist)
+        self.A = sparse.diags(mass).tocsr()
+        self._L = None
+        if k > 0:
+            lam, phi, _ = synth.eigenbasis(self.vertlist, self.facelist, max(20, k), method="arpack" if self.n_vertices > 3000 else "dense")
+            self.eigenvalues, self.eigenvectors = lam[:k], phi[:, :k]           # laplacian.py:165-167
+            if return_spectrum:
+                return self.eigenvalues, self.eigenvectors
+
+    def process(self, k=200, skip_normals=True, intrinsic=False, robust=False, verbose=False):
+        """trimesh.py:498-531: reuse a stored spectrum when it is large enough, else compute it."""
+        if (self.eigenvectors is not None) and (self.eigenvalues is not None) and (len(self.eigenvalues) >= k):
+            self.eigenvectors = self.eigenvectors[:, :k]
+            self.eigenvalues = self.eigenvalues[:k]
+        else:
+            self.laplacian_spectrum(k, return_spectrum=False, intrinsic=intrinsic, robust=robust, verbose=verbose)
+        return self
+
+    # ------------------------------------------------------------- spectral helpers
+    def project(self, func, k=None):
+        """Phi[:, :k]^T (A func) (trimesh.py:533-556), on the GPU."""
+        if k is not None and k > self.eigenvectors.shape[1]:
+            raise ValueError(f'At least {k} eigenvectors should be computed before projecting')
+        from ...engine import default_engine
+        func = np.asarray(func)
+        one_d = func.ndim == 1
+        F = (func[:, None] if one_d else func).astype(np.float32)
+        kk = self.eigenvectors.shape[1] if k is None else k
+        out = default_engine().project(self.eigenvectors[None].astype(np.float32), self.A.diagonal()[None].astype(np.float32),
+                                       F[None], kk, exact=True)[0].cpu().numpy().astype(np.float64)
+        return out[:, 0] if one_d else out
+
+    def decode(self, projection):
+        """Phi[:, :k] @ projection (trimesh.py:558-577); a trivially small host product."""
+        k = projection.shape[0]
+        if k <= self.eigenvectors.shape[1]:
+            return self.eigenvectors[:, :k] @ projection
+        raise ValueError(f'At least {k} eigenvectors should be computed before decoding')
+
+    def l2_sqnorm(self, func):
+        return self.l2_inner(func, func)
+
+    def l2_inner(self, func1, func2):
+        return np.einsum('np,np->p', func1, self.A @ func2) if func1.ndim > 1 else func1 @ (self.A @ func2)
+
+    def integrate(self, func):
+        return func.T @ self.A.diagonal()

@@ -1,0 +1,44 @@
+"""
+Spectral ICP with the reference's signatures (densematcher/pyFM/refine/icp.py); the loop runs on the GPU (dm_icp).
+"""
+import numpy as np
+
+
+def _run(FM_12, evects1, evects2, nit):
+    from ...engine import default_engine
+    FM_12 = np.asarray(FM_12, dtype=np.float64)
+    k2, k1 = FM_12.shape
+    eng = default_engine()
+    C, resid, info = eng.icp(np.ascontiguousarray(evects1[:, :k1], dtype=np.float32)[None],
+                             np.ascontiguousarray(evects2[:, :k2], dtype=np.float32)[None], FM_12[None], nit, return_resid=True)
+    if int(info[0]) != 0:
+        raise np.linalg.LinAlgError("ICP: Phi2^T Phi2 is not positive definite")
+    if float(resid[0]) > 1e-8:
+        raise np.linalg.LinAlgError(f"ICP: polar iteration did not converge (|C^T C - I| = {float(resid[0]):.2e}): "
+                                    "the least-squares map is close to rank deficient")
+    return C[0].cpu().numpy()
+
+
+def icp_iteration(FM_12, evects1, evects2, A1=None, use_adj=False, n_jobs=1):
+    """reference icp.py:10-40"""
+    return _run(FM_12, evects1, evects2, 1)
+
+
+def icp_refine(FM_12, evects1, evects2, A1=None, nit=10, tol=1e-10, use_adj=False, return_p2p=False, n_jobs=1, verbose=False):
+    """reference icp.py:43-107 (fixed iteration count; the tolerance-driven variant needs a host decision per
+    iteration and is not on the GPU path)"""
+    if nit is None or nit <= 0:
+        raise NotImplementedError("tolerance-driven ICP (nit=None) is not on the GPU path; pass nit")
+    FM_icp = _run(FM_12, evects1, evects2, nit)
+    if return_p2p:
+        from .. import spectral
+        p2p_21 = spectral.FM_to_p2p(FM_icp, evects1, evects2, A1)[0]
+        return FM_icp, p2p_21
+    return FM_icp
+
+
+def mesh_icp_refine(FM_12, mesh1, mesh2, nit=10, tol=1e-10, use_adj=False, return_p2p=False, n_jobs=1, verbose=False):
+    """reference icp.py:110-150"""
+    k2, k1 = np.asarray(FM_12).shape
+    return icp_refine(FM_12, mesh1.eigenvectors[:, :k1], mesh2.eigenvectors[:, :k2], mesh1.A, nit=nit, tol=tol, use_adj=use_adj,
+                      return_p2p=return_p2p, n_jobs=n_jobs, verbose=verbose)

@@ -1,0 +1,116 @@
+"""
+FM <-> p2p conversion with the reference's signatures (densematcher/pyFM/spectral/convert.py).
+"""
+import numpy as np
+import scipy.sparse as sparse
+
+
+def _diag_of(A, n):
+    """lumped mass: accept a sparse diagonal matrix, a dense square matrix or the diagonal itself"""
+    if A is None:
+        return None
+    if sparse.issparse(A):
+        d = A.diagonal()
+    else:
+        A = np.asarray(A)
+        d = A if A.ndim == 1 else np.diag(A)
+    if d.shape[0] != n:
+        raise ValueError("Can't compute exact pseudo inverse with subsampled eigenvectors")
+    return np.ascontiguousarray(d, dtype=np.float32)
+
+
+class MappedIndicator:
+    """The (n2, n1) matrix Phi2 C Phi1^T A1 of the reference (convert.py:144), kept implicit.
+
+    `argmax(axis=...)` comes from the fused G-tile kernel (the matrix is never formed); converting to an array
+    (np.asarray, arithmetic, indexing) materialises it once on the GPU with dm_mapped_indicator."""
+    def __init__(self, eng, Phi1, Phi2, a1, C, ind21, ind12):
+        self._eng, self._args = eng, (Phi1, Phi2, a1, C)
+        self._ind21, self._ind12 = ind21, ind12
+        self._dense = None
+        self.shape = (Phi2.shape[1], Phi1.shape[1])
+        self.ndim = 2
+        self.dtype = np.dtype(np.float64)
+
+    def argmax(self, axis=None):
+        if axis in (1, -1):
+            return self._ind21
+        if axis == 0:
+            return self._ind12
+        return np.asarray(self).argmax(axis)
+
+    def __array__(self, dtype=None, copy=None):
+        if self._dense is None:
+            self._dense = self._eng.mapped_indicator(*self._args)[0].cpu().numpy()
+        return self._dense if dtype is None else self._dense.astype(dtype)
+
+    def __mul__(self, other):
+        other = np.asarray(other)
+        if other.shape in ((self.shape[0], 1), (1, 1), ()) and np.all(other == 1):
+            return self                  # functional_map.py:49: `mapped_indicator * eta[..., None]`, eta == 1 after fit
+        return np.asarray(self) * other
+
+    __rmul__ = __mul__
+
+    def __getitem__(self, idx):
+        return np.asarray(self)[idx]
+
+
+def FM_to_p2p(FM_12, evects1, evects2, A1, use_adj=False, n_jobs=1):
+    """(p2p_21, p2p_12, mapped_indicator) -- reference convert.py:96-147 (`use_adj`, `n_jobs` accepted, ignored
+    there too).  Eigenvectors are sliced to the map's size (the fork's unsliced :144 only works when they are)."""
+    from ...engine import default_engine
+    FM_12 = np.asarray(FM_12, dtype=np.float64)
+    k2, k1 = FM_12.shape
+    assert k1 <= evects1.shape[1], f'At least {k1} should be provided, here only {evects1.shape[1]} are given'
+    assert k2 <= evects2.shape[1], f'At least {k2} should be provided, here only {evects2.shape[1]} are given'
+    eng = default_engine()
+    Phi1 = eng._dev(np.ascontiguousarray(evects1[:, :k1], dtype=np.float32)[None], __import__("torch").float32, "Phi1")
+    Phi2 = eng._dev(np.ascontiguousarray(evects2[:, :k2], dtype=np.float32)[None], __import__("torch").float32, "Phi2")
+    a1 = _diag_of(A1, evects1.shape[0])
+    out = eng.fm_to_p2p(Phi1, Phi2, None if a1 is None else a1[None], FM_12[None], knn=True, ind=a1 is not None)
+    p2p_21 = out["knn21"][0].cpu().numpy().astype(np.int64)
+    p2p_12 = out["knn12"][0].cpu().numpy().astype(np.int64)
+    indicator = None
+    if a1 is not None:
+        indicator = MappedIndicator(eng, Phi1, Phi2, a1[None], FM_12[None], out["ind21"][0].cpu().numpy().astype(np.int64),
+                                    out["ind12"][0].cpu().numpy().astype(np.int64))
+    return p2p_21, p2p_12, indicator
+
+
+def mesh_FM_to_p2p(FM_12, mesh1, mesh2, use_adj=False, subsample=None, n_jobs=1):
+    """reference convert.py:149-182"""
+    k2, k1 = FM_12.shape
+    if subsample is None:
+        return FM_to_p2p(FM_12, mesh1.eigenvectors[:, :k1], mesh2.eigenvectors[:, :k2], mesh1.A, use_adj=use_adj, n_jobs=n_jobs)
+    sub1, sub2 = subsample
+    return FM_to_p2p(FM_12, mesh1.eigenvectors[sub1, :k1], mesh2.eigenvectors[sub2, :k2], None, use_adj=use_adj, n_jobs=n_jobs)
+
+
+def p2p_to_FM(p2p_21, evects1, evects2, A2=None):
+    """reference convert.py:14-51.  With A2: Phi2^T (A2 Phi1[p2p_21]) on the GPU.  Without A2 the reference solves a
+    least-squares problem (ICP, SURVEY.md 'next #1'): normal equations on the GPU (dm_icp)."""
+    from ...engine import default_engine
+    if np.asarray(p2p_21).ndim != 1:
+        raise NotImplementedError("sparse (n2,n1) maps are outside the matching path: pass the (n2,) index map")
+    eng = default_engine()
+    if A2 is None:
+        raise NotImplementedError("least-squares p2p_to_FM (no A2) belongs to ICP, not yet on the GPU path")
+    a2 = _diag_of(A2, evects2.shape[0])
+    C = eng.p2p_to_fm(np.ascontiguousarray(p2p_21, dtype=np.int32)[None], np.ascontiguousarray(evects1, dtype=np.float32)[None],
+                      np.ascontiguousarray(evects2, dtype=np.float32)[None], a2[None], evects1.shape[1], evects2.shape[1])
+    return C[0].cpu().numpy()
+
+
+def mesh_p2p_to_FM(p2p_21, mesh1, mesh2, dims=None, subsample=None):
+    """reference convert.py:54-93"""
+    if dims is None:
+        k1, k2 = len(mesh1.eigenvalues), len(mesh2.eigenvalues)
+    elif np.issubdtype(type(dims), np.integer):
+        k1 = k2 = dims
+    else:
+        k1, k2 = dims
+    if subsample is None:
+        return p2p_to_FM(p2p_21, mesh1.eigenvectors[:, :k1], mesh2.eigenvectors[:, :k2], A2=mesh2.A)
+    sub1, sub2 = subsample
+    return p2p_to_FM(p2p_21, mesh1.eigenvectors[sub1, :k1], mesh2.eigenvectors[sub2, :k2], A2=None)

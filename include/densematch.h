@@ -126,6 +126,20 @@ int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const float* mass1, const double* C,
                  int32_t* knn21, int32_t* knn12, int32_t* ind21, int32_t* ind12);
 
+/* ---- exact nearest neighbour, k = 1 -----------------------------------------
+ * out[b,i] = argmin_j |X[b,j,:] - Y[b,i,:]|^2 (lowest j on ties); X (B,nx,p), Y (B,ny,p) fp64.
+ * Replaces pyFM/spectral/nn_utils.py:4-38 (knn_query: sklearn kd-tree, k = 1). */
+int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p,
+                     const double* X, const double* Y, int32_t* out /* B*ny */);
+
+/* ---- dense mapped indicator --------------------------------------------------
+ * M[b] = ((Phi2[:, :k2] C) Phi1[:, :k1]^T) * mass1[None, :]   (B,N2,N1) fp64.
+ * Replaces the matrix returned by FM_to_p2p (pyFM/spectral/convert.py:144) for
+ * callers that want it; the arg-max maps come from dm_fm_to_p2p without it. */
+int dm_mapped_indicator(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                        const float* Phi1, int ld1, const float* Phi2, int ld2,
+                        const float* mass1, const double* C, double* M);
+
 /* ---- vertex map -> functional map -----------------------------------------
  * C[b] = Phi2[b][:, :k2]^T (mass2[b] * Phi1[b][p21[b], :k1])   (k2 x k1) fp64.
  * Replaces pyFM/spectral/convert.py:14-51 (p2p_to_FM, A2 given). */
@@ -141,6 +155,16 @@ int dm_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
 int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step,
                const float* Phi1, int ld1, const float* Phi2, int ld2,
                const float* mass2, const double* C0, double* Cout, int32_t* p21_out /*nullable*/);
+
+/* ---- spectral ICP -------------------------------------------------------------
+ * nit times: p21 = knn21(C); Chat = argmin |Phi2[:, :k2] X - Phi1[p21, :k1]|_F (no mass);
+ * C = U eye(k2,k1) V^T with U S V^T = svd(Chat), i.e. the orthogonal polar factor of Chat.
+ * Replaces pyFM/refine/icp.py:10-40,43-107 (fixed nit; functional.py:564 uses nit = 10).
+ * C0, Cout (B,k2,k1) fp64; resid (B) fp64 optional = max |Cout^T Cout - I| (convergence of the
+ * Newton-Schulz polar iteration); info (B): 0 ok, c+1 = normal equations not SPD.  k1 <= k2 <= 176. */
+int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+           const float* Phi1, int ld1, const float* Phi2, int ld2,
+           const double* C0, int nit, double* Cout, double* resid /*nullable*/, int32_t* info);
 
 #ifdef __cplusplus
 }
