@@ -31,12 +31,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const double* __
     out[i] = (float)s;
 }
 
-static int pick_split(int wgs_unsplit, int K, int bk) {
-    int nsplit = 1;
-    while (wgs_unsplit * nsplit < 1024 && nsplit < 16 && K / (nsplit * 2) >= 8 * bk) nsplit *= 2;
-    return nsplit;
-}
-
 extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass,
                           const void* F, int f_dtype, float* Ared) {
     if (!ctx) return DM_EINVAL;
@@ -49,8 +43,9 @@ extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* 
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     if (f_dtype == DM_F16 && !want_f64) return dm_project_f16split(ctx, B, N, D, k, Phi, ld, mass, F, Ared);
     const int tiles = dm_cdiv(k, TN_T) * dm_cdiv(D, TN_T);
-    const int nsplit = pick_split(tiles * B, N, TN_BK);
-    const int kchunk = dm_cdiv(dm_cdiv(N, nsplit), TN_BK) * TN_BK;
+    // split-K by a fixed chunk of vertices: the summation order of a pair must not depend on the batch it is in
+    const int kchunk = 512;
+    const int nsplit = dm_cdiv(N, kchunk);
     double* partial = nullptr;
     if (nsplit > 1) {
         int rc = dm_ws_reserve(ctx, (size_t)nsplit * B * k * D * 8);

@@ -217,11 +217,10 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Ph
     p.Phi = Phi; p.mass = mass; p.F = (const _Float16*)F;
     p.B = B; p.N = N; p.D = D; p.k = k; p.ld = ld;
     p.tiles_m = dm_cdiv(k, PT); p.tiles_d = dm_cdiv(D, PT);
-    const int wgs = B * p.tiles_m * p.tiles_d;
-    int nsplit = 1;
-    while (wgs * nsplit < 1536 && nsplit < 16 && N / (nsplit * 2) >= 4 * PBK) nsplit *= 2;
+    // split-K by a fixed chunk of vertices: the summation order of a pair must not depend on the batch it is in
+    p.kchunk = 512;
+    const int nsplit = dm_cdiv(N, p.kchunk);
     p.nsplit = nsplit;
-    p.kchunk = dm_cdiv(dm_cdiv(N, nsplit), PBK) * PBK;
     const size_t pbytes = (size_t)nsplit * B * k * D * 4;
     int rc = dm_ws_reserve(ctx, dm_align_up(pbytes) + 4096);
     if (rc) return rc;

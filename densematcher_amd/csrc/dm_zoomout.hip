@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_fm_kernel(const double* __r
     C[b * strideC + (long long)m * ldc + c] = s;
 }
 
+// split-K by a fixed chunk of vertices: the summation order of a pair must not depend on the batch it is in
+constexpr int FM_KCHUNK = 256;
 static int fm_split(int B, int N2, int k1, int k2) {
-    const int wgs = B * dm_cdiv(k2, TN_T) * dm_cdiv(k1, TN_T);
-    int nsplit = 1;
-    while (wgs * nsplit < 1024 && nsplit < 32 && N2 / (nsplit * 2) >= 4 * TN_BK) nsplit *= 2;
-    return nsplit;
+    (void)B; (void)k1; (void)k2;
+    return dm_cdiv(N2, FM_KCHUNK);
 }
 
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2) {
@@ -50,7 +50,7 @@ int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, cons
                         int ld1, const float* Phi2, int ld2, const float* mass2, double* C, int ldc,
                         long long strideC) {
     const int nsplit = fm_split(B, N2, k1, k2);
-    const int kchunk = dm_cdiv(dm_cdiv(N2, nsplit), TN_BK) * TN_BK;
+    const int kchunk = FM_KCHUNK;
     double* partial = nullptr;
     if (nsplit > 1) {
         partial = (double*)dm_ws_take(ctx, (size_t)nsplit * B * k2 * k1 * 8);

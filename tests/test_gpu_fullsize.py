@@ -1,0 +1,112 @@
+"""
+GPU (-m gpu): BASELINE.json's full sizes, checked through size-independent properties (exact round trips,
+batch invariance, consistency between fused and step-by-step paths) plus the oracle on a sampled pair.
+"""
+import numpy as np
+import pytest
+import torch
+
+from densematcher_amd import synth
+from oracle import dm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from densematcher_amd.engine import MatchEngine
+    return MatchEngine()
+
+
+def test_config3_simnn_full_batch_roundtrip(eng):
+    """batch=64, N=2048, D=768: targets are exact copies of permuted sources -> the map must be the permutation"""
+    B, N, D = 64, 2048, 768
+    g = torch.Generator(device="cuda").manual_seed(3)
+    S = torch.randn(B, N, D, device="cuda", generator=g, dtype=torch.float32).to(torch.float16)
+    perm = torch.stack([torch.randperm(N, device="cuda", generator=g) for _ in range(B)])
+    T = torch.gather(S, 1, perm[:, :, None].expand(B, N, D))
+    nn, best, margin = eng.simnn(T, S, return_scores=True)
+    assert torch.equal(nn.long(), perm)
+    assert float(margin.min()) > 0
+    # idempotence: matching the matched rows again returns the same indices
+    nn2 = eng.simnn(torch.gather(S, 1, nn.long()[:, :, None].expand(B, N, D)), S)
+    assert torch.equal(nn2, nn)
+    # one sampled pair against the float64 oracle, noisy (hard) targets
+    Tn = (T[7].float() + 1.0 * torch.randn(N, D, device="cuda", generator=g)).to(torch.float16)
+    got = eng.simnn(Tn[None], S[7][None])[0].cpu().numpy()
+    assert np.array_equal(got, orc.simnn(Tn.cpu().numpy(), S[7].cpu().numpy()))
+
+
+def test_config2_batch_invariance_and_oracle(eng):
+    """batch=64, N=2048, D=768, k=128: a pair's result does not depend on its batch; sampled pairs match the oracle"""
+    B, k = 64, 128
+    batch = synth.make_pair_batch(B, 64, 32, 768, k, sigma=0.1, n_distinct_meshes=2)
+    dev = {n: torch.as_tensor(v).to(eng.device) for n, v in batch.items()}
+    out = eng.match(dev, k=k, check=True)
+    assert out["C"].shape == (B, k, k) and out["knn21"].shape == (B, 2048)
+    for i in (0, 37, 63):
+        one = eng.match({n: v[i:i + 1].contiguous() for n, v in dev.items()}, k=k)
+        assert torch.equal(one["C"][0], out["C"][i])
+        for name in ("knn21", "knn12", "ind21", "ind12"):
+            assert torch.equal(one[name][0], out[name][i]), name
+    assert torch.all(out["C"][:, 1:, 0] == 0)
+    i = 11
+    Co, k21, k12, i21, i12 = orc.match_pair(batch["Phi1"][i], batch["Phi2"][i], batch["lam1"][i], batch["lam2"][i], batch["a1"][i],
+                                            batch["a2"][i], batch["F1"][i], batch["F2"][i])
+    Cg = out["C"][i].cpu().numpy()
+    assert np.abs(Cg - Co).max() <= 1e-4
+    same = orc.fm_to_p2p_all(Cg, batch["Phi1"][i].astype(np.float64), batch["Phi2"][i].astype(np.float64), batch["a1"][i])
+    for got, name in zip(same, ["knn21", "knn12", "ind21", "ind12"]):
+        assert np.array_equal(out[name][i].cpu().numpy(), got), name
+
+
+def test_config4_zoomout_consistency(eng):
+    """N=2048, k 50 -> 200: the fused loop equals its own steps chained by hand (no hidden state)"""
+    B, N, kmax = 2, 2048, 200
+    bases = [synth.random_basis(N, kmax, 10 + i) for i in range(2 * B)]
+    Phi1 = np.stack([b[1] for b in bases[:B]]).astype(np.float32)
+    Phi2 = np.stack([b[1] for b in bases[B:]]).astype(np.float32)
+    a2 = np.stack([b[2] for b in bases[B:]]).astype(np.float32)
+    C0 = np.stack([np.eye(50) + 0.01 * np.random.default_rng(i).standard_normal((50, 50)) for i in range(B)])
+    Cz, pz = eng.zoomout(Phi1, Phi2, a2, C0, nit=150, step=1, return_p2p=True)
+    assert Cz.shape == (B, 200, 200)
+    # the last step by hand: C_199 -> p21 -> C_200
+    C199 = eng.zoomout(Phi1, Phi2, a2, C0, nit=149, step=1)
+    p = eng.fm_to_p2p(Phi1[:, :, :199].copy(), Phi2[:, :, :199].copy(), None, C199, knn=True, ind=False)["knn21"]
+    C200 = eng.p2p_to_fm(p, Phi1, Phi2, a2, 200, 200)
+    assert torch.equal(C200, Cz)
+    p_final = eng.fm_to_p2p(Phi1, Phi2, None, Cz, knn=True, ind=False)["knn21"]
+    assert torch.equal(p_final, pz)
+    # step 10 reaches the same size in 15 iterations
+    C10 = eng.zoomout(Phi1, Phi2, a2, C0, nit=15, step=10)
+    assert C10.shape == (B, 200, 200)
+
+
+def test_config5_large_n_roundtrip(eng):
+    """N=8192, D=384, k=200: permuted copies of a basis map back to the permutation; solver fallback path (n=199)"""
+    B, N, D, k = 4, 8192, 384, 200
+    lam, phi, a = synth.random_basis(N, k, 5)
+    rng = np.random.default_rng(1)
+    perm = np.stack([rng.permutation(N) for _ in range(B)])
+    Phi1 = np.repeat(phi[None].astype(np.float32), B, axis=0)
+    Phi2 = np.stack([phi[perm[b]] for b in range(B)]).astype(np.float32)
+    a1 = np.repeat(a[None].astype(np.float32), B, axis=0)
+    C = np.repeat(np.eye(k)[None], B, axis=0)
+    out = eng.fm_to_p2p(Phi1, Phi2, a1, C)
+    inv = np.empty_like(perm)
+    for b in range(B):
+        inv[b, perm[b]] = np.arange(N)
+    assert np.array_equal(out["knn21"].cpu().numpy(), perm)        # target vertex i is source vertex perm[i]
+    assert np.array_equal(out["knn12"].cpu().numpy(), inv)
+    # full pipeline at this size on 2 pairs: C within 1e-4 of the oracle, maps exact on the same C
+    F1, F2, _ = synth.feature_pair(N, N, D, 1, 2, sigma=0.2, perm="identity")
+    lam2, phi2, a2 = synth.random_basis(N, k, 6)
+    batch = {"Phi1": phi[None].astype(np.float32), "Phi2": phi2[None].astype(np.float32), "lam1": lam[None], "lam2": lam2[None],
+             "a1": a[None].astype(np.float32), "a2": a2[None].astype(np.float32), "F1": F1[None], "F2": F2[None]}
+    res = eng.match({n: torch.as_tensor(v).to(eng.device) for n, v in batch.items()}, k=k, check=True)
+    Co = orc.fit(batch["Phi1"][0], batch["Phi2"][0], lam, lam2, batch["a1"][0], batch["a2"][0], F1, F2, 1e4, 1e3)
+    Cg = res["C"][0].cpu().numpy()
+    assert np.abs(Cg - Co).max() <= 1e-4
+    same = orc.fm_to_p2p_all(Cg, batch["Phi1"][0].astype(np.float64), batch["Phi2"][0].astype(np.float64), batch["a1"][0], chunk=512)
+    for got, name in zip(same, ["knn21", "knn12", "ind21", "ind12"]):
+        assert np.array_equal(res[name][0].cpu().numpy(), got), name
