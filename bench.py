@@ -132,6 +132,7 @@ def main():
         flops_per_launch = tot / 150.0
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
     peak = PEAK_TFLOPS[dtype]
+    traffic = pmc_traffic_bytes(kernel) if args.workload == "fmap" and not args.batch else None
 
     out = {
         "metric": "mesh-pairs/sec at N=2048 D=768 k=128" if args.workload == "fmap" else f"mesh-pairs/sec ({args.workload})",
@@ -140,7 +141,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": w["cfg"], "pairs_per_gpu": B, "N": N, "D": D, "k": k, "parallelism": f"pairs sharded over {world} GPU(s), no collective"},
         "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3) if achieved else None, "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None, "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
+                     "traffic_source": "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_fmap_hbm_traffic_pmc.csv: "
+                                       "2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None,
                      "launches": launches, "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops_per_launch},
     }
 
@@ -150,6 +153,24 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic_bytes(kernel):
+    """HBM bytes per launch of the dominant kernel, measured in separate rocprofv3 --pmc passes of this same command
+    (PMC collection cannot run inside the timed region); summary committed under profiles/."""
+    path = os.path.join(REPO, "profiles", "r01_fmap_hbm_traffic_pmc.csv")
+    key = {"gred_f64": "gred_kernel"}.get(kernel, kernel)
+    try:
+        import csv
+        rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))]
+        hdr = rows[0]
+        for r in rows[1:]:
+            if key in r[0]:
+                d = dict(zip(hdr, r))
+                return int((float(d["fetch_MB_corrected"]) + float(d["write_MB"])) * 1e6)
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(workload, host, k):

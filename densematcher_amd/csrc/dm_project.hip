@@ -36,48 +36,63 @@ __device__ __forceinline__ f16x8 tr_frag(const _Float16* base, int row0, int col
     return r;
 }
 
-// max |mass[n] * Phi[n][m]| per pair -> power-of-two scale.  One 16-lane group per row, float4 per lane when the
-// layout allows it; many workgroups per pair so the 4 MB basis streams at HBM speed.
+// max |mass[n] * Phi[n][c]| per pair -> power-of-two scale.  The basis is streamed as one flat float4 array (all ld
+// columns: entries beyond k can only make the scale more conservative), four loads in flight per thread.
 __global__ __launch_bounds__(256) void proj_absmax_kernel(const float* __restrict__ Phi, const float* __restrict__ mass, int N,
-                                                          int k, int ld, unsigned int* __restrict__ amax) {
+                                                          int ld, float* __restrict__ amax_part) {
     const int b = blockIdx.y;
     const float* P = Phi + (long long)b * N * ld;
     const float* a = mass + (long long)b * N;
-    const int sub = threadIdx.x & 15, rowl = threadIdx.x >> 4;          // 16 rows per pass per workgroup
-    const bool vec = ((ld & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0);
+    const unsigned total = (unsigned)N * (unsigned)ld;           // < 2^31 per pair (checked by the caller)
     float m = 0.f;
-    for (int n = blockIdx.x * 16 + rowl; n < N; n += gridDim.x * 16) {
-        const float an = fabsf(a[n]);
-        const float* row = P + (long long)n * ld;
-        float rm = 0.f;
-        if (vec) {
-            for (int c = sub * 4; c < k; c += 64) {
-                if (c + 3 < k) {
-                    const float4 v = *reinterpret_cast<const float4*>(row + c);
-                    rm = fmaxf(fmaxf(rm, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w)));
-                } else {
-                    for (int e = c; e < k; ++e) rm = fmaxf(rm, fabsf(row[e]));
-                }
+    if (((ld & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {
+        const unsigned nvec = total >> 2, ld4 = (unsigned)ld >> 2;
+        const float4* P4 = reinterpret_cast<const float4*>(P);
+        // each workgroup streams contiguous 16 KiB chunks (4 consecutive float4 per lane would be 64 B per lane; the
+        // four loads of a lane are 4 KiB apart inside the chunk so that every wave instruction is one contiguous KiB):
+        // large power-of-two strides between the loads in flight camp on a few HBM channels
+        for (unsigned c0 = blockIdx.x * 1024; c0 < nvec; c0 += gridDim.x * 1024) {
+            float4 v[4];
+            float an[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned e = c0 + u * 256 + threadIdx.x;
+                const bool ok = e < nvec;
+                v[u] = ok ? P4[e] : float4{0.f, 0.f, 0.f, 0.f};
+                an[u] = ok ? fabsf(a[e / ld4]) : 0.f;              // 32-bit division (a 64-bit one dominated this kernel)
             }
-        } else {
-            for (int c = sub; c < k; c += 16) rm = fmaxf(rm, fabsf(row[c]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = fmaxf(m, an[u] * fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
         }
-        m = fmaxf(m, an * rm);
+    } else {
+        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256)
+            m = fmaxf(m, fabsf(a[e / (unsigned)ld]) * fabsf(P[e]));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax + b, __float_as_uint(m));
+    // one partial per workgroup, no atomics: 16 k same-line atomics serialise (~7 ns each) and took 100 us
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) amax_part[b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
 struct proj_params {
-    const float* Phi; const float* mass; const _Float16* F; const unsigned int* amax;
+    const float* Phi; const float* mass; const _Float16* F; const float* amax_part; int n_part;
     float* partial;          // (nsplit, B, k, D) fp32
     int B, N, D, k, ld, nsplit, kchunk, tiles_m, tiles_d;
 };
 
 __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 3 * PBK * PLD];     // [2 buffers][Xhi | Xlo | F], 60 KiB
-    const int tile = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-aware: the d-tiles that share one (pair, vertex chunk) slab of the basis are neighbours in the
+    // logical order and therefore meet in the same XCD's L2 (otherwise every tile re-fetches the slab from HBM)
+    const int ntile = p.tiles_m * p.tiles_d;
+    const int id = xcd_remap(blockIdx.x, ntile * p.nsplit * p.B);
+    const int tile = id % ntile;
+    const int split = (id / ntile) % p.nsplit;
+    const int b = id / (ntile * p.nsplit);
     const int tm = tile / p.tiles_d, td = tile - tm * p.tiles_d;
     const int m0 = tm * PT, d0 = td * PT;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -85,7 +100,8 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
     const int nbeg = split * p.kchunk, nend = min(p.N, nbeg + p.kchunk);
 
     // scale = 2^e with max |X| * scale in [2^13, 2^14)
-    const float amax = __uint_as_float(p.amax[b]);
+    float amax = 0.f;
+    for (int q = 0; q < p.n_part; ++q) amax = fmaxf(amax, p.amax_part[b * p.n_part + q]);
     int ex = 0;
     if (amax > 0.f) (void)frexpf(amax, &ex);                 // amax = f * 2^ex, f in [0.5, 1)
     const float scale = ldexpf(1.0f, 14 - ex);
@@ -221,15 +237,16 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Ph
     p.kchunk = 512;
     const int nsplit = dm_cdiv(N, p.kchunk);
     p.nsplit = nsplit;
+    if ((long long)N * ld >= (1ll << 31)) return dm_fail(ctx, DM_EINVAL, "dm_project: N * ld must be below 2^31");
     const size_t pbytes = (size_t)nsplit * B * k * D * 4;
-    int rc = dm_ws_reserve(ctx, dm_align_up(pbytes) + 4096);
+    int rc = dm_ws_reserve(ctx, dm_align_up(pbytes) + (size_t)B * 64 * 4 + 4096);
     if (rc) return rc;
     p.partial = (float*)dm_ws_take(ctx, pbytes);
-    unsigned int* amax = (unsigned int*)dm_ws_take(ctx, (size_t)B * 4);
-    p.amax = amax;
-    DM_CHECK_HIP(ctx, hipMemsetAsync(amax, 0, (size_t)B * 4, ctx->stream));
-    DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel, dim3(min(64, dm_cdiv(N, 16)), B), dim3(256), 0, Phi, mass, N, k, ld, amax);
-    DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel, dim3(p.tiles_m * p.tiles_d, nsplit, B), dim3(256), 0, p);
+    const int n_part = max(1, min(64, (int)(((long long)N * ld) / 4096)));
+    float* amax_part = (float*)dm_ws_take(ctx, (size_t)B * n_part * 4);
+    p.amax_part = amax_part; p.n_part = n_part;
+    DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel, dim3(n_part, B), dim3(256), 0, Phi, mass, N, ld, amax_part);
+    DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), 0, p);
     const long long n = (long long)B * k * D;
     DM_LAUNCH(ctx, "project_reduce", proj_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.partial, nsplit, n,
               Ared);

@@ -12,10 +12,12 @@
 // within twice the accumulation error bound  D (1 + 1/16) 2^-23 |t_i| max_j |s_j|  is re-evaluated
 // in float64 (products of fp16 are exact in f64, the f64 sum is exact to 1e-16 relative), so the
 // returned index equals the float64 argmax with the lowest-index tie rule.
+#include <stdlib.h>
+
 #include "dm_device.h"
 #include "dm_internal.h"
 
-constexpr int ST = 128;    // tile: 128 target rows x 128 source rows
+constexpr int ST = 256;    // tile: 256 target rows x 256 source rows per workgroup
 constexpr int SBK = 64;    // contraction (halves) per LDS stage: one 128-byte line per row
 #define DM_NEG_INF_F32 (-__builtin_huge_valf())
 
@@ -37,10 +39,31 @@ struct simnn_params {
     float* tnorm2;                           // (B, N2)  |t_i|^2, written by the workgroups of source tile 0
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
+    int dbg;      // experiments only (env DM_SIMNN_DEBUG): 1 = skip the epilogue, 2 = one K stage only, 3 = no norms
 };
 
-__global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
-    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 2 * ST * SBK];   // T[2] | S[2], 64 KiB
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 struct ends up in scratch as a staging array)
+
+// sum of squares of 8 halves with v_dot2_f32_f16 (fp32 accumulate)
+__device__ __forceinline__ float sumsq8(f16x8 v, float acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f16x2 h = {v[2 * e], v[2 * e + 1]};
+        acc = __builtin_amdgcn_fdot2(h, h, acc, false);
+    }
+    return acc;
+}
+
+// FULL: every workgroup tile is interior and D is a multiple of the stage depth -> the main loop carries no
+// bounds checks and no address arithmetic beyond two pointer bumps.
+//
+// Tile = 256 target rows x 256 source rows per 512-thread workgroup (8 waves = 2 source halves x 4 target quarters,
+// each wave 128 source x 64 target = 4 x 2 MFMA tiles, 128 accumulator registers).  A 128 x 128 tile moves
+// 64 flop per L2 byte, which at the fp16 MFMA rate asks the L2 for more than it can deliver; 256 x 256 halves that.
+template <bool FULL>
+__global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
     _Float16* Ts = smem;
     _Float16* Ss = smem + 2 * ST * SBK;
 
@@ -51,14 +74,14 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
     const int tt_ = tts / p.tilesS, ts_ = tts - tt_ * p.tilesS;
     const int i0 = tt_ * ST, j0 = ts_ * ST;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wt = wave >> 1, ws = wave & 1;
+    const int wsrc = wave & 1, wtgt = wave >> 1;
 
     const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.D;
     const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.D;
 
-    f32x16 acc[2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -66,34 +89,43 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
 
     // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that
     // own the first tile of the other operand (every row of T / S is seen exactly once that way)
-    const bool do_tn = (ts_ == 0) && (ws == 0);
-    const bool do_sn = (tt_ == 0) && (wt == 0);
-    float nrm_t[2] = {0.f, 0.f}, nrm_s[2] = {0.f, 0.f};
+    const bool do_tn = (ts_ == 0) && (wsrc == 0) && p.dbg != 3;
+    const bool do_sn = (tt_ == 0) && (wtgt == 0) && p.dbg != 3;
+    float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const int lrow = t >> 3, lchunk = t & 7;
-    uint4 rt[4], rs[4];
+    const int lrow = t >> 3, lchunk = t & 7;                                   // staging: rows q*64 + lrow, 16-byte chunk lchunk
+    const _Float16* tptr = T + (long long)(i0 + lrow) * p.D + lchunk * 8;
+    const _Float16* sptr = S + (long long)(j0 + lrow) * p.D + lchunk * 8;
+    u32x4 rt[4], rs[4];
     // (macros, not lambdas: by-reference lambda captures of the staging arrays end up in scratch)
 #define SIMNN_FETCH(s_)                                                                                          \
     {                                                                                                            \
-        const int k_ = (s_) * SBK + lchunk * 8;                                                                  \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
-            const int row = q * 32 + lrow;                                                                       \
-            const int gi = i0 + row, gj = j0 + row;                                                              \
-            rt[q] = (gi < p.N2 && k_ < p.D) ? *reinterpret_cast<const uint4*>(T + (long long)gi * p.D + k_)      \
-                                            : uint4{0, 0, 0, 0};                                                 \
-            rs[q] = (gj < p.N1 && k_ < p.D) ? *reinterpret_cast<const uint4*>(S + (long long)gj * p.D + k_)      \
-                                            : uint4{0, 0, 0, 0};                                                 \
+        if (FULL) {                                                                                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+                rt[q] = *reinterpret_cast<const u32x4*>(tptr + (long long)q * 64 * p.D + (s_) * SBK);           \
+                rs[q] = *reinterpret_cast<const u32x4*>(sptr + (long long)q * 64 * p.D + (s_) * SBK);           \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            const int k_ = (s_) * SBK + lchunk * 8;                                                              \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+                const int row = q * 64 + lrow;                                                                   \
+                const int gi = i0 + row, gj = j0 + row;                                                          \
+                rt[q] = (gi < p.N2 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(T + (long long)gi * p.D + k_)  \
+                                                : u32x4{0, 0, 0, 0};                                             \
+                rs[q] = (gj < p.N1 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(S + (long long)gj * p.D + k_)  \
+                                                : u32x4{0, 0, 0, 0};                                             \
+            }                                                                                                    \
         }                                                                                                        \
     }
 #define SIMNN_STASH(buf_)                                                                                        \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
-        const int row = q * 32 + lrow;                                                                           \
+        const int row = q * 64 + lrow;                                                                           \
         const int off = (buf_) * ST * SBK + lds_off_halves(row, lchunk);                                         \
-        *reinterpret_cast<uint4*>(Ts + off) = rt[q];                                                             \
-        *reinterpret_cast<uint4*>(Ss + off) = rs[q];                                                             \
+        *reinterpret_cast<u32x4*>(Ts + off) = rt[q];                                                             \
+        *reinterpret_cast<u32x4*>(Ss + off) = rs[q];                                                             \
     }
 
-    const int ns = (p.D + SBK - 1) / SBK;
+    const int ns = (p.dbg == 2) ? 1 : (p.D + SBK - 1) / SBK;
     SIMNN_FETCH(0)
     SIMNN_STASH(0)
     __syncthreads();
@@ -105,26 +137,23 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
 #pragma unroll
         for (int kk = 0; kk < SBK / 16; ++kk) {
             const int chunk = kk * 2 + (lane >> 5);
-            f16x8 fs[2], ft[2];
+            f16x8 fs[4], ft[2];
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(ws * 64 + x * 32 + (lane & 31), chunk));
-                ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wt * 64 + x * 32 + (lane & 31), chunk));
-            }
+            for (int x = 0; x < 4; ++x)
+                fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(wsrc * 128 + x * 32 + (lane & 31), chunk));
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+                ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wtgt * 64 + x * 32 + (lane & 31), chunk));
             if (do_tn) {
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) nrm_t[x] = fmaf((float)ft[x][e], (float)ft[x][e], nrm_t[x]);
+                for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft[x], nrm_t[x]);
             }
             if (do_sn) {
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) nrm_s[x] = fmaf((float)fs[x][e], (float)fs[x][e], nrm_s[x]);
+                for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs[x], nrm_s[x]);
             }
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < 4; ++st)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
                     acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs[st], ft[tt], acc[st][tt], 0, 0, 0);
@@ -135,20 +164,31 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
 #undef SIMNN_FETCH
 #undef SIMNN_STASH
 
+    if (p.dbg == 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
+        if (sacc == 1.2345f) p.pb[0] = sacc;
+        return;
+    }
     if (do_tn) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
-            const int gi = i0 + wt * 64 + x * 32 + (lane & 31);
+            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
             if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
         }
     }
     if (do_sn) {
         float m = 0.f;
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < 4; ++x) {
             const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
-            const int gj = j0 + ws * 64 + x * 32 + (lane & 31);
+            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
             if (gj < p.N1) m = fmaxf(m, v);
         }
 #pragma unroll
@@ -156,21 +196,21 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
         if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
     }
 
-    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + ws*64 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
-    //                                   i = i0 + wt*64 + tt*32 + (lane&31)
-    float* sb = reinterpret_cast<float*>(smem);          // [2 ws][128]
-    int* sj = reinterpret_cast<int*>(smem) + 2 * 128;
-    float* ss = reinterpret_cast<float*>(smem) + 4 * 128;
+    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
+    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
+    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
+    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
         int bj = DM_IDX_NONE;
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = j0 + ws * 64 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = (j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
+                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
                 // candidates arrive in ascending j: strict > keeps the lowest index on ties
                 const bool up = v > bv;
                 sv = up ? bv : fmaxf(sv, v);
@@ -182,17 +222,184 @@ __global__ __launch_bounds__(256, 2) void simnn_kernel(simnn_params p) {
         const float os = __shfl_xor(sv, 32);
         top2_merge(bv, bj, sv, ob, oj, os);
         if (lane < 32) {
-            const int li = wt * 64 + tt * 32 + lane;
-            sb[ws * 128 + li] = bv; sj[ws * 128 + li] = bj; ss[ws * 128 + li] = sv;
+            const int li = wtgt * 64 + tt * 32 + lane;
+            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
         }
     }
     __syncthreads();
-    if (t < 128) {
+    if (t < ST) {
         const int gi = i0 + t;
         if (gi < p.N2) {
             float bv = sb[t], sv = ss[t];
             int bj = sj[t];
-            top2_merge(bv, bj, sv, sb[128 + t], sj[128 + t], ss[128 + t]);
+            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
+            const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
+            p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
+        }
+    }
+}
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Interior tiles, D % 64 == 0: same tiling as simnn_kernel, operands staged by LDS-DMA.
+__global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
+    constexpr bool FULL = true;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
+    _Float16* Ts = smem;
+    _Float16* Ss = smem + 2 * ST * SBK;
+
+    const int id = xcd_remap(blockIdx.x, p.total);
+    const int tiles = p.tilesT * p.tilesS;
+    const int b = id / tiles;
+    const int tts = id - b * tiles;
+    const int tt_ = tts / p.tilesS, ts_ = tts - tt_ * p.tilesS;
+    const int i0 = tt_ * ST, j0 = ts_ * ST;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wsrc = wave & 1, wtgt = wave >> 1;
+
+    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.D;
+    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.D;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that
+    // own the first tile of the other operand (every row of T / S is seen exactly once that way)
+    const bool do_tn = (ts_ == 0) && (wsrc == 0) && p.dbg != 3;
+    const bool do_sn = (tt_ == 0) && (wtgt == 0) && p.dbg != 3;
+    float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // Staging by LDS-DMA (global_load_lds, 16 B per lane): one instruction fills 8 consecutive 128-byte rows of the
+    // LDS image (wave-uniform base + lane * 16).  The image is swizzled (chunk c of row r lives in slot
+    // c ^ ((r >> 1) & 7)), and since the DMA destination is lane-linear the swizzle is applied to the per-lane
+    // SOURCE address: lane l fills slot (l & 7) of row (l >> 3), so it fetches chunk (l & 7) ^ ((row >> 1) & 7).
+    // Wave w stages row groups 4w .. 4w+3 (8 rows each) of both operands: 8 DMA instructions per stage, no VGPRs,
+    // no ds_write.
+    const int grow = lane >> 3;
+    const _Float16* tsrc[4];
+    const _Float16* ssrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + grow;
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        tsrc[q] = T + (long long)(i0 + row) * p.D + chunk * 8;
+        ssrc[q] = S + (long long)(j0 + row) * p.D + chunk * 8;
+    }
+#define SIMNN_DMA(s_, buf_)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+        const int off = (buf_) * ST * SBK + (wave * 4 + q) * 8 * SBK;                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
+    }
+
+    const int ns = (p.dbg == 2) ? 1 : p.D / SBK;
+    SIMNN_DMA(0, 0)
+    __syncthreads();                       // (the barrier's release waits for the outstanding LDS-DMA: vmcnt(0))
+    // the k loop exists twice: the few workgroups that also accumulate row norms take the second copy, so the hot
+    // copy has no conditional inside a k-step (a branch there splits the basic block and stops the compiler from
+    // interleaving the next ds_reads with the MFMAs)
+#define SIMNN_KLOOP(NORMS)                                                                                             \
+    for (int s = 0; s < ns; ++s) {                                                                                     \
+        const int buf = s & 1;                                                                                         \
+        if (s + 1 < ns) { SIMNN_DMA(s + 1, buf ^ 1) }                                                                  \
+        const _Float16* Tb = Ts + buf * ST * SBK;                                                                      \
+        const _Float16* Sb = Ss + buf * ST * SBK;                                                                      \
+        _Pragma("unroll") for (int kk = 0; kk < SBK / 16; ++kk) {                                                      \
+            const int chunk = kk * 2 + (lane >> 5);                                                                    \
+            f16x8 fs[4], ft[2];                                                                                        \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                              \
+                fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(wsrc * 128 + x * 32 + (lane & 31), chunk)); \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                              \
+                ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wtgt * 64 + x * 32 + (lane & 31), chunk));  \
+            if (NORMS) {                                                                                               \
+                if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft[x], nrm_t[x]); }       \
+                if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs[x], nrm_s[x]); }       \
+            }                                                                                                          \
+            _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                           \
+                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                       \
+                    acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs[st], ft[tt], acc[st][tt], 0, 0, 0);        \
+        }                                                                                                              \
+        __syncthreads();                                                                                               \
+    }
+    if ((ts_ == 0 || tt_ == 0) && p.dbg != 3) { SIMNN_KLOOP(true) } else { SIMNN_KLOOP(false) }
+#undef SIMNN_KLOOP
+#undef SIMNN_DMA
+
+    if (p.dbg == 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
+        if (sacc == 1.2345f) p.pb[0] = sacc;
+        return;
+    }
+    if (do_tn) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
+            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
+            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
+        }
+    }
+    if (do_sn) {
+        float m = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
+            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
+            if (gj < p.N1) m = fmaxf(m, v);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
+    }
+
+    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
+    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
+    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
+    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
+        int bj = DM_IDX_NONE;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
+                // candidates arrive in ascending j: strict > keeps the lowest index on ties
+                const bool up = v > bv;
+                sv = up ? bv : fmaxf(sv, v);
+                bj = up ? j : bj;
+                bv = fmaxf(bv, v);
+            }
+        const float ob = __shfl_xor(bv, 32);
+        const int oj = __shfl_xor(bj, 32);
+        const float os = __shfl_xor(sv, 32);
+        top2_merge(bv, bj, sv, ob, oj, os);
+        if (lane < 32) {
+            const int li = wtgt * 64 + tt * 32 + lane;
+            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
+        }
+    }
+    __syncthreads();
+    if (t < ST) {
+        const int gi = i0 + t;
+        if (gi < p.N2) {
+            float bv = sb[t], sv = ss[t];
+            int bj = sj[t];
+            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
             const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
             p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
         }
@@ -253,9 +460,9 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
         for (int ts = 0; ts < tilesS; ++ts) {
             const float tb = pb[((long long)b * tilesS + ts) * N2pad + i];
             if (!(tb >= thr)) continue;                       // uniform: every thread reads the same word
-            // wave w re-scores candidates [ts*128 + w*32, +32) in ascending order
-            for (int q = 0; q < 32; ++q) {
-                const int j = ts * ST + wave * 32 + q;
+            // wave w re-scores candidates [ts*ST + w*ST/4, +ST/4) in ascending order
+            for (int q = 0; q < ST / 4; ++q) {
+                const int j = ts * ST + wave * (ST / 4) + q;
                 if (j >= N1) break;
                 const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
                 double s = 0.0;
@@ -297,6 +504,7 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     p.N2 = N2; p.N1 = N1; p.D = D; p.N2pad = pad_to(N2, ST);
     p.tilesT = p.N2pad / ST; p.tilesS = dm_cdiv(N1, ST);
     p.total = B * p.tilesT * p.tilesS;
+    { const char* e = getenv("DM_SIMNN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     const size_t np = (size_t)B * p.tilesS * p.N2pad;
     const size_t need = 3 * dm_align_up(np * 4) + dm_align_up((size_t)B * N2 * 4) * 3 + dm_align_up((size_t)B * 4) + 8192;
     int rc = dm_ws_reserve(ctx, need);
@@ -312,7 +520,17 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(p.smax2, 0, (size_t)B * 4, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
-    DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_kernel, dim3(p.total), dim3(256), 0, p);
+    const size_t lds_main = (size_t)2 * 2 * ST * SBK * sizeof(_Float16);       // 128 KiB
+    static bool lds_main_set = false;
+    if (!lds_main_set) {
+        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+        lds_main_set = true;
+    }
+    if (N2 % ST == 0 && N1 % ST == 0 && D % SBK == 0)
+        DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel, dim3(p.total), dim3(512), lds_main, p);
+    else
+        DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_kernel<false>, dim3(p.total), dim3(512), lds_main, p);
     // twice the fp32 accumulation bound: D exact products, D (1 + 1/16) additions, unit roundoff 2^-23
     // (safe for round-to-nearest and for truncating adders), 1 % slack for the fp32 norms
     const float tau_scale = 2.0f * 1.01f * (float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f;
