@@ -36,6 +36,8 @@ __device__ __forceinline__ int lds_off_halves(int row, int chunk) {
 struct simnn_params {
     const _Float16* Ftgt; const _Float16* Fsrc;
     float* pb; int32_t* pj; float* ps;       // partials (B, tilesS, N2pad)
+    float* pb32;                             // (B, N1pad/32, N2pad) fp32 maximum over each block of 32 source rows (fix-up filter)
+    int nsub;                                // N1pad / 32
     float* tnorm2;                           // (B, N2)  |t_i|^2, written by the workgroups of source tile 0
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
         float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
         int bj = DM_IDX_NONE;
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int st = 0; st < 4; ++st) {
+            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -216,7 +219,13 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
                 sv = up ? bv : fmaxf(sv, v);
                 bj = up ? j : bj;
                 bv = fmaxf(bv, v);
+                m32 = fmaxf(m32, v);
             }
+            m32 = fmaxf(m32, __shfl_xor(m32, 32));
+            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
+            if (lane < 32 && gi32 < p.N2)
+                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
+        }
         const float ob = __shfl_xor(bv, 32);
         const int oj = __shfl_xor(bj, 32);
         const float os = __shfl_xor(sv, 32);
@@ -373,7 +382,8 @@ __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
         float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
         int bj = DM_IDX_NONE;
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
+        for (int st = 0; st < 4; ++st) {
+            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -383,7 +393,13 @@ __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
                 sv = up ? bv : fmaxf(sv, v);
                 bj = up ? j : bj;
                 bv = fmaxf(bv, v);
+                m32 = fmaxf(m32, v);
             }
+            m32 = fmaxf(m32, __shfl_xor(m32, 32));
+            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
+            if (lane < 32 && gi32 < p.N2)
+                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
+        }
         const float ob = __shfl_xor(bv, 32);
         const int oj = __shfl_xor(bj, 32);
         const float os = __shfl_xor(sv, 32);
@@ -435,10 +451,12 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restric
 }
 
 // float64 re-evaluation of the flagged rows: one workgroup per flagged row (grid-stride over the list).  Only the
-// source tiles whose fp32 tile maximum reaches (best - tau) can contain the float64 argmax (every fp32 score is
-// within tau/2 of the exact one); their 128 candidates are re-scored exactly: fp16 products are exact in f64.
+// blocks of 32 source rows whose fp32 maximum reaches (best - tau) can contain the float64 argmax (every fp32 score
+// is within tau/2 of the exact one).  Such a block is re-scored exactly by the whole workgroup: 8 lanes per
+// candidate, each wave instruction reads 8 x 128 contiguous bytes (fully used cache lines); fp16 products are exact
+// in f64 and the summation order is fixed, so duplicated rows give identical scores and the lowest index wins.
 __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __restrict__ Ftgt, const _Float16* __restrict__ Fsrc,
-                                                          int N2, int N1, int D, const float* __restrict__ pb, int tilesS,
+                                                          int N2, int N1, int D, const float* __restrict__ pb32, int nsub,
                                                           int N2pad, const int32_t* __restrict__ flag_count,
                                                           const int32_t* __restrict__ flag_list,
                                                           const float* __restrict__ flag_thr, int32_t* __restrict__ nn) {
@@ -447,6 +465,7 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
     int* wj = reinterpret_cast<int*>(wv + 4);
     const int count = *flag_count;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cand = threadIdx.x >> 3, part = threadIdx.x & 7;       // 32 candidates x 8 lanes
     for (int e = blockIdx.x; e < count; e += gridDim.x) {
         const int o = flag_list[e];
         const float thr = flag_thr[e];
@@ -457,31 +476,37 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
         __syncthreads();
         double bv = -DM_INF_F64;
         int bj = DM_IDX_NONE;
-        for (int ts = 0; ts < tilesS; ++ts) {
-            const float tb = pb[((long long)b * tilesS + ts) * N2pad + i];
+        for (int sb = 0; sb < nsub; ++sb) {
+            const float tb = pb32[((long long)b * nsub + sb) * N2pad + i];
             if (!(tb >= thr)) continue;                       // uniform: every thread reads the same word
-            // wave w re-scores candidates [ts*ST + w*ST/4, +ST/4) in ascending order
-            for (int q = 0; q < ST / 4; ++q) {
-                const int j = ts * ST + wave * (ST / 4) + q;
-                if (j >= N1) break;
+            const int j = sb * 32 + cand;
+            double sacc = 0.0;
+            if (j < N1) {
                 const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
-                double s = 0.0;
-                for (int k = lane * 8; k < D; k += 512) {
+                for (int k = part * 8; k < D; k += 64) {      // D % 8 == 0 is guaranteed by the caller
                     const f16x8 v = *reinterpret_cast<const f16x8*>(sr + k);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) s = fma((double)v[u], trow[k + u], s);
+                    for (int u = 0; u < 8; ++u) sacc = fma((double)v[u], trow[k + u], sacc);
                 }
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                if (s > bv) { bv = s; bj = j; }               // ascending j within the wave: strict keeps the lowest
             }
+            sacc += __shfl_xor(sacc, 1);
+            sacc += __shfl_xor(sacc, 2);
+            sacc += __shfl_xor(sacc, 4);
+            if (j < N1 && sacc > bv) { bv = sacc; bj = j; }   // blocks ascend: strict keeps the lowest index
+        }
+        // (all 8 lanes of a candidate hold the same pair; merge over the candidates of the workgroup)
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const double ov = __shfl_xor(bv, off);
+            const int oj = __shfl_xor(bj, off);
+            argmax_merge(bv, bj, ov, oj);
         }
         if (lane == 0) { wv[wave] = bv; wj[wave] = bj; }
         __syncthreads();
         if (threadIdx.x == 0) {
             double v = wv[0];
             int j = wj[0];
-            for (int w = 1; w < 4; ++w) argmax_merge(v, j, wv[w], wj[w]);   // index tie-break: waves interleave tiles
+            for (int w = 1; w < 4; ++w) argmax_merge(v, j, wv[w], wj[w]);
             if (j != DM_IDX_NONE) nn[o] = j;
         }
     }
@@ -506,12 +531,16 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     p.total = B * p.tilesT * p.tilesS;
     { const char* e = getenv("DM_SIMNN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     const size_t np = (size_t)B * p.tilesS * p.N2pad;
-    const size_t need = 3 * dm_align_up(np * 4) + dm_align_up((size_t)B * N2 * 4) * 3 + dm_align_up((size_t)B * 4) + 8192;
+    p.nsub = p.tilesS * (ST / 32);
+    const size_t np32 = (size_t)B * p.nsub * p.N2pad;
+    const size_t need = 3 * dm_align_up(np * 4) + dm_align_up(np32 * 4) + dm_align_up((size_t)B * N2 * 4) * 3 +
+                        dm_align_up((size_t)B * 4) + 8192;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     p.pb = (float*)dm_ws_take(ctx, np * 4);
     p.pj = (int32_t*)dm_ws_take(ctx, np * 4);
     p.ps = (float*)dm_ws_take(ctx, np * 4);
+    p.pb32 = (float*)dm_ws_take(ctx, np32 * 4);
     p.tnorm2 = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* flag_list = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* flag_thr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
@@ -544,6 +573,6 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
         lds_set = lds;
     }
     DM_LAUNCH(ctx, "simnn_fixup_f64", simnn_fixup_kernel, dim3(2048), dim3(256), lds, (const _Float16*)Ftgt,
-              (const _Float16*)Fsrc, N2, N1, D, p.pb, p.tilesS, p.N2pad, flag_count, flag_list, flag_thr, nn21);
+              (const _Float16*)Fsrc, N2, N1, D, p.pb32, p.nsub, p.N2pad, flag_count, flag_list, flag_thr, nn21);
     return DM_OK;
 }
