@@ -422,6 +422,206 @@ __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
     }
 }
 
+// Phased variant of simnn_glds_kernel (experiment, DM_SIMNN_PHASED=1).  Every k-step is split in a LOAD part
+// (LDS-DMA pieces of the next stage + the six fragment reads) and an MFMA part, each closed by a raw s_barrier; the
+// second wave group (waves 4-7, one per SIMD like waves 0-3) runs one barrier behind the first, so on every SIMD one
+// wave is in its MFMA part while the other is in its LOAD part (cdna_hip_programming.md T3/T5).
+__global__ __launch_bounds__(512, 2) void simnn_phased_kernel(simnn_params p) {
+    constexpr bool FULL = true;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
+    _Float16* Ts = smem;
+    _Float16* Ss = smem + 2 * ST * SBK;
+
+    const int id = xcd_remap(blockIdx.x, p.total);
+    const int tiles = p.tilesT * p.tilesS;
+    const int b = id / tiles;
+    const int tts = id - b * tiles;
+    const int tt_ = tts / p.tilesS, ts_ = tts - tt_ * p.tilesS;
+    const int i0 = tt_ * ST, j0 = ts_ * ST;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wsrc = wave & 1, wtgt = wave >> 1;
+
+    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.D;
+    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.D;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that
+    // own the first tile of the other operand (every row of T / S is seen exactly once that way)
+    const bool do_tn = (ts_ == 0) && (wsrc == 0) && p.dbg != 3;
+    const bool do_sn = (tt_ == 0) && (wtgt == 0) && p.dbg != 3;
+    float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // Staging by LDS-DMA (global_load_lds, 16 B per lane): one instruction fills 8 consecutive 128-byte rows of the
+    // LDS image (wave-uniform base + lane * 16).  The image is swizzled (chunk c of row r lives in slot
+    // c ^ ((r >> 1) & 7)), and since the DMA destination is lane-linear the swizzle is applied to the per-lane
+    // SOURCE address: lane l fills slot (l & 7) of row (l >> 3), so it fetches chunk (l & 7) ^ ((row >> 1) & 7).
+    // Wave w stages row groups 4w .. 4w+3 (8 rows each) of both operands: 8 DMA instructions per stage, no VGPRs,
+    // no ds_write.
+    const int grow = lane >> 3;
+    const _Float16* tsrc[4];
+    const _Float16* ssrc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + grow;
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        tsrc[q] = T + (long long)(i0 + row) * p.D + chunk * 8;
+        ssrc[q] = S + (long long)(j0 + row) * p.D + chunk * 8;
+    }
+#define SIMNN_DMA(s_, buf_)                                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
+        const int off = (buf_) * ST * SBK + (wave * 4 + q) * 8 * SBK;                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
+    }
+
+    const int ns = (p.dbg == 2) ? 1 : p.D / SBK;
+    const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
+    SIMNN_DMA(0, 0)
+    __syncthreads();                       // (waits for the LDS-DMA: vmcnt(0))
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 is one barrier behind from here on
+#define SIMNN_DMA1P(s_, buf_, q)                                                                                 \
+    {                                                                                                            \
+        const int off = (buf_) * ST * SBK + (wave * 4 + (q)) * 8 * SBK;                                          \
+        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
+    }
+#define SIMNN_DMA2(s_, buf_, q0)                                                                                 \
+    _Pragma("unroll") for (int q = (q0); q < (q0) + 2; ++q) {                                                    \
+        const int off = (buf_) * ST * SBK + (wave * 4 + q) * 8 * SBK;                                            \
+        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
+    }
+#define SIMNN_KLOOP(NORMS)                                                                                             \
+    for (int s = 0; s < ns; ++s) {                                                                                     \
+        const int buf = s & 1;                                                                                         \
+        const bool more = s + 1 < ns;                                                                                  \
+        const _Float16* Tb = Ts + buf * ST * SBK;                                                                      \
+        const _Float16* Sb = Ss + buf * ST * SBK;                                                                      \
+        _Pragma("unroll") for (int kk = 0; kk < SBK / 16; ++kk) {                                                      \
+            /* ---- LOAD part */                                                                                       \
+            if (kk < 2 && more) { SIMNN_DMA2(s + 1, buf ^ 1, kk * 2) }                                                 \
+            const int chunk = kk * 2 + (lane >> 5);                                                                    \
+            f16x8 fs[4], ft[2];                                                                                        \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                              \
+                fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(wsrc * 128 + x * 32 + (lane & 31), chunk)); \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                              \
+                ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wtgt * 64 + x * 32 + (lane & 31), chunk));  \
+            if (kk == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            /* ---- MFMA part */                                                                                       \
+            if (NORMS) {                                                                                               \
+                if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft[x], nrm_t[x]); }       \
+                if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs[x], nrm_s[x]); }       \
+            }                                                                                                          \
+            __builtin_amdgcn_s_setprio(1);                                                                             \
+            _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                           \
+                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                       \
+                    acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs[st], ft[tt], acc[st][tt], 0, 0, 0);        \
+            __builtin_amdgcn_s_setprio(0);                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            __builtin_amdgcn_s_barrier();                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+        }                                                                                                              \
+    }
+    if ((ts_ == 0 || tt_ == 0) && p.dbg != 3) { SIMNN_KLOOP(true) } else { SIMNN_KLOOP(false) }
+#undef SIMNN_KLOOP
+#undef SIMNN_DMA2
+#undef SIMNN_DMA1P
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // re-align the two groups
+    __syncthreads();
+#undef SIMNN_DMA
+
+    if (p.dbg == 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
+        if (sacc == 1.2345f) p.pb[0] = sacc;
+        return;
+    }
+    if (do_tn) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
+            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
+            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
+        }
+    }
+    if (do_sn) {
+        float m = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
+            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
+            if (gj < p.N1) m = fmaxf(m, v);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
+    }
+
+    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
+    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
+    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
+    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
+        int bj = DM_IDX_NONE;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
+                // candidates arrive in ascending j: strict > keeps the lowest index on ties
+                const bool up = v > bv;
+                sv = up ? bv : fmaxf(sv, v);
+                bj = up ? j : bj;
+                bv = fmaxf(bv, v);
+                m32 = fmaxf(m32, v);
+            }
+            m32 = fmaxf(m32, __shfl_xor(m32, 32));
+            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
+            if (lane < 32 && gi32 < p.N2)
+                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
+        }
+        const float ob = __shfl_xor(bv, 32);
+        const int oj = __shfl_xor(bj, 32);
+        const float os = __shfl_xor(sv, 32);
+        top2_merge(bv, bj, sv, ob, oj, os);
+        if (lane < 32) {
+            const int li = wtgt * 64 + tt * 32 + lane;
+            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
+        }
+    }
+    __syncthreads();
+    if (t < ST) {
+        const int gi = i0 + t;
+        if (gi < p.N2) {
+            float bv = sb[t], sv = ss[t];
+            int bj = sj[t];
+            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
+            const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
+            p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restrict__ pb, const int32_t* __restrict__ pj,
                                                           const float* __restrict__ ps, int tilesS, int N2, int N2pad,
                                                           const float* __restrict__ tnorm2, const unsigned int* __restrict__ smax2,
@@ -556,8 +756,17 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
         DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
         lds_main_set = true;
     }
-    if (N2 % ST == 0 && N1 % ST == 0 && D % SBK == 0)
-        DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel, dim3(p.total), dim3(512), lds_main, p);
+    if (N2 % ST == 0 && N1 % ST == 0 && D % SBK == 0) {
+        static bool phased_set = false;
+        if (!phased_set) {
+            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_phased_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+            phased_set = true;
+        }
+        const char* pe = getenv("DM_SIMNN_PHASED");
+        const int phased = pe ? atoi(pe) : 0;
+        if (phased) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_phased_kernel, dim3(p.total), dim3(512), lds_main, p);
+        else DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel, dim3(p.total), dim3(512), lds_main, p);
+    }
     else
         DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_kernel<false>, dim3(p.total), dim3(512), lds_main, p);
     // twice the fp32 accumulation bound: D exact products, D (1 + 1/16) additions, unit roundoff 2^-23
