@@ -111,6 +111,7 @@ struct gred_params {
     double* rv_knn; int32_t* rj_knn; double* rv_ind; int32_t* rj_ind;   // (B, tilesN, N2pad)
     double* cv_knn; int32_t* ci_knn; double* cv_ind; int32_t* ci_ind;   // (B, tilesM, N1pad)
     int N2, N1, N2pad, N1pad, Kpad, Kloop, tilesM, tilesN, total;
+    int prio;     // raise the wave priority during the MFMA main loop
     int stagger;  // number of s_sleep(127) the odd-slot workgroups of the first round wait (0 = off)
     int dbg;      // experiments only (env DM_GRED_DEBUG): 1 = skip the reduction epilogue, 2 = skip the MFMA main loop
 };
@@ -325,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     }
 
     const int ns = (p.dbg == 2) ? 1 : p.Kloop / GBK;
+    // the MFMA main loop outranks the co-resident workgroup's VALU epilogue at the issue port (the two workgroups of a
+    // CU are kept in opposite phases, see `stagger`)
+    if (p.prio) __builtin_amdgcn_s_setprio(2);
     GRED_FETCH(0)
     GRED_STASH(0)
     __syncthreads();
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     }
 #undef GRED_FETCH
 #undef GRED_STASH
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
 
     if (p.dbg == 1) {
         double sacc = 0.0;
@@ -438,6 +443,7 @@ int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a) {
     p.total = a.B * p.tilesM * p.tilesN;
     { const char* e = getenv("DM_GRED_DEBUG"); p.dbg = e ? atoi(e) : 0; }
     { const char* e = getenv("DM_GRED_STAGGER"); p.stagger = e ? atoi(e) : 2; }
+    { const char* e = getenv("DM_GRED_PRIO"); p.prio = e ? atoi(e) : 1; }
     // two instantiations: all four reductions (needs n1, n2, mass1) or the row arg-min knn21 alone (needs n1)
     const bool all = a.knn12 || a.ind21 || a.ind12;
     if (!a.n1 || (all && (!a.n2 || !a.mass1)))
