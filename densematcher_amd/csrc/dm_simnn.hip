@@ -57,6 +57,86 @@ __device__ __forceinline__ float sumsq8(f16x8 v, float acc) {
     return acc;
 }
 
+// Shared epilogue: row norms, top-2 reduction of the accumulators over the tile's 256 source rows, 32-row block
+// maxima for the fix-up filter.  Reuses the start of the staging LDS as scratch (callers synchronise before).
+//   acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+//                                     i = i0 + wtgt*64 + tt*32 + (lane&31)
+template <bool FULL>
+__device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
+                                           bool do_tn, bool do_sn, int b, int i0, int j0, int ts_, _Float16* smem) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wsrc = wave & 1, wtgt = wave >> 1;
+    if (do_tn) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
+            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
+            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
+        }
+    }
+    if (do_sn) {
+        float m = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
+            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
+            if (gj < p.N1) m = fmaxf(m, v);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
+    }
+
+    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
+    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
+    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
+    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
+    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
+        int bj = DM_IDX_NONE;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
+                // candidates arrive in ascending j: strict > keeps the lowest index on ties
+                const bool up = v > bv;
+                sv = up ? bv : fmaxf(sv, v);
+                bj = up ? j : bj;
+                bv = fmaxf(bv, v);
+                m32 = fmaxf(m32, v);
+            }
+            m32 = fmaxf(m32, __shfl_xor(m32, 32));
+            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
+            if (lane < 32 && gi32 < p.N2)
+                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
+        }
+        const float ob = __shfl_xor(bv, 32);
+        const int oj = __shfl_xor(bj, 32);
+        const float os = __shfl_xor(sv, 32);
+        top2_merge(bv, bj, sv, ob, oj, os);
+        if (lane < 32) {
+            const int li = wtgt * 64 + tt * 32 + lane;
+            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
+        }
+    }
+    __syncthreads();
+    if (t < ST) {
+        const int gi = i0 + t;
+        if (gi < p.N2) {
+            float bv = sb[t], sv = ss[t];
+            int bj = sj[t];
+            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
+            const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
+            p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
+        }
+    }
+}
+
 // FULL: every workgroup tile is interior and D is a multiple of the stage depth -> the main loop carries no
 // bounds checks and no address arithmetic beyond two pointer bumps.
 //
@@ -177,81 +257,17 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
         if (sacc == 1.2345f) p.pb[0] = sacc;
         return;
     }
-    if (do_tn) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
-            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
-            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
-        }
-    }
-    if (do_sn) {
-        float m = 0.f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
-            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
-            if (gj < p.N1) m = fmaxf(m, v);
-        }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
-    }
-
-    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
-    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
-    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
-    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
-    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
-        int bj = DM_IDX_NONE;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
-                // candidates arrive in ascending j: strict > keeps the lowest index on ties
-                const bool up = v > bv;
-                sv = up ? bv : fmaxf(sv, v);
-                bj = up ? j : bj;
-                bv = fmaxf(bv, v);
-                m32 = fmaxf(m32, v);
-            }
-            m32 = fmaxf(m32, __shfl_xor(m32, 32));
-            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
-            if (lane < 32 && gi32 < p.N2)
-                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
-        }
-        const float ob = __shfl_xor(bv, 32);
-        const int oj = __shfl_xor(bj, 32);
-        const float os = __shfl_xor(sv, 32);
-        top2_merge(bv, bj, sv, ob, oj, os);
-        if (lane < 32) {
-            const int li = wtgt * 64 + tt * 32 + lane;
-            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
-        }
-    }
-    __syncthreads();
-    if (t < ST) {
-        const int gi = i0 + t;
-        if (gi < p.N2) {
-            float bv = sb[t], sv = ss[t];
-            int bj = sj[t];
-            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
-            const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
-            p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
-        }
-    }
+    simnn_tail<FULL>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, smem);
 }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Interior tiles, D % 64 == 0: same tiling as simnn_kernel, operands staged by LDS-DMA.
+// EXP (experiments, env DM_SIMNN_EXP with DM_SIMNN_PIPE=0): 0 = product kernel; 3 = MFMA only (no LDS-DMA, no fragment
+// reads in the loop); 7 = LDS-DMA only (no MFMA, no fragment reads).  3 and 7 give wrong results and exist to bound
+// the main loop from both sides.
+template <int EXP>
 __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
     constexpr bool FULL = true;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
@@ -313,26 +329,30 @@ __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
     // the k loop exists twice: the few workgroups that also accumulate row norms take the second copy, so the hot
     // copy has no conditional inside a k-step (a branch there splits the basic block and stops the compiler from
     // interleaving the next ds_reads with the MFMAs)
+    f16x8 fs[4], ft[2];
 #define SIMNN_KLOOP(NORMS)                                                                                             \
     for (int s = 0; s < ns; ++s) {                                                                                     \
         const int buf = s & 1;                                                                                         \
-        if (s + 1 < ns) { SIMNN_DMA(s + 1, buf ^ 1) }                                                                  \
+        if (s + 1 < ns && EXP != 3) { SIMNN_DMA(s + 1, buf ^ 1) }                                                      \
         const _Float16* Tb = Ts + buf * ST * SBK;                                                                      \
         const _Float16* Sb = Ss + buf * ST * SBK;                                                                      \
         _Pragma("unroll") for (int kk = 0; kk < SBK / 16; ++kk) {                                                      \
             const int chunk = kk * 2 + (lane >> 5);                                                                    \
-            f16x8 fs[4], ft[2];                                                                                        \
+            if ((EXP != 3 && EXP != 7) || (s == 0 && kk == 0)) {                                                       \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                              \
                 fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(wsrc * 128 + x * 32 + (lane & 31), chunk)); \
             _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                              \
                 ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wtgt * 64 + x * 32 + (lane & 31), chunk));  \
+            }                                                                                                          \
             if (NORMS) {                                                                                               \
                 if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft[x], nrm_t[x]); }       \
                 if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs[x], nrm_s[x]); }       \
             }                                                                                                          \
+            if (EXP != 7 || s == 0) {                                                                                  \
             _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                           \
                 _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                       \
                     acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs[st], ft[tt], acc[st][tt], 0, 0, 0);        \
+            }                                                                                                          \
         }                                                                                                              \
         __syncthreads();                                                                                               \
     }
@@ -351,86 +371,27 @@ __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
         if (sacc == 1.2345f) p.pb[0] = sacc;
         return;
     }
-    if (do_tn) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
-            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
-            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
-        }
-    }
-    if (do_sn) {
-        float m = 0.f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
-            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
-            if (gj < p.N1) m = fmaxf(m, v);
-        }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
-    }
-
-    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
-    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
-    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
-    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
-    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
-        int bj = DM_IDX_NONE;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
-                // candidates arrive in ascending j: strict > keeps the lowest index on ties
-                const bool up = v > bv;
-                sv = up ? bv : fmaxf(sv, v);
-                bj = up ? j : bj;
-                bv = fmaxf(bv, v);
-                m32 = fmaxf(m32, v);
-            }
-            m32 = fmaxf(m32, __shfl_xor(m32, 32));
-            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
-            if (lane < 32 && gi32 < p.N2)
-                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
-        }
-        const float ob = __shfl_xor(bv, 32);
-        const int oj = __shfl_xor(bj, 32);
-        const float os = __shfl_xor(sv, 32);
-        top2_merge(bv, bj, sv, ob, oj, os);
-        if (lane < 32) {
-            const int li = wtgt * 64 + tt * 32 + lane;
-            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
-        }
-    }
-    __syncthreads();
-    if (t < ST) {
-        const int gi = i0 + t;
-        if (gi < p.N2) {
-            float bv = sb[t], sv = ss[t];
-            int bj = sj[t];
-            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
-            const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
-            p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
-        }
-    }
+    simnn_tail<FULL>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, smem);
 }
 
-// Phased variant of simnn_glds_kernel (experiment, DM_SIMNN_PHASED=1).  Every k-step is split in a LOAD part
-// (LDS-DMA pieces of the next stage + the six fragment reads) and an MFMA part, each closed by a raw s_barrier; the
-// second wave group (waves 4-7, one per SIMD like waves 0-3) runs one barrier behind the first, so on every SIMD one
-// wave is in its MFMA part while the other is in its LOAD part (cdna_hip_programming.md T3/T5).
-__global__ __launch_bounds__(512, 2) void simnn_phased_kernel(simnn_params p) {
+// Deep-pipelined variant (default for interior tiles, D % 32 == 0).  Same 256 x 256 tile and wave layout as
+// simnn_glds_kernel, but the contraction is staged 32 halves at a time through a ring of FOUR 32 KiB LDS buffers and
+// the LDS-DMA of stage s+3 is issued while stage s is computed: a first-touch miss (HBM / Infinity Cache, ~2 us under
+// load; every tile has some because one pair's operands, 6 MB, exceed an XCD's 4 MB L2) then has three stages to
+// land instead of one.  The wait before each barrier is a COUNTED vmcnt (the two younger stages stay in flight).
+//
+// LDS image of one operand stage: 256 rows x 64 B; chunk c (16 B) of row r lives in slot c ^ ((r >> 2) & 3), so the
+// 16 rows of a ds_read_b128 lane group (four runs of 4 consecutive rows with distinct (r >> 2) & 3) cover all 16
+// slots of the 256-byte bank row.  One DMA instruction fills 16 rows (lane l -> row l >> 2, slot l & 3), the swizzle
+// is applied on the source address.
+constexpr int PBK = 32;                    // halves per stage
+constexpr int PNBUF = 4;                   // ring depth
+constexpr int PSTAGE = 2 * ST * PBK;       // halves per ring slot: T image then S image
+#define DM_WAITCNT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15))     /* vmcnt(n), lgkmcnt / expcnt untouched */
+template <int EXP>
+__global__ __launch_bounds__(512, 2) void simnn_pipe_kernel(simnn_params p) {
     constexpr bool FULL = true;
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
-    _Float16* Ts = smem;
-    _Float16* Ss = smem + 2 * ST * SBK;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // 4 x (T 16 KiB | S 16 KiB)
 
     const int id = xcd_remap(blockIdx.x, p.total);
     const int tiles = p.tilesT * p.tilesS;
@@ -452,93 +413,108 @@ __global__ __launch_bounds__(512, 2) void simnn_phased_kernel(simnn_params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that
-    // own the first tile of the other operand (every row of T / S is seen exactly once that way)
     const bool do_tn = (ts_ == 0) && (wsrc == 0) && p.dbg != 3;
     const bool do_sn = (tt_ == 0) && (wtgt == 0) && p.dbg != 3;
     float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
 
-    // Staging by LDS-DMA (global_load_lds, 16 B per lane): one instruction fills 8 consecutive 128-byte rows of the
-    // LDS image (wave-uniform base + lane * 16).  The image is swizzled (chunk c of row r lives in slot
-    // c ^ ((r >> 1) & 7)), and since the DMA destination is lane-linear the swizzle is applied to the per-lane
-    // SOURCE address: lane l fills slot (l & 7) of row (l >> 3), so it fetches chunk (l & 7) ^ ((row >> 1) & 7).
-    // Wave w stages row groups 4w .. 4w+3 (8 rows each) of both operands: 8 DMA instructions per stage, no VGPRs,
-    // no ds_write.
-    const int grow = lane >> 3;
-    const _Float16* tsrc[4];
-    const _Float16* ssrc[4];
+    // wave w stages rows 32w .. 32w+31 of both operands: 4 DMA instructions per stage
+    const _Float16* tsrc[2];
+    const _Float16* ssrc[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + grow;
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    for (int q = 0; q < 2; ++q) {
+        const int row = wave * 32 + q * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
         tsrc[q] = T + (long long)(i0 + row) * p.D + chunk * 8;
         ssrc[q] = S + (long long)(j0 + row) * p.D + chunk * 8;
     }
-#define SIMNN_DMA(s_, buf_)                                                                                      \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
-        const int off = (buf_) * ST * SBK + (wave * 4 + q) * 8 * SBK;                                            \
-        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
-    }
-
-    const int ns = (p.dbg == 2) ? 1 : p.D / SBK;
-    const int grp = __builtin_amdgcn_readfirstlane(wave) >> 2;
-    SIMNN_DMA(0, 0)
-    __syncthreads();                       // (waits for the LDS-DMA: vmcnt(0))
-    if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 is one barrier behind from here on
-#define SIMNN_DMA1P(s_, buf_, q)                                                                                 \
+#define SIMNN_DMA1(s_, q)                                                                                        \
     {                                                                                                            \
-        const int off = (buf_) * ST * SBK + (wave * 4 + (q)) * 8 * SBK;                                          \
-        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
+        _Float16* dst = smem + ((s_) & (PNBUF - 1)) * PSTAGE + (wave * 32 + (q) * 16) * PBK;                     \
+        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * PBK), (lptr_t)dst, 16, 0, 0);                \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * PBK), (lptr_t)(dst + ST * PBK), 16, 0, 0);   \
     }
-#define SIMNN_DMA2(s_, buf_, q0)                                                                                 \
-    _Pragma("unroll") for (int q = (q0); q < (q0) + 2; ++q) {                                                    \
-        const int off = (buf_) * ST * SBK + (wave * 4 + q) * 8 * SBK;                                            \
-        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
+#define SIMNN_DMA(s_) SIMNN_DMA1(s_, 0) SIMNN_DMA1(s_, 1)
+
+    // fragment addresses: row (lane & 31) of a 32-row block, chunk kk*2 + (lane >> 5); the swizzle term depends on
+    // the lane only, and kk = 1 flips bit 1 of the slot
+    const int swz = (lane >> 2) & 3;
+    const int c0 = (lane >> 5) ^ swz;
+    const int frow = (lane & 31) * PBK;
+    const int foff0 = frow + (c0 << 3), foff1 = frow + ((c0 ^ 2) << 3);
+    const int sbase = ST * PBK + wsrc * 128 * PBK, tbase = wtgt * 64 * PBK;
+
+    const int ns = (p.dbg == 2) ? 3 : p.D / PBK;                 // >= 3 (host checks D >= 96)
+    SIMNN_DMA(0)
+    SIMNN_DMA(1)
+    SIMNN_DMA(2)
+    DM_WAITCNT_VM(8);                                            // stage 0 has landed; stages 1, 2 in flight
+    __builtin_amdgcn_s_barrier();
+
+    // The loop is rotated by half a stage: the barrier that publishes stage s+1 sits between the two k-steps of
+    // stage s, so the first fragments of stage s+1 are fetched under the MFMAs of (s, kk=1) and no fragment read is
+    // exposed after a barrier.  Ring slot (s+3)&3 == (s-1)&3 was last read by the (s-1, kk=1) fragments, complete
+    // (lgkmcnt(0)) before the barrier of iteration s-1, which every wave has left before iteration s starts.
+    f16x8 fsa[4], fta[2], fsb[4], ftb[2];
+#define SIMNN_READ(fs_, ft_, s_, fo_)                                                                                  \
+    if (EXP != 7 || (s_) == 0) {                                                                                       \
+        const _Float16* Bs = smem + ((s_) & (PNBUF - 1)) * PSTAGE;                                                     \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                  \
+            fs_[x] = *reinterpret_cast<const f16x8*>(Bs + sbase + x * 32 * PBK + (fo_));                               \
+        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                                  \
+            ft_[x] = *reinterpret_cast<const f16x8*>(Bs + tbase + x * 32 * PBK + (fo_));                               \
     }
-#define SIMNN_KLOOP(NORMS)                                                                                             \
-    for (int s = 0; s < ns; ++s) {                                                                                     \
-        const int buf = s & 1;                                                                                         \
-        const bool more = s + 1 < ns;                                                                                  \
-        const _Float16* Tb = Ts + buf * ST * SBK;                                                                      \
-        const _Float16* Sb = Ss + buf * ST * SBK;                                                                      \
-        _Pragma("unroll") for (int kk = 0; kk < SBK / 16; ++kk) {                                                      \
-            /* ---- LOAD part */                                                                                       \
-            if (kk < 2 && more) { SIMNN_DMA2(s + 1, buf ^ 1, kk * 2) }                                                 \
-            const int chunk = kk * 2 + (lane >> 5);                                                                    \
-            f16x8 fs[4], ft[2];                                                                                        \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                              \
-                fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(wsrc * 128 + x * 32 + (lane & 31), chunk)); \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                              \
-                ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wtgt * 64 + x * 32 + (lane & 31), chunk));  \
-            if (kk == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
-            __builtin_amdgcn_s_barrier();                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
-            /* ---- MFMA part */                                                                                       \
-            if (NORMS) {                                                                                               \
-                if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft[x], nrm_t[x]); }       \
-                if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs[x], nrm_s[x]); }       \
-            }                                                                                                          \
-            __builtin_amdgcn_s_setprio(1);                                                                             \
-            _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                           \
-                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                       \
-                    acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs[st], ft[tt], acc[st][tt], 0, 0, 0);        \
-            __builtin_amdgcn_s_setprio(0);                                                                             \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
-            __builtin_amdgcn_s_barrier();                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                                         \
+#define SIMNN_MMA(fs_, ft_, NORMS)                                                                                     \
+    if (EXP != 7 || s == 0) {                                                                                          \
+        if (NORMS) {                                                                                                   \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft_[x], nrm_t[x]); }          \
+            if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs_[x], nrm_s[x]); }          \
         }                                                                                                              \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
+            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                           \
+                acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], acc[st][tt], 0, 0, 0);          \
     }
-    if ((ts_ == 0 || tt_ == 0) && p.dbg != 3) { SIMNN_KLOOP(true) } else { SIMNN_KLOOP(false) }
+#define SIMNN_SYNC(n_)                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15));            /* vmcnt(n) lgkmcnt(0) */                             \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+#define SIMNN_KLOOP(NORMS)                                                                                             \
+    {                                                                                                                  \
+        int s = 0;                                                                                                     \
+        SIMNN_READ(fsa, fta, 0, foff0)                                                                                 \
+        for (; s < ns - 3; ++s) {                                                                                      \
+            SIMNN_READ(fsb, ftb, s, foff1)                                                                             \
+            SIMNN_DMA1(s + 3, 0)                                                                                       \
+            SIMNN_MMA(fsa, fta, NORMS)                                                                                 \
+            SIMNN_SYNC(6)                                                                                              \
+            SIMNN_READ(fsa, fta, s + 1, foff0)                                                                         \
+            SIMNN_DMA1(s + 3, 1)                                                                                       \
+            SIMNN_MMA(fsb, ftb, NORMS)                                                                                 \
+        }                                                                                                              \
+        SIMNN_READ(fsb, ftb, s, foff1)                                                                                 \
+        SIMNN_MMA(fsa, fta, NORMS)                                                                                     \
+        SIMNN_SYNC(4)                                                                                                  \
+        SIMNN_READ(fsa, fta, s + 1, foff0)                                                                             \
+        SIMNN_MMA(fsb, ftb, NORMS)                                                                                     \
+        ++s;                                                                                                           \
+        SIMNN_READ(fsb, ftb, s, foff1)                                                                                 \
+        SIMNN_MMA(fsa, fta, NORMS)                                                                                     \
+        SIMNN_SYNC(0)                                                                                                  \
+        SIMNN_READ(fsa, fta, s + 1, foff0)                                                                             \
+        SIMNN_MMA(fsb, ftb, NORMS)                                                                                     \
+        ++s;                                                                                                           \
+        SIMNN_READ(fsb, ftb, s, foff1)                                                                                 \
+        SIMNN_MMA(fsa, fta, NORMS)                                                                                     \
+        SIMNN_MMA(fsb, ftb, NORMS)                                                                                     \
+    }
+    if ((ts_ == 0 || tt_ == 0) && p.dbg != 3) SIMNN_KLOOP(true) else SIMNN_KLOOP(false)
 #undef SIMNN_KLOOP
-#undef SIMNN_DMA2
-#undef SIMNN_DMA1P
-    if (grp == 0) __builtin_amdgcn_s_barrier();          // re-align the two groups
-    __syncthreads();
+#undef SIMNN_SYNC
+#undef SIMNN_MMA
+#undef SIMNN_READ
+#undef SIMNN_DMA1
 #undef SIMNN_DMA
+    __syncthreads();                                             // the epilogue reuses the ring as scratch
 
     if (p.dbg == 1) {
         float sacc = 0.f;
@@ -551,76 +527,9 @@ __global__ __launch_bounds__(512, 2) void simnn_phased_kernel(simnn_params p) {
         if (sacc == 1.2345f) p.pb[0] = sacc;
         return;
     }
-    if (do_tn) {
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
-            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
-            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
-        }
-    }
-    if (do_sn) {
-        float m = 0.f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
-            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
-            if (gj < p.N1) m = fmaxf(m, v);
-        }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
-    }
-
-    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
-    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
-    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
-    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
-    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
-        int bj = DM_IDX_NONE;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
-                // candidates arrive in ascending j: strict > keeps the lowest index on ties
-                const bool up = v > bv;
-                sv = up ? bv : fmaxf(sv, v);
-                bj = up ? j : bj;
-                bv = fmaxf(bv, v);
-                m32 = fmaxf(m32, v);
-            }
-            m32 = fmaxf(m32, __shfl_xor(m32, 32));
-            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
-            if (lane < 32 && gi32 < p.N2)
-                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
-        }
-        const float ob = __shfl_xor(bv, 32);
-        const int oj = __shfl_xor(bj, 32);
-        const float os = __shfl_xor(sv, 32);
-        top2_merge(bv, bj, sv, ob, oj, os);
-        if (lane < 32) {
-            const int li = wtgt * 64 + tt * 32 + lane;
-            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
-        }
-    }
-    __syncthreads();
-    if (t < ST) {
-        const int gi = i0 + t;
-        if (gi < p.N2) {
-            float bv = sb[t], sv = ss[t];
-            int bj = sj[t];
-            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
-            const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
-            p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
-        }
-    }
+    simnn_tail<FULL>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, smem);
 }
+
 
 __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restrict__ pb, const int32_t* __restrict__ pj,
                                                           const float* __restrict__ ps, int tilesS, int N2, int N2pad,
@@ -752,20 +661,32 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     const size_t lds_main = (size_t)2 * 2 * ST * SBK * sizeof(_Float16);       // 128 KiB
     static bool lds_main_set = false;
     if (!lds_main_set) {
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
         DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
         lds_main_set = true;
     }
-    if (N2 % ST == 0 && N1 % ST == 0 && D % SBK == 0) {
-        static bool phased_set = false;
-        if (!phased_set) {
-            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_phased_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
-            phased_set = true;
+    const bool interior = (N2 % ST == 0 && N1 % ST == 0);
+    const char* pe = getenv("DM_SIMNN_PIPE");                                  // 0: the two-buffer kernel (experiments)
+    const int pipe = pe ? atoi(pe) : 1;
+    if (interior && pipe && D % PBK == 0 && D >= 3 * PBK) {
+        static bool pipe_set = false;
+        if (!pipe_set) {
+            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_pipe_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
+            pipe_set = true;
         }
-        const char* pe = getenv("DM_SIMNN_PHASED");
-        const int phased = pe ? atoi(pe) : 0;
-        if (phased) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_phased_kernel, dim3(p.total), dim3(512), lds_main, p);
-        else DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel, dim3(p.total), dim3(512), lds_main, p);
+        const char* xe = getenv("DM_SIMNN_EXP");
+        if (xe && atoi(xe) == 7) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_pipe_kernel<7>, dim3(p.total), dim3(512), lds_main, p);
+        else DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_pipe_kernel<0>, dim3(p.total), dim3(512), lds_main, p);
+    }
+    else if (interior && D % SBK == 0) {
+        const char* xe = getenv("DM_SIMNN_EXP");
+        const int ex = xe ? atoi(xe) : 0;
+        if (ex == 3) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel<3>, dim3(p.total), dim3(512), lds_main, p);
+        else if (ex == 7) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel<7>, dim3(p.total), dim3(512), lds_main, p);
+        else DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel<0>, dim3(p.total), dim3(512), lds_main, p);
     }
     else
         DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_kernel<false>, dim3(p.total), dim3(512), lds_main, p);

@@ -129,8 +129,13 @@ def test_zoomout(eng, fx_cfg1, fx_cfg2):
 
 
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("B,N2,N1,D", [(1, 128, 128, 64), (2, 300, 517, 96), (3, 1000, 777, 384), (1, 2048, 2048, 768)])
-def test_simnn_random(eng, B, N2, N1, D):
+@pytest.mark.parametrize("B,N2,N1,D", [(1, 128, 128, 64), (2, 300, 517, 96), (3, 1000, 777, 384), (1, 2048, 2048, 768),
+                                       (2, 256, 512, 96), (2, 512, 256, 64), (1, 768, 512, 160), (1, 512, 512, 136)])
+@pytest.mark.parametrize("pipe", ["1", "0"])
+def test_simnn_random(eng, B, N2, N1, D, pipe, monkeypatch):
+    # interior shapes (N % 256 == 0) take the ring-buffered LDS-DMA kernel when D % 32 == 0 and D >= 96, the two-buffer
+    # LDS-DMA kernel when D % 64 == 0 (or DM_SIMNN_PIPE=0), everything else the bounds-checked register-staged kernel
+    monkeypatch.setenv("DM_SIMNN_PIPE", pipe)
     rng = np.random.default_rng(B * 1000 + N2)
     S = rng.standard_normal((B, N1, D)).astype(np.float16)
     T = rng.standard_normal((B, N2, D)).astype(np.float16)
