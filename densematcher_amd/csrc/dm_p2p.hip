@@ -103,6 +103,8 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
 constexpr int GT = 128;    // G tile (rows and columns) per workgroup
 constexpr int GBK = 16;    // contraction depth per LDS stage
 constexpr int GLD = 144;   // LDS row stride (f64): 288 dwords = 32 (mod 64)
+constexpr int GX_WAVE = 64 * 17 + 64 * 17 / 2;   // epilogue exchange buffer per wave (doubles): 64 x 17 values + 64 x 17 indices
+static_assert((4 * 2 * 128 + 4 * 2 * 128 / 2 + 4 * GX_WAVE) <= 2 * 2 * GBK * GLD, "epilogue scratch must fit in the staging LDS");
 
 struct gred_params {
     const double* AT; const double* BT;
@@ -127,11 +129,20 @@ struct gred_params {
 //  columns: (value, row) pairs tracked in-lane while sweeping the rows in ascending order, merged across the four
 //           16-lane groups at the end.
 template <bool MASK, bool ALL>
-__device__ __forceinline__ void gred_epilogue(const gred_params& p, const f64x4 (&acc)[4][4], double* sv, int* sj, int b,
-                                              int i0, int j0, int lane, int wm, int wn) {
+__device__ __forceinline__ void gred_epilogue(const gred_params& p, const f64x4 (&acc)[4][4], double* sv, int* sj,
+                                              double* xch, int b, int i0, int j0, int lane, int wm, int wn) {
     const int cl = lane & 15, rg = lane >> 4;
     // ---- sweep 1: row reductions -------------------------------------------------------------------------
+    // (f64 MFMA runs on the vector ALU's double-precision datapath on this part -- tools/ubench_coissue.hip: VALU work
+    // of a co-resident wave ADDS to the MFMA time, nothing overlaps -- so the epilogue is priced per VALU instruction.)
+    // Per kind: (A) every lane reduces its four columns of a row slot in registers, (value, lowest column) pairs;
+    // (B) the 16 partial pairs of each row cross the wave through a private LDS exchange buffer, row-major with a
+    // 17-entry row stride (conflict-free both ways); (C) lane L finishes row L: value tree, then the lowest column
+    // among the partials that attain it.  About half the VALU instructions of DPP butterflies per row slot.
     {
+        const int wave = wm * 2 + wn;
+        double* xv = xch + wave * GX_WAVE;                         // [64 rows][17]
+        int* xj = reinterpret_cast<int*>(xv + 64 * 17);            // [64 rows][17]
         double a1[4], n1c[4];
         int gcol[4];
 #pragma unroll
@@ -143,52 +154,60 @@ __device__ __forceinline__ void gred_epilogue(const gred_params& p, const f64x4 
             n1c[nt] = p.n1[(long long)b * p.N1pad + gj];
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int kind = (ALL ? 0 : 1); kind < 2; ++kind) {         // 0: ind21 (arg-max of G a1), 1: knn21 (arg-min)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lrow = wm * 64 + mt * 16 + rg + 4 * r;
-                double vi[4], vk[4];
+            for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const double g = acc[mt][nt][r];
-                    vi[nt] = g * a1[nt];                           // (Phi2 C Phi1^T) @ A1, convert.py:144
-                    vk[nt] = n1c[nt] - 2.0 * g;                    // |x|^2 - 2 <x,y>
-                    if (MASK) {
-                        const bool cv = gcol[nt] != DM_IDX_NONE;
-                        vi[nt] = cv ? vi[nt] : -DM_INF_F64;
-                        vk[nt] = cv ? vk[nt] : DM_INF_F64;
+                for (int r = 0; r < 4; ++r) {
+                    double v[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const double g = acc[mt][nt][r];
+                        // arg-min of (|x|^2 - 2 <x,y>) is carried as the arg-max of its negation's ordering:
+                        // the comparisons below are written per kind, the values are the reference's own
+                        v[nt] = (kind == 0) ? g * a1[nt]                        // (Phi2 C Phi1^T) @ A1, convert.py:144
+                                            : n1c[nt] - 2.0 * g;                // |x|^2 - 2 <x,y>
+                        if (MASK) {
+                            const bool cv = gcol[nt] != DM_IDX_NONE;
+                            v[nt] = cv ? v[nt] : ((kind == 0) ? -DM_INF_F64 : DM_INF_F64);
+                        }
                     }
+                    double m01, m23, m;
+                    int j01, j23, j;
+                    if (kind == 0) {
+                        m01 = fmax(v[0], v[1]); j01 = (v[1] > v[0]) ? gcol[1] : gcol[0];
+                        m23 = fmax(v[2], v[3]); j23 = (v[3] > v[2]) ? gcol[3] : gcol[2];
+                        m = fmax(m01, m23); j = (m23 > m01) ? j23 : j01;
+                    } else {
+                        m01 = fmin(v[0], v[1]); j01 = (v[1] < v[0]) ? gcol[1] : gcol[0];
+                        m23 = fmin(v[2], v[3]); j23 = (v[3] < v[2]) ? gcol[3] : gcol[2];
+                        m = fmin(m01, m23); j = (m23 < m01) ? j23 : j01;
+                    }
+                    const int row = mt * 16 + rg + 4 * r;
+                    xv[row * 17 + cl] = m;
+                    xj[row * 17 + cl] = j;
                 }
-                // pass A: row extremes over the 64 columns held by this wave
-                double mi = 0.0, mk;
-                int ji = DM_IDX_NONE, jk = DM_IDX_NONE;
-                if (ALL) {
-                    mi = fmax(fmax(vi[0], vi[1]), fmax(vi[2], vi[3]));
-                    mi = fmax(mi, dpp_f64<0xB1>(mi)); mi = fmax(mi, dpp_f64<0x4E>(mi));
-                    mi = fmax(mi, dpp_f64<0x141>(mi)); mi = fmax(mi, dpp_f64<0x140>(mi));
-                }
-                mk = fmin(fmin(vk[0], vk[1]), fmin(vk[2], vk[3]));
-                mk = fmin(mk, dpp_f64<0xB1>(mk)); mk = fmin(mk, dpp_f64<0x4E>(mk));
-                mk = fmin(mk, dpp_f64<0x141>(mk)); mk = fmin(mk, dpp_f64<0x140>(mk));
-                // pass B: lowest column that attains the extreme
-#pragma unroll
-                for (int nt = 3; nt >= 0; --nt) {                   // descending: the lowest matching column is kept
-                    if (ALL) ji = (vi[nt] == mi) ? gcol[nt] : ji;
-                    jk = (vk[nt] == mk) ? gcol[nt] : jk;
-                }
-                if (ALL) {
-                    ji = min(ji, dpp_i32<0xB1>(ji)); ji = min(ji, dpp_i32<0x4E>(ji));
-                    ji = min(ji, dpp_i32<0x141>(ji)); ji = min(ji, dpp_i32<0x140>(ji));
-                }
-                jk = min(jk, dpp_i32<0xB1>(jk)); jk = min(jk, dpp_i32<0x4E>(jk));
-                jk = min(jk, dpp_i32<0x141>(jk)); jk = min(jk, dpp_i32<0x140>(jk));
-                if (cl == 0) {
-                    if (ALL) { sv[(0 * 2 + wn) * 128 + lrow] = mi; sj[(0 * 2 + wn) * 128 + lrow] = ji; }
-                    sv[(1 * 2 + wn) * 128 + lrow] = mk; sj[(1 * 2 + wn) * 128 + lrow] = jk;
-                }
-                // one row slot at a time: without this the scheduler interleaves all 16 slots and spills
-                __builtin_amdgcn_sched_barrier(0);
             }
+            // (same wave wrote what it reads: the LDS queue of a wave is in order, no barrier)
+            double w[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) w[c] = xv[lane * 17 + c];
+            double m8[8], m4[4];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) m8[c] = (kind == 0) ? fmax(w[2 * c], w[2 * c + 1]) : fmin(w[2 * c], w[2 * c + 1]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m4[c] = (kind == 0) ? fmax(m8[2 * c], m8[2 * c + 1]) : fmin(m8[2 * c], m8[2 * c + 1]);
+            const double ma = (kind == 0) ? fmax(m4[0], m4[1]) : fmin(m4[0], m4[1]);
+            const double mb = (kind == 0) ? fmax(m4[2], m4[3]) : fmin(m4[2], m4[3]);
+            const double mrow = (kind == 0) ? fmax(ma, mb) : fmin(ma, mb);
+            int jrow = DM_IDX_NONE;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int jc = xj[lane * 17 + c];
+                jrow = min(jrow, (w[c] == mrow) ? jc : DM_IDX_NONE);
+            }
+            sv[(kind * 2 + wn) * 128 + wm * 64 + lane] = mrow;
+            sj[(kind * 2 + wn) * 128 + wm * 64 + lane] = jrow;
         }
     }
     if (!ALL) return;
@@ -289,9 +308,10 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // Two workgroups share a CU.  Started together they stay in lock-step (both in the MFMA main loop, then both in
-    // the VALU epilogue) and the two pipes never overlap.  The second resident workgroup of the first dispatch
-    // round is delayed by about half a tile period once; the phase shift then persists for the whole launch.
+    // Two workgroups share a CU so that one computes while the other waits for memory.  (Experiment knob, off by
+    // default: delay the second resident workgroup of the first dispatch round by half a tile period so the two stay
+    // in opposite phases.  It bought 6 % while the epilogue was DPP-bound and nothing since: f64 MFMA and VALU work
+    // share the double-precision datapath on this part and cannot overlap, tools/ubench_coissue.hip.)
     if (p.stagger && blockIdx.x < 512) {
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;      // HW_ID.wave_id bit 0
         if (slot) {
@@ -326,8 +346,7 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     }
 
     const int ns = (p.dbg == 2) ? 1 : p.Kloop / GBK;
-    // the MFMA main loop outranks the co-resident workgroup's VALU epilogue at the issue port (the two workgroups of a
-    // CU are kept in opposite phases, see `stagger`)
+    // (experiment knob, off by default: the MFMA main loop outranks the co-resident workgroup's epilogue at the issue port)
     if (p.prio) __builtin_amdgcn_s_setprio(2);
     GRED_FETCH(0)
     GRED_STASH(0)
@@ -370,8 +389,9 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     // LDS is free now (the loop ended with a barrier): reuse it for the cross-wave merges.
     double* sv = smem;                                            // [4 kinds][2 waves][128]
     int* sj = reinterpret_cast<int*>(smem + 4 * 2 * 128);         // [4 kinds][2 waves][128]
-    if ((i0 + GT <= p.N2) && (j0 + GT <= p.N1)) gred_epilogue<false, ALL>(p, acc, sv, sj, b, i0, j0, lane, wm, wn);
-    else gred_epilogue<true, ALL>(p, acc, sv, sj, b, i0, j0, lane, wm, wn);
+    double* xch = smem + 4 * 2 * 128 + 4 * 2 * 128 / 2;         // per-wave exchange buffers, GX_WAVE doubles each
+    if ((i0 + GT <= p.N2) && (j0 + GT <= p.N1)) gred_epilogue<false, ALL>(p, acc, sv, sj, xch, b, i0, j0, lane, wm, wn);
+    else gred_epilogue<true, ALL>(p, acc, sv, sj, xch, b, i0, j0, lane, wm, wn);
     __syncthreads();
     // merge the two waves that share a row (wn = 0, 1) / a column (wm = 0, 1); lower half first
     if (t < 128) {
@@ -442,8 +462,8 @@ int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a) {
     p.tilesM = a.N2pad / GT; p.tilesN = a.N1pad / GT;
     p.total = a.B * p.tilesM * p.tilesN;
     { const char* e = getenv("DM_GRED_DEBUG"); p.dbg = e ? atoi(e) : 0; }
-    { const char* e = getenv("DM_GRED_STAGGER"); p.stagger = e ? atoi(e) : 2; }
-    { const char* e = getenv("DM_GRED_PRIO"); p.prio = e ? atoi(e) : 1; }
+    { const char* e = getenv("DM_GRED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+    { const char* e = getenv("DM_GRED_PRIO"); p.prio = e ? atoi(e) : 0; }
     // two instantiations: all four reductions (needs n1, n2, mass1) or the row arg-min knn21 alone (needs n1)
     const bool all = a.knn12 || a.ind21 || a.ind12;
     if (!a.n1 || (all && (!a.n2 || !a.mass1)))
