@@ -6,6 +6,8 @@
 //   minimiser of w_d/2 |C A - B|^2 + w_l/2 sum C^2 ev with column 0 pinned (base_functions.py:49,95,759):
 //   for every row i:  (P[f,f] + w_l diag(ev[i,f])) C[i,f] = Q[i,f] - P[f,0] C[i,0],
 //   P = w_d A A^T, Q = w_d B A^T, f = 1..k1-1   
+#include <stdlib.h>
+
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
 
@@ -146,16 +148,27 @@ struct OutScaled {
 // =================================================================================================
 __device__ __forceinline__ int tri(int r) { return r * (r + 1) / 2; }
 
-__global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restrict__ PQ, const double* __restrict__ lam1,
-                                                         const double* __restrict__ lam2, const double* __restrict__ c00,
-                                                         double w_lap, int k1, int k2, double* __restrict__ C,
-                                                         int32_t* __restrict__ info) {
+constexpr int SP_NT = 1024;              // threads per workgroup of the packed solver (16 waves, four per SIMD)
+constexpr int SP_NW = SP_NT / 64;
+constexpr int SP_U = 2;                   // blocks of the trailing update a wave has in flight per trip
+
+// Packed-storage solver (any n <= 199; the default above the blocked solver's n <= 176).  The lower triangle of
+// [P_ff + w_l diag(ev_i) ; rhs] lives in LDS row-packed (159 KiB at n = 199: nothing else fits, so one workgroup per
+// CU), and the workgroup is made of 16 waves because every phase is bound by instruction issue, not by the LDS or the
+// matrix cores: four waves per SIMD interleave where one wave would wait out each dependent step.
+__global__ __launch_bounds__(SP_NT) void fmap_solve_kernel(const double* __restrict__ PQ, const double* __restrict__ lam1,
+                                                           const double* __restrict__ lam2, const double* __restrict__ c00,
+                                                           double w_lap, int k1, int k2, double* __restrict__ C,
+                                                           int32_t* __restrict__ info, int dbg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = k1 - 1;
     double* M = sm;                         // tri(n + 1) entries
-    double* col = sm + tri(n + 1);          // max(n + 1, 4)
-    double* red = col + max(n + 1, 4);      // 2: [0] = eigenvalue scale, [1] = failure flag
+    double* col = sm + tri(n + 1);          // max(n + 1, 16): reduction scratch
+    double* red = col + max(n + 1, 16);     // 4: [0] eigenvalue scale, [1] failure flag, [2] scratch word for masked stores, [3] = 0.0 for masked loads
+    const int dummy = (int)(red + 2 - M), zero = (int)(red + 3 - M);
     const int b = blockIdx.y, i = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63;
+    const int swave = __builtin_amdgcn_readfirstlane(t >> 6);
     const double* P = PQ + (long long)b * (k1 + k2) * k1;
     const double* Q = P + (long long)k1 * k1;
     const double* l1 = lam1 + (long long)b * k1;
@@ -163,15 +176,18 @@ __global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restric
 
     // scale = max(lam1.max(), lam2.max())   (functional.py:404)
     double mx = -DM_INF_F64;
-    for (int q = t; q < k1; q += 256) mx = fmax(mx, l1[q]);
-    for (int q = t; q < k2; q += 256) mx = fmax(mx, l2[q]);
+    for (int q = t; q < k1; q += SP_NT) mx = fmax(mx, l1[q]);
+    for (int q = t; q < k2; q += SP_NT) mx = fmax(mx, l2[q]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
-    if ((t & 63) == 0) col[t >> 6] = mx;
+    if (lane == 0) col[swave] = mx;
     __syncthreads();
     if (t == 0) {
-        red[0] = fmax(fmax(col[0], col[1]), fmax(col[2], col[3]));
+        double m = col[0];
+        for (int q = 1; q < SP_NW; ++q) m = fmax(m, col[q]);
+        red[0] = m;
         red[1] = 0.0;
+        red[3] = 0.0;
     }
     __syncthreads();
     const double scale = red[0];
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restric
     const double l2i = l2[i] / scale;
 
     // load [M ; rhs]
-    for (int r = t >> 4; r <= n; r += 16) {
+    for (int r = t >> 4; r <= n; r += SP_NT / 16) {
         for (int c = t & 15; c <= r && c < n; c += 16) {
             double v;
             if (r < n) {
@@ -196,45 +212,230 @@ __global__ __launch_bounds__(256) void fmap_solve_kernel(const double* __restric
     }
     __syncthreads();
 
-    for (int j = 0; j < n; ++j) {
-        const double piv = M[tri(j) + j];
-        if (!(piv > 0.0)) {                      // uniform: every thread reads the same LDS word
-            if (t == 0) red[1] = 1.0;
-            break;
+    // Right-looking Cholesky on the packed lower triangle, four columns per step; the right-hand side is carried as
+    // row n, so the forward substitution happens in the same sweep.
+    //   (1) waves 0-3 (the threads that own a row) factor the 4x4 diagonal block in registers (10 broadcast LDS reads);
+    //   (2) thread t finishes the four panel entries of row j + w + t by a 4-term forward substitution;
+    //   (3) the trailing triangle takes its rank-4 update on the f64 matrix cores, 16x16 blocks straight from / to the
+    //       packed storage: D = (-L_panel[R]) L_panel[C]^T + M[R][C]  (v_mfma_f64_16x16x4_f64, K = the panel width).
+    const int li = lane & 15, lq = lane >> 4;
+    int x4[4], txl[4], dl[4];                                 // lane parts of the packed addresses (see step 3)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        x4[r4] = lq + 4 * r4;
+        txl[r4] = tri(x4[r4]) + li;
+        dl[r4] = li - x4[r4];
+    }
+    const int tli = tri(li) + lq;
+    const int Rmax = n >> 4;                                  // last (possibly partial) block row; row n = right-hand side
+    const bool plastA = li <= n - Rmax * 16, pcn = li < n - Rmax * 16;
+    bool plast[4], pdiag[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        plast[r4] = x4[r4] <= n - Rmax * 16;
+        pdiag[r4] = dl[r4] <= 0;
+    }
+    for (int j = 0; j < n && dbg != 3; j += 4) {
+        const int w = min(4, n - j);
+        double d[4][4], inv[4];
+        if (swave < 4) {
+            // (1) diagonal block, identity-padded beyond w
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c <= q; ++c) d[q][c] = (q < w) ? M[tri(j + q) + j + c] : (q == c ? 1.0 : 0.0);
+            bool ok = true;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int c = 0; c < q; ++c) {
+                    double sdot = d[q][c];
+#pragma unroll
+                    for (int e = 0; e < c; ++e) sdot -= d[q][e] * d[c][e];
+                    d[q][c] = sdot * inv[c];
+                }
+                double piv = d[q][q];
+#pragma unroll
+                for (int e = 0; e < q; ++e) piv -= d[q][e] * d[q][e];
+                ok = ok && (piv > 0.0);
+                double rs = __builtin_amdgcn_rsq(piv);       // piv^-1/2: hardware seed + two Newton steps, no divide / sqrt
+                const double hp = 0.5 * piv;
+                rs = rs * (1.5 - hp * rs * rs);
+                rs = rs * (1.5 - hp * rs * rs);
+                inv[q] = rs;
+                d[q][q] = rs;                                // the diagonal stores 1 / L[q][q] (all later uses multiply)
+            }
+            if (!ok && t == 0 && dbg != 1 && dbg != 4 && dbg != 5) red[1] = 1.0;
         }
-        const double inv = 1.0 / sqrt(piv);
-        for (int r = j + 1 + t; r <= n; r += 256) {
-            const double x = M[tri(r) + j] * inv;
-            M[tri(r) + j] = x;
-            col[r] = x;
+        __syncthreads();                         // the diagonal block has been read by everyone who needs it
+        if (red[1] != 0.0) break;                // uniform: one LDS word
+        // (2) rows below the panel (the right-hand side row n included); one thread also stores the block's factor
+        if (swave < 4) {
+            const int r = j + w + t;
+            if (r <= n) {
+                double* Mr = M + tri(r) + j;
+                double x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < w) {
+                        double sdot = Mr[q];
+#pragma unroll
+                        for (int e = 0; e < q; ++e) sdot -= x[e] * d[q][e];
+                        x[q] = sdot * inv[q];
+                        Mr[q] = x[q];
+                    } else {
+                        x[q] = 0.0;
+                    }
+                }
+            }
+            if (t == 255) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c <= q; ++c)
+                        if (q < w) M[tri(j + q) + j + c] = d[q][c];
+            }
         }
         __syncthreads();
-        if (t == 0) M[tri(j) + j] = sqrt(piv);
-        for (int r = j + 1 + (t >> 4); r <= n; r += 16) {
-            const double lr = col[r];
-            const int cend = min(r, n - 1);
-            for (int c = j + 1 + (t & 15); c <= cend; c += 16) M[tri(r) + c] -= lr * col[c];
+        // (3) trailing update.  Blocks are aligned to multiples of 16; entries left of column j + w (already final),
+        // above the diagonal, or beyond the matrix are masked.  A wave takes every 16th block of the trailing block
+        // triangle, SP_U at a time; all loads are unconditional (masked lanes read M[0], masked stores go to a scratch
+        // word) so that the code is straight-line and the LDS reads of a trip are in flight together.
+        // Addresses: tri(16 R + x) = tri(16 R) + 16 R x + tri(x) with the lane parts (x, tri(x)) hoisted out of the
+        // loop and the block parts on the scalar unit.
+        const int jw = j + w;
+        if (jw < n && dbg != 1) {
+            const int Cmin = jw >> 4, T = Rmax - Cmin + 1;
+            const int nblk = T * (T + 1) / 2;
+            const bool kv = lq < w;
+            const bool pfirst = li >= jw - Cmin * 16;           // column / row not yet final (first block row / column only)
+            const bool fullc = (jw & 15) == 0, fullr = (n & 15) == 15;   // first block column / last block row complete
+            int rho = 0, gam = swave;                         // block (rho, gam), gam <= rho, of the trailing triangle
+            while (gam > rho) { gam -= rho + 1; ++rho; }
+            for (int idx = swave; idx < nblk; idx += SP_NW * SP_U) {
+                f64x4 acc[SP_U];
+                double av[SP_U], bv[SP_U];
+                int addr[SP_U][4];
+                bool val[SP_U][4];
+                int Rs[SP_U], Cs[SP_U];
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) {
+                    Rs[u] = Cmin + rho; Cs[u] = Cmin + gam;
+                    gam += SP_NW;
+                    while (gam > rho) { gam -= rho + 1; ++rho; }
+                }
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) {
+                    // every lane predicate below is a per-kernel or per-panel constant; the block only selects which
+                    // of them apply (scalar conditions), so a block costs no vector compares
+                    const bool bvld = idx + SP_NW * u < nblk;
+                    const int R = Rs[u], Cb = Cs[u];
+                    const int s16R = R * 16, s16C = Cb * 16;
+                    const int TRj = (s16R * (s16R + 1) >> 1) + j, TCj = (s16C * (s16C + 1) >> 1) + j;
+                    const int TRC = (s16R * (s16R + 1) >> 1) + s16C;
+                    if (bvld && w == 4 && (Cb > Cmin || fullc) && Cb < R && (R < Rmax || fullr)) {
+                        // interior block (wave-uniform test): nothing is masked
+                        av[u] = M[(int)__umul24(li, s16R) + tli + TRj];
+                        bv[u] = M[(int)__umul24(li, s16C) + tli + TCj];
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            val[u][r4] = true;
+                            addr[u][r4] = (int)__umul24(x4[r4], s16R) + txl[r4] + TRC;
+                            acc[u][r4] = M[addr[u][r4]];
+                        }
+                    } else {
+                        const bool cok = bvld && (Cb != Rmax || pcn) && (Cb != Cmin || pfirst);
+                        const bool aok = bvld && kv && (R != Rmax || plastA) && (R != Cmin || pfirst);
+                        const bool bok = cok && kv;
+                        av[u] = M[aok ? (int)__umul24(li, s16R) + tli + TRj : zero];
+                        bv[u] = M[bok ? (int)__umul24(li, s16C) + tli + TCj : zero];
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            val[u][r4] = cok && (R != Rmax || plast[r4]) && (R != Cb || pdiag[r4]);
+                            addr[u][r4] = val[u][r4] ? (int)__umul24(x4[r4], s16R) + txl[r4] + TRC : zero;
+                            acc[u][r4] = M[addr[u][r4]];
+                        }
+                    }
+                    av[u] = -av[u];
+                }
+                if (dbg == 4) {                                 // experiment: loads only
+                    double sink = 0.0;
+#pragma unroll
+                    for (int u = 0; u < SP_U; ++u) sink += av[u] + bv[u] + acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+                    if (sink == 1.2345) M[0] = sink;
+                    continue;
+                }
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u) acc[u] = mfma_f64_16x16x4(av[u], bv[u], acc[u]);
+                if (dbg == 5) {                                 // experiment: no stores
+                    double sink = 0.0;
+#pragma unroll
+                    for (int u = 0; u < SP_U; ++u) sink += acc[u][0] + acc[u][1] + acc[u][2] + acc[u][3];
+                    if (sink == 1.2345) M[0] = sink;
+                    continue;
+                }
+#pragma unroll
+                for (int u = 0; u < SP_U; ++u)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) M[val[u][r4] ? addr[u][r4] : dummy] = acc[u][r4];   // masked lanes -> scratch word
+            }
         }
         __syncthreads();
     }
     __syncthreads();
     if (red[1] != 0.0) {
         if (t == 0) atomicMax(&info[b], i + 1);
-        for (int c = t; c < k1; c += 256) C[((long long)b * k2 + i) * k1 + c] = (c == 0) ? ci0 : 0.0;
+        for (int c = t; c < k1; c += SP_NT) C[((long long)b * k2 + i) * k1 + c] = (c == 0) ? ci0 : 0.0;
         return;
     }
-    // back substitution L^T x = y, y = M[n][0..n-1]
+    // back substitution L^T x = y (y = row n), four unknowns per step from the bottom: the part of the four dot
+    // products below the panel is spread over the threads that own a row and summed through LDS, the 4x4 triangle is
+    // finished by every thread redundantly.
     double* y = M + tri(n);
-    for (int j = n - 1; j >= 0; --j) {
-        const double xj = y[j] / M[tri(j) + j];
+    for (int j = ((n - 1) >> 2) << 2; j >= 0 && dbg != 2; j -= 4) {
+        const int w = min(4, n - j);
+        if (swave < 4) {
+            double sdot[4] = {0.0, 0.0, 0.0, 0.0};
+            const int r = j + w + t;
+            if (r < n) {
+                const double xr = y[r];
+                const double* Mr = M + tri(r) + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sdot[q] = (q < w) ? Mr[q] * xr : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sdot[q] += dpp_f64<0xB1>(sdot[q]); sdot[q] += dpp_f64<0x4E>(sdot[q]);
+                sdot[q] += dpp_f64<0x141>(sdot[q]); sdot[q] += dpp_f64<0x140>(sdot[q]);
+                sdot[q] += __shfl_xor(sdot[q], 16); sdot[q] += __shfl_xor(sdot[q], 32);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) col[swave * 4 + q] = sdot[q];
+            }
+        }
         __syncthreads();
-        if (t == 0) y[j] = xj;
-        for (int c = t; c < j; c += 256) y[c] -= M[tri(j) + c] * xj;
+        if (t == 0) {
+            double x[4];
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                if (q < w) {
+                    double v = y[j + q] - (col[q] + col[4 + q] + col[8 + q] + col[12 + q]);
+#pragma unroll
+                    for (int e = 3; e > q; --e)
+                        if (e < w) v -= M[tri(j + e) + j + q] * x[e];
+                    x[q] = v * M[tri(j + q) + j + q];       // (reciprocal diagonal)
+                    y[j + q] = x[q];
+                } else {
+                    x[q] = 0.0;
+                }
+            }
+        }
         __syncthreads();
     }
     double* Crow = C + ((long long)b * k2 + i) * k1;
     if (t == 0) Crow[0] = ci0;
-    for (int c = t; c < n; c += 256) Crow[c + 1] = y[c];
+    for (int c = t; c < n; c += SP_NT) Crow[c + 1] = y[c];
 }
 
 #ifdef DM_SOLVE_TIMING
@@ -375,7 +576,8 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     const size_t pq_bytes = (size_t)B * (k1 + k2) * k1 * 8;
     const int n = k1 - 1;
     const int NB = (n + 15) / 16;
-    const bool blocked = (n >= 1 && NB <= 11);
+    const char* pk = getenv("DM_SOLVE_PACKED");                 // 1: force the packed-storage solver (tests)
+    const bool blocked = (n >= 1 && NB <= 11) && !(pk && atoi(pk));
     const size_t img_bytes = blocked ? (size_t)B * (NB * (NB + 1) / 2) * 256 * 8 : 0;
     int rc = dm_ws_reserve(ctx, dm_align_up(pq_bytes) + img_bytes);
     if (rc) return rc;
@@ -404,14 +606,15 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
                   w_lap, k1, k2, NB, C, info);
         return DM_OK;
     }
-    const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 4 ? 4 : n + 1) + 2) * sizeof(double);
+    const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 16 ? 16 : n + 1) + 4) * sizeof(double);
     static size_t lds_set = 0;
     if (lds > lds_set) {
         DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)fmap_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)lds));
         lds_set = lds;
     }
-    DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_kernel, dim3(k2, B), dim3(256), lds, PQ, lam1, lam2, c00, w_lap, k1, k2,
-              C, info);
+    const char* de = getenv("DM_SOLVE_DEBUG");                  // experiments: 1 no trailing update, 2 no back substitution, 3 no factorisation
+    DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_kernel, dim3(k2, B), dim3(SP_NT), lds, PQ, lam1, lam2, c00, w_lap, k1, k2,
+              C, info, de ? atoi(de) : 0);
     return DM_OK;
 }

@@ -217,8 +217,11 @@ def test_errors(eng):
 
 
 @pytest.mark.parametrize("k1,k2,D", [(2, 3, 16), (17, 17, 40), (50, 40, 96), (128, 128, 256), (177, 60, 200), (178, 20, 256), (200, 24, 256)])
-def test_solver_shapes(eng, k1, k2, D):
-    """blocked-MFMA Cholesky (n <= 176) and the packed fallback (n <= 199), square and rectangular maps"""
+@pytest.mark.parametrize("packed", ["0", "1"])
+def test_solver_shapes(eng, k1, k2, D, packed, monkeypatch):
+    """blocked-MFMA Cholesky (n <= 176) and the packed-storage rank-4 solver (n <= 199; forced for every shape by
+    DM_SOLVE_PACKED=1), square and rectangular maps"""
+    monkeypatch.setenv("DM_SOLVE_PACKED", packed)
     rng = np.random.default_rng(k1 * 7 + k2)
     Bn = 2
     A = rng.standard_normal((Bn, k1, D)).astype(np.float32) * 0.1
