@@ -133,3 +133,12 @@ extern "C" int dm_profile_read(dm_ctx* ctx, int* launches, double* total_ms) {
     ctx->prof_used = 0;
     return DM_OK;
 }
+
+int dm_grant_lds(dm_ctx* ctx, const void* func, size_t bytes) {
+    size_t& have = ctx->lds_granted[func];
+    if (bytes > have) {
+        DM_CHECK_HIP(ctx, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return DM_OK;
+}

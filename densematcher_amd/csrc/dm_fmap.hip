@@ -596,23 +596,15 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     if (blocked) {
         // blocked MFMA solver: NB(NB+1)/2 + 2 blocks of 2 KiB, vectors
         const size_t lds = ((size_t)(NB * (NB + 1) / 2 + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);
-        static size_t lds_set_b = 0;
-        if (lds > lds_set_b) {
-            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)fmap_solve_blocked_kernel,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set_b = lds;
-        }
+        rc = dm_grant_lds(ctx, (const void*)fmap_solve_blocked_kernel, lds);
+        if (rc) return rc;
         DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_blocked_kernel, dim3(k2, B), dim3(256), lds, PQ, Timg, lam1, lam2, c00,
                   w_lap, k1, k2, NB, C, info);
         return DM_OK;
     }
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 16 ? 16 : n + 1) + 4) * sizeof(double);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)fmap_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)lds));
-        lds_set = lds;
-    }
+    rc = dm_grant_lds(ctx, (const void*)fmap_solve_kernel, lds);
+    if (rc) return rc;
     const char* de = getenv("DM_SOLVE_DEBUG");                  // experiments: 1 no trailing update, 2 no back substitution, 3 no factorisation
     DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_kernel, dim3(k2, B), dim3(SP_NT), lds, PQ, lam1, lam2, c00, w_lap, k1, k2,
               C, info, de ? atoi(de) : 0);

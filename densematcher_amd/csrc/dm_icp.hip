@@ -185,11 +185,8 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     DM_CHECK_HIP(ctx, hipMemsetAsync(BT, 0, bBT, ctx->stream));
 
     const size_t lds = ((size_t)(nblk + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)spd_multi_rhs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    rc = dm_grant_lds(ctx, (const void*)spd_multi_rhs_kernel, lds);
+    if (rc) return rc;
 
     for (int it = 0; it < nit; ++it) {
         ctx->ws_off = ws_mark;

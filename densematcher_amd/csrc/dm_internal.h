@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "densematch.h"
@@ -28,9 +29,14 @@ struct dm_ctx {
     std::string prof_name;
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop)
     size_t prof_used = 0;                  // events used so far
+
+    // largest dynamic-LDS size already granted to each kernel on this device (hipFuncSetAttribute is per device)
+    std::unordered_map<const void*, size_t> lds_granted;
 };
 
 int dm_fail(dm_ctx* ctx, int code, const char* fmt, ...);
+// allow `func` to be launched with `bytes` of dynamic LDS (> 64 KiB needs an explicit opt-in); remembered per context
+int dm_grant_lds(dm_ctx* ctx, const void* func, size_t bytes);
 
 #define DM_CHECK_HIP(ctx, expr)                                                        \
     do {                                                                               \

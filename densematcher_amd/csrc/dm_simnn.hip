@@ -659,24 +659,18 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     DM_CHECK_HIP(ctx, hipMemsetAsync(p.smax2, 0, (size_t)B * 4, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
     const size_t lds_main = (size_t)2 * 2 * ST * SBK * sizeof(_Float16);       // 128 KiB
-    static bool lds_main_set = false;
-    if (!lds_main_set) {
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_glds_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
-        lds_main_set = true;
+    {
+        const void* kernels[] = {(const void*)simnn_glds_kernel<0>, (const void*)simnn_glds_kernel<3>, (const void*)simnn_glds_kernel<7>,
+                                 (const void*)simnn_kernel<false>, (const void*)simnn_pipe_kernel<0>, (const void*)simnn_pipe_kernel<7>};
+        for (const void* kf : kernels) {
+            rc = dm_grant_lds(ctx, kf, lds_main);
+            if (rc) return rc;
+        }
     }
     const bool interior = (N2 % ST == 0 && N1 % ST == 0);
     const char* pe = getenv("DM_SIMNN_PIPE");                                  // 0: the two-buffer kernel (experiments)
     const int pipe = pe ? atoi(pe) : 1;
     if (interior && pipe && D % PBK == 0 && D >= 3 * PBK) {
-        static bool pipe_set = false;
-        if (!pipe_set) {
-            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
-            DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_pipe_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main));
-            pipe_set = true;
-        }
         const char* xe = getenv("DM_SIMNN_EXP");
         if (xe && atoi(xe) == 7) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_pipe_kernel<7>, dim3(p.total), dim3(512), lds_main, p);
         else DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_pipe_kernel<0>, dim3(p.total), dim3(512), lds_main, p);
@@ -696,11 +690,9 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb, p.pj, p.ps, p.tilesS, N2,
               p.N2pad, p.tnorm2, p.smax2, tau_scale, nn21, best, margin, flag_count, flag_list, flag_thr);
     const size_t lds = (size_t)D * 8 + 64;
-    static size_t lds_set = 0;
-    if (lds > 65536 && lds > lds_set) {
-        DM_CHECK_HIP(ctx, hipFuncSetAttribute((const void*)simnn_fixup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)lds));
-        lds_set = lds;
+    if (lds > 65536) {
+        rc = dm_grant_lds(ctx, (const void*)simnn_fixup_kernel, lds);
+        if (rc) return rc;
     }
     DM_LAUNCH(ctx, "simnn_fixup_f64", simnn_fixup_kernel, dim3(2048), dim3(256), lds, (const _Float16*)Ftgt,
               (const _Float16*)Fsrc, N2, N1, D, p.pb32, p.nsub, p.N2pad, flag_count, flag_list, flag_thr, nn21);
