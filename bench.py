@@ -64,16 +64,23 @@ def main():
     ap.add_argument("--workload", default="fmap", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse the N>1 path)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     w = dict(WORKLOADS[args.workload])
     if args.batch:
@@ -123,7 +130,7 @@ def main():
     launches, kernel_ms = eng.profile_read()
     eng.profile_kernel("")
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -72,7 +72,15 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
     if (j >= Npad) return;
     const double* E = embT + (long long)b * krpad * Npad;
     double s = 0.0;
-    for (int r = 0; r < kr; ++r) {
+    int r = 0;
+    for (; r + 16 <= kr; r += 16) {              // 16 loads in flight, summed in ascending order
+        double x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = E[(long long)(r + u) * Npad + j];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += x[u] * x[u];
+    }
+    for (; r < kr; ++r) {
         const double x = E[(long long)r * Npad + j];
         s += x * x;
     }
