@@ -13,6 +13,14 @@
 #ifndef DBG_ACC
 #define DBG_ACC(slot)
 #endif
+// phase counters of tools/solve_timing.py (a -DDM_SOLVE_TIMING build of dm_fmap.hip defines g_solve_dbg before this header)
+#if defined(DM_SOLVE_TIMING) && defined(DM_SOLVE_TIMING_HAVE_COUNTERS)
+#define CH_T0() long long _c0 = clock64(); const bool _cd = (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0);
+#define CH_ACC(slot) { const long long _c1 = clock64(); if (_cd) g_solve_dbg[slot] += _c1 - _c0; _c0 = _c1; }
+#else
+#define CH_T0()
+#define CH_ACC(slot)
+#endif
 
 // ---- register-resident factorisation of one 16x16 diagonal block (one wave) ------------------------------
 // Lane (r = lane & 15, g = lane >> 4) holds columns 4g..4g+3 of row r of the symmetric block S and of the identity
@@ -60,37 +68,48 @@ __device__ __forceinline__ void diag_step(double (&s)[4], double (&w)[4], int la
 }
 
 
+// diagonal block J: in-register elimination by wave 0 (see diag_step); leaves Ws[m][k] = W[k][m], W = L_JJ^-1.
+// (Tried and slower on MI355X: a row-per-lane form with the pivot row through v_readlane, 8.4 k instead of 5.9 k cycles
+// per block; the column broadcast by v_permlane32_swap / v_permlane16_swap instead of ds_bpermute, 7.4 k.)
+__device__ __forceinline__ void diag_block(const double* S, double* Ws, double* red, int lane) {
+    const int r = lane & 15, g = lane >> 4;
+    double ds[4], dw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ds[e] = S[r * 16 + 4 * g + e];
+        dw[e] = (r == 4 * g + e) ? 1.0 : 0.0;
+    }
+    bool ok = true;
+    diag_step<0>(ds, dw, lane, ok);   diag_step<1>(ds, dw, lane, ok);
+    diag_step<2>(ds, dw, lane, ok);   diag_step<3>(ds, dw, lane, ok);
+    diag_step<4>(ds, dw, lane, ok);   diag_step<5>(ds, dw, lane, ok);
+    diag_step<6>(ds, dw, lane, ok);   diag_step<7>(ds, dw, lane, ok);
+    diag_step<8>(ds, dw, lane, ok);   diag_step<9>(ds, dw, lane, ok);
+    diag_step<10>(ds, dw, lane, ok);  diag_step<11>(ds, dw, lane, ok);
+    diag_step<12>(ds, dw, lane, ok);  diag_step<13>(ds, dw, lane, ok);
+    diag_step<14>(ds, dw, lane, ok);  diag_step<15>(ds, dw, lane, ok);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Ws[r * 16 + 4 * g + e] = dw[e];
+    if (!ok && lane == 0) red[5] = 1.0;
+}
+
 // T: blocks; Ws: 256-double scratch (W^T of the current block); rhs: NB*16 (in: right-hand side, becomes y);
 // xv: NB*16 (out: solution); red[5]: failure flag (must be 0 on entry); tri_rc: 128 ints, (u -> row << 8 | col) of a
-// lower-triangular enumeration.  All 256 threads call it.  Returns false when a pivot was not positive.
+// lower-triangular enumeration with tri_rc[0] = (0, 0).  All 256 threads call it.  Returns false when a pivot was
+// not positive.
+//
+// Look-ahead: the diagonal elimination is a serial chain on one wave (16 dependent steps), so during the trailing
+// update of column J wave 0 only refreshes block (J+1, J+1) and immediately eliminates it, while waves 1-3 update the
+// rest of the trailing triangle: the chain of column J+1 hides behind the MFMA work of column J.
 __device__ __forceinline__ bool blocked_chol_solve(double* T, double* Ws, double* rhs, double* xv, double* red,
                                                    const int* tri_rc, int NB, int t, int lane, int wave) {
+    CH_T0()
+    if (wave == 0) diag_block(T, Ws, red, lane);
+    __syncthreads();
+    CH_ACC(1)
     for (int J = 0; J < NB; ++J) {
+        if (red[5] != 0.0) break;                // uniform: set before the barrier that closed the previous phase
         double* S = T + (J * (J + 1) / 2 + J) * 256;
-        // ---- (a) diagonal block, wave 0 only, in registers (see diag_step)
-        if (wave == 0) {
-            const int r = lane & 15, g = lane >> 4;
-            double ds[4], dw[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ds[e] = S[r * 16 + 4 * g + e];
-                dw[e] = (r == 4 * g + e) ? 1.0 : 0.0;
-            }
-            bool ok = true;
-            diag_step<0>(ds, dw, lane, ok);   diag_step<1>(ds, dw, lane, ok);
-            diag_step<2>(ds, dw, lane, ok);   diag_step<3>(ds, dw, lane, ok);
-            diag_step<4>(ds, dw, lane, ok);   diag_step<5>(ds, dw, lane, ok);
-            diag_step<6>(ds, dw, lane, ok);   diag_step<7>(ds, dw, lane, ok);
-            diag_step<8>(ds, dw, lane, ok);   diag_step<9>(ds, dw, lane, ok);
-            diag_step<10>(ds, dw, lane, ok);  diag_step<11>(ds, dw, lane, ok);
-            diag_step<12>(ds, dw, lane, ok);  diag_step<13>(ds, dw, lane, ok);
-            diag_step<14>(ds, dw, lane, ok);  diag_step<15>(ds, dw, lane, ok);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Ws[r * 16 + 4 * g + e] = dw[e];      // Ws[m][k] = W[k][m]
-            if (!ok && lane == 0) red[5] = 1.0;
-        }
-        __syncthreads();
-        if (red[5] != 0.0) break;
         // forward solve of this block of the right-hand side, y_J = W rhs_J (16 lanes of the last wave, beside the panel)
         if (t >= 240) {
             const int k = t - 240;
@@ -114,59 +133,80 @@ __device__ __forceinline__ bool blocked_chol_solve(double* T, double* Ws, double
 #pragma unroll
             for (int r = 0; r < 4; ++r) Tij[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
         }
+        S[t] = Ws[t];                            // W_J parked in the (now free) diagonal slot: Ws is reused below
         __syncthreads();
+        CH_ACC(2)
         if (t < 16) rhs[J * 16 + t] = xv[J * 16 + t];
-        // ---- (c) trailing update, right-hand-side update, and W_J parked in the (now free) diagonal slot
+        // ---- (c) trailing update and right-hand-side update (waves 1-3) | block (J+1, J+1) and its elimination (wave 0)
         {
             const int m = NB - 1 - J;                 // remaining block rows
             const int nupd = m * (m + 1) / 2;
-            // four independent blocks per wave per pass: their LDS reads and MFMA chains overlap
-            for (int u0 = wave * 4; u0 < nupd; u0 += 16) {
-                f64x4 acc[4];
-                int off_ik[4], off_ij[4], off_kj[4];
-                const int o0 = (lane >> 4) * 16 + (lane & 15);
+            const int o0 = (lane >> 4) * 16 + (lane & 15);
+            if (wave == 0) {
+                if (m > 0) {
+                    const int I = J + 1;
+                    double* Tii = T + (I * (I + 1) / 2 + I) * 256;
+                    const double* Tij = T + (I * (I + 1) / 2 + J) * 256;
+                    f64x4 acc;
+                    double op[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int u = min(u0 + q, nupd - 1);
-                    const int rc = tri_rc[u];
-                    const int I = J + 1 + (rc >> 8), K = J + 1 + (rc & 255);             // J < K <= I < NB
-                    off_ik[q] = (I * (I + 1) / 2 + K) * 256 + o0;
-                    off_ij[q] = (I * (I + 1) / 2 + J) * 256 + o0;
-                    off_kj[q] = (K * (K + 1) / 2 + J) * 256 + o0;
+                    for (int r = 0; r < 4; ++r) acc[r] = Tii[o0 + r * 64];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[q][r] = T[off_ik[q] + r * 64];
+                    for (int ks = 0; ks < 4; ++ks) op[ks] = Tij[o0 + ks * 64];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) acc = mfma_f64_16x16x4(-op[ks], op[ks], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Tii[o0 + r * 64] = acc[r];
+                    diag_block(Tii, Ws, red, lane);   // (same wave wrote Tii: the LDS queue of a wave is in order)
                 }
-                double opa[4][4], opb[4][4];       // all LDS operand reads first: their latency overlaps the MFMA chains
+            } else {
+                // four independent blocks per wave per pass: their LDS reads and MFMA chains overlap
+                for (int u0 = 1 + (wave - 1) * 4; u0 < nupd; u0 += 12) {
+                    f64x4 acc[4];
+                    int off_ik[4], off_ij[4], off_kj[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q) {
+                        const int u = min(u0 + q, nupd - 1);
+                        const int rc = tri_rc[u];
+                        const int I = J + 1 + (rc >> 8), K = J + 1 + (rc & 255);             // J < K <= I < NB
+                        off_ik[q] = (I * (I + 1) / 2 + K) * 256 + o0;
+                        off_ij[q] = (I * (I + 1) / 2 + J) * 256 + o0;
+                        off_kj[q] = (K * (K + 1) / 2 + J) * 256 + o0;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        opa[q][ks] = -T[off_kj[q] + ks * 64];
-                        opb[q][ks] = T[off_ij[q] + ks * 64];
+                        for (int r = 0; r < 4; ++r) acc[q][r] = T[off_ik[q] + r * 64];
                     }
+                    double opa[4][4], opb[4][4];       // all LDS operand reads first: their latency overlaps the MFMA chains
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = mfma_f64_16x16x4(opa[q][ks], opb[q][ks], acc[q]);
+                        for (int ks = 0; ks < 4; ++ks) {
+                            opa[q][ks] = -T[off_kj[q] + ks * 64];
+                            opb[q][ks] = T[off_ij[q] + ks * 64];
+                        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (u0 + q < nupd) {
+                    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) T[off_ik[q] + r * 64] = acc[q][r];
-                    }
+                        for (int q = 0; q < 4; ++q) acc[q] = mfma_f64_16x16x4(opa[q][ks], opb[q][ks], acc[q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (u0 + q < nupd) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) T[off_ik[q] + r * 64] = acc[q][r];
+                        }
+                }
+                // rhs_I -= L_IJ y_J   (row ii of block I: sum_k T_IJ[k][ii] y_J[k])
+                for (int e = t - 64; e < m * 16; e += 192) {
+                    const int I = J + 1 + (e >> 4), ii = e & 15;
+                    const double* Tij = T + (I * (I + 1) / 2 + J) * 256;
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sacc += Tij[k * 16 + ii] * xv[J * 16 + k];
+                    rhs[I * 16 + ii] -= sacc;
+                }
             }
-            // rhs_I -= L_IJ y_J   (row ii of block I: sum_k T_IJ[k][ii] y_J[k])
-            if (t < m * 16) {
-                const int I = J + 1 + (t >> 4), ii = t & 15;
-                const double* Tij = T + (I * (I + 1) / 2 + J) * 256;
-                double sacc = 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) sacc += Tij[k * 16 + ii] * xv[J * 16 + k];
-                rhs[I * 16 + ii] -= sacc;
-            }
-            S[t] = Ws[t];
         }
         __syncthreads();
+        CH_ACC(7)
     }
     __syncthreads();
     if (red[5] != 0.0) return false;

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(SP_NT) void fmap_solve_kernel(const double* __restr
 #ifdef DM_SOLVE_TIMING
 // phase cycle counters of workgroup (0,0), thread 0 (experiment builds only: tools/solve_timing.py)
 __device__ long long g_solve_dbg[16];
+#define DM_SOLVE_TIMING_HAVE_COUNTERS 1
 extern "C" int dm_debug_solve_timing(long long* out16) {
     return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_solve_dbg), sizeof(long long) * 16) == hipSuccess ? 0 : -3;
 }

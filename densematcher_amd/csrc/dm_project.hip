@@ -17,19 +17,24 @@
 #include "dm_device.h"
 #include "dm_internal.h"
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-constexpr int PT = 128;      // output tile (m x d)
+constexpr int PT = 128;      // output tile: PT basis functions x PTD descriptor channels.  The fp32 -> hi/lo split of the
+constexpr int PTD = 256;     // basis slab is VALU work repeated by every d-tile of a (pair, chunk): wide d-tiles amortise it
 constexpr int PBK = 32;      // vertices per stage
 constexpr int PLD = 160;     // LDS row stride in halves (320 B): rows land 16 banks apart -> conflict-free tr reads
+constexpr int PLDF = 288;    // same property for the 256-wide descriptor rows (576 B = 144 dwords = 16 mod 64)
+constexpr int PSTAGE = 2 * PBK * PLD + PBK * PLDF;   // halves per stage buffer: Xhi | Xlo | F
 
+template <int LD>
 __device__ __forceinline__ f16x8 tr_frag(const _Float16* base, int row0, int col, int lane) {
     // 16-lane group: lane t supplies the address of row (row0 + (t >> 2)), columns col + 4 (t & 3) .. +3 and
     // receives column (col + t), rows row0 .. row0 + 3.  Two reads give 8 consecutive k.
     const int t = lane & 15;
-    const _Float16* p = base + (row0 + (t >> 2)) * PLD + col + 4 * (t & 3);
+    const _Float16* p = base + (row0 + (t >> 2)) * LD + col + 4 * (t & 3);
     const h4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)p);
-    const h4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(p + 4 * PLD));
+    const h4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(p + 4 * LD));
     f16x8 r;
     r[0] = (_Float16)a[0]; r[1] = (_Float16)a[1]; r[2] = (_Float16)a[2]; r[3] = (_Float16)a[3];
     r[4] = (_Float16)b[0]; r[5] = (_Float16)b[1]; r[6] = (_Float16)b[2]; r[7] = (_Float16)b[3];
@@ -85,7 +90,7 @@ struct proj_params {
 };
 
 __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
-    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 3 * PBK * PLD];     // [2 buffers][Xhi | Xlo | F], 60 KiB
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];               // [2 buffers][Xhi | Xlo | F], 76 KiB
     // 1-D grid, XCD-aware: the d-tiles that share one (pair, vertex chunk) slab of the basis are neighbours in the
     // logical order and therefore meet in the same XCD's L2 (otherwise every tile re-fetches the slab from HBM)
     const int ntile = p.tiles_m * p.tiles_d;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
     const int split = (id / ntile) % p.nsplit;
     const int b = id / (ntile * p.nsplit);
     const int tm = tile / p.tiles_d, td = tile - tm * p.tiles_d;
-    const int m0 = tm * PT, d0 = td * PT;
+    const int m0 = tm * PT, d0 = td * PTD;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int nbeg = split * p.kchunk, nend = min(p.N, nbeg + p.kchunk);
@@ -110,19 +115,20 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
     const float* mass = p.mass + (long long)b * p.N;
     const _Float16* F = p.F + (long long)b * p.N * p.D;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];                                        // wave tile 64 (m) x 128 (d)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    const int srow = t >> 3, scol = (t & 7) * 16;            // staging: row of the stage, 16 consecutive columns
+    const int srow = t >> 3, scol = (t & 7) * 16;            // staging: row of the stage, 16 consecutive basis columns
+    const int fcol = (t & 7) * 32;                           //          and 32 consecutive descriptor channels
     const bool xvec = ((p.ld & 3) == 0) && ((((uintptr_t)p.Phi) & 15) == 0);
     const bool fvec = ((p.D & 7) == 0) && ((((uintptr_t)p.F) & 15) == 0);
     float xr[16];
-    uint4 fr[2];
+    u32x4 fr[4];
 #define PROJ_FETCH(s_)                                                                                        \
     {                                                                                                         \
         const int n_ = nbeg + (s_) * PBK + srow;                                                              \
@@ -138,23 +144,23 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
             _Pragma("unroll") for (int q = 0; q < 16; ++q)                                                    \
                 xr[q] = (rv && m0 + scol + q < p.k) ? xrow[q] * an : 0.f;                                     \
         }                                                                                                     \
-        const _Float16* frow = F + (long long)n_ * p.D + d0 + scol;                                           \
-        if (rv && fvec && d0 + scol + 15 < p.D) {                                                             \
-            fr[0] = *reinterpret_cast<const uint4*>(frow);                                                    \
-            fr[1] = *reinterpret_cast<const uint4*>(frow + 8);                                                \
+        const _Float16* frow = F + (long long)n_ * p.D + d0 + fcol;                                           \
+        if (rv && fvec && d0 + fcol + 31 < p.D) {                                                             \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) fr[q] = *reinterpret_cast<const u32x4*>(frow + 8 * q); \
         } else {                                                                                              \
-            _Float16 tmp[16];                                                                                 \
-            _Pragma("unroll") for (int q = 0; q < 16; ++q)                                                    \
-                tmp[q] = (rv && d0 + scol + q < p.D) ? frow[q] : (_Float16)0.f;                               \
-            fr[0] = *reinterpret_cast<const uint4*>(tmp);                                                     \
-            fr[1] = *reinterpret_cast<const uint4*>(tmp + 8);                                                 \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+                f16x8 tmp;                                                                                    \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                 \
+                    tmp[e] = (rv && d0 + fcol + 8 * q + e < p.D) ? frow[8 * q + e] : (_Float16)0.f;           \
+                fr[q] = *reinterpret_cast<const u32x4*>(&tmp);                                                \
+            }                                                                                                 \
         }                                                                                                     \
     }
 #define PROJ_STASH(buf_)                                                                                      \
     {                                                                                                         \
-        _Float16* Xh = smem + (buf_) * 3 * PBK * PLD + srow * PLD + scol;                                     \
+        _Float16* Xh = smem + (buf_) * PSTAGE + srow * PLD + scol;                                            \
         _Float16* Xl = Xh + PBK * PLD;                                                                        \
-        _Float16* Fs = Xl + PBK * PLD;                                                                        \
+        _Float16* Fs = smem + (buf_) * PSTAGE + 2 * PBK * PLD + srow * PLDF + fcol;                           \
         f16x8 h[2], l[2];                                                                                     \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                      \
             const _Float16 hi = (_Float16)xr[q];                                                              \
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
         }                                                                                                     \
         *reinterpret_cast<f16x8*>(Xh) = h[0]; *reinterpret_cast<f16x8*>(Xh + 8) = h[1];                       \
         *reinterpret_cast<f16x8*>(Xl) = l[0]; *reinterpret_cast<f16x8*>(Xl + 8) = l[1];                       \
-        *reinterpret_cast<uint4*>(Fs) = fr[0]; *reinterpret_cast<uint4*>(Fs + 8) = fr[1];                     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(Fs + 8 * q) = fr[q];          \
     }
 
     const int ns = (nend - nbeg + PBK - 1) / PBK;
@@ -175,24 +181,25 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
     for (int s = 0; s < ns; ++s) {
         const int buf = s & 1;
         if (s + 1 < ns) PROJ_FETCH(s + 1)
-        const _Float16* Xh = smem + buf * 3 * PBK * PLD;
+        const _Float16* Xh = smem + buf * PSTAGE;
         const _Float16* Xl = Xh + PBK * PLD;
         const _Float16* Fs = Xl + PBK * PLD;
 #pragma unroll
         for (int ks = 0; ks < PBK / 16; ++ks) {
             const int row0 = ks * 16 + 8 * (lane >> 5);
             const int sub = 16 * ((lane >> 4) & 1) + (lane & 15) - (lane & 15);   // 16-column half of the 32-wide tile
-            f16x8 ah[2], al[2], bf[2];
+            f16x8 ah[2], al[2], bf[4];
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
-                ah[x] = tr_frag(Xh, row0, wm * 64 + x * 32 + sub, lane);
-                al[x] = tr_frag(Xl, row0, wm * 64 + x * 32 + sub, lane);
-                bf[x] = tr_frag(Fs, row0, wn * 64 + x * 32 + sub, lane);
+                ah[x] = tr_frag<PLD>(Xh, row0, wm * 64 + x * 32 + sub, lane);
+                al[x] = tr_frag<PLD>(Xl, row0, wm * 64 + x * 32 + sub, lane);
             }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) bf[x] = tr_frag<PLDF>(Fs, row0, wn * 128 + x * 32 + sub, lane);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < 4; ++nt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bf[nt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bf[nt], acc[mt][nt], 0, 0, 0);
                 }
@@ -203,17 +210,17 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
 #undef PROJ_FETCH
 #undef PROJ_STASH
 
-    // acc[mt][nt][r] = O[m = m0 + wm*64 + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)][d = d0 + wn*64 + nt*32 + (lane&31)]
+    // acc[mt][nt][r] = O[m = m0 + wm*64 + mt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)][d = d0 + wn*128 + nt*32 + (lane&31)]
     const float inv_scale = 1.0f / scale;
     float* out = p.partial + ((long long)split * p.B + b) * p.k * p.D;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int d = d0 + wn * 64 + nt * 32 + (lane & 31);
+                const int d = d0 + wn * 128 + nt * 32 + (lane & 31);
                 if (m < p.k && d < p.D) out[(long long)m * p.D + d] = acc[mt][nt][r] * inv_scale;
             }
 }
@@ -232,7 +239,7 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Ph
     proj_params p;
     p.Phi = Phi; p.mass = mass; p.F = (const _Float16*)F;
     p.B = B; p.N = N; p.D = D; p.k = k; p.ld = ld;
-    p.tiles_m = dm_cdiv(k, PT); p.tiles_d = dm_cdiv(D, PT);
+    p.tiles_m = dm_cdiv(k, PT); p.tiles_d = dm_cdiv(D, PTD);
     // split-K by a fixed chunk of vertices: the summation order of a pair must not depend on the batch it is in
     p.kchunk = 512;
     const int nsplit = dm_cdiv(N, p.kchunk);
@@ -246,7 +253,10 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Ph
     float* amax_part = (float*)dm_ws_take(ctx, (size_t)B * n_part * 4);
     p.amax_part = amax_part; p.n_part = n_part;
     DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel, dim3(n_part, B), dim3(256), 0, Phi, mass, N, ld, amax_part);
-    DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), 0, p);
+    const size_t lds = (size_t)2 * PSTAGE * sizeof(_Float16);
+    rc = dm_grant_lds(ctx, (const void*)proj_f16split_kernel, lds);
+    if (rc) return rc;
+    DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), lds, p);
     const long long n = (long long)B * k * D;
     DM_LAUNCH(ctx, "project_reduce", proj_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.partial, nsplit, n,
               Ared);

@@ -34,9 +34,9 @@ for _ in range(reps):
 torch.cuda.synchronize()
 out = (C.c_longlong * 16)()
 assert eng.lib.dm_debug_solve_timing(out) == 0
-names = ["block load", "(a) diag block", "(b) panel MFMA", "(c) rhs update + copy + barrier", "back substitution",
-         "prologue (eigenvalue scale)", "penalty staging", "(c) trailing MFMA (wave 0)", "block load: global loads"]
-tot = sum(out[:9])
+names = ["block load", "(a) diag block (wave 0) + barrier", "(b) panel MFMA + barrier", "whole solve (a+b+c+back substitution)",
+         "store", "prologue (eigenvalue scale)", "penalty staging", "(c) trailing MFMA + rhs + barrier", "block load: global loads"]
+tot = out[0] + out[3] + out[4] + out[5] + out[6] + out[8]
 for n_, v in zip(names, out[:9]):
     print(f"{n_:28s} {v / reps:12.0f} cycles/solve  {100.0 * v / tot:5.1f} %")
 print("total", tot / reps)
