@@ -81,6 +81,23 @@ def test_fm_to_p2p_bit_exact(eng, fxname, pre, cname, request):
     assert np.array_equal(_np(out2["knn21"]), _np(out["knn21"]))
 
 
+@pytest.mark.parametrize("B,N1,N2,k1,k2,ld1,ld2", [(2, 300, 517, 20, 33, 24, 33), (1, 129, 128, 17, 16, 17, 20),
+                                                  (3, 1000, 777, 64, 50, 64, 64), (1, 257, 1030, 5, 9, 8, 12)])
+def test_fm_to_p2p_ragged_rectangular(eng, B, N1, N2, k1, k2, ld1, ld2):
+    """N1 != N2, k1 != k2, leading dimensions > k, sizes that are not multiples of any tile: all four maps bit-exact"""
+    rng = np.random.default_rng(N1 * 31 + N2)
+    Phi1 = (rng.standard_normal((B, N1, ld1)) * 0.05).astype(np.float32)
+    Phi2 = (rng.standard_normal((B, N2, ld2)) * 0.05).astype(np.float32)
+    a1 = (rng.uniform(0.5, 1.5, (B, N1)) / N1).astype(np.float32)
+    C = rng.standard_normal((B, k2, k1))
+    out = eng.fm_to_p2p(Phi1, Phi2, a1, C)
+    for b in range(B):
+        ref = orc.fm_to_p2p_all(C[b], Phi1[b], Phi2[b], a1[b])
+        for name, r in zip(["knn21", "knn12", "ind21", "ind12"], ref):
+            got = _np(out[name])[b].astype(np.int64)
+            assert np.array_equal(got, r), f"pair {b} {name}: {(got != r).sum()} mismatches"
+
+
 def test_ties_lowest_index(eng, fx_ties):
     fx = fx_ties
     out = eng.fm_to_p2p(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a1"]), _b(fx["C"]))
@@ -126,6 +143,36 @@ def test_zoomout(eng, fx_cfg1, fx_cfg2):
     assert np.array_equal(_np(C0)[0], fx["C_fit"])
     with pytest.raises(AssertionError):
         eng.zoomout(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), _b(fx["C_fit"]), nit=4, step=4)
+
+
+def _smooth_basis(rng, N, k):
+    """random low-frequency-looking columns (mass-orthonormal is not needed by the arithmetic under test)"""
+    x = np.linspace(0.0, 1.0, N)[:, None]
+    f = np.arange(1, k + 1)[None, :]
+    return (np.cos(np.pi * f * x + rng.uniform(0, 6.28, (1, k))) * np.sqrt(2.0 / N)).astype(np.float32)
+
+
+@pytest.mark.parametrize("N1,N2,k0,nit,step", [(400, 333, 6, 5, 2), (520, 700, 10, 4, 3)])
+def test_refine_ragged(eng, N1, N2, k0, nit, step):
+    """ZoomOut, p2p_to_FM and ICP on meshes of different sizes (N1 != N2, nothing a multiple of a tile)"""
+    rng = np.random.default_rng(N1 + N2)
+    kmax = k0 + nit * step
+    Phi1, Phi2 = _smooth_basis(rng, N1, kmax), _smooth_basis(rng, N2, kmax)
+    a2 = (rng.uniform(0.5, 1.5, N2) / N2).astype(np.float32)
+    C0 = np.eye(k0) + 0.05 * rng.standard_normal((k0, k0))
+    C, p = eng.zoomout(_b(Phi1), _b(Phi2), _b(a2), _b(C0), nit=nit, step=step, return_p2p=True)
+    Co, po = orc.zoomout_refine(C0, Phi1, Phi2, nit=nit, step=step, a2=a2, return_p2p=True)
+    assert np.array_equal(_np(p)[0].astype(np.int64), po)
+    assert np.abs(_np(C)[0] - Co).max() <= 1e-11
+    # rectangular p2p -> FM
+    k1, k2 = k0 + 3, k0 + 1
+    Cr = _np(eng.p2p_to_fm(_b(po.astype(np.int32)), _b(Phi1), _b(Phi2), _b(a2), k1, k2))[0]
+    Cro = orc.p2p_to_fm(po, Phi1[:, :k1], Phi2[:, :k2], a2)
+    assert Cr.shape == (k2, k1) and np.abs(Cr - Cro).max() <= 1e-13 * max(1.0, np.abs(Cro).max())
+    # ICP from the same start: orthonormal columns, same map as the oracle
+    Ci = _np(eng.icp(_b(Phi1[:, :k0]), _b(Phi2[:, :k0]), _b(C0), nit=3))[0]
+    Cio = orc.icp_refine(C0, Phi1[:, :k0], Phi2[:, :k0], nit=3)
+    assert np.abs(Ci - Cio).max() <= 1e-9
 
 
 # --------------------------------------------------------------------------- #
