@@ -145,6 +145,29 @@ def test_zoomout(eng, fx_cfg1, fx_cfg2):
         eng.zoomout(_b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), _b(fx["C_fit"]), nit=4, step=4)
 
 
+@pytest.mark.parametrize("N1,N2,k1,k2,D", [(1, 1, 1, 1, 8), (2, 3, 1, 2, 8), (3, 2, 2, 2, 16), (5, 7, 3, 4, 8), (17, 16, 2, 2, 24)])
+def test_tiny_shapes(eng, N1, N2, k1, k2, D):
+    """degenerate sizes (a single vertex, a single eigenfunction): every entry point still equals the oracle"""
+    rng = np.random.default_rng(N1 * 100 + N2)
+    Phi1 = (rng.standard_normal((1, N1, k1)) * 0.3).astype(np.float32)
+    Phi2 = (rng.standard_normal((1, N2, k2)) * 0.3).astype(np.float32)
+    a1 = rng.uniform(0.5, 1.5, (1, N1)).astype(np.float32)
+    a2 = rng.uniform(0.5, 1.5, (1, N2)).astype(np.float32)
+    C = rng.standard_normal((1, k2, k1))
+    out = eng.fm_to_p2p(Phi1, Phi2, a1, C)
+    ref = orc.fm_to_p2p_all(C[0], Phi1[0], Phi2[0], a1[0])
+    for name, r in zip(["knn21", "knn12", "ind21", "ind12"], ref):
+        assert np.array_equal(_np(out[name])[0], r), name
+    F1 = rng.standard_normal((1, N1, D)).astype(np.float16)
+    F2 = rng.standard_normal((1, N2, D)).astype(np.float16)
+    assert np.array_equal(_np(eng.simnn(F2, F1))[0], orc.simnn(F2[0], F1[0]))
+    Ao = orc.project(Phi1[0], a1[0], F1[0])
+    assert np.abs(_np(eng.project(Phi1, a1, F1, k1))[0] - Ao).max() <= 1e-5 * np.abs(Ao).max()
+    p = rng.integers(0, N1, (1, N2)).astype(np.int32)
+    Cpo = orc.p2p_to_fm(p[0], Phi1[0], Phi2[0], a2[0])
+    assert np.abs(_np(eng.p2p_to_fm(p, Phi1, Phi2, a2, k1, k2))[0] - Cpo).max() <= 1e-12 * max(1.0, np.abs(Cpo).max())
+
+
 def _smooth_basis(rng, N, k):
     """random low-frequency-looking columns (mass-orthonormal is not needed by the arithmetic under test)"""
     x = np.linspace(0.0, 1.0, N)[:, None]
