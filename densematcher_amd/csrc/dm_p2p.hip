@@ -311,7 +311,13 @@ __global__ __launch_bounds__(256, 2) void gred_kernel(gred_params p) {
     const int tiles = p.tilesM * p.tilesN;
     const int b = id / tiles;
     const int tmn = id - b * tiles;
-    const int tm = tmn / p.tilesN, tn = tmn - tm * p.tilesN;
+    // tile order inside a pair: bands of 8 tile rows, column-major inside a band, so the ~64 tiles that are resident
+    // on an XCD at one time form an 8 x 8 block and share 16 operand panels (3.4 MB at k = 200) instead of one row's
+    // 1 + 64 panels -- at N = 8192 the row order re-fetched the B panels from HBM for every tile row (PMC: 57 GB/launch)
+    const int band = tmn / (8 * p.tilesN);
+    const int brow0 = band * 8, brows = min(8, p.tilesM - brow0);
+    const int brem = tmn - band * 8 * p.tilesN;
+    const int tn = brem / brows, tm = brow0 + (brem - tn * brows);
     const int i0 = tm * GT, j0 = tn * GT;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
