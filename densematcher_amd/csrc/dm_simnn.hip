@@ -430,8 +430,8 @@ __global__ __launch_bounds__(512, 2) void simnn_pipe_kernel(simnn_params p) {
 #define SIMNN_DMA1(s_, q)                                                                                        \
     {                                                                                                            \
         _Float16* dst = smem + ((s_) & (PNBUF - 1)) * PSTAGE + (wave * 32 + (q) * 16) * PBK;                     \
-        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * PBK), (lptr_t)dst, 16, 0, 0);                \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * PBK), (lptr_t)(dst + ST * PBK), 16, 0, 0);   \
+        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (kbase + kstep * (s_)) * PBK), (lptr_t)dst, 16, 0, 0);                \
+        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (kbase + kstep * (s_)) * PBK), (lptr_t)(dst + ST * PBK), 16, 0, 0);   \
     }
 #define SIMNN_DMA(s_) SIMNN_DMA1(s_, 0) SIMNN_DMA1(s_, 1)
 
@@ -444,6 +444,12 @@ __global__ __launch_bounds__(512, 2) void simnn_pipe_kernel(simnn_params p) {
     const int sbase = ST * PBK + wsrc * 128 * PBK, tbase = wtgt * 64 * PBK;
 
     const int ns = (p.dbg == 2) ? 3 : p.D / PBK;                 // >= 3 (host checks D >= 96)
+    // The 32 workgroups of an XCD sweep the contraction roughly in step; consecutive waves of 32 tiles alternate the
+    // sweep direction, so a wave starts on the K chunks its predecessor touched last (still in the 4 MB L2) when they
+    // share operand panels -- a pair's panels (6 MB) do not fit, and with one direction the LRU has always just
+    // evicted the chunk that is needed next.  (Any order gives the same exact result: ties go to the fix-up.)
+    const bool krev = ((tts >> 5) & 1) != 0;
+    const int kbase = krev ? ns - 1 : 0, kstep = krev ? -1 : 1;
     SIMNN_DMA(0)
     SIMNN_DMA(1)
     SIMNN_DMA(2)
