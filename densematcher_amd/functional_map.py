@@ -24,12 +24,14 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
     p2p_21 / p2p_12 are the indicator arg-max maps (:49-50), the *_adjoint ones the kd-tree maps (:48).
     '''
     assert descr_type in ["neural", "HKS", "WKS"]
-    if descr_type != "neural":
-        raise NotImplementedError(f"{descr_type} descriptors are outside the matching path (pass neural features c1, c2)")
     mesh1 = TriMesh(_np(mesh1_t.verts_list()[0]), _np(mesh1_t.faces_list()[0]))
     mesh2 = TriMesh(_np(mesh2_t.verts_list()[0]), _np(mesh2_t.faces_list()[0]))
-    process_params = {'n_ev': (n_ev, n_ev), 'n_descr': c1.shape[1], 'landmarks': None, 'descr1': _np(c1), 'descr2': _np(c2),
-                      'subsample_step': 1}
+    if descr_type == "neural":
+        process_params = {'n_ev': (n_ev, n_ev), 'n_descr': c1.shape[1], 'landmarks': None, 'descr1': _np(c1), 'descr2': _np(c2),
+                          'subsample_step': 1}
+    else:                                     # spectral signatures instead of network features (functional_map.py:19-35)
+        process_params = {'n_ev': (n_ev, n_ev), 'n_descr': 16 if descr_type == "HKS" else 2048, 'landmarks': None,
+                          'descr_type': descr_type, 'subsample_step': 1}
     model = FunctionalMapping(mesh1, mesh2, partial=False, optimizer=optimizer)
     model.preprocess(**process_params, verbose=False)
     fit_params = dict(fit_params or {})

@@ -6,7 +6,7 @@ import copy
 
 import numpy as np
 
-from . import refine, spectral
+from . import refine, signatures as sg, spectral
 
 _OPTIMIZERS = ("L-BFGS-B", "fmin_l_bfgs_b", "l-bfgs-b")
 
@@ -80,20 +80,33 @@ class FunctionalMapping:
     def fitted(self):
         return self.FM is not None
 
+    def _get_lmks(self, landmarks, verbose=False):
+        # (p,) / (p,1): the same vertex indices on both meshes; (p,2): one column per mesh      functional.py:253-262
+        lm = np.asarray(landmarks)
+        if lm.squeeze().ndim == 1:
+            return lm.squeeze(), lm.squeeze().copy()
+        return lm[:, 0], lm[:, 1]
+
     # ---------------------------------------------------------------- preprocess (functional.py:264-350)
     def preprocess(self, n_ev=(50, 50), n_descr=100, descr_type='WKS', landmarks=None, subsample_step=1, k_process=None,
                    verbose=False, descr1=None, descr2=None):
         self.k1, self.k2 = n_ev
         if k_process is None:
             k_process = 1
-        if landmarks is not None and len(landmarks) > 0:
-            raise NotImplementedError("landmark descriptors (HKS/WKS) are outside the matching path")
+        use_lm = landmarks is not None and len(landmarks) > 0
         self.mesh1.process(max(self.k1, k_process), verbose=verbose, robust=True, intrinsic=False)
         self.mesh2.process(max(self.k2, k_process), verbose=verbose, robust=True, intrinsic=False)
+        if use_lm:
+            lmks1, lmks2 = self._get_lmks(landmarks)
         if descr1 is not None and descr2 is not None:
             self.descr1, self.descr2 = descr1, descr2
-        elif descr_type in ('HKS', 'WKS'):
-            raise NotImplementedError(f"{descr_type} signatures are an alternative descriptor source, not the neural path")
+        elif descr_type in ('HKS', 'WKS'):                                       # functional.py:308-329
+            sig = sg.mesh_HKS if descr_type == 'HKS' else sg.mesh_WKS
+            self.descr1 = sig(self.mesh1, n_descr, k=self.k1)                    # (N1, n_descr)
+            self.descr2 = sig(self.mesh2, n_descr, k=self.k2)
+            if use_lm:
+                self.descr1 = np.hstack([self.descr1, sig(self.mesh1, n_descr, landmarks=lmks1, k=self.k1)])
+                self.descr2 = np.hstack([self.descr2, sig(self.mesh2, n_descr, landmarks=lmks2, k=self.k2)])
         else:
             raise ValueError(f'Descriptor type "{descr_type}" not implemented')
         self.descr1 = self.descr1[:, np.arange(0, self.descr1.shape[1], subsample_step)]      # functional.py:333-334

@@ -143,3 +143,39 @@ def test_functional_mapping_and_surface_map(fx_cfg1, monkeypatch):
     assert min(agree[:4]) >= 0.98
     assert res[6] is not None and len(res[6]) == 2          # hungarian_icp (host SciPy passthrough)
     assert res[2] is None and res[3] is None
+
+
+def test_fit_on_spectral_signatures():
+    """descr_type='HKS' (row a-3 of the scope table): descriptors from the host mirror, fit on the GPU; float64
+    descriptors go through the float64 projection path.  Against the oracle on the same descriptors, and (loosely)
+    against the map the reference's own fp32 L-BFGS-B produced (tests/golden/fx_sig.npz)."""
+    import os
+    import types
+    from densematcher_amd.pyFM import FunctionalMapping
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "fx_sig.npz"))
+    k = int(fx["k"])
+
+    def mesh(which):
+        m = types.SimpleNamespace(eigenvalues=fx[f"lam{which}"][:k].copy(), eigenvectors=fx[f"Phi{which}"][:, :k].astype(np.float64),
+                                  A=sp.diags(fx[f"a{which}"].astype(np.float64)).tocsr())
+        m.process = lambda *a, **kw: m
+        m.area = float(fx[f"a{which}"].astype(np.float64).sum())
+        return m
+
+    model = FunctionalMapping(mesh(1), mesh(2), partial=False, optimizer="L-BFGS-B")
+    model.preprocess(n_ev=(k, k), n_descr=16, descr_type="HKS", landmarks=fx["landmarks2"], subsample_step=2)
+    assert np.abs(model.descr1 - fx["pre_descr1"]).max() <= 1e-12 * np.abs(fx["pre_descr1"]).max()
+    model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, optinit="zeros")
+    Co = orc.fit(fx["Phi1"][:, :k], fx["Phi2"][:, :k], fx["lam1"][:k], fx["lam2"][:k], fx["a1"], fx["a2"],
+                 model.descr1.astype(np.float32), model.descr2.astype(np.float32), 1e4, 1e3)
+    assert np.abs(model.FM - Co).max() <= 1e-4
+    # The HKS problem is ill-conditioned (32 nearly collinear descriptors): the reference's fp32 L-BFGS-B stops in a flat
+    # valley (|grad| = 2e-2, 0.5 away in C) at an energy 6.5e-5 (relative) ABOVE the minimum.  Parity is therefore
+    # stated on the energy both minimise: the GPU map is at least as good and within 1e-3 of the reference's value.
+    A = orc.project(fx["Phi1"][:, :k], fx["a1"], model.descr1.astype(np.float32))
+    B = orc.project(fx["Phi2"][:, :k], fx["a2"], model.descr2.astype(np.float32))
+    ev = orc.ev_sqdiff(fx["lam1"][:k], fx["lam2"][:k])
+    e_gpu, e_ref = orc.energy(model.FM, A, B, ev, 1e4, 1e3), orc.energy(fx["C_fit_hks"], A, B, ev, 1e4, 1e3)
+    print("energy: GPU", e_gpu, " reference fit", e_ref, " |C_gpu - C_fit| =", np.abs(model.FM - fx["C_fit_hks"]).max())
+    assert e_gpu <= e_ref * (1 + 1e-12) and (e_ref - e_gpu) <= 1e-3 * e_ref
+    assert np.array_equal(model.FM[:, 0], fx["C_fit_hks"][:, 0])                 # the pinned column (get_x0) is identical

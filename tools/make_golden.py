@@ -293,11 +293,51 @@ def case_cfg2():
           " ind21==perm:", (i21 == perm).mean())
 
 
+
+def case_signatures():
+    """HKS / WKS descriptors (pyFM/signatures) of the config-1 meshes, plain and landmark versions, and the
+    functional map the reference fits on HKS descriptors (functional.py:308-329 -> fit)."""
+    import densematcher.pyFM.signatures as ref_sg
+    nu, nv, k, kbig = 25, 20, 30, 48
+    v1, f1 = synth.torus_mesh(nu, nv)
+    v2, f2 = synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
+    m1, (phi1, lam1, a1) = processed_mesh(v1, f1, kbig)
+    m2, (phi2, lam2, a2) = processed_mesh(v2, f2, kbig)
+    lm = np.array([3, 77, 410])
+    lm2 = np.array([[3, 5], [77, 90], [410, 400]])
+    wks_big = ref_sg.mesh_WKS(m1, 2048, k=k)
+    t1, t2 = truncated(m1, k), truncated(m2, k)
+    model = FunctionalMapping(t1, t2, partial=False, optimizer="L-BFGS-B")
+    # (process() would recompute the spectrum: the truncated meshes already hold exactly k eigenpairs, so the
+    #  reference's `process(max(k, 1))` is a no-op only if patched -- same trick as compute_surface_map above)
+    orig_process = TriMesh.process
+    TriMesh.process = lambda self, k=200, **kw: self
+    try:
+        model.preprocess(n_ev=(k, k), n_descr=16, descr_type="HKS", landmarks=lm2, subsample_step=2)
+    finally:
+        TriMesh.process = orig_process
+    d1, d2 = model.descr1.copy(), model.descr2.copy()
+    model.fit(**FIT, device=CPU)
+    np.savez_compressed(
+        os.path.join(OUT, "fx_sig.npz"),
+        Phi1=phi1, lam1=lam1, a1=a1, Phi2=phi2, lam2=lam2, a2=a2, k=k, landmarks=lm, landmarks2=lm2,
+        hks=ref_sg.mesh_HKS(m1, 16, k=k), wks=ref_sg.mesh_WKS(m1, 24, k=k),
+        hks_lm=ref_sg.mesh_HKS(m1, 5, landmarks=lm, k=k), wks_lm=ref_sg.mesh_WKS(m1, 7, landmarks=lm, k=k),
+        hks_allk=ref_sg.mesh_HKS(m2, 9), wks_big_cols=wks_big[:, ::64].copy(), wks_big_sum=wks_big.sum(axis=1),
+        pre_descr1=d1, pre_descr2=d2, C_fit_hks=model.FM.copy(),
+    )
+    print("signatures: hks", d1.shape, "C_fit_hks", model.FM.shape)
+
+
 if __name__ == "__main__":
     np.random.seed(0)
     torch.manual_seed(0)
-    base = case_cfg1()
-    case_ties(base)
-    case_cfg2()
+    if "--signatures-only" in sys.argv:
+        case_signatures()
+    else:
+        base = case_cfg1()
+        case_ties(base)
+        case_cfg2()
+        case_signatures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
