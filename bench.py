@@ -142,7 +142,7 @@ def main():
         flops_per_launch = tot / 150.0
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
     peak = PEAK_TFLOPS[dtype]
-    traffic = pmc_traffic_bytes(kernel) if args.workload == "fmap" and not args.batch else None
+    traffic, traffic_file = (pmc_traffic_bytes(kernel, args.workload) if not args.batch else (None, None))
 
     out = {
         "metric": "mesh-pairs/sec at N=2048 D=768 k=128" if args.workload == "fmap" else f"mesh-pairs/sec ({args.workload})",
@@ -152,7 +152,7 @@ def main():
         "config": {"workload": w["cfg"], "pairs_per_gpu": B, "N": N, "D": D, "k": k, "parallelism": f"pairs sharded over {world} GPU(s), no collective"},
         "roofline": {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3) if achieved else None, "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
-                     "traffic_source": "HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_fmap_hbm_traffic_pmc.csv: "
+                     "traffic_source": f"HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/{traffic_file}: "
                                        "2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None,
                      "launches": launches, "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops_per_launch},
     }
@@ -165,11 +165,12 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic_bytes(kernel):
+def pmc_traffic_bytes(kernel, workload):
     """HBM bytes per launch of the dominant kernel, measured in separate rocprofv3 --pmc passes of this same command
-    (PMC collection cannot run inside the timed region); summary committed under profiles/."""
-    path = os.path.join(REPO, "profiles", "r01_fmap_hbm_traffic_pmc.csv")
-    key = {"gred_f64": "gred_kernel"}.get(kernel, kernel)
+    (PMC collection cannot run inside the timed region); summaries committed under profiles/."""
+    fname = f"r01_{workload}_hbm_traffic_pmc.csv"
+    path = os.path.join(REPO, "profiles", fname)
+    key = {"gred_f64": "gred_kernel", "simnn_f16_mfma": "simnn_pipe_kernel"}.get(kernel, kernel)
     try:
         import csv
         rows = [r for r in csv.reader(l for l in open(path) if not l.startswith("#"))]
@@ -177,10 +178,10 @@ def pmc_traffic_bytes(kernel):
         for r in rows[1:]:
             if key in r[0]:
                 d = dict(zip(hdr, r))
-                return int((float(d["fetch_MB_corrected"]) + float(d["write_MB"])) * 1e6)
+                return int((float(d["fetch_MB_corrected"]) + float(d["write_MB"])) * 1e6), fname
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(workload, host, k):
