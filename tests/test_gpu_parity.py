@@ -319,3 +319,78 @@ def test_project_ragged(eng, B, N, D, k, ld):
         ref = orc.project(Phi[b][:, :k], a[b], F[b])
         assert np.abs(exact[b] - ref).max() <= 2e-7 * np.abs(ref).max()
         assert np.abs(fast[b] - ref).max() <= 3e-6 * np.abs(ref).max()
+
+
+# --------------------------------------------------------------------------- #
+# randomised shapes (hypothesis): whatever the sizes, the integer outputs equal the oracle's
+def _fuzz_settings():
+    from hypothesis import HealthCheck, settings
+    return settings(max_examples=25, deadline=None, derandomize=True,
+                    suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+def test_fuzz_fm_to_p2p(eng):
+    from hypothesis import given, strategies as st
+
+    @_fuzz_settings()
+    @given(st.integers(1, 3), st.integers(1, 400), st.integers(1, 400), st.integers(1, 40), st.integers(1, 40), st.integers(0, 9),
+           st.integers(0, 2 ** 31 - 1))
+    def run(B, N1, N2, k1, k2, extra_ld, seed):
+        rng = np.random.default_rng(seed)
+        Phi1 = (rng.standard_normal((B, N1, k1 + extra_ld)) * 0.1).astype(np.float32)
+        Phi2 = (rng.standard_normal((B, N2, k2 + (extra_ld // 2))) * 0.1).astype(np.float32)
+        a1 = rng.uniform(0.1, 2.0, (B, N1)).astype(np.float32)
+        C = rng.standard_normal((B, k2, k1))
+        out = eng.fm_to_p2p(Phi1, Phi2, a1, C)
+        for b in range(B):
+            ref = orc.fm_to_p2p_all(C[b], Phi1[b], Phi2[b], a1[b])
+            for name, r in zip(["knn21", "knn12", "ind21", "ind12"], ref):
+                assert np.array_equal(_np(out[name])[b], r), (name, B, N1, N2, k1, k2)
+    run()
+
+
+def test_fuzz_simnn(eng):
+    from hypothesis import given, strategies as st
+
+    @_fuzz_settings()
+    @given(st.integers(1, 3), st.integers(1, 600), st.integers(1, 600), st.integers(1, 40), st.booleans(), st.integers(0, 2 ** 31 - 1))
+    def run(B, N2, N1, d8, dup, seed):
+        rng = np.random.default_rng(seed)
+        D = 8 * d8
+        S = rng.standard_normal((B, N1, D)).astype(np.float16)
+        T = rng.standard_normal((B, N2, D)).astype(np.float16)
+        if dup and N1 > 4:                                   # duplicated source rows: the lowest index has to win
+            S[:, N1 // 2] = S[:, 1]
+            T[:, 0] = S[:, 1]
+        nn = _np(eng.simnn(T, S))
+        for b in range(B):
+            assert np.array_equal(nn[b], orc.simnn(T[b], S[b])), (B, N2, N1, D)
+    run()
+
+
+def test_fuzz_project_and_solve(eng):
+    from hypothesis import given, strategies as st
+
+    @_fuzz_settings()
+    @given(st.integers(1, 2), st.integers(2, 300), st.integers(1, 48), st.integers(1, 48), st.integers(1, 12), st.integers(0, 2 ** 31 - 1))
+    def run(B, N, k1, k2, d8, seed):
+        rng = np.random.default_rng(seed)
+        D = 8 * d8
+        Phi1 = (rng.standard_normal((B, N, k1)) * 0.1).astype(np.float32)
+        Phi2 = (rng.standard_normal((B, N, k2)) * 0.1).astype(np.float32)
+        a = (rng.uniform(0.5, 1.5, (B, N)) / N).astype(np.float32)
+        F1 = rng.standard_normal((B, N, D)).astype(np.float16)
+        F2 = rng.standard_normal((B, N, D)).astype(np.float16)
+        A = _np(eng.project(Phi1, a, F1, k1, exact=True))
+        Bm = _np(eng.project(Phi2, a, F2, k2, exact=True))
+        lam1 = np.sort(rng.uniform(0, 50, (B, k1)), axis=1); lam1[:, 0] = 0
+        lam2 = np.sort(rng.uniform(0, 60, (B, k2)), axis=1); lam2[:, 0] = 0
+        c00 = rng.choice([-1.0, 1.0], B) * rng.uniform(0.5, 1.5, B)
+        C = _np(eng.fmap_solve(A, Bm, lam1, lam2, c00, 1e4, 1e3))
+        for b in range(B):
+            Ao = orc.project(Phi1[b], a[b], F1[b])
+            assert np.abs(A[b] - Ao).max() <= 2e-7 * max(np.abs(Ao).max(), 1e-30)
+            x0 = np.zeros((k2, k1)); x0[0, 0] = c00[b]
+            Co = orc.fmap_solve(A[b], Bm[b], lam1[b], lam2[b], x0, 1e4, 1e3)
+            assert np.abs(C[b] - Co).max() <= 1e-8 * max(1.0, np.abs(Co).max()), (k1, k2, D, np.abs(C[b] - Co).max())
+    run()
