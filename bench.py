@@ -109,7 +109,10 @@ def main():
 
         def step():
             return eng.zoomout(dev["Phi1"], dev["Phi2"], dev["a2"], C0, nit=nit, step=1)
-        kernel, dtype = "gred_f64", "f64"
+        # dominant kernel: the fp16-split first pass of the nearest-neighbour search (dm_knnsplit.hip); with
+        # DM_KNN_SPLIT=0 the float64 G kernel does the same job
+        split = os.environ.get("DM_KNN_SPLIT", "1") != "0"
+        kernel, dtype = ("simnn_f16_mfma", "f16") if split else ("gred_f64", "f64")
         flops_per_launch = None                                     # varies with k: summed below
         unit_name = "mesh-pairs/s"
 
@@ -137,9 +140,18 @@ def main():
     pairs_total = B * world * args.steps
     value = pairs_total / elapsed
     avg_ms = kernel_ms / max(launches, 1)
+    extra = {}
     if args.workload == "zoomout":
-        tot = sum(2.0 * N * N * (((kk + 15) // 16) * 16) * B for kk in range(50, 200))
-        flops_per_launch = tot / 150.0
+        ks = range(50, 200)
+        alg = sum(2.0 * N * N * kk * B for kk in ks) / 150.0        # 2 N^2 k per pair and iteration
+        if kernel == "simnn_f16_mfma":
+            # what the fp16 matrix cores execute: three fp16 products per contraction index (hi*hi, hi*lo, lo*hi) plus
+            # three bias entries, padded to the 32-wide stage
+            flops_per_launch = sum(2.0 * N * N * max(96, -(-(3 * kk + 3) // 32) * 32) * B for kk in ks) / 150.0
+            extra = {"algorithmic_f64_flops_per_launch": alg,
+                     "note": "achieved/peak count the fp16 flops the split executes (3x the algorithmic 2N^2k + padding)"}
+        else:
+            flops_per_launch = sum(2.0 * N * N * (((kk + 15) // 16) * 16) * B for kk in ks) / 150.0
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
     peak = PEAK_TFLOPS[dtype]
     traffic, traffic_file = (pmc_traffic_bytes(kernel, args.workload) if not args.batch else (None, None))
@@ -154,7 +166,8 @@ def main():
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
                      "traffic_source": f"HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/{traffic_file}: "
                                        "2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None,
-                     "launches": launches, "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops_per_launch},
+                     "launches": launches, "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops_per_launch,
+                     **extra},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -98,6 +98,7 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
 struct dm_gred_args {
     int B, N2, N1;                    // G is N2 x N1
     int Kloop;                        // contraction depth actually traversed (multiple of 16, <= Kpad)
+    int Ktrue = 0;                    // rows of BT that can be non-zero (<= Kloop; 0 = unknown, use Kloop)
     const double* AT; int N2pad;      // (B, Kpad, N2pad)  rows = Phi2^T
     const double* BT; int N1pad;      // (B, Kpad, N1pad)  rows = emb1^T
     int Kpad;
@@ -108,6 +109,22 @@ struct dm_gred_args {
 };
 int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a);
 size_t dm_gred_ws_bytes(int B, int N2, int N1);
+
+// fp16 tile kernel + merge of the feature-similarity NN, reusable as a first pass (dm_simnn.hip)
+struct dm_simnn_queue {               // rows queued for exact re-evaluation and the 32-source block maxima that prune it
+    const float* pb32; int nsub; int N2pad;
+    const int32_t* flag_count; const int32_t* flag_list; const float* flag_thr;
+};
+size_t dm_simnn_ws_bytes(int B, int N2, int N1);
+int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, const _Float16* Fsrc, float rel_extra,
+                  const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q);
+
+// knn21 alone (ZoomOut, ICP): fp16-split first pass on the fp16 matrix cores + exact float64 re-evaluation of the
+// ambiguous rows (dm_knnsplit.hip); same arguments as dm_launch_gred, only AT, BT, n1 and knn21 are used
+int dm_launch_knn_split(dm_ctx* ctx, const dm_gred_args& a);
+size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int Kloop);
+// knn21-only dispatch: the split path unless DM_KNN_SPLIT=0 (then the float64 G kernel)
+int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a);
 
 // C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,

@@ -1,0 +1,201 @@
+// knn21[i] = argmin_j  n1_j - 2 <x_i, y_j>     (x_i = row i of Phi2, y_j = row j of Phi1 C^T; the ZoomOut / ICP map)
+// in two passes instead of the float64 G kernel:
+//
+//  1. fp16 matrix cores.  Both operands are scaled by a power of two (max |.| in [1, 2)) and split in two fp16 pieces,
+//     x = xh + xl, y = yh + yl (22 significant bits), and laid out as fp16 "feature" rows
+//         target i : [ xh_0, xh_0, xl_0 | xh_1, xh_1, xl_1 | ... |  1,  1,  1 | 0 pad ]
+//         source j : [ yh_0, yl_0, yh_0 | yh_1, yl_1, yh_1 | ... | b0, b1, b2 | 0 pad ]      b0+b1+b2 = -n1_j sx sy / 2
+//     so that one fp16 inner product (exact products, fp32 accumulation) is
+//         sx sy (<x_i, y_j> - n1_j / 2) - <xl, yl> - split residuals
+//     and the arg-max of it over j is the wanted arg-min up to a bounded error.  The tile kernel, the top-2 bookkeeping
+//     and the 32-source block maxima are those of dm_simnn_f16 (dm_simnn_core).
+//  2. every row whose (best - second) is inside twice the error bound is re-evaluated exactly: float64 products of
+//     the original operands, only over the 32-source blocks whose fp32 maximum can still win, lowest index on ties.
+//     Bound, relative to |t_i| max_j |s_j| (>= |x~_i| |y~_j|): fp32 accumulation D (1 + 1/16) 2^-23 (dm_simnn_core)
+//     + 2^-19 for the split (dropped <xl, yl> <= 2^-22, two residuals <= 2^-22 each, fp16 subnormal floor
+//     <= 2 sqrt(k) 2^-25 <= 2^-20.2 for k <= 200, bias pieces 2^-32).
+//     If -n1_j sx sy / 2 does not fit fp16 (operand scales more than ~2^15 apart) the pair is flagged as a whole and
+//     every row takes the exact path: slower, never wrong.
+#include <stdlib.h>
+
+#include "dm_device.h"
+#include "dm_internal.h"
+
+static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+
+constexpr int KS_NCH = 32;     // partial maxima per (pair, operand)
+
+// amax[(b*2 + which) * KS_NCH + chunk] = max |M[r][c]| over rows r = chunk (mod KS_NCH), r < K  (which: 0 = AT, 1 = BT)
+__global__ __launch_bounds__(256) void ks_absmax_kernel(const double* __restrict__ AT, const double* __restrict__ BT, int K,
+                                                        int N2, int N2pad, int N1, int N1pad, int Kpad, double* __restrict__ amax) {
+    __shared__ double sh[4];
+    const int chunk = blockIdx.x, which = blockIdx.y, b = blockIdx.z, t = threadIdx.x;
+    const double* M = which ? BT + (long long)b * Kpad * N1pad : AT + (long long)b * Kpad * N2pad;
+    const int n = which ? N1 : N2, npad = which ? N1pad : N2pad;
+    double m = 0.0;
+    for (int r = chunk; r < K; r += KS_NCH)
+        for (int c = t; c < n; c += 256) m = fmax(m, fabs(M[(long long)r * npad + c]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((t & 63) == 0) sh[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) amax[(b * 2 + which) * KS_NCH + chunk] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// power of two s with max |v| s in [1, 2)  (1 when the operand is all zero)
+__device__ __forceinline__ double ks_scale(const double* __restrict__ amax, int b, int which) {
+    double m = 0.0;
+    for (int q = 0; q < KS_NCH; ++q) m = fmax(m, amax[(b * 2 + which) * KS_NCH + q]);
+    int ex = 0;
+    if (!(m > 0.0) || !(m < DM_INF_F64)) return 1.0;
+    (void)frexp(m, &ex);                                          // m = f 2^ex, f in [0.5, 1)
+    return ldexp(1.0, 1 - ex);
+}
+
+__device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (double)hi);
+}
+
+// Feature rows, layout [ 3 K split entries | 3 bias entries | zero pad ].  A workgroup handles 256 vertices x 16
+// contraction indices: the K-major float64 operand is read coalesced over the vertices, every thread writes 96
+// contiguous, 16-byte aligned bytes of its row.  blockIdx.y == ceil(K / 16): bias entries and padding.
+template <bool SRC>
+__global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict__ M, const double* __restrict__ n1,
+                                                       const double* __restrict__ amax, int K, int N, int Npad, int Kpad, int D,
+                                                       _Float16* __restrict__ F, int32_t* __restrict__ overflow) {
+    const int b = blockIdx.z, r0 = blockIdx.y * 16;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= N) return;
+    _Float16* row = F + ((long long)b * N + v) * D;
+    const double sx = ks_scale(amax, b, 0), sy = ks_scale(amax, b, 1);
+    if (r0 >= K) {
+        if (SRC) {
+            const double beta = -0.5 * n1[(long long)b * Npad + v] * sx * sy;
+            if (!(fabs(beta) < 60000.0)) { overflow[b] = 1; row[3 * K] = row[3 * K + 1] = row[3 * K + 2] = (_Float16)0.0f; }
+            else {
+                const _Float16 b0 = (_Float16)beta;
+                const double r1 = beta - (double)b0;
+                const _Float16 b1 = (_Float16)r1;
+                row[3 * K] = b0; row[3 * K + 1] = b1; row[3 * K + 2] = (_Float16)(r1 - (double)b1);
+            }
+        } else {
+            row[3 * K] = row[3 * K + 1] = row[3 * K + 2] = (_Float16)1.0f;
+        }
+        for (int c = 3 * K + 3; c < D; ++c) row[c] = (_Float16)0.0f;
+        return;
+    }
+    const double sc = SRC ? sy : sx;
+    const double* col = M + ((long long)b * Kpad + r0) * Npad + v;
+    if (r0 + 16 <= K) {
+        f16x8 o[6];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            _Float16 h, l;
+            split2(col[(long long)q * Npad] * sc, h, l);
+            const int e = 3 * q;                                  // target: (h, h, l)   source: (h, l, h)
+            o[e >> 3][e & 7] = h;
+            o[(e + 1) >> 3][(e + 1) & 7] = SRC ? l : h;
+            o[(e + 2) >> 3][(e + 2) & 7] = SRC ? h : l;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) *reinterpret_cast<f16x8*>(row + 3 * r0 + 8 * q) = o[q];
+    } else {
+        for (int q = 0; r0 + q < K; ++q) {
+            _Float16 h, l;
+            split2(col[(long long)q * Npad] * sc, h, l);
+            row[3 * (r0 + q)] = h; row[3 * (r0 + q) + 1] = SRC ? l : h; row[3 * (r0 + q) + 2] = SRC ? h : l;
+        }
+    }
+}
+
+// exact re-evaluation: one workgroup per queued row.  Thread (part = t >> 5, c = t & 31) accumulates the contraction
+// rows r = part, part + 8, ... of candidate j = 32 block + c (each wave instruction reads two 256-byte runs of BT);
+// the eight partial sums are added in a fixed order, so duplicated columns score identically and the lowest index wins.
+__global__ __launch_bounds__(256) void ks_exact_kernel(const double* __restrict__ AT, const double* __restrict__ BT,
+                                                       const double* __restrict__ n1, int K, int N2, int N2pad, int N1, int N1pad,
+                                                       int Kpad, const float* __restrict__ pb32, int nsub, int N2pad_s,
+                                                       const int32_t* __restrict__ flag_count, const int32_t* __restrict__ flag_list,
+                                                       const float* __restrict__ flag_thr, int32_t* __restrict__ nn) {
+    extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums + 32 scores
+    double* part_s = xrow + K;
+    const int count = *flag_count;
+    const int t = threadIdx.x, c = t & 31, part = t >> 5;
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int o = flag_list[e];
+        const float thr = flag_thr[e];
+        const int b = o / N2, i = o - b * N2;
+        const double* A = AT + (long long)b * Kpad * N2pad + i;
+        const double* Bm = BT + (long long)b * Kpad * N1pad;
+        __syncthreads();
+        for (int r = t; r < K; r += 256) xrow[r] = A[(long long)r * N2pad];
+        __syncthreads();
+        double bv = DM_INF_F64;
+        int bj = DM_IDX_NONE;
+        for (int sb = 0; sb < nsub; ++sb) {
+            const float tb = pb32[((long long)b * nsub + sb) * N2pad_s + i];
+            if (!(tb >= thr)) continue;                          // uniform: every thread reads the same word
+            const int j = sb * 32 + c;
+            double sacc = 0.0;
+            if (j < N1)
+                for (int r = part; r < K; r += 8) sacc = fma(xrow[r], Bm[(long long)r * N1pad + j], sacc);
+            part_s[part * 32 + c] = sacc;
+            __syncthreads();
+            if (t < 32) {
+                double g = part_s[c];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) g += part_s[q * 32 + c];
+                const double v = n1[(long long)b * N1pad + j] - 2.0 * g;          // |y|^2 - 2 <x, y>
+                if (j < N1 && v < bv) { bv = v; bj = j; }        // blocks ascend: strict keeps the lowest index
+            }
+            __syncthreads();
+        }
+        if (t < 32) {
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const double ov = __shfl_xor(bv, off);
+                const int oj = __shfl_xor(bj, off);
+                argmin_merge(bv, bj, ov, oj);
+            }
+            if (t == 0 && bj != DM_IDX_NONE) nn[o] = bj;
+        }
+    }
+}
+
+static inline int ks_depth(int K) { return pad_to(3 + 3 * K, 32) < 96 ? 96 : pad_to(3 + 3 * K, 32); }
+
+size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int Kloop) {
+    const size_t D = ks_depth(Kloop);
+    return dm_align_up((size_t)B * N2 * D * 2) + dm_align_up((size_t)B * N1 * D * 2) + dm_align_up((size_t)B * 2 * KS_NCH * 8) +
+           dm_align_up((size_t)B * 4) + dm_simnn_ws_bytes(B, N2, N1) + 8192;
+}
+
+int dm_launch_knn_split(dm_ctx* ctx, const dm_gred_args& a) {
+    if (!a.AT || !a.BT || !a.n1 || !a.knn21) return dm_fail(ctx, DM_EINVAL, "knn_split: missing operand");
+    const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop, D = ks_depth(K);
+    _Float16* Ft = (_Float16*)dm_ws_take(ctx, (size_t)a.B * a.N2 * D * 2);
+    _Float16* Fs = (_Float16*)dm_ws_take(ctx, (size_t)a.B * a.N1 * D * 2);
+    double* amax = (double*)dm_ws_take(ctx, (size_t)a.B * 2 * KS_NCH * 8);
+    int32_t* overflow = (int32_t*)dm_ws_take(ctx, (size_t)a.B * 4);
+    if (!Ft || !Fs || !amax || !overflow) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
+    DM_CHECK_HIP(ctx, hipMemsetAsync(overflow, 0, (size_t)a.B * 4, ctx->stream));
+    DM_LAUNCH(ctx, "knn_split_absmax", ks_absmax_kernel, dim3(KS_NCH, 2, a.B), dim3(256), 0, a.AT, a.BT, K, a.N2, a.N2pad, a.N1,
+              a.N1pad, a.Kpad, amax);
+    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(a.N2, 256), dm_cdiv(K, 16) + 1, a.B), dim3(256), 0, a.AT,
+              (const double*)nullptr, amax, K, a.N2, a.N2pad, a.Kpad, D, Ft, (int32_t*)nullptr);
+    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 256), dm_cdiv(K, 16) + 1, a.B), dim3(256), 0, a.BT,
+              a.n1, amax, K, a.N1, a.N1pad, a.Kpad, D, Fs, overflow);
+    dm_simnn_queue q;
+    int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, Ft, Fs, 1.9073486e-6f /* 2^-19 */, overflow, a.knn21, nullptr, nullptr, &q);
+    if (rc) return rc;
+    const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
+    DM_LAUNCH(ctx, "knn_split_exact_f64", ks_exact_kernel, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, K, a.N2, a.N2pad, a.N1,
+              a.N1pad, a.Kpad, q.pb32, q.nsub, q.N2pad, q.flag_count, q.flag_list, q.flag_thr, a.knn21);
+    return DM_OK;
+}
+
+int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a) {
+    const char* e = getenv("DM_KNN_SPLIT");
+    if (e && atoi(e) == 0) return dm_launch_gred(ctx, a);
+    return dm_launch_knn_split(ctx, a);
+}

@@ -576,7 +576,8 @@ extern "C" int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p, const
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     const int nxpad = pad_to(nx, GT), nypad = pad_to(ny, GT), Kpad = pad_to(p, GBK);
     const size_t bA = (size_t)B * Kpad * nypad * 8, bB = (size_t)B * Kpad * nxpad * 8;
-    int rc = dm_ws_reserve(ctx, dm_align_up(bA) + dm_align_up(bB) + dm_align_up((size_t)B * nxpad * 8) + dm_gred_ws_bytes(B, ny, nx));
+    int rc = dm_ws_reserve(ctx, dm_align_up(bA) + dm_align_up(bB) + dm_align_up((size_t)B * nxpad * 8) + dm_gred_ws_bytes(B, ny, nx) +
+                                dm_knn_split_ws_bytes(B, ny, nx, Kpad));
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bA);
     double* BT = (double*)dm_ws_take(ctx, bB);
@@ -587,11 +588,11 @@ extern "C" int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p, const
     if (rc) return rc;
     DM_LAUNCH(ctx, "colnorm", colnorm_kernel, dim3(dm_cdiv(nxpad, 256), B), dim3(256), 0, BT, p, Kpad, nxpad, n1);
     dm_gred_args a;
-    a.B = B; a.N2 = ny; a.N1 = nx; a.Kloop = Kpad;
+    a.B = B; a.N2 = ny; a.N1 = nx; a.Kloop = Kpad; a.Ktrue = p;
     a.AT = AT; a.N2pad = nypad; a.BT = BT; a.N1pad = nxpad; a.Kpad = Kpad;
     a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
     a.knn21 = out; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
-    return dm_launch_gred(ctx, a);
+    return dm_launch_knn21(ctx, a);
 }
 
 // ---- dense mapped indicator (pyFM/spectral/convert.py:144) ------------------------------------------------------

@@ -542,7 +542,8 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restric
                                                           const float* __restrict__ tnorm2, const unsigned int* __restrict__ smax2,
                                                           float tau_scale, int32_t* __restrict__ nn, float* __restrict__ best,
                                                           float* __restrict__ margin, int32_t* __restrict__ flag_count,
-                                                          int32_t* __restrict__ flag_list, float* __restrict__ flag_thr) {
+                                                          int32_t* __restrict__ flag_list, float* __restrict__ flag_thr,
+                                                          const int32_t* __restrict__ force_flag) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N2) return;
@@ -558,10 +559,11 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restric
     if (best) best[o] = bv;
     if (margin) margin[o] = m;
     const float tau = tau_scale * sqrtf(tnorm2[o] * __uint_as_float(smax2[b]));
-    if (!(m > tau)) {
+    const bool forced = force_flag && force_flag[b] != 0;   // the caller could not bound the error for this pair: re-score everything
+    if (forced || !(m > tau)) {
         const int pos = atomicAdd(flag_count, 1);
         flag_list[pos] = (int32_t)o;
-        flag_thr[pos] = bv - tau;          // candidates scoring below this (in fp32) cannot be the float64 argmax
+        flag_thr[pos] = forced ? DM_NEG_INF_F32 : bv - tau;   // candidates scoring below this (in fp32) cannot be the float64 argmax
     }
 }
 
@@ -629,18 +631,19 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
-extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const void* Ftgt, const void* Fsrc, int32_t* nn21,
-                            float* best, float* margin) {
-    if (!ctx) return DM_EINVAL;
-    DM_REQUIRE(ctx, B > 0 && N2 > 0 && N1 > 0 && D > 0, "sizes must be positive");
-    DM_REQUIRE(ctx, Ftgt && Fsrc && nn21, "null pointer");
-    DM_REQUIRE(ctx, D % 8 == 0, "D must be a multiple of 8 (16-byte fp16 rows)");
-    DM_REQUIRE(ctx, D <= 16384, "D too large for the float64 fix-up row buffer");
-    DM_REQUIRE(ctx, (((uintptr_t)Ftgt | (uintptr_t)Fsrc) & 15) == 0, "feature pointers must be 16-byte aligned");
-    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+size_t dm_simnn_ws_bytes(int B, int N2, int N1) {
+    const size_t N2pad = pad_to(N2, ST), tilesS = dm_cdiv(N1, ST);
+    const size_t np = (size_t)B * tilesS * N2pad, np32 = (size_t)B * tilesS * (ST / 32) * N2pad;
+    return 3 * dm_align_up(np * 4) + dm_align_up(np32 * 4) + dm_align_up((size_t)B * N2 * 4) * 3 + dm_align_up((size_t)B * 4) + 8192;
+}
 
+// Tile kernel + merge: fp32 scores, top-2 per target row, the rows whose margin is inside the error bound queued for an
+// exact re-evaluation by the caller.  Workspace comes from the context arena (the caller reserved dm_simnn_ws_bytes).
+// rel_extra: additional relative error of a score (in units of |t_i| max_j |s_j|) on top of the fp32 accumulation bound.
+int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, const _Float16* Fsrc, float rel_extra,
+                  const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q) {
     simnn_params p;
-    p.Ftgt = (const _Float16*)Ftgt; p.Fsrc = (const _Float16*)Fsrc;
+    p.Ftgt = Ftgt; p.Fsrc = Fsrc;
     p.N2 = N2; p.N1 = N1; p.D = D; p.N2pad = pad_to(N2, ST);
     p.tilesT = p.N2pad / ST; p.tilesS = dm_cdiv(N1, ST);
     p.total = B * p.tilesT * p.tilesS;
@@ -648,10 +651,6 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     const size_t np = (size_t)B * p.tilesS * p.N2pad;
     p.nsub = p.tilesS * (ST / 32);
     const size_t np32 = (size_t)B * p.nsub * p.N2pad;
-    const size_t need = 3 * dm_align_up(np * 4) + dm_align_up(np32 * 4) + dm_align_up((size_t)B * N2 * 4) * 3 +
-                        dm_align_up((size_t)B * 4) + 8192;
-    int rc = dm_ws_reserve(ctx, need);
-    if (rc) return rc;
     p.pb = (float*)dm_ws_take(ctx, np * 4);
     p.pj = (int32_t*)dm_ws_take(ctx, np * 4);
     p.ps = (float*)dm_ws_take(ctx, np * 4);
@@ -661,10 +660,13 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     float* flag_thr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     p.smax2 = (unsigned int*)dm_ws_take(ctx, (size_t)B * 4);
     int32_t* flag_count = (int32_t*)dm_ws_take(ctx, 256);
+    if (!p.pb || !p.pj || !p.ps || !p.pb32 || !p.tnorm2 || !flag_list || !flag_thr || !p.smax2 || !flag_count)
+        return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(p.smax2, 0, (size_t)B * 4, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
     const size_t lds_main = (size_t)2 * 2 * ST * SBK * sizeof(_Float16);       // 128 KiB
+    int rc;
     {
         const void* kernels[] = {(const void*)simnn_glds_kernel<0>, (const void*)simnn_glds_kernel<3>, (const void*)simnn_glds_kernel<7>,
                                  (const void*)simnn_kernel<false>, (const void*)simnn_pipe_kernel<0>, (const void*)simnn_pipe_kernel<7>};
@@ -690,17 +692,37 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     }
     else
         DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_kernel<false>, dim3(p.total), dim3(512), lds_main, p);
-    // twice the fp32 accumulation bound: D exact products, D (1 + 1/16) additions, unit roundoff 2^-23
-    // (safe for round-to-nearest and for truncating adders), 1 % slack for the fp32 norms
-    const float tau_scale = 2.0f * 1.01f * (float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f;
+    // twice the error bound of a score, relative to |t_i| max_j |s_j|: fp32 accumulation (D exact products,
+    // D (1 + 1/16) additions, unit roundoff 2^-23, safe for round-to-nearest and for truncating adders) + the caller's
+    // own term; 1 % slack for the fp32 norms
+    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + rel_extra);
     DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb, p.pj, p.ps, p.tilesS, N2,
-              p.N2pad, p.tnorm2, p.smax2, tau_scale, nn21, best, margin, flag_count, flag_list, flag_thr);
+              p.N2pad, p.tnorm2, p.smax2, tau_scale, nn21, best, margin, flag_count, flag_list, flag_thr, force_flag);
+    q->pb32 = p.pb32; q->nsub = p.nsub; q->N2pad = p.N2pad;
+    q->flag_count = flag_count; q->flag_list = flag_list; q->flag_thr = flag_thr;
+    return DM_OK;
+}
+
+extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const void* Ftgt, const void* Fsrc, int32_t* nn21,
+                            float* best, float* margin) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N2 > 0 && N1 > 0 && D > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Ftgt && Fsrc && nn21, "null pointer");
+    DM_REQUIRE(ctx, D % 8 == 0, "D must be a multiple of 8 (16-byte fp16 rows)");
+    DM_REQUIRE(ctx, D <= 16384, "D too large for the float64 fix-up row buffer");
+    DM_REQUIRE(ctx, (((uintptr_t)Ftgt | (uintptr_t)Fsrc) & 15) == 0, "feature pointers must be 16-byte aligned");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = dm_ws_reserve(ctx, dm_simnn_ws_bytes(B, N2, N1));
+    if (rc) return rc;
+    dm_simnn_queue q;
+    rc = dm_simnn_core(ctx, B, N2, N1, D, (const _Float16*)Ftgt, (const _Float16*)Fsrc, 0.0f, nullptr, nn21, best, margin, &q);
+    if (rc) return rc;
     const size_t lds = (size_t)D * 8 + 64;
     if (lds > 65536) {
         rc = dm_grant_lds(ctx, (const void*)simnn_fixup_kernel, lds);
         if (rc) return rc;
     }
     DM_LAUNCH(ctx, "simnn_fixup_f64", simnn_fixup_kernel, dim3(2048), dim3(256), lds, (const _Float16*)Ftgt,
-              (const _Float16*)Fsrc, N2, N1, D, p.pb32, p.nsub, p.N2pad, flag_count, flag_list, flag_thr, nn21);
+              (const _Float16*)Fsrc, N2, N1, D, q.pb32, q.nsub, q.N2pad, q.flag_count, q.flag_list, q.flag_thr, nn21);
     return DM_OK;
 }

@@ -99,7 +99,7 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
     const size_t bytes_C = (size_t)B * kf * kf * 8;
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + 2 * dm_align_up(bytes_C) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2 * 4) +
-                        dm_gred_ws_bytes(B, N2, N1) + dm_p2pfm_ws_bytes(B, N2, kf, kf);
+                        dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_ws_bytes(B, N2, N1, Kpad) + dm_p2pfm_ws_bytes(B, N2, kf, kf);
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bytes_AT);
@@ -129,11 +129,11 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
         rc = dm_launch_embed(ctx, B, N1, k, k, Phi1, ld1, cur, k, (long long)k * k, 0, BT, Kpad, N1pad, n1, 0);
         if (rc) return rc;
         dm_gred_args a;
-        a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = pad_to(k, 16);
+        a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = pad_to(k, 16); a.Ktrue = k;
         a.AT = AT; a.N2pad = N2pad; a.BT = BT; a.N1pad = N1pad; a.Kpad = Kpad;
         a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
         a.knn21 = last ? p21_out : p21; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
-        rc = dm_launch_gred(ctx, a);
+        rc = dm_launch_knn21(ctx, a);
         if (rc) return rc;
         if (last) break;
         const int kn = k + step;

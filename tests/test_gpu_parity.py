@@ -394,3 +394,41 @@ def test_fuzz_project_and_solve(eng):
             Co = orc.fmap_solve(A[b], Bm[b], lam1[b], lam2[b], x0, 1e4, 1e3)
             assert np.abs(C[b] - Co).max() <= 1e-8 * max(1.0, np.abs(Co).max()), (k1, k2, D, np.abs(C[b] - Co).max())
     run()
+
+
+# --------------------------------------------------------------------------- #
+# nearest-neighbour search on the fp16-split first pass (dm_knnsplit.hip) -- the path of ZoomOut, ICP and knn_query
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_knn_query_adversarial(eng, split, monkeypatch):
+    """exact duplicates (lowest index wins), last-bit near ties, wildly different operand scales (bias overflow ->
+    every row takes the exact path), an all-zero operand, an offset cloud (every margin inside the bound)"""
+    monkeypatch.setenv("DM_KNN_SPLIT", split)
+    rng = np.random.default_rng(11)
+    nx, ny, p = 700, 300, 24
+    X = rng.standard_normal((nx, p))
+    X[400:420] = X[10:30]                                       # duplicated tree points
+    X[500] = X[100]; X[500, 3] = np.nextafter(X[500, 3], np.inf)
+    Y = X[rng.integers(0, nx, ny)] + 1e-3 * rng.standard_normal((ny, p))
+    Y[0] = X[100]; Y[1] = X[500]; Y[2] = X[15]
+    cases = {"base": (X, Y), "scaled tree": (X * 3e7, Y * 3e7), "tiny": (X * 1e-12, Y * 1e-12),
+             "mixed scale": (X * 1e6, Y * 1e-3), "offset": (X + 1000.0, Y + 1000.0), "zero query": (X, np.zeros_like(Y)),
+             "zero tree": (np.zeros_like(X), Y)}
+    for name, (Xc, Yc) in cases.items():
+        got = _np(eng.knn_query(Xc[None], Yc[None]))[0]
+        ref = orc.knn_query(Xc, Yc)
+        assert np.array_equal(got, ref), f"{name}: {(got != ref).sum()} mismatches"
+    assert not np.isin(_np(eng.knn_query(X[None], Y[None]))[0], np.arange(400, 420)).any()
+
+
+def test_zoomout_split_equals_f64_kernel(eng, monkeypatch):
+    """the two nearest-neighbour implementations give the same ZoomOut trajectory bit for bit (config-4 shape, reduced)"""
+    from densematcher_amd import synth
+    batch = synth.make_pair_batch(2, 64, 32, 8, 80, sigma=0.1, n_distinct_meshes=2, seed0=5, basis="random")
+    C0 = np.eye(40)[None].repeat(2, axis=0)
+    res = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("DM_KNN_SPLIT", split)
+        C, p = eng.zoomout(batch["Phi1"], batch["Phi2"], batch["a2"], C0, nit=10, step=4, return_p2p=True)
+        res[split] = (_np(C), _np(p))
+    assert np.array_equal(res["1"][1], res["0"][1])
+    assert np.array_equal(res["1"][0], res["0"][0])
