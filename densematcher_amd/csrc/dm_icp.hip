@@ -161,7 +161,8 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     const size_t bT = (size_t)B * k1 * k1 * 8;
     const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + dm_align_up(bG) + dm_align_up(bImg) +
                         2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 3 * dm_align_up((size_t)B * N2 * 4) +
-                        dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_ws_bytes(B, N2, N1, Kpad) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
+                        dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, k2) + dm_knn_split_ws_bytes(B, N2, N1, k2) +
+                        dm_align_up((size_t)B * (N1pad / 256 + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bAT);
@@ -178,7 +179,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* iota = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* ones = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    const size_t ws_mark = ctx->ws_off;
+    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / 256 + 1) * 8);
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemcpyAsync(Ccur, C0, bC, hipMemcpyDeviceToDevice, ctx->stream));
@@ -186,6 +187,10 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     // iteration independent: Phi2^T (K-major f64) and the Gram matrix Phi2^T Phi2 with its blocked image
     rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad);
     if (rc) return rc;
+    dm_knn_split_state knn;                    // fp16 split of Phi2 for the nearest-neighbour searches, once
+    rc = dm_knn_split_prepare(ctx, B, N2, N2pad, Kpad, k2, AT, &knn);
+    if (rc) return rc;
+    const size_t ws_mark = ctx->ws_off;
     rc = dm_launch_p2p_to_fm(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
     if (rc) return rc;
     DM_LAUNCH(ctx, "blockify", blockify_kernel, dim3(nblk, B), dim3(256), 0, G, k2, NB, img);
@@ -198,7 +203,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     for (int it = 0; it < nit; ++it) {
         ctx->ws_off = ws_mark;
         // p21 = NN(tree = Phi1 C^T, query = Phi2)
-        rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, Ccur, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 0);
+        rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, Ccur, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 0, amaxS);
         if (rc) return rc;
         dm_gred_args a;
         a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = Kpad;
@@ -206,7 +211,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
         a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
         a.knn21 = p21; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
         a.Ktrue = k2;
-        rc = dm_launch_knn21(ctx, a);
+        rc = dm_launch_knn21(ctx, a, knn, amaxS);
         if (rc) return rc;
         // R = Phi2^T Phi1[p21]   (k2 x k1);   Chat = (Phi2^T Phi2)^-1 R
         rc = dm_launch_p2p_to_fm(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);

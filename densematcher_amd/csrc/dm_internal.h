@@ -92,7 +92,8 @@ int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld,
 // Cm is (B, kr, km) f64 with row stride ldc; if transC, Cm[b][m][r] is read instead.
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld,
                     const double* Cm, int ldc, long long strideC, int transC,
-                    double* embT, int krpad, int Npad, double* nrm, int zero_first);
+                    double* embT, int krpad, int Npad, double* nrm, int zero_first,
+                    double* amax_part = nullptr);   // amax_part: (B, ceil(Npad/256)) max |embT| per 256 columns (nullable)
 
 // Fused G = A^T B tile kernel with the arg-reductions (see dm_p2p.hip).
 struct dm_gred_args {
@@ -116,15 +117,22 @@ struct dm_simnn_queue {               // rows queued for exact re-evaluation and
     const int32_t* flag_count; const int32_t* flag_list; const float* flag_thr;
 };
 size_t dm_simnn_ws_bytes(int B, int N2, int N1);
-int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, const _Float16* Fsrc, float rel_extra,
+int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, int ldT, const _Float16* Fsrc, int ldS,
+                  float rel_extra,
                   const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q);
 
-// knn21 alone (ZoomOut, ICP): fp16-split first pass on the fp16 matrix cores + exact float64 re-evaluation of the
-// ambiguous rows (dm_knnsplit.hip); same arguments as dm_launch_gred, only AT, BT, n1 and knn21 are used
-int dm_launch_knn_split(dm_ctx* ctx, const dm_gred_args& a);
-size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int Kloop);
-// knn21-only dispatch: the split path unless DM_KNN_SPLIT=0 (then the float64 G kernel)
-int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a);
+// knn21 alone (ZoomOut, ICP, knn_query): fp16-split first pass on the fp16 matrix cores + exact float64 re-evaluation of
+// the ambiguous rows (dm_knnsplit.hip).  The target side (rows of AT) is prepared once for the largest contraction depth
+// kf of a call; every search then passes the current depth in a.Ktrue and the per-256-column maxima of |BT| in amaxS
+// (what colnorm_kernel / dm_launch_embed emit).  Only AT, BT, n1, knn21 of dm_gred_args are used.
+struct dm_knn_split_state {
+    _Float16* Ft = nullptr; int ldT = 0; double* amaxT = nullptr; int kf = 0;
+    bool enabled = false;             // false (DM_KNN_SPLIT=0): dm_launch_knn21 runs the float64 G kernel instead
+};
+size_t dm_knn_split_prep_bytes(int B, int N2, int kf);
+size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int kf);
+int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf, const double* AT, dm_knn_split_state* st);
+int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state& st, const double* amaxS);
 
 // C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,

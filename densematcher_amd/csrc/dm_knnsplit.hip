@@ -3,8 +3,8 @@
 //
 //  1. fp16 matrix cores.  Both operands are scaled by a power of two (max |.| in [1, 2)) and split in two fp16 pieces,
 //     x = xh + xl, y = yh + yl (22 significant bits), and laid out as fp16 "feature" rows
-//         target i : [ xh_0, xh_0, xl_0 | xh_1, xh_1, xl_1 | ... |  1,  1,  1 | 0 pad ]
-//         source j : [ yh_0, yl_0, yh_0 | yh_1, yl_1, yh_1 | ... | b0, b1, b2 | 0 pad ]      b0+b1+b2 = -n1_j sx sy / 2
+//         target i : [  1,  1,  1, 0 x5 | xh_0, xh_0, xl_0 | xh_1, xh_1, xl_1 | ... | 0 pad ]
+//         source j : [ b0, b1, b2, 0 x5 | yh_0, yl_0, yh_0 | yh_1, yl_1, yh_1 | ... | 0 pad ]      b0+b1+b2 = -n1_j sx sy / 2
 //     so that one fp16 inner product (exact products, fp32 accumulation) is
 //         sx sy (<x_i, y_j> - n1_j / 2) - <xl, yl> - split residuals
 //     and the arg-max of it over j is the wanted arg-min up to a bounded error.  The tile kernel, the top-2 bookkeeping
@@ -23,29 +23,29 @@
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
-constexpr int KS_NCH = 32;     // partial maxima per (pair, operand)
+constexpr int KS_NCH = 32;     // partial maxima per pair of the target operand
+constexpr int KS_BIAS = 8;     // halves reserved in front of the split entries (three used): keeps them 16-byte aligned
 
-// amax[(b*2 + which) * KS_NCH + chunk] = max |M[r][c]| over rows r = chunk (mod KS_NCH), r < K  (which: 0 = AT, 1 = BT)
-__global__ __launch_bounds__(256) void ks_absmax_kernel(const double* __restrict__ AT, const double* __restrict__ BT, int K,
-                                                        int N2, int N2pad, int N1, int N1pad, int Kpad, double* __restrict__ amax) {
+// amax[b * KS_NCH + chunk] = max |AT[r][c]| over rows r = chunk (mod KS_NCH), r < K
+__global__ __launch_bounds__(256) void ks_absmax_kernel(const double* __restrict__ AT, int K, int N2, int N2pad, int Kpad,
+                                                        double* __restrict__ amax) {
     __shared__ double sh[4];
-    const int chunk = blockIdx.x, which = blockIdx.y, b = blockIdx.z, t = threadIdx.x;
-    const double* M = which ? BT + (long long)b * Kpad * N1pad : AT + (long long)b * Kpad * N2pad;
-    const int n = which ? N1 : N2, npad = which ? N1pad : N2pad;
+    const int chunk = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const double* M = AT + (long long)b * Kpad * N2pad;
     double m = 0.0;
     for (int r = chunk; r < K; r += KS_NCH)
-        for (int c = t; c < n; c += 256) m = fmax(m, fabs(M[(long long)r * npad + c]));
+        for (int c = t; c < N2; c += 256) m = fmax(m, fabs(M[(long long)r * N2pad + c]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
     if ((t & 63) == 0) sh[t >> 6] = m;
     __syncthreads();
-    if (t == 0) amax[(b * 2 + which) * KS_NCH + chunk] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    if (t == 0) amax[b * KS_NCH + chunk] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
 
-// power of two s with max |v| s in [1, 2)  (1 when the operand is all zero)
-__device__ __forceinline__ double ks_scale(const double* __restrict__ amax, int b, int which) {
+// power of two s with (max of the `count` partial maxima) * s in [1, 2)  (1 when the operand is all zero)
+__device__ __forceinline__ double ks_scale(const double* __restrict__ amax, int count) {
     double m = 0.0;
-    for (int q = 0; q < KS_NCH; ++q) m = fmax(m, amax[(b * 2 + which) * KS_NCH + q]);
+    for (int q = 0; q < count; ++q) m = fmax(m, amax[q]);
     int ex = 0;
     if (!(m > 0.0) || !(m < DM_INF_F64)) return 1.0;
     (void)frexp(m, &ex);                                          // m = f 2^ex, f in [0.5, 1)
@@ -57,36 +57,44 @@ __device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (double)hi);
 }
 
-// Feature rows, layout [ 3 K split entries | 3 bias entries | zero pad ].  A workgroup handles 256 vertices x 16
-// contraction indices: the K-major float64 operand is read coalesced over the vertices, every thread writes 96
-// contiguous, 16-byte aligned bytes of its row.  blockIdx.y == ceil(K / 16): bias entries and padding.
+// Feature rows, layout [ 8 bias slots (3 used) | 3 entries per contraction index | zero pad ], row stride ld.  A
+// workgroup handles 256 vertices x 16 contraction indices: the K-major float64 operand is read coalesced over the
+// vertices, every thread writes 96 contiguous, 16-byte aligned bytes of its row.  blockIdx.y == ceil(K / 16): bias slots
+// and the padding up to `fill`.  SRC: source rows (h, l, h) with the bias -n1 sx sy / 2; else target rows (h, h, l)
+// with ones.  The target is built once for the largest depth: a search at depth K' < K reads only 8 + 3 K' (+ pad)
+// entries of it, and the source rows are zero beyond 8 + 3 K'.
 template <bool SRC>
 __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict__ M, const double* __restrict__ n1,
-                                                       const double* __restrict__ amax, int K, int N, int Npad, int Kpad, int D,
+                                                       const double* __restrict__ amaxT, const double* __restrict__ amaxS, int nS,
+                                                       int K, int N, int Npad, int Kpad, int ld, int fill,
                                                        _Float16* __restrict__ F, int32_t* __restrict__ overflow) {
     const int b = blockIdx.z, r0 = blockIdx.y * 16;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= N) return;
-    _Float16* row = F + ((long long)b * N + v) * D;
-    const double sx = ks_scale(amax, b, 0), sy = ks_scale(amax, b, 1);
+    _Float16* row = F + ((long long)b * N + v) * ld;
+    const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
     if (r0 >= K) {
+        f16x8 head = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
         if (SRC) {
+            const double sy = ks_scale(amaxS + b * nS, nS);
             const double beta = -0.5 * n1[(long long)b * Npad + v] * sx * sy;
-            if (!(fabs(beta) < 60000.0)) { overflow[b] = 1; row[3 * K] = row[3 * K + 1] = row[3 * K + 2] = (_Float16)0.0f; }
+            if (!(fabs(beta) < 60000.0)) overflow[b] = 1;
             else {
                 const _Float16 b0 = (_Float16)beta;
                 const double r1 = beta - (double)b0;
                 const _Float16 b1 = (_Float16)r1;
-                row[3 * K] = b0; row[3 * K + 1] = b1; row[3 * K + 2] = (_Float16)(r1 - (double)b1);
+                head[0] = b0; head[1] = b1; head[2] = (_Float16)(r1 - (double)b1);
             }
         } else {
-            row[3 * K] = row[3 * K + 1] = row[3 * K + 2] = (_Float16)1.0f;
+            head[0] = head[1] = head[2] = (_Float16)1.0f;
         }
-        for (int c = 3 * K + 3; c < D; ++c) row[c] = (_Float16)0.0f;
+        *reinterpret_cast<f16x8*>(row) = head;
+        for (int c = KS_BIAS + 3 * K; c < fill; ++c) row[c] = (_Float16)0.0f;
         return;
     }
-    const double sc = SRC ? sy : sx;
+    const double sc = SRC ? ks_scale(amaxS + b * nS, nS) : sx;
     const double* col = M + ((long long)b * Kpad + r0) * Npad + v;
+    _Float16* dst = row + KS_BIAS + 3 * r0;
     if (r0 + 16 <= K) {
         f16x8 o[6];
 #pragma unroll
@@ -99,12 +107,12 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
             o[(e + 2) >> 3][(e + 2) & 7] = SRC ? h : l;
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) *reinterpret_cast<f16x8*>(row + 3 * r0 + 8 * q) = o[q];
+        for (int q = 0; q < 6; ++q) *reinterpret_cast<f16x8*>(dst + 8 * q) = o[q];
     } else {
         for (int q = 0; r0 + q < K; ++q) {
             _Float16 h, l;
             split2(col[(long long)q * Npad] * sc, h, l);
-            row[3 * (r0 + q)] = h; row[3 * (r0 + q) + 1] = SRC ? l : h; row[3 * (r0 + q) + 2] = SRC ? h : l;
+            dst[3 * q] = h; dst[3 * q + 1] = SRC ? l : h; dst[3 * q + 2] = SRC ? h : l;
         }
     }
 }
@@ -162,40 +170,48 @@ __global__ __launch_bounds__(256) void ks_exact_kernel(const double* __restrict_
     }
 }
 
-static inline int ks_depth(int K) { return pad_to(3 + 3 * K, 32) < 96 ? 96 : pad_to(3 + 3 * K, 32); }
+static inline int ks_depth(int K) { return pad_to(KS_BIAS + 3 * K, 32) < 96 ? 96 : pad_to(KS_BIAS + 3 * K, 32); }
 
-size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int Kloop) {
-    const size_t D = ks_depth(Kloop);
-    return dm_align_up((size_t)B * N2 * D * 2) + dm_align_up((size_t)B * N1 * D * 2) + dm_align_up((size_t)B * 2 * KS_NCH * 8) +
-           dm_align_up((size_t)B * 4) + dm_simnn_ws_bytes(B, N2, N1) + 8192;
+size_t dm_knn_split_prep_bytes(int B, int N2, int kf) {
+    return dm_align_up((size_t)B * N2 * ks_depth(kf) * 2) + dm_align_up((size_t)B * KS_NCH * 8) + 4096;
+}
+size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int kf) {
+    return dm_align_up((size_t)B * N1 * ks_depth(kf) * 2) + dm_align_up((size_t)B * 4) + dm_simnn_ws_bytes(B, N2, N1) + 8192;
 }
 
-int dm_launch_knn_split(dm_ctx* ctx, const dm_gred_args& a) {
-    if (!a.AT || !a.BT || !a.n1 || !a.knn21) return dm_fail(ctx, DM_EINVAL, "knn_split: missing operand");
-    const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop, D = ks_depth(K);
-    _Float16* Ft = (_Float16*)dm_ws_take(ctx, (size_t)a.B * a.N2 * D * 2);
+int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf, const double* AT, dm_knn_split_state* st) {
+    const char* e = getenv("DM_KNN_SPLIT");
+    st->enabled = !(e && atoi(e) == 0);
+    if (!st->enabled) return DM_OK;
+    st->kf = kf; st->ldT = ks_depth(kf);
+    st->Ft = (_Float16*)dm_ws_take(ctx, (size_t)B * N2 * st->ldT * 2);
+    st->amaxT = (double*)dm_ws_take(ctx, (size_t)B * KS_NCH * 8);
+    if (!st->Ft || !st->amaxT) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
+    DM_LAUNCH(ctx, "knn_split_absmax", ks_absmax_kernel, dim3(KS_NCH, B), dim3(256), 0, AT, kf, N2, N2pad, Kpad, st->amaxT);
+    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 256), dm_cdiv(kf, 16) + 1, B), dim3(256), 0, AT,
+              (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, st->Ft,
+              (int32_t*)nullptr);
+    return DM_OK;
+}
+
+int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state& st, const double* amaxS) {
+    if (!st.enabled) return dm_launch_gred(ctx, a);
+    if (!a.AT || !a.BT || !a.n1 || !a.knn21 || !amaxS) return dm_fail(ctx, DM_EINVAL, "knn_split: missing operand");
+    const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop;
+    if (K > st.kf) return dm_fail(ctx, DM_EINVAL, "knn_split: depth %d beyond the prepared %d", K, st.kf);
+    const int D = ks_depth(K);
     _Float16* Fs = (_Float16*)dm_ws_take(ctx, (size_t)a.B * a.N1 * D * 2);
-    double* amax = (double*)dm_ws_take(ctx, (size_t)a.B * 2 * KS_NCH * 8);
     int32_t* overflow = (int32_t*)dm_ws_take(ctx, (size_t)a.B * 4);
-    if (!Ft || !Fs || !amax || !overflow) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
+    if (!Fs || !overflow) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
     DM_CHECK_HIP(ctx, hipMemsetAsync(overflow, 0, (size_t)a.B * 4, ctx->stream));
-    DM_LAUNCH(ctx, "knn_split_absmax", ks_absmax_kernel, dim3(KS_NCH, 2, a.B), dim3(256), 0, a.AT, a.BT, K, a.N2, a.N2pad, a.N1,
-              a.N1pad, a.Kpad, amax);
-    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(a.N2, 256), dm_cdiv(K, 16) + 1, a.B), dim3(256), 0, a.AT,
-              (const double*)nullptr, amax, K, a.N2, a.N2pad, a.Kpad, D, Ft, (int32_t*)nullptr);
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 256), dm_cdiv(K, 16) + 1, a.B), dim3(256), 0, a.BT,
-              a.n1, amax, K, a.N1, a.N1pad, a.Kpad, D, Fs, overflow);
+              a.n1, st.amaxT, amaxS, dm_cdiv(a.N1pad, 256), K, a.N1, a.N1pad, a.Kpad, D, D, Fs, overflow);
     dm_simnn_queue q;
-    int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, Ft, Fs, 1.9073486e-6f /* 2^-19 */, overflow, a.knn21, nullptr, nullptr, &q);
+    int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, st.Ft, st.ldT, Fs, D, 1.9073486e-6f /* 2^-19 */, overflow, a.knn21, nullptr,
+                           nullptr, &q);
     if (rc) return rc;
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
     DM_LAUNCH(ctx, "knn_split_exact_f64", ks_exact_kernel, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, K, a.N2, a.N2pad, a.N1,
               a.N1pad, a.Kpad, q.pb32, q.nsub, q.N2pad, q.flag_count, q.flag_list, q.flag_thr, a.knn21);
     return DM_OK;
-}
-
-int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a) {
-    const char* e = getenv("DM_KNN_SPLIT");
-    if (e && atoi(e) == 0) return dm_launch_gred(ctx, a);
-    return dm_launch_knn_split(ctx, a);
 }

@@ -64,31 +64,43 @@ struct OutKMajor {
     }
 };
 
-// nrm[b][j] = sum_r embT[b][r][j]^2 over r < kr (fixed ascending order: deterministic)
+// nrm[b][j] = sum_r embT[b][r][j]^2 over r < kr (fixed ascending order: deterministic);
+// amax_part[b * gridDim.x + blockIdx.x] = max |embT| over the workgroup's 256 columns (nullable; dm_knnsplit.hip scales by it)
 __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__ embT, int kr, int krpad, int Npad,
-                                                      double* __restrict__ nrm) {
+                                                      double* __restrict__ nrm, double* __restrict__ amax_part) {
+    __shared__ double wmax[4];
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Npad) return;
     const double* E = embT + (long long)b * krpad * Npad;
-    double s = 0.0;
-    int r = 0;
-    for (; r + 16 <= kr; r += 16) {              // 16 loads in flight, summed in ascending order
-        double x[16];
+    double s = 0.0, m = 0.0;
+    if (j < Npad) {
+        int r = 0;
+        for (; r + 16 <= kr; r += 16) {              // 16 loads in flight, summed in ascending order
+            double x[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) x[u] = E[(long long)(r + u) * Npad + j];
+            for (int u = 0; u < 16; ++u) x[u] = E[(long long)(r + u) * Npad + j];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += x[u] * x[u];
+            for (int u = 0; u < 16; ++u) { s += x[u] * x[u]; m = fmax(m, fabs(x[u])); }
+        }
+        for (; r < kr; ++r) {
+            const double x = E[(long long)r * Npad + j];
+            s += x * x;
+            m = fmax(m, fabs(x));
+        }
+        nrm[(long long)b * Npad + j] = s;
     }
-    for (; r < kr; ++r) {
-        const double x = E[(long long)r * Npad + j];
-        s += x * x;
+    if (amax_part) {                                 // uniform
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) amax_part[b * gridDim.x + blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
     }
-    nrm[(long long)b * Npad + j] = s;
 }
 
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld, const double* Cm, int ldc,
-                    long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first) {
+                    long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first,
+                    double* amax_part) {
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
     if (zero_first && (kr != krpad || N != Npad))
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
@@ -100,7 +112,7 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
               N, km);
     if (nrm) {
         dim3 g2(dm_cdiv(Npad, 256), B);
-        DM_LAUNCH(ctx, "colnorm", colnorm_kernel, g2, dim3(256), 0, embT, kr, krpad, Npad, nrm);
+        DM_LAUNCH(ctx, "colnorm", colnorm_kernel, g2, dim3(256), 0, embT, kr, krpad, Npad, nrm, amax_part);
     }
     return DM_OK;
 }
@@ -577,22 +589,27 @@ extern "C" int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p, const
     const int nxpad = pad_to(nx, GT), nypad = pad_to(ny, GT), Kpad = pad_to(p, GBK);
     const size_t bA = (size_t)B * Kpad * nypad * 8, bB = (size_t)B * Kpad * nxpad * 8;
     int rc = dm_ws_reserve(ctx, dm_align_up(bA) + dm_align_up(bB) + dm_align_up((size_t)B * nxpad * 8) + dm_gred_ws_bytes(B, ny, nx) +
-                                dm_knn_split_ws_bytes(B, ny, nx, Kpad));
+                                dm_knn_split_prep_bytes(B, ny, p) + dm_knn_split_ws_bytes(B, ny, nx, p) +
+                                dm_align_up((size_t)B * (nxpad / 256 + 1) * 8));
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bA);
     double* BT = (double*)dm_ws_take(ctx, bB);
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * nxpad * 8);
+    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (nxpad / 256 + 1) * 8);
     rc = launch_transpose_f64(ctx, B, ny, p, Y, p, AT, Kpad, nypad);
     if (rc) return rc;
     rc = launch_transpose_f64(ctx, B, nx, p, X, p, BT, Kpad, nxpad);
     if (rc) return rc;
-    DM_LAUNCH(ctx, "colnorm", colnorm_kernel, dim3(dm_cdiv(nxpad, 256), B), dim3(256), 0, BT, p, Kpad, nxpad, n1);
+    DM_LAUNCH(ctx, "colnorm", colnorm_kernel, dim3(dm_cdiv(nxpad, 256), B), dim3(256), 0, BT, p, Kpad, nxpad, n1, amaxS);
+    dm_knn_split_state knn;
+    rc = dm_knn_split_prepare(ctx, B, ny, nypad, Kpad, p, AT, &knn);
+    if (rc) return rc;
     dm_gred_args a;
     a.B = B; a.N2 = ny; a.N1 = nx; a.Kloop = Kpad; a.Ktrue = p;
     a.AT = AT; a.N2pad = nypad; a.BT = BT; a.N1pad = nxpad; a.Kpad = Kpad;
     a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
     a.knn21 = out; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
-    return dm_launch_knn21(ctx, a);
+    return dm_launch_knn21(ctx, a, knn, amaxS);
 }
 
 // ---- dense mapped indicator (pyFM/spectral/convert.py:144) ------------------------------------------------------

@@ -41,6 +41,7 @@ struct simnn_params {
     float* tnorm2;                           // (B, N2)  |t_i|^2, written by the workgroups of source tile 0
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
+    int ldT, ldS;                            // row strides (halves) of Ftgt / Fsrc, >= D, multiples of 8
     int dbg;      // experiments only (env DM_SIMNN_DEBUG): 1 = skip the epilogue, 2 = one K stage only, 3 = no norms
 };
 
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wsrc = wave & 1, wtgt = wave >> 1;
 
-    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.D;
-    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.D;
+    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.ldT;
+    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.ldS;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -176,25 +177,25 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
     float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int lrow = t >> 3, lchunk = t & 7;                                   // staging: rows q*64 + lrow, 16-byte chunk lchunk
-    const _Float16* tptr = T + (long long)(i0 + lrow) * p.D + lchunk * 8;
-    const _Float16* sptr = S + (long long)(j0 + lrow) * p.D + lchunk * 8;
+    const _Float16* tptr = T + (long long)(i0 + lrow) * p.ldT + lchunk * 8;
+    const _Float16* sptr = S + (long long)(j0 + lrow) * p.ldS + lchunk * 8;
     u32x4 rt[4], rs[4];
     // (macros, not lambdas: by-reference lambda captures of the staging arrays end up in scratch)
 #define SIMNN_FETCH(s_)                                                                                          \
     {                                                                                                            \
         if (FULL) {                                                                                              \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-                rt[q] = *reinterpret_cast<const u32x4*>(tptr + (long long)q * 64 * p.D + (s_) * SBK);           \
-                rs[q] = *reinterpret_cast<const u32x4*>(sptr + (long long)q * 64 * p.D + (s_) * SBK);           \
+                rt[q] = *reinterpret_cast<const u32x4*>(tptr + (long long)q * 64 * p.ldT + (s_) * SBK);         \
+                rs[q] = *reinterpret_cast<const u32x4*>(sptr + (long long)q * 64 * p.ldS + (s_) * SBK);         \
             }                                                                                                    \
         } else {                                                                                                 \
             const int k_ = (s_) * SBK + lchunk * 8;                                                              \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
                 const int row = q * 64 + lrow;                                                                   \
                 const int gi = i0 + row, gj = j0 + row;                                                          \
-                rt[q] = (gi < p.N2 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(T + (long long)gi * p.D + k_)  \
+                rt[q] = (gi < p.N2 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(T + (long long)gi * p.ldT + k_) \
                                                 : u32x4{0, 0, 0, 0};                                             \
-                rs[q] = (gj < p.N1 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(S + (long long)gj * p.D + k_)  \
+                rs[q] = (gj < p.N1 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(S + (long long)gj * p.ldS + k_) \
                                                 : u32x4{0, 0, 0, 0};                                             \
             }                                                                                                    \
         }                                                                                                        \
@@ -283,8 +284,8 @@ __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wsrc = wave & 1, wtgt = wave >> 1;
 
-    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.D;
-    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.D;
+    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.ldT;
+    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.ldS;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
     for (int q = 0; q < 4; ++q) {
         const int row = (wave * 4 + q) * 8 + grow;
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        tsrc[q] = T + (long long)(i0 + row) * p.D + chunk * 8;
-        ssrc[q] = S + (long long)(j0 + row) * p.D + chunk * 8;
+        tsrc[q] = T + (long long)(i0 + row) * p.ldT + chunk * 8;
+        ssrc[q] = S + (long long)(j0 + row) * p.ldS + chunk * 8;
     }
 #define SIMNN_DMA(s_, buf_)                                                                                      \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(512, 2) void simnn_pipe_kernel(simnn_params p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wsrc = wave & 1, wtgt = wave >> 1;
 
-    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.D;
-    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.D;
+    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.ldT;
+    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.ldS;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -424,8 +425,8 @@ __global__ __launch_bounds__(512, 2) void simnn_pipe_kernel(simnn_params p) {
     for (int q = 0; q < 2; ++q) {
         const int row = wave * 32 + q * 16 + (lane >> 2);
         const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        tsrc[q] = T + (long long)(i0 + row) * p.D + chunk * 8;
-        ssrc[q] = S + (long long)(j0 + row) * p.D + chunk * 8;
+        tsrc[q] = T + (long long)(i0 + row) * p.ldT + chunk * 8;
+        ssrc[q] = S + (long long)(j0 + row) * p.ldS + chunk * 8;
     }
 #define SIMNN_DMA1(s_, q)                                                                                        \
     {                                                                                                            \
@@ -640,11 +641,13 @@ size_t dm_simnn_ws_bytes(int B, int N2, int N1) {
 // Tile kernel + merge: fp32 scores, top-2 per target row, the rows whose margin is inside the error bound queued for an
 // exact re-evaluation by the caller.  Workspace comes from the context arena (the caller reserved dm_simnn_ws_bytes).
 // rel_extra: additional relative error of a score (in units of |t_i| max_j |s_j|) on top of the fp32 accumulation bound.
-int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, const _Float16* Fsrc, float rel_extra,
+int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, int ldT, const _Float16* Fsrc, int ldS,
+                  float rel_extra,
                   const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q) {
     simnn_params p;
     p.Ftgt = Ftgt; p.Fsrc = Fsrc;
     p.N2 = N2; p.N1 = N1; p.D = D; p.N2pad = pad_to(N2, ST);
+    p.ldT = ldT; p.ldS = ldS;
     p.tilesT = p.N2pad / ST; p.tilesS = dm_cdiv(N1, ST);
     p.total = B * p.tilesT * p.tilesS;
     { const char* e = getenv("DM_SIMNN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
@@ -715,7 +718,7 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     int rc = dm_ws_reserve(ctx, dm_simnn_ws_bytes(B, N2, N1));
     if (rc) return rc;
     dm_simnn_queue q;
-    rc = dm_simnn_core(ctx, B, N2, N1, D, (const _Float16*)Ftgt, (const _Float16*)Fsrc, 0.0f, nullptr, nn21, best, margin, &q);
+    rc = dm_simnn_core(ctx, B, N2, N1, D, (const _Float16*)Ftgt, D, (const _Float16*)Fsrc, D, 0.0f, nullptr, nn21, best, margin, &q);
     if (rc) return rc;
     const size_t lds = (size_t)D * 8 + 64;
     if (lds > 65536) {

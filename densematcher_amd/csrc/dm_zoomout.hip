@@ -99,7 +99,8 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
     const size_t bytes_C = (size_t)B * kf * kf * 8;
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + 2 * dm_align_up(bytes_C) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2 * 4) +
-                        dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_ws_bytes(B, N2, N1, Kpad) + dm_p2pfm_ws_bytes(B, N2, kf, kf);
+                        dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, kf) + dm_knn_split_ws_bytes(B, N2, N1, kf) +
+                        dm_align_up((size_t)B * (N1pad / 256 + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, kf, kf);
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bytes_AT);
@@ -108,12 +109,17 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
     double* Cb = (double*)dm_ws_take(ctx, bytes_C);
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
     int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    const size_t ws_mark = ctx->ws_off;
+    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / 256 + 1) * 8);   // max |emb1| per 256 columns (colnorm)
 
     // Phi2^T for all kf columns, once.  Row c of AT only enters G when c < current k because the
     // matching row of BT (emb1^T) is zero beyond the current map size.
     rc = dm_launch_phiT(ctx, B, N2, kf, Phi2, ld2, AT, Kpad, N2pad);
     if (rc) return rc;
+    // target side of the nearest-neighbour search (fp16 split of Phi2, all kf columns), once for the whole call
+    dm_knn_split_state knn;
+    rc = dm_knn_split_prepare(ctx, B, N2, N2pad, Kpad, kf, AT, &knn);
+    if (rc) return rc;
+    const size_t ws_mark = ctx->ws_off;
     DM_CHECK_HIP(ctx, hipMemcpyAsync(Ca, C0, (size_t)B * k0 * k0 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     // emb1^T buffer: rows >= current k and columns >= N1 must read as zero; rows only ever grow, so one clear suffices
     DM_CHECK_HIP(ctx, hipMemsetAsync(BT, 0, bytes_BT, ctx->stream));
@@ -126,14 +132,14 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
         if (last && !p21_out) break;
         ctx->ws_off = ws_mark;
         // emb1 = Phi1[:, :k] C^T  ->  BT (rows >= k zero), n1
-        rc = dm_launch_embed(ctx, B, N1, k, k, Phi1, ld1, cur, k, (long long)k * k, 0, BT, Kpad, N1pad, n1, 0);
+        rc = dm_launch_embed(ctx, B, N1, k, k, Phi1, ld1, cur, k, (long long)k * k, 0, BT, Kpad, N1pad, n1, 0, amaxS);
         if (rc) return rc;
         dm_gred_args a;
         a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = pad_to(k, 16); a.Ktrue = k;
         a.AT = AT; a.N2pad = N2pad; a.BT = BT; a.N1pad = N1pad; a.Kpad = Kpad;
         a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
         a.knn21 = last ? p21_out : p21; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
-        rc = dm_launch_knn21(ctx, a);
+        rc = dm_launch_knn21(ctx, a, knn, amaxS);
         if (rc) return rc;
         if (last) break;
         const int kn = k + step;
