@@ -69,8 +69,9 @@ __device__ __forceinline__ void diag_step(double (&s)[4], double (&w)[4], int la
 
 
 // diagonal block J: in-register elimination by wave 0 (see diag_step); leaves Ws[m][k] = W[k][m], W = L_JJ^-1.
-// (Tried and slower on MI355X: a row-per-lane form with the pivot row through v_readlane, 8.4 k instead of 5.9 k cycles
-// per block; the column broadcast by v_permlane32_swap / v_permlane16_swap instead of ds_bpermute, 7.4 k.)
+// (Tried on MI355X, none faster than the 5.9 k cycles per block of this form: a row-per-lane form with the pivot row
+// through DPP row_newbcast 6.7 k -- no LDS on the chain, but 700 instead of 400 f64 VALU instructions --, through
+// v_readlane 8.4 k; the column broadcast by v_permlane32_swap / v_permlane16_swap instead of ds_bpermute 7.4 k.)
 __device__ __forceinline__ void diag_block(const double* S, double* Ws, double* red, int lane) {
     const int r = lane & 15, g = lane >> 4;
     double ds[4], dw[4];
