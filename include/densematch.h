@@ -128,7 +128,10 @@ int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
 
 /* ---- exact nearest neighbour, k = 1 -----------------------------------------
  * out[b,i] = argmin_j |X[b,j,:] - Y[b,i,:]|^2 (lowest j on ties); X (B,nx,p), Y (B,ny,p) fp64.
- * Replaces pyFM/spectral/nn_utils.py:4-38 (knn_query: sklearn kd-tree, k = 1). */
+ * Replaces pyFM/spectral/nn_utils.py:4-38 (knn_query: sklearn kd-tree, k = 1).
+ * Exact: a first pass on the fp16 matrix cores with a rigorous error bound, every row inside the bound
+ * re-evaluated in float64 from the original operands (also the search inside dm_zoomout / dm_icp;
+ * environment DM_KNN_SPLIT=0 selects the float64 matrix-core kernel for all of it instead). */
 int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p,
                      const double* X, const double* Y, int32_t* out /* B*ny */);
 
@@ -161,7 +164,7 @@ int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step,
  * C = U eye(k2,k1) V^T with U S V^T = svd(Chat), i.e. the orthogonal polar factor of Chat.
  * Replaces pyFM/refine/icp.py:10-40,43-107 (fixed nit; functional.py:564 uses nit = 10).
  * C0, Cout (B,k2,k1) fp64; resid (B) fp64 optional = max |Cout^T Cout - I| (convergence of the
- * Newton-Schulz polar iteration); info (B): 0 ok, c+1 = normal equations not SPD.  k1 <= k2 <= 176. */
+ * polar iteration); info (B): 0 ok, c+1 = normal equations not SPD.  k1 <= k2 <= 176. */
 int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
            const float* Phi1, int ld1, const float* Phi2, int ld2,
            const double* C0, int nit, double* Cout, double* resid /*nullable*/, int32_t* info);
