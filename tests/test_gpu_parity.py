@@ -432,3 +432,22 @@ def test_zoomout_split_equals_f64_kernel(eng, monkeypatch):
         res[split] = (_np(C), _np(p))
     assert np.array_equal(res["1"][1], res["0"][1])
     assert np.array_equal(res["1"][0], res["0"][0])
+
+
+def test_fuzz_knn_query(eng):
+    from hypothesis import given, strategies as st
+
+    @_fuzz_settings()
+    @given(st.integers(1, 3), st.integers(1, 700), st.integers(1, 700), st.integers(1, 70), st.sampled_from([1.0, 1e-6, 1e5]),
+           st.booleans(), st.integers(0, 2 ** 31 - 1))
+    def run(B, nx, ny, p, scale, clustered, seed):
+        rng = np.random.default_rng(seed)
+        X = rng.standard_normal((B, nx, p)) * scale
+        Y = rng.standard_normal((B, ny, p)) * scale
+        if clustered and nx > 3:                             # queries on top of tree points, some tree points duplicated
+            Y[:, : min(ny, nx)] = X[:, : min(ny, nx)]
+            X[:, nx // 2] = X[:, 0]
+        got = _np(eng.knn_query(X, Y))
+        for b in range(B):
+            assert np.array_equal(got[b], orc.knn_query(X[b], Y[b])), (B, nx, ny, p, scale, clustered)
+    run()
