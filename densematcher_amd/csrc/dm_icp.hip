@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void blockify_kernel(const double* __restrict_
     img[((long long)b * (NB * (NB + 1) / 2) + q) * 256 + kk * 16 + ii] = v;
 }
 
-// X[b][:, c] = G[b]^-1 R[b][:, c]: one workgroup per (column c, pair b)
+// X[b][:, c] = G[b]^-1 R[b][:, c] (R = identity when null): one workgroup per (column c, pair b)
 __global__ __launch_bounds__(256) void spd_multi_rhs_kernel(const double* __restrict__ img, const double* __restrict__ R, int n,
                                                             int nrhs, int NB, double* __restrict__ X, int32_t* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void spd_multi_rhs_kernel(const double* __rest
                 if (q < nvec) dst[q] = v[u];
             }
         }
-        for (int r = t; r < NB * 16; r += 256) rhs[r] = (r < n) ? R[((long long)b * n + r) * nrhs + c] : 0.0;
+        // R == nullptr: right-hand side = unit vector c, i.e. column c of the inverse
+        for (int r = t; r < NB * 16; r += 256) rhs[r] = (r < n) ? (R ? R[((long long)b * n + r) * nrhs + c] : (r == c ? 1.0 : 0.0)) : 0.0;
         int* tri_rc = reinterpret_cast<int*>(LT);
         for (int u = t; u < 128; u += 256) {
             int a_ = 0;
@@ -122,6 +123,10 @@ struct OutPlainTN {
     double* p; long long stride_b; int ld;
     __device__ __forceinline__ void store(int b, int, int m, int c, double v) const { p[b * stride_b + (long long)m * ld + c] = v; }
 };
+struct OutPlainNT {
+    double* p; long long stride_b; int ld;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] = v; }
+};
 struct OutAxpby {                      // Xnew = alpha Xold + beta (product)
     const double* xo; double* xn; long long stride_b; int ld; double alpha, beta;
     __device__ __forceinline__ void store(int b, int i, int j, double v) const {
@@ -159,7 +164,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     const size_t bAT = (size_t)B * Kpad * N2pad * 8, bBT = (size_t)B * Kpad * N1pad * 8;
     const size_t bC = (size_t)B * k2 * k1 * 8, bG = (size_t)B * k2 * k2 * 8, bImg = (size_t)B * nblk * 256 * 8;
     const size_t bT = (size_t)B * k1 * k1 * 8;
-    const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + dm_align_up(bG) + dm_align_up(bImg) +
+    const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + 2 * dm_align_up(bG) + dm_align_up(bImg) +
                         2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 3 * dm_align_up((size_t)B * N2 * 4) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, k2) + dm_knn_split_ws_bytes(B, N2, N1, k2) +
                         dm_align_up((size_t)B * (N1pad / 256 + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
@@ -172,6 +177,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     double* Xa = (double*)dm_ws_take(ctx, bC);
     double* Xb = (double*)dm_ws_take(ctx, bC);
     double* G = (double*)dm_ws_take(ctx, bG);
+    double* Ginv = (double*)dm_ws_take(ctx, bG);
     double* img = (double*)dm_ws_take(ctx, bImg);
     double* Tm = (double*)dm_ws_take(ctx, bT);
     double* Wm = (double*)dm_ws_take(ctx, bT);
@@ -199,6 +205,10 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     const size_t lds = ((size_t)(nblk + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);
     rc = dm_grant_lds(ctx, (const void*)spd_multi_rhs_kernel, lds);
     if (rc) return rc;
+    // the Gram matrix does not change over the iterations: invert it once (k2 unit right-hand sides on the blocked LDS
+    // Cholesky; Phi2^T Phi2 is well conditioned, the basis is mass-orthonormal) and apply the inverse by a GEMM per iteration
+    DM_LAUNCH(ctx, "icp_normal_eq_chol", spd_multi_rhs_kernel, dim3(k2, B), dim3(256), lds, img, (const double*)nullptr, k2, k2, NB,
+              Ginv, info);
 
     for (int it = 0; it < nit; ++it) {
         ctx->ws_off = ws_mark;
@@ -216,7 +226,13 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
         // R = Phi2^T Phi1[p21]   (k2 x k1);   Chat = (Phi2^T Phi2)^-1 R
         rc = dm_launch_p2p_to_fm(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);
         if (rc) return rc;
-        DM_LAUNCH(ctx, "icp_normal_eq_chol", spd_multi_rhs_kernel, dim3(k1, B), dim3(256), lds, img, R, k2, k1, NB, Xa, info);
+        {   // Chat = (Phi2^T Phi2)^-1 R with the inverse computed once before the loop
+            KRowsF64 ga{Ginv, (long long)k2 * k2, k2, k2, k2, 0};
+            KRowsF64 rb{R, (long long)k2 * k1, k1, k1, k2, 1};
+            OutPlainNT oc{Xa, (long long)k2 * k1, k1};
+            DM_LAUNCH(ctx, "icp_apply_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutPlainNT>),
+                      dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ga, rb, oc, k2, k1, k2);
+        }
         // polar factor of Chat by Newton-Schulz
         DM_LAUNCH(ctx, "polar_scale", polar_scale_kernel, dim3(B), dim3(256), 0, Xa, k2, k1);
         double* xo = Xa;
