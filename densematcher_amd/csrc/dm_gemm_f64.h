@@ -249,6 +249,12 @@ struct KRowsF64 {
     const double* p; long long stride_b; int ld; int nrows; int ncols; int trans;
     __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
         const double* base = p + b * stride_b;
+        if (!trans && row < nrows && k0 + 7 < ncols && ((ld & 1) == 0) && ((stride_b & 1) == 0) && ((((uintptr_t)p) & 15) == 0)) {
+            const f64x2* q = reinterpret_cast<const f64x2*>(base + (long long)row * ld + k0);   // four 16-byte loads
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const f64x2 x = q[e]; v[2 * e] = x[0]; v[2 * e + 1] = x[1]; }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int k = k0 + e;
