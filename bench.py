@@ -39,6 +39,7 @@ WORKLOADS = {
     "simnn": dict(nu=64, nv=32, D=768, k=0, B=64, cfg="configs[2]: batch=64 pairs, N=2048, D=768 brute-force NN feature similarity + argmax"),
     "zoomout": dict(nu=64, nv=32, D=0, k=200, B=32, cfg="configs[3]: 32 pairs/GPU, N=2048, k=50->200 ZoomOut refinement"),
     "stress": dict(nu=128, nv=64, D=384, k=200, B=64, cfg="configs[4]: batch=64 pairs, N=8192, D=384, k=200 (HBM-bound stress)"),
+    "icp": dict(nu=64, nv=32, D=0, k=128, B=64, cfg="SURVEY 8(f) next #1: spectral ICP, 10 iterations, 64 pairs/GPU, N=2048, k=128"),
 }
 
 
@@ -103,6 +104,18 @@ def main():
         kernel, dtype = "simnn_f16_mfma", "f16"
         flops_per_launch = 2.0 * N * N * D * B                      # 2 N2 N1 D per pair
         unit_name = "mesh-pairs/s"
+    elif args.workload == "icp":
+        gen = torch.Generator(device=eng.device).manual_seed(1 + rank)
+        C0 = torch.eye(k, dtype=torch.float64, device=eng.device).repeat(B, 1, 1) \
+            + 0.01 * torch.randn(B, k, k, dtype=torch.float64, device=eng.device, generator=gen)
+
+        def step():
+            return eng.icp(dev["Phi1"], dev["Phi2"], C0, nit=10)
+        split = os.environ.get("DM_KNN_SPLIT", "1") != "0"
+        kernel, dtype = ("simnn_f16_mfma", "f16") if split else ("gred_f64", "f64")
+        kd = max(96, -(-(3 * k + 8) // 32) * 32)                   # fp16 depth of the split features (dm_knnsplit.hip)
+        flops_per_launch = 2.0 * N * N * (kd if split else ((k + 15) // 16) * 16) * B
+        unit_name = "mesh-pairs/s"
     else:
         k0, nit = 50, 150
         C0 = torch.eye(k0, dtype=torch.float64, device=eng.device).repeat(B, 1, 1)
@@ -147,7 +160,7 @@ def main():
         if kernel == "simnn_f16_mfma":
             # what the fp16 matrix cores execute: three fp16 products per contraction index (hi*hi, hi*lo, lo*hi) plus
             # three bias entries, padded to the 32-wide stage
-            flops_per_launch = sum(2.0 * N * N * max(96, -(-(3 * kk + 3) // 32) * 32) * B for kk in ks) / 150.0
+            flops_per_launch = sum(2.0 * N * N * max(96, -(-(3 * kk + 8) // 32) * 32) * B for kk in ks) / 150.0
             extra = {"algorithmic_f64_flops_per_launch": alg,
                      "note": "achieved/peak count the fp16 flops the split executes (3x the algorithmic 2N^2k + padding)"}
         else:
@@ -219,6 +232,10 @@ def cpu_baseline(workload, host, k):
             if time.perf_counter() - t0 > budget:
                 break
         what = "float64 GEMM + argmax (oracle.simnn)"
+    elif workload == "icp":
+        orc.icp_refine(np.eye(k), host["Phi1"][0][:, :k], host["Phi2"][0][:, :k], nit=10)
+        done = 1
+        what = "spectral ICP, 10 iterations (oracle.icp_refine: brute-force NN, lstsq, SVD)"
     else:
         C0 = np.eye(50)
         orc.zoomout_refine(C0, host["Phi1"][0], host["Phi2"][0], nit=150, step=1, a2=host["a2"][0])
