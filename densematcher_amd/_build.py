@@ -35,7 +35,19 @@ def _newest_dep():
     return max(os.path.getmtime(d) for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+LIB_EXP = os.path.join(HERE, "libdensematch_exp.so")
+
+
+def build_experiments(force=False, verbose=False):
+    """The same sources with -DDM_EXPERIMENTS: ablation knobs read from the environment (DM_SIMNN_DEBUG, DM_GRED_DEBUG,
+    DM_SOLVE_DEBUG ...), some of which give WRONG results.  Used by tools/*_experiment.py only; a separate file that
+    nothing in the package loads."""
+    return build(force=force, verbose=verbose, extra_flags=("-DDM_EXPERIMENTS",), lib=LIB_EXP, objdir=os.path.join(BUILD, "exp"))
+
+
+def build(force=False, verbose=False, extra_flags=(), lib=None, objdir=None):
+    LIB = lib or globals()["LIB"]
+    BUILD = objdir or globals()["BUILD"]
     os.makedirs(BUILD, exist_ok=True)
     newest = _newest_dep()
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
@@ -67,3 +79,5 @@ def build(force=False, verbose=False, extra_flags=()):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--experiments" in sys.argv:
+        print(build_experiments(force="--force" in sys.argv, verbose=True))

@@ -25,6 +25,7 @@ SIGNATURES = {
     "dm_last_error": (C.c_char_p, [_p]),
     "dm_version": (C.c_char_p, []),
     "dm_workspace_bytes": (C.c_size_t, [_p]),
+    "dm_set_option": (_i, [_p, C.c_char_p, _i]),
     "dm_profile_kernel": (_i, [_p, C.c_char_p]),
     "dm_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(_d)]),
     "dm_simnn_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
@@ -32,6 +33,7 @@ SIGNATURES = {
     "dm_fmap_c00": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_fmap_solve": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _d, _d, _p, _p]),
     "dm_fm_to_p2p": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "dm_fm_to_p2p_uses_split": (_i, [_p, _i, _i, _i]),
     "dm_knn_query_f64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "dm_mapped_indicator": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_p2p_to_fm": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
@@ -39,27 +41,28 @@ SIGNATURES = {
     "dm_zoomout": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libdensematch.so (built in-tree by `python -m densematcher_amd._build`)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load libdensematch.so (built in-tree by `python -m densematcher_amd._build`).  `path`: another build of the same
+    ABI (tools/ load the -DDM_EXPERIMENTS build this way); nothing in the package passes it."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: the HIP library has not been built. "
+            f"{path} not found: the HIP library has not been built. "
             "Run `python -m densematcher_amd._build` (needs hipcc). There is no CPU fallback.")
     # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; import it first so that the
     # library binds to the runtime that owns the tensors' device memory and streams.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 

@@ -41,6 +41,7 @@ extern "C" int dm_create(int device, void* hip_stream, dm_ctx** out) {
         return create_fail(buf, hipSuccess);
     }
     dm_ctx* ctx = new dm_ctx();
+    ctx->n_cu = prop.multiProcessorCount;
     ctx->device = device;
     ctx->stream = (hipStream_t)hip_stream;
     *out = ctx;
@@ -54,6 +55,26 @@ extern "C" int dm_destroy(dm_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
     delete ctx;
+    return DM_OK;
+}
+
+#ifdef DM_EXPERIMENTS
+#include <stdlib.h>
+int dm_knob(const char* env_name, int dflt) {
+    const char* e = getenv(env_name);
+    return e ? atoi(e) : dflt;
+}
+#endif
+
+extern "C" int dm_set_option(dm_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return DM_EINVAL;
+    const std::string n = name;
+    if (n == "simnn_pipe") ctx->opt_simnn_pipe = value;
+    else if (n == "knn_split") ctx->opt_knn_split = value;
+    else if (n == "solve_packed") ctx->opt_solve_packed = value;
+    else if (n == "p2p_split") ctx->opt_p2p_split = value;
+    else if (n == "simnn_persist") ctx->opt_simnn_persist = value;
+    else return dm_fail(ctx, DM_EINVAL, "dm_set_option: unknown option '%s'", name);
     return DM_OK;
 }
 

@@ -577,8 +577,7 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     const size_t pq_bytes = (size_t)B * (k1 + k2) * k1 * 8;
     const int n = k1 - 1;
     const int NB = (n + 15) / 16;
-    const char* pk = getenv("DM_SOLVE_PACKED");                 // 1: force the packed-storage solver (tests)
-    const bool blocked = (n >= 1 && NB <= 11) && !(pk && atoi(pk));
+    const bool blocked = (n >= 1 && NB <= 11) && !ctx->opt_solve_packed;   // dm_set_option("solve_packed", 1): tests
     const size_t img_bytes = blocked ? (size_t)B * (NB * (NB + 1) / 2) * 256 * 8 : 0;
     int rc = dm_ws_reserve(ctx, dm_align_up(pq_bytes) + img_bytes);
     if (rc) return rc;
@@ -606,8 +605,8 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 16 ? 16 : n + 1) + 4) * sizeof(double);
     rc = dm_grant_lds(ctx, (const void*)fmap_solve_kernel, lds);
     if (rc) return rc;
-    const char* de = getenv("DM_SOLVE_DEBUG");                  // experiments: 1 no trailing update, 2 no back substitution, 3 no factorisation
+    // DM_EXPERIMENTS builds only: 1 no trailing update, 2 no back substitution, 3 no factorisation (wrong results)
     DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_kernel, dim3(k2, B), dim3(SP_NT), lds, PQ, lam1, lam2, c00, w_lap, k1, k2,
-              C, info, de ? atoi(de) : 0);
+              C, info, dm_knob("DM_SOLVE_DEBUG", 0));
     return DM_OK;
 }

@@ -32,7 +32,23 @@ struct dm_ctx {
 
     // largest dynamic-LDS size already granted to each kernel on this device (hipFuncSetAttribute is per device)
     std::unordered_map<const void*, size_t> lds_granted;
+
+    // dm_set_option: selection between equivalent (always exact) code paths; tests use it to cover the non-default ones
+    int opt_simnn_pipe = 1;      // 0: every similarity tile goes through the bounds-checked register-staged kernel
+    int opt_knn_split = 1;       // 0: knn21 (ZoomOut, ICP, knn_query) on the float64 G kernel instead of the fp16 split
+    int opt_solve_packed = 0;    // 1: the packed-storage solver for every system size it supports
+    int opt_p2p_split = 1;       // 0: dm_fm_to_p2p on the float64 G kernel instead of the fp16 split first pass
+    int opt_simnn_persist = 1;   // 0: one workgroup per similarity tile instead of one persistent workgroup per CU
+    int n_cu = 0;                // multiProcessorCount of the device
 };
+
+// Experiment knobs (ablation variants that may produce WRONG results) exist only in a -DDM_EXPERIMENTS build, where
+// they are read from the environment; the product library never calls getenv.
+#ifdef DM_EXPERIMENTS
+int dm_knob(const char* env_name, int dflt);
+#else
+static inline int dm_knob(const char*, int dflt) { return dflt; }
+#endif
 
 int dm_fail(dm_ctx* ctx, int code, const char* fmt, ...);
 // allow `func` to be launched with `bytes` of dynamic LDS (> 64 KiB needs an explicit opt-in); remembered per context

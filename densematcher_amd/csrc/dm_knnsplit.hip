@@ -12,12 +12,10 @@
 //  2. every row whose (best - second) is inside twice the error bound is re-evaluated exactly: float64 products of
 //     the original operands, only over the 32-source blocks whose fp32 maximum can still win, lowest index on ties.
 //     Bound, relative to |t_i| max_j |s_j| (>= |x~_i| |y~_j|): fp32 accumulation D (1 + 1/16) 2^-23 (dm_simnn_core)
-//     + 2^-19 for the split (dropped <xl, yl> <= 2^-22, two residuals <= 2^-22 each, fp16 subnormal floor
-//     <= 2 sqrt(k) 2^-25 <= 2^-20.2 for k <= 200, bias pieces 2^-32).
+//     + for the split: dropped <xl, yl> <= 2^-22, two residuals <= 2^-22 each, fp16 subnormal floor <= 2 sqrt(K) 2^-25
+//     (computed from the depth K of the search, 25 % slack; about 2^-19 at K = 200), bias pieces 2^-32.
 //     If -n1_j sx sy / 2 does not fit fp16 (operand scales more than ~2^15 apart) the pair is flagged as a whole and
 //     every row takes the exact path: slower, never wrong.
-#include <stdlib.h>
-
 #include "dm_device.h"
 #include "dm_internal.h"
 
@@ -180,8 +178,7 @@ size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int kf) {
 }
 
 int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf, const double* AT, dm_knn_split_state* st) {
-    const char* e = getenv("DM_KNN_SPLIT");
-    st->enabled = !(e && atoi(e) == 0);
+    st->enabled = ctx->opt_knn_split != 0;
     if (!st->enabled) return DM_OK;
     st->kf = kf; st->ldT = ks_depth(kf);
     st->Ft = (_Float16*)dm_ws_take(ctx, (size_t)B * N2 * st->ldT * 2);
@@ -207,8 +204,10 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 256), dm_cdiv(K, 16) + 1, a.B), dim3(256), 0, a.BT,
               a.n1, st.amaxT, amaxS, dm_cdiv(a.N1pad, 256), K, a.N1, a.N1pad, a.Kpad, D, D, Fs, overflow);
     dm_simnn_queue q;
-    int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, st.Ft, st.ldT, Fs, D, 1.9073486e-6f /* 2^-19 */, overflow, a.knn21, nullptr,
-                           nullptr, &q);
+    // error of the split on top of the fp32 accumulation, relative to |t_i| max_j |s_j|: the dropped <xl, yl> and the two
+    // residuals (3 * 2^-22), the fp16 subnormal floor (2 sqrt(K) 2^-25), 25 % slack; 2^-19 at K = 200
+    const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
+    int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, st.Ft, st.ldT, Fs, D, rel_extra, overflow, a.knn21, nullptr, nullptr, &q);
     if (rc) return rc;
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
     DM_LAUNCH(ctx, "knn_split_exact_f64", ks_exact_kernel, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, K, a.N2, a.N2pad, a.N1,

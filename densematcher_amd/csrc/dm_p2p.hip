@@ -487,9 +487,9 @@ int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a) {
     p.N2 = a.N2; p.N1 = a.N1; p.N2pad = a.N2pad; p.N1pad = a.N1pad; p.Kpad = a.Kpad; p.Kloop = a.Kloop;
     p.tilesM = a.N2pad / GT; p.tilesN = a.N1pad / GT;
     p.total = a.B * p.tilesM * p.tilesN;
-    { const char* e = getenv("DM_GRED_DEBUG"); p.dbg = e ? atoi(e) : 0; }
-    { const char* e = getenv("DM_GRED_STAGGER"); p.stagger = e ? atoi(e) : 0; }
-    { const char* e = getenv("DM_GRED_PRIO"); p.prio = e ? atoi(e) : 0; }
+    p.dbg = dm_knob("DM_GRED_DEBUG", 0);          // DM_EXPERIMENTS builds only (the product passes 0)
+    p.stagger = dm_knob("DM_GRED_STAGGER", 0);
+    p.prio = dm_knob("DM_GRED_PRIO", 0);
     // two instantiations: all four reductions (needs n1, n2, mass1) or the row arg-min knn21 alone (needs n1)
     const bool all = a.knn12 || a.ind21 || a.ind12;
     if (!a.n1 || (all && (!a.n2 || !a.mass1)))
@@ -554,6 +554,7 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     double* E2 = bytes_E2 ? (double*)dm_ws_take(ctx, bytes_E2) : nullptr;
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
     double* n2 = (double*)dm_ws_take(ctx, (size_t)B * N2pad * 8);
+    if (!AT || !BT || (bytes_E2 && !E2) || !n1 || !n2) return dm_fail(ctx, DM_ENOMEM, "fm_to_p2p: workspace not reserved");
 
     // AT = Phi2[:, :k2]^T (K-major f64)
     rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad);
@@ -577,6 +578,12 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
     return dm_launch_gred(ctx, a);
+}
+
+// which path dm_fm_to_p2p takes for these sizes on this context (bench.py names the dominant kernel accordingly)
+extern "C" int dm_fm_to_p2p_uses_split(const dm_ctx* ctx, int N2, int N1, int k) {
+    (void)ctx; (void)N2; (void)N1; (void)k;
+    return 0;
 }
 
 // ---- generic exact nearest neighbour (pyFM/spectral/nn_utils.py:4-38, k = 1) ---------------------------------

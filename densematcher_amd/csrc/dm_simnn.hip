@@ -2,24 +2,24 @@
 //
 //   nn21[b,i] = argmax_j <Ftgt[b,i,:], Fsrc[b,j,:]>          oracle/dm_oracle.py: simnn
 //
-// S^T = Fsrc Ftgt^T is produced 128x128 tile by tile on the fp16 matrix cores
+// S^T = Fsrc Ftgt^T is produced 256x256 tile by tile on the fp16 matrix cores
 // (v_mfma_f32_32x32x16_f16: exact fp16 products, fp32 accumulation) and consumed in registers by
 // a top-2 row reduction; S never reaches memory.  The operands are swapped (src is the MFMA "A"
 // side) so that each lane owns ONE target row and 16 source candidates per MFMA tile: the
 // reduction is in-lane except for one cross-half step.
 //
-// Exactness: fp32 accumulation can reorder near-ties.  Every row whose (best - second best) is
-// within twice the accumulation error bound  D (1 + 1/16) 2^-23 |t_i| max_j |s_j|  is re-evaluated
-// in float64 (products of fp16 are exact in f64, the f64 sum is exact to 1e-16 relative), so the
-// returned index equals the float64 argmax with the lowest-index tie rule.
-#include <stdlib.h>
-
+// Exactness: fp32 accumulation can reorder near-ties, and the in-register reduction compares scores whose low 4
+// mantissa bits carry the candidate's position.  Every row whose (best - second best) is within
+// (2 D (1 + 1/16) 2^-23 + 3 * 2^-19) |t_i| max_j |s_j|  is re-evaluated in float64 (products of fp16 are exact in
+// f64, the f64 sum is exact to 1e-16 relative), so the returned index equals the float64 argmax with the
+// lowest-index tie rule.
 #include "dm_device.h"
 #include "dm_internal.h"
 
 constexpr int ST = 256;    // tile: 256 target rows x 256 source rows per workgroup
-constexpr int SBK = 64;    // contraction (halves) per LDS stage: one 128-byte line per row
+constexpr int SBK = 64;    // contraction (halves) per LDS stage of the register-staged kernel
 #define DM_NEG_INF_F32 (-__builtin_huge_valf())
+#define DM_KEY_NONE (-3.0e38f)   // finite "no candidate" score: its bit pattern stays finite with position bits OR-ed in
 
 __device__ __forceinline__ void top2_merge(float& b, int& i, float& s, float ob, int oi, float os) {
     if (ob > b || (ob == b && oi < i)) { s = fmaxf(b, os); b = ob; i = oi; }
@@ -42,7 +42,7 @@ struct simnn_params {
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
     int ldT, ldS;                            // row strides (halves) of Ftgt / Fsrc, >= D, multiples of 8
-    int dbg;      // experiments only (env DM_SIMNN_DEBUG): 1 = skip the epilogue, 2 = one K stage only, 3 = no norms
+    int dbg;                                 // DM_EXPERIMENTS builds only (0 in the product): see simnn_pipe_kernel
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -58,19 +58,49 @@ __device__ __forceinline__ float sumsq8(f16x8 v, float acc) {
     return acc;
 }
 
+// single-instruction float helpers for the reduction (the operands are scores with position bits in the low
+// mantissa: plain fmaxf would add a canonicalising v_max in front of every use)
+__device__ __forceinline__ float k_max(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float k_min(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float k_max3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float k_med3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// value of the other half-wave's lane (lane ^ 32) with one v_permlane32_swap (VALU) instead of a ds_bpermute round trip
+__device__ __forceinline__ unsigned xhalf_u32(unsigned v, bool upper) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0] = [lo | lo], r[1] = [hi | hi]
+    return upper ? r[0] : r[1];
+}
+__device__ __forceinline__ float xhalf(float v, bool upper) { return __uint_as_float(xhalf_u32(__float_as_uint(v), upper)); }
+__device__ __forceinline__ int xhalf(int v, bool upper) { return (int)xhalf_u32((unsigned)v, upper); }
+// maximum over the two half-waves (keys)
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(__uint_as_float(r[0])), "v"(__uint_as_float(r[1])));
+    return d;
+}
+// score with its low 4 mantissa bits replaced by `code` (v_and_or_b32); code = 15 - position, so that among equal
+// (truncated) positive scores the earliest position is the largest key
+__device__ __forceinline__ float k_key(float v, int code) { return __int_as_float((__float_as_int(v) & ~15) | code); }
+
 // Shared epilogue: row norms, top-2 reduction of the accumulators over the tile's 256 source rows, 32-row block
-// maxima for the fix-up filter.  Reuses the start of the staging LDS as scratch (callers synchronise before).
+// maxima for the fix-up filter.  `scratch` is 6 KiB of LDS that no in-flight LDS-DMA targets; the barrier inside is a
+// raw s_barrier (lgkmcnt only) so that LDS-DMA of the next tile stays in flight across it.
 //   acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
 //                                     i = i0 + wtgt*64 + tt*32 + (lane&31)
-template <bool FULL>
+// Per lane and target row the 64 candidates are reduced as KEYS (k_key): 16 v_and_or + 23 max/med3 per block of
+// 16, instead of compare/select chains on (value, index) pairs.  A key differs from its score by < 2^-19 relative;
+// for any candidate j other than the winner  fp32(best) - fp32(j) >= (bv - sv) - 3 * 2^-19 |t||s|  (one for bv, one
+// for the second key, one for its truncation), which is part of the bound that sends a row to the exact fix-up.
+template <bool FULL, int TT, int SKIP = 0>     // SKIP (experiments): 2 no block-maxima stores, 4 no merge / partial stores
 __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
-                                           bool do_tn, bool do_sn, int b, int i0, int j0, int ts_, _Float16* smem) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wsrc = wave & 1, wtgt = wave >> 1;
+                                           bool do_tn, bool do_sn, int b, int i0, int j0, int ts_, float* scratch,
+                                           int lane, int wsrc, int wtgt) {
+    const int t = threadIdx.x;
+    const int hi = lane >> 5;
     if (do_tn) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            const float v = nrm_t[x] + __shfl_xor(nrm_t[x], 32);
+            const float v = nrm_t[x] + xhalf(nrm_t[x], hi != 0);
             const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
             if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
         }
@@ -79,7 +109,7 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
         float m = 0.f;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            const float v = nrm_s[x] + __shfl_xor(nrm_s[x], 32);
+            const float v = nrm_s[x] + xhalf(nrm_s[x], hi != 0);
             const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
             if (gj < p.N1) m = fmaxf(m, v);
         }
@@ -88,67 +118,83 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
         if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
     }
 
-    // acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
-    //                                   i = i0 + wtgt*64 + tt*32 + (lane&31)
-    float* sb = reinterpret_cast<float*>(smem);          // [2 wsrc][256]
-    int* sj = reinterpret_cast<int*>(smem) + 2 * ST;
-    float* ss = reinterpret_cast<float*>(smem) + 4 * ST;
+    float* sb = scratch;                                 // [2 wsrc][TT]
+    int* sj = reinterpret_cast<int*>(scratch) + 2 * TT;
+    float* ss = scratch + 4 * TT;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-        float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
-        int bj = DM_IDX_NONE;
+        float Bk = DM_KEY_NONE, Sk = DM_KEY_NONE;        // running best / second-best key of this lane
+        int Bst = 0;                                     // block (of 16 candidates) the best key came from
+        const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            float m32 = DM_NEG_INF_F32;                  // maximum over this block of 32 source rows
+            float k[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = (FULL || j < p.N1) ? acc[st][tt][r] : DM_NEG_INF_F32;
-                // candidates arrive in ascending j: strict > keeps the lowest index on ties
-                const bool up = v > bv;
-                sv = up ? bv : fmaxf(sv, v);
-                bj = up ? j : bj;
-                bv = fmaxf(bv, v);
-                m32 = fmaxf(m32, v);
+                float v = acc[st][tt][r];
+                if (!FULL) {
+                    const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    v = (j < p.N1) ? v : DM_KEY_NONE;
+                }
+                k[r] = k_key(v, 15 - r);                 // position r ascends with j inside the block
             }
-            m32 = fmaxf(m32, __shfl_xor(m32, 32));
-            const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
-            if (lane < 32 && gi32 < p.N2)
+            float bk = k_max(k[0], k[1]), sk = k_min(k[0], k[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) {
+                const float m = k_med3(bk, k[r], k[r + 1]);
+                bk = k_max3(bk, k[r], k[r + 1]);
+                sk = k_max(sk, m);
+            }
+            // maximum over this block of 32 source rows (both half-waves), an upper bound of its fp32 scores up to 2^-19
+            const float m32 = xhalf_max(bk);
+            if (!(SKIP & 2) && lane < 32 && gi32 < p.N2)
                 p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
+            Sk = k_max3(Sk, sk, k_min(Bk, bk));
+            Bst = (bk > Bk) ? st : Bst;                  // (equal truncated scores: either block; such a row is re-scored exactly)
+            Bk = k_max(Bk, bk);
         }
-        const float ob = __shfl_xor(bv, 32);
-        const int oj = __shfl_xor(bj, 32);
-        const float os = __shfl_xor(sv, 32);
+        // keys -> (value, source index, second value)
+        const int kb = __float_as_int(Bk);
+        const int r_ = 15 - (kb & 15);
+        float bv = __int_as_float(kb & ~15), sv = __int_as_float(__float_as_int(Sk) & ~15);
+        int bj = j0 + wsrc * 128 + Bst * 32 + (r_ & 3) + 8 * (r_ >> 2) + 4 * hi;
+        if (!FULL && !(bv > -1.0e38f)) { bv = DM_NEG_INF_F32; bj = DM_IDX_NONE; }
+        if (!FULL && !(sv > -1.0e38f)) sv = DM_NEG_INF_F32;
+        const float ob = xhalf(bv, hi != 0);
+        const int oj = xhalf(bj, hi != 0);
+        const float os = xhalf(sv, hi != 0);
         top2_merge(bv, bj, sv, ob, oj, os);
-        if (lane < 32) {
+        if ((SKIP & 4) && bv == 1.2345f) p.pb[lane] = sv + bj;
+        if (!(SKIP & 4) && lane < 32) {
             const int li = wtgt * 64 + tt * 32 + lane;
-            sb[wsrc * ST + li] = bv; sj[wsrc * ST + li] = bj; ss[wsrc * ST + li] = sv;
+            sb[wsrc * TT + li] = bv; sj[wsrc * TT + li] = bj; ss[wsrc * TT + li] = sv;
         }
     }
-    __syncthreads();
-    if (t < ST) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the scratch writes; vmcnt untouched
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(SKIP & 4) && t < TT) {
         const int gi = i0 + t;
         if (gi < p.N2) {
             float bv = sb[t], sv = ss[t];
             int bj = sj[t];
-            top2_merge(bv, bj, sv, sb[ST + t], sj[ST + t], ss[ST + t]);
+            top2_merge(bv, bj, sv, sb[TT + t], sj[TT + t], ss[TT + t]);
             const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
             p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
         }
     }
 }
 
-// FULL: every workgroup tile is interior and D is a multiple of the stage depth -> the main loop carries no
-// bounds checks and no address arithmetic beyond two pointer bumps.
-//
+// Bounds-checked kernel for edge tiles and contraction depths that are not a multiple of 32: one workgroup per
+// tile, operands staged through registers (two 64-deep LDS buffers), zero fill outside the matrices.
 // Tile = 256 target rows x 256 source rows per 512-thread workgroup (8 waves = 2 source halves x 4 target quarters,
-// each wave 128 source x 64 target = 4 x 2 MFMA tiles, 128 accumulator registers).  A 128 x 128 tile moves
-// 64 flop per L2 byte, which at the fp16 MFMA rate asks the L2 for more than it can deliver; 256 x 256 halves that.
-template <bool FULL>
-__global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
+// each wave 128 source x 64 target = 4 x 2 MFMA tiles, 128 accumulator registers).
+__global__ __launch_bounds__(512, 2) void simnn_edge_kernel(simnn_params p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB, scratch
     _Float16* Ts = smem;
     _Float16* Ss = smem + 2 * ST * SBK;
+    float* scratch = reinterpret_cast<float*>(smem + 4 * ST * SBK);           // 6 KiB behind the staging buffers
 
     const int id = xcd_remap(blockIdx.x, p.total);
     const int tiles = p.tilesT * p.tilesS;
@@ -172,32 +218,23 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
 
     // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that
     // own the first tile of the other operand (every row of T / S is seen exactly once that way)
-    const bool do_tn = (ts_ == 0) && (wsrc == 0) && p.dbg != 3;
-    const bool do_sn = (tt_ == 0) && (wtgt == 0) && p.dbg != 3;
+    const bool do_tn = (ts_ == 0) && (wsrc == 0);
+    const bool do_sn = (tt_ == 0) && (wtgt == 0);
     float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int lrow = t >> 3, lchunk = t & 7;                                   // staging: rows q*64 + lrow, 16-byte chunk lchunk
-    const _Float16* tptr = T + (long long)(i0 + lrow) * p.ldT + lchunk * 8;
-    const _Float16* sptr = S + (long long)(j0 + lrow) * p.ldS + lchunk * 8;
     u32x4 rt[4], rs[4];
     // (macros, not lambdas: by-reference lambda captures of the staging arrays end up in scratch)
 #define SIMNN_FETCH(s_)                                                                                          \
     {                                                                                                            \
-        if (FULL) {                                                                                              \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-                rt[q] = *reinterpret_cast<const u32x4*>(tptr + (long long)q * 64 * p.ldT + (s_) * SBK);         \
-                rs[q] = *reinterpret_cast<const u32x4*>(sptr + (long long)q * 64 * p.ldS + (s_) * SBK);         \
-            }                                                                                                    \
-        } else {                                                                                                 \
-            const int k_ = (s_) * SBK + lchunk * 8;                                                              \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-                const int row = q * 64 + lrow;                                                                   \
-                const int gi = i0 + row, gj = j0 + row;                                                          \
-                rt[q] = (gi < p.N2 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(T + (long long)gi * p.ldT + k_) \
-                                                : u32x4{0, 0, 0, 0};                                             \
-                rs[q] = (gj < p.N1 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(S + (long long)gj * p.ldS + k_) \
-                                                : u32x4{0, 0, 0, 0};                                             \
-            }                                                                                                    \
+        const int k_ = (s_) * SBK + lchunk * 8;                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                          \
+            const int row = q * 64 + lrow;                                                                       \
+            const int gi = i0 + row, gj = j0 + row;                                                              \
+            rt[q] = (gi < p.N2 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(T + (long long)gi * p.ldT + k_)    \
+                                            : u32x4{0, 0, 0, 0};                                                 \
+            rs[q] = (gj < p.N1 && k_ < p.D) ? *reinterpret_cast<const u32x4*>(S + (long long)gj * p.ldS + k_)    \
+                                            : u32x4{0, 0, 0, 0};                                                 \
         }                                                                                                        \
     }
 #define SIMNN_STASH(buf_)                                                                                        \
@@ -208,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
         *reinterpret_cast<u32x4*>(Ss + off) = rs[q];                                                             \
     }
 
-    const int ns = (p.dbg == 2) ? 1 : (p.D + SBK - 1) / SBK;
+    const int ns = (p.D + SBK - 1) / SBK;
     SIMNN_FETCH(0)
     SIMNN_STASH(0)
     __syncthreads();
@@ -246,195 +283,123 @@ __global__ __launch_bounds__(512, 2) void simnn_kernel(simnn_params p) {
     }
 #undef SIMNN_FETCH
 #undef SIMNN_STASH
-
-    if (p.dbg == 1) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
-        if (sacc == 1.2345f) p.pb[0] = sacc;
-        return;
-    }
-    simnn_tail<FULL>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, smem);
+    simnn_tail<false, ST>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt);
 }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Interior tiles, D % 64 == 0: same tiling as simnn_kernel, operands staged by LDS-DMA.
-// EXP (experiments, env DM_SIMNN_EXP with DM_SIMNN_PIPE=0): 0 = product kernel; 3 = MFMA only (no LDS-DMA, no fragment
-// reads in the loop); 7 = LDS-DMA only (no MFMA, no fragment reads).  3 and 7 give wrong results and exist to bound
-// the main loop from both sides.
-template <int EXP>
-__global__ __launch_bounds__(512, 2) void simnn_glds_kernel(simnn_params p) {
-    constexpr bool FULL = true;
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
-    _Float16* Ts = smem;
-    _Float16* Ss = smem + 2 * ST * SBK;
-
-    const int id = xcd_remap(blockIdx.x, p.total);
-    const int tiles = p.tilesT * p.tilesS;
-    const int b = id / tiles;
-    const int tts = id - b * tiles;
-    const int tt_ = tts / p.tilesS, ts_ = tts - tt_ * p.tilesS;
-    const int i0 = tt_ * ST, j0 = ts_ * ST;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wsrc = wave & 1, wtgt = wave >> 1;
-
-    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.ldT;
-    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.ldS;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-    // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that
-    // own the first tile of the other operand (every row of T / S is seen exactly once that way)
-    const bool do_tn = (ts_ == 0) && (wsrc == 0) && p.dbg != 3;
-    const bool do_sn = (tt_ == 0) && (wtgt == 0) && p.dbg != 3;
-    float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
-
-    // Staging by LDS-DMA (global_load_lds, 16 B per lane): one instruction fills 8 consecutive 128-byte rows of the
-    // LDS image (wave-uniform base + lane * 16).  The image is swizzled (chunk c of row r lives in slot
-    // c ^ ((r >> 1) & 7)), and since the DMA destination is lane-linear the swizzle is applied to the per-lane
-    // SOURCE address: lane l fills slot (l & 7) of row (l >> 3), so it fetches chunk (l & 7) ^ ((row >> 1) & 7).
-    // Wave w stages row groups 4w .. 4w+3 (8 rows each) of both operands: 8 DMA instructions per stage, no VGPRs,
-    // no ds_write.
-    const int grow = lane >> 3;
-    const _Float16* tsrc[4];
-    const _Float16* ssrc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + grow;
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        tsrc[q] = T + (long long)(i0 + row) * p.ldT + chunk * 8;
-        ssrc[q] = S + (long long)(j0 + row) * p.ldS + chunk * 8;
-    }
-#define SIMNN_DMA(s_, buf_)                                                                                      \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                              \
-        const int off = (buf_) * ST * SBK + (wave * 4 + q) * 8 * SBK;                                            \
-        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (s_) * SBK), (lptr_t)(Ts + off), 16, 0, 0);         \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (s_) * SBK), (lptr_t)(Ss + off), 16, 0, 0);         \
-    }
-
-    const int ns = (p.dbg == 2) ? 1 : p.D / SBK;
-    SIMNN_DMA(0, 0)
-    __syncthreads();                       // (the barrier's release waits for the outstanding LDS-DMA: vmcnt(0))
-    // the k loop exists twice: the few workgroups that also accumulate row norms take the second copy, so the hot
-    // copy has no conditional inside a k-step (a branch there splits the basic block and stops the compiler from
-    // interleaving the next ds_reads with the MFMAs)
-    f16x8 fs[4], ft[2];
-#define SIMNN_KLOOP(NORMS)                                                                                             \
-    for (int s = 0; s < ns; ++s) {                                                                                     \
-        const int buf = s & 1;                                                                                         \
-        if (s + 1 < ns && EXP != 3) { SIMNN_DMA(s + 1, buf ^ 1) }                                                      \
-        const _Float16* Tb = Ts + buf * ST * SBK;                                                                      \
-        const _Float16* Sb = Ss + buf * ST * SBK;                                                                      \
-        _Pragma("unroll") for (int kk = 0; kk < SBK / 16; ++kk) {                                                      \
-            const int chunk = kk * 2 + (lane >> 5);                                                                    \
-            if ((EXP != 3 && EXP != 7) || (s == 0 && kk == 0)) {                                                       \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                              \
-                fs[x] = *reinterpret_cast<const f16x8*>(Sb + lds_off_halves(wsrc * 128 + x * 32 + (lane & 31), chunk)); \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                              \
-                ft[x] = *reinterpret_cast<const f16x8*>(Tb + lds_off_halves(wtgt * 64 + x * 32 + (lane & 31), chunk));  \
-            }                                                                                                          \
-            if (NORMS) {                                                                                               \
-                if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft[x], nrm_t[x]); }       \
-                if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs[x], nrm_s[x]); }       \
-            }                                                                                                          \
-            if (EXP != 7 || s == 0) {                                                                                  \
-            _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                           \
-                _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                       \
-                    acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs[st], ft[tt], acc[st][tt], 0, 0, 0);        \
-            }                                                                                                          \
-        }                                                                                                              \
-        __syncthreads();                                                                                               \
-    }
-    if ((ts_ == 0 || tt_ == 0) && p.dbg != 3) { SIMNN_KLOOP(true) } else { SIMNN_KLOOP(false) }
-#undef SIMNN_KLOOP
-#undef SIMNN_DMA
-
-    if (p.dbg == 1) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
-        if (sacc == 1.2345f) p.pb[0] = sacc;
-        return;
-    }
-    simnn_tail<FULL>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, smem);
-}
-
-// Deep-pipelined variant (default for interior tiles, D % 32 == 0).  Same 256 x 256 tile and wave layout as
-// simnn_glds_kernel, but the contraction is staged 32 halves at a time through a ring of FOUR 32 KiB LDS buffers and
-// the LDS-DMA of stage s+3 is issued while stage s is computed: a first-touch miss (HBM / Infinity Cache, ~2 us under
-// load; every tile has some because one pair's operands, 6 MB, exceed an XCD's 4 MB L2) then has three stages to
-// land instead of one.  The wait before each barrier is a COUNTED vmcnt (the two younger stages stay in flight).
+// Interior tiles, D % 32 == 0, D >= 96: the main kernel, in two shapes (template WT = target quarters per workgroup):
+//   WT = 2: 4 waves, tile = 128 target x 256 source rows, ring of 3 stages (72 KiB) -> TWO workgroups per CU.  The two
+//           waves of a SIMD then belong to different workgroups: one workgroup's barrier / fragment-read bubbles and
+//           its whole reduction epilogue are covered by the other's MFMAs.  (default)
+//   WT = 4: 8 waves, tile = 256 x 256, ring of 4 stages (128 KiB), one workgroup per CU: a third less L2 -> LDS traffic,
+//           but both waves of a SIMD meet every barrier together and nothing covers the epilogue.
 //
-// LDS image of one operand stage: 256 rows x 64 B; chunk c (16 B) of row r lives in slot c ^ ((r >> 2) & 3), so the
+// * Operands go L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs, no ds_write) through a ring of
+//   32-halves-deep stages; the DMA of stage g + NBUF - 1 is issued while stage g is computed and the wait before each
+//   barrier is a COUNTED vmcnt (the younger stages stay in flight).
+// * The ring is indexed by a stage counter that runs across tiles: a workgroup walks a LIST of tiles (launched one or
+//   two per CU: "persistent"; launched one per tile the list has one entry) and the first stages of the next tile are
+//   in flight during the last stages and the reduction epilogue of the current one.  The tiles a workgroup walks are
+//   those of its XCD (block b runs on XCD b % 8; each XCD gets a contiguous range of tile ids = whole mesh pairs,
+//   whose operand panels then meet in one 4 MiB L2), consecutive ids per round.
+// * K-staggered sweep: the workgroups that share a target panel (same tt) or a source panel (same ts) run in
+//   lockstep, so with a common sweep order every one of them sees every first touch of a line as an L2 miss.
+//   Tile (tt, ts) starts its (cyclic) sweep at a stage that depends on (tt, ts) instead: after its first stages each
+//   workgroup trails a neighbour that has already pulled the lines into the XCD's L2.  The sum is the same up to fp32
+//   rounding, which the exact fix-up absorbs.
+//
+// LDS image of one operand stage: rows x 64 B; chunk c (16 B) of row r lives in slot c ^ ((r >> 2) & 3), so the
 // 16 rows of a ds_read_b128 lane group (four runs of 4 consecutive rows with distinct (r >> 2) & 3) cover all 16
 // slots of the 256-byte bank row.  One DMA instruction fills 16 rows (lane l -> row l >> 2, slot l & 3), the swizzle
 // is applied on the source address.
+//
+// XV = compile-time variant bits; the product instantiates SIMNN_PRODUCT_XV only, a DM_EXPERIMENTS build a list of them
+// (the ablations give WRONG results): low 4 bits: 1 skip the epilogue, 3 no norms, 7 LDS-DMA only, 8 no LDS-DMA, 9 = 8 + 1;
+// 16 / 32: K stagger by one stage / spread over the whole sweep; 64: fragment reads pinned in front of the MFMAs.
 constexpr int PBK = 32;                    // halves per stage
-constexpr int PNBUF = 4;                   // ring depth
-constexpr int PSTAGE = 2 * ST * PBK;       // halves per ring slot: T image then S image
-#define DM_WAITCNT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15))     /* vmcnt(n), lgkmcnt / expcnt untouched */
-template <int EXP>
-__global__ __launch_bounds__(512, 2) void simnn_pipe_kernel(simnn_params p) {
-    constexpr bool FULL = true;
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // 4 x (T 16 KiB | S 16 KiB)
+constexpr int SIMNN_PRODUCT_XV = 64;
+constexpr int SIMNN_PRODUCT_WT = 4;
+#define DM_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15))    /* vmcnt(n) lgkmcnt(0) */
+static inline size_t simnn_pipe_lds(int WT) {
+    const int TT = 64 * WT, NBUF = WT == 4 ? 4 : 3;
+    return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + 3 * 2 * ST * 4;
+}
 
-    const int id = xcd_remap(blockIdx.x, p.total);
+__device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int& b, int& tt_, int& ts_) {
     const int tiles = p.tilesT * p.tilesS;
-    const int b = id / tiles;
+    b = id / tiles;
     const int tts = id - b * tiles;
-    const int tt_ = tts / p.tilesS, ts_ = tts - tt_ * p.tilesS;
-    const int i0 = tt_ * ST, j0 = ts_ * ST;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    tt_ = tts / p.tilesS;
+    ts_ = tts - tt_ * p.tilesS;
+}
+
+template <int XV, int WT>
+__global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p) {
+    constexpr int TT = 64 * WT;                  // target rows per tile
+    constexpr int NW = 2 * WT;                   // waves
+    constexpr int NBUF = WT == 4 ? 4 : 3;        // ring depth
+    constexpr int PD = NBUF - 1;                 // stages the DMA runs ahead
+    constexpr int PSTAGE = (TT + ST) * PBK;      // halves per ring slot: T image then S image
+    constexpr int NSI = 16 / NW;                 // DMA instructions per wave and stage for S (T: always 2)
+    constexpr int VM_STEADY = (PD - 2) * (2 + NSI) + 1 + NSI / 2;   // loads that may stay in flight at the barrier
+    constexpr int dbg = XV & 15;
+    constexpr int STAG = (XV >> 4) & 3;
+    constexpr bool PINR = (XV & 64) != 0;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | scratch
+    float* scratch = reinterpret_cast<float*>(smem + NBUF * PSTAGE);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wsrc = wave & 1, wtgt = wave >> 1;
 
-    const _Float16* T = p.Ftgt + (long long)b * p.N2 * p.ldT;
-    const _Float16* S = p.Fsrc + (long long)b * p.N1 * p.ldS;
+    // tiles of this workgroup: ids base + slot, base + slot + nslot, ... of the XCD's range [base, base + cnt)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nslot = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q8 = p.total >> 3, r8 = p.total & 7;
+    const int base = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    if (slot >= cnt) return;
+    const int ntile = (cnt - slot + nslot - 1) / nslot;
+    const int ns = p.D / PBK;                                    // >= NBUF + 1 (host)
 
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-    const bool do_tn = (ts_ == 0) && (wsrc == 0) && p.dbg != 3;
-    const bool do_sn = (tt_ == 0) && (wtgt == 0) && p.dbg != 3;
-    float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
-
-    // wave w stages rows 32w .. 32w+31 of both operands: 4 DMA instructions per stage
-    const _Float16* tsrc[2];
-    const _Float16* ssrc[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = wave * 32 + q * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        tsrc[q] = T + (long long)(i0 + row) * p.ldT + chunk * 8;
-        ssrc[q] = S + (long long)(j0 + row) * p.ldS + chunk * 8;
+    // LDS-DMA source: per-lane part (row l >> 2 of a 16-row group, swizzled chunk) + uniform part (tile, wave, stage)
+    const unsigned voffT = (unsigned)(((lane >> 2) * p.ldT + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+    const unsigned voffS = (unsigned)(((lane >> 2) * p.ldS + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+    // the stage stream being fetched (runs PD stages ahead of the one being computed)
+    int d_tile = 0, d_s = 0, d_kp = 0, d_slot = 0;
+    const char* d_T = nullptr;                   // rows wave*32 .. of the tile's target panel (2 x 16 rows per stage)
+    const char* d_S = nullptr;                   // rows wave*16*NSI .. of the tile's source panel (NSI x 16 rows)
+#define SIMNN_DMA_TILE()                                                                                               \
+    {                                                                                                                  \
+        int b_, tt_, ts_;                                                                                              \
+        simnn_decode(p, base + slot + d_tile * nslot, b_, tt_, ts_);                                                   \
+        d_T = reinterpret_cast<const char*>(p.Ftgt + ((long long)b_ * p.N2 + tt_ * TT + wave * 32) * p.ldT);           \
+        d_S = reinterpret_cast<const char*>(p.Fsrc + ((long long)b_ * p.N1 + ts_ * ST + wave * 16 * NSI) * p.ldS);     \
+        d_kp = STAG == 0 ? 0 : (STAG == 1 ? (ts_ + tt_) % ns : ((ts_ + tt_) * ns / p.tilesS) % ns);                    \
+        d_s = 0;                                                                                                       \
     }
-#define SIMNN_DMA1(s_, q)                                                                                        \
-    {                                                                                                            \
-        _Float16* dst = smem + ((s_) & (PNBUF - 1)) * PSTAGE + (wave * 32 + (q) * 16) * PBK;                     \
-        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc[q] + (kbase + kstep * (s_)) * PBK), (lptr_t)dst, 16, 0, 0);                \
-        __builtin_amdgcn_global_load_lds((gptr_t)(ssrc[q] + (kbase + kstep * (s_)) * PBK), (lptr_t)(dst + ST * PBK), 16, 0, 0);   \
+    // half H_ (0 / 1) of the DMA instructions of the stage stream's current stage: T piece H_, S pieces H_*NSI/2 ..
+#define SIMNN_DMA1(H_)                                                                                                 \
+    if (!(dbg & 8) || d_tile == 0) {                                                                                   \
+        _Float16* dstT = smem + d_slot * PSTAGE + (wave * 32 + (H_) * 16) * PBK;                                       \
+        const char* gt = d_T + ((long long)((H_) * 16) * p.ldT + d_kp * PBK) * 2;                                      \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gt + voffT), (lptr_t)dstT, 16, 0, 0);                                \
+        _Pragma("unroll") for (int u = 0; u < NSI / 2; ++u) {                                                          \
+            const int piece = (H_) * (NSI / 2) + u;                                                                    \
+            _Float16* dstS = smem + d_slot * PSTAGE + (TT + wave * 16 * NSI + piece * 16) * PBK;                       \
+            const char* gs = d_S + ((long long)(piece * 16) * p.ldS + d_kp * PBK) * 2;                                 \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gs + voffS), (lptr_t)dstS, 16, 0, 0);                            \
+        }                                                                                                              \
     }
-#define SIMNN_DMA(s_) SIMNN_DMA1(s_, 0) SIMNN_DMA1(s_, 1)
+#define SIMNN_DMA_NEXT()                                                                                               \
+    {                                                                                                                  \
+        ++d_s;                                                                                                         \
+        d_kp = (d_kp + 1 == ns) ? 0 : d_kp + 1;                                                                        \
+        d_slot = (d_slot + 1 == NBUF) ? 0 : d_slot + 1;                                                                \
+        if (d_s == ns) { ++d_tile; if (d_tile < ntile) SIMNN_DMA_TILE() }                                              \
+    }
 
     // fragment addresses: row (lane & 31) of a 32-row block, chunk kk*2 + (lane >> 5); the swizzle term depends on
     // the lane only, and kk = 1 flips bit 1 of the slot
@@ -442,101 +407,128 @@ __global__ __launch_bounds__(512, 2) void simnn_pipe_kernel(simnn_params p) {
     const int c0 = (lane >> 5) ^ swz;
     const int frow = (lane & 31) * PBK;
     const int foff0 = frow + (c0 << 3), foff1 = frow + ((c0 ^ 2) << 3);
-    const int sbase = ST * PBK + wsrc * 128 * PBK, tbase = wtgt * 64 * PBK;
+    const int sbase = TT * PBK + wsrc * 128 * PBK, tbase = wtgt * 64 * PBK;
 
-    const int ns = (p.dbg == 2) ? 3 : p.D / PBK;                 // >= 3 (host checks D >= 96)
-    // The 32 workgroups of an XCD sweep the contraction roughly in step; consecutive waves of 32 tiles alternate the
-    // sweep direction, so a wave starts on the K chunks its predecessor touched last (still in the 4 MB L2) when they
-    // share operand panels -- a pair's panels (6 MB) do not fit, and with one direction the LRU has always just
-    // evicted the chunk that is needed next.  (Any order gives the same exact result: ties go to the fix-up.)
-    const bool krev = ((tts >> 5) & 1) != 0;
-    const int kbase = krev ? ns - 1 : 0, kstep = krev ? -1 : 1;
-    SIMNN_DMA(0)
-    SIMNN_DMA(1)
-    SIMNN_DMA(2)
-    DM_WAITCNT_VM(8);                                            // stage 0 has landed; stages 1, 2 in flight
+    SIMNN_DMA_TILE()
+#pragma unroll
+    for (int q = 0; q < PD; ++q) { SIMNN_DMA1(0) SIMNN_DMA1(1) SIMNN_DMA_NEXT() }
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((PD - 1) * (2 + NSI)));     // vmcnt: stage 0 has landed; the others in flight
     __builtin_amdgcn_s_barrier();
 
-    // The loop is rotated by half a stage: the barrier that publishes stage s+1 sits between the two k-steps of
-    // stage s, so the first fragments of stage s+1 are fetched under the MFMAs of (s, kk=1) and no fragment read is
-    // exposed after a barrier.  Ring slot (s+3)&3 == (s-1)&3 was last read by the (s-1, kk=1) fragments, complete
-    // (lgkmcnt(0)) before the barrier of iteration s-1, which every wave has left before iteration s starts.
+    // The stage loop is rotated by half a stage: the barrier that publishes stage g+1 sits between the two k-steps of
+    // stage g, so the first fragments of stage g+1 are fetched under the MFMAs of (g, kk=1) and no fragment read is
+    // exposed after a barrier.  Ring slot of stage g+PD == slot of stage g-1, last read by the (g-1, kk=1) fragments,
+    // complete (lgkmcnt(0)) before the barrier of iteration g-1, which every wave has left before iteration g starts.
+    // vmcnt before the barrier of iteration g: stage g+1 must have landed; younger are the stages g+2 .. g+PD-1 and the
+    // first half of stage g+PD, fewer at the very end of the walk.  Stores of an epilogue in between only make the
+    // count conservative (it bounds loads + stores in flight).
     f16x8 fsa[4], fta[2], fsb[4], ftb[2];
-#define SIMNN_READ(fs_, ft_, s_, fo_)                                                                                  \
-    if (EXP != 7 || (s_) == 0) {                                                                                       \
-        const _Float16* Bs = smem + ((s_) & (PNBUF - 1)) * PSTAGE;                                                     \
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    constexpr bool NOEPI = (dbg & 7) == 1 || (dbg & 7) == 7;
+    constexpr int EPI_ST = 8;                     // stores every wave issues in an epilogue: the 2 x 4 block maxima
+    int r_slot = 0;                               // ring slot of the stage being computed
+#define SIMNN_READ(fs_, ft_, slot_, fo_)                                                                               \
+    if ((dbg & 7) != 7) {                                                                                              \
+        const _Float16* Bs = smem + (slot_) * PSTAGE;                                                                  \
         _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                  \
             fs_[x] = *reinterpret_cast<const f16x8*>(Bs + sbase + x * 32 * PBK + (fo_));                               \
         _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                                  \
             ft_[x] = *reinterpret_cast<const f16x8*>(Bs + tbase + x * 32 * PBK + (fo_));                               \
     }
-#define SIMNN_MMA(fs_, ft_, NORMS)                                                                                     \
-    if (EXP != 7 || s == 0) {                                                                                          \
+#define SIMNN_MMA(fs_, ft_, NORMS, ZERO_)                                                                              \
+    if ((dbg & 7) != 7) {                                                                                              \
         if (NORMS) {                                                                                                   \
             if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft_[x], nrm_t[x]); }          \
             if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs_[x], nrm_s[x]); }          \
         }                                                                                                              \
         _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
             _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                           \
-                acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], acc[st][tt], 0, 0, 0);          \
+                acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], (ZERO_) ? zero16 : acc[st][tt], 0, 0, 0); \
     }
-#define SIMNN_SYNC(n_)                                                                                                 \
+#define SIMNN_SYNC(n_, AFTER_EPI_)                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15));            /* vmcnt(n) lgkmcnt(0) */                             \
+    if ((AFTER_EPI_) && n > 0 && !NOEPI) DM_WAIT_VM_LGKM0((n_) + EPI_ST);                                              \
+    else DM_WAIT_VM_LGKM0(n_);                                                                                         \
     __builtin_amdgcn_s_barrier();                                                                                      \
     __builtin_amdgcn_sched_barrier(0);
-#define SIMNN_KLOOP(NORMS)                                                                                             \
+#define SIMNN_PIN() if (PINR) __builtin_amdgcn_sched_barrier(0);
+    // one stage: DMA_ = 1 in the steady state (stage g+PD exists), VM_ = loads allowed to stay in flight at the barrier,
+    // NEXT_ = fetch the first fragments of the next stage (in the steady state also across a tile boundary: they wait
+    // in registers while the epilogue runs)
+#define SIMNN_STAGE(NORMS, DMA_, VM_, NEXT_, ZERO_, AFTER_EPI_)                                                        \
     {                                                                                                                  \
-        int s = 0;                                                                                                     \
-        SIMNN_READ(fsa, fta, 0, foff0)                                                                                 \
-        for (; s < ns - 3; ++s) {                                                                                      \
-            SIMNN_READ(fsb, ftb, s, foff1)                                                                             \
-            SIMNN_DMA1(s + 3, 0)                                                                                       \
-            SIMNN_MMA(fsa, fta, NORMS)                                                                                 \
-            SIMNN_SYNC(6)                                                                                              \
-            SIMNN_READ(fsa, fta, s + 1, foff0)                                                                         \
-            SIMNN_DMA1(s + 3, 1)                                                                                       \
-            SIMNN_MMA(fsb, ftb, NORMS)                                                                                 \
-        }                                                                                                              \
-        SIMNN_READ(fsb, ftb, s, foff1)                                                                                 \
-        SIMNN_MMA(fsa, fta, NORMS)                                                                                     \
-        SIMNN_SYNC(4)                                                                                                  \
-        SIMNN_READ(fsa, fta, s + 1, foff0)                                                                             \
-        SIMNN_MMA(fsb, ftb, NORMS)                                                                                     \
-        ++s;                                                                                                           \
-        SIMNN_READ(fsb, ftb, s, foff1)                                                                                 \
-        SIMNN_MMA(fsa, fta, NORMS)                                                                                     \
-        SIMNN_SYNC(0)                                                                                                  \
-        SIMNN_READ(fsa, fta, s + 1, foff0)                                                                             \
-        SIMNN_MMA(fsb, ftb, NORMS)                                                                                     \
-        ++s;                                                                                                           \
-        SIMNN_READ(fsb, ftb, s, foff1)                                                                                 \
-        SIMNN_MMA(fsa, fta, NORMS)                                                                                     \
-        SIMNN_MMA(fsb, ftb, NORMS)                                                                                     \
+        const int n_slot = (r_slot + 1 == NBUF) ? 0 : r_slot + 1;                                                      \
+        SIMNN_READ(fsb, ftb, r_slot, foff1)                                                                            \
+        if (DMA_) { SIMNN_DMA1(0) }                                                                                    \
+        SIMNN_PIN()                                                                                                    \
+        SIMNN_MMA(fsa, fta, NORMS, ZERO_)                                                                              \
+        SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
+        if (NEXT_) { SIMNN_READ(fsa, fta, n_slot, foff0) }                                                             \
+        if (DMA_) { SIMNN_DMA1(1) }                                                                                    \
+        SIMNN_PIN()                                                                                                    \
+        SIMNN_MMA(fsb, ftb, NORMS, false)                                                                              \
+        r_slot = n_slot;                                                                                               \
+        if (DMA_) SIMNN_DMA_NEXT()                                                                                     \
     }
-    if ((ts_ == 0 || tt_ == 0) && p.dbg != 3) SIMNN_KLOOP(true) else SIMNN_KLOOP(false)
-#undef SIMNN_KLOOP
+    // Every stage of every tile but the last PD of the walk is a steady-state stage: no branch inside the body.  The
+    // first k-step of a tile accumulates onto zero.  The first PD-1 stages of a tile that follows an epilogue let that
+    // epilogue's stores stay in flight too (every wave issued at least EPI_ST of them; vmcnt counts loads + stores in
+    // issue order, so allowing EPI_ST more keeps the wait to the LDS-DMA it is meant for instead of a store's round trip).
+#define SIMNN_TILE_LOOP(NORMS)                                                                                         \
+    {                                                                                                                  \
+        const int nsteady = (n + 1 < ntile) ? ns : ns - PD;          /* >= 2 (host: ns >= NBUF + 1) */                 \
+        SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, true, true)                                                                \
+        if (PD == 3) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, true)                                                  \
+        for (int s = PD - 1; s < nsteady; ++s) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, false)                       \
+        if (n + 1 == ntile) {                                                                                          \
+            if (PD == 3) SIMNN_STAGE(NORMS, 0, 2 + NSI, 1, false, false)                                               \
+            SIMNN_STAGE(NORMS, 0, 0, 1, false, false)                                                                  \
+            SIMNN_STAGE(NORMS, 0, 0, 0, false, false)                                                                  \
+        }                                                                                                              \
+    }
+
+    SIMNN_READ(fsa, fta, 0, foff0)
+    for (int n = 0; n < ntile; ++n) {
+        int b, tt_, ts_;
+        simnn_decode(p, base + slot + n * nslot, b, tt_, ts_);
+        const int i0 = tt_ * TT, j0 = ts_ * ST;
+        f32x16 acc[4][2];
+        // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that own
+        // the first tile of the other operand (every row of T / S is seen exactly once that way).  Those tiles run a
+        // second copy of the loop, so the hot copy has no conditional inside a k-step.
+        constexpr bool want_n = (dbg & 7) != 3 && (dbg & 7) != 7;
+        const bool do_tn = (ts_ == 0) && (wsrc == 0) && want_n;
+        const bool do_sn = (tt_ == 0) && (wtgt == 0) && want_n;
+        float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
+
+        if ((ts_ == 0 || tt_ == 0) && want_n) { SIMNN_TILE_LOOP(true) } else { SIMNN_TILE_LOOP(false) }
+
+        if ((dbg & 7) == 1 || (dbg & 7) == 7) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
+            if (sacc == 1.2345f) p.pb[0] = sacc;
+            continue;
+        }
+        simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);                          // nothing of this workgroup may still be in flight
+#undef SIMNN_TILE_LOOP
+#undef SIMNN_STAGE
+#undef SIMNN_PIN
 #undef SIMNN_SYNC
 #undef SIMNN_MMA
 #undef SIMNN_READ
+#undef SIMNN_DMA_NEXT
 #undef SIMNN_DMA1
-#undef SIMNN_DMA
-    __syncthreads();                                             // the epilogue reuses the ring as scratch
-
-    if (p.dbg == 1) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
-        if (sacc == 1.2345f) p.pb[0] = sacc;
-        return;
-    }
-    simnn_tail<FULL>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, smem);
+#undef SIMNN_DMA_TILE
 }
-
 
 __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restrict__ pb, const int32_t* __restrict__ pj,
                                                           const float* __restrict__ ps, int tilesS, int N2, int N2pad,
@@ -650,7 +642,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     p.ldT = ldT; p.ldS = ldS;
     p.tilesT = p.N2pad / ST; p.tilesS = dm_cdiv(N1, ST);
     p.total = B * p.tilesT * p.tilesS;
-    { const char* e = getenv("DM_SIMNN_DEBUG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = dm_knob("DM_SIMNN_DEBUG", 0);
     const size_t np = (size_t)B * p.tilesS * p.N2pad;
     p.nsub = p.tilesS * (ST / 32);
     const size_t np32 = (size_t)B * p.nsub * p.N2pad;
@@ -668,37 +660,54 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(p.smax2, 0, (size_t)B * 4, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
-    const size_t lds_main = (size_t)2 * 2 * ST * SBK * sizeof(_Float16);       // 128 KiB
-    int rc;
-    {
-        const void* kernels[] = {(const void*)simnn_glds_kernel<0>, (const void*)simnn_glds_kernel<3>, (const void*)simnn_glds_kernel<7>,
-                                 (const void*)simnn_kernel<false>, (const void*)simnn_pipe_kernel<0>, (const void*)simnn_pipe_kernel<7>};
-        for (const void* kf : kernels) {
-            rc = dm_grant_lds(ctx, kf, lds_main);
-            if (rc) return rc;
-        }
-    }
+    const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16) + 3 * 2 * ST * 4;
     const bool interior = (N2 % ST == 0 && N1 % ST == 0);
-    const char* pe = getenv("DM_SIMNN_PIPE");                                  // 0: the two-buffer kernel (experiments)
-    const int pipe = pe ? atoi(pe) : 1;
-    if (interior && pipe && D % PBK == 0 && D >= 3 * PBK) {
-        const char* xe = getenv("DM_SIMNN_EXP");
-        if (xe && atoi(xe) == 7) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_pipe_kernel<7>, dim3(p.total), dim3(512), lds_main, p);
-        else DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_pipe_kernel<0>, dim3(p.total), dim3(512), lds_main, p);
+    // DM_EXPERIMENTS: DM_SIMNN_DEBUG = variant bits XV (simnn_pipe_kernel) + 256 / 512 for the 8-wave / 4-wave shape
+    const int WT = (p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT);
+    // (the stage loop peels its first and last stages: the contraction must be at least ring depth + 1 stages deep)
+    if (interior && ctx->opt_simnn_pipe && D % PBK == 0 && D >= (WT == 4 ? 5 : 4) * PBK) {
+        const int TT = 64 * WT;
+        p.tilesT = p.N2pad / TT;
+        p.total = B * p.tilesT * p.tilesS;
+        const size_t lds_pipe = simnn_pipe_lds(WT);
+        // workgroups that fit a CU at once walk the tiles (opt_simnn_persist: 0 = one workgroup per tile, 1 = as many
+        // workgroups as are resident when there are more tiles than that, n > 1 = n workgroups (tests))
+        const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+        const int resident = ncu * (WT == 4 ? 1 : 2);
+        const int want = ctx->opt_simnn_persist > 1 ? ctx->opt_simnn_persist : (ctx->opt_simnn_persist ? resident : p.total);
+        const int grid = want < p.total ? want : p.total;
+        int rc = DM_OK;
+#define SIMNN_LAUNCH_XV(XV_, WT_)                                                                                      \
+        {                                                                                                              \
+            rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<XV_, WT_>, lds_pipe);                                \
+            if (rc) return rc;                                                                                         \
+            DM_LAUNCH(ctx, "simnn_f16_mfma", (simnn_pipe_kernel<XV_, WT_>), dim3(grid), dim3(128 * WT_), lds_pipe, p); \
+        }
+#ifdef DM_EXPERIMENTS
+        switch (p.dbg) {
+#define SIMNN_CASE(XV_) case 512 + XV_: SIMNN_LAUNCH_XV(XV_, 2) break; case 256 + XV_: SIMNN_LAUNCH_XV(XV_, 4) break;
+            SIMNN_CASE(0) SIMNN_CASE(1) SIMNN_CASE(7) SIMNN_CASE(9)
+            SIMNN_CASE(16) SIMNN_CASE(32) SIMNN_CASE(64)
+            SIMNN_CASE(64 + 1) SIMNN_CASE(64 + 7) SIMNN_CASE(64 + 9) SIMNN_CASE(64 + 16) SIMNN_CASE(64 + 32)
+            SIMNN_CASE(64 + 32 + 1) SIMNN_CASE(64 + 32 + 7) SIMNN_CASE(64 + 32 + 9)
+            SIMNN_CASE(64 + 2) SIMNN_CASE(64 + 4) SIMNN_CASE(64 + 6)
+#undef SIMNN_CASE
+            default: SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT) break;
+        }
+#else
+        SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT)
+#endif
+#undef SIMNN_LAUNCH_XV
+    } else {
+        int rc = dm_grant_lds(ctx, (const void*)simnn_edge_kernel, lds_edge);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_edge_kernel, dim3(p.total), dim3(512), lds_edge, p);
     }
-    else if (interior && D % SBK == 0) {
-        const char* xe = getenv("DM_SIMNN_EXP");
-        const int ex = xe ? atoi(xe) : 0;
-        if (ex == 3) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel<3>, dim3(p.total), dim3(512), lds_main, p);
-        else if (ex == 7) DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel<7>, dim3(p.total), dim3(512), lds_main, p);
-        else DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_glds_kernel<0>, dim3(p.total), dim3(512), lds_main, p);
-    }
-    else
-        DM_LAUNCH(ctx, "simnn_f16_mfma", simnn_kernel<false>, dim3(p.total), dim3(512), lds_main, p);
     // twice the error bound of a score, relative to |t_i| max_j |s_j|: fp32 accumulation (D exact products,
     // D (1 + 1/16) additions, unit roundoff 2^-23, safe for round-to-nearest and for truncating adders) + the caller's
-    // own term; 1 % slack for the fp32 norms
-    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + rel_extra);
+    // own term, plus 3 * 2^-19 for the 4 mantissa bits the reduction keys give up (simnn_tail); 1 % slack for the
+    // fp32 norms
+    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 1.5f * 1.9073486e-6f + rel_extra);
     DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb, p.pj, p.ps, p.tilesS, N2,
               p.N2pad, p.tnorm2, p.smax2, tau_scale, nn21, best, margin, flag_count, flag_list, flag_thr, force_flag);
     q->pb32 = p.pb32; q->nsub = p.nsub; q->N2pad = p.N2pad;

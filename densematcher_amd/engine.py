@@ -25,10 +25,10 @@ def _ptr(t):
 
 
 class MatchEngine:
-    def __init__(self, device=None):
+    def __init__(self, device=None, lib_path=None):
         if not torch.cuda.is_available():
             raise RuntimeError("MatchEngine needs a ROCm GPU (gfx950); there is no CPU fallback")
-        self.lib = _lib.load()
+        self.lib = _lib.load(lib_path)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
                                    (device if isinstance(device, int) else torch.device(device).index or 0))
         self.stream = torch.cuda.current_stream(self.device)
@@ -62,6 +62,27 @@ class MatchEngine:
 
     def synchronize(self):
         self.stream.synchronize()
+
+    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 1, "solve_packed": 0}
+
+    def set_option(self, name, value):
+        """Choose between equivalent code paths of the library (include/densematch.h: dm_set_option); every setting
+        returns the same, exact results."""
+        self._chk(self.lib.dm_set_option(self.ctx, name.encode(), int(value)))
+
+    def reset_options(self):
+        for k, v in self.OPTION_DEFAULTS.items():
+            self.set_option(k, v)
+
+    @staticmethod
+    def split_depth(k):
+        """fp16 contraction depth of the split features for a float64 depth k (dm_knnsplit.hip: 3 entries per index + 8
+        bias slots, padded to the 32-wide stage, at least 96)."""
+        return max(96, -(-(8 + 3 * k) // 32) * 32)
+
+    def p2p_split_active(self, N2, N1, k):
+        """True when fm_to_p2p takes the fp16-split first passes (bench.py names its dominant kernel accordingly)."""
+        return bool(self.lib.dm_fm_to_p2p_uses_split(self.ctx, int(N2), int(N1), int(k)))
 
     def workspace_bytes(self):
         return int(self.lib.dm_workspace_bytes(self.ctx))

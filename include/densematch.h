@@ -58,6 +58,15 @@ const char* dm_last_error(const dm_ctx* ctx);
 const char* dm_version(void);
 /* bytes of ctx-owned scratch currently allocated (grown lazily, never shrunk). */
 size_t dm_workspace_bytes(const dm_ctx* ctx);
+/* Choose between equivalent code paths (every value of every option returns the same, exact results; the
+ * defaults are the fast paths).  No reference counterpart: the reference has one CPU path.  Options:
+ *   "simnn_pipe"    1 | 0   feature-similarity tiles: LDS-DMA ring kernel | bounds-checked register-staged kernel
+ *   "simnn_persist" 1 | 0 | n>1   one persistent workgroup per CU walking its tiles | one workgroup per tile | exactly n workgroups
+ *   "knn_split"     1 | 0   knn21 of dm_zoomout / dm_icp / dm_knn_query_f64: fp16-split first pass | float64 G kernel
+ *   "p2p_split"     1 | 0   dm_fm_to_p2p: fp16-split first passes + exact fix-up | float64 G kernel
+ *   "solve_packed"  0 | 1   dm_fmap_solve: blocked LDS Cholesky when it fits | packed-storage solver always
+ * Unknown names return DM_EINVAL.  The library never reads environment variables. */
+int dm_set_option(dm_ctx* ctx, const char* name, int value);
 
 /* ---- kernel timing (HIP events on the ctx stream) ----------------------- */
 /* Bracket every launch of the kernel called `name` (see DESIGN.md for names)
@@ -126,12 +135,16 @@ int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const float* mass1, const double* C,
                  int32_t* knn21, int32_t* knn12, int32_t* ind21, int32_t* ind12);
 
+/* 1 when dm_fm_to_p2p would take the fp16-split passes for these sizes with the context's options, else 0 (the float64
+ * G kernel).  Informational (bench.py reports the dominant kernel of the step); no reference counterpart. */
+int dm_fm_to_p2p_uses_split(const dm_ctx* ctx, int N2, int N1, int k);
+
 /* ---- exact nearest neighbour, k = 1 -----------------------------------------
  * out[b,i] = argmin_j |X[b,j,:] - Y[b,i,:]|^2 (lowest j on ties); X (B,nx,p), Y (B,ny,p) fp64.
  * Replaces pyFM/spectral/nn_utils.py:4-38 (knn_query: sklearn kd-tree, k = 1).
  * Exact: a first pass on the fp16 matrix cores with a rigorous error bound, every row inside the bound
  * re-evaluated in float64 from the original operands (also the search inside dm_zoomout / dm_icp;
- * environment DM_KNN_SPLIT=0 selects the float64 matrix-core kernel for all of it instead). */
+ * dm_set_option("knn_split", 0) selects the float64 matrix-core kernel for all of it instead). */
 int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p,
                      const double* X, const double* Y, int32_t* out /* B*ny */);
 

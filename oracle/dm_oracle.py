@@ -302,3 +302,40 @@ def match_pair(phi1, phi2, lam1, lam2, a1, a2, F1, F2, w_descr=1e4, w_lap=1e3):
     C = fit(phi1, phi2, lam1, lam2, a1, a2, F1, F2, w_descr, w_lap)
     knn21, knn12, ind21, ind12 = fm_to_p2p_all(C, phi1, phi2, a1)
     return C, knn21, knn12, ind21, ind12
+
+
+def knn_query_kdtree(X, Y):
+    """knn_query exactly as the reference runs it: sklearn NearestNeighbors(kd_tree, leaf_size=40), k = 1
+    -- pyFM/spectral/nn_utils.py:28-30.  Falls back to the brute-force restatement when scikit-learn is absent."""
+    try:
+        from sklearn.neighbors import NearestNeighbors
+    except ImportError:
+        return knn_query(X, Y)
+    tree = NearestNeighbors(n_neighbors=1, leaf_size=40, algorithm="kd_tree", n_jobs=1)
+    tree.fit(np.asarray(X, dtype=np.float64))
+    return tree.kneighbors(np.asarray(Y, dtype=np.float64), return_distance=False).squeeze()
+
+
+def match_pair_reference_faithful(phi1, phi2, lam1, lam2, a1, a2, F1, F2, w_descr=1e4, w_lap=1e3, maxiter=100000):
+    """One pair with the reference's own algorithm choices (the timed "reference-faithful" CPU baseline of bench.py,
+    BASELINE.md section 3): projections (base_functions.py:526-532), ITERATIVE L-BFGS-B on the energy with SciPy's
+    default tolerances as in pyFM/functional.py:477 (float64 energy / analytic gradient instead of the fp32 torch
+    autograd), kd-tree nearest neighbours in both directions (convert.py:134-140), the dense N2 x N1 mapped indicator
+    (convert.py:144) and its two arg-maxes (functional_map.py:49-50)."""
+    k1, k2 = phi1.shape[1], phi2.shape[1]
+    A = project(phi1, a1, F1)
+    B = project(phi2, a2, F2)
+    ev = ev_sqdiff(lam1, lam2)
+    x0 = get_x0(k1, k2, float(phi1[0, 0]), float(phi2[0, 0]), float(np.asarray(a1, dtype=np.float64).sum()),
+                float(np.asarray(a2, dtype=np.float64).sum()), "zeros")
+    res = scipy.optimize.minimize(lambda x: energy(x.reshape(k2, k1), A, B, ev, w_descr, w_lap), x0.ravel(),
+                                  jac=lambda x: grad_energy(x.reshape(k2, k1), A, B, ev, w_descr, w_lap).ravel(),
+                                  method="L-BFGS-B", options={"maxiter": maxiter})
+    C = res.x.reshape(k2, k1)
+    e1 = np.asarray(phi1, dtype=np.float64)
+    e2 = np.asarray(phi2, dtype=np.float64)
+    knn12 = knn_query_kdtree(e2 @ C, e1)
+    knn21 = knn_query_kdtree(e1 @ C.T, e2)
+    ind = ((e2 @ C) @ e1.T) * np.asarray(a1, dtype=np.float64)[None, :]
+    ind21, ind12 = indicator_argmax(ind)
+    return C, knn21, knn12, ind21, ind12

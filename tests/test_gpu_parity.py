@@ -14,9 +14,16 @@ C_TOL = 1e-4          # BASELINE.json north_star: float C matrix within 1e-4
 
 
 @pytest.fixture(scope="module")
-def eng():
+def _engine():
     from densematcher_amd.engine import MatchEngine
     return MatchEngine()
+
+
+@pytest.fixture
+def eng(_engine):
+    """the module's engine; code-path options (dm_set_option) are back at their defaults after every test"""
+    yield _engine
+    _engine.reset_options()
 
 
 def _np(t):
@@ -200,12 +207,14 @@ def test_refine_ragged(eng, N1, N2, k0, nit, step):
 
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("B,N2,N1,D", [(1, 128, 128, 64), (2, 300, 517, 96), (3, 1000, 777, 384), (1, 2048, 2048, 768),
-                                       (2, 256, 512, 96), (2, 512, 256, 64), (1, 768, 512, 160), (1, 512, 512, 136)])
-@pytest.mark.parametrize("pipe", ["1", "0"])
-def test_simnn_random(eng, B, N2, N1, D, pipe, monkeypatch):
-    # interior shapes (N % 256 == 0) take the ring-buffered LDS-DMA kernel when D % 32 == 0 and D >= 96, the two-buffer
-    # LDS-DMA kernel when D % 64 == 0 (or DM_SIMNN_PIPE=0), everything else the bounds-checked register-staged kernel
-    monkeypatch.setenv("DM_SIMNN_PIPE", pipe)
+                                       (2, 256, 512, 96), (2, 512, 256, 64), (1, 768, 512, 160), (1, 512, 512, 136), (3, 512, 768, 128), (5, 256, 256, 96)])
+@pytest.mark.parametrize("pipe", ["persist", "pertile", "edge"])
+def test_simnn_random(eng, B, N2, N1, D, pipe):
+    # interior shapes (N % 256 == 0) take the ring-buffered LDS-DMA kernel when D % 32 == 0 and D >= 96 (one persistent
+    # workgroup per CU when there are more tiles than CUs, else -- or with simnn_persist = 0 -- one workgroup per tile);
+    # everything else, and everything with simnn_pipe = 0, the bounds-checked register-staged kernel
+    eng.set_option("simnn_pipe", 0 if pipe == "edge" else 1)
+    eng.set_option("simnn_persist", 8 if pipe == "persist" else 0)      # 8 workgroups walk all the tiles
     rng = np.random.default_rng(B * 1000 + N2)
     S = rng.standard_normal((B, N1, D)).astype(np.float16)
     T = rng.standard_normal((B, N2, D)).astype(np.float16)
@@ -288,10 +297,10 @@ def test_errors(eng):
 
 @pytest.mark.parametrize("k1,k2,D", [(2, 3, 16), (17, 17, 40), (50, 40, 96), (128, 128, 256), (177, 60, 200), (178, 20, 256), (200, 24, 256)])
 @pytest.mark.parametrize("packed", ["0", "1"])
-def test_solver_shapes(eng, k1, k2, D, packed, monkeypatch):
+def test_solver_shapes(eng, k1, k2, D, packed):
     """blocked-MFMA Cholesky (n <= 176) and the packed-storage rank-4 solver (n <= 199; forced for every shape by
-    DM_SOLVE_PACKED=1), square and rectangular maps"""
-    monkeypatch.setenv("DM_SOLVE_PACKED", packed)
+    dm_set_option "solve_packed"), square and rectangular maps"""
+    eng.set_option("solve_packed", int(packed))
     rng = np.random.default_rng(k1 * 7 + k2)
     Bn = 2
     A = rng.standard_normal((Bn, k1, D)).astype(np.float32) * 0.1
@@ -399,10 +408,10 @@ def test_fuzz_project_and_solve(eng):
 # --------------------------------------------------------------------------- #
 # nearest-neighbour search on the fp16-split first pass (dm_knnsplit.hip) -- the path of ZoomOut, ICP and knn_query
 @pytest.mark.parametrize("split", ["1", "0"])
-def test_knn_query_adversarial(eng, split, monkeypatch):
+def test_knn_query_adversarial(eng, split):
     """exact duplicates (lowest index wins), last-bit near ties, wildly different operand scales (bias overflow ->
     every row takes the exact path), an all-zero operand, an offset cloud (every margin inside the bound)"""
-    monkeypatch.setenv("DM_KNN_SPLIT", split)
+    eng.set_option("knn_split", int(split))
     rng = np.random.default_rng(11)
     nx, ny, p = 700, 300, 24
     X = rng.standard_normal((nx, p))
@@ -420,14 +429,14 @@ def test_knn_query_adversarial(eng, split, monkeypatch):
     assert not np.isin(_np(eng.knn_query(X[None], Y[None]))[0], np.arange(400, 420)).any()
 
 
-def test_zoomout_split_equals_f64_kernel(eng, monkeypatch):
+def test_zoomout_split_equals_f64_kernel(eng):
     """the two nearest-neighbour implementations give the same ZoomOut trajectory bit for bit (config-4 shape, reduced)"""
     from densematcher_amd import synth
     batch = synth.make_pair_batch(2, 64, 32, 8, 80, sigma=0.1, n_distinct_meshes=2, seed0=5, basis="random")
     C0 = np.eye(40)[None].repeat(2, axis=0)
     res = {}
     for split in ("1", "0"):
-        monkeypatch.setenv("DM_KNN_SPLIT", split)
+        eng.set_option("knn_split", int(split))
         C, p = eng.zoomout(batch["Phi1"], batch["Phi2"], batch["a2"], C0, nit=10, step=4, return_p2p=True)
         res[split] = (_np(C), _np(p))
     assert np.array_equal(res["1"][1], res["0"][1])
