@@ -134,6 +134,38 @@ struct OutAxpby {                      // Xnew = alpha Xold + beta (product)
         xn[o] = alpha * xo[o] + beta * v;
     }
 };
+// Newton-Schulz start for the inverse of a symmetric positive definite G (k2 > 176: the Gram matrix does not fit the
+// in-LDS Cholesky): X0 = G / |G|_1^2, every eigenvalue of X0 G in (0, 1]   (one workgroup per pair)
+__global__ __launch_bounds__(256) void ns_inverse_init_kernel(const double* __restrict__ G, int n, double* __restrict__ X) {
+    __shared__ double cs[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double* M = G + (long long)b * n * n;
+    double c = 0.0;
+    if (t < n) for (int i = 0; i < n; ++i) c += fabs(M[(long long)i * n + t]);
+    cs[t] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) cs[t] = fmax(cs[t], cs[t + off]);
+        __syncthreads();
+    }
+    const double inv = cs[0] > 0.0 ? 1.0 / (cs[0] * cs[0]) : 0.0;
+    for (int e = t; e < n * n; e += 256) X[(long long)b * n * n + e] = M[e] * inv;
+}
+// info[b] = n + 1 when the Newton-Schulz inverse did not converge (max |G X - I| > 1e-9)
+__global__ __launch_bounds__(256) void ns_inverse_check_kernel(const double* __restrict__ Tm, int n, int32_t* __restrict__ info) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double m = 0.0;
+    for (int e = t; e < n * n; e += 256) m = fmax(m, fabs(Tm[(long long)b * n * n + e] - ((e / n == e % n) ? 1.0 : 0.0)));
+    sh[t] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) sh[t] = fmax(sh[t], sh[t + off]);
+        __syncthreads();
+    }
+    if (t == 0 && !(sh[0] <= 1e-9)) info[b] = n + 1;
+}
+
 // resid[b] = max |T - I| (one workgroup per pair)
 __global__ __launch_bounds__(256) void ortho_resid_kernel(const double* __restrict__ Tm, int k, double* __restrict__ resid) {
     __shared__ double sh[256];
@@ -149,22 +181,115 @@ __global__ __launch_bounds__(256) void ortho_resid_kernel(const double* __restri
     if (t == 0) resid[b] = sh[0];
 }
 
+// Ginv = G^-1 for B symmetric positive definite k x k matrices (G = Phi2^T Phi2, well conditioned: the basis is
+// mass-orthonormal).  k <= 176: k unit right-hand sides on the blocked LDS Cholesky (img = scratch for its blocked image);
+// 177 <= k <= 256: Newton-Schulz  X <- 2 X - (X G) X  on the float64 matrix cores (Gx, Gt = two k x k scratch matrices per
+// pair; every iterate is a polynomial in G, hence symmetric and commuting with G); the error 1 - lambda(X G) squares per
+// step from 1 - 1/cond^2 at the start: 2 log2(cond) + 6 steps, 36 cover cond up to 3e4; a pair that did not converge is
+// reported in info (k + 1), a Gram matrix that is not positive definite as column + 1.
+static size_t gram_inverse_ws_bytes(int B, int k) {
+    const int NB = (k + 15) / 16;
+    return NB <= 11 ? dm_align_up((size_t)B * (NB * (NB + 1) / 2) * 256 * 8) : 2 * dm_align_up((size_t)B * k * k * 8);
+}
+static int gram_inverse(dm_ctx* ctx, int B, int k2, const double* G, double* Ginv, double* img, double* Gx, double* Gt, int32_t* info) {
+    const int NB = (k2 + 15) / 16, nblk = NB * (NB + 1) / 2;
+    const bool chol = NB <= 11;
+    if (chol) {
+        DM_LAUNCH(ctx, "blockify", blockify_kernel, dim3(nblk, B), dim3(256), 0, G, k2, NB, img);
+        const size_t lds = ((size_t)(nblk + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);
+        int rc = dm_grant_lds(ctx, (const void*)spd_multi_rhs_kernel, lds);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "icp_normal_eq_chol", spd_multi_rhs_kernel, dim3(k2, B), dim3(256), lds, img, (const double*)nullptr, k2, k2, NB,
+                  Ginv, info);
+        return DM_OK;
+    }
+    constexpr int NS_INV = 36;
+    DM_LAUNCH(ctx, "ns_inverse_init", ns_inverse_init_kernel, dim3(B), dim3(256), 0, G, k2, Ginv);
+    double* xo = Ginv;
+    double* xn = Gx;
+    const dim3 grid(dm_cdiv(k2, NT_T) * dm_cdiv(k2, NT_T), 1, B);
+    // (the second operand is read transposed: O = A B^T in the kernel, and writing X G as X G^T / T X as T X^T would double
+    //  the antisymmetric rounding error of X at every step once the iteration has converged)
+    for (int q = 0; q < NS_INV; ++q) {
+        KRowsF64 x_{xo, (long long)k2 * k2, k2, k2, k2, 0};
+        KRowsF64 gT{G, (long long)k2 * k2, k2, k2, k2, 1};
+        OutPlainNT ot{Gt, (long long)k2 * k2, k2};
+        DM_LAUNCH(ctx, "ns_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutPlainNT>), grid, dim3(256), 0, x_, gT, ot, k2, k2, k2);
+        KRowsF64 t_{Gt, (long long)k2 * k2, k2, k2, k2, 0};
+        KRowsF64 xT{xo, (long long)k2 * k2, k2, k2, k2, 1};
+        OutAxpby on{xo, xn, (long long)k2 * k2, k2, 2.0, -1.0};
+        DM_LAUNCH(ctx, "ns_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutAxpby>), grid, dim3(256), 0, t_, xT, on, k2, k2, k2);
+        double* tmp = xo; xo = xn; xn = tmp;
+    }
+    // (NS_INV is even: the result is back in Ginv)
+    KRowsF64 x_{Ginv, (long long)k2 * k2, k2, k2, k2, 0};
+    KRowsF64 gT{G, (long long)k2 * k2, k2, k2, k2, 1};
+    OutPlainNT ot{Gt, (long long)k2 * k2, k2};
+    DM_LAUNCH(ctx, "ns_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutPlainNT>), grid, dim3(256), 0, x_, gT, ot, k2, k2, k2);
+    DM_LAUNCH(ctx, "ns_inverse_check", ns_inverse_check_kernel, dim3(B), dim3(256), 0, Gt, k2, info);
+    return DM_OK;
+}
+
+// ---- least-squares vertex map -> functional map ------------------------------------------------------------------
+// C = argmin |Phi2[:, :k2] X - Phi1[p21, :k1]|_F  (no mass): normal equations (Phi2^T Phi2) C = Phi2^T Phi1[p21].
+extern "C" int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const float* Phi1,
+                                  int ld1, const float* Phi2, int ld2, double* C, int32_t* info) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, p21 && Phi1 && Phi2 && C && info, "null pointer");
+    DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
+    DM_REQUIRE(ctx, k2 <= 256, "the least-squares map needs k2 <= 256");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bG = (size_t)B * k2 * k2 * 8, bC = (size_t)B * k2 * k1 * 8;
+    const int NB = (k2 + 15) / 16;
+    const size_t need = 2 * dm_align_up(bG) + dm_align_up(bC) + gram_inverse_ws_bytes(B, k2) + 2 * dm_align_up((size_t)B * N2 * 4) +
+                        dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
+    int rc = dm_ws_reserve(ctx, need);
+    if (rc) return rc;
+    double* G = (double*)dm_ws_take(ctx, bG);
+    double* Ginv = (double*)dm_ws_take(ctx, bG);
+    double* R = (double*)dm_ws_take(ctx, bC);
+    double* img = nullptr; double* Gx = nullptr; double* Gt = nullptr;
+    if (NB <= 11) img = (double*)dm_ws_take(ctx, (size_t)B * (NB * (NB + 1) / 2) * 256 * 8);
+    else { Gx = (double*)dm_ws_take(ctx, bG); Gt = (double*)dm_ws_take(ctx, bG); }
+    int32_t* iota = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    float* ones = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    if (!G || !Ginv || !R || (NB <= 11 ? !img : (!Gx || !Gt)) || !iota || !ones) return dm_fail(ctx, DM_ENOMEM, "p2p_to_fm_lstsq: workspace not reserved");
+    DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
+    DM_LAUNCH(ctx, "iota_ones", iota_ones_kernel, dim3((unsigned)(((long long)B * N2 + 255) / 256)), dim3(256), 0, iota, ones, N2, B);
+    const size_t ws_mark = ctx->ws_off;
+    rc = dm_launch_p2p_to_fm(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
+    if (rc) return rc;
+    rc = gram_inverse(ctx, B, k2, G, Ginv, img, Gx, Gt, info);
+    if (rc) return rc;
+    ctx->ws_off = ws_mark;
+    rc = dm_launch_p2p_to_fm(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);
+    if (rc) return rc;
+    KRowsF64 ga{Ginv, (long long)k2 * k2, k2, k2, k2, 0};
+    KRowsF64 rb{R, (long long)k2 * k1, k1, k1, k2, 1};
+    OutPlainNT oc{C, (long long)k2 * k1, k1};
+    DM_LAUNCH(ctx, "icp_apply_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutPlainNT>),
+              dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ga, rb, oc, k2, k1, k2);
+    return DM_OK;
+}
+
 extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1, const float* Phi2,
                       int ld2, const double* C0, int nit, double* Cout, double* resid, int32_t* info) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0 && nit >= 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi1 && Phi2 && C0 && Cout && info, "null pointer");
     DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
-    DM_REQUIRE(ctx, k2 <= 176 && k1 <= 256 && k2 <= 256, "ICP on the GPU needs k2 <= 176 (in-LDS Cholesky of Phi2^T Phi2)");
+    DM_REQUIRE(ctx, k1 <= 256 && k2 <= 256, "ICP on the GPU needs k1, k2 <= 256");
     DM_REQUIRE(ctx, k2 >= k1, "the polar factor U eye(k2,k1) V^T needs k2 >= k1");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
 
     const int N1pad = pad_to(N1, 128), N2pad = pad_to(N2, 128), Kpad = pad_to(k2, 16);
     const int NB = (k2 + 15) / 16, nblk = NB * (NB + 1) / 2;
+    const bool chol = NB <= 11;                 // the blocked LDS Cholesky holds the Gram matrix up to k2 = 176 (gram_inverse)
     const size_t bAT = (size_t)B * Kpad * N2pad * 8, bBT = (size_t)B * Kpad * N1pad * 8;
     const size_t bC = (size_t)B * k2 * k1 * 8, bG = (size_t)B * k2 * k2 * 8, bImg = (size_t)B * nblk * 256 * 8;
     const size_t bT = (size_t)B * k1 * k1 * 8;
-    const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + 2 * dm_align_up(bG) + dm_align_up(bImg) +
+    const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + 4 * dm_align_up(bG) + dm_align_up(bImg) +
                         2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 3 * dm_align_up((size_t)B * N2 * 4) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, k2) + dm_knn_split_ws_bytes(B, N2, N1, k2) +
                         dm_align_up((size_t)B * (N1pad / 256 + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
@@ -186,6 +311,11 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     int32_t* iota = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* ones = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / 256 + 1) * 8);
+    double* Gx = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
+    double* Gt = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
+    if (!AT || !BT || !Ccur || !R || !Xa || !Xb || !G || !Ginv || !img || !Tm || !Wm || !n1 || !p21 || !iota || !ones || !amaxS ||
+        (!chol && (!Gx || !Gt)))
+        return dm_fail(ctx, DM_ENOMEM, "icp: workspace not reserved");
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemcpyAsync(Ccur, C0, bC, hipMemcpyDeviceToDevice, ctx->stream));
@@ -199,16 +329,10 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     const size_t ws_mark = ctx->ws_off;
     rc = dm_launch_p2p_to_fm(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
     if (rc) return rc;
-    DM_LAUNCH(ctx, "blockify", blockify_kernel, dim3(nblk, B), dim3(256), 0, G, k2, NB, img);
     DM_CHECK_HIP(ctx, hipMemsetAsync(BT, 0, bBT, ctx->stream));
-
-    const size_t lds = ((size_t)(nblk + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);
-    rc = dm_grant_lds(ctx, (const void*)spd_multi_rhs_kernel, lds);
+    // the Gram matrix does not change over the iterations: invert it once and apply the inverse by a GEMM per iteration
+    rc = gram_inverse(ctx, B, k2, G, Ginv, img, Gx, Gt, info);
     if (rc) return rc;
-    // the Gram matrix does not change over the iterations: invert it once (k2 unit right-hand sides on the blocked LDS
-    // Cholesky; Phi2^T Phi2 is well conditioned, the basis is mass-orthonormal) and apply the inverse by a GEMM per iteration
-    DM_LAUNCH(ctx, "icp_normal_eq_chol", spd_multi_rhs_kernel, dim3(k2, B), dim3(256), lds, img, (const double*)nullptr, k2, k2, NB,
-              Ginv, info);
 
     for (int it = 0; it < nit; ++it) {
         ctx->ws_off = ws_mark;

@@ -198,6 +198,24 @@ class MatchEngine:
         self._chk(self.lib.dm_p2p_to_fm(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2), _ptr(Cm)))
         return Cm
 
+    def p2p_to_fm_lstsq(self, p21, Phi1, Phi2, k1, k2):
+        """argmin_X |Phi2[:, :k2] X - Phi1[p21, :k1]|_F (reference convert.py:51, no mass matrix) -> (B,k2,k1) f64."""
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        p21 = self._dev(p21, torch.int32, "p21")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        if p21.shape != (B, N2):
+            raise ValueError("p2p_to_fm_lstsq: p21 must be (B,N2)")
+        Cm = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        info = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_p2p_to_fm_lstsq(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(Cm),
+                                              _ptr(info)))
+        bad = torch.nonzero(info).flatten()
+        if bad.numel():
+            raise _lib.DenseMatchError(f"least-squares map: Phi2^T Phi2 is not positive definite for pairs {bad.tolist()[:8]}")
+        return Cm
+
     def zoomout(self, Phi1, Phi2, a2, C0, nit, step=1, return_p2p=False):
         Phi1 = self._dev(Phi1, torch.float32, "Phi1")
         Phi2 = self._dev(Phi2, torch.float32, "Phi2")

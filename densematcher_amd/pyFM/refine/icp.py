@@ -25,11 +25,17 @@ def icp_iteration(FM_12, evects1, evects2, A1=None, use_adj=False, n_jobs=1):
 
 
 def icp_refine(FM_12, evects1, evects2, A1=None, nit=10, tol=1e-10, use_adj=False, return_p2p=False, n_jobs=1, verbose=False):
-    """reference icp.py:43-107 (fixed iteration count; the tolerance-driven variant needs a host decision per
-    iteration and is not on the GPU path)"""
-    if nit is None or nit <= 0:
-        raise NotImplementedError("tolerance-driven ICP (nit=None) is not on the GPU path; pass nit")
-    FM_icp = _run(FM_12, evects1, evects2, nit)
+    """reference icp.py:43-107.  A fixed iteration count runs as one GPU call; with nit = None / 0 the reference iterates
+    until max |C_new - C| <= tol (at most 10000 times, :84-96): one GPU iteration per host decision, as there."""
+    if nit is not None and nit > 0:
+        FM_icp = _run(FM_12, evects1, evects2, nit)
+    else:
+        FM_curr = np.array(FM_12, dtype=np.float64)
+        for _ in range(10000):
+            FM_icp = _run(FM_curr, evects1, evects2, 1)
+            if np.max(np.abs(FM_curr - FM_icp)) <= tol:
+                break
+            FM_curr = FM_icp
     if return_p2p:
         from .. import spectral
         p2p_21 = spectral.FM_to_p2p(FM_icp, evects1, evects2, A1)[0]

@@ -16,33 +16,57 @@ def _steps(step):
     return step1, step2
 
 
+def _knn21(eng, FM, evects1, evects2):
+    """p2p_21 of upstream-pyFM FM_to_p2p: NN(tree = Phi1[:, :k1] C^T, query = Phi2[:, :k2])"""
+    k2, k1 = FM.shape
+    out = eng.fm_to_p2p(np.ascontiguousarray(evects1[:, :k1], dtype=np.float32)[None],
+                        np.ascontiguousarray(evects2[:, :k2], dtype=np.float32)[None], None, np.ascontiguousarray(FM)[None], knn=True, ind=False)
+    return out["knn21"]
+
+
 def _run(FM_12, evects1, evects2, nit, step, A2, return_p2p):
+    """A2 given, square map, one step size: the fused GPU loop (dm_zoomout, no host synchronisation).  Rectangular maps,
+    two step sizes, or A2 = None (least-squares p2p_to_FM, what the reference does on subsampled vertices): the same two
+    GPU kernels per iteration, chained from the host like the reference chains its two calls (zoomout.py:40-42)."""
     from ...engine import default_engine
     from ..spectral.convert import _diag_of
     step1, step2 = _steps(step)
     k2_0, k1_0 = FM_12.shape
-    if step1 != step2 or k1_0 != k2_0:
-        raise NotImplementedError("the GPU ZoomOut handles square maps with one step size")
     eng = default_engine()
-    a2 = _diag_of(A2, evects2.shape[0])
-    kf = k1_0 + nit * step1
-    res = eng.zoomout(np.ascontiguousarray(evects1[:, :kf], dtype=np.float32)[None],
-                      np.ascontiguousarray(evects2[:, :kf], dtype=np.float32)[None], a2[None],
-                      np.ascontiguousarray(FM_12, dtype=np.float64)[None], nit, step1, return_p2p=return_p2p)
+    FM_12 = np.ascontiguousarray(FM_12, dtype=np.float64)
+    if A2 is not None and step1 == step2 and k1_0 == k2_0:
+        a2 = _diag_of(A2, evects2.shape[0])
+        kf = k1_0 + nit * step1
+        res = eng.zoomout(np.ascontiguousarray(evects1[:, :kf], dtype=np.float32)[None],
+                          np.ascontiguousarray(evects2[:, :kf], dtype=np.float32)[None], a2[None], FM_12[None], nit, step1,
+                          return_p2p=return_p2p)
+        if return_p2p:
+            return res[0][0].cpu().numpy(), res[1][0].cpu().numpy().astype(np.int64)
+        return res[0].cpu().numpy()
+    a2 = None if A2 is None else _diag_of(A2, evects2.shape[0])
+    FM = FM_12
+    for _ in range(nit):
+        k2, k1 = FM.shape
+        p21 = _knn21(eng, FM, evects1, evects2)
+        E1 = np.ascontiguousarray(evects1[:, :k1 + step1], dtype=np.float32)[None]
+        E2 = np.ascontiguousarray(evects2[:, :k2 + step2], dtype=np.float32)[None]
+        if a2 is None:
+            FM = eng.p2p_to_fm_lstsq(p21, E1, E2, k1 + step1, k2 + step2)[0].cpu().numpy()
+        else:
+            FM = eng.p2p_to_fm(p21, E1, E2, a2[None], k1 + step1, k2 + step2)[0].cpu().numpy()
     if return_p2p:
-        return res[0][0].cpu().numpy(), res[1][0].cpu().numpy().astype(np.int64)
-    return res[0].cpu().numpy()
+        return FM, _knn21(eng, FM, evects1, evects2)[0].cpu().numpy().astype(np.int64)
+    return FM
 
 
 def zoomout_iteration(FM_12, evects1, evects2, step=1, A2=None, n_jobs=1):
     """reference zoomout.py:7-44"""
-    if A2 is None:
-        raise NotImplementedError("ZoomOut on subsampled eigenvectors (least-squares p2p_to_FM) is not on the GPU path")
     return _run(np.asarray(FM_12), evects1, evects2, 1, step, A2, False)
 
 
 def zoomout_refine(FM_12, evects1, evects2, nit=10, step=1, A2=None, subsample=None, return_p2p=False, n_jobs=1, verbose=False):
-    """reference zoomout.py:47-115"""
+    """reference zoomout.py:47-115.  subsample = (sub1, sub2): the iterations run on those vertices with the least-squares
+    p2p_to_FM (:100-102), the final vertex map on all vertices (:111-113)."""
     FM_12 = np.asarray(FM_12)
     k2_0, k1_0 = FM_12.shape
     step1, step2 = _steps(step)
@@ -50,16 +74,22 @@ def zoomout_refine(FM_12, evects1, evects2, nit=10, step=1, A2=None, subsample=N
         f"Not enough eigenvectors on source : {k1_0 + nit * step1} are needed when {evects1.shape[1]} are provided"
     assert k2_0 + nit * step2 <= evects2.shape[1], \
         f"Not enough eigenvectors on target : {k2_0 + nit * step2} are needed when {evects2.shape[1]} are provided"
-    if subsample is not None or A2 is None:
-        raise NotImplementedError("ZoomOut on subsampled eigenvectors (least-squares p2p_to_FM) is not on the GPU path")
+    if subsample is not None:
+        sub1, sub2 = subsample
+        FM = _run(FM_12, np.asarray(evects1)[sub1], np.asarray(evects2)[sub2], nit, step, None, False)
+        if return_p2p:
+            from ...engine import default_engine
+            return FM, _knn21(default_engine(), FM, evects1, evects2)[0].cpu().numpy().astype(np.int64)
+        return FM
     return _run(FM_12, evects1, evects2, nit, step, A2, return_p2p)
 
 
 def mesh_zoomout_refine(FM_12, mesh1, mesh2, nit=10, step=1, subsample=None, return_p2p=False, n_jobs=1, verbose=False):
     """reference zoomout.py:118-161"""
-    if subsample is not None:
-        raise NotImplementedError("farthest-point subsampling is outside the matching path")
-    return zoomout_refine(FM_12, mesh1.eigenvectors, mesh2.eigenvectors, nit, step=step, A2=mesh2.A, subsample=None,
+    if np.issubdtype(type(subsample), np.integer):
+        raise NotImplementedError("farthest-point sampling (mesh.extract_fps) is outside the matching path: pass the two "
+                                  "index arrays as subsample=(sub1, sub2)")
+    return zoomout_refine(FM_12, mesh1.eigenvectors, mesh2.eigenvectors, nit, step=step, A2=mesh2.A, subsample=subsample,
                           return_p2p=return_p2p, n_jobs=n_jobs, verbose=verbose)
 
 

@@ -88,18 +88,26 @@ def mesh_FM_to_p2p(FM_12, mesh1, mesh2, use_adj=False, subsample=None, n_jobs=1)
 
 
 def p2p_to_FM(p2p_21, evects1, evects2, A2=None):
-    """reference convert.py:14-51.  With A2: Phi2^T (A2 Phi1[p2p_21]) on the GPU.  Without A2 the reference solves a
-    least-squares problem (ICP, SURVEY.md 'next #1'): normal equations on the GPU (dm_icp)."""
+    """reference convert.py:14-51.  With A2: Phi2^T (A2 Phi1[p2p_21]) (dm_p2p_to_fm).  Without A2 the reference solves the
+    least-squares problem lstsq(Phi2, Phi1[p2p_21]) (:51): normal equations on the GPU (dm_p2p_to_fm_lstsq).
+    p2p_21 may also be a sparse (n2, n1) map P (:39): the pulled-back basis P Phi1 is then formed on the host (a sparse
+    product, as in the reference) and enters the same kernels with the identity as index map."""
     from ...engine import default_engine
-    if np.asarray(p2p_21).ndim != 1:
-        raise NotImplementedError("sparse (n2,n1) maps are outside the matching path: pass the (n2,) index map")
     eng = default_engine()
+    evects1 = np.asarray(evects1)
+    evects2 = np.asarray(evects2)
+    k1, k2 = evects1.shape[1], evects2.shape[1]
+    if sparse.issparse(p2p_21) or np.asarray(p2p_21).ndim != 1:
+        pulled = np.asarray(p2p_21 @ evects1)                               # (n2, k1)
+        idx = np.arange(pulled.shape[0], dtype=np.int32)
+    else:
+        pulled, idx = evects1, np.ascontiguousarray(p2p_21, dtype=np.int32)
+    P1 = np.ascontiguousarray(pulled, dtype=np.float32)[None]
+    P2 = np.ascontiguousarray(evects2, dtype=np.float32)[None]
     if A2 is None:
-        raise NotImplementedError("least-squares p2p_to_FM (no A2) belongs to ICP, not yet on the GPU path")
+        return eng.p2p_to_fm_lstsq(idx[None], P1, P2, k1, k2)[0].cpu().numpy()
     a2 = _diag_of(A2, evects2.shape[0])
-    C = eng.p2p_to_fm(np.ascontiguousarray(p2p_21, dtype=np.int32)[None], np.ascontiguousarray(evects1, dtype=np.float32)[None],
-                      np.ascontiguousarray(evects2, dtype=np.float32)[None], a2[None], evects1.shape[1], evects2.shape[1])
-    return C[0].cpu().numpy()
+    return eng.p2p_to_fm(idx[None], P1, P2, a2[None], k1, k2)[0].cpu().numpy()
 
 
 def mesh_p2p_to_FM(p2p_21, mesh1, mesh2, dims=None, subsample=None):

@@ -28,7 +28,9 @@ def shard_batch(batch, rank, world):
 
 def gather_results(local, n_items, rank=None, world=None, dst=0, group=None):
     """Gather per-rank result dicts (each value (b_local, ...)) to `dst` in pair order.  Returns the full dict on
-    `dst`, None elsewhere.  Blocks may have different sizes, so the gather is padded to the largest block."""
+    `dst`, None elsewhere.  Blocks may have different sizes (or be empty: fewer pairs than ranks), so every rank first
+    learns the key / dtype / trailing-shape list from the lowest rank that has results, then takes part in one padded
+    gather per key -- the same collectives on every rank, whatever its block holds."""
     import torch.distributed as dist
     if rank is None:
         rank = dist.get_rank(group)
@@ -36,12 +38,24 @@ def gather_results(local, n_items, rank=None, world=None, dst=0, group=None):
         world = dist.get_world_size(group)
     sizes = [block_range(n_items, r, world) for r in range(world)]
     maxb = max(hi - lo for lo, hi in sizes)
+    local = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))) for k, v in (local or {}).items()
+             if v is not None}
+    # schema = [(key, dtype name, trailing shape)], published by the first rank with a non-empty block
+    owner = next((r for r, (lo, hi) in enumerate(sizes) if hi > lo), 0)
+    schema = [[(k, str(local[k].dtype).replace("torch.", ""), tuple(local[k].shape[1:])) for k in sorted(local)]] \
+        if rank == owner else [None]
+    dist.broadcast_object_list(schema, src=owner, group=group)
+    dev = next(iter(local.values())).device if local else torch.device("cpu")
+    backend = dist.get_backend(group)
+    if backend == "nccl" and dev.type != "cuda":
+        dev = torch.device("cuda", torch.cuda.current_device())
     out = {} if rank == dst else None
-    for key in sorted(local):
-        t = local[key]
-        t = t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t))
-        pad = torch.zeros((maxb,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[: t.shape[0]] = t
+    for key, dtname, trail in schema[0]:
+        dtype = getattr(torch, dtname)
+        t = local.get(key)
+        pad = torch.zeros((maxb,) + tuple(trail), dtype=dtype, device=dev)
+        if t is not None and t.shape[0]:
+            pad[: t.shape[0]] = t.to(dev)
         bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
         dist.gather(pad, bufs, dst=dst, group=group)
         if rank == dst:
@@ -53,9 +67,11 @@ def match_sharded(batch_host, engine_factory, rank, world, gather=True, **match_
     """Run the hot path on this rank's block of `batch_host` (dict of host arrays with leading pair axis).
     `engine_factory()` returns a MatchEngine for this rank's GPU.  With gather=True rank 0 receives every map."""
     local, (lo, hi) = shard_batch(batch_host, rank, world)
-    eng = engine_factory()
-    dev = {k: torch.as_tensor(v).to(eng.device) for k, v in local.items()}
-    res = eng.match(dev, **match_kwargs) if hi > lo else {}
+    res = {}
+    if hi > lo:
+        eng = engine_factory()
+        dev = {k: torch.as_tensor(v).to(eng.device) for k, v in local.items()}
+        res = eng.match(dev, **match_kwargs)
     if not gather or world == 1:
         return res
     B = next(iter(batch_host.values())).shape[0]

@@ -163,6 +163,16 @@ int dm_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const int32_t* p21, const float* Phi1, int ld1, const float* Phi2, int ld2,
                  const float* mass2, double* C);
 
+/* ---- vertex map -> functional map, least squares -------------------------------
+ * C[b] = argmin_X |Phi2[b][:, :k2] X - Phi1[b][p21[b], :k1]|_F   (k2 x k1) fp64, no mass matrix.
+ * Replaces pyFM/spectral/convert.py:51 (p2p_to_FM with A2 = None: scipy.linalg.lstsq), the form ICP and ZoomOut on
+ * subsampled vertices use.  Normal equations (Phi2^T Phi2) C = Phi2^T Phi1[p21]; info (B): 0 ok, else the Gram
+ * matrix was not positive definite / its inverse did not converge.  k2 <= 256.  Phi1 rows may be any (N1 x ld1)
+ * matrix (a pulled-back basis P Phi1 with p21 = identity gives the sparse-map form of convert.py:39). */
+int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                       const int32_t* p21, const float* Phi1, int ld1, const float* Phi2, int ld2,
+                       double* C, int32_t* info);
+
 /* ---- ZoomOut ----------------------------------------------------------------
  * nit times: p21 = knn21(C_k); C_{k+step} = p2p_to_fm(p21) with k+step columns.
  * Replaces pyFM/refine/zoomout.py:7-44,47-115 (with upstream FM_to_p2p
@@ -177,7 +187,8 @@ int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step,
  * C = U eye(k2,k1) V^T with U S V^T = svd(Chat), i.e. the orthogonal polar factor of Chat.
  * Replaces pyFM/refine/icp.py:10-40,43-107 (fixed nit; functional.py:564 uses nit = 10).
  * C0, Cout (B,k2,k1) fp64; resid (B) fp64 optional = max |Cout^T Cout - I| (convergence of the
- * polar iteration); info (B): 0 ok, c+1 = normal equations not SPD.  k1 <= k2 <= 176. */
+ * polar iteration); info (B): 0 ok, c+1 = normal equations not SPD.  k1 <= k2 <= 256 (k2 <= 176: in-LDS Cholesky of
+ * Phi2^T Phi2; above: Newton-Schulz inverse on the float64 matrix cores). */
 int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
            const float* Phi1, int ld1, const float* Phi2, int ld2,
            const double* C0, int nit, double* Cout, double* resid /*nullable*/, int32_t* info);

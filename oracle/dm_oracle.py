@@ -234,7 +234,7 @@ def p2p_to_fm(p2p_21, phi1, phi2, a2=None):
 # --------------------------------------------------------------------------- #
 # refinement
 # --------------------------------------------------------------------------- #
-def zoomout_refine(C, phi1, phi2, nit, step=1, a2=None, return_p2p=False, trajectory=None):
+def zoomout_refine(C, phi1, phi2, nit, step=1, a2=None, return_p2p=False, trajectory=None, subsample=None):
     """ZoomOut -- pyFM/refine/zoomout.py:7-44 (iteration), :47-115 (loop),
     with upstream-pyFM FM_to_p2p semantics (the fork's call at :40/:112 is
     broken): p2p_21 = NN(tree = Phi1[:, :k1] C^T,
@@ -251,10 +251,13 @@ def zoomout_refine(C, phi1, phi2, nit, step=1, a2=None, return_p2p=False, trajec
     e1 = np.asarray(phi1, dtype=np.float64)
     e2 = np.asarray(phi2, dtype=np.float64)
     C = np.array(C, dtype=np.float64)
+    s1, s2, a2_it = e1, e2, a2
+    if subsample is not None:                                    # zoomout.py:94-102: subsampled vertices, least squares
+        s1, s2, a2_it = e1[subsample[0]], e2[subsample[1]], None
     for _ in range(nit):
         k2, k1 = C.shape
-        p21 = knn_query(e1[:, :k1] @ C.T, e2[:, :k2])           # zoomout.py:40
-        C = p2p_to_fm(p21, e1[:, :k1 + step1], e2[:, :k2 + step2], a2)   # zoomout.py:42
+        p21 = knn_query(s1[:, :k1] @ C.T, s2[:, :k2])           # zoomout.py:40
+        C = p2p_to_fm(p21, s1[:, :k1 + step1], s2[:, :k2 + step2], a2_it)   # zoomout.py:42
         if trajectory is not None:
             trajectory.append((p21, C))
     if return_p2p:
@@ -339,3 +342,128 @@ def match_pair_reference_faithful(phi1, phi2, lam1, lam2, a1, a2, F1, F2, w_desc
     ind = ((e2 @ C) @ e1.T) * np.asarray(a1, dtype=np.float64)[None, :]
     ind21, ind12 = indicator_argmax(ind)
     return C, knn21, knn12, ind21, ind12
+
+
+# --------------------------------------------------------------------------- #
+# the other energy terms of FunctionalMapping.fit
+# --------------------------------------------------------------------------- #
+M_TERMS = ("w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1")
+
+
+def mapped_indicator(C, phi1, phi2, a1):
+    """evects2 @ C @ evects1.T @ A1 (N2 x N1) -- base_functions.py:315, 348, 364, 375, 408 (first line of each term)."""
+    return (np.asarray(phi2, np.float64) @ C) @ (np.asarray(phi1, np.float64) * np.asarray(a1, np.float64)[:, None]).T
+
+
+def m_terms_energy_grad(C, phi1, phi2, a1, w_p2p=0.0, w_stochastic=0.0, w_ent=0.0, w_range01=0.0, w_sumto1=0.0):
+    """Sum of the weighted energy terms that are functions of the mapped indicator M = Phi2 C Phi1^T A1, and its
+    gradient with respect to C (what torch autograd returns in the reference: dE/dC = Phi2^T (dE/dM) (A1 Phi1)):
+        p2p               sum (M^2 - M)^2                                        base_functions.py:296-322
+        doubly_stochastic sum_j (sum_i M_ij^2 - n2/n1)^2 + sum_i (sum_j M_ij^2 - 1)^2     :324-361
+        entropy           sum -c log(c + 1e-10), c = clamp(M, 0, 1)              :363-372
+        range01           sum relu(-M)^2 + relu(M - 1)^2                         :374-385
+        sumto1 (v = None) sum_j (cs_j - mean cs)^2 + sum_i (rs_i - mean rs)^2, cs / rs = column / row sums   :387-428
+    Returns (energy, grad (k2,k1))."""
+    phi1 = np.asarray(phi1, np.float64)
+    phi2 = np.asarray(phi2, np.float64)
+    a1 = np.asarray(a1, np.float64)
+    M = mapped_indicator(C, phi1, phi2, a1)
+    n2, n1 = M.shape
+    E = 0.0
+    D = np.zeros_like(M)
+    if w_p2p > 0:
+        q = M * M - M
+        E += w_p2p * np.square(q).sum()
+        D += w_p2p * 2.0 * q * (2.0 * M - 1.0)
+    if w_stochastic > 0:
+        Msq = M * M
+        dc = Msq.sum(axis=0) - n2 / n1
+        dr = Msq.sum(axis=1) - 1.0
+        E += w_stochastic * (np.square(dc).sum() + np.square(dr).sum())
+        D += w_stochastic * (2.0 * dc[None, :] + 2.0 * dr[:, None]) * 2.0 * M
+    if w_ent > 0:
+        c = np.clip(M, 0.0, 1.0)
+        E += w_ent * np.sum(-c * np.log(c + 1e-10))
+        inside = (M >= 0.0) & (M <= 1.0)                 # torch.clamp passes the gradient on the closed interval
+        D += w_ent * np.where(inside, -np.log(c + 1e-10) - c / (c + 1e-10), 0.0)
+    if w_range01 > 0:
+        lo = np.maximum(-M, 0.0)
+        hi = np.maximum(M - 1.0, 0.0)
+        E += w_range01 * (np.square(lo).sum() + np.square(hi).sum())
+        D += w_range01 * (-2.0 * lo + 2.0 * hi)
+    if w_sumto1 > 0:
+        cs, rs = M.sum(axis=0), M.sum(axis=1)
+        dc, dr = cs - cs.mean(), rs - rs.mean()
+        E += w_sumto1 * (np.square(dc).sum() + np.square(dr).sum())
+        D += w_sumto1 * (2.0 * dc[None, :] + 2.0 * dr[:, None])      # (the deviations sum to zero: the mean's derivative drops out)
+    G = phi2.T @ (D @ (phi1 * a1[:, None]))
+    return float(E), G
+
+
+def descr_ops(phi, mass, F):
+    """Multiplication operators of the descriptors in the reduced basis, (D, k, k): Phi^T A diag(f_i) Phi
+    -- base_functions.py:550-555 (commute_left / commute_right; pinv = Phi^T A, functional.py:416-417)."""
+    phi = np.asarray(phi, np.float64)
+    F = np.asarray(F, np.float64)
+    pinv = phi.T * np.asarray(mass, np.float64)[None, :]
+    return np.stack([pinv @ (F[:, i, None] * phi) for i in range(F.shape[1])])
+
+
+def dcomm_energy_grad(C, ops1, ops2):
+    """sum_i 0.5 |C L_i - R_i C|^2 and its gradient -- base_functions.py:124-226 (op_commutation / oplist_commutation)."""
+    E = 0.0
+    G = np.zeros_like(C)
+    for L, R in zip(ops1, ops2):
+        T = C @ L - R @ C
+        E += 0.5 * np.square(T).sum()
+        G += T @ L.T - R.T @ T
+    return float(E), G
+
+
+def energy_grad_general(C, A, B, ev, phi1, phi2, a1, weights, ops1=None, ops2=None):
+    """energy_func_std / grad_energy_std restated for the terms the GPU path implements (base_functions.py:480-763):
+    w_descr, w_lap, w_dcomm, w_p2p, w_stochastic, w_ent, w_range01, w_sumto1; the gradient's column 0 is zeroed (:759)."""
+    w = dict(w_descr=0.0, w_lap=0.0, w_dcomm=0.0, w_p2p=0.0, w_stochastic=0.0, w_ent=0.0, w_range01=0.0, w_sumto1=0.0)
+    w.update(weights)
+    E = energy(C, A, B, ev, w["w_descr"], w["w_lap"])
+    G = w["w_descr"] * (C @ A - B) @ A.T + w["w_lap"] * C * ev
+    if w["w_dcomm"] > 0:
+        e, g = dcomm_energy_grad(C, ops1, ops2)
+        E += w["w_dcomm"] * e
+        G += w["w_dcomm"] * g
+    if any(w[t] > 0 for t in M_TERMS):
+        e, g = m_terms_energy_grad(C, phi1, phi2, a1, **{t: w[t] for t in M_TERMS})
+        E += e
+        G += g
+    G[:, 0] = 0
+    return E, G
+
+
+def fit_general(phi1, phi2, lam1, lam2, a1, a2, F1, F2, weights, optinit="zeros", maxiter=100000, x0=None, tight=True):
+    """FunctionalMapping.fit with any of the implemented terms switched on -- pyFM/functional.py:352-487: L-BFGS-B
+    (scipy.optimize.minimize, :477) on energy_func_std / grad_energy_std, here in float64 with tight tolerances.
+    Returns (C, scipy result)."""
+    k1, k2 = phi1.shape[1], phi2.shape[1]
+    A = project(phi1, a1, F1)
+    B = project(phi2, a2, F2)
+    ev = ev_sqdiff(lam1, lam2)
+    if x0 is None:
+        x0 = get_x0(k1, k2, float(phi1[0, 0]), float(phi2[0, 0]), float(np.asarray(a1, np.float64).sum()),
+                    float(np.asarray(a2, np.float64).sum()), optinit)
+    ops1 = ops2 = None
+    if weights.get("w_dcomm", 0) > 0:
+        ops1, ops2 = descr_ops(phi1, a1, F1), descr_ops(phi2, a2, F2)
+    cache = {}
+
+    def fg(x):
+        key = x.tobytes()
+        if key not in cache:
+            cache.clear()
+            cache[key] = energy_grad_general(x.reshape(k2, k1), A, B, ev, phi1, phi2, a1, weights, ops1, ops2)
+        return cache[key]
+
+    opts = {"maxiter": maxiter, "maxfun": 10 * maxiter}
+    if tight:
+        opts.update({"ftol": 1e-20, "gtol": 1e-10, "maxcor": 30})
+    res = scipy.optimize.minimize(lambda x: fg(x)[0], x0.ravel(), jac=lambda x: fg(x)[1].ravel(), method="L-BFGS-B", options=opts)
+    return res.x.reshape(k2, k1), res

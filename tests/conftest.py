@@ -38,3 +38,13 @@ def fx_cfg2():
     assert synth.sha256_of(F1, F2) == str(fx["feat_sha256"]), "regenerated descriptors differ from the fixture's"
     fx["F1"], fx["F2"] = F1, F2
     return fx
+
+
+@pytest.fixture(scope="session")
+def fx_cfg2_icp():
+    return load_golden("fx_cfg2_icp.npz")
+
+
+@pytest.fixture(scope="session")
+def fx_cfg1_terms():
+    return load_golden("fx_cfg1_terms.npz")

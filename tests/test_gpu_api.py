@@ -89,6 +89,45 @@ def test_refine_functions(fx_cfg1):
     assert np.abs(C1 - C1o).max() < 1e-9
 
 
+def test_refine_variants(fx_cfg1):
+    """the forms of ICP / ZoomOut / p2p_to_FM beyond the fused GPU loops: tolerance-driven ICP (icp.py:84-96), least-squares
+    and sparse-map p2p_to_FM (convert.py:39,51), rectangular maps with two step sizes and subsampled vertices in ZoomOut
+    (zoomout.py:80-105)"""
+    from densematcher_amd.pyFM import refine, spectral
+    fx = fx_cfg1
+    k = int(fx["k"])
+    e1, e2 = fx["Phi1"].astype(np.float64), fx["Phi2"].astype(np.float64)
+    A2 = sp.diags(fx["a2"].astype(np.float64)).tocsr()
+    # least squares against the reference's own output, sparse map form against the index form
+    Cl = spectral.p2p_to_FM(fx["knn21"], e1[:, :k], e2[:, :k])
+    assert np.abs(Cl - fx["C_from_p2p_lstsq"]).max() < 1e-9
+    n2, n1 = e2.shape[0], e1.shape[0]
+    P = sp.csr_matrix((np.ones(n2), (np.arange(n2), fx["knn21"])), shape=(n2, n1))
+    assert np.abs(spectral.p2p_to_FM(P, e1[:, :k], e2[:, :k], A2=A2) - fx["C_from_p2p"]).max() < 1e-12
+    assert np.abs(spectral.p2p_to_FM(P, e1[:, :k], e2[:, :k]) - Cl).max() < 1e-12
+    # tolerance-driven ICP: same fixed point as the oracle's loop with the same stopping rule
+    C = refine.icp_refine(fx["C_fit"], e1[:, :k], e2[:, :k], None, nit=None, tol=1e-7)
+    Co = np.array(fx["C_fit"])
+    for _ in range(10000):
+        Cn = orc.icp_refine(Co, e1[:, :k], e2[:, :k], nit=1)
+        done = np.max(np.abs(Cn - Co)) <= 1e-7
+        Co = Cn
+        if done:
+            break
+    assert np.abs(C - Co).max() < 1e-8
+    # rectangular map, two step sizes
+    C0 = fx["C20"][:18, :20]
+    Cz, pz = refine.zoomout_refine(C0, e1, e2, nit=5, step=(2, 3), A2=A2, return_p2p=True)
+    Czo, pzo = orc.zoomout_refine(C0, e1, e2, nit=5, step=(2, 3), a2=fx["a2"], return_p2p=True)
+    assert Cz.shape == (33, 30) and np.array_equal(pz, pzo) and np.abs(Cz - Czo).max() < 1e-11
+    # subsampled vertices (least-squares p2p_to_FM inside, final map on all vertices)
+    rng = np.random.default_rng(0)
+    sub = (np.sort(rng.choice(n1, 300, replace=False)), np.sort(rng.choice(n2, 320, replace=False)))
+    Cs, ps = refine.zoomout_refine(fx["C20"], e1, e2, nit=6, step=2, A2=A2, subsample=sub, return_p2p=True)
+    Cso, pso = orc.zoomout_refine(fx["C20"], e1, e2, nit=6, step=2, a2=fx["a2"], subsample=sub, return_p2p=True)
+    assert Cs.shape == (32, 32) and np.abs(Cs - Cso).max() < 1e-8 and np.array_equal(ps, pso)
+
+
 def test_functional_mapping_and_surface_map(fx_cfg1, monkeypatch):
     """whole reference call surface on the fixture's (float32-rounded) spectrum"""
     from densematcher_amd.functional_map import compute_surface_map
@@ -141,6 +180,15 @@ def test_functional_mapping_and_surface_map(fx_cfg1, monkeypatch):
              (res[4] == fx["csm_p2p_21_icp"]).mean(), (res[12] == fx["csm_p2p_21_icp_adjoint"]).mean()]
     print("compute_surface_map agreement with the reference tuple:", [round(float(a), 4) for a in agree])
     assert min(agree[:4]) >= 0.98
+    # slots 4,5 / 12,13: the ICP maps, bit-exact against the oracle's ICP + maps started from the SAME plain map
+    # (functional_map.py:71-77; the agreement with the reference tuple above is lower only because ICP amplifies the
+    # 5e-4 distance between the closed-form C and the reference's fp32 L-BFGS C_fit)
+    e1, e2 = fx["Phi1"][:, :k].astype(np.float64), fx["Phi2"][:, :k].astype(np.float64)
+    C_icp_o = orc.icp_refine(Cg, e1, e2, nit=10)
+    assert np.abs(res[7].FM - C_icp_o).max() < 1e-8
+    qi = orc.fm_to_p2p_all(res[7].FM, e1, e2, fx["a1"])
+    for got, ref in zip([res[12], res[13], res[4], res[5]], qi):
+        assert np.array_equal(got, ref)
     assert res[6] is not None and len(res[6]) == 2          # hungarian_icp (host SciPy passthrough)
     assert res[2] is None and res[3] is None
 

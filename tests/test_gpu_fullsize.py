@@ -110,3 +110,48 @@ def test_config5_large_n_roundtrip(eng):
     same = orc.fm_to_p2p_all(Cg, batch["Phi1"][0].astype(np.float64), batch["Phi2"][0].astype(np.float64), batch["a1"][0], chunk=512)
     for got, name in zip(same, ["knn21", "knn12", "ind21", "ind12"]):
         assert np.array_equal(res[name][0].cpu().numpy(), got), name
+
+
+def test_config4_zoomout_full_length_against_oracle(eng):
+    """config 4 at its full length for one pair: ZoomOut 50 -> 200, step 1, 150 iterations, N = 2048, against the oracle
+    (about 10 s of NumPy): the final vertex map bit-exact, C within 1e-9"""
+    batch = synth.make_pair_batch(1, 64, 32, 8, 200, sigma=0.1, n_distinct_meshes=2, seed0=9)
+    rng = np.random.default_rng(4)
+    C0 = np.eye(50) + 0.02 * rng.standard_normal((50, 50))
+    Cz, pz = eng.zoomout(batch["Phi1"], batch["Phi2"], batch["a2"], C0[None], nit=150, step=1, return_p2p=True)
+    Co, po = orc.zoomout_refine(C0, batch["Phi1"][0], batch["Phi2"][0], nit=150, step=1, a2=batch["a2"][0], return_p2p=True)
+    assert Cz.shape == (1, 200, 200)
+    assert np.array_equal(pz[0].cpu().numpy(), po)
+    assert np.abs(Cz[0].cpu().numpy() - Co).max() < 1e-9
+
+
+def test_config4_zoomout_batch32(eng):
+    """config 4 at its per-GPU batch (32 pairs): every pair's trajectory is independent of its batch"""
+    B = 32
+    batch = synth.make_pair_batch(B, 64, 32, 8, 200, sigma=0.1, n_distinct_meshes=2, seed0=9)
+    rng = np.random.default_rng(4)
+    C0 = np.stack([np.eye(50) + 0.02 * rng.standard_normal((50, 50)) for _ in range(B)])
+    Cz, pz = eng.zoomout(batch["Phi1"], batch["Phi2"], batch["a2"], C0, nit=150, step=1, return_p2p=True)
+    for i in (0, 17, 31):
+        C1, p1 = eng.zoomout(batch["Phi1"][i:i + 1], batch["Phi2"][i:i + 1], batch["a2"][i:i + 1], C0[i:i + 1], nit=150, step=1,
+                             return_p2p=True)
+        assert torch.equal(C1[0], Cz[i]) and torch.equal(p1[0], pz[i])
+
+
+def test_config5_batch64(eng):
+    """config 5 at its full batch (64 pairs, N = 8192, D = 384, k = 200), once: batch invariance on sampled pairs, one
+    pair's maps against the oracle on the same C"""
+    B, N, D, k = 64, 8192, 384, 200
+    batch = synth.make_pair_batch(B, 128, 64, D, k, sigma=0.2, n_distinct_meshes=2, basis="random", seed0=3)
+    dev = {n: torch.as_tensor(v).to(eng.device) for n, v in batch.items()}
+    out = eng.match(dev, k=k, check=True)
+    for i in (5, 63):
+        one = eng.match({n: v[i:i + 1].contiguous() for n, v in dev.items()}, k=k)
+        assert torch.equal(one["C"][0], out["C"][i])
+        for name in ("knn21", "knn12", "ind21", "ind12"):
+            assert torch.equal(one[name][0], out[name][i]), name
+    i = 40
+    Cg = out["C"][i].cpu().numpy()
+    same = orc.fm_to_p2p_all(Cg, batch["Phi1"][i].astype(np.float64), batch["Phi2"][i].astype(np.float64), batch["a1"][i], chunk=512)
+    for got, name in zip(same, ["knn21", "knn12", "ind21", "ind12"]):
+        assert np.array_equal(out[name][i].cpu().numpy(), got), name

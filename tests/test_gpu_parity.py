@@ -460,3 +460,39 @@ def test_fuzz_knn_query(eng):
         for b in range(B):
             assert np.array_equal(got[b], orc.knn_query(X[b], Y[b])), (B, nx, ny, p, scale, clustered)
     run()
+
+
+# --------------------------------------------------------------------------- #
+# ICP at the benchmark's size, against the reference's own output (tools/make_golden_r02.py)
+def test_icp_config2_size_against_reference(eng, fx_cfg2, fx_cfg2_icp):
+    """N = 2048, k = 128, 10 iterations from the reference's C_fit: C within 1e-8 of the reference's icp_refine
+    (lstsq + SVD on the host there, normal equations + polar iteration here), the four maps of the refined C bit-exact"""
+    fx = fx_cfg2
+    k = int(fx["k"])
+    Phi1, Phi2 = fx["Phi1"][:, :k].copy(), fx["Phi2"][:, :k].copy()
+    C, resid, info = eng.icp(_b(Phi1), _b(Phi2), _b(fx["C_fit"]), nit=10, return_resid=True)
+    C = _np(C)[0]
+    assert int(_np(info)[0]) == 0 and float(_np(resid)[0]) < 1e-12
+    err = np.abs(C - fx_cfg2_icp["C_icp"]).max()
+    print("config-2 ICP |C_gpu - C_icp(reference)| =", err)
+    assert err < 1e-8
+    maps = eng.fm_to_p2p(_b(Phi1), _b(Phi2), _b(fx["a1"]), _b(fx_cfg2_icp["C_icp"]))
+    for name in ("knn21", "knn12", "ind21", "ind12"):
+        assert np.array_equal(_np(maps[name])[0], fx_cfg2_icp["icp_" + name]), name
+
+
+@pytest.mark.parametrize("k1,k2", [(200, 200), (180, 200), (177, 177), (40, 256)])
+def test_icp_large_k(eng, k1, k2):
+    """k2 > 176: the Gram matrix is inverted by Newton-Schulz on the matrix cores instead of the in-LDS Cholesky
+    (compute_surface_map(n_ev = 200) runs ICP at k = 200, functional_map.py:71)"""
+    from densematcher_amd import synth
+    N = 1500
+    lam1, phi1, a1 = synth.random_basis(N, max(k1, k2), 21)
+    lam2, phi2, a2 = synth.random_basis(N, max(k1, k2), 22)
+    rng = np.random.default_rng(k1 + k2)
+    C0 = np.eye(k2, k1) + 0.02 * rng.standard_normal((k2, k1))
+    P1, P2 = phi1[:, :k1].astype(np.float32), phi2[:, :k2].astype(np.float32)
+    C, resid, info = eng.icp(_b(P1), _b(P2), _b(C0), nit=3, return_resid=True)
+    assert int(_np(info)[0]) == 0
+    Co = orc.icp_refine(C0, P1.astype(np.float64), P2.astype(np.float64), nit=3)
+    assert np.abs(_np(C)[0] - Co).max() < 1e-8

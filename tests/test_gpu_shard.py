@@ -1,0 +1,78 @@
+"""
+GPU (-m gpu): the N > 1 path with the real engine.  The GPU box has one device, so both ranks use cuda:0
+(two processes, two HIP contexts, gloo for the gather / barrier): the partition, the per-rank engines and the gather
+run exactly as on N GPUs; only the device index differs.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _batch(B):
+    from densematcher_amd import synth
+    return synth.make_pair_batch(B, 20, 12, 64, 32, sigma=0.3, n_distinct_meshes=2, seed0=3)
+
+
+def _worker(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from densematcher_amd import shard
+    from densematcher_amd.engine import MatchEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = shard.match_sharded(_batch(B), lambda: MatchEngine(0), rank, world, gather=True, k=24)
+    dist.barrier()
+    if rank == 0:
+        q.put({k: v.cpu().numpy() for k, v in res.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [5, 1])
+def test_match_sharded_real_engine_two_ranks(B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    from densematcher_amd.engine import MatchEngine
+    eng = MatchEngine(0)
+    ref = eng.match({k: torch.as_tensor(v).to(eng.device) for k, v in _batch(B).items()}, k=24)
+    assert set(got) == {"C", "knn21", "knn12", "ind21", "ind12"}
+    for name in got:
+        assert np.array_equal(got[name], ref[name].cpu().numpy()), name       # a pair's result does not depend on its rank
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself and reports n_gpus = 2."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--single-device", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["pairs_per_gpu"] == 4 and out["value"] > 0

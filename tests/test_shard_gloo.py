@@ -50,7 +50,7 @@ def _worker(rank, world, port, B, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [4, 5])
+@pytest.mark.parametrize("B", [4, 5, 1])      # 1: fewer pairs than ranks, rank 1 holds an empty block
 def test_match_sharded_two_ranks(B):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
