@@ -17,7 +17,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdensematch.so")
-SOURCES = ["dm_ctx.hip", "dm_p2p.hip", "dm_fmap.hip", "dm_project.hip", "dm_zoomout.hip", "dm_icp.hip", "dm_simnn.hip", "dm_knnsplit.hip"]
+SOURCES = ["dm_ctx.hip", "dm_p2p.hip", "dm_fmap.hip", "dm_project.hip", "dm_zoomout.hip", "dm_icp.hip", "dm_simnn.hip", "dm_knnsplit.hip", "dm_energy.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
@@ -68,7 +68,7 @@ def build(force=False, verbose=False, extra_flags=(), lib=None, objdir=None):
             print(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     r = subprocess.run(cmd, capture_output=True, text=True)

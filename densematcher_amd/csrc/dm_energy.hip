@@ -1,0 +1,473 @@
+// General functional-map energy and gradient on the device (dm_fmap_energy_grad, dm_fmap_descr_ops):
+// what scipy's L-BFGS-B evaluates in FunctionalMapping.fit when terms beyond w_descr / w_lap are switched on.
+//
+// Reference arithmetic reproduced (oracle/dm_oracle.py: energy_grad_general; pyFM/optimize/base_functions.py:480-763):
+//   E(C) = w_descr 1/2 |C A - B|^2 + w_lap 1/2 sum C^2 ev                                    :31-121
+//        + w_dcomm sum_d 1/2 |C L_d - R_d C|^2,  L_d = Phi1^T A1 diag(f_d) Phi1, R_d likewise   :124-226, 546-565
+//        + terms in the mapped indicator M = Phi2 C Phi1^T A1 (N2 x N1):                       :296-428
+//            w_p2p sum (M^2 - M)^2;  w_stochastic [sum_j (sum_i M^2 - n2/n1)^2 + sum_i (sum_j M^2 - 1)^2];
+//            w_ent sum -c log(c + 1e-10), c = clamp(M, 0, 1);  w_range01 sum relu(-M)^2 + relu(M - 1)^2;
+//            w_sumto1 [sum_j (cs_j - mean cs)^2 + sum_i (rs_i - mean rs)^2]   (v = None branch)
+//   gradient: the analytic derivative of the above (what torch autograd returns there), dE/dC = Phi2^T (dE/dM) (A1 Phi1)
+//   for the M terms; column 0 is zeroed (:759).
+//
+// Everything is float64 on the f64 matrix cores.  The mapped indicator IS materialised here (B N2 N1 doubles in the
+// context workspace: 32 MiB per pair at N = 2048): these terms need two passes over it (row / column statistics, then
+// the element-wise derivative) and one evaluation is a few milliseconds against the reference's seconds; the arg-max
+// maps (dm_fm_to_p2p) never form it.  All reductions use fixed orders: the same input gives the same bits.
+#include "dm_gemm_f64.h"
+#include "dm_internal.h"
+
+static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+
+enum { W_DESCR = 0, W_LAP, W_DCOMM, W_P2P, W_STOCH, W_ENT, W_RANGE01, W_SUMTO1, W_COUNT };
+struct mterm_weights { double p2p, stoch, ent, range01, sumto1; };
+
+// ---- functors -----------------------------------------------------------------------------------------------------
+struct KRowsStackedAB {            // rows 0..k1-1 = A, k1..k1+k2-1 = Bm (fp32, K = D contiguous)
+    const float* A; const float* Bm; int k1, k2, D;
+    __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
+        const float* r = nullptr;
+        if (row < k1) r = A + ((long long)b * k1 + row) * D;
+        else if (row < k1 + k2) r = Bm + ((long long)b * k2 + (row - k1)) * D;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (r && k0 + e < D) ? (double)r[k0 + e] : 0.0;
+    }
+};
+struct OutNT {
+    double* p; long long stride_b; int ld;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] = v; }
+};
+struct OutNTScaledCols {           // M = (product) * mass1[j]
+    double* p; long long stride_b; int ld; const float* mass1; int N1;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const {
+        p[b * stride_b + (long long)i * ld + j] = v * (double)mass1[(long long)b * N1 + j];
+    }
+};
+struct OutNTSub {                  // T <- T - product   (in place, one thread per element)
+    double* p; long long stride_b; int ld;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] -= v; }
+};
+// rows of a (B, nrows, ld) float64 matrix shared by `div` consecutive batch slots z (z / div selects the pair);
+// `trans` reads element (row, k) at p[k * ld + row]
+struct KRowsF64Bcast {
+    const double* p; long long stride_b; int ld; int nrows; int ncols; int trans; int div;
+    __device__ __forceinline__ void load8(int z, int row, int k0, double (&v)[8]) const {
+        const double* base = p + (long long)(z / div) * stride_b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + e;
+            double x = 0.0;
+            if (row < nrows && k < ncols) x = trans ? base[(long long)k * ld + row] : base[(long long)row * ld + k];
+            v[e] = x;
+        }
+    }
+};
+// row i of the (k2 x nops*k1) matrix [T_0 | T_1 | ...] / row j of [L_0 | L_1 | ...]: element (row, d*kin + k) = X[b][d][row][k]
+struct KRowsF64Blocks {
+    const double* p; int nops; int nrows; int kin;     // p (B, nops, nrows, kin)
+    __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = k0 + e;
+            double x = 0.0;
+            if (row < nrows && kk < nops * kin) {
+                const int d = kk / kin, k = kk - d * kin;
+                x = p[(((long long)b * nops + d) * nrows + row) * kin + k];
+            }
+            v[e] = x;
+        }
+    }
+};
+struct RowsF64TN {                 // K-major float64 operand for gemm_tn_f64
+    const double* p; long long stride_b; int ld; int ncols;
+    __device__ __forceinline__ void load4(int b, int n, int col0, double (&v)[4]) const {
+        const double* row = p + b * stride_b + (long long)n * ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (col0 + e < ncols) ? row[col0 + e] : 0.0;
+    }
+};
+// rows of Phi (fp32) scaled by mass[n] * F[n][d]; batch slot z = b * D + d
+struct RowsPhiTimesDescr {
+    const float* Phi; long long stride_b; int ld; int ncols;
+    const float* mass; int N; const void* F; int f16; int D;
+    __device__ __forceinline__ void load4(int z, int n, int col0, double (&v)[4]) const {
+        const int b = z / D, d = z - b * D;
+        const float* row = Phi + b * stride_b + (long long)n * ld;
+        const long long fo = ((long long)b * N + n) * D + d;
+        const double f = f16 ? (double)reinterpret_cast<const _Float16*>(F)[fo] : (double)reinterpret_cast<const float*>(F)[fo];
+        const double s = (double)mass[(long long)b * N + n] * f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (col0 + e < ncols) ? s * (double)row[col0 + e] : 0.0;
+    }
+};
+struct RowsPhiBatchDiv {           // plain rows of Phi (fp32) for batch slot z = b * D + d
+    const float* Phi; long long stride_b; int ld; int ncols; int D;
+    __device__ __forceinline__ void load4(int z, int n, int col0, double (&v)[4]) const {
+        const float* row = Phi + (long long)(z / D) * stride_b + (long long)n * ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (col0 + e < ncols) ? (double)row[col0 + e] : 0.0;
+    }
+};
+struct OutTNPartial {              // split-K partials (nsplit, Z, m, c), or the result itself when nsplit == 1
+    double* p; long long Z; int M; int N;
+    __device__ __forceinline__ void store(int z, int split, int m, int c, double v) const {
+        p[(((long long)split * Z + z) * M + m) * N + c] = v;
+    }
+};
+
+// out[i] = sum_q partial[q][i]   (fixed order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partial, int nsplit, long long n,
+                                                              double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += partial[(long long)q * n + i];
+    out[i] = s;
+}
+
+// deterministic workgroup sum (256 threads): returns the total in every thread
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ---- quadratic terms -------------------------------------------------------------------------------------------------
+// grad = w_d (C P - Q) + w_l C * ev;  e_quad[b] = 1/2 w_d (sum C (CP - 2Q) + |B|^2) + 1/2 w_l sum C^2 ev      (one workgroup per pair)
+__global__ __launch_bounds__(256) void quad_terms_kernel(const double* __restrict__ C, const double* __restrict__ CP,
+                                                         const double* __restrict__ PQ, const float* __restrict__ Bm,
+                                                         const double* __restrict__ lam1, const double* __restrict__ lam2,
+                                                         int k1, int k2, int D, double w_d, double w_l, double* __restrict__ grad,
+                                                         double* __restrict__ e_quad) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double mx = 0.0;
+    for (int j = t; j < k1; j += 256) mx = fmax(mx, lam1[(long long)b * k1 + j]);
+    for (int i = t; i < k2; i += 256) mx = fmax(mx, lam2[(long long)b * k2 + i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    if ((t & 63) == 0) sh[t >> 6] = mx;
+    __syncthreads();
+    const double scale = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    const double* Cb = C + (long long)b * k2 * k1;
+    const double* CPb = CP + (long long)b * k2 * k1;
+    const double* Q = PQ + ((long long)b * (k1 + k2) + k1) * k1;
+    double acc = 0.0;
+    for (int e = t; e < k2 * k1; e += 256) {
+        const int i = e / k1, j = e - i * k1;
+        const double c = Cb[e], cp = CPb[e], q = Q[e];
+        const double dl = lam1[(long long)b * k1 + j] / scale - lam2[(long long)b * k2 + i] / scale;   // functional.py:404-405
+        const double ev = dl * dl;
+        grad[(long long)b * k2 * k1 + e] = w_d * (cp - q) + w_l * c * ev;
+        acc += 0.5 * w_d * c * (cp - 2.0 * q) + 0.5 * w_l * c * c * ev;
+    }
+    double bn = 0.0;
+    for (int e = t; e < k2 * D; e += 256) { const double x = (double)Bm[(long long)b * k2 * D + e]; bn += x * x; }
+    const double tot = block_sum_256(acc + 0.5 * w_d * bn, sh);
+    if (t == 0) e_quad[b] = tot;
+}
+
+// ---- statistics of the mapped indicator ------------------------------------------------------------------------------
+// one wave per row: rs[i] = sum_j M_ij, rsq[i] = sum_j M_ij^2
+__global__ __launch_bounds__(256) void m_row_stats_kernel(const double* __restrict__ M, int N2, int N1, double* __restrict__ rs,
+                                                          double* __restrict__ rsq) {
+    const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N2) return;
+    const double* row = M + ((long long)b * N2 + i) * N1;
+    double s = 0.0, q = 0.0;
+    for (int j = lane; j < N1; j += 64) { const double m = row[j]; s += m; q += m * m; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+    if (lane == 0) { rs[(long long)b * N2 + i] = s; rsq[(long long)b * N2 + i] = q; }
+}
+// column sums over chunks of 256 rows: pcs / pcsq (B, nchunk, N1)
+__global__ __launch_bounds__(256) void m_col_stats_kernel(const double* __restrict__ M, int N2, int N1, int nchunk,
+                                                          double* __restrict__ pcs, double* __restrict__ pcsq) {
+    const int b = blockIdx.z, ch = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N1) return;
+    const int i0 = ch * 256, i1 = min(N2, i0 + 256);
+    const double* col = M + (long long)b * N2 * N1 + j;
+    double s = 0.0, q = 0.0;
+    for (int i = i0; i < i1; ++i) { const double m = col[(long long)i * N1]; s += m; q += m * m; }
+    pcs[((long long)b * nchunk + ch) * N1 + j] = s;
+    pcsq[((long long)b * nchunk + ch) * N1 + j] = q;
+}
+// cs / csq from the chunk partials, and the means of rs and cs: stat[b] = {mean rs, mean cs}   (one workgroup per pair)
+__global__ __launch_bounds__(256) void m_finish_stats_kernel(const double* __restrict__ pcs, const double* __restrict__ pcsq, int nchunk,
+                                                             int N2, int N1, const double* __restrict__ rs, double* __restrict__ cs,
+                                                             double* __restrict__ csq, double* __restrict__ stat) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double sc = 0.0;
+    for (int j = t; j < N1; j += 256) {
+        double s = 0.0, q = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) { s += pcs[((long long)b * nchunk + ch) * N1 + j]; q += pcsq[((long long)b * nchunk + ch) * N1 + j]; }
+        cs[(long long)b * N1 + j] = s; csq[(long long)b * N1 + j] = q;
+        sc += s;
+    }
+    const double tot_c = block_sum_256(sc, sh);
+    double sr = 0.0;
+    for (int i = t; i < N2; i += 256) sr += rs[(long long)b * N2 + i];
+    const double tot_r = block_sum_256(sr, sh);
+    if (t == 0) { stat[2 * b] = tot_r / (double)N2; stat[2 * b + 1] = tot_c / (double)N1; }
+}
+
+// ---- element-wise derivative -----------------------------------------------------------------------------------------
+// M_ij <- (dE/dM_ij) * mass1_j in place; pe[b][block] = this workgroup's share of the energy.  One workgroup per 4 rows.
+__global__ __launch_bounds__(256) void m_derivative_kernel(double* __restrict__ M, int N2, int N1, const float* __restrict__ mass1,
+                                                           const double* __restrict__ rs, const double* __restrict__ rsq,
+                                                           const double* __restrict__ cs, const double* __restrict__ csq,
+                                                           const double* __restrict__ stat, mterm_weights w, double* __restrict__ pe) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const double mean_r = stat[2 * b], mean_c = stat[2 * b + 1];
+    const double n2_over_n1 = (double)N2 / (double)N1;
+    double acc = 0.0;
+    for (int r = 0; r < 4; ++r) {
+        const int i = blockIdx.x * 4 + r;
+        if (i >= N2) break;
+        double* row = M + ((long long)b * N2 + i) * N1;
+        const double dr_s = (w.sumto1 > 0.0) ? rs[(long long)b * N2 + i] - mean_r : 0.0;
+        const double dr_q = (w.stoch > 0.0) ? rsq[(long long)b * N2 + i] - 1.0 : 0.0;
+        for (int j = t; j < N1; j += 256) {
+            const double m = row[j];
+            double d = 0.0;
+            if (w.p2p > 0.0) { const double q = m * m - m; acc += w.p2p * q * q; d += w.p2p * 2.0 * q * (2.0 * m - 1.0); }
+            if (w.stoch > 0.0) d += w.stoch * (2.0 * (csq[(long long)b * N1 + j] - n2_over_n1) + 2.0 * dr_q) * 2.0 * m;
+            if (w.ent > 0.0) {
+                const double c = fmin(fmax(m, 0.0), 1.0);
+                const double lg = log(c + 1e-10);
+                acc += w.ent * (-c * lg);
+                if (m >= 0.0 && m <= 1.0) d += w.ent * (-lg - c / (c + 1e-10));   // torch.clamp passes the gradient on [0, 1]
+            }
+            if (w.range01 > 0.0) {
+                const double lo = fmax(-m, 0.0), hi = fmax(m - 1.0, 0.0);
+                acc += w.range01 * (lo * lo + hi * hi);
+                d += w.range01 * (-2.0 * lo + 2.0 * hi);
+            }
+            if (w.sumto1 > 0.0) d += w.sumto1 * (2.0 * (cs[(long long)b * N1 + j] - mean_c) + 2.0 * dr_s);
+            row[j] = d * (double)mass1[(long long)b * N1 + j];
+        }
+        // the row's share of the row-statistics terms (once per row)
+        if (t == 0) acc += w.stoch * dr_q * dr_q + w.sumto1 * dr_s * dr_s;
+    }
+    const double tot = block_sum_256(acc, sh);
+    if (t == 0) pe[(long long)b * gridDim.x + blockIdx.x] = tot;
+}
+// e_m[b] = sum of the workgroup shares + the column-statistics terms   (one workgroup per pair)
+__global__ __launch_bounds__(256) void m_finish_energy_kernel(const double* __restrict__ pe, int nblk, int N1, int N2,
+                                                              const double* __restrict__ cs, const double* __restrict__ csq,
+                                                              const double* __restrict__ stat, mterm_weights w, double* __restrict__ e_m) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double acc = 0.0;
+    for (int q = t; q < nblk; q += 256) acc += pe[(long long)b * nblk + q];
+    const double mean_c = stat[2 * b + 1], n2_over_n1 = (double)N2 / (double)N1;
+    if (w.stoch > 0.0 || w.sumto1 > 0.0)
+        for (int j = t; j < N1; j += 256) {
+            const double dq = csq[(long long)b * N1 + j] - n2_over_n1, ds = cs[(long long)b * N1 + j] - mean_c;
+            acc += w.stoch * dq * dq + w.sumto1 * ds * ds;
+        }
+    const double tot = block_sum_256(acc, sh);
+    if (t == 0) e_m[b] = tot;
+}
+
+// e_dc[b] = 1/2 sum T^2 over the pair's nops * k2 * k1 entries   (one workgroup per pair)
+__global__ __launch_bounds__(256) void half_sumsq_kernel(const double* __restrict__ T, long long n, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double acc = 0.0;
+    for (long long e = t; e < n; e += 256) { const double x = T[(long long)b * n + e]; acc += x * x; }
+    const double tot = block_sum_256(acc, sh);
+    if (t == 0) out[b] = 0.5 * tot;
+}
+
+// grad += gm + w_dc (g1 - g2), column 0 zeroed; energy = e_quad + e_m + w_dc e_dc
+__global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad, const double* __restrict__ gm, const double* __restrict__ g1,
+                                                      const double* __restrict__ g2, double w_dc, int k1, int k2,
+                                                      const double* __restrict__ e_quad, const double* __restrict__ e_m,
+                                                      const double* __restrict__ e_dc, double* __restrict__ energy) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int e = t; e < k2 * k1; e += 256) {
+        const long long o = (long long)b * k2 * k1 + e;
+        double g = grad[o];
+        if (gm) g += gm[o];
+        if (g1) g += w_dc * (g1[o] - g2[o]);
+        grad[o] = (e % k1 == 0) ? 0.0 : g;                              // base_functions.py:759
+    }
+    if (t == 0) energy[b] = e_quad[b] + (e_m ? e_m[b] : 0.0) + (e_dc ? w_dc * e_dc[b] : 0.0);
+}
+
+extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D, const float* Phi1, int ld1,
+                                   const float* Phi2, int ld2, const float* mass1, const float* A, const float* Bm,
+                                   const double* lam1, const double* lam2, const double* ops1, const double* ops2, int n_ops,
+                                   const double* weights, const double* C, double* energy, double* grad) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0 && D > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, A && Bm && lam1 && lam2 && weights && C && energy && grad, "null pointer");
+    double w[W_COUNT];
+    for (int q = 0; q < W_COUNT; ++q) {
+        w[q] = weights[q];
+        DM_REQUIRE(ctx, w[q] >= 0.0, "weights must be >= 0");
+    }
+    const mterm_weights mw{w[W_P2P], w[W_STOCH], w[W_ENT], w[W_RANGE01], w[W_SUMTO1]};
+    const bool m_terms = mw.p2p > 0 || mw.stoch > 0 || mw.ent > 0 || mw.range01 > 0 || mw.sumto1 > 0;
+    const bool dcomm = w[W_DCOMM] > 0.0 && n_ops > 0;
+    DM_REQUIRE(ctx, !m_terms || (Phi1 && Phi2 && mass1 && ld1 >= k1 && ld2 >= k2), "the indicator terms need Phi1, Phi2, mass1");
+    DM_REQUIRE(ctx, !(w[W_DCOMM] > 0.0) || (ops1 && ops2 && n_ops > 0), "w_dcomm > 0 needs the descriptor operators (dm_fmap_descr_ops)");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+
+    const size_t bKK = (size_t)B * k2 * k1 * 8;
+    const int nchunk = dm_cdiv(N2, 256), nblk = dm_cdiv(N2, 4);
+    const int N1pad = pad_to(N1, 64), k1pad = pad_to(k1, 64);
+    const int nsplit_m = dm_cdiv(N2, 512);
+    const int nsplit_d = dcomm ? dm_cdiv(n_ops * k2, 512) : 0;
+    size_t need = dm_align_up((size_t)B * (k1 + k2) * k1 * 8) + 4 * dm_align_up(bKK) + 4 * dm_align_up((size_t)B * 8) + 65536;
+    if (m_terms)
+        need += dm_align_up((size_t)B * N2 * N1 * 8) + dm_align_up((size_t)B * N2 * k1 * 8) + dm_align_up((size_t)B * k1pad * N1pad * 8) +
+                2 * dm_align_up((size_t)B * N2 * 8) + 2 * dm_align_up((size_t)B * N1 * 8) + 2 * dm_align_up((size_t)B * nchunk * N1 * 8) +
+                dm_align_up((size_t)B * 2 * 8) + dm_align_up((size_t)B * nblk * 8) + dm_align_up((size_t)nsplit_m * bKK);
+    if (dcomm) need += dm_align_up((size_t)B * n_ops * k2 * k1 * 8) + dm_align_up((size_t)nsplit_d * bKK);
+    int rc = dm_ws_reserve(ctx, need);
+    if (rc) return rc;
+    double* PQ = (double*)dm_ws_take(ctx, (size_t)B * (k1 + k2) * k1 * 8);
+    double* CP = (double*)dm_ws_take(ctx, bKK);
+    double* Gm = (double*)dm_ws_take(ctx, bKK);
+    double* G1 = (double*)dm_ws_take(ctx, bKK);
+    double* G2 = (double*)dm_ws_take(ctx, bKK);
+    double* e_quad = (double*)dm_ws_take(ctx, (size_t)B * 8);
+    double* e_m = (double*)dm_ws_take(ctx, (size_t)B * 8);
+    double* e_dc = (double*)dm_ws_take(ctx, (size_t)B * 8);
+    if (!PQ || !CP || !Gm || !G1 || !G2 || !e_quad || !e_m || !e_dc) return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
+
+    // ---- quadratic terms: P = A A^T, Q = Bm A^T (unscaled), C P
+    {
+        KRowsStackedAB opa{A, Bm, k1, k2, D};
+        KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
+        OutNT out{PQ, (long long)(k1 + k2) * k1, k1};
+        DM_LAUNCH(ctx, "energy_gram_nt_f64", (gemm_nt_f64<KRowsStackedAB, KRowsF32, OutNT>),
+                  dim3(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, opa, opb, out, k1 + k2, k1, D);
+        KRowsF64 ca{C, (long long)k2 * k1, k1, k2, k1, 0};
+        KRowsF64 pb{PQ, (long long)(k1 + k2) * k1, k1, k1, k1, 1};          // (C P)_ij = sum_k C_ik P_kj
+        OutNT ocp{CP, (long long)k2 * k1, k1};
+        DM_LAUNCH(ctx, "energy_cp_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutNT>), dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
+                  dim3(256), 0, ca, pb, ocp, k2, k1, k1);
+        DM_LAUNCH(ctx, "energy_quad", quad_terms_kernel, dim3(B), dim3(256), 0, C, CP, PQ, Bm, lam1, lam2, k1, k2, D, w[W_DESCR], w[W_LAP],
+                  grad, e_quad);
+    }
+
+    // ---- terms in the mapped indicator
+    if (m_terms) {
+        double* M = (double*)dm_ws_take(ctx, (size_t)B * N2 * N1 * 8);
+        double* E2 = (double*)dm_ws_take(ctx, (size_t)B * N2 * k1 * 8);            // Phi2 C, later Y = D' Phi1
+        double* P1T = (double*)dm_ws_take(ctx, (size_t)B * k1pad * N1pad * 8);     // Phi1^T (K-major float64)
+        double* rs = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
+        double* rsq = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
+        double* cs = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);
+        double* csq = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);
+        double* pcs = (double*)dm_ws_take(ctx, (size_t)B * nchunk * N1 * 8);
+        double* pcsq = (double*)dm_ws_take(ctx, (size_t)B * nchunk * N1 * 8);
+        double* stat = (double*)dm_ws_take(ctx, (size_t)B * 2 * 8);
+        double* pe = (double*)dm_ws_take(ctx, (size_t)B * nblk * 8);
+        double* part = (double*)dm_ws_take(ctx, (size_t)nsplit_m * bKK);
+        if (!M || !E2 || !P1T || !rs || !rsq || !cs || !csq || !pcs || !pcsq || !stat || !pe || !part)
+            return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
+        {   // E2 = Phi2 C;  M = (E2 Phi1^T) * mass1   (convert.py:144)
+            KRowsF32 opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
+            KRowsF64 opb{C, (long long)k2 * k1, k1, k1, k2, 1};
+            OutNT out{E2, (long long)N2 * k1, k1};
+            DM_LAUNCH(ctx, "emb2_nt_f64", (gemm_nt_f64<KRowsF32, KRowsF64, OutNT>), dim3(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
+                      dim3(256), 0, opa, opb, out, N2, k1, k2);
+            KRowsF64 ea{E2, (long long)N2 * k1, k1, N2, k1, 0};
+            KRowsF32 pb{Phi1, (long long)N1 * ld1, ld1, N1, k1};
+            OutNTScaledCols om{M, (long long)N2 * N1, N1, mass1, N1};
+            DM_LAUNCH(ctx, "indicator_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF32, OutNTScaledCols>),
+                      dim3(dm_cdiv(N2, NT_T) * dm_cdiv(N1, NT_T), 1, B), dim3(256), 0, ea, pb, om, N2, N1, k1);
+        }
+        DM_LAUNCH(ctx, "energy_row_stats", m_row_stats_kernel, dim3(dm_cdiv(N2, 4), B), dim3(256), 0, M, N2, N1, rs, rsq);
+        DM_LAUNCH(ctx, "energy_col_stats", m_col_stats_kernel, dim3(dm_cdiv(N1, 256), nchunk, B), dim3(256), 0, M, N2, N1, nchunk, pcs, pcsq);
+        DM_LAUNCH(ctx, "energy_finish_stats", m_finish_stats_kernel, dim3(B), dim3(256), 0, pcs, pcsq, nchunk, N2, N1, rs, cs, csq, stat);
+        DM_LAUNCH(ctx, "energy_derivative", m_derivative_kernel, dim3(nblk, B), dim3(256), 0, M, N2, N1, mass1, rs, rsq, cs, csq, stat, mw, pe);
+        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, nblk, N1, N2, cs, csq, stat, mw, e_m);
+        {   // Y = D' Phi1 (N2 x k1);  Gm = Phi2^T Y
+            rc = dm_launch_phiT(ctx, B, N1, k1, Phi1, ld1, P1T, k1pad, N1pad);
+            if (rc) return rc;
+            KRowsF64 da{M, (long long)N2 * N1, N1, N2, N1, 0};
+            KRowsF64 pb{P1T, (long long)k1pad * N1pad, N1pad, k1, N1, 0};
+            OutNT oy{E2, (long long)N2 * k1, k1};
+            DM_LAUNCH(ctx, "energy_back_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutNT>), dim3(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
+                      dim3(256), 0, da, pb, oy, N2, k1, N1);
+            RowsF32Scaled opx{Phi2, (long long)N2 * ld2, ld2, k2, nullptr, 0};
+            RowsF64TN opy{E2, (long long)N2 * k1, k1, k1};
+            OutTNPartial op{nsplit_m > 1 ? part : Gm, B, k2, k1};
+            DM_LAUNCH(ctx, "energy_back_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF64TN, OutTNPartial>),
+                      dim3(dm_cdiv(k2, TN_T) * dm_cdiv(k1, TN_T), nsplit_m, B), dim3(256), 0, opx, opy, op, k2, k1, N2, 512);
+            if (nsplit_m > 1) {
+                const long long n = (long long)B * k2 * k1;
+                DM_LAUNCH(ctx, "splitk_reduce", reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, part, nsplit_m, n, Gm);
+            }
+        }
+    }
+
+    // ---- descriptor commutativity: T_d = C L_d - R_d C;  G1 = sum_d T_d L_d^T;  G2 = sum_d R_d^T T_d
+    if (dcomm) {
+        double* T = (double*)dm_ws_take(ctx, (size_t)B * n_ops * k2 * k1 * 8);
+        double* part = (double*)dm_ws_take(ctx, (size_t)nsplit_d * bKK);
+        if (!T || !part) return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
+        const int Z = B * n_ops;
+        const dim3 gz(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, Z);
+        {
+            KRowsF64Bcast ca{C, (long long)k2 * k1, k1, k2, k1, 0, n_ops};
+            KRowsF64 lb{ops1, (long long)k1 * k1, k1, k1, k1, 1};          // (C L)_ij = sum_k C_ik L_kj
+            OutNT ot{T, (long long)k2 * k1, k1};
+            DM_LAUNCH(ctx, "dcomm_cl_nt_f64", (gemm_nt_f64<KRowsF64Bcast, KRowsF64, OutNT>), gz, dim3(256), 0, ca, lb, ot, k2, k1, k1);
+            KRowsF64 ra{ops2, (long long)k2 * k2, k2, k2, k2, 0};
+            KRowsF64Bcast cb{C, (long long)k2 * k1, k1, k1, k2, 1, n_ops};  // (R C)_ij = sum_k R_ik C_kj
+            OutNTSub os{T, (long long)k2 * k1, k1};
+            DM_LAUNCH(ctx, "dcomm_rc_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64Bcast, OutNTSub>), gz, dim3(256), 0, ra, cb, os, k2, k1, k2);
+        }
+        DM_LAUNCH(ctx, "dcomm_energy", half_sumsq_kernel, dim3(B), dim3(256), 0, T, (long long)n_ops * k2 * k1, e_dc);
+        {
+            KRowsF64Blocks ta{T, n_ops, k2, k1};
+            KRowsF64Blocks lb{ops1, n_ops, k1, k1};
+            OutNT og{G1, (long long)k2 * k1, k1};
+            DM_LAUNCH(ctx, "dcomm_tl_nt_f64", (gemm_nt_f64<KRowsF64Blocks, KRowsF64Blocks, OutNT>),
+                      dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ta, lb, og, k2, k1, n_ops * k1);
+            RowsF64TN rx{ops2, (long long)n_ops * k2 * k2, k2, k2};
+            RowsF64TN ty{T, (long long)n_ops * k2 * k1, k1, k1};
+            OutTNPartial op{nsplit_d > 1 ? part : G2, B, k2, k1};
+            DM_LAUNCH(ctx, "dcomm_rt_tn_f64", (gemm_tn_f64<RowsF64TN, RowsF64TN, OutTNPartial>),
+                      dim3(dm_cdiv(k2, TN_T) * dm_cdiv(k1, TN_T), nsplit_d, B), dim3(256), 0, rx, ty, op, k2, k1, n_ops * k2, 512);
+            if (nsplit_d > 1) {
+                const long long n = (long long)B * k2 * k1;
+                DM_LAUNCH(ctx, "splitk_reduce", reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, part, nsplit_d, n, G2);
+            }
+        }
+    }
+    DM_LAUNCH(ctx, "energy_combine", combine_kernel, dim3(B), dim3(256), 0, grad, m_terms ? Gm : (const double*)nullptr,
+              dcomm ? G1 : (const double*)nullptr, dcomm ? G2 : (const double*)nullptr, w[W_DCOMM], k1, k2, e_quad,
+              m_terms ? e_m : (const double*)nullptr, dcomm ? e_dc : (const double*)nullptr, energy);
+    return DM_OK;
+}
+
+// ops[b][d] = Phi^T diag(mass * F[:, d]) Phi   (k x k float64) for every descriptor d
+extern "C" int dm_fmap_descr_ops(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass, const void* F,
+                                 int f_dtype, double* ops) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N > 0 && D > 0 && k > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi && mass && F && ops, "null pointer");
+    DM_REQUIRE(ctx, ld >= k, "eigenvector row stride smaller than k");
+    DM_REQUIRE(ctx, f_dtype == DM_F16 || f_dtype == DM_F32, "f_dtype must be DM_F16 or DM_F32");
+    DM_REQUIRE(ctx, (long long)B * D <= 65535, "too many (pair, descriptor) slots for one launch: split the batch");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    RowsPhiTimesDescr opx{Phi, (long long)N * ld, ld, k, mass, N, F, f_dtype == DM_F16, D};
+    RowsPhiBatchDiv opy{Phi, (long long)N * ld, ld, k, D};
+    OutTNPartial out{ops, (long long)B * D, k, k};
+    DM_LAUNCH(ctx, "descr_ops_tn_f64", (gemm_tn_f64<RowsPhiTimesDescr, RowsPhiBatchDiv, OutTNPartial>),
+              dim3(dm_cdiv(k, TN_T) * dm_cdiv(k, TN_T), 1, B * D), dim3(256), 0, opx, opy, out, k, k, N, N);
+    return DM_OK;
+}

@@ -165,6 +165,101 @@ class MatchEngine:
                     f"(row {int(info[bad[0]]) - 1}): descriptors are rank deficient in the basis and w_lap cannot fix it")
         return Cm
 
+    WEIGHT_ORDER = ("w_descr", "w_lap", "w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1")
+
+    def descr_ops(self, Phi, mass, F, k=None):
+        """Multiplication operators of the descriptors in the reduced basis, Phi^T diag(mass * f_d) Phi -> (B,D,k,k) f64
+        (reference base_functions.py:550-555)."""
+        Phi = self._dev(Phi, torch.float32, "Phi")
+        mass = self._dev(mass, torch.float32, "mass")
+        if not isinstance(F, torch.Tensor):
+            F = torch.as_tensor(F)
+        fdt = torch.float16 if F.dtype == torch.float16 else torch.float32
+        F = self._dev(F, fdt, "F")
+        B, N, ld = Phi.shape
+        k = ld if k is None else k
+        D = F.shape[2]
+        ops = torch.empty((B, D, k, k), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_fmap_descr_ops(self.ctx, B, N, D, k, _ptr(Phi), ld, _ptr(mass), _ptr(F),
+                                             _lib.DM_F16 if fdt == torch.float16 else _lib.DM_F32, _ptr(ops)))
+        return ops
+
+    def energy_grad(self, Cm, A, Bm, lam1, lam2, weights, Phi1=None, Phi2=None, a1=None, ops1=None, ops2=None):
+        """Energy (B,) and gradient (B,k2,k1) of the functional-map objective for the weights in `weights` (dict with keys
+        of WEIGHT_ORDER; reference energy_func_std / grad_energy_std, base_functions.py:480-763)."""
+        Cm = self._dev(Cm, torch.float64, "C")
+        A = self._dev(A, torch.float32, "A")
+        Bm = self._dev(Bm, torch.float32, "Bm")
+        lam1 = self._dev(lam1, torch.float64, "lam1")
+        lam2 = self._dev(lam2, torch.float64, "lam2")
+        B, k2, k1 = Cm.shape
+        D = A.shape[2]
+        if A.shape != (B, k1, D) or Bm.shape != (B, k2, D) or lam1.shape != (B, k1) or lam2.shape != (B, k2):
+            raise ValueError("energy_grad: shapes do not agree")
+        unknown = set(weights) - set(self.WEIGHT_ORDER)
+        if unknown:
+            raise ValueError(f"energy_grad: unknown weights {sorted(unknown)}")
+        w = (C.c_double * 8)(*[float(weights.get(n, 0.0)) for n in self.WEIGHT_ORDER])
+        N1 = N2 = ld1 = ld2 = 1
+        if Phi1 is not None:
+            Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+            Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+            a1 = self._dev(a1, torch.float32, "a1")
+            _, N1, ld1 = Phi1.shape
+            _, N2, ld2 = Phi2.shape
+        n_ops = 0
+        if ops1 is not None:
+            ops1 = self._dev(ops1, torch.float64, "ops1")
+            ops2 = self._dev(ops2, torch.float64, "ops2")
+            n_ops = ops1.shape[1]
+            if ops1.shape != (B, n_ops, k1, k1) or ops2.shape != (B, n_ops, k2, k2):
+                raise ValueError("energy_grad: descriptor operators must be (B,D,k1,k1) and (B,D,k2,k2)")
+        energy = torch.empty((B,), dtype=torch.float64, device=self.device)
+        grad = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_fmap_energy_grad(self.ctx, B, N1, N2, k1, k2, D, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(A),
+                                               _ptr(Bm), _ptr(lam1), _ptr(lam2), _ptr(ops1), _ptr(ops2), n_ops,
+                                               C.cast(w, C.c_void_p), _ptr(Cm), _ptr(energy), _ptr(grad)))
+        return energy, grad
+
+    def fit_general(self, batch, weights, x0, k=None, maxiter=1000000, lbfgs_options=None):
+        """FunctionalMapping.fit for any of the implemented energy terms, a whole batch at once: L-BFGS-B
+        (scipy.optimize.minimize, as the reference, functional.py:477) on the sum of the pairs' energies -- the pairs are
+        independent, so the minimiser of the sum is the tuple of the pairs' minimisers -- with energy and gradient
+        evaluated on the GPU (one dm_fmap_energy_grad call per evaluation for the whole batch, float64).
+        x0 (B,k2,k1): start, its first column is the pinned one.  Returns (C (B,k2,k1) numpy, scipy result)."""
+        import numpy as np
+        import scipy.optimize
+        k1 = k if k is not None else batch["lam1"].shape[1]
+        k2 = k if k is not None else batch["lam2"].shape[1]
+        Phi1, Phi2 = batch["Phi1"], batch["Phi2"]
+        A = self.project(Phi1, batch["a1"], batch["F1"], k1)
+        Bm = self.project(Phi2, batch["a2"], batch["F2"], k2)
+        lam1 = self._dev(batch["lam1"], torch.float64, "lam1")[:, :k1].contiguous()
+        lam2 = self._dev(batch["lam2"], torch.float64, "lam2")[:, :k2].contiguous()
+        ops1 = ops2 = None
+        if weights.get("w_dcomm", 0) > 0:
+            ops1 = self.descr_ops(Phi1, batch["a1"], batch["F1"], k1)
+            ops2 = self.descr_ops(Phi2, batch["a2"], batch["F2"], k2)
+        P1 = self._dev(Phi1, torch.float32, "Phi1")[:, :, :k1].contiguous()
+        P2 = self._dev(Phi2, torch.float32, "Phi2")[:, :, :k2].contiguous()
+        a1 = self._dev(batch["a1"], torch.float32, "a1")
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B = x0.shape[0]
+        cache = {}
+
+        def fg(x):
+            key = x.tobytes()
+            if key not in cache:
+                cache.clear()
+                e, g = self.energy_grad(torch.from_numpy(x.reshape(B, k2, k1)), A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
+                cache[key] = (float(e.sum().item()), g.cpu().numpy().ravel())
+            return cache[key]
+
+        opts = {"maxiter": maxiter, "maxfun": 10 * maxiter}
+        opts.update(lbfgs_options or {})
+        res = scipy.optimize.minimize(lambda x: fg(x)[0], x0.ravel(), jac=lambda x: fg(x)[1], method="L-BFGS-B", options=opts)
+        return res.x.reshape(B, k2, k1), res
+
     def fm_to_p2p(self, Phi1, Phi2, a1, Cm, k1=None, k2=None, knn=True, ind=True):
         """Returns dict with knn21, knn12 (kd-tree maps of the reference) and ind21, ind12 (indicator arg-max)."""
         Phi1 = self._dev(Phi1, torch.float32, "Phi1")

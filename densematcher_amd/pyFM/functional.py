@@ -9,6 +9,10 @@ import numpy as np
 from . import refine, signatures as sg, spectral
 
 _OPTIMIZERS = ("L-BFGS-B", "fmin_l_bfgs_b", "l-bfgs-b")
+# L-BFGS-B stopping rule of the iterative fit.  The reference passes only maxiter (SciPy defaults ftol = 2.2e-9, gtol = 1e-5)
+# and evaluates in float32, which stops 1e-4 .. 1e-3 short of the minimiser; the float64 evaluation here
+# makes a tight rule meaningful, and the 1e-4 parity bar on C needs it.
+LBFGS_OPTIONS = {"ftol": 1e-15, "gtol": 1e-9, "maxcor": 30}
 
 
 class FunctionalMapping:
@@ -117,9 +121,11 @@ class FunctionalMapping:
     def fit(self, w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_orient=0, w_area=0, w_conformal=0, w_p2p=0, w_stochastic=0, w_ent=0,
             w_range01=0, w_sumto1=0, w_area_difference=0, w_mumford_shah=0, mumford_shah_var=0.1, w_eta_entropy=0,
             orient_reversing=False, optinit='zeros', verbose=False, maxiter=1000000, device=None):
-        """Minimiser of w_descr/2 |C A - B|^2 + w_lap/2 sum C^2 ev with the first column pinned: what the reference's
-        L-BFGS-B loop converges to, obtained in closed form.  Only the two quadratic
-        terms are on the GPU path; any other weight > 0 raises (SURVEY.md 'next #2')."""
+        """reference functional.py:352-487.  With only w_descr / w_lap > 0 the minimiser (what the reference's L-BFGS-B
+        converges to, first column pinned) is obtained in closed form on the GPU.  With
+        w_dcomm, w_p2p, w_stochastic, w_ent, w_range01 or w_sumto1 > 0 the reference's own scheme runs: L-BFGS-B
+        (scipy.optimize.minimize, :477) from get_x0(optinit), energy and gradient evaluated on the GPU in float64
+        (dm_fmap_energy_grad).  The remaining terms (orientation, area, conformal, Mumford-Shah) are not on the path."""
         from ..engine import default_engine
         if optinit not in ['random', 'identity', 'zeros']:
             raise ValueError(f"optinit arg should be 'random', 'identity' or 'zeros', not {optinit}")
@@ -127,13 +133,14 @@ class FunctionalMapping:
             raise ValueError(f"Unknown solver {self.optimizer}")
         if self.partial:
             raise NotImplementedError()                                        # functional.py:480
-        others = dict(w_dcomm=w_dcomm, w_orient=w_orient, w_area=w_area, w_conformal=w_conformal, w_p2p=w_p2p,
-                      w_stochastic=w_stochastic, w_ent=w_ent, w_range01=w_range01, w_sumto1=w_sumto1,
-                      w_area_difference=w_area_difference, w_mumford_shah=w_mumford_shah, w_eta_entropy=w_eta_entropy)
-        live = [n for n, v in others.items() if v > 0]
+        off_path = dict(w_orient=w_orient, w_area=w_area, w_conformal=w_conformal, w_area_difference=w_area_difference,
+                        w_mumford_shah=w_mumford_shah, w_eta_entropy=w_eta_entropy)
+        live = [n for n, v in off_path.items() if v > 0]
         if live:
-            raise NotImplementedError(f"energy terms {live} are not on the accelerated path (only w_descr, w_lap); pass 0")
-        if not (w_descr > 0 or w_lap > 0):
+            raise NotImplementedError(f"energy terms {live} are not on the accelerated path; pass 0")
+        general = dict(w_dcomm=w_dcomm, w_p2p=w_p2p, w_stochastic=w_stochastic, w_ent=w_ent, w_range01=w_range01, w_sumto1=w_sumto1)
+        iterative = any(v > 0 for v in general.values())
+        if not (w_descr > 0 or w_lap > 0 or iterative):
             raise ValueError("every energy weight is 0")                       # base_functions.py:534,639 would fail too
         if not self.preprocessed:
             self.preprocess()
@@ -151,11 +158,19 @@ class FunctionalMapping:
                  "F1": np.ascontiguousarray(d1, dtype=fdt)[None], "F2": np.ascontiguousarray(d2, dtype=fdt)[None]}
         dev = {n: eng._dev(v, {np.float16: __import__("torch").float16, np.float32: __import__("torch").float32,
                                np.float64: __import__("torch").float64}[v.dtype.type], n) for n, v in batch.items()}
-        A = eng.project(dev["Phi1"], dev["a1"], dev["F1"])
-        B = eng.project(dev["Phi2"], dev["a2"], dev["F2"])
-        c00 = eng.c00(dev["Phi1"], dev["Phi2"], dev["a1"], dev["a2"])
-        C = eng.fmap_solve(A, B, dev["lam1"], dev["lam2"], c00, w_descr, w_lap, check=True)
-        self.FM = C[0].cpu().numpy()
+        if iterative:
+            weights = dict(w_descr=w_descr, w_lap=w_lap, **general)
+            C, res = eng.fit_general(dev, weights, self.get_x0(optinit=optinit)[None], maxiter=maxiter, lbfgs_options=LBFGS_OPTIONS)
+            self.FM = C[0]
+            self.fit_result = res
+            if verbose:
+                print(f"\tTask funcall : {res.nfev}, nit : {res.nit}, warnflag : {res.message}")
+        else:
+            A = eng.project(dev["Phi1"], dev["a1"], dev["F1"])
+            B = eng.project(dev["Phi2"], dev["a2"], dev["F2"])
+            c00 = eng.c00(dev["Phi1"], dev["Phi2"], dev["a1"], dev["a2"])
+            C = eng.fmap_solve(A, B, dev["lam1"], dev["lam2"], c00, w_descr, w_lap, check=True)
+            self.FM = C[0].cpu().numpy()
         self.eta = np.ones(m2.eigenvectors.shape[0])                           # functional.py:483
         self._dev = dev
 

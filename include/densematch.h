@@ -122,6 +122,28 @@ int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D,
                   const double* lam1, const double* lam2, const double* c00,
                   double w_descr, double w_lap, double* C, int32_t* info);
 
+/* ---- general functional-map energy and gradient -----------------------------------
+ * What scipy's L-BFGS-B evaluates in FunctionalMapping.fit when energy terms beyond w_descr / w_lap are switched on:
+ * replaces energy_func_std / grad_energy_std (pyFM/optimize/base_functions.py:480-763) for the terms
+ *   weights[0..7] = w_descr, w_lap, w_dcomm, w_p2p, w_stochastic, w_ent, w_range01, w_sumto1   (HOST array of 8 doubles)
+ * i.e. descr_preservation :31, LB_commutation :79, oplist_commutation :168 (descriptor multiplication operators),
+ * p2p :296, doubly_stochastic :324, entropy :363, range01 :374, sumto1 :387 (eta == 1, v = None).
+ * energy (B) fp64 = the reference's energy value; grad (B,k2,k1) fp64 = its gradient with column 0 zeroed (:759).
+ * A (B,k1,D), Bm (B,k2,D) fp32 = the projections (dm_project); ops1 (B,n_ops,k1,k1), ops2 (B,n_ops,k2,k2) fp64 =
+ * dm_fmap_descr_ops of the two meshes (needed only when w_dcomm > 0; n_ops = number of descriptors).  The terms in the
+ * mapped indicator (last five weights) need Phi1, Phi2, mass1 and B*N2*N1 doubles of context workspace. */
+int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D,
+                        const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass1,
+                        const float* A, const float* Bm, const double* lam1, const double* lam2,
+                        const double* ops1 /*nullable*/, const double* ops2 /*nullable*/, int n_ops,
+                        const double* weights /*host, 8*/, const double* C, double* energy, double* grad);
+
+/* ops[b][d] = Phi[b][:, :k]^T diag(mass[b] * F[b][:, d]) Phi[b][:, :k]   (B, D, k, k) fp64: the multiplication operator
+ * of descriptor d in the reduced basis.  Replaces commute_left / commute_right of base_functions.py:550-555
+ * (pinv @ (descr[:, i, None] * evects), pinv = evects^T A, pyFM/functional.py:416-417).  B * D <= 65535 per call. */
+int dm_fmap_descr_ops(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass,
+                      const void* F, int f_dtype, double* ops);
+
 /* ---- functional map -> vertex maps ---------------------------------------
  * With G = Phi2[:, :k2] C Phi1[:, :k1]^T (never materialised):
  *   knn21[i] = argmin_j |C Phi1_j|^2 - 2 G_ij      (pyFM/spectral/convert.py:138-140)

@@ -48,3 +48,9 @@ def fx_cfg2_icp():
 @pytest.fixture(scope="session")
 def fx_cfg1_terms():
     return load_golden("fx_cfg1_terms.npz")
+
+
+@pytest.fixture(scope="session")
+def oracle_cfg1_fits():
+    """float64 minimisers computed by the ORACLE (tools/make_oracle_vectors.py), committed to save test time"""
+    return load_golden("oracle_cfg1_fits.npz")

@@ -140,7 +140,7 @@ def test_functional_mapping_and_surface_map(fx_cfg1, monkeypatch):
     model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
     model.preprocess(n_ev=(k, k), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
     with pytest.raises(NotImplementedError):
-        model.fit(w_descr=1e4, w_lap=1e3)                      # reference default w_dcomm=1 is not on the path
+        model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_area=1.0)    # area / conformal / orientation terms are off the path
     model.fit(**fit_params)
     assert model.FM.shape == (k, k) and model.FM.dtype == np.float64
     assert np.abs(model.FM - fx["C_f64"]).max() < 1e-4
@@ -227,3 +227,93 @@ def test_fit_on_spectral_signatures():
     print("energy: GPU", e_gpu, " reference fit", e_ref, " |C_gpu - C_fit| =", np.abs(model.FM - fx["C_fit_hks"]).max())
     assert e_gpu <= e_ref * (1 + 1e-12) and (e_ref - e_gpu) <= 1e-3 * e_ref
     assert np.array_equal(model.FM[:, 0], fx["C_fit_hks"][:, 0])                 # the pinned column (get_x0) is identical
+
+
+# --------------------------------------------------------------------------- #
+# the energy terms beyond w_descr / w_lap
+MIX = dict(w_descr=1e4, w_lap=1e3, w_dcomm=0.5, w_p2p=0.05, w_stochastic=0.02, w_ent=0.1, w_range01=1.0, w_sumto1=2.0)
+NOTEBOOK = dict(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_ent=1e-1, w_sumto1=1e1, optinit="zeros", maxiter=5000)   # example.ipynb cell 11
+
+
+def _terms_setup(fx, nd=None):
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    k = int(fx["k"])
+    F1, F2 = (fx["F1"], fx["F2"]) if nd is None else (fx["F1"][:, :nd].copy(), fx["F2"][:, :nd].copy())
+    e1, e2 = fx["Phi1"][:, :k].copy(), fx["Phi2"][:, :k].copy()
+    A = eng.project(e1[None], fx["a1"][None], F1[None], exact=True)
+    B = eng.project(e2[None], fx["a2"][None], F2[None], exact=True)
+    return eng, k, e1, e2, F1, F2, A, B
+
+
+def test_energy_terms_against_oracle(fx_cfg1, fx_cfg1_terms):
+    """dm_fmap_energy_grad: every term alone and all together, value and gradient, against the oracle (itself pinned to the
+    reference's torch functions at this very C, tests/test_oracle_golden.py) -- base_functions.py:480-763"""
+    fx, ft = fx_cfg1, fx_cfg1_terms
+    nd = 12
+    eng, k, e1, e2, F1, F2, A, B = _terms_setup(fx, nd)
+    C = ft["C_test"]
+    A64, B64 = A[0].cpu().numpy().astype(np.float64), B[0].cpu().numpy().astype(np.float64)
+    ev = orc.ev_sqdiff(fx["lam1"][:k], fx["lam2"][:k])
+    o1, o2 = orc.descr_ops(e1, fx["a1"], F1), orc.descr_ops(e2, fx["a2"], F2)
+    ops1 = eng.descr_ops(e1[None], fx["a1"][None], F1[None])
+    ops2 = eng.descr_ops(e2[None], fx["a2"][None], F2[None])
+    assert np.abs(ops1[0].cpu().numpy() - o1).max() <= 1e-13 * np.abs(o1).max()
+    assert np.abs(ops2[0].cpu().numpy() - o2).max() <= 1e-13 * np.abs(o2).max()
+    cases = [{n: v} for n, v in MIX.items()] + [MIX, {n: v for n, v in NOTEBOOK.items() if n.startswith("w_")}]
+    for w in cases:
+        E, G = eng.energy_grad(C[None], A, B, fx["lam1"][None, :k], fx["lam2"][None, :k], w, e1[None], e2[None], fx["a1"][None], ops1, ops2)
+        Eo, Go = orc.energy_grad_general(C, A64, B64, ev, e1, e2, fx["a1"], w, o1, o2)
+        E, G = float(E[0]), G[0].cpu().numpy()
+        assert abs(E - Eo) <= 1e-11 * abs(Eo), (w, E, Eo)
+        assert np.abs(G - Go).max() <= 1e-11 * max(np.abs(Go).max(), 1e-300), (w, np.abs(G - Go).max(), np.abs(Go).max())
+        assert np.all(G[:, 0] == 0)
+    # a batch evaluates every pair independently
+    E2, G2 = eng.energy_grad(np.stack([C, 0.5 * C]), A.repeat(2, 1, 1), B.repeat(2, 1, 1), np.stack([fx["lam1"][:k]] * 2),
+                             np.stack([fx["lam2"][:k]] * 2), MIX, np.stack([e1] * 2), np.stack([e2] * 2), np.stack([fx["a1"]] * 2),
+                             ops1.repeat(2, 1, 1, 1), ops2.repeat(2, 1, 1, 1))
+    E1, G1 = eng.energy_grad(C[None], A, B, fx["lam1"][None, :k], fx["lam2"][None, :k], MIX, e1[None], e2[None], fx["a1"][None], ops1, ops2)
+    assert float(E2[0]) == float(E1[0]) and np.array_equal(G2[0].cpu().numpy(), G1[0].cpu().numpy())
+
+
+def test_fit_with_notebook_params(fx_cfg1, fx_cfg1_terms, oracle_cfg1_fits):
+    """FunctionalMapping.fit with the reference notebook's fit_params (example.ipynb cell 11: w_ent = 0.1, w_sumto1 = 10):
+    within 1e-4 of the float64 minimiser of the reference energy, within the reference's fp32 noise floor of its own fit()
+    output, stationary and not worse than it on the oracle's energy"""
+    from densematcher_amd.pyFM import FunctionalMapping
+    fx = fx_cfg1
+    k = int(fx["k"])
+    model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
+    model.preprocess(n_ev=(k, k), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
+    model.fit(**NOTEBOOK)
+    C = model.FM
+    print("notebook fit:", model.fit_result.nit, "iterations,", model.fit_result.nfev, "evaluations;",
+          "|C - C_oracle| =", np.abs(C - oracle_cfg1_fits["C_nb"]).max(), " |C - C_fit(reference)| =", np.abs(C - fx_cfg1_terms["C_fit_nb"]).max())
+    assert np.abs(C - oracle_cfg1_fits["C_nb"]).max() <= 1e-4
+    assert np.abs(C - fx_cfg1_terms["C_fit_nb"]).max() <= 2e-3
+    assert np.array_equal(C[:, 0], model.get_x0()[:, 0])
+    e1, e2 = fx["Phi1"][:, :k], fx["Phi2"][:, :k]
+    A, B = orc.project(e1, fx["a1"], fx["F1"]), orc.project(e2, fx["a2"], fx["F2"])
+    ev = orc.ev_sqdiff(fx["lam1"][:k], fx["lam2"][:k])
+    w = {n: v for n, v in NOTEBOOK.items() if n.startswith("w_")}
+    Eg, Gg = orc.energy_grad_general(C, A, B, ev, e1, e2, fx["a1"], w)
+    Er, _ = orc.energy_grad_general(fx_cfg1_terms["C_fit_nb"], A, B, ev, e1, e2, fx["a1"], w)
+    # (the GPU objective uses the fp32-rounded projections of dm_project: the float64 oracle gradient at its minimiser is ~1e-5 relative)
+    assert Eg <= Er and np.abs(Gg).max() <= 1e-4 * max(1.0, abs(Eg))
+
+
+def test_fit_with_descriptor_commutativity(fx_cfg1, fx_cfg1_terms):
+    """the pyFM default w_dcomm = 1 (all 128 descriptor operators): the bare model.fit(w_descr, w_lap) call of the reference"""
+    from densematcher_amd.pyFM import FunctionalMapping
+    fx = fx_cfg1
+    k = int(fx["k"])
+    model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
+    model.preprocess(n_ev=(k, k), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
+    model.fit(w_descr=1e4, w_lap=1e3)                           # w_dcomm defaults to 1
+    Co, _ = orc.fit_general(fx["Phi1"][:, :k], fx["Phi2"][:, :k], fx["lam1"][:k], fx["lam2"][:k], fx["a1"], fx["a2"], fx["F1"], fx["F2"],
+                            dict(w_descr=1e4, w_lap=1e3, w_dcomm=1.0))
+    print("w_dcomm fit: |C - C_oracle| =", np.abs(model.FM - Co).max(), " |C - C_fit(reference)| =", np.abs(model.FM - fx_cfg1_terms["C_fit_dcomm"]).max())
+    assert np.abs(model.FM - Co).max() <= 1e-4
+    assert np.abs(model.FM - fx_cfg1_terms["C_fit_dcomm"]).max() <= 2e-3
+    with pytest.raises(NotImplementedError):
+        model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_orient=1.0)

@@ -149,3 +149,34 @@ def test_simnn_definition():
     assert np.array_equal(S[nn], T)
     S2 = np.concatenate([S, S[:5]])            # duplicates: lowest index wins
     assert np.array_equal(orc.simnn(T, S2), nn)
+
+
+def test_general_energy_terms_against_reference(fx_cfg1, fx_cfg1_terms):
+    """every further energy term of the restatement equals the reference's torch function (value and autograd gradient,
+    evaluated in float64 by tools/make_golden_r02.py) at a fixed C: base_functions.py:124-226, 296-428"""
+    fx, ft = fx_cfg1, fx_cfg1_terms
+    k = int(fx["k"])
+    e1, e2 = fx["Phi1"][:, :k].astype(np.float64), fx["Phi2"][:, :k].astype(np.float64)
+    C = ft["C_test"]
+    for name, w in (("p2p", "w_p2p"), ("stochastic", "w_stochastic"), ("ent", "w_ent"), ("range01", "w_range01"), ("sumto1", "w_sumto1")):
+        E, G = orc.m_terms_energy_grad(C, e1, e2, fx["a1"], **{w: 1.0})
+        assert abs(E - float(ft["E_" + name])) <= 1e-12 * abs(float(ft["E_" + name])), name
+        assert np.abs(G - ft["G_" + name]).max() <= 1e-12 * np.abs(ft["G_" + name]).max(), name
+    nd = int(ft["dcomm_ndescr"])
+    o1 = orc.descr_ops(e1, fx["a1"], fx["F1"][:, :nd])
+    o2 = orc.descr_ops(e2, fx["a2"], fx["F2"][:, :nd])
+    assert np.abs(o1 - ft["ops1"]).max() < 1e-14 and np.abs(o2 - ft["ops2"]).max() < 1e-14
+    E, G = orc.dcomm_energy_grad(C, o1, o2)
+    assert abs(E - float(ft["E_dcomm"])) <= 1e-12 * float(ft["E_dcomm"])
+    assert np.abs(G - ft["G_dcomm"]).max() <= 1e-12 * np.abs(ft["G_dcomm"]).max()
+
+
+def test_fit_with_descriptor_commutativity_against_reference(fx_cfg1, fx_cfg1_terms):
+    """the pyFM default w_dcomm = 1 (quadratic): the float64 L-BFGS-B of the restatement lands within the reference's fp32
+    noise floor of its fit() output"""
+    fx = fx_cfg1
+    k = int(fx["k"])
+    C, res = orc.fit_general(fx["Phi1"][:, :k], fx["Phi2"][:, :k], fx["lam1"][:k], fx["lam2"][:k], fx["a1"], fx["a2"], fx["F1"], fx["F2"],
+                             dict(w_descr=1e4, w_lap=1e3, w_dcomm=1.0))
+    assert np.abs(C - fx_cfg1_terms["C_fit_dcomm"]).max() < 2e-3
+    assert np.array_equal(C[:, 0], fx_cfg1_terms["C_fit_dcomm"][:, 0])
