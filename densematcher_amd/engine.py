@@ -293,6 +293,38 @@ class MatchEngine:
         self._chk(self.lib.dm_p2p_to_fm(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2), _ptr(Cm)))
         return Cm
 
+    def precise_map(self, Phi1, Phi2, Cm, faces1, dense=False):
+        """Barycentric projection of every vertex of mesh 2 onto the faces of mesh 1 in the spectral embedding (reference
+        get_precise_map, functional.py:221-251).  Returns (face_match (B,N2) int32, bary (B,N2,3) f64[, dense (B,N2,N1) f64])."""
+        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
+        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        Cm = self._dev(Cm, torch.float64, "C")
+        faces1 = self._dev(faces1, torch.int32, "faces1")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        k2, k1 = Cm.shape[1], Cm.shape[2]
+        nf = faces1.shape[1]
+        if faces1.shape != (B, nf, 3) or Cm.shape[0] != B:
+            raise ValueError("precise_map: faces1 must be (B,nf,3) and C (B,k2,k1)")
+        fm = torch.empty((B, N2), dtype=torch.int32, device=self.device)
+        bary = torch.empty((B, N2, 3), dtype=torch.float64, device=self.device)
+        M = torch.empty((B, N2, N1), dtype=torch.float64, device=self.device) if dense else None
+        info = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_precise_map(self.ctx, B, N1, N2, k1, k2, nf, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(Cm), _ptr(faces1),
+                                          _ptr(fm), _ptr(bary), _ptr(M), _ptr(info)))
+        return (fm, bary, M) if dense else (fm, bary)
+
+    def linear_sum_assignment(self, cost, maximize=False):
+        """Optimal assignment of every matrix of the batch `cost` (B,nr,nc) f64 -> col_of_row (B,nr) int32, -1 = unassigned
+        (identical to scipy.optimize.linear_sum_assignment, reference functional_map.py:57,66,78)."""
+        cost = self._dev(cost, torch.float64, "cost")
+        if cost.dim() != 3:
+            raise ValueError("linear_sum_assignment expects (B,nr,nc)")
+        B, nr, nc = cost.shape
+        out = torch.empty((B, nr), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_linear_sum_assignment(self.ctx, B, nr, nc, _ptr(cost), 1 if maximize else 0, _ptr(out)))
+        return out
+
     def p2p_to_fm_lstsq(self, p21, Phi1, Phi2, k1, k2):
         """argmin_X |Phi2[:, :k2] X - Phi1[p21, :k1]|_F (reference convert.py:51, no mass matrix) -> (B,k2,k1) f64."""
         Phi1 = self._dev(Phi1, torch.float32, "Phi1")

@@ -14,6 +14,19 @@ def _np(x):
     return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
 
 
+def _assign(matrix):
+    """scipy.optimize.linear_sum_assignment(matrix, maximize=True) (functional_map.py:57,66,78; eta == 1 after fit) on the GPU:
+    same algorithm and tie rules as SciPy, identical (row_ind, col_ind).  `matrix`: a MappedIndicator or a device tensor."""
+    from .engine import default_engine
+    eng = default_engine()
+    dev = matrix.device_tensor() if hasattr(matrix, "device_tensor") else matrix
+    if dev.dim() == 2:
+        dev = dev[None]
+    col = eng.linear_sum_assignment(dev, maximize=True)[0].cpu().numpy().astype(np.int64)
+    rows = np.nonzero(col >= 0)[0]
+    return rows, col[rows]
+
+
 def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, optimizer="fmin_l_bfgs_b", descr_type="neural",
                         maxiter=100000, optimize_p2p=False, fit_params=None):
     '''
@@ -41,26 +54,35 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
     p2p_21 = (model.mapped_indicator * model.eta[..., None]).argmax(axis=1)     # functional_map.py:49
     p2p_12 = (model.mapped_indicator * model.eta[..., None]).argmax(axis=0)     # functional_map.py:50
 
-    timing = os.environ.get("TIMEIT", False)
-    hungarian = hungarian_precise = None
+    timing = os.environ.get("TIMEIT", False)                                    # functional_map.py:52-54
+    if timing:
+        compute_extra = True
+
+    start_s = time.time()
+    hungarian = _assign(model.mapped_indicator) if compute_extra else None      # functional_map.py:57
+    if timing:
+        print("Hungarian for vanilla took", time.time() - start_s, "seconds")
+    start_s = time.time()
+    hungarian_precise = None
     if compute_extra:
-        # Hungarian on the dense indicator and the precise (barycentric) map: SURVEY.md 'next #3', not accelerated yet
-        raise NotImplementedError("compute_extra (Hungarian on the plain map, precise map) is not on the accelerated path yet")
+        precise = model._precise_map_device()                                   # functional_map.py:62 (get_precise_map().toarray())
+        if timing:
+            print("getting precise map took", time.time() - start_s, "seconds")
+        start_s = time.time()
+        hungarian_precise = _assign(precise)                                    # functional_map.py:66
+        if timing:
+            print("Hungarian for precise took", time.time() - start_s, "seconds")
 
     start_s = time.time()
     model.icp_refine()                                                          # functional_map.py:71, nit=10
     if timing:
         print("ICP refinement took", time.time() - start_s, "seconds")
+    start_s = time.time()
     p2p_21_icp_adjoint, p2p_12_icp_adjoint = model.get_p2p(n_jobs=1)
     p2p_21_icp = (model.mapped_indicator * model.eta[..., None]).argmax(axis=1)
     p2p_12_icp = (model.mapped_indicator * model.eta[..., None]).argmax(axis=0)
-    # functional_map.py:78: the reference always runs the Hungarian algorithm on the ICP indicator (host SciPy,
-    # 1-2 s at N = 2048).  It is NOT on the accelerated path (SURVEY.md 'next #3'): this is the reference's own SciPy
-    # call applied to the GPU-built dense matrix, kept so that the 14-tuple is complete.  DENSEMATCHER_HUNGARIAN=0
-    # skips it (slot 6 = None).
-    hungarian_icp = None
-    if os.environ.get("DENSEMATCHER_HUNGARIAN", "1") != "0":
-        from scipy.optimize import linear_sum_assignment
-        hungarian_icp = linear_sum_assignment(np.asarray(model.mapped_indicator), maximize=True)
+    hungarian_icp = _assign(model.mapped_indicator)                             # functional_map.py:78
+    if timing:
+        print("Hungarian for icp took", time.time() - start_s, "seconds")
     return (p2p_21, p2p_12, hungarian, hungarian_precise, p2p_21_icp, p2p_12_icp, hungarian_icp, model, model.mesh1, model.mesh2,
             p2p_21_adjoint, p2p_12_adjoint, p2p_21_icp_adjoint, p2p_12_icp_adjoint)

@@ -196,6 +196,22 @@ class FunctionalMapping:
                                                                        n_jobs=n_jobs)
         return p2p_21, p2p_12
 
+    def get_precise_map(self, precompute_dmin=True, use_adj=True, batch_size=None, n_jobs=1, verbose=False):
+        """functional.py:221-251: (n2, n1) sparse precise map from mesh2 to mesh1"""
+        if not self.fitted:
+            raise ValueError('Model should be fit and fit to obtain p2p map')
+        return spectral.mesh_FM_to_p2p_precise(self.FM, self.mesh1, self.mesh2, precompute_dmin=precompute_dmin, use_adj=use_adj,
+                                               batch_size=batch_size, n_jobs=n_jobs, verbose=verbose)
+
+    def _precise_map_device(self):
+        """get_precise_map().toarray() kept on the GPU (compute_surface_map feeds it to the assignment kernel)"""
+        from ..engine import default_engine
+        k2, k1 = self.FM.shape
+        return default_engine().precise_map(np.ascontiguousarray(self.mesh1.eigenvectors[:, :k1], dtype=np.float32)[None],
+                                            np.ascontiguousarray(self.mesh2.eigenvectors[:, :k2], dtype=np.float32)[None],
+                                            np.asarray(self.FM, dtype=np.float64)[None],
+                                            np.ascontiguousarray(self.mesh1.facelist, dtype=np.int32)[None], dense=True)[2][0]
+
     def icp_refine(self, nit=10, tol=None, use_adj=False, overwrite=True, verbose=False, n_jobs=1):
         """functional.py:564-586"""
         if not self.fitted:

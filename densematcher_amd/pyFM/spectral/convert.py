@@ -39,9 +39,15 @@ class MappedIndicator:
             return self._ind12
         return np.asarray(self).argmax(axis)
 
+    def device_tensor(self):
+        """the (n2, n1) matrix on the GPU (formed once by dm_mapped_indicator): input of the assignment kernel"""
+        if getattr(self, "_dev", None) is None:
+            self._dev = self._eng.mapped_indicator(*self._args)[0]
+        return self._dev
+
     def __array__(self, dtype=None, copy=None):
         if self._dense is None:
-            self._dense = self._eng.mapped_indicator(*self._args)[0].cpu().numpy()
+            self._dense = self.device_tensor().cpu().numpy()
         return self._dense if dtype is None else self._dense.astype(dtype)
 
     def __mul__(self, other):
@@ -85,6 +91,25 @@ def mesh_FM_to_p2p(FM_12, mesh1, mesh2, use_adj=False, subsample=None, n_jobs=1)
         return FM_to_p2p(FM_12, mesh1.eigenvectors[:, :k1], mesh2.eigenvectors[:, :k2], mesh1.A, use_adj=use_adj, n_jobs=n_jobs)
     sub1, sub2 = subsample
     return FM_to_p2p(FM_12, mesh1.eigenvectors[sub1, :k1], mesh2.eigenvectors[sub2, :k2], None, use_adj=use_adj, n_jobs=n_jobs)
+
+
+def mesh_FM_to_p2p_precise(FM_12, mesh1, mesh2, precompute_dmin=True, use_adj=True, batch_size=None, n_jobs=1, verbose=False):
+    """reference convert.py:185-229: (n2, n1) sparse matrix with the barycentric coordinates of the image of every vertex
+    of mesh 2 on mesh 1.  GPU: dm_precise_map (use_adj = True, the form get_precise_map uses; the memory / batching
+    switches of the reference have no counterpart)."""
+    from ...engine import default_engine
+    if not use_adj:
+        raise NotImplementedError("only the adjoint form (use_adj=True, the default of get_precise_map) is on the GPU path")
+    FM_12 = np.asarray(FM_12, dtype=np.float64)
+    k2, k1 = FM_12.shape
+    faces = np.ascontiguousarray(mesh1.facelist, dtype=np.int32)
+    fm, bary = default_engine().precise_map(np.ascontiguousarray(mesh1.eigenvectors[:, :k1], dtype=np.float32)[None],
+                                            np.ascontiguousarray(mesh2.eigenvectors[:, :k2], dtype=np.float32)[None], FM_12[None], faces[None])
+    fm, bary = fm[0].cpu().numpy().astype(np.int64), bary[0].cpu().numpy()
+    n2, n1 = mesh2.eigenvectors.shape[0], mesh1.eigenvectors.shape[0]
+    rows = np.tile(np.arange(n2), 3)                                         # projection_utils.py:360-399
+    cols = np.concatenate([faces[fm, 0], faces[fm, 1], faces[fm, 2]])
+    return sparse.csr_matrix((np.concatenate([bary[:, 0], bary[:, 1], bary[:, 2]]), (rows, cols)), shape=(n2, n1))
 
 
 def p2p_to_FM(p2p_21, evects1, evects2, A2=None):

@@ -467,3 +467,203 @@ def fit_general(phi1, phi2, lam1, lam2, a1, a2, F1, F2, weights, optinit="zeros"
         opts.update({"ftol": 1e-20, "gtol": 1e-10, "maxcor": 30})
     res = scipy.optimize.minimize(lambda x: fg(x)[0], x0.ravel(), jac=lambda x: fg(x)[1].ravel(), method="L-BFGS-B", options=opts)
     return res.x.reshape(k2, k1), res
+
+
+# --------------------------------------------------------------------------- #
+# linear assignment (functional_map.py:57,66,78: scipy.optimize.linear_sum_assignment(..., maximize=True))
+# --------------------------------------------------------------------------- #
+def linear_sum_assignment(cost, maximize=False):
+    """Third-party arithmetic: scipy.optimize.linear_sum_assignment (SciPy is unpinned in the reference's setup.py; the
+    build container has 1.15.3), i.e. the shortest-augmenting-path algorithm of D. F. Crouse, "On implementing 2D
+    rectangular assignment algorithms", IEEE TAES 52(4), 2016, as implemented in scipy/optimize/rectangular_lsap:
+    rows are augmented in order; each augmentation is a Dijkstra search over the columns in the order of a `remaining`
+    list that starts reversed and is compacted by swap-removal; among columns of equal tentative cost the first in scan
+    order wins unless an unassigned column ties, in which case the last unassigned one does; duals are updated after
+    each search.  Restated here step for step (pure Python: small cases only) so that the GPU kernel, which follows
+    the same steps, can be checked bit for bit; tests/test_oracle_golden.py checks this restatement against SciPy.
+    Returns (row_ind, col_ind) like SciPy."""
+    cost = np.array(cost, dtype=np.float64)
+    if maximize:
+        cost = -cost
+    transposed = cost.shape[0] > cost.shape[1]
+    if transposed:
+        cost = cost.T.copy()
+    nr, nc = cost.shape
+    u, v = np.zeros(nr), np.zeros(nc)
+    col4row, row4col = -np.ones(nr, dtype=np.int64), -np.ones(nc, dtype=np.int64)
+    path = -np.ones(nc, dtype=np.int64)
+    for cur in range(nr):
+        spc = np.full(nc, np.inf)
+        SR, SC = np.zeros(nr, dtype=bool), np.zeros(nc, dtype=bool)
+        remaining = [nc - it - 1 for it in range(nc)]
+        nrem, min_val, sink, i = nc, 0.0, -1, cur
+        while sink == -1:
+            index, lowest = -1, np.inf
+            SR[i] = True
+            for it in range(nrem):
+                j = remaining[it]
+                r = min_val + cost[i, j] - u[i] - v[j]
+                if r < spc[j]:
+                    path[j] = i
+                    spc[j] = r
+                if spc[j] < lowest or (spc[j] == lowest and row4col[j] == -1):
+                    lowest, index = spc[j], it
+            min_val = lowest
+            if not np.isfinite(min_val):
+                raise ValueError("cost matrix is infeasible")
+            j = remaining[index]
+            if row4col[j] == -1:
+                sink = j
+            else:
+                i = row4col[j]
+            SC[j] = True
+            nrem -= 1
+            remaining[index] = remaining[nrem]
+        u[cur] += min_val
+        for i2 in np.nonzero(SR)[0]:
+            if i2 != cur:
+                u[i2] += min_val - spc[col4row[i2]]
+        v[SC] -= min_val - spc[SC]
+        j = sink
+        while True:
+            i2 = path[j]
+            row4col[j] = i2
+            col4row[i2], j = j, col4row[i2]
+            if i2 == cur:
+                break
+    if transposed:
+        order = np.argsort(col4row)
+        return col4row[order], order
+    return np.arange(nr), col4row
+
+
+# --------------------------------------------------------------------------- #
+# precise (barycentric) map -- FunctionalMapping.get_precise_map, functional.py:221-251
+# --------------------------------------------------------------------------- #
+def _point_triangle(a, b, c, d, e, f, multi):
+    """Closest point of a triangle to a point, in the triangle's (s, t) coordinates -- D. Eberly's regions as coded in
+    pyFM/spectral/projection_utils.py.  multi = False: pointTriangleDistance (:731-998), used when a point has ONE
+    candidate face.  multi = True: the vectorised point_to_triangles_projection (:369-728), used otherwise; it differs
+    from the scalar code in region 4 only, where two of its squared distances are formed with the unclamped s / t
+    (:535, :559) -- kept, because the face with the smallest distance is chosen on these values.
+    Returns (s, t, squared distance)."""
+    det = a * c - b * b
+    s = b * e - c * d
+    t = b * d - a * e
+    if s + t <= det:
+        if s < 0.0:
+            if t < 0.0:                                           # region 4
+                if d < 0:
+                    if -d >= a:
+                        return 1.0, 0.0, a + 2.0 * d + f
+                    s_ = -d / a
+                    return s_, 0.0, (d * s + f) if multi else (d * s_ + f)
+                if e >= 0.0:
+                    return 0.0, 0.0, f
+                if -e >= c:
+                    return 0.0, 1.0, c + 2.0 * e + f
+                t_ = -e / c
+                return 0.0, t_, (e * t + f) if multi else (e * t_ + f)
+            if e >= 0:                                            # region 3
+                return 0.0, 0.0, f
+            if -e >= c:
+                return 0.0, 1.0, c + 2.0 * e + f
+            t_ = -e / c
+            return 0.0, t_, e * t_ + f
+        if t < 0:                                                 # region 5
+            if d >= 0:
+                return 0.0, 0.0, f
+            if -d >= a:
+                return 1.0, 0.0, a + 2.0 * d + f
+            s_ = -d / a
+            return s_, 0.0, d * s_ + f
+        inv = 1.0 / det                                           # region 0
+        s_, t_ = s * inv, t * inv
+        return s_, t_, s_ * (a * s_ + b * t_ + 2.0 * d) + t_ * (b * s_ + c * t_ + 2.0 * e) + f
+    if s < 0.0:                                                   # region 2
+        tmp0, tmp1 = b + d, c + e
+        if tmp1 > tmp0:
+            numer, denom = tmp1 - tmp0, a - 2.0 * b + c
+            if numer >= denom:
+                return 1.0, 0.0, a + 2.0 * d + f
+            s_ = numer / denom
+            t_ = 1 - s_
+            return s_, t_, s_ * (a * s_ + b * t_ + 2 * d) + t_ * (b * s_ + c * t_ + 2 * e) + f
+        if tmp1 <= 0.0:
+            return 0.0, 1.0, c + 2.0 * e + f
+        if e >= 0.0:
+            return 0.0, 0.0, f
+        t_ = -e / c
+        return 0.0, t_, e * t_ + f
+    if t < 0.0:                                                   # region 6
+        tmp0, tmp1 = b + e, a + d
+        if tmp1 > tmp0:
+            numer, denom = tmp1 - tmp0, a - 2.0 * b + c
+            if numer >= denom:
+                return 0.0, 1.0, c + 2.0 * e + f
+            t_ = numer / denom
+            s_ = 1 - t_
+            return s_, t_, s_ * (a * s_ + b * t_ + 2.0 * d) + t_ * (b * s_ + c * t_ + 2.0 * e) + f
+        if tmp1 <= 0.0:
+            return 1.0, 0.0, a + 2.0 * d + f
+        if d >= 0.0:
+            return 0.0, 0.0, f
+        s_ = -d / a
+        return s_, 0.0, d * s_ + f
+    numer = c + e - b - d                                         # region 1
+    if numer <= 0:
+        return 0.0, 1.0, c + 2.0 * e + f
+    denom = a - 2.0 * b + c
+    if numer >= denom:
+        return 1.0, 0.0, a + 2.0 * d + f
+    s_ = numer / denom
+    t_ = 1 - s_
+    return s_, t_, s_ * (a * s_ + b * t_ + 2.0 * d) + t_ * (b * s_ + c * t_ + 2.0 * e) + f
+
+
+def project_pc_to_triangles(vert_emb, faces, points_emb):
+    """For every point the face of the embedded mesh it projects onto and the barycentric coordinates of the projection
+    -- pyFM/spectral/projection_utils.py:16-115 (precompute_dmin = True): candidate faces are those whose nearest
+    vertex is closer than the point's nearest vertex plus the face's longest edge (:356), the closest projection wins
+    (first face index on equal distances).  Returns (face_match (n2,), bary (n2,3))."""
+    V = np.asarray(vert_emb, dtype=np.float64)
+    P = np.asarray(points_emb, dtype=np.float64)
+    faces = np.asarray(faces)
+    e0, e1, e2 = V[faces[:, 0]], V[faces[:, 1]], V[faces[:, 2]]
+    lmax = np.max(np.stack([np.linalg.norm(e1 - e0, axis=1), np.linalg.norm(e2 - e1, axis=1), np.linalg.norm(e0 - e2, axis=1)]), axis=0)   # :118-142
+    nn = knn_query(V, P)
+    Deltamin = np.linalg.norm(V[nn] - P, axis=1)                                                   # :145-178
+    vs, ps = np.linalg.norm(V, axis=1) ** 2, np.linalg.norm(P, axis=1) ** 2
+    face_match = np.zeros(P.shape[0], dtype=np.int64)
+    bary = np.zeros((P.shape[0], 3))
+    ax1, ax2 = e1 - e0, e2 - e0
+    fa, fb, fc = np.einsum("ij,ij->i", ax1, ax1), np.einsum("ij,ij->i", ax1, ax2), np.einsum("ij,ij->i", ax2, ax2)
+    for i in range(P.shape[0]):
+        dv = np.sqrt(np.maximum((-2.0 * (V @ P[i]) + vs) + ps[i], 0.0))                           # mycdist, :181-229
+        dmin = np.minimum(np.minimum(dv[faces[:, 0]], dv[faces[:, 1]]), dv[faces[:, 2]])           # :282-327
+        cand = np.where(dmin - lmax < Deltamin[i])[0]                                              # :356
+        multi = len(cand) > 1
+        best = None
+        for fi in cand:
+            diff = e0[fi] - P[i]
+            s, t, sq = _point_triangle(fa[fi], fb[fi], fc[fi], ax1[fi] @ diff, ax2[fi] @ diff, diff @ diff, multi)
+            dist = np.sqrt(max(sq, 0.0))
+            if best is None or dist < best[0]:
+                best = (dist, fi, s, t)
+        face_match[i] = best[1]
+        bary[i] = (1.0 - best[2] - best[3], best[2], best[3])
+    return face_match, bary
+
+
+def precise_map_dense(C, phi1, phi2, faces1):
+    """get_precise_map().toarray() -- functional.py:221-251 -> convert.py:185-229 (use_adj = True: emb1 = Phi1[:, :k1],
+    emb2 = Phi2[:, :k2] C) -> projection_utils.py:16,360-399 (three barycentric weights per row)."""
+    k2, k1 = C.shape
+    e1 = np.asarray(phi1[:, :k1], dtype=np.float64)
+    e2 = np.asarray(phi2[:, :k2], dtype=np.float64) @ C
+    fm, bary = project_pc_to_triangles(e1, faces1, e2)
+    M = np.zeros((e2.shape[0], e1.shape[0]))
+    faces1 = np.asarray(faces1)
+    for c in range(3):
+        np.add.at(M, (np.arange(e2.shape[0]), faces1[fm, c]), bary[:, c])
+    return M, fm, bary

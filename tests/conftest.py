@@ -54,3 +54,13 @@ def fx_cfg1_terms():
 def oracle_cfg1_fits():
     """float64 minimisers computed by the ORACLE (tools/make_oracle_vectors.py), committed to save test time"""
     return load_golden("oracle_cfg1_fits.npz")
+
+
+@pytest.fixture(scope="session")
+def fx_cfg1_precise():
+    return load_golden("fx_cfg1_precise.npz")
+
+
+@pytest.fixture(scope="session")
+def fx_cfg1_notebook_call():
+    return load_golden("fx_cfg1_notebook_call.npz")

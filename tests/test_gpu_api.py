@@ -189,8 +189,9 @@ def test_functional_mapping_and_surface_map(fx_cfg1, monkeypatch):
     qi = orc.fm_to_p2p_all(res[7].FM, e1, e2, fx["a1"])
     for got, ref in zip([res[12], res[13], res[4], res[5]], qi):
         assert np.array_equal(got, ref)
-    assert res[6] is not None and len(res[6]) == 2          # hungarian_icp (host SciPy passthrough)
-    assert res[2] is None and res[3] is None
+    assert res[6] is not None and len(res[6]) == 2          # hungarian_icp: the GPU assignment kernel (SciPy's algorithm)
+    assert np.array_equal(res[6][0], np.arange(500))
+    assert res[2] is None and res[3] is None                # compute_extra=False
 
 
 def test_fit_on_spectral_signatures():
@@ -317,3 +318,57 @@ def test_fit_with_descriptor_commutativity(fx_cfg1, fx_cfg1_terms):
     assert np.abs(model.FM - fx_cfg1_terms["C_fit_dcomm"]).max() <= 2e-3
     with pytest.raises(NotImplementedError):
         model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_orient=1.0)
+
+
+def test_compute_surface_map_notebook_call(fx_cfg1, fx_cfg1_notebook_call, monkeypatch):
+    """The reference's one documented call (example.ipynb cell 11) runs unchanged: notebook fit_params (w_ent, w_sumto1),
+    compute_extra=True (Hungarian on the plain map, precise map + Hungarian, ICP, Hungarian on the ICP map).  Every output is
+    pinned to the oracle on the SAME functional maps; against the reference's own tuple the agreement is reported
+    (its C comes from a float32 L-BFGS-B that stops 7e-4 away from the minimiser)."""
+    import scipy.optimize
+    from densematcher_amd.functional_map import compute_surface_map
+    from densematcher_amd.pyFM.mesh import TriMesh
+    fx, ref = fx_cfg1, fx_cfg1_notebook_call
+    k = int(fx["k"])
+    by_verts = [(fx["verts1"], 1), (fx["verts2"], 2)]
+
+    def process(self, k=200, **kw):
+        for vv, which in by_verts:
+            if np.array_equal(self.vertlist, vv):
+                src = _mesh(fx, which, k)
+                self.W, self.A, self.eigenvalues, self.eigenvectors = src.W, src.A, src.eigenvalues, src.eigenvectors
+                return self
+        raise RuntimeError("unknown mesh")
+
+    monkeypatch.setattr(TriMesh, "process", process)
+    res = compute_surface_map(_Duck(fx["verts1"], fx["faces1"]), _Duck(fx["verts2"], fx["faces2"]), fx["F1"], fx["F2"], n_ev=k,
+                              compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(NOTEBOOK))
+    assert len(res) == 14 and all(r is not None for r in res)
+    model = res[7]
+    e1, e2 = fx["Phi1"][:, :k].astype(np.float64), fx["Phi2"][:, :k].astype(np.float64)
+    C0, Ci = model._FM_base, model.FM
+    assert np.abs(C0 - ref["FM_base"]).max() <= 2e-3                       # the reference's fp32 noise floor
+    # plain map: maps, Hungarian, precise map + Hungarian -- oracle on the same C
+    q = orc.fm_to_p2p_all(C0, e1, e2, fx["a1"])
+    for got, want in zip([res[10], res[11], res[0], res[1]], q):
+        assert np.array_equal(got, want)
+    M0 = orc.mapped_indicator(C0, e1, e2, fx["a1"])
+    h0 = scipy.optimize.linear_sum_assignment(M0, maximize=True)
+    assert np.array_equal(res[2][0], h0[0])
+    assert abs(M0[res[2]].sum() - M0[h0].sum()) <= 1e-9 * abs(M0[h0].sum())    # (same objective; the GPU indicator differs in the last bits)
+    P0, _, _ = orc.precise_map_dense(C0, e1, e2, fx["faces1"])
+    hp = scipy.optimize.linear_sum_assignment(P0, maximize=True)
+    assert abs(P0[res[3]].sum() - P0[hp].sum()) <= 1e-9 * abs(P0[hp].sum())
+    # ICP map
+    assert np.abs(Ci - orc.icp_refine(C0, e1, e2, nit=10)).max() < 1e-8
+    qi = orc.fm_to_p2p_all(Ci, e1, e2, fx["a1"])
+    for got, want in zip([res[12], res[13], res[4], res[5]], qi):
+        assert np.array_equal(got, want)
+    Mi = orc.mapped_indicator(Ci, e1, e2, fx["a1"])
+    hi = scipy.optimize.linear_sum_assignment(Mi, maximize=True)
+    assert abs(Mi[res[6]].sum() - Mi[hi].sum()) <= 1e-9 * abs(Mi[hi].sum())
+    agree = {n: round(float((np.asarray(a) == ref[n]).mean()), 4) for n, a in
+             dict(p2p_21=res[0], p2p_12=res[1], hungarian_cols=res[2][1], hungarian_precise_cols=res[3][1], p2p_21_icp=res[4],
+                  p2p_12_icp=res[5], hungarian_icp_cols=res[6][1], p2p_21_adjoint=res[10], p2p_12_adjoint=res[11]).items()}
+    print("notebook call, agreement with the reference's tuple:", agree)
+    assert min(agree[n] for n in ("p2p_21", "p2p_12", "p2p_21_adjoint", "p2p_12_adjoint", "hungarian_cols")) >= 0.95

@@ -496,3 +496,64 @@ def test_icp_large_k(eng, k1, k2):
     assert int(_np(info)[0]) == 0
     Co = orc.icp_refine(C0, P1.astype(np.float64), P2.astype(np.float64), nit=3)
     assert np.abs(_np(C)[0] - Co).max() < 1e-8
+
+
+# --------------------------------------------------------------------------- #
+# linear assignment (the Hungarian outputs of compute_surface_map)
+def test_linear_sum_assignment_equals_scipy(eng):
+    """identical assignment to scipy.optimize.linear_sum_assignment (not only the same objective): real costs, integer
+    costs with many ties, sparse matrices as the precise map gives, rectangular both ways, both senses, batched"""
+    import scipy.optimize
+    rng = np.random.default_rng(3)
+    for trial, (nr, nc) in enumerate([(1, 1), (5, 9), (9, 5), (64, 64), (200, 230), (230, 200), (500, 500), (700, 512)]):
+        mats = []
+        for q in range(3):
+            c = rng.standard_normal((nr, nc))
+            if q == 1:
+                c = np.round(3 * c)
+            if q == 2:
+                c = c * (rng.random((nr, nc)) < 0.02)
+            mats.append(c)
+        for mx in (False, True):
+            got = _np(eng.linear_sum_assignment(np.stack(mats), maximize=mx))
+            for q, c in enumerate(mats):
+                r0, c0 = scipy.optimize.linear_sum_assignment(c, maximize=mx)
+                rows = np.nonzero(got[q] >= 0)[0]
+                assert np.array_equal(rows, r0) and np.array_equal(got[q][rows], c0), (nr, nc, q, mx)
+
+
+def test_hungarian_of_mapped_indicator(eng, fx_cfg1):
+    """functional_map.py:57,78: the assignment of the mapped indicator of the fixture's map equals the reference's
+    hungarian_icp output when computed from the reference's ICP map"""
+    import scipy.optimize
+    fx = fx_cfg1
+    k = int(fx["k"])
+    M = eng.mapped_indicator(_b(fx["Phi1"][:, :k].copy()), _b(fx["Phi2"][:, :k].copy()), _b(fx["a1"]), _b(fx["csm_FM"]))
+    got = _np(eng.linear_sum_assignment(M, maximize=True))[0]
+    r0, c0 = scipy.optimize.linear_sum_assignment(_np(M)[0], maximize=True)
+    assert np.array_equal(got, c0)
+    agree = (got == fx["csm_hungarian_icp_cols"]).mean()
+    print("hungarian_icp agreement with the reference tuple:", agree)
+    assert agree >= 0.999
+
+
+def test_precise_map_and_its_assignment(eng, fx_cfg1, fx_cfg1_precise):
+    """dm_precise_map against the reference's get_precise_map (tests/golden/fx_cfg1_precise.npz) and the oracle; the
+    assignment of the dense precise map (hungarian_precise, functional_map.py:62-66) against the reference's"""
+    fx = fx_cfg1
+    k = int(fx["k"])
+    P1, P2 = fx["Phi1"][:, :k].copy(), fx["Phi2"][:, :k].copy()
+    fm, bary, M = eng.precise_map(_b(P1), _b(P2), _b(fx["C_fit"]), _b(fx["faces1"].astype(np.int32)), dense=True)
+    Mo, fmo, baryo = orc.precise_map_dense(fx["C_fit"], P1.astype(np.float64), P2.astype(np.float64), fx["faces1"])
+    P = np.zeros_like(Mo)
+    P[fx_cfg1_precise["precise_rows"], fx_cfg1_precise["precise_cols"]] = fx_cfg1_precise["precise_vals"]
+    Mg = _np(M)[0]
+    print("precise map: faces equal to the oracle's:", (_np(fm)[0] == fmo).mean(), " max |M - M_reference| =", np.abs(Mg - P).max())
+    assert np.abs(Mg - P).max() < 1e-9 and np.abs(Mg - Mo).max() < 1e-9
+    assert np.abs(_np(bary)[0] - baryo)[_np(fm)[0] == fmo].max() < 1e-9
+    got = _np(eng.linear_sum_assignment(M, maximize=True))[0]
+    import scipy.optimize
+    assert np.array_equal(got, scipy.optimize.linear_sum_assignment(Mg, maximize=True)[1])
+    agree = (got == fx_cfg1_precise["hungarian_precise_cols"]).mean()
+    print("hungarian_precise agreement with the reference:", agree)
+    assert agree >= 0.99

@@ -180,3 +180,34 @@ def test_fit_with_descriptor_commutativity_against_reference(fx_cfg1, fx_cfg1_te
                              dict(w_descr=1e4, w_lap=1e3, w_dcomm=1.0))
     assert np.abs(C - fx_cfg1_terms["C_fit_dcomm"]).max() < 2e-3
     assert np.array_equal(C[:, 0], fx_cfg1_terms["C_fit_dcomm"][:, 0])
+
+
+def test_linear_sum_assignment_restatement_equals_scipy():
+    """the step-for-step restatement of SciPy's rectangular LSAP (third-party arithmetic of functional_map.py:57,66,78)
+    returns SciPy's assignment exactly: random real costs, integer costs with many ties, sparse 0/1-like matrices as
+    the precise map produces, rectangular both ways, maximize"""
+    import scipy.optimize
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        n = int(rng.integers(2, 45))
+        m = int(n + rng.integers(-6, 7))
+        m = max(m, 1)
+        c = rng.standard_normal((n, m))
+        if trial % 4 == 1:
+            c = np.round(2 * c)
+        if trial % 4 == 2:
+            c = c * (rng.random((n, m)) < 0.1)
+        mx = bool(trial % 2)
+        r0, c0 = scipy.optimize.linear_sum_assignment(c, maximize=mx)
+        r1, c1 = orc.linear_sum_assignment(c, maximize=mx)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (trial, n, m)
+
+
+def test_precise_map_against_reference(fx_cfg1, fx_cfg1_precise):
+    """get_precise_map: face choice and barycentric weights of every vertex equal the reference's sparse matrix"""
+    fx = fx_cfg1
+    M, fm, bary = orc.precise_map_dense(fx["C_fit"], fx["Phi1"].astype(np.float64), fx["Phi2"].astype(np.float64), fx["faces1"])
+    P = np.zeros_like(M)
+    P[fx_cfg1_precise["precise_rows"], fx_cfg1_precise["precise_cols"]] = fx_cfg1_precise["precise_vals"]
+    assert np.abs(M - P).max() < 1e-12
+    assert np.allclose(bary.sum(axis=1), 1.0)

@@ -9,6 +9,8 @@ the same inputs.
     fx_cfg1_terms.npz reference energy terms p2p / doubly_stochastic / entropy / range01 / sumto1 / op_commutation
                       (values and autograd gradients, float64 torch) at a fixed C, and the reference fit() with the
                       notebook's fit_params (example.ipynb cell 11: w_ent = 0.1, w_sumto1 = 10) and with w_dcomm = 1
+    fx_cfg1_notebook_call.npz the 14-tuple of compute_surface_map(compute_extra=True, notebook fit_params) on the config-1 pair
+    fx_cfg1_precise.npz reference get_precise_map (barycentric map) of the config-1 pair and its Hungarian assignment
 """
 import os
 import sys
@@ -94,11 +96,70 @@ def case_cfg1_terms():
     np.savez_compressed(os.path.join(OUT, "fx_cfg1_terms.npz"), **out)
 
 
+def case_cfg1_precise():
+    """reference get_precise_map of the config-1 pair from C_fit (sparse triplets) and the assignment of its dense form
+    (functional_map.py:62-66: hungarian_precise)"""
+    import scipy.optimize
+    fx = dict(np.load(os.path.join(OUT, "fx_cfg1.npz"), allow_pickle=False))
+    k = int(fx["k"])
+    m1, m2 = mg.truncated(mesh_from_fixture(fx, 1), k), mg.truncated(mesh_from_fixture(fx, 2), k)
+    model = mg.FunctionalMapping(m1, m2, partial=False, optimizer="L-BFGS-B")
+    model.descr1, model.descr2 = fx["F1"], fx["F2"]
+    model.FM = fx["C_fit"]
+    P = model.get_precise_map().toarray()                                   # functional.py:221-251
+    hp = scipy.optimize.linear_sum_assignment(P, maximize=True)
+    r, c = np.nonzero(P)
+    np.savez_compressed(os.path.join(OUT, "fx_cfg1_precise.npz"), precise_rows=r, precise_cols=c, precise_vals=P[r, c],
+                        hungarian_precise_cols=hp[1])
+    print("precise map: nnz per row", (P != 0).sum(1).max())
+
+
+def case_cfg1_notebook_call():
+    """the reference's documented call (example.ipynb cell 11): compute_surface_map(..., compute_extra=True, fit_params =
+    notebook values) on the config-1 pair, stored spectrum: every integer output of the 14-tuple"""
+    fx = dict(np.load(os.path.join(OUT, "fx_cfg1.npz"), allow_pickle=False))
+    k = int(fx["k"])
+    by_verts = [(fx["verts1"], 1), (fx["verts2"], 2)]
+    orig_process = mg.TriMesh.process
+
+    def patched(self, k=200, **kw):
+        for vv, which in by_verts:
+            if np.array_equal(self.vertlist, vv):
+                a = fx[f"a{which}"].astype(np.float64)
+                self.W = mg.ref_lap.cotangent_weights(fx[f"verts{which}"], fx[f"faces{which}"])
+                self.A = sp.diags(a).tocsr()
+                self.L = sp.diags(1.0 / a).tocsr() @ self.W
+                self.eigenvalues = fx[f"lam{which}"][:k].copy()
+                self.eigenvectors = fx[f"Phi{which}"][:, :k].astype(np.float64)
+                return self
+        raise RuntimeError("unknown mesh")
+
+    mg.TriMesh.process = patched
+    orig_fit = mg.FunctionalMapping.fit
+    mg.FunctionalMapping.fit = lambda self, **kw: orig_fit(self, **{**kw, "device": mg.CPU, "verbose": False})
+    try:
+        res = mg.compute_surface_map(mg._Duck(fx["verts1"], fx["faces1"]), mg._Duck(fx["verts2"], fx["faces2"]), fx["F1"], fx["F2"],
+                                     n_ev=k, compute_extra=True, optimizer="L-BFGS-B",
+                                     fit_params=dict(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_ent=1e-1, w_sumto1=1e1, optinit="zeros", maxiter=5000))
+    finally:
+        mg.TriMesh.process = orig_process
+        mg.FunctionalMapping.fit = orig_fit
+    np.savez_compressed(os.path.join(OUT, "fx_cfg1_notebook_call.npz"),
+                        p2p_21=res[0], p2p_12=res[1], hungarian_cols=res[2][1], hungarian_precise_cols=res[3][1],
+                        p2p_21_icp=res[4], p2p_12_icp=res[5], hungarian_icp_cols=res[6][1], FM=res[7].FM, FM_base=res[7]._FM_base,
+                        p2p_21_adjoint=res[10], p2p_12_adjoint=res[11], p2p_21_icp_adjoint=res[12], p2p_12_icp_adjoint=res[13])
+    print("notebook call: done")
+
+
 if __name__ == "__main__":
     np.random.seed(0)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["icp", "terms"]
+    which = sys.argv[1:] or ["icp", "terms", "precise", "notebook"]
     if "icp" in which:
         case_cfg2_icp()
     if "terms" in which:
         case_cfg1_terms()
+    if "precise" in which:
+        case_cfg1_precise()
+    if "notebook" in which:
+        case_cfg1_notebook_call()
