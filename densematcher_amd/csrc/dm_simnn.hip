@@ -317,7 +317,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //
 // XV = compile-time variant bits; the product instantiates SIMNN_PRODUCT_XV only, a DM_EXPERIMENTS build a list of them
 // (the ablations give WRONG results): low 4 bits: 1 skip the epilogue, 3 no norms, 7 LDS-DMA only, 8 no LDS-DMA, 9 = 8 + 1;
-// 16 / 32: K stagger by one stage / spread over the whole sweep; 64: fragment reads pinned in front of the MFMAs.
+// 16 / 32: K stagger by one stage / spread over the whole sweep; 64: fragment reads pinned in front of the MFMAs;
+// 128: the second wave of every SIMD runs its MFMAs first and its reads / DMA last inside each barrier interval.
+// Measured on config 3 (tools/simnn_experiment.py, profiles/r02_simnn_variants.txt): stagger helps the DMA-only
+// ablation (366 -> 268 us) but not the whole kernel; flipping the second wave changes nothing; the 4-wave shape hides
+// the epilogue (21 instead of 57 us) and loses more to its 1.5x DMA traffic.
 constexpr int PBK = 32;                    // halves per stage
 constexpr int SIMNN_PRODUCT_XV = 64;
 constexpr int SIMNN_PRODUCT_WT = 4;
@@ -347,6 +351,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     constexpr int dbg = XV & 15;
     constexpr int STAG = (XV >> 4) & 3;
     constexpr bool PINR = (XV & 64) != 0;
+    constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | scratch
     float* scratch = reinterpret_cast<float*>(smem + NBUF * PSTAGE);
 
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     constexpr bool NOEPI = (dbg & 7) == 1 || (dbg & 7) == 7;
     constexpr int EPI_ST = 8;                     // stores every wave issues in an epilogue: the 2 x 4 block maxima
     int r_slot = 0;                               // ring slot of the stage being computed
+    const bool late = FLIP && wave >= NW / 2;
 #define SIMNN_READ(fs_, ft_, slot_, fo_)                                                                               \
     if ((dbg & 7) != 7) {                                                                                              \
         const _Float16* Bs = smem + (slot_) * PSTAGE;                                                                  \
@@ -460,15 +466,17 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #define SIMNN_STAGE(NORMS, DMA_, VM_, NEXT_, ZERO_, AFTER_EPI_)                                                        \
     {                                                                                                                  \
         const int n_slot = (r_slot + 1 == NBUF) ? 0 : r_slot + 1;                                                      \
-        SIMNN_READ(fsb, ftb, r_slot, foff1)                                                                            \
-        if (DMA_) { SIMNN_DMA1(0) }                                                                                    \
-        SIMNN_PIN()                                                                                                    \
+        if (!late) { SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } SIMNN_PIN() }                       \
         SIMNN_MMA(fsa, fta, NORMS, ZERO_)                                                                              \
+        if (late) { SIMNN_PIN() SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } }                        \
         SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
-        if (NEXT_) { SIMNN_READ(fsa, fta, n_slot, foff0) }                                                             \
-        if (DMA_) { SIMNN_DMA1(1) }                                                                                    \
-        SIMNN_PIN()                                                                                                    \
+        if (!late) { if (NEXT_) { SIMNN_READ(fsa, fta, n_slot, foff0) } if (DMA_) { SIMNN_DMA1(1) } SIMNN_PIN() }        \
         SIMNN_MMA(fsb, ftb, NORMS, false)                                                                              \
+        if (late) { SIMNN_PIN() if (NEXT_) { SIMNN_READ(fsa, fta, n_slot, foff0) } if (DMA_) { SIMNN_DMA1(1) } }         \
+        /* the fragments of the next half-stage were requested eight MFMAs ago: make their arrival explicit here, or    \
+           the compiler, merging the loop back-edge, waits lgkmcnt(0) in FRONT of the next MFMAs -- i.e. for the reads   \
+           that were only just issued there */                                                                         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
         r_slot = n_slot;                                                                                               \
         if (DMA_) SIMNN_DMA_NEXT()                                                                                     \
     }
@@ -691,6 +699,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             SIMNN_CASE(64 + 1) SIMNN_CASE(64 + 7) SIMNN_CASE(64 + 9) SIMNN_CASE(64 + 16) SIMNN_CASE(64 + 32)
             SIMNN_CASE(64 + 32 + 1) SIMNN_CASE(64 + 32 + 7) SIMNN_CASE(64 + 32 + 9)
             SIMNN_CASE(64 + 2) SIMNN_CASE(64 + 4) SIMNN_CASE(64 + 6)
+            SIMNN_CASE(64 + 128) SIMNN_CASE(64 + 128 + 1) SIMNN_CASE(64 + 128 + 9)
 #undef SIMNN_CASE
             default: SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT) break;
         }

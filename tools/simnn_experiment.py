@@ -18,7 +18,7 @@ S = (S / S.norm(dim=2, keepdim=True)).to(torch.float16)
 T = (T / T.norm(dim=2, keepdim=True)).to(torch.float16)
 # (DM_SIMNN_DEBUG, simnn_persist)
 W8, W4 = 256, 512     # + 256: the 8-wave 256 x 256 shape (one workgroup per CU); + 512: 4 waves, 128 x 256, two per CU
-configs = [(W8 + 64, 1), (W8 + 64 + 1, 1), (W8 + 64 + 2, 1), (W8 + 64 + 4, 1), (W8 + 64 + 6, 1)] if len(sys.argv) < 2 else \
+configs = [(W8 + 64, 1), (W8 + 1024 + 64, 1), (W8 + 64 + 1, 1), (W8 + 1024 + 64 + 1, 1), (W8 + 64 + 9, 1), (W8 + 1024 + 64 + 9, 1)] if len(sys.argv) < 2 else \
     [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
 res = {c: [] for c in configs}
 ref = (T[3].double() @ S[3].double().T).argmax(dim=1)
