@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Per-kernel averages of every counter in one or more rocprofv3 `--pmc ... --output-format csv` result files, with the
 derived quantities the roofline discussion needs:
-    effective clock      = GRBM_GUI_ACTIVE / kernel duration          (MI355X_MICROARCH.md, "DVFS give-back")
-    MFMA utilisation     = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x CUs x GRBM_GUI_ACTIVE)
+    effective clock      = GRBM_GUI_ACTIVE / 8 / kernel duration      (MI355X_MICROARCH.md, "DVFS give-back"; rocprofv3 reports the
+                           counter summed over the 8 XCDs' GRBMs: the raw quotient would be 15 GHz)
+    MFMA utilisation     = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)
+                           (SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles x number of 32x32x16 MFMA wave-instructions, summed over the chip)
 
     python tools/pmc_counters.py out.csv kernel_substring file1_counter_collection.csv [file2 ...]
 """
@@ -36,12 +38,13 @@ def main():
     lines += [f"{c},{v:.6g}" for c, v in avg.items()]
     lines.append(f"kernel_duration_ns_under_pmc,{avg_ns:.6g}")
     if "GRBM_GUI_ACTIVE" in avg:
-        lines.append(f"effective_clock_GHz,{avg['GRBM_GUI_ACTIVE'] / avg_ns:.4f}")
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg:
-        for ncu in (256,):
-            lines.append(f"mfma_util_vs_{ncu}cu_x4simd,{avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * ncu * avg['GRBM_GUI_ACTIVE']):.4f}")
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "SQ_BUSY_CYCLES" in avg:
-        lines.append(f"mfma_busy_over_sq_busy,{avg['SQ_VALU_MFMA_BUSY_CYCLES'] / avg['SQ_BUSY_CYCLES']:.4f}")
+        cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
+        lines.append(f"elapsed_cycles_per_xcd,{cyc:.6g}")
+        lines.append(f"effective_clock_GHz,{cyc / avg_ns:.4f}")
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
+            lines.append(f"mfma_pipe_busy_fraction,{avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * cyc):.4f}")
+    if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
+        lines.append(f"l2_hit_rate,{avg['TCC_HIT_sum'] / (avg['TCC_HIT_sum'] + avg['TCC_MISS_sum']):.4f}")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
