@@ -39,6 +39,7 @@ SIGNATURES = {
     "dm_knn_query_f64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "dm_mapped_indicator": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_p2p_to_fm": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
+    "dm_eigenbasis": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dm_precise_map": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_linear_sum_assignment": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "dm_p2p_to_fm_lstsq": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),

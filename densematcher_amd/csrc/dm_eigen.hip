@@ -1,0 +1,416 @@
+// Laplace-Beltrami eigenbasis on the device (dm_eigenbasis): SURVEY.md 8(f) #4.
+//
+// Reference computation replaced: TriMesh.process -> laplacian_spectrum (pyFM/mesh/trimesh.py:440-531) ->
+// laplacian.laplacian_spectrum (pyFM/mesh/laplacian.py:143-182): scipy.sparse.linalg.eigsh(W, k, M=A, sigma=-0.01)
+// (ARPACK shift-invert, a host sparse factorisation + Lanczos): the k smallest eigenpairs of W phi = lambda A phi,
+// Phi^T A Phi = I.  ARPACK starts from a random vector and multiple eigenvalues come out in an arbitrary basis, so
+// there is no bit parity to keep; the tests compare eigenvalues, invariant subspaces and the
+// vertex maps built on the basis.
+//
+// GPU formulation: Chebyshev-filtered subspace iteration on the symmetric standard form L = A^-1/2 W A^-1/2 (the caller
+// passes L in ELL format: the sparsity pattern of a mesh Laplacian is its vertex adjacency, host bookkeeping as in the
+// reference).  m = k + guard vectors; every outer iteration is
+//     Rayleigh-Ritz:  H = X^T L X (m x m)  ->  cyclic two-sided Jacobi eigensolver (one workgroup per mesh)  ->  X <- X Q
+//     filter:         Y = T_d((L - c) / e) X   three-term recurrence, d sparse products (SpMM) with fused axpby,
+//                     damping [theta_m, lambda_max(Gershgorin)], normalised at theta_0
+//     orthonormalise: columns scaled to unit length (a filtered Ritz vector keeps its direction: the block stays well
+//                     conditioned, cond < 1e3 with the degree ramp 4, 8, 16, 30 ...), then the orthogonal polar factor
+//                     by the matrix-polynomial iteration of dm_icp.hip (GEMMs only, no Cholesky, no size limit)
+// All dense work runs on the f64 matrix cores through the gemm tiles of dm_gemm_f64.h.  No host synchronisation: the
+// iteration count is an argument and the residual max_j |L x_j - theta_j x_j| is returned per mesh.
+#include "dm_gemm_f64.h"
+#include "dm_internal.h"
+
+static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+
+constexpr int EIG_NS_LIFT = 12, EIG_NS_POLISH = 8;
+constexpr double EIG_NS_A = 3.4445, EIG_NS_B = -4.7750, EIG_NS_C = 2.0315;
+constexpr int EIG_MAX_DEG = 64;
+
+// ---- functors ---------------------------------------------------------------------------------------------------------
+struct EigRowsTN {                  // K-major float64 operand for gemm_tn_f64: rows n of a (B, nrows, ld) matrix
+    const double* p; long long stride_b; int ld; int ncols;
+    __device__ __forceinline__ void load4(int b, int n, int col0, double (&v)[4]) const {
+        const double* row = p + b * stride_b + (long long)n * ld;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (col0 + e < ncols) ? row[col0 + e] : 0.0;
+    }
+};
+struct EigOutTNPartial {
+    double* p; long long Z; int M; int N;
+    __device__ __forceinline__ void store(int z, int split, int m, int c, double v) const {
+        p[(((long long)split * Z + z) * M + m) * N + c] = v;
+    }
+};
+struct EigOutNT {
+    double* p; long long stride_b; int ld;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] = v; }
+};
+struct EigOutAxpby {                // Xnew = alpha Xold + beta (product)
+    const double* xo; double* xn; long long stride_b; int ld; double alpha, beta;
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const {
+        const long long o = b * stride_b + (long long)i * ld + j;
+        xn[o] = alpha * xo[o] + beta * v;
+    }
+};
+
+__global__ __launch_bounds__(256) void eig_reduce_partials_kernel(const double* __restrict__ partial, int nsplit, long long n,
+                                                                  double* __restrict__ out, int symmetrise_m) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += partial[(long long)q * n + i];
+    if (symmetrise_m > 0) {         // (H + H^T) / 2: the Jacobi sweeps assume exact symmetry
+        const long long mm = (long long)symmetrise_m * symmetrise_m;
+        const long long b = i / mm, e = i - b * mm;
+        const int r = (int)(e / symmetrise_m), c = (int)(e - (long long)r * symmetrise_m);
+        const long long j = b * mm + (long long)c * symmetrise_m + r;
+        double s2 = 0.0;
+        for (int q = 0; q < nsplit; ++q) s2 += partial[(long long)q * n + j];
+        s = 0.5 * (s + s2);
+    }
+    out[i] = s;
+}
+
+// ---- sparse product with the fused three-term recurrence ------------------------------------------------------------------
+// Ynew[i][c] = alpha (sum_nz L[i][n] Y[n][c] - cc Y[i][c]) - beta Yprev[i][c];  (alpha, cc, beta) = coef[b][step] or (1, 0, 0)
+__global__ __launch_bounds__(256) void spmm_ell_kernel(const double* __restrict__ vals, const int32_t* __restrict__ cols, int N, int nnz,
+                                                       const double* __restrict__ Y, const double* __restrict__ Yprev,
+                                                       double* __restrict__ Ynew, int m, const double* __restrict__ coef, int step) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= m) return;
+    const double* Yb = Y + (long long)b * N * m;
+    const double* vr = vals + ((long long)b * N + i) * nnz;
+    const int32_t* cr = cols + ((long long)b * N + i) * nnz;
+    double acc = 0.0;
+    for (int q = 0; q < nnz; ++q) acc += vr[q] * Yb[(long long)cr[q] * m + c];
+    double alpha = 1.0, cc = 0.0, beta = 0.0;
+    if (coef) { const double* k = coef + ((long long)b * EIG_MAX_DEG + step) * 3; alpha = k[0]; cc = k[1]; beta = k[2]; }
+    double out = alpha * (acc - cc * Yb[(long long)i * m + c]);
+    if (Yprev && beta != 0.0) out -= beta * Yprev[((long long)b * N + i) * m + c];
+    Ynew[((long long)b * N + i) * m + c] = out;
+}
+
+// lmax[b] = max_i sum_q |L[i][q]|   (Gershgorin bound of the largest eigenvalue)
+__global__ __launch_bounds__(256) void gershgorin_kernel(const double* __restrict__ vals, int N, int nnz, double* __restrict__ lmax) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    double mx = 0.0;
+    for (int i = t; i < N; i += 256) {
+        const double* vr = vals + ((long long)b * N + i) * nnz;
+        double s = 0.0;
+        for (int q = 0; q < nnz; ++q) s += fabs(vr[q]);
+        mx = fmax(mx, s);
+    }
+    sh[t] = mx;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (t < off) sh[t] = fmax(sh[t], sh[t + off]); __syncthreads(); }
+    if (t == 0) lmax[b] = sh[0];
+}
+
+// coefficients of the scaled Chebyshev recurrence of degree `deg` damping [theta[m-1], lmax], normalised at theta[0]
+// (Y_1 = (sigma_1 / e)(L - c) X;  Y_{j+1} = (2 sigma_{j+1} / e)(L - c) Y_j - sigma_j sigma_{j+1} Y_{j-1})
+__global__ void cheb_coef_kernel(const double* __restrict__ theta, int m, const double* __restrict__ lmax, int deg, double* __restrict__ coef) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const double a0 = theta[(long long)b * m], a = theta[(long long)b * m + m - 1];
+    const double bb = fmax(lmax[b], a * (1.0 + 1e-6) + 1e-300);
+    const double e = 0.5 * (bb - a), c = 0.5 * (bb + a);
+    const double sigma1 = e / (a0 - c);
+    double sig_prev = sigma1;
+    double* k = coef + (long long)b * EIG_MAX_DEG * 3;
+    k[0] = sigma1 / e; k[1] = c; k[2] = 0.0;
+    for (int j = 2; j <= deg; ++j) {
+        const double sig = 1.0 / (2.0 / sigma1 - sig_prev);
+        k[(j - 1) * 3] = 2.0 * sig / e; k[(j - 1) * 3 + 1] = c; k[(j - 1) * 3 + 2] = sig_prev * sig;
+        sig_prev = sig;
+    }
+}
+
+// ---- dense helpers -----------------------------------------------------------------------------------------------------------
+// X[b][:, c] <- scale * X[b][:, c] / |X[b][:, c]|     (one workgroup per column)
+__global__ __launch_bounds__(256) void unit_columns_kernel(double* __restrict__ X, int N, int m, double scale) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    double* col = X + (long long)b * N * m + c;
+    double s = 0.0;
+    for (int i = t; i < N; i += 256) { const double v = col[(long long)i * m]; s += v * v; }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (t < off) sh[t] += sh[t + off]; __syncthreads(); }
+    const double nrm = sqrt(sh[0]);
+    const double f = nrm > 0.0 ? scale / nrm : 0.0;
+    for (int i = t; i < N; i += 256) col[(long long)i * m] *= f;
+}
+
+// resid[b] = max_{c < k} |LX[:, c] - theta_c X[:, c]|   (one workgroup per column; max through ordered-bits atomicMax)
+__global__ __launch_bounds__(256) void ritz_residual_kernel(const double* __restrict__ X, const double* __restrict__ LX, int N, int m,
+                                                            const double* __restrict__ theta, unsigned long long* __restrict__ resid_bits) {
+    __shared__ double sh[256];
+    const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const double th = theta[(long long)b * m + c];
+    double s = 0.0;
+    for (int i = t; i < N; i += 256) {
+        const long long o = ((long long)b * N + i) * m + c;
+        const double r = LX[o] - th * X[o];
+        s += r * r;
+    }
+    sh[t] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (t < off) sh[t] += sh[t + off]; __syncthreads(); }
+    if (t == 0) atomicMax(resid_bits + b, (unsigned long long)__double_as_longlong(sqrt(sh[0])));   // (non-negative doubles order like their bits)
+}
+
+// Cyclic two-sided Jacobi eigensolver of a symmetric m x m matrix (m <= 512), one workgroup of 1024 threads per matrix,
+// round-robin ordering (m/2 disjoint rotations per round: the row updates of a round are independent, then the column
+// updates of H and of the accumulated eigenvectors V).  H is overwritten (diagonal = eigenvalues), V (m x m, columns).
+__global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ Hs, double* __restrict__ Vs, int m, int max_sweeps) {
+    __shared__ double rc[256], rs[256];
+    __shared__ int rp[256], rq[256];
+    __shared__ unsigned long long s_off, s_diag;
+    const int b = blockIdx.x, t = threadIdx.x;
+    double* H = Hs + (long long)b * m * m;
+    double* V = Vs + (long long)b * m * m;
+    const int mm = m + (m & 1), half = mm / 2;
+    for (int e = t; e < m * m; e += 1024) V[e] = (e / m == e % m) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (t == 0) { s_off = 0ull; s_diag = 0ull; }
+        __syncthreads();
+        for (int r = 0; r < mm - 1; ++r) {
+            if (t < half) {
+                int p, q;
+                if (t == 0) { p = mm - 1; q = r; }
+                else { p = (r + t) % (mm - 1); q = (r - t + (mm - 1)) % (mm - 1); }
+                if (p > q) { const int x = p; p = q; q = x; }
+                double c = 1.0, s = 0.0;
+                if (q < m) {
+                    const double a = H[(long long)p * m + p], d = H[(long long)q * m + q], bq = H[(long long)p * m + q];
+                    atomicMax(&s_off, (unsigned long long)__double_as_longlong(fabs(bq)));
+                    atomicMax(&s_diag, (unsigned long long)__double_as_longlong(fmax(fabs(a), fabs(d))));
+                    if (fabs(bq) > 1e-300) {
+                        const double tau = (d - a) / (2.0 * bq);
+                        const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + tt * tt);
+                        s = tt * c;
+                    }
+                }
+                rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = s;
+            }
+            __syncthreads();
+            for (int idx = t; idx < half * m; idx += 1024) {              // rows p, q <- J^T rows
+                const int pr = idx / m, j = idx - pr * m;
+                const double s = rs[pr];
+                if (s != 0.0) {
+                    const double c = rc[pr];
+                    const long long op = (long long)rp[pr] * m + j, oq = (long long)rq[pr] * m + j;
+                    const double hp = H[op], hq = H[oq];
+                    H[op] = c * hp - s * hq; H[oq] = s * hp + c * hq;
+                }
+            }
+            __syncthreads();
+            for (int idx = t; idx < half * m; idx += 1024) {              // columns p, q <- columns J   (H and V)
+                const int i = idx / half, pr = idx - i * half;
+                const double s = rs[pr];
+                if (s != 0.0) {
+                    const double c = rc[pr];
+                    const long long op = (long long)i * m + rp[pr], oq = (long long)i * m + rq[pr];
+                    const double hp = H[op], hq = H[oq];
+                    H[op] = c * hp - s * hq; H[oq] = s * hp + c * hq;
+                    const double vp = V[op], vq = V[oq];
+                    V[op] = c * vp - s * vq; V[oq] = s * vp + c * vq;
+                }
+            }
+            __syncthreads();
+        }
+        const double off = __longlong_as_double((long long)s_off), dg = __longlong_as_double((long long)s_diag);
+        __syncthreads();
+        if (off <= 1e-15 * dg) break;
+    }
+}
+
+// theta[b] = sorted diagonal of H; Q[b][:, rank] = V[b][:, j]   (ascending; equal values keep their index order)
+__global__ __launch_bounds__(256) void ritz_sort_kernel(const double* __restrict__ Hs, const double* __restrict__ Vs, int m,
+                                                        double* __restrict__ theta, double* __restrict__ Q) {
+    extern __shared__ double sd[];               // m diagonal values, then m ranks (as ints)
+    int* rank = reinterpret_cast<int*>(sd + m);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double* H = Hs + (long long)b * m * m;
+    const double* V = Vs + (long long)b * m * m;
+    for (int j = t; j < m; j += 256) sd[j] = H[(long long)j * m + j];
+    __syncthreads();
+    for (int j = t; j < m; j += 256) {
+        const double v = sd[j];
+        int r = 0;
+        for (int i = 0; i < m; ++i) r += (sd[i] < v || (sd[i] == v && i < j)) ? 1 : 0;
+        rank[j] = r;
+        theta[(long long)b * m + r] = v;
+    }
+    __syncthreads();
+    for (int e = t; e < m * m; e += 256) {
+        const int i = e / m, j = e - i * m;
+        Q[(long long)b * m * m + (long long)i * m + rank[j]] = V[e];
+    }
+}
+
+// Phi[b][i][c] = X[b][i][c] / sqrt(mass[b][i]) for c < k, sign fixed so that the entry of largest magnitude is positive;
+// lam[b][c] = theta[b][c]
+__global__ __launch_bounds__(256) void eig_finish_kernel(const double* __restrict__ X, int N, int m, int k, const float* __restrict__ mass,
+                                                         const double* __restrict__ theta, double* __restrict__ Phi, double* __restrict__ lam) {
+    __shared__ double sh[256];
+    __shared__ int shi[256];
+    const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    double best = -1.0; int bi = 0;
+    for (int i = t; i < N; i += 256) {
+        const double v = fabs(X[((long long)b * N + i) * m + c]);
+        if (v > best) { best = v; bi = i; }
+    }
+    sh[t] = best; shi[t] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off && (sh[t + off] > sh[t] || (sh[t + off] == sh[t] && shi[t + off] < shi[t]))) { sh[t] = sh[t + off]; shi[t] = shi[t + off]; }
+        __syncthreads();
+    }
+    const double sgn = X[((long long)b * N + shi[0]) * m + c] < 0.0 ? -1.0 : 1.0;
+    for (int i = t; i < N; i += 256)
+        Phi[((long long)b * N + i) * k + c] = sgn * X[((long long)b * N + i) * m + c] / sqrt((double)mass[(long long)b * N + i]);
+    if (t == 0) lam[(long long)b * k + c] = theta[(long long)b * m + c];
+}
+
+// ---- building blocks on the host side ------------------------------------------------------------------------------------------
+struct eig_ws {
+    int B, N, m;
+    double *T, *W, *part;           // m x m scratch (x2) and split-K partials
+    int nsplit;
+};
+// G (B, m, m) = P^T R over the N rows (split-K, fixed order); symmetrised when asked
+static int eig_gram(dm_ctx* ctx, const eig_ws& w, const double* P, const double* R, double* G, int symmetrise) {
+    EigRowsTN px{P, (long long)w.N * w.m, w.m, w.m};
+    EigRowsTN ry{R, (long long)w.N * w.m, w.m, w.m};
+    EigOutTNPartial out{w.part, w.B, w.m, w.m};
+    DM_LAUNCH(ctx, "eig_gram_tn_f64", (gemm_tn_f64<EigRowsTN, EigRowsTN, EigOutTNPartial>),
+              dim3(dm_cdiv(w.m, TN_T) * dm_cdiv(w.m, TN_T), w.nsplit, w.B), dim3(256), 0, px, ry, out, w.m, w.m, w.N, 512);
+    const long long n = (long long)w.B * w.m * w.m;
+    DM_LAUNCH(ctx, "eig_reduce", eig_reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w.part, w.nsplit, n, G,
+              symmetrise ? w.m : 0);
+    return DM_OK;
+}
+// Xout = alpha Xin + beta Xin M   (N x m times m x m; M read as is, it is symmetric or already the wanted factor)
+static int eig_apply(dm_ctx* ctx, const eig_ws& w, const double* Xin, const double* M, int transM, double alpha, double beta, double* Xout) {
+    KRowsF64 xa{Xin, (long long)w.N * w.m, w.m, w.N, w.m, 0};
+    KRowsF64 mb{M, (long long)w.m * w.m, w.m, w.m, w.m, transM};
+    EigOutAxpby out{Xin, Xout, (long long)w.N * w.m, w.m, alpha, beta};
+    DM_LAUNCH(ctx, "eig_apply_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, EigOutAxpby>), dim3(dm_cdiv(w.N, NT_T) * dm_cdiv(w.m, NT_T), 1, w.B),
+              dim3(256), 0, xa, mb, out, w.N, w.m, w.m);
+    return DM_OK;
+}
+// orthogonal polar factor of X (singular values in (0, 1]) by odd matrix polynomials; returns the buffer holding it
+static int eig_polar(dm_ctx* ctx, const eig_ws& w, double* Xa, double* Xb, double** result) {
+    double* xo = Xa;
+    double* xn = Xb;
+    for (int q = 0; q < EIG_NS_LIFT + EIG_NS_POLISH; ++q) {
+        const bool lift = q < EIG_NS_LIFT;
+        int rc = eig_gram(ctx, w, xo, xo, w.T, 1);                                  // T = X^T X
+        if (rc) return rc;
+        if (lift) {                                                                  // W = b T + c T T
+            KRowsF64 ta{w.T, (long long)w.m * w.m, w.m, w.m, w.m, 0};
+            EigOutAxpby ow{w.T, w.W, (long long)w.m * w.m, w.m, EIG_NS_B, EIG_NS_C};
+            DM_LAUNCH(ctx, "eig_poly_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, EigOutAxpby>), dim3(dm_cdiv(w.m, NT_T) * dm_cdiv(w.m, NT_T), 1, w.B),
+                      dim3(256), 0, ta, ta, ow, w.m, w.m, w.m);
+        }
+        rc = eig_apply(ctx, w, xo, lift ? w.W : w.T, 0, lift ? EIG_NS_A : 1.5, lift ? 1.0 : -0.5, xn);
+        if (rc) return rc;
+        double* tmp = xo; xo = xn; xn = tmp;
+    }
+    *result = xo;
+    return DM_OK;
+}
+
+extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* ell_cols, const double* ell_vals, const float* mass,
+                             int k, int guard, int n_iter, int degree, int warm_start, double* X /* B*N*(k+guard), in/out */,
+                             double* lam /* B*k */, double* Phi /* B*N*k */, double* resid /* B */) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N > 0 && nnz > 0 && k > 0 && guard >= 0 && n_iter > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, ell_cols && ell_vals && mass && X && lam && Phi && resid, "null pointer");
+    const int m = k + guard;
+    DM_REQUIRE(ctx, m <= N && m <= 512, "k + guard must be <= min(N, 512)");
+    DM_REQUIRE(ctx, degree >= 2 && degree <= EIG_MAX_DEG, "filter degree must be in [2, 64]");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bX = (size_t)B * N * m * 8, bM = (size_t)B * m * m * 8;
+    eig_ws w;
+    w.B = B; w.N = N; w.m = m; w.nsplit = dm_cdiv(N, 512);
+    int rc = dm_ws_reserve(ctx, 3 * dm_align_up(bX) + 5 * dm_align_up(bM) + dm_align_up((size_t)w.nsplit * bM) + dm_align_up((size_t)B * m * 8) +
+                                    dm_align_up((size_t)B * EIG_MAX_DEG * 3 * 8) + 2 * dm_align_up((size_t)B * 8) + 4096);
+    if (rc) return rc;
+    double* Ya = (double*)dm_ws_take(ctx, bX);
+    double* Yb = (double*)dm_ws_take(ctx, bX);
+    double* Yc = (double*)dm_ws_take(ctx, bX);
+    double* H = (double*)dm_ws_take(ctx, bM);
+    double* V = (double*)dm_ws_take(ctx, bM);
+    double* Q = (double*)dm_ws_take(ctx, bM);
+    w.T = (double*)dm_ws_take(ctx, bM);
+    w.W = (double*)dm_ws_take(ctx, bM);
+    w.part = (double*)dm_ws_take(ctx, (size_t)w.nsplit * bM);
+    double* theta = (double*)dm_ws_take(ctx, (size_t)B * m * 8);
+    double* coef = (double*)dm_ws_take(ctx, (size_t)B * EIG_MAX_DEG * 3 * 8);
+    double* lmax = (double*)dm_ws_take(ctx, (size_t)B * 8);
+    unsigned long long* rbits = (unsigned long long*)dm_ws_take(ctx, (size_t)B * 8);
+    if (!Ya || !Yb || !Yc || !H || !V || !Q || !w.T || !w.W || !w.part || !theta || !coef || !lmax || !rbits)
+        return dm_fail(ctx, DM_ENOMEM, "eigenbasis: workspace not reserved");
+    DM_LAUNCH(ctx, "eig_gershgorin", gershgorin_kernel, dim3(B), dim3(256), 0, ell_vals, N, nnz, lmax);
+    const dim3 gsp(dm_cdiv(m, 256), N, B);
+    const double* Xcur = X;
+
+    if (!warm_start) {      // the caller's X holds a random block: orthonormalise it (unit columns / sqrt(m): singular values <= 1)
+        DM_LAUNCH(ctx, "eig_unit_columns", unit_columns_kernel, dim3(m, B), dim3(256), 0, X, N, m, 1.0 / sqrt((double)m));
+        double* r = nullptr;
+        DM_CHECK_HIP(ctx, hipMemcpyAsync(Ya, X, bX, hipMemcpyDeviceToDevice, ctx->stream));
+        rc = eig_polar(ctx, w, Ya, Yb, &r);
+        if (rc) return rc;
+        DM_CHECK_HIP(ctx, hipMemcpyAsync(X, r, bX, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    for (int it = 0; it <= n_iter; ++it) {
+        // Rayleigh-Ritz on span(Xcur): H = X^T L X, eigen-decomposition, X <- X Q
+        DM_LAUNCH(ctx, "eig_spmm", spmm_ell_kernel, gsp, dim3(256), 0, ell_vals, ell_cols, N, nnz, Xcur, (const double*)nullptr,
+                  Ya, m, (const double*)nullptr, 0);
+        rc = eig_gram(ctx, w, Xcur, Ya, H, 1);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "eig_jacobi", jacobi_eigh_kernel, dim3(B), dim3(1024), 0, H, V, m, 30);
+        DM_LAUNCH(ctx, "eig_ritz_sort", ritz_sort_kernel, dim3(B), dim3(256), (size_t)m * 8 + (size_t)m * 4, (const double*)H, (const double*)V, m,
+                  theta, Q);
+        rc = eig_apply(ctx, w, Xcur, Q, 1, 0.0, 1.0, Yb);                            // Ritz vectors: (X Q)_ic = sum_k X_ik Q_kc
+        if (rc) return rc;
+        DM_CHECK_HIP(ctx, hipMemcpyAsync(X, Yb, bX, hipMemcpyDeviceToDevice, ctx->stream));
+        if (it == n_iter) break;
+        // filter: degree ramps 4, 8, 16, ... up to `degree` on a cold start
+        int deg = degree;
+        if (!warm_start) { const int ramp = 4 << it; if (it < 8 && ramp < deg) deg = ramp; }
+        DM_LAUNCH(ctx, "eig_cheb_coef", cheb_coef_kernel, dim3(B), dim3(64), 0, (const double*)theta, m, (const double*)lmax, deg, coef);
+        const double* y0 = X;
+        double* bufs[3] = {Ya, Yb, Yc};
+        const double* yprev = nullptr;
+        const double* ycur = y0;
+        for (int j = 1; j <= deg; ++j) {
+            double* ynew = bufs[j % 3];
+            DM_LAUNCH(ctx, "eig_spmm", spmm_ell_kernel, gsp, dim3(256), 0, ell_vals, ell_cols, N, nnz, ycur, yprev, ynew, m, (const double*)coef, j - 1);
+            yprev = ycur; ycur = ynew;
+        }
+        // orthonormalise the filtered block
+        double* Yf = const_cast<double*>(ycur);
+        DM_LAUNCH(ctx, "eig_unit_columns", unit_columns_kernel, dim3(m, B), dim3(256), 0, Yf, N, m, 1.0 / sqrt((double)m));
+        double* other = (Yf == Ya) ? Yb : Ya;
+        double* r = nullptr;
+        rc = eig_polar(ctx, w, Yf, other, &r);
+        if (rc) return rc;
+        DM_CHECK_HIP(ctx, hipMemcpyAsync(X, r, bX, hipMemcpyDeviceToDevice, ctx->stream));   // (the three Y buffers are scratch again)
+    }
+    // residual of the k wanted pairs, outputs
+    DM_LAUNCH(ctx, "eig_spmm", spmm_ell_kernel, gsp, dim3(256), 0, ell_vals, ell_cols, N, nnz, (const double*)X, (const double*)nullptr, Ya, m,
+              (const double*)nullptr, 0);
+    DM_CHECK_HIP(ctx, hipMemsetAsync(rbits, 0, (size_t)B * 8, ctx->stream));
+    DM_LAUNCH(ctx, "eig_residual", ritz_residual_kernel, dim3(k, B), dim3(256), 0, (const double*)X, (const double*)Ya, N, m, (const double*)theta, rbits);
+    DM_CHECK_HIP(ctx, hipMemcpyAsync(resid, rbits, (size_t)B * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    DM_LAUNCH(ctx, "eig_finish", eig_finish_kernel, dim3(k, B), dim3(256), 0, (const double*)X, N, m, k, mass, (const double*)theta, Phi, lam);
+    return DM_OK;
+}

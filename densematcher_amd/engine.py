@@ -293,6 +293,52 @@ class MatchEngine:
         self._chk(self.lib.dm_p2p_to_fm(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2), _ptr(Cm)))
         return Cm
 
+    def eigenbasis(self, W_list, mass, k, guard=32, degree=30, tol=1e-9, max_rounds=12, seed=0):
+        """k smallest eigenpairs of W phi = lambda A phi for a batch of meshes with the same vertex count (reference
+        TriMesh.process -> laplacian_spectrum: ARPACK on the host).  W_list: sparse stiffness matrices (host, SciPy);
+        mass (B,N) lumped masses.  The sparsity bookkeeping (ELL layout of A^-1/2 W A^-1/2) is host work, as assembling W
+        is in the reference; the iteration runs on the GPU (dm_eigenbasis) until max_j |L x_j - lam_j x_j| <= tol * lam_k.
+        Returns (lam (B,k) f64, Phi (B,N,k) f64, resid (B,), rounds)."""
+        import numpy as np
+        import scipy.sparse as sp
+        # (the C ABI carries lumped masses as fp32, like every other entry point: the problem solved is the one with the
+        #  rounded masses, so that Phi^T A Phi = I holds for the A the matching kernels will see)
+        mass = np.ascontiguousarray(mass, dtype=np.float32).astype(np.float64)
+        B, N = mass.shape
+        if np.any(mass <= 0):
+            raise ValueError("eigenbasis: every vertex needs a positive lumped mass (isolated or degenerate vertices?)")
+        mats = []
+        for b in range(B):
+            d = sp.diags(1.0 / np.sqrt(mass[b]))
+            mats.append((d @ sp.csr_matrix(W_list[b]) @ d).tocsr())
+        nnz = max(int(np.diff(Lm.indptr).max()) for Lm in mats)
+        cols = np.tile(np.arange(N, dtype=np.int32)[None, :, None], (B, 1, nnz))
+        vals = np.zeros((B, N, nnz))
+        for b, Lm in enumerate(mats):
+            cnt = np.diff(Lm.indptr)
+            pos = np.arange(Lm.nnz) - np.repeat(Lm.indptr[:-1], cnt)
+            rows = np.repeat(np.arange(N), cnt)
+            cols[b, rows, pos] = Lm.indices
+            vals[b, rows, pos] = Lm.data
+        m = min(k + guard, N)
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        X = torch.randn((B, N, m), dtype=torch.float64, device=self.device, generator=g)
+        cols_d = torch.as_tensor(cols).to(self.device)
+        vals_d = torch.as_tensor(vals).to(self.device)
+        mass_d = torch.as_tensor(mass.astype(np.float32)).to(self.device)
+        lam = torch.empty((B, k), dtype=torch.float64, device=self.device)
+        Phi = torch.empty((B, N, k), dtype=torch.float64, device=self.device)
+        resid = torch.empty((B,), dtype=torch.float64, device=self.device)
+        rounds = 0
+        for rounds in range(1, max_rounds + 1):
+            n_iter = 5 if rounds == 1 else 2
+            self._chk(self.lib.dm_eigenbasis(self.ctx, B, N, nnz, _ptr(cols_d), _ptr(vals_d), _ptr(mass_d), k, m - k, n_iter, degree,
+                                             0 if rounds == 1 else 1, _ptr(X), _ptr(lam), _ptr(Phi), _ptr(resid)))
+            scale = torch.clamp(lam[:, -1].abs(), min=1e-300)
+            if bool((resid <= tol * scale).all()):
+                break
+        return lam, Phi, resid, rounds
+
     def precise_map(self, Phi1, Phi2, Cm, faces1, dense=False):
         """Barycentric projection of every vertex of mesh 2 onto the faces of mesh 1 in the spectral embedding (reference
         get_precise_map, functional.py:221-251).  Returns (face_match (B,N2) int32, bary (B,N2,3) f64[, dense (B,N2,N1) f64])."""

@@ -3,12 +3,15 @@ TriMesh: the data carrier of the matching path (reference: densematcher/pyFM/mes
 
 Only what the hot path consumes is kept: vertices / faces, the cotangent stiffness matrix W, the lumped
 (diagonal) mass matrix A, L = A^-1 W, the Laplace-Beltrami spectrum, `area`, `process`, `project`, `decode`.
-Producing the spectrum is an INPUT of the accelerated path ("next #4"): like the
-reference (trimesh.py:440-531 -> laplacian.py:143-182, SciPy/ARPACK) it runs on the host with SciPy.
-The reference's `robust=True` uses the external `robust_laplacian` wheel (tufted Laplacian); here the
-classical cotangent Laplacian with lumped masses is used for every mesh (identical on manifold meshes up
-to the mollification of degenerate triangles).
+Producing the spectrum: the stiffness / mass matrices are assembled on the host like in the
+reference (trimesh.py:440-531 -> laplacian.py:143-182); the eigensolve -- ARPACK shift-invert there -- runs on the GPU
+(dm_eigenbasis: Chebyshev-filtered subspace iteration).
+The reference's `robust=True` uses the external `robust_laplacian` wheel (tufted intrinsic-Delaunay Laplacian with
+mollification); it is used here too when it can be imported.  When it cannot, the classical cotangent Laplacian with
+lumped masses is used and a warning says so: the two agree on Delaunay triangulations without degenerate faces only.
 """
+import warnings
+
 import numpy as np
 import scipy.sparse as sparse
 
@@ -88,14 +91,33 @@ class TriMesh:
 
     # ------------------------------------------------------------- spectrum (host side input of the path)
     def laplacian_spectrum(self, k, intrinsic=False, return_spectrum=True, robust=False, verbose=False):
+        """trimesh.py:440-496 -> laplacian.py:143-182.  W, A on the host; the k smallest eigenpairs on the GPU."""
         if self.facelist is None:
             raise NotImplementedError("point-cloud Laplacians are outside the matching path")
-        self.W, mass = synth.cotan_laplacian(self.vertlist, self.facelist)
+        mass = None
+        if robust:
+            try:
+                import robust_laplacian                                       # trimesh.py:465-470
+                self.W, Am = robust_laplacian.mesh_laplacian(self.vertlist, self.facelist, mollify_factor=1e-5)
+                self.W = sparse.csr_matrix(self.W)
+                mass = np.asarray(Am.diagonal())
+            except ImportError:
+                warnings.warn("robust=True asked for, but the robust_laplacian package is not installed: using the classical "
+                              "cotangent Laplacian with lumped masses (identical on Delaunay meshes without degenerate faces only)")
+        if mass is None:
+            self.W, mass = synth.cotan_laplacian(self.vertlist, self.facelist)
+        if np.any(mass <= 0):
+            raise ValueError("vertices with zero lumped mass (isolated vertices or degenerate faces): clean the mesh first")
         self.A = sparse.diags(mass).tocsr()
         self._L = None
         if k > 0:
-            lam, phi, _ = synth.eigenbasis(self.vertlist, self.facelist, max(20, k), method="arpack" if self.n_vertices > 3000 else "dense")
-            self.eigenvalues, self.eigenvectors = lam[:k], phi[:, :k]           # laplacian.py:165-167
+            kk = min(max(20, k), self.n_vertices - 1)                          # laplacian.py:165 computes at least 20 pairs
+            from ...engine import default_engine
+            lam, phi, resid, _ = default_engine().eigenbasis([self.W], mass[None], kk, tol=1e-10)
+            if float(resid[0]) > 1e-6 * max(1.0, float(lam[0, -1])):
+                raise RuntimeError(f"eigensolver did not converge (residual {float(resid[0]):.2e})")
+            self.eigenvalues, self.eigenvectors = lam[0, :k].cpu().numpy(), phi[0, :, :k].cpu().numpy()   # laplacian.py:165-167
+            self.eigenvalues[0] = max(self.eigenvalues[0], 0.0) if abs(self.eigenvalues[0]) < 1e-9 * max(1.0, self.eigenvalues[-1]) else self.eigenvalues[0]
             if return_spectrum:
                 return self.eigenvalues, self.eigenvectors
 

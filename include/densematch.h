@@ -185,6 +185,22 @@ int dm_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const int32_t* p21, const float* Phi1, int ld1, const float* Phi2, int ld2,
                  const float* mass2, double* C);
 
+/* ---- Laplace-Beltrami eigenbasis -----------------------------------------------------
+ * The k smallest eigenpairs of  W phi = lambda A phi  (Phi^T A Phi = I) for B meshes of N vertices each.
+ * Replaces the eigensolve of TriMesh.process / laplacian_spectrum (pyFM/mesh/trimesh.py:440-531 -> pyFM/mesh/laplacian.py:
+ * 143-182: scipy.sparse.linalg.eigsh(W, k, M=A, sigma=-0.01), ARPACK) by a Chebyshev-filtered subspace iteration.
+ * Input: L = A^-1/2 W A^-1/2 in ELL format -- ell_cols (B,N,nnz) int32, ell_vals (B,N,nnz) fp64, padded with (col = row,
+ * val = 0) -- and mass (B,N) fp32 = diag(A).  X (B,N,k+guard) fp64: in, a random block (warm_start = 0) or the block a
+ * previous call returned (warm_start = 1); out, the orthonormal Ritz vectors of L.  n_iter filtered iterations of
+ * polynomial degree `degree` (<= 64; a cold start ramps 4, 8, 16, ... up to it).
+ * Output: lam (B,k) fp64 ascending, Phi (B,N,k) fp64 (sign: largest entry of a column positive), resid (B) fp64 =
+ * max_j |L x_j - lam_j x_j| over the k wanted pairs -- the caller iterates (warm_start = 1) until it is small enough.
+ * ARPACK's output is not reproducible either (random start vector, arbitrary basis of multiple eigenvalues): parity is
+ * stated on eigenvalues and invariant subspaces, never on bits.  k + guard <= min(N, 512). */
+int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* ell_cols, const double* ell_vals, const float* mass,
+                  int k, int guard, int n_iter, int degree, int warm_start,
+                  double* X, double* lam, double* Phi, double* resid);
+
 /* ---- precise (barycentric) map ----------------------------------------------------
  * For every vertex i of mesh 2 the face of mesh 1 its spectral embedding projects onto and the barycentric coordinates
  * of the projection: face_match (B,N2) int32, bary (B,N2,3) fp64; dense (B,N2,N1) fp64 optional = the same map as a

@@ -372,3 +372,35 @@ def test_compute_surface_map_notebook_call(fx_cfg1, fx_cfg1_notebook_call, monke
                   p2p_12_icp=res[5], hungarian_icp_cols=res[6][1], p2p_21_adjoint=res[10], p2p_12_adjoint=res[11]).items()}
     print("notebook call, agreement with the reference's tuple:", agree)
     assert min(agree[n] for n in ("p2p_21", "p2p_12", "p2p_21_adjoint", "p2p_12_adjoint", "hungarian_cols")) >= 0.95
+
+
+def test_compute_surface_map_from_raw_meshes():
+    """no injected spectrum: TriMesh.process assembles the cotangent Laplacian on the host and computes the eigenbasis on
+    the GPU (dm_eigenbasis); the vertex maps equal those of the oracle pipeline run on SciPy's dense eigenbasis of the same
+    W, A (functional maps are basis dependent -- signs, rotations inside clusters -- vertex maps are not)"""
+    import warnings
+    import scipy.linalg
+    from densematcher_amd import synth
+    from densematcher_amd.functional_map import compute_surface_map
+    nu, nv, D = 32, 24, 96
+    (v1, f1), (v2, f2) = synth.torus_mesh(nu, nv, perturb=0.05, seed=3), synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
+    (W1, m1), (W2, m2) = synth.cotan_laplacian(v1, f1), synth.cotan_laplacian(v2, f2)
+    m1, m2 = m1.astype(np.float32).astype(np.float64), m2.astype(np.float32).astype(np.float64)
+    w1, V1 = scipy.linalg.eigh(W1.toarray(), np.diag(m1))
+    w2, V2 = scipy.linalg.eigh(W2.toarray(), np.diag(m2))
+    k = max(range(34, 46), key=lambda q: min(w1[q] - w1[q - 1], w2[q] - w2[q - 1]))
+    F1, F2, _ = synth.feature_pair(nu * nv, nu * nv, D, 5, 6, sigma=0.3, perm="identity")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        res = compute_surface_map(_Duck(v1, f1), _Duck(v2, f2), F1, F2, n_ev=k, optimizer="L-BFGS-B",
+                                  fit_params=dict(w_descr=1e4, w_lap=1e3, w_dcomm=0, optinit="zeros"))
+    assert any("robust_laplacian" in str(w_.message) for w_ in caught)       # robust=True cannot be honoured here: said loudly
+    model = res[7]
+    assert np.abs(model.mesh1.eigenvalues - w1[:k]).max() <= 1e-8 * w1[k - 1]
+    # oracle on the host basis (the fp32 rounding of the basis at the ABI included)
+    e1, e2 = V1[:, :k].astype(np.float32).astype(np.float64), V2[:, :k].astype(np.float32).astype(np.float64)
+    Co = orc.fit(e1, e2, w1[:k], w2[:k], m1, m2, F1, F2, 1e4, 1e3)
+    q = orc.fm_to_p2p_all(Co, e1, e2, m1)
+    agree = [float((got == want).mean()) for got, want in zip([res[10], res[11], res[0], res[1]], q)]
+    print("raw-mesh compute_surface_map vs oracle on SciPy's eigenbasis:", agree)
+    assert min(agree) >= 0.99

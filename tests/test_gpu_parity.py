@@ -557,3 +557,68 @@ def test_precise_map_and_its_assignment(eng, fx_cfg1, fx_cfg1_precise):
     agree = (got == fx_cfg1_precise["hungarian_precise_cols"]).mean()
     print("hungarian_precise agreement with the reference:", agree)
     assert agree >= 0.99
+
+
+# --------------------------------------------------------------------------- #
+# the eigenbasis on the GPU
+@pytest.mark.parametrize("nu,nv,k", [(25, 20, 30), (64, 32, 128), (64, 32, 200)])
+def test_eigenbasis_against_dense_eigh(eng, nu, nv, k):
+    """dm_eigenbasis (Chebyshev-filtered subspace iteration) against the dense generalized eigensolver of SciPy on the
+    same W, A: eigenvalues to 1e-9 relative, A-orthonormality, the invariant subspace (clusters of equal eigenvalues come
+    in an arbitrary basis, so vectors are compared through the projector), residuals"""
+    import scipy.linalg
+    import scipy.sparse as sps
+    from densematcher_amd import synth
+    meshes = [synth.torus_mesh(nu, nv, perturb=p, seed=s) for p, s in ((0.0, 0), (0.08, 1))]
+    Ws, masses = zip(*[synth.cotan_laplacian(v, f) for v, f in meshes])
+    masses = [m_.astype(np.float32).astype(np.float64) for m_ in masses]          # masses cross the ABI as fp32
+    lam, Phi, resid, rounds = eng.eigenbasis(list(Ws), np.stack(masses), k, tol=1e-10)
+    lam, Phi = _np(lam), _np(Phi)
+    print(f"N={nu * nv} k={k}: {rounds} rounds, residual {float(resid.max()):.2e}")
+    for b in range(2):
+        w, V = scipy.linalg.eigh(Ws[b].toarray(), np.diag(masses[b]))
+        scale = w[k - 1]
+        assert np.abs(lam[b] - w[:k]).max() <= 1e-9 * scale
+        A = sps.diags(masses[b])
+        G = Phi[b].T @ (A @ Phi[b])
+        assert np.abs(G - np.eye(k)).max() <= 1e-9
+        R = Ws[b] @ Phi[b] - (A @ Phi[b]) * lam[b][None, :]
+        assert np.abs(R).max() <= 1e-7 * scale
+        # the invariant subspace below the last cluster boundary inside the first k values
+        cut = k
+        while cut > 1 and (w[cut] - w[cut - 1]) <= 1e-6 * scale:
+            cut -= 1                                           # (do not cut a cluster of equal eigenvalues)
+        P = V[:, :cut].T @ (A @ Phi[b][:, :cut])
+        assert np.abs(P.T @ P - np.eye(cut)).max() <= 1e-7
+
+
+def test_maps_on_gpu_eigenbasis_match_maps_on_host_eigenbasis(eng):
+    """end to end: a pair matched on the GPU-made bases gives the same vertex maps as on SciPy's dense bases (the functional
+    map itself is basis dependent inside clusters of equal eigenvalues, the maps are not)"""
+    import scipy.linalg
+    from densematcher_amd import synth
+    nu, nv, D = 32, 24, 96
+    (v1, f1), (v2, f2) = synth.torus_mesh(nu, nv, perturb=0.05, seed=3), synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
+    (W1, m1), (W2, m2) = synth.cotan_laplacian(v1, f1), synth.cotan_laplacian(v2, f2)
+    m1, m2 = m1.astype(np.float32).astype(np.float64), m2.astype(np.float32).astype(np.float64)
+    # truncate where neither spectrum has a near-multiple eigenvalue across the cut (span of the first k is then unique)
+    w1 = scipy.linalg.eigh(W1.toarray(), np.diag(m1), eigvals_only=True)
+    w2 = scipy.linalg.eigh(W2.toarray(), np.diag(m2), eigvals_only=True)
+    k = max(range(34, 46), key=lambda q: min(w1[q] - w1[q - 1], w2[q] - w2[q - 1]))
+    lam, Phi, resid, _ = eng.eigenbasis([W1, W2], np.stack([m1, m2]), k, tol=1e-11)
+    lam, Phi = _np(lam), _np(Phi)
+    F1, F2, _ = synth.feature_pair(nu * nv, nu * nv, D, 5, 6, sigma=0.3, perm="identity")
+    res = {}
+    for name in ("gpu", "host"):
+        if name == "gpu":
+            b1, b2, l1, l2 = Phi[0], Phi[1], lam[0], lam[1]
+        else:
+            l1, b1 = scipy.linalg.eigh(W1.toarray(), np.diag(m1), subset_by_index=[0, k - 1])
+            l2, b2 = scipy.linalg.eigh(W2.toarray(), np.diag(m2), subset_by_index=[0, k - 1])
+        batch = {"Phi1": b1.astype(np.float32)[None], "Phi2": b2.astype(np.float32)[None], "lam1": l1[None], "lam2": l2[None],
+                 "a1": m1.astype(np.float32)[None], "a2": m2.astype(np.float32)[None], "F1": F1[None], "F2": F2[None]}
+        out = eng.match({n: torch.as_tensor(v_).to(eng.device) for n, v_ in batch.items()}, k=k)
+        res[name] = {n: _np(out[n])[0] for n in ("knn21", "knn12", "ind21", "ind12")}
+    agree = {n: float((res["gpu"][n] == res["host"][n]).mean()) for n in res["gpu"]}
+    print("maps on GPU basis vs host basis:", agree)
+    assert min(agree.values()) >= 0.99
