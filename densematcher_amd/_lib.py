@@ -37,6 +37,7 @@ SIGNATURES = {
     "dm_fm_to_p2p": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_fm_to_p2p_uses_split": (_i, [_p, _i, _i, _i]),
     "dm_knn_query_f64": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
+    "dm_knn_query_topk_f64": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dm_mapped_indicator": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_p2p_to_fm": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "dm_eigenbasis": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -291,3 +291,80 @@ extern "C" int dm_precise_map(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2
               face_match, bary, dense, overflow);
     return DM_OK;
 }
+
+// ---- k nearest neighbours, k > 1 (pyFM/spectral/nn_utils.py:4-38) ----------------------------------------------------
+// idx[b][i][r] = index of the r-th nearest row of X[b] to Y[b][i] (ascending distance, lowest index first on equal
+// distances), dist = the Euclidean distances.  The (ny x nx) distance matrix is formed on the f64 matrix cores
+// (|x|^2 - 2 <x, y> + |y|^2, clipped at 0), one workgroup per query row then extracts the k smallest by k arg-min passes
+// over the row held in LDS.  The k = 1 searches of the matching path never take this route (dm_knn_query_f64).
+struct OutSqDist {
+    double* p; long long stride_b; int ld; const double* xs; int nx; const double* ys; int ny;
+    __device__ __forceinline__ void store(int b, int i, int j, double xy) const {
+        p[b * stride_b + (long long)i * ld + j] = fmax((xs[(long long)b * nx + j] - 2.0 * xy) + ys[(long long)b * ny + i], 0.0);
+    }
+};
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const double* __restrict__ X, int N, int k, double* __restrict__ sq) {
+    const int b = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= N) return;
+    const double* row = X + ((long long)b * N + r) * k;
+    double s = 0.0;
+    for (int c = 0; c < k; ++c) s += row[c] * row[c];
+    sq[(long long)b * N + r] = s;
+}
+__global__ __launch_bounds__(256) void topk_rows_kernel(const double* __restrict__ D2, int nx, int ny, int k, int32_t* __restrict__ idx,
+                                                        double* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) double tk_row[];
+    __shared__ double w_v[4];
+    __shared__ int w_j[4];
+    const int i = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const double* dr = D2 + ((long long)b * ny + i) * nx;
+    for (int j = t; j < nx; j += 256) tk_row[j] = dr[j];
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        double bv = DM_INF_F64; int bj = DM_IDX_NONE;
+        for (int j = t; j < nx; j += 256) { const double x = tk_row[j]; if (x < bv) { bv = x; bj = j; } }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off); const int oj = __shfl_xor(bj, off);
+            argmin_merge(bv, bj, ov, oj);
+        }
+        if (lane == 0) { w_v[wave] = bv; w_j[wave] = bj; }
+        __syncthreads();
+        if (t == 0) {
+            double v0 = w_v[0]; int j0 = w_j[0];
+            for (int w = 1; w < 4; ++w) argmin_merge(v0, j0, w_v[w], w_j[w]);
+            const long long o = ((long long)b * ny + i) * k + r;
+            idx[o] = (j0 == DM_IDX_NONE) ? 0 : j0;
+            if (dist) dist[o] = (j0 == DM_IDX_NONE) ? DM_INF_F64 : sqrt(v0);
+            if (j0 != DM_IDX_NONE) tk_row[j0] = DM_INF_F64;            // taken: out of the next passes
+        }
+        __syncthreads();
+    }
+}
+extern "C" int dm_knn_query_topk_f64(dm_ctx* ctx, int B, int nx, int ny, int p, int k, const double* X, const double* Y,
+                                     int32_t* idx, double* dist) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && nx > 0 && ny > 0 && p > 0 && k > 0 && k <= nx, "sizes must be positive, k <= nx");
+    DM_REQUIRE(ctx, X && Y && idx, "null pointer");
+    DM_REQUIRE(ctx, (size_t)nx * 8 <= 150 * 1024, "too many tree points for the in-LDS distance row");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bD = (size_t)B * ny * nx * 8;
+    int rc = dm_ws_reserve(ctx, dm_align_up(bD) + dm_align_up((size_t)B * nx * 8) + dm_align_up((size_t)B * ny * 8) + 4096);
+    if (rc) return rc;
+    double* D2 = (double*)dm_ws_take(ctx, bD);
+    double* xs = (double*)dm_ws_take(ctx, (size_t)B * nx * 8);
+    double* ys = (double*)dm_ws_take(ctx, (size_t)B * ny * 8);
+    if (!D2 || !xs || !ys) return dm_fail(ctx, DM_ENOMEM, "knn top-k: workspace not reserved");
+    DM_LAUNCH(ctx, "knn_sumsq", row_sumsq_kernel, dim3(dm_cdiv(nx, 256), B), dim3(256), 0, X, nx, p, xs);
+    DM_LAUNCH(ctx, "knn_sumsq", row_sumsq_kernel, dim3(dm_cdiv(ny, 256), B), dim3(256), 0, Y, ny, p, ys);
+    KRowsF64 ya{Y, (long long)ny * p, p, ny, p, 0};
+    KRowsF64 xb{X, (long long)nx * p, p, nx, p, 0};
+    OutSqDist out{D2, (long long)ny * nx, nx, xs, nx, ys, ny};
+    DM_LAUNCH(ctx, "knn_dist_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutSqDist>), dim3(dm_cdiv(ny, NT_T) * dm_cdiv(nx, NT_T), 1, B), dim3(256), 0,
+              ya, xb, out, ny, nx, p);
+    const size_t lds = (size_t)nx * 8;
+    rc = dm_grant_lds(ctx, (const void*)topk_rows_kernel, lds);
+    if (rc) return rc;
+    DM_LAUNCH(ctx, "knn_topk", topk_rows_kernel, dim3(ny, B), dim3(256), lds, (const double*)D2, nx, ny, k, idx, dist);
+    return DM_OK;
+}

@@ -435,6 +435,17 @@ class MatchEngine:
         self._chk(self.lib.dm_knn_query_f64(self.ctx, B, nx, ny, p, _ptr(X), _ptr(Y), _ptr(out)))
         return out
 
+    def knn_query_topk(self, X, Y, k):
+        """the k nearest rows of X for every row of Y, nearest first -> (idx (B,ny,k) int32, dist (B,ny,k) f64)"""
+        X = self._dev(X, torch.float64, "X")
+        Y = self._dev(Y, torch.float64, "Y")
+        B, nx, p = X.shape
+        ny = Y.shape[1]
+        idx = torch.empty((B, ny, k), dtype=torch.int32, device=self.device)
+        dist = torch.empty((B, ny, k), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_knn_query_topk_f64(self.ctx, B, nx, ny, p, k, _ptr(X), _ptr(Y), _ptr(idx), _ptr(dist)))
+        return idx, dist
+
     def mapped_indicator(self, Phi1, Phi2, a1, Cm):
         """Dense (B,N2,N1) float64 indicator ((Phi2 C) Phi1^T) * a1 -- only for callers that want the matrix."""
         Phi1 = self._dev(Phi1, torch.float32, "Phi1")

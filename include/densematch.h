@@ -170,6 +170,13 @@ int dm_fm_to_p2p_uses_split(const dm_ctx* ctx, int N2, int N1, int k);
 int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p,
                      const double* X, const double* Y, int32_t* out /* B*ny */);
 
+/* ---- k nearest neighbours, k > 1 -------------------------------------------------------
+ * idx[b,i,r] = index of the r-th nearest row of X[b] to Y[b,i] (ascending distance, lowest index on equal distances),
+ * dist (nullable) = the Euclidean distances; idx / dist (B,ny,k).  Replaces pyFM/spectral/nn_utils.py:4-38 for k > 1
+ * (sklearn kneighbors).  The k = 1 searches of the matching path use dm_knn_query_f64. */
+int dm_knn_query_topk_f64(dm_ctx* ctx, int B, int nx, int ny, int p, int k,
+                          const double* X, const double* Y, int32_t* idx, double* dist /*nullable*/);
+
 /* ---- dense mapped indicator --------------------------------------------------
  * M[b] = ((Phi2[:, :k2] C) Phi1[:, :k1]^T) * mass1[None, :]   (B,N2,N1) fp64.
  * Replaces the matrix returned by FM_to_p2p (pyFM/spectral/convert.py:144) for

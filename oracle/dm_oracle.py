@@ -667,3 +667,14 @@ def precise_map_dense(C, phi1, phi2, faces1):
     for c in range(3):
         np.add.at(M, (np.arange(e2.shape[0]), faces1[fm, c]), bary[:, c])
     return M, fm, bary
+
+
+def knn_query_topk(X, Y, k):
+    """The k nearest rows of X for every row of Y, nearest first, lowest index on equal distances
+    -- pyFM/spectral/nn_utils.py:4-38 with k > 1 (sklearn kneighbors returns neighbours sorted by distance).
+    Brute force on directly-formed differences -> (dist (ny,k), idx (ny,k))."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    d = np.sqrt(((Y[:, None, :] - X[None, :, :]) ** 2).sum(-1))
+    idx = np.argsort(d, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(d, idx, axis=1), idx

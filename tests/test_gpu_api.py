@@ -404,3 +404,85 @@ def test_compute_surface_map_from_raw_meshes():
     agree = [float((got == want).mean()) for got, want in zip([res[10], res[11], res[0], res[1]], q)]
     print("raw-mesh compute_surface_map vs oracle on SciPy's eigenbasis:", agree)
     assert min(agree) >= 0.99
+
+
+def test_knn_query_top_k():
+    """nn_utils.knn_query with k > 1 (sklearn kneighbors semantics: (n2, k), nearest first)"""
+    from densematcher_amd.pyFM.spectral.nn_utils import knn_query
+    rng = np.random.default_rng(5)
+    for nx, ny, p, k in ((700, 333, 3, 5), (1500, 64, 40, 8), (97, 211, 7, 97)):
+        X, Y = rng.standard_normal((nx, p)), rng.standard_normal((ny, p))
+        d_ref, i_ref = orc.knn_query_topk(X, Y, k)
+        d, i = knn_query(X, Y, k=k, return_distance=True)
+        assert i.shape == (ny, k) and i.dtype == np.int64 and d.shape == (ny, k)
+        assert np.abs(d - d_ref).max() < 1e-12 * max(1.0, d_ref.max())
+        gap_ok = np.ones((ny, k), dtype=bool)            # positions whose rank is decided by more than rounding
+        dn = np.sqrt(((Y[:, None, :] - X[None]) ** 2).sum(-1))
+        dn.sort(axis=1)
+        gaps = np.diff(dn, axis=1)
+        for r in range(k):
+            lo = gaps[:, r - 1] if r > 0 else np.inf
+            hi = gaps[:, r] if r < nx - 1 else np.inf
+            gap_ok[:, r] = np.minimum(lo, hi) > 1e-10
+        assert np.array_equal(i[gap_ok], i_ref[gap_ok]) and gap_ok.mean() > 0.99
+        assert np.array_equal(knn_query(X, Y, k=k), i)
+        assert all(len(set(row)) == k for row in i)
+    # exact duplicates: the lowest index comes first, like a stable sort on the distances
+    X = np.repeat(rng.standard_normal((50, 3)), 3, axis=0)
+    Y = rng.standard_normal((40, 3))
+    _, i_ref = orc.knn_query_topk(X, Y, 6)
+    assert np.array_equal(knn_query(X, Y, k=6), i_ref)
+    # k = 1 keeps the reference's squeezed shapes
+    d1, i1 = knn_query(X, Y, k=1, return_distance=True)
+    assert i1.shape == (40,) and d1.shape == (40,) and np.array_equal(i1, i_ref[:, 0])
+
+
+def test_function_space_helpers(fx_cfg1):
+    """TriMesh.project / decode / l2_* / integrate and FunctionalMapping.project / decode / transport / transfer
+    (reference pyFM/mesh/trimesh.py:533-640, pyFM/functional.py:730-831) against their closed forms in float64."""
+    from densematcher_amd.pyFM.functional import FunctionalMapping
+    fx = fx_cfg1
+    k = int(fx["k"])
+    m1, m2 = _mesh(fx, 1), _mesh(fx, 2)
+    rng = np.random.default_rng(11)
+    f = rng.standard_normal((m1.n_vertices, 4))
+    a1 = m1.A.diagonal()
+    want = m1.eigenvectors.T @ (a1[:, None] * f)
+    scale = np.abs(want).max()
+    assert np.abs(m1.project(f) - want).max() < 2e-6 * scale                      # fp32 inputs, exact accumulation
+    assert np.abs(m1.project(f[:, 0], k=20) - want[:20, 0]).max() < 2e-6 * scale
+    assert m1.project(f[:, 0]).shape == (m1.eigenvectors.shape[1],)
+    with pytest.raises(ValueError):
+        m1.project(f, k=m1.eigenvectors.shape[1] + 1)
+    c = rng.standard_normal((k, 3))
+    assert np.array_equal(m1.decode(c), m1.eigenvectors[:, :k] @ c)
+    with pytest.raises(ValueError):
+        m1.decode(np.zeros((m1.eigenvectors.shape[1] + 1, 2)))
+    assert np.allclose(m1.l2_inner(f, 2 * f), 2 * (f * a1[:, None] * f).sum(0), rtol=1e-13)
+    assert np.allclose(m1.l2_sqnorm(f[:, 1]), (f[:, 1] ** 2 * a1).sum(), rtol=1e-13)
+    assert np.allclose(m1.integrate(f), a1 @ f, rtol=1e-13)
+    assert np.isclose(m1.integrate(np.ones(m1.n_vertices)), a1.sum(), rtol=1e-13)
+
+    model = FunctionalMapping(m1, m2)
+    model.k1 = model.k2 = k
+    with pytest.raises(ValueError):
+        model.transport(c)
+    model.descr1 = model.descr2 = np.zeros((1, 1))                                # "preprocessed"
+    model.FM = fx["C_fit"].astype(np.float64)
+    assert np.abs(model.project(f) - want[:k]).max() < 2e-6 * scale
+    a2 = m2.A.diagonal()
+    g = rng.standard_normal((m2.n_vertices, 2))
+    want2 = m2.eigenvectors[:, :k].T @ (a2[:, None] * g)
+    assert np.abs(model.project(g, mesh_ind=2) - want2).max() < 2e-6 * np.abs(want2).max()
+    with pytest.raises(ValueError):
+        model.project(f, mesh_ind=3)
+    assert np.array_equal(model.decode(c), m2.eigenvectors[:, :k] @ c)
+    assert np.array_equal(model.decode(c, mesh_ind=1), m1.eigenvectors[:, :k] @ c)
+    assert np.allclose(model.transport(c), model.FM @ c, rtol=1e-13)
+    assert np.allclose(model.transport(c, reverse=True), np.linalg.pinv(model.FM) @ c, rtol=1e-12)
+    t = model.transfer(f)
+    assert t.shape == (m2.n_vertices, 4)
+    assert np.abs(t - m2.eigenvectors[:, :k] @ (model.FM @ want[:k])).max() < 1e-5 * np.abs(t).max()
+    tr = model.transfer(g, reverse=True)
+    assert tr.shape == (m1.n_vertices, 2)
+    assert np.abs(tr - m1.eigenvectors[:, :k] @ (np.linalg.pinv(model.FM) @ want2)).max() < 1e-5 * np.abs(tr).max()
