@@ -163,12 +163,13 @@ def main():
             return eng.match(dev, k=k)
         split = eng.p2p_split_active(N, N, k)
         if split:
-            kernel, dtype = "simnn_f16_mfma", "f16"
-            kd = eng.split_depth(k)
+            kernel, dtype = "simnn2_f16_mfma", "f16"
+            kd = -(-3 * k // 32) * 32
             flops_per_launch = 2.0 * N * N * kd * B
             extra = {"launches_per_step": 2, "algorithmic_f64_flops_per_step": 2.0 * N * N * k * B,
-                     "note": "four maps = two fp16-split passes (knn21+ind21, knn12+ind12) + exact float64 fix-up; achieved/peak count "
-                             "the fp16 flops one pass executes (3 products per contraction index + bias, padded to 32)"}
+                     "note": "four maps = two passes of the two-key fp16 tile kernel (knn21+ind21, knn12+ind12) + exact float64 "
+                             "re-evaluation of the ambiguous rows; achieved/peak count the fp16 flops one pass executes (3 products "
+                             "per contraction index, padded to 32); algorithmic_f64_flops_per_step is SURVEY 8(d)'s 2 N^2 k"}
         else:
             kernel, dtype = "gred_f64", "f64"
             flops_per_launch = 2.0 * N * N * k * B                  # G = Phi2 C Phi1^T, SURVEY 8(d): 2 N^2 k per pair
@@ -297,7 +298,10 @@ def pmc_traffic_bytes(kernel, workload):
     """HBM bytes per launch of the dominant kernel, measured in separate rocprofv3 --pmc passes of this same command
     (PMC collection cannot run inside the timed region); summaries committed under profiles/."""
     import csv
-    key = {"gred_f64": "gred_kernel", "simnn_f16_mfma": "simnn_pipe_kernel"}.get(kernel, kernel)
+    dual = lambda name: name.rstrip('"').endswith(", 1>(simnn_params)") or name.rstrip('"').endswith(", 2>(simnn_params)")
+    match = {"gred_f64": lambda n: "gred_kernel" in n,
+             "simnn_f16_mfma": lambda n: "simnn_pipe_kernel" in n and not dual(n),
+             "simnn2_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 1>(simnn_params)")}.get(kernel, lambda n: kernel in n)
     for rnd in ("r02", "r01"):
         fname = f"{rnd}_{workload}_hbm_traffic_pmc.csv"
         path = os.path.join(REPO, "profiles", fname)
@@ -305,7 +309,7 @@ def pmc_traffic_bytes(kernel, workload):
             rows = [r for r in csv.reader(ln for ln in open(path) if not ln.startswith("#"))]
             hdr = rows[0]
             for r in rows[1:]:
-                if key in r[0]:
+                if match(r[0]):
                     d = dict(zip(hdr, r))
                     return int((float(d["fetch_MB_corrected"]) + float(d["write_MB"])) * 1e6), fname
         except Exception:

@@ -40,38 +40,37 @@ __device__ __forceinline__ double readlane_f64(double x, int srclane) {
     return __hiloint2double(hi, lo);
 }
 template <int J>
-__device__ __forceinline__ void diag_step(double (&s)[4], double (&w)[4], int lane, bool& ok) {
+__device__ __forceinline__ void diag_step(double (&s)[4], double (&w)[4], double& pv, int lane, bool& ok) {
     constexpr int gj = J >> 2, ej = J & 3;
     const double piv = readlane_f64(s[ej], J | (gj << 4));                  // S[J][J], wave uniform
     ok = ok && (piv > 0.0);
     double rp = __builtin_amdgcn_rcp(piv);                                   // 1 / piv   (seed + 2 Newton steps)
     rp = fma(fma(-piv, rp, 1.0), rp, rp);
     rp = fma(fma(-piv, rp, 1.0), rp, rp);
-    double inv = __builtin_amdgcn_rsq(piv);                                  // piv^-1/2  (off the critical chain)
-    const double hp = 0.5 * piv;
-    inv = inv * (1.5 - hp * inv * inv);
-    inv = inv * (1.5 - hp * inv * inv);
+    pv = (lane == J) ? piv : pv;                                             // lane J keeps pivot J: the piv^-1/2 column scaling is
+                                                                             // done once for all 16 columns after the chain
     const int src = (lane & 15) | (gj << 4);
     const double v = __shfl(s[ej], src);                                     // S[r][J]
     const double z = __shfl(w[ej], src);                                     // E[r][J]
     const double vr = -v * rp, zr = -z * rp;
     // No column mask: for finished columns c < J the broadcast row entry S[J][c] is a rounding-level residue of
     // its own elimination (S[r][c] (1 - piv rp)), so touching them perturbs the result by O(1e-16) only; column J
-    // itself is overwritten below.
+    // of E is final before this step's update (restored below).
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const double t = dpp_row_bcast<J>(s[e]);                             // S[J][4g+e]
         s[e] = fma(vr, t, s[e]);
         w[e] = fma(zr, t, w[e]);
     }
-    if ((lane >> 4) == gj) w[ej] = z * inv;                                  // column J of E is final: E[r][J] piv^-1/2
+    if ((lane >> 4) == gj) w[ej] = z;                                        // column J of E: E[r][J], scaled by piv^-1/2 at the end
 }
 
 
 // diagonal block J: in-register elimination by wave 0 (see diag_step); leaves Ws[m][k] = W[k][m], W = L_JJ^-1.
-// (Tried on MI355X, none faster than the 5.9 k cycles per block of this form: a row-per-lane form with the pivot row
-// through DPP row_newbcast 6.7 k -- no LDS on the chain, but 700 instead of 400 f64 VALU instructions --, through
-// v_readlane 8.4 k; the column broadcast by v_permlane32_swap / v_permlane16_swap instead of ds_bpermute 7.4 k.)
+// (Tried on MI355X, none faster than this form: a row-per-lane form with the pivot row through DPP row_newbcast 6.7 k
+// cycles per block against 5.9 k -- no LDS on the chain, but 700 instead of 400 f64 VALU instructions --, through
+// v_readlane 8.4 k; the column broadcast by v_permlane32_swap / v_permlane16_swap instead of ds_bpermute 7.4 k.
+// The 16 inverse square roots are taken together after the chain: one rsq + Newton sequence instead of sixteen.)
 __device__ __forceinline__ void diag_block(const double* S, double* Ws, double* red, int lane) {
     const int r = lane & 15, g = lane >> 4;
     double ds[4], dw[4];
@@ -81,16 +80,21 @@ __device__ __forceinline__ void diag_block(const double* S, double* Ws, double* 
         dw[e] = (r == 4 * g + e) ? 1.0 : 0.0;
     }
     bool ok = true;
-    diag_step<0>(ds, dw, lane, ok);   diag_step<1>(ds, dw, lane, ok);
-    diag_step<2>(ds, dw, lane, ok);   diag_step<3>(ds, dw, lane, ok);
-    diag_step<4>(ds, dw, lane, ok);   diag_step<5>(ds, dw, lane, ok);
-    diag_step<6>(ds, dw, lane, ok);   diag_step<7>(ds, dw, lane, ok);
-    diag_step<8>(ds, dw, lane, ok);   diag_step<9>(ds, dw, lane, ok);
-    diag_step<10>(ds, dw, lane, ok);  diag_step<11>(ds, dw, lane, ok);
-    diag_step<12>(ds, dw, lane, ok);  diag_step<13>(ds, dw, lane, ok);
-    diag_step<14>(ds, dw, lane, ok);  diag_step<15>(ds, dw, lane, ok);
+    double pv = 1.0;
+    diag_step<0>(ds, dw, pv, lane, ok);   diag_step<1>(ds, dw, pv, lane, ok);
+    diag_step<2>(ds, dw, pv, lane, ok);   diag_step<3>(ds, dw, pv, lane, ok);
+    diag_step<4>(ds, dw, pv, lane, ok);   diag_step<5>(ds, dw, pv, lane, ok);
+    diag_step<6>(ds, dw, pv, lane, ok);   diag_step<7>(ds, dw, pv, lane, ok);
+    diag_step<8>(ds, dw, pv, lane, ok);   diag_step<9>(ds, dw, pv, lane, ok);
+    diag_step<10>(ds, dw, pv, lane, ok);  diag_step<11>(ds, dw, pv, lane, ok);
+    diag_step<12>(ds, dw, pv, lane, ok);  diag_step<13>(ds, dw, pv, lane, ok);
+    diag_step<14>(ds, dw, pv, lane, ok);  diag_step<15>(ds, dw, pv, lane, ok);
+    double inv = __builtin_amdgcn_rsq(pv);                                   // lane c < 16: piv_c^-1/2
+    const double hp = 0.5 * pv;
+    inv = inv * (1.5 - hp * inv * inv);
+    inv = inv * (1.5 - hp * inv * inv);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Ws[r * 16 + 4 * g + e] = dw[e];
+    for (int e = 0; e < 4; ++e) Ws[r * 16 + 4 * g + e] = dw[e] * __shfl(inv, 4 * g + e);
     if (!ok && lane == 0) red[5] = 1.0;
 }
 

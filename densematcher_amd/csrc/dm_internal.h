@@ -99,8 +99,10 @@ static inline int dm_cdiv(int a, int b) { return (a + b - 1) / b; }
 // ---- internal building blocks (each in its own .hip) -------------------------
 // K-major float64 copy of the first k columns of Phi:  out[b][c][i] = Phi[b][i][c]
 // (c < k), zero for padded entries; out is (B, kpad, Npad).
+// amax (nullable, zeroed by the caller): (B, DM_NCH) partial maxima of |Phi[:, :k]| (bit patterns of non-negative doubles)
+constexpr int DM_NCH = 32;
 int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld,
-                   double* out, int kpad, int Npad);
+                   double* out, int kpad, int Npad, double* amax = nullptr);
 
 // embT[b][r][j] = sum_m Cm[b][r][m] * Phi[b][j][m]   (r < kr, m < km), K-major f64
 // (B, krpad, Npad); nrm[b][j] = sum_r embT[b][r][j]^2 (nullable).  Only entries (r < kr, j < N)
@@ -132,10 +134,22 @@ struct dm_simnn_queue {               // rows queued for exact re-evaluation and
     const float* pb32; int nsub; int N2pad;
     const int32_t* flag_count; const int32_t* flag_list; const float* flag_thr;
 };
-size_t dm_simnn_ws_bytes(int B, int N2, int N1);
+// Second reduction of the same fp16 products in one pass (the four maps of dm_fm_to_p2p, dm_knnsplit.hip):
+//   key A = score + bias[j] (-> nn21 / q of dm_simnn_core),  key B = score * scale[j], or the plain score when scale is null
+struct dm_simnn_dual {
+    const float* bias;                // (B, N1)
+    const float* scale;               // (B, N1), nullable
+    const float* tau_add;             // (B) max_j |bias_j|: the biased key is bounded relative to |t| max|s| + tau_add
+    const float* tau_mul;             // (B) max_j scale_j (nullable): the scaled key relative to |t| max|s| tau_mul
+    int32_t* nn_b;                    // (B, N2) arg-max of key B
+    dm_simnn_queue* q_b;              // its queue of ambiguous rows
+};
+size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual = 0);
+bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D);
 int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, int ldT, const _Float16* Fsrc, int ldS,
                   float rel_extra,
-                  const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q);
+                  const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q,
+                  const dm_simnn_dual* dual = nullptr);
 
 // knn21 alone (ZoomOut, ICP, knn_query): fp16-split first pass on the fp16 matrix cores + exact float64 re-evaluation of
 // the ambiguous rows (dm_knnsplit.hip).  The target side (rows of AT) is prepared once for the largest contraction depth
@@ -149,6 +163,12 @@ size_t dm_knn_split_prep_bytes(int B, int N2, int kf);
 size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int kf);
 int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf, const double* AT, dm_knn_split_state* st);
 int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state& st, const double* amaxS);
+
+// all four maps of dm_fm_to_p2p: two passes of the two-key fp16 tile kernel + exact float64 re-evaluation (dm_knnsplit.hip)
+bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K);
+size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K);
+size_t dm_fm_split_zero_bytes(int B);      // block the caller zeroes: (B, DM_NCH) maxima of |Phi2| (filled by dm_launch_phiT) + per-pair bounds
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, void* zeroed, const float* Phi2, int ld2);
 
 // C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,

@@ -21,7 +21,7 @@
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
-constexpr int KS_NCH = 32;     // partial maxima per pair of the target operand
+constexpr int KS_NCH = DM_NCH; // partial maxima per pair of the target operand
 constexpr int KS_BIAS = 8;     // halves reserved in front of the split entries (three used): keeps them 16-byte aligned
 
 // amax[b * KS_NCH + chunk] = max |AT[r][c]| over rows r = chunk (mod KS_NCH), r < K
@@ -64,7 +64,7 @@ __device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
 template <bool SRC>
 __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict__ M, const double* __restrict__ n1,
                                                        const double* __restrict__ amaxT, const double* __restrict__ amaxS, int nS,
-                                                       int K, int N, int Npad, int Kpad, int ld, int fill,
+                                                       int K, int N, int Npad, int Kpad, int ld, int fill, int head,
                                                        _Float16* __restrict__ F, int32_t* __restrict__ overflow) {
     const int b = blockIdx.z, r0 = blockIdx.y * 16;
     const int v = blockIdx.x * 256 + threadIdx.x;
@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
     _Float16* row = F + ((long long)b * N + v) * ld;
     const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
     if (r0 >= K) {
-        f16x8 head = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+        if (head == 0) {                                          // no bias slots (the two-key pass adds the bias in fp32)
+            for (int c = 3 * K; c < fill; ++c) row[c] = (_Float16)0.0f;
+            return;
+        }
+        f16x8 head8 = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
         if (SRC) {
             const double sy = ks_scale(amaxS + b * nS, nS);
             const double beta = -0.5 * n1[(long long)b * Npad + v] * sx * sy;
@@ -81,18 +85,18 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
                 const _Float16 b0 = (_Float16)beta;
                 const double r1 = beta - (double)b0;
                 const _Float16 b1 = (_Float16)r1;
-                head[0] = b0; head[1] = b1; head[2] = (_Float16)(r1 - (double)b1);
+                head8[0] = b0; head8[1] = b1; head8[2] = (_Float16)(r1 - (double)b1);
             }
         } else {
-            head[0] = head[1] = head[2] = (_Float16)1.0f;
+            head8[0] = head8[1] = head8[2] = (_Float16)1.0f;
         }
-        *reinterpret_cast<f16x8*>(row) = head;
+        *reinterpret_cast<f16x8*>(row) = head8;
         for (int c = KS_BIAS + 3 * K; c < fill; ++c) row[c] = (_Float16)0.0f;
         return;
     }
     const double sc = SRC ? ks_scale(amaxS + b * nS, nS) : sx;
     const double* col = M + ((long long)b * Kpad + r0) * Npad + v;
-    _Float16* dst = row + KS_BIAS + 3 * r0;
+    _Float16* dst = row + head + 3 * r0;
     if (r0 + 16 <= K) {
         f16x8 o[6];
 #pragma unroll
@@ -117,13 +121,21 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
 
 // exact re-evaluation: one workgroup per queued row.  Thread (part = t >> 5, c = t & 31) accumulates the contraction
 // rows r = part, part + 8, ... of candidate j = 32 block + c (each wave instruction reads two 256-byte runs of BT);
-// the eight partial sums are added in a fixed order, so duplicated columns score identically and the lowest index wins.
+// the eight partial sums are added in a fixed order, so duplicated columns score identically and the lowest index wins
+// -- and g(i, j) is the same number whichever operand plays the target (the four maps of dm_fm_to_p2p agree on it).
+// KIND (the value the reference compares, targets = columns of AT, candidates = columns of BT):
+//   0  arg-min_j  w[j] - 2 g        w = |candidate|^2                 knn21 (and knn12 with the operands swapped)
+//   1  arg-max_j  g massS[j]        indicator row,    convert.py:144  ind21
+//   2  arg-max_j  g massT[i]        indicator column (the target's own mass)  ind12, operands swapped
+template <int KIND>
 __global__ __launch_bounds__(256) void ks_exact_kernel(const double* __restrict__ AT, const double* __restrict__ BT,
-                                                       const double* __restrict__ n1, int K, int N2, int N2pad, int N1, int N1pad,
+                                                       const double* __restrict__ n1, const float* __restrict__ massS,
+                                                       const float* __restrict__ massT, int K, int N2, int N2pad, int N1, int N1pad,
                                                        int Kpad, const float* __restrict__ pb32, int nsub, int N2pad_s,
                                                        const int32_t* __restrict__ flag_count, const int32_t* __restrict__ flag_list,
                                                        const float* __restrict__ flag_thr, int32_t* __restrict__ nn) {
     extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums + 32 scores
+    __shared__ unsigned long long cmask[4];
     double* part_s = xrow + K;
     const int count = *flag_count;
     const int t = threadIdx.x, c = t & 31, part = t >> 5;
@@ -136,32 +148,52 @@ __global__ __launch_bounds__(256) void ks_exact_kernel(const double* __restrict_
         __syncthreads();
         for (int r = t; r < K; r += 256) xrow[r] = A[(long long)r * N2pad];
         __syncthreads();
-        double bv = DM_INF_F64;
+        double bv = KIND == 0 ? DM_INF_F64 : -DM_INF_F64;
         int bj = DM_IDX_NONE;
-        for (int sb = 0; sb < nsub; ++sb) {
-            const float tb = pb32[((long long)b * nsub + sb) * N2pad_s + i];
-            if (!(tb >= thr)) continue;                          // uniform: every thread reads the same word
-            const int j = sb * 32 + c;
-            double sacc = 0.0;
-            if (j < N1)
-                for (int r = part; r < K; r += 8) sacc = fma(xrow[r], Bm[(long long)r * N1pad + j], sacc);
-            part_s[part * 32 + c] = sacc;
+        const double mt = KIND == 2 ? (double)massT[(long long)b * N2 + i] : 0.0;
+        // candidate blocks: one gather of the row's block maxima (256 at a time), then only the blocks that can still
+        // hold the optimum are visited, in ascending order
+        for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
+            const int sbt = sb0 + t;
+            const bool keep = sbt < nsub && pb32[((long long)b * nsub + sbt) * N2pad_s + i] >= thr;
+            const unsigned long long km = __ballot(keep);
+            if ((t & 63) == 0) cmask[t >> 6] = km;
             __syncthreads();
-            if (t < 32) {
-                double g = part_s[c];
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long mm = cmask[w];                 // uniform
+                while (mm) {
+                    const int sb = sb0 + w * 64 + __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const int j = sb * 32 + c;
+                    double sacc = 0.0;
+                    if (j < N1)
+                        for (int r = part; r < K; r += 8) sacc = fma(xrow[r], Bm[(long long)r * N1pad + j], sacc);
+                    part_s[part * 32 + c] = sacc;
+                    __syncthreads();
+                    if (t < 32 && j < N1) {
+                        double g = part_s[c];
 #pragma unroll
-                for (int q = 1; q < 8; ++q) g += part_s[q * 32 + c];
-                const double v = n1[(long long)b * N1pad + j] - 2.0 * g;          // |y|^2 - 2 <x, y>
-                if (j < N1 && v < bv) { bv = v; bj = j; }        // blocks ascend: strict keeps the lowest index
+                        for (int q = 1; q < 8; ++q) g += part_s[q * 32 + c];
+                        // blocks ascend: strict comparisons keep the lowest index
+                        if (KIND == 0) {
+                            const double v = n1[(long long)b * N1pad + j] - 2.0 * g;          // |y|^2 - 2 <x, y>
+                            if (v < bv) { bv = v; bj = j; }
+                        } else {
+                            const double v = g * (KIND == 1 ? (double)massS[(long long)b * N1 + j] : mt);
+                            if (v > bv) { bv = v; bj = j; }
+                        }
+                    }
+                    __syncthreads();
+                }
             }
-            __syncthreads();
+            __syncthreads();                                      // (cmask is rewritten by the next chunk of blocks)
         }
         if (t < 32) {
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {
                 const double ov = __shfl_xor(bv, off);
                 const int oj = __shfl_xor(bj, off);
-                argmin_merge(bv, bj, ov, oj);
+                if (KIND == 0) argmin_merge(bv, bj, ov, oj); else argmax_merge(bv, bj, ov, oj);
             }
             if (t == 0 && bj != DM_IDX_NONE) nn[o] = bj;
         }
@@ -186,7 +218,7 @@ int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf
     if (!st->Ft || !st->amaxT) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
     DM_LAUNCH(ctx, "knn_split_absmax", ks_absmax_kernel, dim3(KS_NCH, B), dim3(256), 0, AT, kf, N2, N2pad, Kpad, st->amaxT);
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 256), dm_cdiv(kf, 16) + 1, B), dim3(256), 0, AT,
-              (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, st->Ft,
+              (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, KS_BIAS, st->Ft,
               (int32_t*)nullptr);
     return DM_OK;
 }
@@ -202,7 +234,7 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     if (!Fs || !overflow) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
     DM_CHECK_HIP(ctx, hipMemsetAsync(overflow, 0, (size_t)a.B * 4, ctx->stream));
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 256), dm_cdiv(K, 16) + 1, a.B), dim3(256), 0, a.BT,
-              a.n1, st.amaxT, amaxS, dm_cdiv(a.N1pad, 256), K, a.N1, a.N1pad, a.Kpad, D, D, Fs, overflow);
+              a.n1, st.amaxT, amaxS, dm_cdiv(a.N1pad, 256), K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow);
     dm_simnn_queue q;
     // error of the split on top of the fp32 accumulation, relative to |t_i| max_j |s_j|: the dropped <xl, yl> and the two
     // residuals (3 * 2^-22), the fp16 subnormal floor (2 sqrt(K) 2^-25), 25 % slack; 2^-19 at K = 200
@@ -210,7 +242,152 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, st.Ft, st.ldT, Fs, D, rel_extra, overflow, a.knn21, nullptr, nullptr, &q);
     if (rc) return rc;
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
-    DM_LAUNCH(ctx, "knn_split_exact_f64", ks_exact_kernel, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, K, a.N2, a.N2pad, a.N1,
+    DM_LAUNCH(ctx, "knn_split_exact_f64", ks_exact_kernel<0>, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, (const float*)nullptr,
+              (const float*)nullptr, K, a.N2, a.N2pad, a.N1,
               a.N1pad, a.Kpad, q.pb32, q.nsub, q.N2pad, q.flag_count, q.flag_list, q.flag_thr, a.knn21);
+    return DM_OK;
+}
+
+// ---- all four maps of dm_fm_to_p2p on the fp16 matrix cores ---------------------------------------------------------
+// Two passes of the two-key tile kernel over the split operands X = Phi2 rows (h, h, l) and Y = emb1 rows (h, l, h)
+// (no bias slots: 3 K halves per row, the fp16 inner product is sx sy <x_i, y_j> up to the split error):
+//   pass A, targets X, sources Y:   key A = s - n1_j sx sy / 2  -> knn21,   key B = s a1_j -> ind21
+//   pass B, targets Y, sources X:   key A = s - n2_i sx sy / 2  -> knn12,   key B = s      -> ind12   (a1_j > 0 is a
+//                                   per-target factor; targets with a1_j == 0 score 0 everywhere: index 0, like np.argmax)
+// then the ambiguous rows of each of the four reductions are re-evaluated exactly (ks_exact_kernel) with the reference's
+// own float64 expressions.  Needs interior 256-tiles and 3 K >= 160 (dm_fm_split_ok); otherwise the float64 G kernel.
+__global__ __launch_bounds__(256) void fs_bias_kernel(const double* __restrict__ nrm, int N, int Npad, const double* __restrict__ amaxT,
+                                                      const double* __restrict__ amaxS, int nS, const float* __restrict__ mass,
+                                                      float* __restrict__ bias, unsigned int* __restrict__ bmax, unsigned int* __restrict__ mmax) {
+    __shared__ float wb[4], wm[4];
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    const double sxy = ks_scale(amaxT + b * KS_NCH, KS_NCH) * ks_scale(amaxS + b * nS, nS);
+    float bb = 0.f, mm = 0.f;
+    if (j < N) {
+        const float v = (float)(-0.5 * nrm[(long long)b * Npad + j] * sxy);
+        bias[(long long)b * N + j] = v;
+        bb = fabsf(v);
+        if (mass) mm = fabsf(mass[(long long)b * N + j]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { bb = fmaxf(bb, __shfl_xor(bb, off)); mm = fmaxf(mm, __shfl_xor(mm, off)); }
+    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6] = bb; wm[threadIdx.x >> 6] = mm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bb = fmaxf(fmaxf(wb[0], wb[1]), fmaxf(wb[2], wb[3]));
+        mm = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        atomicMax(bmax + b, __float_as_uint(bb));
+        if (mass) atomicMax(mmax + b, __float_as_uint(mm));
+    }
+}
+// ind12[j] = 0 where the target's mass is zero (the whole indicator column is 0: np.argmax returns the first index)
+__global__ __launch_bounds__(256) void fs_zero_mass_kernel(const float* __restrict__ mass, long long n, int32_t* __restrict__ ind12) {
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o < n && mass[o] == 0.0f) ind12[o] = 0;
+}
+
+// X feature rows straight from the fp32 basis (row-major: no transpose): thread (vertex, group of 8 contraction indices)
+// reads 32 contiguous bytes and writes 48; same values as ks_build_kernel<false> on the float64 copy of the same numbers
+__global__ __launch_bounds__(256) void fs_build_rows_kernel(const float* __restrict__ Phi, int N, int K, int ld, const double* __restrict__ amaxT,
+                                                            int D, _Float16* __restrict__ F) {
+    const int b = blockIdx.y;
+    const int ngrp = (D + 23) / 24;
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (long long)N * ngrp) return;
+    const int v = (int)(o / ngrp), q = (int)(o - (long long)v * ngrp);
+    // (x sx, |.| < 2, is exact in fp32 -- sx is a power of two --, and so is x sx - h: the pieces equal those of the float64 split)
+    const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
+    const float* src = Phi + ((long long)b * N + v) * ld + 8 * q;
+    _Float16* dst = F + ((long long)b * N + v) * D + 24 * q;
+    _Float16 o24[24];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        _Float16 h = (_Float16)0.0f, l = (_Float16)0.0f;
+        if (8 * q + u < K) { const float x = (float)((double)src[u] * sx); h = (_Float16)x; l = (_Float16)(x - (float)h); }
+        o24[3 * u] = h; o24[3 * u + 1] = h; o24[3 * u + 2] = l;
+    }
+    if (24 * q + 24 <= D) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            f16x8 w;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = o24[8 * e + u];
+            *reinterpret_cast<f16x8*>(dst + 8 * e) = w;
+        }
+    } else {
+        for (int e = 0; 24 * q + e < D; ++e) dst[e] = o24[e];
+    }
+}
+
+static inline int fs_depth(int K) { return pad_to(3 * K, 32); }
+size_t dm_fm_split_zero_bytes(int B) { return dm_align_up((size_t)B * KS_NCH * 8) + 3 * dm_align_up((size_t)B * 4); }
+bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K) {
+    return ctx->opt_p2p_split != 0 && dm_simnn_dual_ok(ctx, N2, N1, fs_depth(K)) && N1 % 256 == 0 && N2 % 256 == 0;
+}
+size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K) {
+    const size_t D = fs_depth(K);
+    return dm_align_up((size_t)B * N2 * D * 2) + dm_align_up((size_t)B * N1 * D * 2) +
+           dm_align_up((size_t)B * N1 * 4) + dm_align_up((size_t)B * N2 * 4) +
+           dm_simnn_ws_bytes(B, N2, N1, 1) + dm_simnn_ws_bytes(B, N1, N2, 1) + 16384;
+}
+// a: AT, BT (K-major f64), n1, n2, mass1 and all four outputs; amaxS: per-256-column maxima of |BT| (colnorm_kernel);
+// zeroed: dm_fm_split_zero_bytes block, zeroed before dm_launch_phiT(Phi2) filled its first part
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, void* zeroed, const float* Phi2, int ld2) {
+    const int B = a.B, N1 = a.N1, N2 = a.N2;
+    const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop;
+    if (!a.AT || !a.BT || !a.n1 || !a.n2 || !a.mass1 || !a.knn21 || !a.knn12 || !a.ind21 || !a.ind12 || !amaxS || !zeroed || !Phi2)
+        return dm_fail(ctx, DM_EINVAL, "fm_split: missing operand");
+    const int D = fs_depth(K);
+    _Float16* Fx = (_Float16*)dm_ws_take(ctx, (size_t)B * N2 * D * 2);
+    _Float16* Fy = (_Float16*)dm_ws_take(ctx, (size_t)B * N1 * D * 2);
+    float* biasA = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
+    float* biasB = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    if (!Fx || !Fy || !biasA || !biasB) return dm_fail(ctx, DM_ENOMEM, "fm_split: workspace not reserved");
+    const double* amaxT = (const double*)zeroed;
+    const size_t mstride = dm_align_up((size_t)B * 4) / 4;
+    unsigned int* bmaxA = reinterpret_cast<unsigned int*>((char*)zeroed + dm_align_up((size_t)B * KS_NCH * 8));
+    unsigned int* mmax = bmaxA + mstride; unsigned int* bmaxB = bmaxA + 2 * mstride;
+    const int nS = dm_cdiv(a.N1pad, 256);
+    {
+        const long long n = (long long)N2 * ((D + 23) / 24);
+        DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
+                  amaxT, D, Fx);
+    }
+    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 256), dm_cdiv(K, 16) + 1, B), dim3(256), 0, a.BT,
+              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr);
+    DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1, 256), B), dim3(256), 0, a.n1, N1, a.N1pad, amaxT,
+              amaxS, nS, a.mass1, biasA, bmaxA, mmax);
+    DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, a.n2, N2, a.N2pad, amaxT,
+              amaxS, nS, (const float*)nullptr, biasB, bmaxB, (unsigned int*)nullptr);
+    const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
+    const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
+    // pass A: targets = Phi2 rows, candidates = emb1 rows
+    {
+        dm_simnn_queue qa, qb;
+        dm_simnn_dual dual{biasA, a.mass1, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb};
+        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<0>, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, (const float*)nullptr,
+                  (const float*)nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad, qa.flag_count, qa.flag_list,
+                  qa.flag_thr, a.knn21);
+        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<1>, dim3(2048), dim3(256), lds, a.AT, a.BT, (const double*)nullptr, a.mass1,
+                  (const float*)nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qb.pb32, qb.nsub, qb.N2pad, qb.flag_count, qb.flag_list,
+                  qb.flag_thr, a.ind21);
+    }
+    // pass B: targets = emb1 rows, candidates = Phi2 rows
+    {
+        dm_simnn_queue qa, qb;
+        dm_simnn_dual dual{biasB, nullptr, reinterpret_cast<const float*>(bmaxB), nullptr, a.ind12, &qb};
+        int rc = dm_simnn_core(ctx, B, N1, N2, D, Fy, D, Fx, D, rel_extra, nullptr, a.knn12, nullptr, nullptr, &qa, &dual);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<0>, dim3(2048), dim3(256), lds, a.BT, a.AT, a.n2, (const float*)nullptr,
+                  (const float*)nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad, qa.flag_count, qa.flag_list,
+                  qa.flag_thr, a.knn12);
+        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<2>, dim3(2048), dim3(256), lds, a.BT, a.AT, (const double*)nullptr,
+                  (const float*)nullptr, a.mass1, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qb.pb32, qb.nsub, qb.N2pad, qb.flag_count,
+                  qb.flag_list, qb.flag_thr, a.ind12);
+        const long long n = (long long)B * N1;
+        DM_LAUNCH(ctx, "fm_split_zero_mass", fs_zero_mass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a.mass1, n, a.ind12);
+    }
     return DM_OK;
 }

@@ -22,18 +22,30 @@ static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 // =================================================================================================
 // K-major float64 copy of Phi:  out[b][c][i] = Phi[b][i][c]
 // =================================================================================================
+// amax (nullable, zeroed by the caller): DM_NCH partial maxima of |Phi[:, :k]| per pair, kept as the bit patterns of
+// non-negative doubles (which order like unsigned integers) so that workgroups can combine them with atomicMax
 template <typename Tin>
 __global__ __launch_bounds__(256) void phiT_kernel(const Tin* __restrict__ Phi, int N, int k, int ld,
-                                                   double* __restrict__ out, int kpad, int Npad) {
+                                                   double* __restrict__ out, int kpad, int Npad, double* __restrict__ amax) {
     __shared__ Tin tile[64][65];
     const int b = blockIdx.z;
     const int i0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const Tin* P = Phi + (long long)b * N * ld;
     double* O = out + (long long)b * kpad * Npad;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double m = 0.0;
     for (int r = ty; r < 64; r += 4) {
         const int i = i0 + r, c = c0 + tx;
-        tile[r][tx] = (i < N && c < k) ? P[(long long)i * ld + c] : (Tin)0;
+        const Tin v = (i < N && c < k) ? P[(long long)i * ld + c] : (Tin)0;
+        tile[r][tx] = v;
+        m = fmax(m, fabs((double)v));
+    }
+    if (amax) {                                           // uniform
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+        if (tx == 0 && m > 0.0)
+            atomicMax(reinterpret_cast<unsigned long long*>(amax) + (long long)b * DM_NCH + (blockIdx.x + blockIdx.y * gridDim.x) % DM_NCH,
+                      (unsigned long long)__double_as_longlong(m));
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -42,15 +54,15 @@ __global__ __launch_bounds__(256) void phiT_kernel(const Tin* __restrict__ Phi, 
     }
 }
 
-int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld, double* out, int kpad, int Npad) {
+int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld, double* out, int kpad, int Npad, double* amax) {
     dim3 grid(dm_cdiv(Npad, 64), dm_cdiv(kpad, 64), B);
-    DM_LAUNCH(ctx, "phiT", phiT_kernel<float>, grid, dim3(256), 0, Phi, N, k, ld, out, kpad, Npad);
+    DM_LAUNCH(ctx, "phiT", phiT_kernel<float>, grid, dim3(256), 0, Phi, N, k, ld, out, kpad, Npad, amax);
     return DM_OK;
 }
 
 static int launch_transpose_f64(dm_ctx* ctx, int B, int N, int k, const double* X, int ld, double* out, int kpad, int Npad) {
     dim3 grid(dm_cdiv(Npad, 64), dm_cdiv(kpad, 64), B);
-    DM_LAUNCH(ctx, "phiT", phiT_kernel<double>, grid, dim3(256), 0, X, N, k, ld, out, kpad, Npad);
+    DM_LAUNCH(ctx, "phiT", phiT_kernel<double>, grid, dim3(256), 0, X, N, k, ld, out, kpad, Npad, (double*)nullptr);
     return DM_OK;
 }
 
@@ -544,9 +556,14 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     const size_t bytes_AT = (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;
     const bool all = knn12 || ind21 || ind12;      // anything beyond knn21 takes the four-reduction kernel
     const size_t bytes_E2 = all ? (size_t)B * K1pad * N2pad * 8 : 0;
+    // all four maps on interior sizes: two passes of the two-key fp16 tile kernel + exact re-evaluation (dm_knnsplit.hip)
+    const bool split = knn21 && knn12 && ind21 && ind12 && mass1 && dm_fm_split_ok(ctx, N2, N1, k2);
+    const size_t bytes_amax = (size_t)B * dm_cdiv(N1pad, 256) * 8;
+    const size_t bytes_zero = split ? dm_fm_split_zero_bytes(B) : 0;    // |Phi2| maxima and the per-pair bounds: one memset
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + dm_align_up(bytes_E2) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2pad * 8) +
-                        dm_align_up((size_t)B * N1 * 4) + dm_gred_ws_bytes(B, N2, N1);
+                        dm_align_up((size_t)B * N1 * 4) + dm_align_up(bytes_amax) + dm_align_up(bytes_zero) +
+                        (split ? dm_fm_split_ws_bytes(B, N2, N1, k2) : dm_gred_ws_bytes(B, N2, N1));
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bytes_AT);
@@ -554,13 +571,17 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     double* E2 = bytes_E2 ? (double*)dm_ws_take(ctx, bytes_E2) : nullptr;
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
     double* n2 = (double*)dm_ws_take(ctx, (size_t)B * N2pad * 8);
-    if (!AT || !BT || (bytes_E2 && !E2) || !n1 || !n2) return dm_fail(ctx, DM_ENOMEM, "fm_to_p2p: workspace not reserved");
+    double* amaxS = (double*)dm_ws_take(ctx, bytes_amax);
+    void* zeroed = bytes_zero ? dm_ws_take(ctx, bytes_zero) : nullptr;
+    if (!AT || !BT || (bytes_E2 && !E2) || !n1 || !n2 || !amaxS || (bytes_zero && !zeroed))
+        return dm_fail(ctx, DM_ENOMEM, "fm_to_p2p: workspace not reserved");
+    if (zeroed) DM_CHECK_HIP(ctx, hipMemsetAsync(zeroed, 0, bytes_zero, ctx->stream));
 
     // AT = Phi2[:, :k2]^T (K-major f64)
-    rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad);
+    rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad, (double*)zeroed);
     if (rc) return rc;
     // BT = emb1^T, emb1 = Phi1[:, :k1] C^T (N1 x k2): emb1T[c][j] = sum_m C[c][m] Phi1[j][m];  n1_j = |emb1_j|^2
-    rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, C, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 1);
+    rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, C, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 1, amaxS);
     if (rc) return rc;
     if (all) {
         // emb2 = Phi2[:, :k2] C (N2 x k1): emb2T[m][i] = sum_c C[c][m] Phi2[i][c];  only n2_i = |emb2_i|^2 is used
@@ -577,13 +598,13 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
         a.mass1 = ones;
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
+    if (split) { a.Ktrue = k2; return dm_launch_fm_split(ctx, a, amaxS, zeroed, Phi2, ld2); }
     return dm_launch_gred(ctx, a);
 }
 
 // which path dm_fm_to_p2p takes for these sizes on this context (bench.py names the dominant kernel accordingly)
 extern "C" int dm_fm_to_p2p_uses_split(const dm_ctx* ctx, int N2, int N1, int k) {
-    (void)ctx; (void)N2; (void)N1; (void)k;
-    return 0;
+    return (ctx && dm_fm_split_ok(ctx, N2, N1, k)) ? 1 : 0;
 }
 
 // ---- generic exact nearest neighbour (pyFM/spectral/nn_utils.py:4-38, k = 1) ---------------------------------

@@ -13,6 +13,8 @@
 // (2 D (1 + 1/16) 2^-23 + 3 * 2^-19) |t_i| max_j |s_j|  is re-evaluated in float64 (products of fp16 are exact in
 // f64, the f64 sum is exact to 1e-16 relative), so the returned index equals the float64 argmax with the
 // lowest-index tie rule.
+#include <string.h>
+
 #include "dm_device.h"
 #include "dm_internal.h"
 
@@ -42,6 +44,10 @@ struct simnn_params {
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
     int ldT, ldS;                            // row strides (halves) of Ftgt / Fsrc, >= D, multiples of 8
+    // two reductions of the same products (DUAL kernels, dm_knnsplit.hip: dm_launch_fm_split):
+    //   key A = score + bias[j]  -> pb / pj / ps / pb32;   key B = score * scale[j] (DUAL 1) or score (DUAL 2) -> the *_2 arrays
+    const float* bias; const float* scale;   // (B, N1) per source row
+    float* pb_2; int32_t* pj_2; float* ps_2; float* pb32_2;
     int dbg;                                 // DM_EXPERIMENTS builds only (0 in the product): see simnn_pipe_kernel
 };
 
@@ -91,10 +97,12 @@ __device__ __forceinline__ float k_key(float v, int code) { return __int_as_floa
 // 16, instead of compare/select chains on (value, index) pairs.  A key differs from its score by < 2^-19 relative;
 // for any candidate j other than the winner  fp32(best) - fp32(j) >= (bv - sv) - 3 * 2^-19 |t||s|  (one for bv, one
 // for the second key, one for its truncation), which is part of the bound that sends a row to the exact fix-up.
-template <bool FULL, int TT, int SKIP = 0>     // SKIP (experiments): 2 no block-maxima stores, 4 no merge / partial stores
+// DUAL (1 / 2): two key sets from the same accumulators, A = score + bias[j], B = score * scale[j] (1) or score (2);
+// `bsl` = this tile's 256 bias values followed by its 256 scale values, in LDS; scratch is then 12 KiB.
+template <bool FULL, int TT, int SKIP = 0, int DUAL = 0>     // SKIP (experiments): 2 no block-maxima stores, 4 no merge / partial stores
 __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
                                            bool do_tn, bool do_sn, int b, int i0, int j0, int ts_, float* scratch,
-                                           int lane, int wsrc, int wtgt) {
+                                           int lane, int wsrc, int wtgt, const float* bsl = nullptr) {
     const int t = threadIdx.x;
     const int hi = lane >> 5;
     if (do_tn) {
@@ -118,9 +126,13 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
         if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
     }
 
-    float* sb = scratch;                                 // [2 wsrc][TT]
-    int* sj = reinterpret_cast<int*>(scratch) + 2 * TT;
-    float* ss = scratch + 4 * TT;
+    constexpr int NKIND = DUAL ? 2 : 1;
+#pragma unroll
+    for (int kind = 0; kind < NKIND; ++kind) {
+    float* sb = scratch + kind * 6 * TT;                 // [2 wsrc][TT]
+    int* sj = reinterpret_cast<int*>(sb) + 2 * TT;
+    float* ss = sb + 4 * TT;
+    float* pb32k = kind ? p.pb32_2 : p.pb32;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         float Bk = DM_KEY_NONE, Sk = DM_KEY_NONE;        // running best / second-best key of this lane
@@ -129,9 +141,17 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             float k[16];
+            f32x4 w4[4];
+            if (DUAL && (kind == 0 || DUAL == 1)) {      // the per-source terms of this block's 16 candidates
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    w4[q] = *reinterpret_cast<const f32x4*>(bsl + kind * 256 + wsrc * 128 + st * 32 + 4 * hi + 8 * q);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[st][tt][r];
+                if (DUAL && kind == 0) v = v + w4[r >> 2][r & 3];
+                if (DUAL == 1 && kind == 1) v = v * w4[r >> 2][r & 3];
                 if (!FULL) {
                     const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     v = (j < p.N1) ? v : DM_KEY_NONE;
@@ -148,7 +168,7 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
             // maximum over this block of 32 source rows (both half-waves), an upper bound of its fp32 scores up to 2^-19
             const float m32 = xhalf_max(bk);
             if (!(SKIP & 2) && lane < 32 && gi32 < p.N2)
-                p.pb32[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
+                pb32k[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
             Sk = k_max3(Sk, sk, k_min(Bk, bk));
             Bst = (bk > Bk) ? st : Bst;                  // (equal truncated scores: either block; such a row is re-scored exactly)
             Bk = k_max(Bk, bk);
@@ -170,18 +190,24 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
             sb[wsrc * TT + li] = bv; sj[wsrc * TT + li] = bj; ss[wsrc * TT + li] = sv;
         }
     }
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the scratch writes; vmcnt untouched
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (!(SKIP & 4) && t < TT) {
-        const int gi = i0 + t;
+    if (!(SKIP & 4) && t < NKIND * TT) {                 // (DUAL: the workgroup has 2 TT threads, one per row and kind)
+        const int kind = t / TT, tr = t - kind * TT;
+        const float* sb = scratch + kind * 6 * TT;
+        const int* sj = reinterpret_cast<const int*>(sb) + 2 * TT;
+        const float* ss = sb + 4 * TT;
+        const int gi = i0 + tr;
         if (gi < p.N2) {
-            float bv = sb[t], sv = ss[t];
-            int bj = sj[t];
-            top2_merge(bv, bj, sv, sb[TT + t], sj[TT + t], ss[TT + t]);
+            float bv = sb[tr], sv = ss[tr];
+            int bj = sj[tr];
+            top2_merge(bv, bj, sv, sb[TT + tr], sj[TT + tr], ss[TT + tr]);
             const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
-            p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv;
+            if (kind == 0) { p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv; }
+            else { p.pb_2[o] = bv; p.pj_2[o] = bj; p.ps_2[o] = sv; }
         }
     }
 }
@@ -325,10 +351,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int PBK = 32;                    // halves per stage
 constexpr int SIMNN_PRODUCT_XV = 64;
 constexpr int SIMNN_PRODUCT_WT = 4;
-#define DM_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15))    /* vmcnt(n) lgkmcnt(0) */
-static inline size_t simnn_pipe_lds(int WT) {
+#define DM_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | ((((n) >> 4) & 3) << 14))    /* vmcnt(n) lgkmcnt(0) */
+static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
     const int TT = 64 * WT, NBUF = WT == 4 ? 4 : 3;
-    return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + 3 * 2 * ST * 4;
+    // ring | reduction scratch (6 KiB per key set) | DUAL: two slots of (256 bias + 256 scale) floats
+    return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + (dual ? 2 : 1) * 3 * 2 * ST * 4 + (dual ? 2 * 512 * 4 : 0);
 }
 
 __device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int& b, int& tt_, int& ts_) {
@@ -339,8 +366,9 @@ __device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int&
     ts_ = tts - tt_ * p.tilesS;
 }
 
-template <int XV, int WT>
+template <int XV, int WT, int DUAL = 0>
 __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p) {
+    static_assert(DUAL == 0 || WT == 4, "the two-key epilogue needs one thread per row and kind");
     constexpr int TT = 64 * WT;                  // target rows per tile
     constexpr int NW = 2 * WT;                   // waves
     constexpr int NBUF = WT == 4 ? 4 : 3;        // ring depth
@@ -354,6 +382,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | scratch
     float* scratch = reinterpret_cast<float*>(smem + NBUF * PSTAGE);
+    float* bias_lds = scratch + 12 * TT;         // DUAL: [2 slots][256 bias | 256 scale], filled by LDS-DMA one tile ahead
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -384,6 +413,15 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         d_S = reinterpret_cast<const char*>(p.Fsrc + ((long long)b_ * p.N1 + ts_ * ST + wave * 16 * NSI) * p.ldS);     \
         d_kp = STAG == 0 ? 0 : (STAG == 1 ? (ts_ + tt_) % ns : ((ts_ + tt_) * ns / p.tilesS) % ns);                    \
         d_s = 0;                                                                                                       \
+        if (DUAL && wave == 0) {      /* the tile's per-source terms: one 1 KiB piece each, landed long before its epilogue */ \
+            float* dstB = bias_lds + (d_tile & 1) * 512;                                                               \
+            const char* gb = reinterpret_cast<const char*>(p.bias + (long long)b_ * p.N1 + ts_ * ST) + lane * 16;      \
+            __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)dstB, 16, 0, 0);                                      \
+            if (DUAL == 1) {                                                                                           \
+                const char* gs = reinterpret_cast<const char*>(p.scale + (long long)b_ * p.N1 + ts_ * ST) + lane * 16; \
+                __builtin_amdgcn_global_load_lds((gptr_t)gs, (lptr_t)(dstB + 256), 16, 0, 0);                          \
+            }                                                                                                          \
+        }                                                                                                              \
     }
     // half H_ (0 / 1) of the DMA instructions of the stage stream's current stage: T piece H_, S pieces H_*NSI/2 ..
 #define SIMNN_DMA1(H_)                                                                                                 \
@@ -432,7 +470,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     constexpr bool NOEPI = (dbg & 7) == 1 || (dbg & 7) == 7;
-    constexpr int EPI_ST = 8;                     // stores every wave issues in an epilogue: the 2 x 4 block maxima
+    constexpr int EPI_ST = DUAL ? 16 : 8;         // stores every wave issues in an epilogue: the 2 x 4 block maxima per key set
     int r_slot = 0;                               // ring slot of the stage being computed
     const bool late = FLIP && wave >= NW / 2;
 #define SIMNN_READ(fs_, ft_, slot_, fo_)                                                                               \
@@ -524,7 +562,8 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
             if (sacc == 1.2345f) p.pb[0] = sacc;
             continue;
         }
-        simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt);
+        simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0, DUAL>(
+            p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt, bias_lds + (n & 1) * 512);
     }
     __builtin_amdgcn_s_waitcnt(0x0070);                          // nothing of this workgroup may still be in flight
 #undef SIMNN_TILE_LOOP
@@ -541,7 +580,8 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restrict__ pb, const int32_t* __restrict__ pj,
                                                           const float* __restrict__ ps, int tilesS, int N2, int N2pad,
                                                           const float* __restrict__ tnorm2, const unsigned int* __restrict__ smax2,
-                                                          float tau_scale, int32_t* __restrict__ nn, float* __restrict__ best,
+                                                          float tau_scale, const float* __restrict__ tau_add,
+                                                          const float* __restrict__ tau_mul, int32_t* __restrict__ nn, float* __restrict__ best,
                                                           float* __restrict__ margin, int32_t* __restrict__ flag_count,
                                                           int32_t* __restrict__ flag_list, float* __restrict__ flag_thr,
                                                           const int32_t* __restrict__ force_flag) {
@@ -559,7 +599,8 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restric
     const float m = bv - sv;
     if (best) best[o] = bv;
     if (margin) margin[o] = m;
-    const float tau = tau_scale * sqrtf(tnorm2[o] * __uint_as_float(smax2[b]));
+    // (two-key pass: tau_add = max_j |bias_j| of the pair for the biased key, tau_mul = max_j scale_j for the scaled key)
+    const float tau = tau_scale * (sqrtf(tnorm2[o] * __uint_as_float(smax2[b])) * (tau_mul ? tau_mul[b] : 1.0f) + (tau_add ? tau_add[b] : 0.0f));
     const bool forced = force_flag && force_flag[b] != 0;   // the caller could not bound the error for this pair: re-score everything
     if (forced || !(m > tau)) {
         const int pos = atomicAdd(flag_count, 1);
@@ -579,6 +620,7 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
                                                           const int32_t* __restrict__ flag_list,
                                                           const float* __restrict__ flag_thr, int32_t* __restrict__ nn) {
     extern __shared__ __attribute__((aligned(16))) double trow[];   // D doubles + 4 (value) + 4 ints
+    __shared__ unsigned long long cmask[4];
     double* wv = trow + D;
     int* wj = reinterpret_cast<int*>(wv + 4);
     const int count = *flag_count;
@@ -594,23 +636,36 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
         __syncthreads();
         double bv = -DM_INF_F64;
         int bj = DM_IDX_NONE;
-        for (int sb = 0; sb < nsub; ++sb) {
-            const float tb = pb32[((long long)b * nsub + sb) * N2pad + i];
-            if (!(tb >= thr)) continue;                       // uniform: every thread reads the same word
-            const int j = sb * 32 + cand;
-            double sacc = 0.0;
-            if (j < N1) {
-                const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
-                for (int k = part * 8; k < D; k += 64) {      // D % 8 == 0 is guaranteed by the caller
-                    const f16x8 v = *reinterpret_cast<const f16x8*>(sr + k);
+        // candidate blocks: one gather of the row's block maxima (256 at a time), then only the blocks that can still
+        // hold the arg-max are visited, in ascending order
+        for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
+            const int sbt = sb0 + (int)threadIdx.x;
+            const bool keep = sbt < nsub && pb32[((long long)b * nsub + sbt) * N2pad + i] >= thr;
+            const unsigned long long km = __ballot(keep);
+            if (lane == 0) cmask[wave] = km;
+            __syncthreads();
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long mm = cmask[w];                 // uniform
+                while (mm) {
+                    const int sb = sb0 + w * 64 + __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const int j = sb * 32 + cand;
+                    double sacc = 0.0;
+                    if (j < N1) {
+                        const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
+                        for (int k = part * 8; k < D; k += 64) {      // D % 8 == 0 is guaranteed by the caller
+                            const f16x8 v = *reinterpret_cast<const f16x8*>(sr + k);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) sacc = fma((double)v[u], trow[k + u], sacc);
+                            for (int u = 0; u < 8; ++u) sacc = fma((double)v[u], trow[k + u], sacc);
+                        }
+                    }
+                    sacc += __shfl_xor(sacc, 1);
+                    sacc += __shfl_xor(sacc, 2);
+                    sacc += __shfl_xor(sacc, 4);
+                    if (j < N1 && sacc > bv) { bv = sacc; bj = j; }   // blocks ascend: strict keeps the lowest index
                 }
             }
-            sacc += __shfl_xor(sacc, 1);
-            sacc += __shfl_xor(sacc, 2);
-            sacc += __shfl_xor(sacc, 4);
-            if (j < N1 && sacc > bv) { bv = sacc; bj = j; }   // blocks ascend: strict keeps the lowest index
+            __syncthreads();
         }
         // (all 8 lanes of a candidate hold the same pair; merge over the candidates of the workgroup)
 #pragma unroll
@@ -632,19 +687,29 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
-size_t dm_simnn_ws_bytes(int B, int N2, int N1) {
+size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual) {
     const size_t N2pad = pad_to(N2, ST), tilesS = dm_cdiv(N1, ST);
     const size_t np = (size_t)B * tilesS * N2pad, np32 = (size_t)B * tilesS * (ST / 32) * N2pad;
-    return 3 * dm_align_up(np * 4) + dm_align_up(np32 * 4) + dm_align_up((size_t)B * N2 * 4) * 3 + dm_align_up((size_t)B * 4) + 8192;
+    const size_t keyset = 3 * dm_align_up(np * 4) + dm_align_up(np32 * 4) + dm_align_up((size_t)B * N2 * 4) * 2 + 512;
+    return (dual ? 2 : 1) * keyset + dm_align_up((size_t)B * N2 * 4) + dm_align_up((size_t)B * 4) + 8192;
+}
+
+// can the two-key pass run on these sizes (interior 256 x 256 tiles, contraction a multiple of a stage and deep enough
+// for the ring)?
+bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D) {
+    return ctx->opt_simnn_pipe && N2 % ST == 0 && N1 % ST == 0 && D % PBK == 0 && D >= 5 * PBK;
 }
 
 // Tile kernel + merge: fp32 scores, top-2 per target row, the rows whose margin is inside the error bound queued for an
 // exact re-evaluation by the caller.  Workspace comes from the context arena (the caller reserved dm_simnn_ws_bytes).
 // rel_extra: additional relative error of a score (in units of |t_i| max_j |s_j|) on top of the fp32 accumulation bound.
+// dual (nullable): a second reduction of the same products, see dm_simnn_dual; nn21 / q then belong to key A.
 int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, int ldT, const _Float16* Fsrc, int ldS,
                   float rel_extra,
-                  const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q) {
+                  const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q,
+                  const dm_simnn_dual* dual) {
     simnn_params p;
+    memset(&p, 0, sizeof(p));
     p.Ftgt = Ftgt; p.Fsrc = Fsrc;
     p.N2 = N2; p.N1 = N1; p.D = D; p.N2pad = pad_to(N2, ST);
     p.ldT = ldT; p.ldS = ldS;
@@ -661,23 +726,40 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     p.tnorm2 = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* flag_list = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* flag_thr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    p.smax2 = (unsigned int*)dm_ws_take(ctx, (size_t)B * 4);
-    int32_t* flag_count = (int32_t*)dm_ws_take(ctx, 256);
-    if (!p.pb || !p.pj || !p.ps || !p.pb32 || !p.tnorm2 || !flag_list || !flag_thr || !p.smax2 || !flag_count)
+    // per-pair source norm maxima and the queue counters: one block, one memset
+    const size_t ctl_bytes = dm_align_up((size_t)B * 4) + 512;
+    char* ctl = (char*)dm_ws_take(ctx, ctl_bytes);
+    if (!p.pb || !p.pj || !p.ps || !p.pb32 || !p.tnorm2 || !flag_list || !flag_thr || !ctl)
         return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
+    p.smax2 = (unsigned int*)ctl;
+    int32_t* flag_count = (int32_t*)(ctl + dm_align_up((size_t)B * 4));
+    int32_t* flag_list2 = nullptr; float* flag_thr2 = nullptr; int32_t* flag_count2 = nullptr;
+    if (dual) {
+        if (!dm_simnn_dual_ok(ctx, N2, N1, D) || !dual->bias || !dual->nn_b || !dual->q_b)
+            return dm_fail(ctx, DM_EINVAL, "simnn: the two-key pass needs interior tiles, D %% 32 == 0, D >= 160");
+        p.bias = dual->bias; p.scale = dual->scale;
+        p.pb_2 = (float*)dm_ws_take(ctx, np * 4);
+        p.pj_2 = (int32_t*)dm_ws_take(ctx, np * 4);
+        p.ps_2 = (float*)dm_ws_take(ctx, np * 4);
+        p.pb32_2 = (float*)dm_ws_take(ctx, np32 * 4);
+        flag_list2 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+        flag_thr2 = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+        flag_count2 = flag_count + 64;
+        if (!p.pb_2 || !p.pj_2 || !p.ps_2 || !p.pb32_2 || !flag_list2 || !flag_thr2)
+            return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
+    }
 
-    DM_CHECK_HIP(ctx, hipMemsetAsync(p.smax2, 0, (size_t)B * 4, ctx->stream));
-    DM_CHECK_HIP(ctx, hipMemsetAsync(flag_count, 0, 4, ctx->stream));
+    DM_CHECK_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, ctx->stream));
     const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16) + 3 * 2 * ST * 4;
     const bool interior = (N2 % ST == 0 && N1 % ST == 0);
     // DM_EXPERIMENTS: DM_SIMNN_DEBUG = variant bits XV (simnn_pipe_kernel) + 256 / 512 for the 8-wave / 4-wave shape
-    const int WT = (p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT);
+    const int WT = dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT));
     // (the stage loop peels its first and last stages: the contraction must be at least ring depth + 1 stages deep)
     if (interior && ctx->opt_simnn_pipe && D % PBK == 0 && D >= (WT == 4 ? 5 : 4) * PBK) {
         const int TT = 64 * WT;
         p.tilesT = p.N2pad / TT;
         p.total = B * p.tilesT * p.tilesS;
-        const size_t lds_pipe = simnn_pipe_lds(WT);
+        const size_t lds_pipe = simnn_pipe_lds(WT, dual ? 1 : 0);
         // workgroups that fit a CU at once walk the tiles (opt_simnn_persist: 0 = one workgroup per tile, 1 = as many
         // workgroups as are resident when there are more tiles than that, n > 1 = n workgroups (tests))
         const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
@@ -685,15 +767,19 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         const int want = ctx->opt_simnn_persist > 1 ? ctx->opt_simnn_persist : (ctx->opt_simnn_persist ? resident : p.total);
         const int grid = want < p.total ? want : p.total;
         int rc = DM_OK;
-#define SIMNN_LAUNCH_XV(XV_, WT_)                                                                                      \
+#define SIMNN_LAUNCH_XV(XV_, WT_, DUAL_, NAME_)                                                                        \
         {                                                                                                              \
-            rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<XV_, WT_>, lds_pipe);                                \
+            rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<XV_, WT_, DUAL_>, lds_pipe);                         \
             if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, "simnn_f16_mfma", (simnn_pipe_kernel<XV_, WT_>), dim3(grid), dim3(128 * WT_), lds_pipe, p); \
+            DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<XV_, WT_, DUAL_>), dim3(grid), dim3(128 * WT_), lds_pipe, p);     \
         }
+        if (dual) {
+            if (dual->scale) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 1, "simnn2_f16_mfma")
+            else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 2, "simnn2_f16_mfma")
+        } else {
 #ifdef DM_EXPERIMENTS
         switch (p.dbg) {
-#define SIMNN_CASE(XV_) case 512 + XV_: SIMNN_LAUNCH_XV(XV_, 2) break; case 256 + XV_: SIMNN_LAUNCH_XV(XV_, 4) break;
+#define SIMNN_CASE(XV_) case 512 + XV_: SIMNN_LAUNCH_XV(XV_, 2, 0, "simnn_f16_mfma") break; case 256 + XV_: SIMNN_LAUNCH_XV(XV_, 4, 0, "simnn_f16_mfma") break;
             SIMNN_CASE(0) SIMNN_CASE(1) SIMNN_CASE(7) SIMNN_CASE(9)
             SIMNN_CASE(16) SIMNN_CASE(32) SIMNN_CASE(64)
             SIMNN_CASE(64 + 1) SIMNN_CASE(64 + 7) SIMNN_CASE(64 + 9) SIMNN_CASE(64 + 16) SIMNN_CASE(64 + 32)
@@ -701,11 +787,12 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             SIMNN_CASE(64 + 2) SIMNN_CASE(64 + 4) SIMNN_CASE(64 + 6)
             SIMNN_CASE(64 + 128) SIMNN_CASE(64 + 128 + 1) SIMNN_CASE(64 + 128 + 9)
 #undef SIMNN_CASE
-            default: SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT) break;
+            default: SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma") break;
         }
 #else
-        SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT)
+        SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma")
 #endif
+        }
 #undef SIMNN_LAUNCH_XV
     } else {
         int rc = dm_grant_lds(ctx, (const void*)simnn_edge_kernel, lds_edge);
@@ -715,12 +802,23 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     // twice the error bound of a score, relative to |t_i| max_j |s_j|: fp32 accumulation (D exact products,
     // D (1 + 1/16) additions, unit roundoff 2^-23, safe for round-to-nearest and for truncating adders) + the caller's
     // own term, plus 3 * 2^-19 for the 4 mantissa bits the reduction keys give up (simnn_tail); 1 % slack for the
-    // fp32 norms
-    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 1.5f * 1.9073486e-6f + rel_extra);
+    // fp32 norms.  Two-key pass: one more rounding (2^-23 covers the fp32 bias / scale and the add / multiply); key A is
+    // bounded relative to |t_i| max|s_j| + max|bias_j|, key B relative to |t_i| max|s_j| max scale_j.
+    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 1.5f * 1.9073486e-6f + rel_extra +
+                                            (dual ? 1.1920929e-7f : 0.0f));
     DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb, p.pj, p.ps, p.tilesS, N2,
-              p.N2pad, p.tnorm2, p.smax2, tau_scale, nn21, best, margin, flag_count, flag_list, flag_thr, force_flag);
+              p.N2pad, p.tnorm2, p.smax2, tau_scale, dual ? dual->tau_add : (const float*)nullptr, (const float*)nullptr, nn21,
+              best, margin, flag_count, flag_list, flag_thr, force_flag);
     q->pb32 = p.pb32; q->nsub = p.nsub; q->N2pad = p.N2pad;
     q->flag_count = flag_count; q->flag_list = flag_list; q->flag_thr = flag_thr;
+    if (dual) {
+        DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb_2, p.pj_2, p.ps_2,
+                  p.tilesS, N2, p.N2pad, p.tnorm2, p.smax2, tau_scale, (const float*)nullptr, dual->tau_mul, dual->nn_b,
+                  (float*)nullptr, (float*)nullptr, flag_count2, flag_list2, flag_thr2, force_flag);
+        dm_simnn_queue* q2 = dual->q_b;
+        q2->pb32 = p.pb32_2; q2->nsub = p.nsub; q2->N2pad = p.N2pad;
+        q2->flag_count = flag_count2; q2->flag_list = flag_list2; q2->flag_thr = flag_thr2;
+    }
     return DM_OK;
 }
 

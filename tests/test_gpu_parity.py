@@ -443,6 +443,53 @@ def test_zoomout_split_equals_f64_kernel(eng):
     assert np.array_equal(res["1"][0], res["0"][0])
 
 
+def _split_case(rng, B, N1, N2, k1, k2, kind):
+    """operands for dm_fm_to_p2p that stress the fp16-split path: near-delta maps, exact duplicates, zero / spread masses"""
+    Phi1 = rng.standard_normal((B, N1, k1)).astype(np.float32)
+    Phi2 = rng.standard_normal((B, N2, k2)).astype(np.float32)
+    C = rng.standard_normal((B, k2, k1)) / np.sqrt(k1)
+    a1 = rng.uniform(0.5, 1.5, (B, N1)).astype(np.float32)
+    if kind == "permuted":                                  # a true correspondence: Phi2 = Phi1[perm] + noise, C ~ identity
+        for b in range(B):
+            perm = rng.permutation(N1)[:N2] if N2 <= N1 else rng.integers(0, N1, N2)
+            km = min(k1, k2)
+            Phi2[b][:, :km] = Phi1[b][perm][:, :km] + 1e-3 * rng.standard_normal((N2, km)).astype(np.float32)
+        C = np.eye(k2, k1)[None].repeat(B, axis=0) + 1e-3 * rng.standard_normal((B, k2, k1))
+    if kind == "duplicates":                                # exact ties in all four reductions
+        Phi1[:, N1 // 2:N1 // 2 + 40] = Phi1[:, :40]
+        Phi2[:, 100:130] = Phi2[:, 300:330]
+        a1[:, N1 // 2:N1 // 2 + 40] = a1[:, :40]
+    if kind == "masses":                                    # zero masses, five decades of spread
+        a1 = (10.0 ** rng.uniform(-5, 0, (B, N1))).astype(np.float32)
+        a1[:, ::97] = 0.0
+    if kind == "scales":                                    # operand scales far apart, smooth decay over the spectrum
+        Phi1 *= (1e-3 * 0.97 ** np.arange(k1)).astype(np.float32)
+        Phi2 *= (2e2 * 0.95 ** np.arange(k2)).astype(np.float32)
+    return Phi1, Phi2, a1, C
+
+
+@pytest.mark.parametrize("kind", ["random", "permuted", "duplicates", "masses", "scales"])
+def test_fm_to_p2p_split_equals_f64_kernel(eng, kind):
+    """the four maps from the two-pass fp16 tile kernel + exact re-evaluation equal those of the float64 G kernel"""
+    rng = np.random.default_rng({"random": 1, "permuted": 2, "duplicates": 3, "masses": 4, "scales": 5}[kind])
+    for (B, N1, N2, k1, k2) in ((3, 512, 768, 64, 64), (2, 1024, 512, 72, 100)):
+        Phi1, Phi2, a1, C = _split_case(rng, B, N1, N2, k1, k2, kind)
+        assert eng.p2p_split_active(N2, N1, k2)
+        res = {}
+        for split in (1, 0):
+            eng.set_option("p2p_split", split)
+            res[split] = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
+        eng.set_option("p2p_split", 1)
+        for name in ("knn21", "knn12", "ind21", "ind12"):
+            bad = int((res[1][name] != res[0][name]).sum())
+            assert bad == 0, (kind, name, bad, (B, N1, N2, k1, k2))
+        for b in range(B):                                   # and the float64 kernel against the oracle, once per kind
+            want = orc.fm_to_p2p_all(C[b], Phi1[b].astype(np.float64), Phi2[b].astype(np.float64), a1[b].astype(np.float64))
+            if kind in ("random", "masses"):
+                for name, w in zip(("knn21", "knn12", "ind21", "ind12"), want):
+                    assert (res[1][name][b] != w).mean() < 1e-3, (kind, name)
+
+
 def test_fuzz_knn_query(eng):
     from hypothesis import given, strategies as st
 
