@@ -292,7 +292,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + 4 * dm_align_up(bG) + dm_align_up(bImg) +
                         2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 3 * dm_align_up((size_t)B * N2 * 4) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, k2) + dm_knn_split_ws_bytes(B, N2, N1, k2) +
-                        dm_align_up((size_t)B * (N1pad / 256 + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
+                        dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bAT);
@@ -310,7 +310,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* iota = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* ones = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / 256 + 1) * 8);
+    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / DM_EMB_COLS + 1) * 8);
     double* Gx = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
     double* Gt = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
     if (!AT || !BT || !Ccur || !R || !Xa || !Xb || !G || !Ginv || !img || !Tm || !Wm || !n1 || !p21 || !iota || !ones || !amaxS ||
@@ -345,7 +345,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
         a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
         a.knn21 = p21; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
         a.Ktrue = k2;
-        rc = dm_launch_knn21(ctx, a, knn, amaxS);
+        rc = dm_launch_knn21(ctx, a, knn, amaxS, dm_cdiv(N1pad, DM_EMB_COLS));
         if (rc) return rc;
         // R = Phi2^T Phi1[p21]   (k2 x k1);   Chat = (Phi2^T Phi2)^-1 R
         rc = dm_launch_p2p_to_fm(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);

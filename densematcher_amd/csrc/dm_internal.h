@@ -107,11 +107,12 @@ int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld,
 // embT[b][r][j] = sum_m Cm[b][r][m] * Phi[b][j][m]   (r < kr, m < km), K-major f64
 // (B, krpad, Npad); nrm[b][j] = sum_r embT[b][r][j]^2 (nullable).  Only entries (r < kr, j < N)
 // are written; zero_first clears the whole buffer before (padding must read as 0).
-// Cm is (B, kr, km) f64 with row stride ldc; if transC, Cm[b][m][r] is read instead.
+// Cm is (B, kr, km) f64 with row stride ldc; if transC, Cm[b][m][r] is read instead.  embT may be null (norms only).
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld,
                     const double* Cm, int ldc, long long strideC, int transC,
                     double* embT, int krpad, int Npad, double* nrm, int zero_first,
-                    double* amax_part = nullptr);   // amax_part: (B, ceil(Npad/256)) max |embT| per 256 columns (nullable)
+                    double* amax_part = nullptr);   // amax_part: (B, ceil(Npad / DM_EMB_COLS)) max |embT| per block of columns (nullable)
+constexpr int DM_EMB_COLS = 64;
 
 // Fused G = A^T B tile kernel with the arg-reductions (see dm_p2p.hip).
 struct dm_gred_args {
@@ -153,7 +154,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
 
 // knn21 alone (ZoomOut, ICP, knn_query): fp16-split first pass on the fp16 matrix cores + exact float64 re-evaluation of
 // the ambiguous rows (dm_knnsplit.hip).  The target side (rows of AT) is prepared once for the largest contraction depth
-// kf of a call; every search then passes the current depth in a.Ktrue and the per-256-column maxima of |BT| in amaxS
+// kf of a call; every search then passes the current depth in a.Ktrue and nS partial maxima of |BT| per pair in amaxS
 // (what colnorm_kernel / dm_launch_embed emit).  Only AT, BT, n1, knn21 of dm_gred_args are used.
 struct dm_knn_split_state {
     _Float16* Ft = nullptr; int ldT = 0; double* amaxT = nullptr; int kf = 0;
@@ -162,13 +163,13 @@ struct dm_knn_split_state {
 size_t dm_knn_split_prep_bytes(int B, int N2, int kf);
 size_t dm_knn_split_ws_bytes(int B, int N2, int N1, int kf);
 int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf, const double* AT, dm_knn_split_state* st);
-int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state& st, const double* amaxS);
+int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state& st, const double* amaxS, int nS);   // nS maxima per pair
 
 // all four maps of dm_fm_to_p2p: two passes of the two-key fp16 tile kernel + exact float64 re-evaluation (dm_knnsplit.hip)
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K);
 size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K);
 size_t dm_fm_split_zero_bytes(int B);      // block the caller zeroes: (B, DM_NCH) maxima of |Phi2| (filled by dm_launch_phiT) + per-pair bounds
-int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, void* zeroed, const float* Phi2, int ld2);
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const float* Phi2, int ld2);
 
 // C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,

@@ -55,67 +55,74 @@ __device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (double)hi);
 }
 
-// Feature rows, layout [ 8 bias slots (3 used) | 3 entries per contraction index | zero pad ], row stride ld.  A
-// workgroup handles 256 vertices x 16 contraction indices: the K-major float64 operand is read coalesced over the
-// vertices, every thread writes 96 contiguous, 16-byte aligned bytes of its row.  blockIdx.y == ceil(K / 16): bias slots
-// and the padding up to `fill`.  SRC: source rows (h, l, h) with the bias -n1 sx sy / 2; else target rows (h, h, l)
-// with ones.  The target is built once for the largest depth: a search at depth K' < K reads only 8 + 3 K' (+ pad)
-// entries of it, and the source rows are zero beyond 8 + 3 K'.
+// Feature rows, layout [ head: 8 bias slots (3 used) or none | 3 entries per contraction index | zero pad up to fill ],
+// row stride ld.  A workgroup builds 64 complete rows in LDS -- the K-major float64 operand is read coalesced over the
+// vertices (thread = vertex x group of 16 contraction indices) -- and writes them out as one contiguous run of 16-byte
+// chunks.  SRC: source rows (h, l, h) with the bias -n1 sx sy / 2 in the head; else target rows (h, h, l) with ones.
+// The target is built once for the largest depth: a search at depth K' < K reads only head + 3 K' (+ pad) entries of it,
+// and the source rows are zero beyond head + 3 K'.
 template <bool SRC>
 __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict__ M, const double* __restrict__ n1,
                                                        const double* __restrict__ amaxT, const double* __restrict__ amaxS, int nS,
                                                        int K, int N, int Npad, int Kpad, int ld, int fill, int head,
                                                        _Float16* __restrict__ F, int32_t* __restrict__ overflow) {
-    const int b = blockIdx.z, r0 = blockIdx.y * 16;
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= N) return;
-    _Float16* row = F + ((long long)b * N + v) * ld;
+    extern __shared__ __attribute__((aligned(16))) _Float16 ks_img[];       // 64 rows x (fill + 8) halves
+    const int ldl = fill + 8;
+    const int b = blockIdx.y, v0 = blockIdx.x * 64;
+    const int vl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int v = v0 + vl;
     const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
-    if (r0 >= K) {
-        if (head == 0) {                                          // no bias slots (the two-key pass adds the bias in fp32)
-            for (int c = 3 * K; c < fill; ++c) row[c] = (_Float16)0.0f;
-            return;
-        }
-        f16x8 head8 = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-        if (SRC) {
-            const double sy = ks_scale(amaxS + b * nS, nS);
-            const double beta = -0.5 * n1[(long long)b * Npad + v] * sx * sy;
-            if (!(fabs(beta) < 60000.0)) overflow[b] = 1;
-            else {
-                const _Float16 b0 = (_Float16)beta;
-                const double r1 = beta - (double)b0;
-                const _Float16 b1 = (_Float16)r1;
-                head8[0] = b0; head8[1] = b1; head8[2] = (_Float16)(r1 - (double)b1);
-            }
-        } else {
-            head8[0] = head8[1] = head8[2] = (_Float16)1.0f;
-        }
-        *reinterpret_cast<f16x8*>(row) = head8;
-        for (int c = KS_BIAS + 3 * K; c < fill; ++c) row[c] = (_Float16)0.0f;
-        return;
-    }
     const double sc = SRC ? ks_scale(amaxS + b * nS, nS) : sx;
-    const double* col = M + ((long long)b * Kpad + r0) * Npad + v;
-    _Float16* dst = row + head + 3 * r0;
-    if (r0 + 16 <= K) {
-        f16x8 o[6];
+    _Float16* row = ks_img + vl * ldl;
+    if (v < N) {
+        for (int r0 = rg * 16; r0 < K; r0 += 64) {
+            const double* col = M + ((long long)b * Kpad + r0) * Npad + v;
+            _Float16* dst = row + head + 3 * r0;
+            if (r0 + 16 <= K) {
+                f16x8 o[6];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            _Float16 h, l;
-            split2(col[(long long)q * Npad] * sc, h, l);
-            const int e = 3 * q;                                  // target: (h, h, l)   source: (h, l, h)
-            o[e >> 3][e & 7] = h;
-            o[(e + 1) >> 3][(e + 1) & 7] = SRC ? l : h;
-            o[(e + 2) >> 3][(e + 2) & 7] = SRC ? h : l;
-        }
+                for (int q = 0; q < 16; ++q) {
+                    _Float16 h, l;
+                    split2(col[(long long)q * Npad] * sc, h, l);
+                    const int e = 3 * q;                                  // target: (h, h, l)   source: (h, l, h)
+                    o[e >> 3][e & 7] = h;
+                    o[(e + 1) >> 3][(e + 1) & 7] = SRC ? l : h;
+                    o[(e + 2) >> 3][(e + 2) & 7] = SRC ? h : l;
+                }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) *reinterpret_cast<f16x8*>(dst + 8 * q) = o[q];
-    } else {
-        for (int q = 0; r0 + q < K; ++q) {
-            _Float16 h, l;
-            split2(col[(long long)q * Npad] * sc, h, l);
-            dst[3 * q] = h; dst[3 * q + 1] = SRC ? l : h; dst[3 * q + 2] = SRC ? h : l;
+                for (int q = 0; q < 6; ++q) *reinterpret_cast<f16x8*>(dst + 8 * q) = o[q];
+            } else {
+                for (int q = 0; r0 + q < K; ++q) {
+                    _Float16 h, l;
+                    split2(col[(long long)q * Npad] * sc, h, l);
+                    dst[3 * q] = h; dst[3 * q + 1] = SRC ? l : h; dst[3 * q + 2] = SRC ? h : l;
+                }
+            }
         }
+        for (int c = head + 3 * K + rg; c < fill; c += 4) row[c] = (_Float16)0.0f;
+        if (rg == 0 && head > 0) {
+            f16x8 head8 = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+            if (SRC) {
+                const double beta = -0.5 * n1[(long long)b * Npad + v] * sx * sc;
+                if (!(fabs(beta) < 60000.0)) overflow[b] = 1;
+                else {
+                    const _Float16 b0 = (_Float16)beta;
+                    const double r1 = beta - (double)b0;
+                    const _Float16 b1 = (_Float16)r1;
+                    head8[0] = b0; head8[1] = b1; head8[2] = (_Float16)(r1 - (double)b1);
+                }
+            } else {
+                head8[0] = head8[1] = head8[2] = (_Float16)1.0f;
+            }
+            *reinterpret_cast<f16x8*>(row) = head8;
+        }
+    }
+    __syncthreads();
+    const int cpr = fill >> 3;                                          // 16-byte chunks per row (fill % 8 == 0)
+    const int nrow = min(64, N - v0);
+    for (int c = threadIdx.x; c < nrow * cpr; c += 256) {
+        const int r = c / cpr, q = c - r * cpr;
+        *reinterpret_cast<f16x8*>(F + ((long long)b * N + v0 + r) * ld + 8 * q) = *reinterpret_cast<const f16x8*>(ks_img + r * ldl + 8 * q);
     }
 }
 
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(256) void ks_exact_kernel(const double* __restrict_
     }
 }
 
+static inline size_t ks_build_lds(int fill) { return (size_t)64 * (fill + 8) * sizeof(_Float16); }
 static inline int ks_depth(int K) { return pad_to(KS_BIAS + 3 * K, 32) < 96 ? 96 : pad_to(KS_BIAS + 3 * K, 32); }
 
 size_t dm_knn_split_prep_bytes(int B, int N2, int kf) {
@@ -217,13 +225,15 @@ int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf
     st->amaxT = (double*)dm_ws_take(ctx, (size_t)B * KS_NCH * 8);
     if (!st->Ft || !st->amaxT) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
     DM_LAUNCH(ctx, "knn_split_absmax", ks_absmax_kernel, dim3(KS_NCH, B), dim3(256), 0, AT, kf, N2, N2pad, Kpad, st->amaxT);
-    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 256), dm_cdiv(kf, 16) + 1, B), dim3(256), 0, AT,
+    int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<false>, ks_build_lds(st->ldT));
+    if (rcb) return rcb;
+    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 64), B), dim3(256), ks_build_lds(st->ldT), AT,
               (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, KS_BIAS, st->Ft,
               (int32_t*)nullptr);
     return DM_OK;
 }
 
-int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state& st, const double* amaxS) {
+int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state& st, const double* amaxS, int nS) {
     if (!st.enabled) return dm_launch_gred(ctx, a);
     if (!a.AT || !a.BT || !a.n1 || !a.knn21 || !amaxS) return dm_fail(ctx, DM_EINVAL, "knn_split: missing operand");
     const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop;
@@ -233,8 +243,10 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int32_t* overflow = (int32_t*)dm_ws_take(ctx, (size_t)a.B * 4);
     if (!Fs || !overflow) return dm_fail(ctx, DM_ENOMEM, "knn_split: workspace not reserved");
     DM_CHECK_HIP(ctx, hipMemsetAsync(overflow, 0, (size_t)a.B * 4, ctx->stream));
-    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 256), dm_cdiv(K, 16) + 1, a.B), dim3(256), 0, a.BT,
-              a.n1, st.amaxT, amaxS, dm_cdiv(a.N1pad, 256), K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow);
+    int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
+    if (rcb) return rcb;
+    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 64), a.B), dim3(256), ks_build_lds(D), a.BT,
+              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow);
     dm_simnn_queue q;
     // error of the split on top of the fp32 accumulation, relative to |t_i| max_j |s_j|: the dropped <xl, yl> and the two
     // residuals (3 * 2^-22), the fp16 subnormal floor (2 sqrt(K) 2^-25), 25 % slack; 2^-19 at K = 200
@@ -332,7 +344,7 @@ size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K) {
 }
 // a: AT, BT (K-major f64), n1, n2, mass1 and all four outputs; amaxS: per-256-column maxima of |BT| (colnorm_kernel);
 // zeroed: dm_fm_split_zero_bytes block, zeroed before dm_launch_phiT(Phi2) filled its first part
-int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, void* zeroed, const float* Phi2, int ld2) {
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const float* Phi2, int ld2) {
     const int B = a.B, N1 = a.N1, N2 = a.N2;
     const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop;
     if (!a.AT || !a.BT || !a.n1 || !a.n2 || !a.mass1 || !a.knn21 || !a.knn12 || !a.ind21 || !a.ind12 || !amaxS || !zeroed || !Phi2)
@@ -347,13 +359,14 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     const size_t mstride = dm_align_up((size_t)B * 4) / 4;
     unsigned int* bmaxA = reinterpret_cast<unsigned int*>((char*)zeroed + dm_align_up((size_t)B * KS_NCH * 8));
     unsigned int* mmax = bmaxA + mstride; unsigned int* bmaxB = bmaxA + 2 * mstride;
-    const int nS = dm_cdiv(a.N1pad, 256);
     {
         const long long n = (long long)N2 * ((D + 23) / 24);
         DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
                   amaxT, D, Fx);
     }
-    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 256), dm_cdiv(K, 16) + 1, B), dim3(256), 0, a.BT,
+    int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
+    if (rcb) return rcb;
+    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 64), B), dim3(256), ks_build_lds(D), a.BT,
               a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr);
     DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1, 256), B), dim3(256), 0, a.n1, N1, a.N1pad, amaxT,
               amaxS, nS, a.mass1, biasA, bmaxA, mmax);

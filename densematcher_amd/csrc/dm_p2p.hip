@@ -110,22 +110,118 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
     }
 }
 
+// embT (K-major, optional) + column norms + per-64-column maxima in one kernel: a workgroup owns 64 vertices and walks
+// all row tiles of the product, so the squared sums never leave the workgroup and are added in a fixed order
+// (identical columns get identical norms).  The tile loop is that of gemm_nt_f64.
+template <bool STORE>
+__global__ __launch_bounds__(256) void embed_norm_kernel(KRowsF64 opa, KRowsF32 opb, double* __restrict__ embT, int krpad, int Npad,
+                                                         int kr, int N, int K, double* __restrict__ nrm, double* __restrict__ amax_part) {
+    __shared__ double As[NT_T * NT_LD];
+    __shared__ double Bs[NT_T * NT_LD];
+    __shared__ double xs[2][64];
+    __shared__ double wmax[4];
+    const int b = blockIdx.z, jblk = blockIdx.x * DM_EMB_COLS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = t >> 2, lk = (t & 3) * 8;
+    const int ns = (K + NT_BK - 1) / NT_BK;
+    const int tiles_i = (kr + NT_T - 1) / NT_T;
+    double* E = STORE ? embT + (long long)b * krpad * Npad : nullptr;
+    double amax = 0.0;
+    for (int tj = 0; tj < DM_EMB_COLS / NT_T; ++tj) {
+        const int j0 = jblk + tj * NT_T;
+        if (j0 >= Npad) break;                                    // uniform
+        double csum[2] = {0.0, 0.0};                              // columns wn*32 + nt*16 + (lane & 15), rows of this lane
+        for (int ti = 0; ti < tiles_i; ++ti) {
+            const int i0 = ti * NT_T;
+            f64x4 acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+            double ra[8], rb[8];
+            opa.load8(b, i0 + lrow, lk, ra);
+            opb.load8(b, j0 + lrow, lk, rb);
+            for (int s = 0; s < ns; ++s) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    As[lrow * NT_LD + lk + e] = ra[e];
+                    Bs[lrow * NT_LD + lk + e] = rb[e];
+                }
+                __syncthreads();
+                if (s + 1 < ns) {
+                    opa.load8(b, i0 + lrow, (s + 1) * NT_BK + lk, ra);
+                    opb.load8(b, j0 + lrow, (s + 1) * NT_BK + lk, rb);
+                }
+#pragma unroll
+                for (int ks = 0; ks < NT_BK / 4; ++ks) {
+                    const int kk = ks * 4 + (lane >> 4);
+                    double a[2], bb[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) a[mt] = As[(wm * 32 + mt * 16 + (lane & 15)) * NT_LD + kk];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) bb[nt] = Bs[(wn * 32 + nt * 16 + (lane & 15)) * NT_LD + kk];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int j = j0 + wn * 32 + nt * 16 + (lane & 15);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
+                        const double v = (i < kr && j < N) ? acc[mt][nt][r] : 0.0;
+                        if (STORE && i < kr && j < N) E[(long long)i * Npad + j] = v;
+                        csum[nt] = fma(v, v, csum[nt]);
+                        amax = fmax(amax, fabs(v));
+                    }
+            }
+        }
+        // column sums: the four row groups of a wave (xor tree: the same order in every lane), then the two row halves
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            csum[nt] += __shfl_xor(csum[nt], 16);
+            csum[nt] += __shfl_xor(csum[nt], 32);
+        }
+        if (wm == 1 && lane < 16) { xs[0][wn * 32 + lane] = csum[0]; xs[1][wn * 32 + lane] = csum[1]; }
+        __syncthreads();
+        if (wm == 0 && lane < 16 && nrm) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int j = j0 + wn * 32 + nt * 16 + lane;
+                if (j < Npad) nrm[(long long)b * Npad + j] = csum[nt] + xs[nt][wn * 32 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (amax_part) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
+        if (lane == 0) wmax[wave] = amax;
+        __syncthreads();
+        if (t == 0) amax_part[b * gridDim.x + blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    }
+}
+
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld, const double* Cm, int ldc,
                     long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first,
                     double* amax_part) {
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
-    if (zero_first && (kr != krpad || N != Npad))
+    if (embT && zero_first && (kr != krpad || N != Npad))
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
     KRowsF64 opa{Cm, strideC, ldc, kr, km, transC};
     KRowsF32 opb{Phi, (long long)N * ld, ld, N, km};
-    OutKMajor out{embT, (long long)krpad * Npad, Npad};
-    dim3 grid(dm_cdiv(kr, NT_T) * dm_cdiv(N, NT_T), 1, B);
-    DM_LAUNCH(ctx, "embed_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF32, OutKMajor>), grid, dim3(256), 0, opa, opb, out, kr,
-              N, km);
-    if (nrm) {
-        dim3 g2(dm_cdiv(Npad, 256), B);
-        DM_LAUNCH(ctx, "colnorm", colnorm_kernel, g2, dim3(256), 0, embT, kr, krpad, Npad, nrm, amax_part);
-    }
+    dim3 grid(dm_cdiv(Npad, DM_EMB_COLS), 1, B);
+    if (embT)
+        DM_LAUNCH(ctx, "embed_nt_f64", embed_norm_kernel<true>, grid, dim3(256), 0, opa, opb, embT, krpad, Npad, kr, N, km, nrm, amax_part);
+    else
+        DM_LAUNCH(ctx, "embed_nt_f64", embed_norm_kernel<false>, grid, dim3(256), 0, opa, opb, embT, krpad, Npad, kr, N, km, nrm, amax_part);
     return DM_OK;
 }
 
@@ -555,10 +651,10 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     const int K1pad = pad_to(k1, GBK);
     const size_t bytes_AT = (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;
     const bool all = knn12 || ind21 || ind12;      // anything beyond knn21 takes the four-reduction kernel
-    const size_t bytes_E2 = all ? (size_t)B * K1pad * N2pad * 8 : 0;
+    const size_t bytes_E2 = 0;                     // emb2 = Phi2 C is only needed for its row norms: never stored (embed_norm_kernel)
     // all four maps on interior sizes: two passes of the two-key fp16 tile kernel + exact re-evaluation (dm_knnsplit.hip)
     const bool split = knn21 && knn12 && ind21 && ind12 && mass1 && dm_fm_split_ok(ctx, N2, N1, k2);
-    const size_t bytes_amax = (size_t)B * dm_cdiv(N1pad, 256) * 8;
+    const size_t bytes_amax = (size_t)B * dm_cdiv(N1pad, DM_EMB_COLS) * 8;
     const size_t bytes_zero = split ? dm_fm_split_zero_bytes(B) : 0;    // |Phi2| maxima and the per-pair bounds: one memset
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + dm_align_up(bytes_E2) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2pad * 8) +
@@ -585,7 +681,7 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     if (rc) return rc;
     if (all) {
         // emb2 = Phi2[:, :k2] C (N2 x k1): emb2T[m][i] = sum_c C[c][m] Phi2[i][c];  only n2_i = |emb2_i|^2 is used
-        rc = dm_launch_embed(ctx, B, N2, k1, k2, Phi2, ld2, C, k1, (long long)k2 * k1, 1, E2, K1pad, N2pad, n2, 1);
+        rc = dm_launch_embed(ctx, B, N2, k1, k2, Phi2, ld2, C, k1, (long long)k2 * k1, 1, (double*)nullptr, K1pad, N2pad, n2, 1);
         if (rc) return rc;
     }
     dm_gred_args a;
@@ -598,7 +694,7 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
         a.mass1 = ones;
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
-    if (split) { a.Ktrue = k2; return dm_launch_fm_split(ctx, a, amaxS, zeroed, Phi2, ld2); }
+    if (split) { a.Ktrue = k2; return dm_launch_fm_split(ctx, a, amaxS, dm_cdiv(N1pad, DM_EMB_COLS), zeroed, Phi2, ld2); }
     return dm_launch_gred(ctx, a);
 }
 
@@ -637,7 +733,7 @@ extern "C" int dm_knn_query_f64(dm_ctx* ctx, int B, int nx, int ny, int p, const
     a.AT = AT; a.N2pad = nypad; a.BT = BT; a.N1pad = nxpad; a.Kpad = Kpad;
     a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
     a.knn21 = out; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
-    return dm_launch_knn21(ctx, a, knn, amaxS);
+    return dm_launch_knn21(ctx, a, knn, amaxS, dm_cdiv(nxpad, 256));
 }
 
 // ---- dense mapped indicator (pyFM/spectral/convert.py:144) ------------------------------------------------------

@@ -100,7 +100,7 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + 2 * dm_align_up(bytes_C) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2 * 4) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, kf) + dm_knn_split_ws_bytes(B, N2, N1, kf) +
-                        dm_align_up((size_t)B * (N1pad / 256 + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, kf, kf);
+                        dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, kf, kf);
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bytes_AT);
@@ -109,7 +109,7 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
     double* Cb = (double*)dm_ws_take(ctx, bytes_C);
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
     int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / 256 + 1) * 8);   // max |emb1| per 256 columns (colnorm)
+    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / DM_EMB_COLS + 1) * 8);   // max |emb1| per 256 columns (colnorm)
 
     // Phi2^T for all kf columns, once.  Row c of AT only enters G when c < current k because the
     // matching row of BT (emb1^T) is zero beyond the current map size.
@@ -139,7 +139,7 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
         a.AT = AT; a.N2pad = N2pad; a.BT = BT; a.N1pad = N1pad; a.Kpad = Kpad;
         a.n1 = n1; a.n2 = nullptr; a.mass1 = nullptr;
         a.knn21 = last ? p21_out : p21; a.knn12 = nullptr; a.ind21 = nullptr; a.ind12 = nullptr;
-        rc = dm_launch_knn21(ctx, a, knn, amaxS);
+        rc = dm_launch_knn21(ctx, a, knn, amaxS, dm_cdiv(N1pad, DM_EMB_COLS));
         if (rc) return rc;
         if (last) break;
         const int kn = k + step;
