@@ -98,6 +98,44 @@ __device__ __forceinline__ void diag_block(const double* S, double* Ws, double* 
     if (!ok && lane == 0) red[5] = 1.0;
 }
 
+struct TriSlots {                             // lower block triangle, block (I, K) at (I (I + 1) / 2 + K) * 256
+    __device__ __forceinline__ int operator()(int I, int K) const { return (I * (I + 1) / 2 + K) * 256; }
+};
+
+// back substitution  L^T x = y  over block rows NB-1 .. 0:  x_J = W_J^T (y_J - sum_{I>J} L_IJ^T x_I); the W_J are parked in
+// the diagonal slots.  One thread per output entry, serial 16-term dot products (no cross-lane reduction chains).
+// All 256 threads call it.
+template <class Slots>
+__device__ __forceinline__ void blocked_back_subst(const double* T, Slots sl, double* rhs, double* xv, int NB, int t) {
+    for (int J = NB - 1; J >= 0; --J) {
+        const double* Wt = T + sl(J, J);                          // Wt[m*16 + k] = W[k][m]
+        if (t < 16) {
+            // x_J[k] = sum_m W[m][k] y[m] = sum_m Wt[k*16 + m] y[m]
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; m += 2) {
+                a0 = fma(Wt[t * 16 + m], rhs[J * 16 + m], a0);
+                a1 = fma(Wt[t * 16 + m + 1], rhs[J * 16 + m + 1], a1);
+            }
+            xv[J * 16 + t] = a0 + a1;
+        }
+        __syncthreads();
+        // y_K -= L_JK^T x_J for K < J:  (L_JK^T x)[k] = sum_i T_JK[k*16 + i] x_J[i]
+        if (t < J * 16) {
+            const int K = t >> 4, k = t & 15;
+            const double* Tjk = T + sl(J, K);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < 16; ii += 2) {
+                a0 = fma(Tjk[k * 16 + ii], xv[J * 16 + ii], a0);
+                a1 = fma(Tjk[k * 16 + ii + 1], xv[J * 16 + ii + 1], a1);
+            }
+            rhs[K * 16 + k] -= a0 + a1;
+        }
+        __syncthreads();
+    }
+}
+
 // T: blocks; Ws: 256-double scratch (W^T of the current block); rhs: NB*16 (in: right-hand side, becomes y);
 // xv: NB*16 (out: solution); red[5]: failure flag (must be 0 on entry); tri_rc: 128 ints, (u -> row << 8 | col) of a
 // lower-triangular enumeration with tri_rc[0] = (0, 0).  All 256 threads call it.  Returns false when a pivot was
@@ -215,34 +253,122 @@ __device__ __forceinline__ bool blocked_chol_solve(double* T, double* Ws, double
     }
     __syncthreads();
     if (red[5] != 0.0) return false;
-    // ---- back substitution  L^T x = y :  x_J = W_J^T (y_J - sum_{I>J} L_IJ^T x_I)
-    // one thread per output entry, serial 16-term dot products (no cross-lane reduction chains)
-    for (int J = NB - 1; J >= 0; --J) {
-        const double* Wt = T + (J * (J + 1) / 2 + J) * 256;     // Wt[m*16 + k] = W[k][m]
-        if (t < 16) {
-            // x_J[k] = sum_m W[m][k] y[m] = sum_m Wt[k*16 + m] y[m]
-            double a0 = 0.0, a1 = 0.0;
+    blocked_back_subst(T, TriSlots{}, rhs, xv, NB, t);
+    return true;
+}
+
+// block offsets of the two-phase layout (fmap_solve_2phase_kernel): the NA leading block rows as a lower block triangle,
+// then the remaining block rows' first NA block columns as a dense panel
+struct PanelSlots {
+    int NA;
+    __device__ __forceinline__ int operator()(int I, int K) const {          // K < NA
+        return (I < NA ? I * (I + 1) / 2 + K : NA * (NA + 1) / 2 + (I - NA) * NA + K) * 256;
+    }
+};
+
+// Columns J = 0 .. NA-1 of the blocked factorisation of an NB x NB block matrix of which only the block columns < NA are
+// resident (slots sl(I, K), K < NA <= NB).  Same phases and look-ahead as blocked_chol_solve; the trailing update stops
+// at block column NA - 1.  Afterwards L11 / the W_J sit in the leading slots, L21 in the panel slots,
+// rhs[0 .. NA) = y1 and rhs[NA .. NB) = b2 - L21 y1.  blk: K-major list of the resident blocks ((I << 8) | K, K < NA,
+// K <= I < NB); cstart[K] = position of (K, K) in it, cstart[NA] = its length.  red[5] must be 0 on entry.
+__device__ __forceinline__ bool blocked_chol_phase1(double* T, PanelSlots sl, double* Ws, double* rhs, double* xv, double* red,
+                                                    const int* blk, const int* cstart, int NB, int t, int lane, int wave) {
+    const int NA = sl.NA;
+    if (wave == 0) diag_block(T + sl(0, 0), Ws, red, lane);
+    __syncthreads();
+    for (int J = 0; J < NA; ++J) {
+        if (red[5] != 0.0) break;                // uniform: set before the barrier that closed the previous phase
+        double* S = T + sl(J, J);
+        if (t >= 240) {
+            const int k = t - 240;
+            double y = 0.0;
 #pragma unroll
-            for (int m = 0; m < 16; m += 2) {
-                a0 = fma(Wt[t * 16 + m], rhs[J * 16 + m], a0);
-                a1 = fma(Wt[t * 16 + m + 1], rhs[J * 16 + m + 1], a1);
-            }
-            xv[J * 16 + t] = a0 + a1;
+            for (int m = 0; m < 16; ++m) y = fma(Ws[m * 16 + k], rhs[J * 16 + m], y);    // W[k][m]
+            xv[J * 16 + k] = y;
         }
-        __syncthreads();
-        // y_K -= L_JK^T x_J for K < J:  (L_JK^T x)[k] = sum_i T_JK[k*16 + i] x_J[i]
-        if (t < J * 16) {
-            const int K = t >> 4, k = t & 15;
-            const double* Tjk = T + (J * (J + 1) / 2 + K) * 256;
-            double a0 = 0.0, a1 = 0.0;
+        for (int I = J + 1 + wave; I < NB; I += 4) {
+            double* Tij = T + sl(I, J);
+            f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            double bq[4];
 #pragma unroll
-            for (int ii = 0; ii < 16; ii += 2) {
-                a0 = fma(Tjk[k * 16 + ii], xv[J * 16 + ii], a0);
-                a1 = fma(Tjk[k * 16 + ii + 1], xv[J * 16 + ii + 1], a1);
+            for (int ks = 0; ks < 4; ++ks) bq[ks] = Tij[((lane >> 4) + 4 * ks) * 16 + (lane & 15)];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double a = Ws[((lane >> 4) + 4 * ks) * 16 + (lane & 15)];
+                acc = mfma_f64_16x16x4(a, bq[ks], acc);
             }
-            rhs[K * 16 + k] -= a0 + a1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Tij[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+        }
+        S[t] = Ws[t];                            // W_J parked in the diagonal slot
+        __syncthreads();
+        if (t < 16) rhs[J * 16 + t] = xv[J * 16 + t];
+        {
+            const int m = NB - 1 - J;
+            const int o0 = (lane >> 4) * 16 + (lane & 15);
+            if (wave == 0) {
+                if (J + 1 < NA) {
+                    const int I = J + 1;
+                    double* Tii = T + sl(I, I);
+                    const double* Tij = T + sl(I, J);
+                    f64x4 acc;
+                    double op[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = Tii[o0 + r * 64];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) op[ks] = Tij[o0 + ks * 64];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) acc = mfma_f64_16x16x4(-op[ks], op[ks], acc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Tii[o0 + r * 64] = acc[r];
+                    diag_block(Tii, Ws, red, lane);
+                }
+            } else {
+                const int uend = cstart[NA];
+                for (int u0 = cstart[J + 1] + 1 + (wave - 1) * 4; u0 < uend; u0 += 12) {
+                    f64x4 acc[4];
+                    int off_ik[4], off_ij[4], off_kj[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rc = blk[min(u0 + q, uend - 1)];
+                        const int I = rc >> 8, K = rc & 255;                                  // J < K <= I < NB, K < NA
+                        off_ik[q] = sl(I, K) + o0;
+                        off_ij[q] = sl(I, J) + o0;
+                        off_kj[q] = sl(K, J) + o0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[q][r] = T[off_ik[q] + r * 64];
+                    }
+                    double opa[4][4], opb[4][4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            opa[q][ks] = -T[off_kj[q] + ks * 64];
+                            opb[q][ks] = T[off_ij[q] + ks * 64];
+                        }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] = mfma_f64_16x16x4(opa[q][ks], opb[q][ks], acc[q]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (u0 + q < uend) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) T[off_ik[q] + r * 64] = acc[q][r];
+                        }
+                }
+                for (int e = t - 64; e < m * 16; e += 192) {
+                    const int I = J + 1 + (e >> 4), ii = e & 15;
+                    const double* Tij = T + sl(I, J);
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sacc += Tij[k * 16 + ii] * xv[J * 16 + k];
+                    rhs[I * 16 + ii] -= sacc;
+                }
+            }
         }
         __syncthreads();
     }
-    return true;
+    __syncthreads();
+    return red[5] == 0.0;
 }

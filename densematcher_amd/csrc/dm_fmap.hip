@@ -565,6 +565,172 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
     DBG_ACC(4)
 }
 
+// =================================================================================================
+// Two-phase blocked solver for 177 <= n <= 208 (NB = 12, 13): the 16x16-blocked lower triangle (up to 182 KiB) does not
+// fit the LDS, so the factorisation runs as a 2 x 2 block elimination with NA = ceil(NB / 2) leading block rows:
+//   phase 1  [A11; A21] resident (NA (NA+1)/2 + (NB-NA) NA blocks): columns 0 .. NA-1 are eliminated (blocked_chol_phase1),
+//            giving L11, L21, y1 and b2 - L21 y1;  L11 (with the W_J) is spilled to a per-workgroup global scratch,
+//   phase 2  A22 is loaded into the freed leading slots, S = A22 - L21 L21^T on the f64 matrix cores, then the ordinary
+//            blocked solve of S x2 = rhs2 (blocked_chol_solve),
+//   back     y1 -= L21^T x2, L11 is read back over S, x1 = L11^-T y1.
+// One workgroup per CU (148 KiB of LDS at NB = 13), persistent over the (pair, row) systems so that the spill area is
+// NA (NA+1)/2 blocks per RESIDENT workgroup (14 MiB in all: it never leaves the L2 / Infinity Cache).
+// =================================================================================================
+__global__ __launch_bounds__(256) void fmap_solve_2phase_kernel(const double* __restrict__ PQ, const double* __restrict__ Timg,
+                                                                const double* __restrict__ lam1, const double* __restrict__ lam2,
+                                                                const double* __restrict__ c00, double w_lap, int k1, int k2,
+                                                                int NB, int B, double* __restrict__ spill, double* __restrict__ C,
+                                                                int32_t* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = k1 - 1;
+    const int NA = (NB + 1) / 2, NBr = NB - NA;
+    const int r1n = NA * (NA + 1) / 2, r2n = NBr * NA;
+    const int nblk_img = NB * (NB + 1) / 2;
+    const PanelSlots sl{NA};
+    double* T = sm;                          // r1n + r2n blocks of 256
+    double* LT = T + (r1n + r2n) * 256;      // 256: diagonal penalties of the current system
+    double* Ws = LT + 256;                   // 256
+    double* rhs = Ws + 256;                  // NB*16
+    double* xv = rhs + NB * 16;              // NB*16
+    double* red = xv + NB * 16;              // 8
+    int* blk = reinterpret_cast<int*>(red + 8);      // <= 96: resident blocks of phase 1, K-major
+    int* cstart = blk + 96;                          // <= 16
+    int* tri_rc = cstart + 16;                       // 128: relative triangle enumeration of blocked_chol_solve
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double* my_spill = spill + (long long)blockIdx.x * r1n * 256;
+
+    if (t == 0) {
+        int u = 0;
+        for (int K = 0; K < NA; ++K) {
+            cstart[K] = u;
+            for (int I = K; I < NB; ++I) blk[u++] = (I << 8) | K;
+        }
+        cstart[NA] = u;
+    }
+    for (int u = t; u < 128; u += 256) {
+        int a_ = 0;
+        while ((a_ + 1) * (a_ + 2) / 2 <= u) ++a_;
+        tri_rc[u] = (a_ << 8) | (u - a_ * (a_ + 1) / 2);
+    }
+    __syncthreads();
+    const int nres = cstart[NA];
+
+    for (long long sys = blockIdx.x; sys < (long long)B * k2; sys += gridDim.x) {
+        const int b = (int)(sys / k2), i = (int)(sys - (long long)b * k2);
+        const double* P = PQ + (long long)b * (k1 + k2) * k1;
+        const double* Q = P + (long long)k1 * k1;
+        const double* l1 = lam1 + (long long)b * k1;
+        const double* l2 = lam2 + (long long)b * k2;
+        const double* img = Timg + (long long)b * nblk_img * 256;
+        double* Crow = C + ((long long)b * k2 + i) * k1;
+
+        double mx = -DM_INF_F64;
+        for (int q = t; q < k1; q += 256) mx = fmax(mx, l1[q]);
+        for (int q = t; q < k2; q += 256) mx = fmax(mx, l2[q]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        if (t == 0) {
+            red[4] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+            red[5] = 0.0;
+        }
+        __syncthreads();
+        const double scale = red[4];
+        const double ci0 = (i == 0) ? c00[b] : 0.0;
+        const double l2i = l2[i] / scale;
+        for (int c = t; c < NB * 16; c += 256) {
+            double pen = 0.0;
+            if (c < n) { const double d = l1[c + 1] / scale - l2i; pen = w_lap * (d * d); }
+            LT[c] = pen;
+            rhs[c] = (c < n) ? Q[(long long)i * k1 + (c + 1)] - P[(long long)(c + 1) * k1] * ci0 : 0.0;
+        }
+        // ---- phase 1 image: the resident blocks, 16-byte streams from the Gram kernel's pre-blocked copy
+        for (int q = t; q < nres * 128; q += 256) {
+            const int u = q >> 7, w = q & 127;
+            const int rc = blk[u];
+            const int I = rc >> 8, K = rc & 255;
+            reinterpret_cast<f64x2*>(T + sl(I, K))[w] = reinterpret_cast<const f64x2*>(img + (long long)(I * (I + 1) / 2 + K) * 256)[w];
+        }
+        __syncthreads();
+        for (int c = t; c < NA * 16; c += 256) {                  // (NA * 16 <= n: no padding rows in the leading part)
+            const int I = c >> 4;
+            T[sl(I, I) + (c & 15) * 17] += LT[c];
+        }
+        __syncthreads();
+        bool ok = blocked_chol_phase1(T, sl, Ws, rhs, xv, red, blk, cstart, NB, t, lane, wave);
+        if (ok) {
+            // ---- spill L11 (and the W_J parked on its diagonal)
+            for (int q = t; q < r1n * 128; q += 256) reinterpret_cast<f64x2*>(my_spill)[q] = reinterpret_cast<const f64x2*>(T)[q];
+            __syncthreads();
+            // ---- A22 into the leading slots (ordinary triangle layout of an NBr x NBr block matrix)
+            for (int q = t; q < NBr * (NBr + 1) / 2 * 128; q += 256) {
+                const int u = q >> 7, w = q & 127;
+                const int rc = tri_rc[u];
+                const int Ir = rc >> 8, Kr = rc & 255, I = NA + Ir, K = NA + Kr;
+                reinterpret_cast<f64x2*>(T + (Ir * (Ir + 1) / 2 + Kr) * 256)[w] =
+                    reinterpret_cast<const f64x2*>(img + (long long)(I * (I + 1) / 2 + K) * 256)[w];
+            }
+            __syncthreads();
+            for (int c = NA * 16 + t; c < NB * 16; c += 256) {
+                const int Ir = (c >> 4) - NA;
+                double* dg = T + (Ir * (Ir + 1) / 2 + Ir) * 256 + (c & 15) * 17;
+                if (c < n) *dg += LT[c]; else *dg = 1.0;          // padding rows / columns are identity
+            }
+            __syncthreads();
+            // ---- S_IK = A22_IK - sum_J L_IJ L_KJ^T   (transposed storage: T_IK -= L_KJ L_IJ^T)
+            {
+                const int o0 = (lane >> 4) * 16 + (lane & 15);
+                const int nS = NBr * (NBr + 1) / 2;
+                for (int u = wave; u < nS; u += 4) {
+                    const int rc = tri_rc[u];
+                    const int Ir = rc >> 8, Kr = rc & 255;
+                    double* Tik = T + (Ir * (Ir + 1) / 2 + Kr) * 256;
+                    f64x4 acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] = Tik[o0 + r * 64];
+                    for (int J = 0; J < NA; ++J) {
+                        const double* Tij = T + sl(NA + Ir, J);
+                        const double* Tkj = T + sl(NA + Kr, J);
+                        double opa[4], opb[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) { opa[ks] = -Tkj[o0 + ks * 64]; opb[ks] = Tij[o0 + ks * 64]; }
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) acc = mfma_f64_16x16x4(opa[ks], opb[ks], acc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Tik[o0 + r * 64] = acc[r];
+                }
+            }
+            __syncthreads();
+            ok = blocked_chol_solve(T, Ws, rhs + NA * 16, xv + NA * 16, red, tri_rc, NBr, t, lane, wave);
+        }
+        if (ok) {
+            // ---- y1 -= L21^T x2:  (L_IK^T x_I)[k] = sum_i T_IK[k*16 + i] x_I[i]
+            if (t < NA * 16) {
+                const int K = t >> 4, k = t & 15;
+                double a0 = 0.0;
+                for (int I = NA; I < NB; ++I) {
+                    const double* Tik = T + sl(I, K);
+#pragma unroll
+                    for (int ii = 0; ii < 16; ++ii) a0 = fma(Tik[k * 16 + ii], xv[I * 16 + ii], a0);
+                }
+                rhs[K * 16 + k] -= a0;
+            }
+            __syncthreads();
+            for (int q = t; q < r1n * 128; q += 256) reinterpret_cast<f64x2*>(T)[q] = reinterpret_cast<const f64x2*>(my_spill)[q];
+            __syncthreads();
+            blocked_back_subst(T, TriSlots{}, rhs, xv, NA, t);
+            if (t == 0) Crow[0] = ci0;
+            for (int c = t; c < n; c += 256) Crow[c + 1] = xv[c];
+        } else {
+            if (t == 0) atomicMax(&info[b], i + 1);
+            for (int c = t; c < k1; c += 256) Crow[c] = (c == 0) ? ci0 : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const float* A, const float* Bm,
                              const double* lam1, const double* lam2, const double* c00, double w_descr, double w_lap,
                              double* C, int32_t* info) {
@@ -577,12 +743,18 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     const size_t pq_bytes = (size_t)B * (k1 + k2) * k1 * 8;
     const int n = k1 - 1;
     const int NB = (n + 15) / 16;
-    const bool blocked = (n >= 1 && NB <= 11) && !ctx->opt_solve_packed;   // dm_set_option("solve_packed", 1): tests
+    const bool two_phase = (NB == 12 || NB == 13) && !ctx->opt_solve_packed;   // 177 <= n <= 208
+    const bool blocked = ((n >= 1 && NB <= 11) && !ctx->opt_solve_packed) || two_phase;   // dm_set_option("solve_packed", 1): tests
     const size_t img_bytes = blocked ? (size_t)B * (NB * (NB + 1) / 2) * 256 * 8 : 0;
-    int rc = dm_ws_reserve(ctx, dm_align_up(pq_bytes) + img_bytes);
+    const int NA = (NB + 1) / 2;
+    const int grid2 = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    const size_t spill_bytes = two_phase ? (size_t)grid2 * (NA * (NA + 1) / 2) * 256 * 8 : 0;
+    int rc = dm_ws_reserve(ctx, dm_align_up(pq_bytes) + dm_align_up(img_bytes) + dm_align_up(spill_bytes) + 4096);
     if (rc) return rc;
     double* PQ = (double*)dm_ws_take(ctx, pq_bytes);
     double* Timg = blocked ? (double*)dm_ws_take(ctx, img_bytes) : nullptr;
+    double* spill = two_phase ? (double*)dm_ws_take(ctx, spill_bytes) : nullptr;
+    if (!PQ || (blocked && !Timg) || (two_phase && !spill)) return dm_fail(ctx, DM_ENOMEM, "fmap_solve: workspace not reserved");
     if (blocked) DM_CHECK_HIP(ctx, hipMemsetAsync(Timg, 0, img_bytes, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
 
@@ -593,6 +765,16 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutScaled>), grid, dim3(256), 0, opa, opb, out,
               k1 + k2, k1, D);
 
+    if (two_phase) {
+        const int NBr = NB - NA;
+        const size_t lds = ((size_t)(NA * (NA + 1) / 2 + NBr * NA + 2) * 256 + 2 * NB * 16 + 8) * sizeof(double) + (96 + 16 + 128) * sizeof(int);
+        rc = dm_grant_lds(ctx, (const void*)fmap_solve_2phase_kernel, lds);
+        if (rc) return rc;
+        const long long nsys = (long long)B * k2;
+        DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_2phase_kernel, dim3((unsigned)(nsys < grid2 ? nsys : grid2)), dim3(256), lds, PQ, Timg,
+                  lam1, lam2, c00, w_lap, k1, k2, NB, B, spill, C, info);
+        return DM_OK;
+    }
     if (blocked) {
         // blocked MFMA solver: NB(NB+1)/2 + 2 blocks of 2 KiB, vectors
         const size_t lds = ((size_t)(NB * (NB + 1) / 2 + 2) * 256 + 2 * NB * 16 + 16 + 8) * sizeof(double);

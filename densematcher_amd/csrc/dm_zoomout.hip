@@ -109,7 +109,8 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
     double* Cb = (double*)dm_ws_take(ctx, bytes_C);
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
     int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / DM_EMB_COLS + 1) * 8);   // max |emb1| per 256 columns (colnorm)
+    double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / DM_EMB_COLS + 1) * 8);   // max |emb1| per block of columns (dm_launch_embed)
+    if (!AT || !BT || !Ca || !Cb || !n1 || !p21 || !amaxS) return dm_fail(ctx, DM_ENOMEM, "zoomout: workspace not reserved");
 
     // Phi2^T for all kf columns, once.  Row c of AT only enters G when c < current k because the
     // matching row of BT (emb1^T) is zero beyond the current map size.

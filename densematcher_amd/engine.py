@@ -54,6 +54,13 @@ class MatchEngine:
         _lib.raise_for(rc, self.lib, self.ctx)
 
     def _dev(self, t, dtype, name):
+        # The context launches on the stream it was created on; temporaries and outputs come from torch's caching
+        # allocator, which recycles a block as soon as the *current* stream is done with it.  Using an engine under
+        # another stream would let blocks be reused while our kernels still run: refuse it.
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            raise RuntimeError("MatchEngine is bound to the stream it was created on; create one engine per stream "
+                               "(default_engine() does) instead of calling it under torch.cuda.stream(other)")
         if not isinstance(t, torch.Tensor):
             t = torch.as_tensor(t)
         if t.device != self.device or t.dtype != dtype or not t.is_contiguous():

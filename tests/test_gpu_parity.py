@@ -295,11 +295,13 @@ def test_errors(eng):
         eng.fmap_solve(A, A, np.arange(6.0)[None], np.arange(6.0)[None], np.ones(1), 1.0, 0.0)
 
 
-@pytest.mark.parametrize("k1,k2,D", [(2, 3, 16), (17, 17, 40), (50, 40, 96), (128, 128, 256), (177, 60, 200), (178, 20, 256), (200, 24, 256)])
+@pytest.mark.parametrize("k1,k2,D", [(2, 3, 16), (17, 17, 40), (50, 40, 96), (128, 128, 256), (177, 60, 200), (178, 20, 256), (193, 9, 256), (194, 300, 208),
+                                     (200, 24, 256)])
 @pytest.mark.parametrize("packed", ["0", "1"])
 def test_solver_shapes(eng, k1, k2, D, packed):
-    """blocked-MFMA Cholesky (n <= 176) and the packed-storage rank-4 solver (n <= 199; forced for every shape by
-    dm_set_option "solve_packed"), square and rectangular maps"""
+    """blocked-MFMA Cholesky (n <= 176), its two-phase form (177 <= n <= 199: 12 or 13 block rows, more systems than
+    workgroups at k2 = 300) and the packed-storage rank-4 solver (forced for every shape by dm_set_option
+    "solve_packed"), square and rectangular maps"""
     eng.set_option("solve_packed", int(packed))
     rng = np.random.default_rng(k1 * 7 + k2)
     Bn = 2
@@ -669,3 +671,15 @@ def test_maps_on_gpu_eigenbasis_match_maps_on_host_eigenbasis(eng):
     agree = {n: float((res["gpu"][n] == res["host"][n]).mean()) for n in res["gpu"]}
     print("maps on GPU basis vs host basis:", agree)
     assert min(agree.values()) >= 0.99
+
+
+def test_engine_refuses_a_foreign_stream(eng):
+    """the context launches on the stream it was created on: calling it under another torch stream would let the
+    caching allocator recycle temporaries while kernels still read them"""
+    import torch
+    X = np.random.default_rng(0).standard_normal((1, 300, 5))
+    other = torch.cuda.Stream()
+    with torch.cuda.stream(other):
+        with pytest.raises(RuntimeError, match="bound to the stream"):
+            eng.knn_query(X, X)
+    assert np.array_equal(_np(eng.knn_query(X, X))[0], np.arange(300))

@@ -1,20 +1,22 @@
 #!/usr/bin/env python
-"""Time fmap_solve_chol alone (config 2: 64 pairs, k = 128) with the library's own launch profiler."""
+"""Time fmap_solve_chol alone (64 pairs, k from the command line, random descriptors) with the library's own launch profiler."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from densematcher_amd.engine import MatchEngine
 
-w = dict(bench.WORKLOADS["fmap"])
-host = bench.make_batch(w, 0)
+import numpy as np
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 eng = MatchEngine(0)
-dev = {n: torch.as_tensor(v).to(eng.device) for n, v in host.items()}
-k = int(sys.argv[1]) if len(sys.argv) > 1 else w["k"]
-A = eng.project(dev["Phi1"], dev["a1"], dev["F1"], k)
-Bm = eng.project(dev["Phi2"], dev["a2"], dev["F2"], k)
-c00 = eng.c00(dev["Phi1"], dev["Phi2"], dev["a1"], dev["a2"])
-lam1, lam2 = dev["lam1"][:, :k].contiguous(), dev["lam2"][:, :k].contiguous()
+rng = np.random.default_rng(0)
+B, D = 64, 384
+A = torch.as_tensor(rng.standard_normal((B, k, D)).astype(np.float32) * 0.1).to(eng.device)
+Bm = torch.as_tensor(rng.standard_normal((B, k, D)).astype(np.float32) * 0.1).to(eng.device)
+lam = np.sort(rng.uniform(0, 50, (B, k)), axis=1); lam[:, 0] = 0
+lam1 = torch.as_tensor(lam).to(eng.device)
+lam2 = torch.as_tensor(lam * 1.1).to(eng.device)
+c00 = torch.ones(B, dtype=torch.float64, device=eng.device)
 for rep in range(3):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.2:
