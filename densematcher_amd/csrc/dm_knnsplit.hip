@@ -134,19 +134,26 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
 //   0  arg-min_j  w[j] - 2 g        w = |candidate|^2                 knn21 (and knn12 with the operands swapped)
 //   1  arg-max_j  g massS[j]        indicator row,    convert.py:144  ind21
 //   2  arg-max_j  g massT[i]        indicator column (the target's own mass)  ind12, operands swapped
+struct ks_exact_args {
+    const double* AT; const double* BT; const double* n1; const float* massS; const float* massT;
+    int K, N2, N2pad, N1, N1pad, Kpad;
+    const float* pb32; int nsub, N2pad_s;
+    const int32_t* flag_count; const int32_t* flag_list; const float* flag_thr; int32_t* nn;
+};
 template <int KIND>
-__global__ __launch_bounds__(256) void ks_exact_kernel(const double* __restrict__ AT, const double* __restrict__ BT,
-                                                       const double* __restrict__ n1, const float* __restrict__ massS,
-                                                       const float* __restrict__ massT, int K, int N2, int N2pad, int N1, int N1pad,
-                                                       int Kpad, const float* __restrict__ pb32, int nsub, int N2pad_s,
-                                                       const int32_t* __restrict__ flag_count, const int32_t* __restrict__ flag_list,
-                                                       const float* __restrict__ flag_thr, int32_t* __restrict__ nn) {
+__device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, int nwg) {
+    const double* __restrict__ AT = a.AT; const double* __restrict__ BT = a.BT; const double* __restrict__ n1 = a.n1;
+    const float* __restrict__ massS = a.massS; const float* __restrict__ massT = a.massT;
+    const int K = a.K, N2 = a.N2, N2pad = a.N2pad, N1 = a.N1, N1pad = a.N1pad, Kpad = a.Kpad;
+    const float* __restrict__ pb32 = a.pb32; const int nsub = a.nsub, N2pad_s = a.N2pad_s;
+    const int32_t* __restrict__ flag_count = a.flag_count; const int32_t* __restrict__ flag_list = a.flag_list;
+    const float* __restrict__ flag_thr = a.flag_thr; int32_t* __restrict__ nn = a.nn;
     extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums + 32 scores
     __shared__ unsigned long long cmask[4];
     double* part_s = xrow + K;
     const int count = *flag_count;
     const int t = threadIdx.x, c = t & 31, part = t >> 5;
-    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    for (int e = wg; e < count; e += nwg) {
         const int o = flag_list[e];
         const float thr = flag_thr[e];
         const int b = o / N2, i = o - b * N2;
@@ -207,6 +214,13 @@ __global__ __launch_bounds__(256) void ks_exact_kernel(const double* __restrict_
     }
 }
 
+// one launch for one or two reductions of a pass: blockIdx.y selects the queue (and the value kind)
+template <int K0, int K1>
+__global__ __launch_bounds__(256) void ks_exact_kernel(ks_exact_args a0, ks_exact_args a1) {
+    if (blockIdx.y == 0) ks_exact_body<K0>(a0, blockIdx.x, gridDim.x);
+    else ks_exact_body<K1>(a1, blockIdx.x, gridDim.x);
+}
+
 static inline size_t ks_build_lds(int fill) { return (size_t)64 * (fill + 8) * sizeof(_Float16); }
 static inline int ks_depth(int K) { return pad_to(KS_BIAS + 3 * K, 32) < 96 ? 96 : pad_to(KS_BIAS + 3 * K, 32); }
 
@@ -254,9 +268,9 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, st.Ft, st.ldT, Fs, D, rel_extra, overflow, a.knn21, nullptr, nullptr, &q);
     if (rc) return rc;
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
-    DM_LAUNCH(ctx, "knn_split_exact_f64", ks_exact_kernel<0>, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, (const float*)nullptr,
-              (const float*)nullptr, K, a.N2, a.N2pad, a.N1,
-              a.N1pad, a.Kpad, q.pb32, q.nsub, q.N2pad, q.flag_count, q.flag_list, q.flag_thr, a.knn21);
+    ks_exact_args ea{a.AT, a.BT, a.n1, nullptr, nullptr, K, a.N2, a.N2pad, a.N1, a.N1pad, a.Kpad, q.pb32, q.nsub, q.N2pad,
+                     q.flag_count, q.flag_list, q.flag_thr, a.knn21};
+    DM_LAUNCH(ctx, "knn_split_exact_f64", (ks_exact_kernel<0, 0>), dim3(2048, 1), dim3(256), lds, ea, ea);
     return DM_OK;
 }
 
@@ -380,12 +394,12 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_dual dual{biasA, a.mass1, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<0>, dim3(2048), dim3(256), lds, a.AT, a.BT, a.n1, (const float*)nullptr,
-                  (const float*)nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad, qa.flag_count, qa.flag_list,
-                  qa.flag_thr, a.knn21);
-        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<1>, dim3(2048), dim3(256), lds, a.AT, a.BT, (const double*)nullptr, a.mass1,
-                  (const float*)nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qb.pb32, qb.nsub, qb.N2pad, qb.flag_count, qb.flag_list,
-                  qb.flag_thr, a.ind21);
+        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
+                         qa.flag_count, qa.flag_list, qa.flag_thr, a.knn21};
+        ks_exact_args e1 = e0;
+        e1.n1 = nullptr; e1.massS = a.mass1; e1.pb32 = qb.pb32; e1.flag_count = qb.flag_count; e1.flag_list = qb.flag_list;
+        e1.flag_thr = qb.flag_thr; e1.nn = a.ind21;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1>), dim3(1024, 2), dim3(256), lds, e0, e1);
     }
     // pass B: targets = emb1 rows, candidates = Phi2 rows
     {
@@ -393,12 +407,12 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_dual dual{biasB, nullptr, reinterpret_cast<const float*>(bmaxB), nullptr, a.ind12, &qb};
         int rc = dm_simnn_core(ctx, B, N1, N2, D, Fy, D, Fx, D, rel_extra, nullptr, a.knn12, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<0>, dim3(2048), dim3(256), lds, a.BT, a.AT, a.n2, (const float*)nullptr,
-                  (const float*)nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad, qa.flag_count, qa.flag_list,
-                  qa.flag_thr, a.knn12);
-        DM_LAUNCH(ctx, "fm_split_exact_f64", ks_exact_kernel<2>, dim3(2048), dim3(256), lds, a.BT, a.AT, (const double*)nullptr,
-                  (const float*)nullptr, a.mass1, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qb.pb32, qb.nsub, qb.N2pad, qb.flag_count,
-                  qb.flag_list, qb.flag_thr, a.ind12);
+        ks_exact_args e0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
+                         qa.flag_count, qa.flag_list, qa.flag_thr, a.knn12};
+        ks_exact_args e1 = e0;
+        e1.n1 = nullptr; e1.massT = a.mass1; e1.pb32 = qb.pb32; e1.flag_count = qb.flag_count; e1.flag_list = qb.flag_list;
+        e1.flag_thr = qb.flag_thr; e1.nn = a.ind12;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 2>), dim3(1024, 2), dim3(256), lds, e0, e1);
         const long long n = (long long)B * N1;
         DM_LAUNCH(ctx, "fm_split_zero_mass", fs_zero_mass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a.mass1, n, a.ind12);
     }

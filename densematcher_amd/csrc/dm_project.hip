@@ -241,7 +241,7 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Ph
     p.B = B; p.N = N; p.D = D; p.k = k; p.ld = ld;
     p.tiles_m = dm_cdiv(k, PT); p.tiles_d = dm_cdiv(D, PTD);
     // split-K by a fixed chunk of vertices: the summation order of a pair must not depend on the batch it is in
-    p.kchunk = 512;
+    p.kchunk = 1024;
     const int nsplit = dm_cdiv(N, p.kchunk);
     p.nsplit = nsplit;
     if ((long long)N * ld >= (1ll << 31)) return dm_fail(ctx, DM_EINVAL, "dm_project: N * ld must be below 2^31");

@@ -577,14 +577,17 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #undef SIMNN_DMA_TILE
 }
 
-__global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restrict__ pb, const int32_t* __restrict__ pj,
-                                                          const float* __restrict__ ps, int tilesS, int N2, int N2pad,
+// one key set of a tile pass: its per-tile partials in, the arg-max and the queue of ambiguous rows out
+struct simnn_merge_set {
+    const float* pb; const int32_t* pj; const float* ps;
+    const float* tau_add; const float* tau_mul;      // two-key pass: max_j |bias_j| for the biased key, max_j scale_j for the scaled key
+    int32_t* nn; int32_t* flag_count; int32_t* flag_list; float* flag_thr;
+};
+__global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_set s0, simnn_merge_set s1, int tilesS, int N2, int N2pad,
                                                           const float* __restrict__ tnorm2, const unsigned int* __restrict__ smax2,
-                                                          float tau_scale, const float* __restrict__ tau_add,
-                                                          const float* __restrict__ tau_mul, int32_t* __restrict__ nn, float* __restrict__ best,
-                                                          float* __restrict__ margin, int32_t* __restrict__ flag_count,
-                                                          int32_t* __restrict__ flag_list, float* __restrict__ flag_thr,
+                                                          float tau_scale, float* __restrict__ best, float* __restrict__ margin,
                                                           const int32_t* __restrict__ force_flag) {
+    const simnn_merge_set& s = blockIdx.z ? s1 : s0;      // (gridDim.z = number of key sets)
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N2) return;
@@ -592,20 +595,21 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(const float* __restric
     int bj = DM_IDX_NONE;
     for (int ts = 0; ts < tilesS; ++ts) {
         const long long o = ((long long)b * tilesS + ts) * N2pad + i;
-        top2_merge(bv, bj, sv, pb[o], pj[o], ps[o]);
+        top2_merge(bv, bj, sv, s.pb[o], s.pj[o], s.ps[o]);
     }
     const long long o = (long long)b * N2 + i;
-    nn[o] = (bj == DM_IDX_NONE) ? 0 : bj;
+    s.nn[o] = (bj == DM_IDX_NONE) ? 0 : bj;
     const float m = bv - sv;
-    if (best) best[o] = bv;
-    if (margin) margin[o] = m;
-    // (two-key pass: tau_add = max_j |bias_j| of the pair for the biased key, tau_mul = max_j scale_j for the scaled key)
-    const float tau = tau_scale * (sqrtf(tnorm2[o] * __uint_as_float(smax2[b])) * (tau_mul ? tau_mul[b] : 1.0f) + (tau_add ? tau_add[b] : 0.0f));
+    if (blockIdx.z == 0) {
+        if (best) best[o] = bv;
+        if (margin) margin[o] = m;
+    }
+    const float tau = tau_scale * (sqrtf(tnorm2[o] * __uint_as_float(smax2[b])) * (s.tau_mul ? s.tau_mul[b] : 1.0f) + (s.tau_add ? s.tau_add[b] : 0.0f));
     const bool forced = force_flag && force_flag[b] != 0;   // the caller could not bound the error for this pair: re-score everything
     if (forced || !(m > tau)) {
-        const int pos = atomicAdd(flag_count, 1);
-        flag_list[pos] = (int32_t)o;
-        flag_thr[pos] = forced ? DM_NEG_INF_F32 : bv - tau;   // candidates scoring below this (in fp32) cannot be the float64 argmax
+        const int pos = atomicAdd(s.flag_count, 1);
+        s.flag_list[pos] = (int32_t)o;
+        s.flag_thr[pos] = forced ? DM_NEG_INF_F32 : bv - tau;   // candidates scoring below this (in fp32) cannot be the float64 argmax
     }
 }
 
@@ -806,15 +810,14 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     // bounded relative to |t_i| max|s_j| + max|bias_j|, key B relative to |t_i| max|s_j| max scale_j.
     const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 1.5f * 1.9073486e-6f + rel_extra +
                                             (dual ? 1.1920929e-7f : 0.0f));
-    DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb, p.pj, p.ps, p.tilesS, N2,
-              p.N2pad, p.tnorm2, p.smax2, tau_scale, dual ? dual->tau_add : (const float*)nullptr, (const float*)nullptr, nn21,
-              best, margin, flag_count, flag_list, flag_thr, force_flag);
+    simnn_merge_set s0{p.pb, p.pj, p.ps, dual ? dual->tau_add : nullptr, nullptr, nn21, flag_count, flag_list, flag_thr};
+    simnn_merge_set s1 = s0;
+    if (dual) s1 = simnn_merge_set{p.pb_2, p.pj_2, p.ps_2, nullptr, dual->tau_mul, dual->nn_b, flag_count2, flag_list2, flag_thr2};
+    DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B, dual ? 2 : 1), dim3(256), 0, s0, s1, p.tilesS, N2,
+              p.N2pad, p.tnorm2, p.smax2, tau_scale, best, margin, force_flag);
     q->pb32 = p.pb32; q->nsub = p.nsub; q->N2pad = p.N2pad;
     q->flag_count = flag_count; q->flag_list = flag_list; q->flag_thr = flag_thr;
     if (dual) {
-        DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, p.pb_2, p.pj_2, p.ps_2,
-                  p.tilesS, N2, p.N2pad, p.tnorm2, p.smax2, tau_scale, (const float*)nullptr, dual->tau_mul, dual->nn_b,
-                  (float*)nullptr, (float*)nullptr, flag_count2, flag_list2, flag_thr2, force_flag);
         dm_simnn_queue* q2 = dual->q_b;
         q2->pb32 = p.pb32_2; q2->nsub = p.nsub; q2->N2pad = p.N2pad;
         q2->flag_count = flag_count2; q2->flag_list = flag_list2; q2->flag_thr = flag_thr2;
