@@ -24,16 +24,6 @@ enum { W_DESCR = 0, W_LAP, W_DCOMM, W_P2P, W_STOCH, W_ENT, W_RANGE01, W_SUMTO1, 
 struct mterm_weights { double p2p, stoch, ent, range01, sumto1; };
 
 // ---- functors -----------------------------------------------------------------------------------------------------
-struct KRowsStackedAB {            // rows 0..k1-1 = A, k1..k1+k2-1 = Bm (fp32, K = D contiguous)
-    const float* A; const float* Bm; int k1, k2, D;
-    __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
-        const float* r = nullptr;
-        if (row < k1) r = A + ((long long)b * k1 + row) * D;
-        else if (row < k1 + k2) r = Bm + ((long long)b * k2 + (row - k1)) * D;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (r && k0 + e < D) ? (double)r[k0 + e] : 0.0;
-    }
-};
 struct OutNT {
     double* p; long long stride_b; int ld;
     __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] = v; }
@@ -346,10 +336,10 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
 
     // ---- quadratic terms: P = A A^T, Q = Bm A^T (unscaled), C P
     {
-        KRowsStackedAB opa{A, Bm, k1, k2, D};
+        KRowsStackedF32 opa{A, Bm, k1, k2, D};
         KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
         OutNT out{PQ, (long long)(k1 + k2) * k1, k1};
-        DM_LAUNCH(ctx, "energy_gram_nt_f64", (gemm_nt_f64<KRowsStackedAB, KRowsF32, OutNT>),
+        DM_LAUNCH(ctx, "energy_gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutNT>),
                   dim3(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, opa, opb, out, k1 + k2, k1, D);
         KRowsF64 ca{C, (long long)k2 * k1, k1, k2, k1, 0};
         KRowsF64 pb{PQ, (long long)(k1 + k2) * k1, k1, k1, k1, 1};          // (C P)_ij = sum_k C_ik P_kj

@@ -116,16 +116,6 @@ extern "C" int dm_fmap_c00(dm_ctx* ctx, int B, int N1, int N2, const float* Phi1
 // =================================================================================================
 // Gram matrices  PQ[b] = w_d [A; Bm] A^T    ((k1 + k2) x k1, float64)
 // =================================================================================================
-struct KRowsStackedF32 {
-    const float* A; const float* Bm; int k1, k2, D;
-    __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
-        const float* r = nullptr;
-        if (row < k1) r = A + ((long long)b * k1 + row) * D;
-        else if (row < k1 + k2) r = Bm + ((long long)b * k2 + (row - k1)) * D;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (r && k0 + e < D) ? (double)r[k0 + e] : 0.0;
-    }
-};
 struct OutScaled {
     double* p; long long stride_b; int ld; double scale;
     // optional second copy of P[1:,1:] in the blocked solver's LDS layout: 16x16 blocks of the lower block

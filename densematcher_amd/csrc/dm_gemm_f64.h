@@ -8,10 +8,33 @@
 // Operands are read through functors so the same tile code serves conversions
 // (f16/f32 -> f64), row scaling (mass) and row gathers (p2p maps).
 #pragma once
+#include <type_traits>
+
 #include "dm_device.h"
 
+// Operand functors stage their data in the type it has in memory (`elem_t`, default double): the conversion to float64
+// happens when the staged registers are written to LDS one stage later.  Converting inside load8 would make every fetch
+// wait for its own data (s_waitcnt right behind the load) instead of overlapping the matrix instructions of the stage.
+template <class T, class = void> struct dm_elem { typedef double type; };
+template <class T> struct dm_elem<T, std::void_t<typename T::elem_t>> { typedef typename T::elem_t type; };
+typedef __attribute__((address_space(1))) const f32x4 dm_gf32x4;      // global address space: global_load, not flat_load
+// TN form: a functor may define raw_t + load4raw / cvt / zero (same idea); otherwise load4 delivers doubles directly.
+template <class T, class = void> struct dm_tn_raw {
+    struct type { double v[4]; };
+    static __device__ __forceinline__ void load(const T& op, int b, int n, int col0, type& r) { op.load4(b, n, col0, r.v); }
+    static __device__ __forceinline__ void zero(type& r) { r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.0; }
+    static __device__ __forceinline__ void cvt(const type& r, double (&v)[4]) { v[0] = r.v[0]; v[1] = r.v[1]; v[2] = r.v[2]; v[3] = r.v[3]; }
+};
+template <class T> struct dm_tn_raw<T, std::void_t<typename T::raw_t>> {
+    typedef typename T::raw_t type;
+    static __device__ __forceinline__ void load(const T& op, int b, int n, int col0, type& r) { op.load4raw(b, n, col0, r); }
+    static __device__ __forceinline__ void zero(type& r) { T::zero(r); }
+    static __device__ __forceinline__ void cvt(const type& r, double (&v)[4]) { T::cvt(r, v); }
+};
+struct dm_f32x4_scaled { f32x4 q; float s; };                         // four fp32 entries of a row and the row's scale
+
 // ----------------------------------------------------------------------------------------------
-// NT form.  OpA/OpB: void load8(int b, int row, int k0, double (&v)[8]) const  -- 8 consecutive k,
+// NT form.  OpA/OpB: void load8(int b, int row, int k0, elem_t (&v)[8]) const  -- 8 consecutive k,
 // zero outside the operand.  Out: void store(int b, int i, int j, double v) const.
 // grid = (tiles_i * tiles_j, 1, B)
 // ----------------------------------------------------------------------------------------------
@@ -37,15 +60,16 @@ __global__ __launch_bounds__(256) void gemm_nt_f64(OpA opa, OpB opb, Out out, in
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    double ra[8], rb[8];
+    typename dm_elem<OpA>::type ra[8];
+    typename dm_elem<OpB>::type rb[8];
     const int ns = (K + NT_BK - 1) / NT_BK;
     opa.load8(b, i0 + lrow, lk, ra);
     opb.load8(b, j0 + lrow, lk, rb);
     for (int s = 0; s < ns; ++s) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            As[lrow * NT_LD + lk + e] = ra[e];
-            Bs[lrow * NT_LD + lk + e] = rb[e];
+            As[lrow * NT_LD + lk + e] = (double)ra[e];
+            Bs[lrow * NT_LD + lk + e] = (double)rb[e];
         }
         __syncthreads();
         if (s + 1 < ns) {
@@ -110,22 +134,29 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(OpX opx, OpY opy, Out out, in
         for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     const int ns = (kend - kbeg + TN_BK - 1) / TN_BK;
-    double rx[4], ry[4];
+    typename dm_tn_raw<OpX>::type rx;
+    typename dm_tn_raw<OpY>::type ry;
     // (macros, not lambdas: by-reference lambda captures of the staging arrays end up in scratch)
 #define TN_FETCH(s_)                                                            \
     {                                                                           \
         const int n_ = kbeg + (s_) * TN_BK + lrow;                              \
         if (n_ < kend) {                                                        \
-            opx.load4(b, n_, m0 + lc, rx);                                      \
-            opy.load4(b, n_, c0 + lc, ry);                                      \
+            dm_tn_raw<OpX>::load(opx, b, n_, m0 + lc, rx);                      \
+            dm_tn_raw<OpY>::load(opy, b, n_, c0 + lc, ry);                      \
         } else {                                                                \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) rx[e] = ry[e] = 0.0;  \
+            dm_tn_raw<OpX>::zero(rx);                                           \
+            dm_tn_raw<OpY>::zero(ry);                                           \
         }                                                                       \
     }
 #define TN_STASH(buf_)                                                          \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                             \
-        Xs[buf_][lrow * TN_LD + lc + e] = rx[e];                                \
-        Ys[buf_][lrow * TN_LD + lc + e] = ry[e];                                \
+    {                                                                           \
+        double vx_[4], vy_[4];                                                  \
+        dm_tn_raw<OpX>::cvt(rx, vx_);                                           \
+        dm_tn_raw<OpY>::cvt(ry, vy_);                                           \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                         \
+            Xs[buf_][lrow * TN_LD + lc + e] = vx_[e];                           \
+            Ys[buf_][lrow * TN_LD + lc + e] = vy_[e];                           \
+        }                                                                       \
     }
     if (ns > 0) {
         TN_FETCH(0)
@@ -148,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(OpX opx, OpY opy, Out out, in
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
         }
-        if (s + 1 < ns) { TN_STASH(buf ^ 1) }
+        if (s + 1 < ns) TN_STASH(buf ^ 1)
         __syncthreads();
     }
 #undef TN_FETCH
@@ -170,38 +201,50 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(OpX opx, OpY opy, Out out, in
 // ----------------------------------------------------------------------------------------------
 // rows of a float32 matrix (B, rows, ld), optionally scaled per row (mass), K-major use (load4)
 struct RowsF32Scaled {
+    typedef dm_f32x4_scaled raw_t;
     const float* p; long long stride_b; int ld; int ncols;
     const float* scale; long long scale_stride_b;   // nullable
-    __device__ __forceinline__ void load4(int b, int n, int col0, double (&v)[4]) const {
+    __device__ __forceinline__ void load4raw(int b, int n, int col0, raw_t& r) const {
         const float* row = p + b * stride_b + (long long)n * ld;
-        const double s = scale ? (double)scale[b * scale_stride_b + n] : 1.0;
+        r.s = scale ? scale[b * scale_stride_b + n] : 1.0f;
         if (col0 + 3 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {
-            const float4 q = *reinterpret_cast<const float4*>(row + col0);
-            v[0] = s * (double)q.x; v[1] = s * (double)q.y; v[2] = s * (double)q.z; v[3] = s * (double)q.w;
+            r.q = *(dm_gf32x4*)(row + col0);
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (col0 + e < ncols) ? s * (double)row[col0 + e] : 0.0;
+            for (int e = 0; e < 4; ++e) r.q[e] = (col0 + e < ncols) ? row[col0 + e] : 0.0f;
         }
+    }
+    static __device__ __forceinline__ void zero(raw_t& r) { r.q = f32x4{0.f, 0.f, 0.f, 0.f}; r.s = 0.f; }
+    static __device__ __forceinline__ void cvt(const raw_t& r, double (&v)[4]) {
+        const double s = (double)r.s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = s * (double)r.q[e];
     }
 };
 
 // gathered, scaled rows of a float32 matrix: row n of the operand is scale[b][n] * p[b][idx[b][n]][:]
 struct RowsF32GatherScaled {
+    typedef dm_f32x4_scaled raw_t;
     const float* p; long long stride_b; int ld; int ncols;
     const int32_t* idx; long long idx_stride_b; int nrows_src;
     const float* scale; long long scale_stride_b;
-    __device__ __forceinline__ void load4(int b, int n, int col0, double (&v)[4]) const {
-        int r = idx[b * idx_stride_b + n];
-        r = min(max(r, 0), nrows_src - 1);
-        const float* row = p + b * stride_b + (long long)r * ld;
-        const double s = (double)scale[b * scale_stride_b + n];
+    __device__ __forceinline__ void load4raw(int b, int n, int col0, raw_t& r) const {
+        int ri = idx[b * idx_stride_b + n];
+        ri = min(max(ri, 0), nrows_src - 1);
+        const float* row = p + b * stride_b + (long long)ri * ld;
+        r.s = scale[b * scale_stride_b + n];
         if (col0 + 3 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {
-            const float4 q = *reinterpret_cast<const float4*>(row + col0);
-            v[0] = s * (double)q.x; v[1] = s * (double)q.y; v[2] = s * (double)q.z; v[3] = s * (double)q.w;
+            r.q = *(dm_gf32x4*)(row + col0);
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (col0 + e < ncols) ? s * (double)row[col0 + e] : 0.0;
+            for (int e = 0; e < 4; ++e) r.q[e] = (col0 + e < ncols) ? row[col0 + e] : 0.0f;
         }
+    }
+    static __device__ __forceinline__ void zero(raw_t& r) { r.q = f32x4{0.f, 0.f, 0.f, 0.f}; r.s = 0.f; }
+    static __device__ __forceinline__ void cvt(const raw_t& r, double (&v)[4]) {
+        const double s = (double)r.s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = s * (double)r.q[e];
     }
 };
 
@@ -224,22 +267,38 @@ struct RowsF16Scaled {
 
 // K-contiguous rows (NT form) of a float32 matrix, rows [0, nrows), columns [0, ncols)
 struct KRowsF32 {
+    typedef float elem_t;
     const float* p; long long stride_b; int ld; int nrows; int ncols;
-    __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
-        if (row >= nrows) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.0;
-            return;
-        }
-        const float* r = p + b * stride_b + (long long)row * ld;
+    __device__ __forceinline__ void load8(int b, int row, int k0, float (&v)[8]) const {
+        // rows beyond the operand only feed outputs the caller masks or rows of zeros: clamp instead of branching
+        const float* r = p + b * stride_b + (long long)min(row, nrows - 1) * ld;
+        const bool in = row < nrows;
         if (k0 + 7 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {
-            const float4 q0 = *reinterpret_cast<const float4*>(r + k0);
-            const float4 q1 = *reinterpret_cast<const float4*>(r + k0 + 4);
-            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
-            v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+            const f32x4 q0 = *(dm_gf32x4*)(r + k0), q1 = *(dm_gf32x4*)(r + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = in ? q0[e] : 0.0f; v[4 + e] = in ? q1[e] : 0.0f; }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (k0 + e < ncols) ? (double)r[k0 + e] : 0.0;
+            for (int e = 0; e < 8; ++e) v[e] = (in && k0 + e < ncols) ? r[k0 + e] : 0.0f;
+        }
+    }
+};
+
+// two fp32 matrices stacked: rows 0 .. k1-1 = A (B, k1, D), rows k1 .. k1+k2-1 = Bm (B, k2, D); K = D contiguous
+struct KRowsStackedF32 {
+    typedef float elem_t;
+    const float* A; const float* Bm; int k1, k2, D;
+    __device__ __forceinline__ void load8(int b, int row, int k0, float (&v)[8]) const {
+        const bool in = row < k1 + k2;
+        const int rc = in ? row : 0;
+        const float* r = (rc < k1) ? A + ((long long)b * k1 + rc) * D : Bm + ((long long)b * k2 + (rc - k1)) * D;
+        if (k0 + 7 < D && ((D & 3) == 0) && (((((uintptr_t)A) | ((uintptr_t)Bm)) & 15) == 0)) {
+            const f32x4 q0 = *(dm_gf32x4*)(r + k0), q1 = *(dm_gf32x4*)(r + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = in ? q0[e] : 0.0f; v[4 + e] = in ? q1[e] : 0.0f; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (in && k0 + e < D) ? r[k0 + e] : 0.0f;
         }
     }
 };

@@ -110,103 +110,173 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
     }
 }
 
-// embT (K-major, optional) + column norms + per-64-column maxima in one kernel: a workgroup owns 64 vertices and walks
-// all row tiles of the product, so the squared sums never leave the workgroup and are added in a fixed order
-// (identical columns get identical norms).  The tile loop is that of gemm_nt_f64.
-template <bool STORE>
-__global__ __launch_bounds__(256) void embed_norm_kernel(KRowsF64 opa, KRowsF32 opb, double* __restrict__ embT, int krpad, int Npad,
-                                                         int kr, int N, int K, double* __restrict__ nrm, double* __restrict__ amax_part) {
-    __shared__ double As[NT_T * NT_LD];
-    __shared__ double Bs[NT_T * NT_LD];
-    __shared__ double xs[2][64];
-    __shared__ double wmax[4];
-    const int b = blockIdx.z, jblk = blockIdx.x * DM_EMB_COLS;
+// embT (K-major, optional) + column norms + per-64-column maxima in one kernel.  A workgroup tile is ALL rows of the
+// product (64 RT >= kr) x 64 vertices, so the squared sums never leave the workgroup and are added in a fixed order
+// (identical columns get identical norms).  Each wave owns 16 RT rows x 64 columns = RT x 4 accumulator tiles of
+// v_mfma_f64_16x16x4_f64.  The contraction runs in stages of 16 through two LDS buffers (one barrier per stage), operands
+// staged through registers; workgroups are persistent and fetch the first stage of their NEXT tile during the last stage
+// of the current one, so no load latency is exposed between tiles (the contraction is only 4-13 stages deep).
+constexpr int EB_BK = 16;     // contraction per stage
+constexpr int EB_LD = 18;     // LDS row stride (f64): 36 dwords -> the 16 rows of a fragment read start on distinct 4-bank groups
+static inline size_t embed_lds(int RT) { return ((size_t)2 * (64 * RT + 64) * EB_LD + 3 * 64 + 4) * sizeof(double); }
+
+template <int RT, bool STORE>
+__global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void embed_tile_kernel(const double* __restrict__ Cm, long long strideC, int ldc, int transC,
+                                                         const float* __restrict__ Phi, long long stridePhi, int ld,
+                                                         double* __restrict__ embT, int krpad, int Npad, int kr, int N, int K,
+                                                         double* __restrict__ nrm, double* __restrict__ amax_part, int ntile_j,
+                                                         int total) {
+    extern __shared__ __attribute__((aligned(16))) double eb_sm[];
+    constexpr int RA = 64 * RT;
+    double* Abuf = eb_sm;                                   // [2][RA][EB_LD]
+    double* Bbuf = eb_sm + 2 * RA * EB_LD;                  // [2][64][EB_LD]
+    double* xs = Bbuf + 2 * 64 * EB_LD;                     // [3][64] column sums of waves 1-3
+    double* wmax = xs + 3 * 64;                             // [4]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lrow = t >> 2, lk = (t & 3) * 8;
-    const int ns = (K + NT_BK - 1) / NT_BK;
-    const int tiles_i = (kr + NT_T - 1) / NT_T;
-    double* E = STORE ? embT + (long long)b * krpad * Npad : nullptr;
-    double amax = 0.0;
-    for (int tj = 0; tj < DM_EMB_COLS / NT_T; ++tj) {
-        const int j0 = jblk + tj * NT_T;
-        if (j0 >= Npad) break;                                    // uniform
-        double csum[2] = {0.0, 0.0};                              // columns wn*32 + nt*16 + (lane & 15), rows of this lane
-        for (int ti = 0; ti < tiles_i; ++ti) {
-            const int i0 = ti * NT_T;
-            f64x4 acc[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
-            double ra[8], rb[8];
-            opa.load8(b, i0 + lrow, lk, ra);
-            opb.load8(b, j0 + lrow, lk, rb);
-            for (int s = 0; s < ns; ++s) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    As[lrow * NT_LD + lk + e] = ra[e];
-                    Bs[lrow * NT_LD + lk + e] = rb[e];
-                }
-                __syncthreads();
-                if (s + 1 < ns) {
-                    opa.load8(b, i0 + lrow, (s + 1) * NT_BK + lk, ra);
-                    opb.load8(b, j0 + lrow, (s + 1) * NT_BK + lk, rb);
-                }
-#pragma unroll
-                for (int ks = 0; ks < NT_BK / 4; ++ks) {
-                    const int kk = ks * 4 + (lane >> 4);
-                    double a[2], bb[2];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) a[mt] = As[(wm * 32 + mt * 16 + (lane & 15)) * NT_LD + kk];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) bb[nt] = Bs[(wn * 32 + nt * 16 + (lane & 15)) * NT_LD + kk];
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int j = j0 + wn * 32 + nt * 16 + (lane & 15);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = i0 + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
-                        const double v = (i < kr && j < N) ? acc[mt][nt][r] : 0.0;
-                        if (STORE && i < kr && j < N) E[(long long)i * Npad + j] = v;
-                        csum[nt] = fma(v, v, csum[nt]);
-                        amax = fmax(amax, fabs(v));
-                    }
-            }
-        }
-        // column sums: the four row groups of a wave (xor tree: the same order in every lane), then the two row halves
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            csum[nt] += __shfl_xor(csum[nt], 16);
-            csum[nt] += __shfl_xor(csum[nt], 32);
-        }
-        if (wm == 1 && lane < 16) { xs[0][wn * 32 + lane] = csum[0]; xs[1][wn * 32 + lane] = csum[1]; }
-        __syncthreads();
-        if (wm == 0 && lane < 16 && nrm) {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int j = j0 + wn * 32 + nt * 16 + lane;
-                if (j < Npad) nrm[(long long)b * Npad + j] = csum[nt] + xs[nt][wn * 32 + lane];
-            }
-        }
-        __syncthreads();
+    const int srow = t >> 2, sk = (t & 3) * 4;             // staging: row srow (+ 64 q), contraction entries sk .. sk+3
+    const int ns = (K + EB_BK - 1) / EB_BK;
+    const bool fastA = !transC && ((ldc & 1) == 0) && ((strideC & 1) == 0) && ((((uintptr_t)Cm) & 15) == 0);
+    const bool fastB = ((ld & 3) == 0) && ((stridePhi & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0);
+
+    // staged operands: kept exactly as loaded (the fp32 -> fp64 conversion happens when they are written to LDS one stage
+    // later: converting at load time would make every fetch wait for its own data); pointers carry the global address
+    // space so that the loads are global_load, not flat_load (a flat load also counts on lgkmcnt and would be waited for
+    // by the fragment reads' lgkmcnt(0))
+    typedef __attribute__((address_space(1))) const double gdouble;
+    typedef __attribute__((address_space(1))) const float gfloat;
+    typedef __attribute__((address_space(1))) const f64x2 gf64x2;
+    typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+    double ra[RT][4];
+    float rb[4];
+    // The operand fetch is a stream of stages that runs one stage ahead of the compute loop, across tile boundaries.  Its
+    // position is kept as running pointers (one 64-bit add per operand row and stage: f64 MFMA shares the vector ALU, every
+    // address instruction in the loop is paid in full).  Rows >= kr and vertices >= N only feed accumulator entries that
+    // the epilogue masks, so their loads are clamped to a valid address instead of being predicated; a stage that lies
+    // completely inside the contraction (wave-uniform test) is then branch-free.  The generic path handles a ragged last
+    // stage and unaligned operands.
+    int f_tile = blockIdx.x, f_s = 0;
+    gdouble* fa[RT];
+    gfloat* fb = nullptr;
+    const long long a_step = transC ? (long long)EB_BK * ldc : EB_BK;
+    // (macros, not lambdas: by-reference lambda captures of the staging arrays end up in scratch)
+#define EB_SET_TILE()                                                                                                  \
+    {                                                                                                                  \
+        const int b_ = f_tile / ntile_j, j0_ = (f_tile - b_ * ntile_j) * 64;                                           \
+        gdouble* cb_ = (gdouble*)Cm + (long long)b_ * strideC;                                                         \
+        _Pragma("unroll") for (int q = 0; q < RT; ++q) {                                                               \
+            const int row_ = min(srow + 64 * q, kr - 1);                                                               \
+            fa[q] = cb_ + (transC ? (long long)sk * ldc + row_ : (long long)row_ * ldc + sk);                          \
+        }                                                                                                              \
+        fb = (gfloat*)Phi + (long long)b_ * stridePhi + (long long)min(j0_ + srow, N - 1) * ld + sk;                   \
+        f_s = 0;                                                                                                       \
     }
-    if (amax_part) {
+#define EB_FETCH()                                                                                                     \
+    {                                                                                                                  \
+        if ((f_s + 1) * EB_BK <= K && fastB && (fastA || transC)) {                                                    \
+            _Pragma("unroll") for (int q = 0; q < RT; ++q) {                                                           \
+                if (!transC) {                                                                                         \
+                    const f64x2 x0_ = ((gf64x2*)fa[q])[0], x1_ = ((gf64x2*)fa[q])[1];                                  \
+                    ra[q][0] = x0_[0]; ra[q][1] = x0_[1]; ra[q][2] = x1_[0]; ra[q][3] = x1_[1];                        \
+                } else {                                                                                               \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) ra[q][e] = fa[q][(long long)e * ldc];                \
+                }                                                                                                      \
+            }                                                                                                          \
+            const f32x4 x_ = *(gf32x4*)fb;                                                                             \
+            rb[0] = x_[0]; rb[1] = x_[1]; rb[2] = x_[2]; rb[3] = x_[3];                                                \
+        } else {                                                                                                       \
+            const int k0_ = f_s * EB_BK + sk;                                                                          \
+            _Pragma("unroll") for (int q = 0; q < RT; ++q)                                                             \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                          \
+                    ra[q][e] = (k0_ + e < K) ? (transC ? fa[q][(long long)e * ldc] : fa[q][e]) : 0.0;                  \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) rb[e] = (k0_ + e < K) ? fb[e] : 0.0f;                        \
+        }                                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < RT; ++q) fa[q] += a_step;                                                \
+        fb += EB_BK;                                                                                                   \
+        if (++f_s == ns) {                                                                                             \
+            f_tile += (int)gridDim.x;                                                                                  \
+            if (f_tile < total) EB_SET_TILE()                                                                          \
+        }                                                                                                              \
+    }
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    EB_SET_TILE()
+    EB_FETCH()
+    int g = 0;                                              // stage counter across tiles: LDS buffer = g & 1
+    while (tile < total) {
+        const int b = tile / ntile_j, j0 = (tile - b * ntile_j) * 64;
+        f64x4 acc[RT][4];
+#pragma unroll
+        for (int a_ = 0; a_ < RT; ++a_)
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < ns; ++s, ++g) {
+            double* As = Abuf + (g & 1) * RA * EB_LD;
+            double* Bs = Bbuf + (g & 1) * 64 * EB_LD;
+#pragma unroll
+            for (int q = 0; q < RT; ++q) {
+                *reinterpret_cast<f64x2*>(As + (srow + 64 * q) * EB_LD + sk) = f64x2{ra[q][0], ra[q][1]};
+                *reinterpret_cast<f64x2*>(As + (srow + 64 * q) * EB_LD + sk + 2) = f64x2{ra[q][2], ra[q][3]};
+            }
+            *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk) = f64x2{(double)rb[0], (double)rb[1]};
+            *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk + 2) = f64x2{(double)rb[2], (double)rb[3]};
+            __syncthreads();
+            // the buffer written above was last read two stages ago, and every wave has passed a barrier since
+            if (f_tile < total) EB_FETCH()
+#pragma unroll
+            for (int ks = 0; ks < EB_BK / 4; ++ks) {
+                const int kk = ks * 4 + (lane >> 4);
+                double av[RT], bv[4];
+#pragma unroll
+                for (int a_ = 0; a_ < RT; ++a_) av[a_] = As[(wave * 16 * RT + a_ * 16 + (lane & 15)) * EB_LD + kk];
+#pragma unroll
+                for (int c_ = 0; c_ < 4; ++c_) bv[c_] = Bs[(c_ * 16 + (lane & 15)) * EB_LD + kk];
+#pragma unroll
+                for (int a_ = 0; a_ < RT; ++a_)
+#pragma unroll
+                    for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = mfma_f64_16x16x4(av[a_], bv[c_], acc[a_][c_]);
+            }
+        }
+        // ---- tile epilogue: optional K-major store, column sums of squares (fixed order), maxima
+        double* E = STORE ? embT + (long long)b * krpad * Npad : nullptr;
+        double csum[4] = {0.0, 0.0, 0.0, 0.0}, amax = 0.0;
+#pragma unroll
+        for (int c_ = 0; c_ < 4; ++c_) {
+            const int j = j0 + c_ * 16 + (lane & 15);
+#pragma unroll
+            for (int a_ = 0; a_ < RT; ++a_)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = wave * 16 * RT + a_ * 16 + (lane >> 4) + 4 * r;
+                    const double v = (i < kr && j < N) ? acc[a_][c_][r] : 0.0;
+                    if (STORE && i < kr && j < N) E[(long long)i * Npad + j] = v;
+                    csum[c_] = fma(v, v, csum[c_]);
+                    amax = fmax(amax, fabs(v));
+                }
+            csum[c_] += __shfl_xor(csum[c_], 16);
+            csum[c_] += __shfl_xor(csum[c_], 32);
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
+        if (wave > 0 && lane < 16) {
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) xs[(wave - 1) * 64 + c_ * 16 + lane] = csum[c_];
+        }
         if (lane == 0) wmax[wave] = amax;
         __syncthreads();
-        if (t == 0) amax_part[b * gridDim.x + blockIdx.x] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+        if (wave == 0 && lane < 16 && nrm) {
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                const int cj = c_ * 16 + lane, j = j0 + cj;
+                if (j < Npad) nrm[(long long)b * Npad + j] = ((csum[c_] + xs[cj]) + xs[64 + cj]) + xs[128 + cj];
+            }
+        }
+        if (t == 0 && amax_part) amax_part[(long long)b * ntile_j + (j0 >> 6)] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+        // (xs / wmax are rewritten only after the next tile's stage barriers)
+        tile += (int)gridDim.x;
     }
+#undef EB_FETCH
+#undef EB_SET_TILE
 }
 
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld, const double* Cm, int ldc,
@@ -215,13 +285,36 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
     if (embT && zero_first && (kr != krpad || N != Npad))
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
-    KRowsF64 opa{Cm, strideC, ldc, kr, km, transC};
-    KRowsF32 opb{Phi, (long long)N * ld, ld, N, km};
-    dim3 grid(dm_cdiv(Npad, DM_EMB_COLS), 1, B);
-    if (embT)
-        DM_LAUNCH(ctx, "embed_nt_f64", embed_norm_kernel<true>, grid, dim3(256), 0, opa, opb, embT, krpad, Npad, kr, N, km, nrm, amax_part);
-    else
-        DM_LAUNCH(ctx, "embed_nt_f64", embed_norm_kernel<false>, grid, dim3(256), 0, opa, opb, embT, krpad, Npad, kr, N, km, nrm, amax_part);
+    if (kr > 256) return dm_fail(ctx, DM_EINVAL, "embed: more than 256 rows");
+    const int RT = dm_cdiv(kr, 64);
+    const int ntile_j = dm_cdiv(Npad, DM_EMB_COLS), total = B * ntile_j;
+    const size_t lds = embed_lds(RT);
+    const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    // resident workgroups per CU: registers (RT x 32 accumulator registers per lane) and LDS
+    const int by_regs = RT == 1 ? 3 : (RT == 2 ? 2 : 1), by_lds = (int)((size_t)160 * 1024 / lds);
+    const int per_cu = by_regs < by_lds ? by_regs : by_lds;
+    const int grid = total < ncu * per_cu ? total : ncu * per_cu;
+#define EB_LAUNCH(RT_)                                                                                                 \
+    {                                                                                                                  \
+        if (embT) {                                                                                                    \
+            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, true>, lds);                                \
+            if (rc) return rc;                                                                                         \
+            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, true>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
+                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total);             \
+        } else {                                                                                                       \
+            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, false>, lds);                               \
+            if (rc) return rc;                                                                                         \
+            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, false>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
+                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total);             \
+        }                                                                                                              \
+    }
+    switch (RT) {
+        case 1: EB_LAUNCH(1) break;
+        case 2: EB_LAUNCH(2) break;
+        case 3: EB_LAUNCH(3) break;
+        default: EB_LAUNCH(4) break;
+    }
+#undef EB_LAUNCH
     return DM_OK;
 }
 
