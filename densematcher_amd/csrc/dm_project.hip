@@ -127,26 +127,31 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
     const int fcol = (t & 7) * 32;                           //          and 32 consecutive descriptor channels
     const bool xvec = ((p.ld & 3) == 0) && ((((uintptr_t)p.Phi) & 15) == 0);
     const bool fvec = ((p.D & 7) == 0) && ((((uintptr_t)p.F) & 15) == 0);
-    float xr[16];
+    // staged exactly as loaded: the mass scaling and the hi / lo split happen in PROJ_STASH, one stage later (arithmetic on
+    // the loaded values inside PROJ_FETCH would make every fetch wait for its own data)
+    float xr[16], an_raw = 0.f;
     u32x4 fr[4];
+    typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4;
+    typedef __attribute__((address_space(1))) const float gfloat;
 #define PROJ_FETCH(s_)                                                                                        \
     {                                                                                                         \
         const int n_ = nbeg + (s_) * PBK + srow;                                                              \
         const bool rv = n_ < nend;                                                                            \
-        const float an = rv ? mass[n_] * scale : 0.f;                                                         \
+        an_raw = rv ? ((gfloat*)mass)[n_] : 0.f;                                                              \
         const float* xrow = Phi + (long long)n_ * p.ld + m0 + scol;                                           \
         if (rv && xvec && m0 + scol + 15 < p.k) {                                                             \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
-                const float4 v = *reinterpret_cast<const float4*>(xrow + 4 * q);                              \
-                xr[4 * q] = v.x * an; xr[4 * q + 1] = v.y * an; xr[4 * q + 2] = v.z * an; xr[4 * q + 3] = v.w * an; \
+                const f32x4 v = *(gf32x4*)(xrow + 4 * q);                                                     \
+                xr[4 * q] = v[0]; xr[4 * q + 1] = v[1]; xr[4 * q + 2] = v[2]; xr[4 * q + 3] = v[3];           \
             }                                                                                                 \
         } else {                                                                                              \
             _Pragma("unroll") for (int q = 0; q < 16; ++q)                                                    \
-                xr[q] = (rv && m0 + scol + q < p.k) ? xrow[q] * an : 0.f;                                     \
+                xr[q] = (rv && m0 + scol + q < p.k) ? xrow[q] : 0.f;                                          \
         }                                                                                                     \
         const _Float16* frow = F + (long long)n_ * p.D + d0 + fcol;                                           \
         if (rv && fvec && d0 + fcol + 31 < p.D) {                                                             \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) fr[q] = *reinterpret_cast<const u32x4*>(frow + 8 * q); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) fr[q] = *(gu32x4*)(frow + 8 * q);                   \
         } else {                                                                                              \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
                 f16x8 tmp;                                                                                    \
@@ -162,10 +167,16 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
         _Float16* Xl = Xh + PBK * PLD;                                                                        \
         _Float16* Fs = smem + (buf_) * PSTAGE + 2 * PBK * PLD + srow * PLDF + fcol;                           \
         f16x8 h[2], l[2];                                                                                     \
+        const float an = an_raw * scale;                                                                      \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                      \
-            const _Float16 hi = (_Float16)xr[q];                                                              \
+            float xs_ = xr[q] * an;                                                                           \
+            /* the product must be ONE rounded value for both pieces: left visible, the compiler contracts it into the */ \
+            /* conversion of hi (v_fma_mix, single rounding) but not into the one it stores, and hi + lo is off by an */ \
+            /* ulp of hi on ties */                                                                           \
+            asm volatile("" : "+v"(xs_));                                                                     \
+            const _Float16 hi = (_Float16)xs_;                                                                \
             h[q >> 3][q & 7] = hi;                                                                            \
-            l[q >> 3][q & 7] = (_Float16)(xr[q] - (float)hi);                                                 \
+            l[q >> 3][q & 7] = (_Float16)(xs_ - (float)hi);                                                   \
         }                                                                                                     \
         *reinterpret_cast<f16x8*>(Xh) = h[0]; *reinterpret_cast<f16x8*>(Xh + 8) = h[1];                       \
         *reinterpret_cast<f16x8*>(Xl) = l[0]; *reinterpret_cast<f16x8*>(Xl + 8) = l[1];                       \
