@@ -180,8 +180,19 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
                     mm &= mm - 1;
                     const int j = sb * 32 + c;
                     double sacc = 0.0;
-                    if (j < N1)
-                        for (int r = part; r < K; r += 8) sacc = fma(xrow[r], Bm[(long long)r * N1pad + j], sacc);
+                    if (j < N1) {
+                        // loads in batches of eight ahead of their (ordered) fma chain: a plain loop would take one L2 round
+                        // trip per term
+                        int r = part;
+                        for (; r + 56 < K; r += 64) {
+                            double y[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) y[u] = Bm[(long long)(r + 8 * u) * N1pad + j];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) sacc = fma(xrow[r + 8 * u], y[u], sacc);
+                        }
+                        for (; r < K; r += 8) sacc = fma(xrow[r], Bm[(long long)r * N1pad + j], sacc);
+                    }
                     part_s[part * 32 + c] = sacc;
                     __syncthreads();
                     if (t < 32 && j < N1) {
@@ -326,10 +337,20 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const float* __restr
     const float* src = Phi + ((long long)b * N + v) * ld + 8 * q;
     _Float16* dst = F + ((long long)b * N + v) * D + 24 * q;
     _Float16 o24[24];
+    float xin[8];
+    if (8 * q + 8 <= K && ((ld & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {       // two 16-byte loads
+        typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+        const f32x4 v0 = ((gf32x4*)src)[0], v1 = ((gf32x4*)src)[1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xin[u] = v0[u]; xin[4 + u] = v1[u]; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xin[u] = (8 * q + u < K) ? src[u] : 0.0f;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        _Float16 h = (_Float16)0.0f, l = (_Float16)0.0f;
-        if (8 * q + u < K) { const float x = (float)((double)src[u] * sx); h = (_Float16)x; l = (_Float16)(x - (float)h); }
+        const float x = (float)((double)xin[u] * sx);                 // exact (sx is a power of two); 0 beyond K
+        const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
         o24[3 * u] = h; o24[3 * u + 1] = h; o24[3 * u + 2] = l;
     }
     if (24 * q + 24 <= D) {

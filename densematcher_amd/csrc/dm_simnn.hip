@@ -593,6 +593,7 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_set s0, si
     if (i >= N2) return;
     float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
     int bj = DM_IDX_NONE;
+#pragma unroll 4
     for (int ts = 0; ts < tilesS; ++ts) {
         const long long o = ((long long)b * tilesS + ts) * N2pad + i;
         top2_merge(bv, bj, sv, s.pb[o], s.pj[o], s.ps[o]);
@@ -657,7 +658,17 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
                     double sacc = 0.0;
                     if (j < N1) {
                         const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
-                        for (int k = part * 8; k < D; k += 64) {      // D % 8 == 0 is guaranteed by the caller
+                        int k = part * 8;                              // D % 8 == 0 is guaranteed by the caller
+                        for (; k + 192 < D; k += 256) {                // four loads ahead of their (ordered) fma chains
+                            f16x8 v[4];
+#pragma unroll
+                            for (int w4 = 0; w4 < 4; ++w4) v[w4] = *reinterpret_cast<const f16x8*>(sr + k + 64 * w4);
+#pragma unroll
+                            for (int w4 = 0; w4 < 4; ++w4)
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) sacc = fma((double)v[w4][u], trow[k + 64 * w4 + u], sacc);
+                        }
+                        for (; k < D; k += 64) {
                             const f16x8 v = *reinterpret_cast<const f16x8*>(sr + k);
 #pragma unroll
                             for (int u = 0; u < 8; ++u) sacc = fma((double)v[u], trow[k + u], sacc);
