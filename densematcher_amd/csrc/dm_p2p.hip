@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
 }
 
 // embT (K-major, optional) + column norms + per-64-column maxima in one kernel.  A workgroup tile is ALL rows of the
-// product (64 RT >= kr) x 64 vertices, so the squared sums never leave the workgroup and are added in a fixed order
-// (identical columns get identical norms).  Each wave owns 16 RT rows x 64 columns = RT x 4 accumulator tiles of
+// product x 64 vertices (walked in groups of 64 RT rows), so the squared sums never leave the workgroup and are added in
+// a fixed order (identical columns get identical norms).  Each wave owns 16 RT rows x 64 columns = RT x 4 accumulator tiles of
 // v_mfma_f64_16x16x4_f64.  The contraction runs in stages of 16 through two LDS buffers (one barrier per stage), operands
 // staged through registers; workgroups are persistent and fetch the first stage of their NEXT tile during the last stage
 // of the current one, so no load latency is exposed between tiles (the contraction is only 4-13 stages deep).
@@ -121,11 +121,11 @@ constexpr int EB_LD = 18;     // LDS row stride (f64): 36 dwords -> the 16 rows 
 static inline size_t embed_lds(int RT) { return ((size_t)2 * (64 * RT + 64) * EB_LD + 3 * 64 + 4) * sizeof(double); }
 
 template <int RT, bool STORE>
-__global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void embed_tile_kernel(const double* __restrict__ Cm, long long strideC, int ldc, int transC,
+__global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __restrict__ Cm, long long strideC, int ldc, int transC,
                                                          const float* __restrict__ Phi, long long stridePhi, int ld,
                                                          double* __restrict__ embT, int krpad, int Npad, int kr, int N, int K,
                                                          double* __restrict__ nrm, double* __restrict__ amax_part, int ntile_j,
-                                                         int total) {
+                                                         int total, int nrg) {
     extern __shared__ __attribute__((aligned(16))) double eb_sm[];
     constexpr int RA = 64 * RT;
     double* Abuf = eb_sm;                                   // [2][RA][EB_LD]
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void embed_tile_kernel(cons
     // the epilogue masks, so their loads are clamped to a valid address instead of being predicated; a stage that lies
     // completely inside the contraction (wave-uniform test) is then branch-free.  The generic path handles a ragged last
     // stage and unaligned operands.
-    int f_tile = blockIdx.x, f_s = 0;
+    int f_tile = blockIdx.x, f_s = 0, f_rg = 0;           // fetch stream position: tile, row group of the tile, stage
     gdouble* fa[RT];
     gfloat* fb = nullptr;
     const long long a_step = transC ? (long long)EB_BK * ldc : EB_BK;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void embed_tile_kernel(cons
         const int b_ = f_tile / ntile_j, j0_ = (f_tile - b_ * ntile_j) * 64;                                           \
         gdouble* cb_ = (gdouble*)Cm + (long long)b_ * strideC;                                                         \
         _Pragma("unroll") for (int q = 0; q < RT; ++q) {                                                               \
-            const int row_ = min(srow + 64 * q, kr - 1);                                                               \
+            const int row_ = min(f_rg * RA + srow + 64 * q, kr - 1);                                                   \
             fa[q] = cb_ + (transC ? (long long)sk * ldc + row_ : (long long)row_ * ldc + sk);                          \
         }                                                                                                              \
         fb = (gfloat*)Phi + (long long)b_ * stridePhi + (long long)min(j0_ + srow, N - 1) * ld + sk;                   \
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void embed_tile_kernel(cons
         _Pragma("unroll") for (int q = 0; q < RT; ++q) fa[q] += a_step;                                                \
         fb += EB_BK;                                                                                                   \
         if (++f_s == ns) {                                                                                             \
-            f_tile += (int)gridDim.x;                                                                                  \
+            if (++f_rg == nrg) { f_rg = 0; f_tile += (int)gridDim.x; }                                                 \
             if (f_tile < total) EB_SET_TILE()                                                                          \
         }                                                                                                              \
     }
@@ -205,54 +205,62 @@ __global__ __launch_bounds__(256, (RT <= 2 ? 2 : 1)) void embed_tile_kernel(cons
     int g = 0;                                              // stage counter across tiles: LDS buffer = g & 1
     while (tile < total) {
         const int b = tile / ntile_j, j0 = (tile - b * ntile_j) * 64;
-        f64x4 acc[RT][4];
-#pragma unroll
-        for (int a_ = 0; a_ < RT; ++a_)
-#pragma unroll
-            for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = f64x4{0.0, 0.0, 0.0, 0.0};
-        for (int s = 0; s < ns; ++s, ++g) {
-            double* As = Abuf + (g & 1) * RA * EB_LD;
-            double* Bs = Bbuf + (g & 1) * 64 * EB_LD;
-#pragma unroll
-            for (int q = 0; q < RT; ++q) {
-                *reinterpret_cast<f64x2*>(As + (srow + 64 * q) * EB_LD + sk) = f64x2{ra[q][0], ra[q][1]};
-                *reinterpret_cast<f64x2*>(As + (srow + 64 * q) * EB_LD + sk + 2) = f64x2{ra[q][2], ra[q][3]};
-            }
-            *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk) = f64x2{(double)rb[0], (double)rb[1]};
-            *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk + 2) = f64x2{(double)rb[2], (double)rb[3]};
-            __syncthreads();
-            // the buffer written above was last read two stages ago, and every wave has passed a barrier since
-            if (f_tile < total) EB_FETCH()
-#pragma unroll
-            for (int ks = 0; ks < EB_BK / 4; ++ks) {
-                const int kk = ks * 4 + (lane >> 4);
-                double av[RT], bv[4];
-#pragma unroll
-                for (int a_ = 0; a_ < RT; ++a_) av[a_] = As[(wave * 16 * RT + a_ * 16 + (lane & 15)) * EB_LD + kk];
-#pragma unroll
-                for (int c_ = 0; c_ < 4; ++c_) bv[c_] = Bs[(c_ * 16 + (lane & 15)) * EB_LD + kk];
-#pragma unroll
-                for (int a_ = 0; a_ < RT; ++a_)
-#pragma unroll
-                    for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = mfma_f64_16x16x4(av[a_], bv[c_], acc[a_][c_]);
-            }
-        }
-        // ---- tile epilogue: optional K-major store, column sums of squares (fixed order), maxima
         double* E = STORE ? embT + (long long)b * krpad * Npad : nullptr;
         double csum[4] = {0.0, 0.0, 0.0, 0.0}, amax = 0.0;
-#pragma unroll
-        for (int c_ = 0; c_ < 4; ++c_) {
-            const int j = j0 + c_ * 16 + (lane & 15);
+        // more than 64 RT rows: the tile is walked in row groups (the vertex slab is streamed again from L2 for each), the
+        // column sums run on across the groups
+        for (int rg = 0; rg < nrg; ++rg) {
+            f64x4 acc[RT][4];
 #pragma unroll
             for (int a_ = 0; a_ < RT; ++a_)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = wave * 16 * RT + a_ * 16 + (lane >> 4) + 4 * r;
-                    const double v = (i < kr && j < N) ? acc[a_][c_][r] : 0.0;
-                    if (STORE && i < kr && j < N) E[(long long)i * Npad + j] = v;
-                    csum[c_] = fma(v, v, csum[c_]);
-                    amax = fmax(amax, fabs(v));
+                for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int s = 0; s < ns; ++s, ++g) {
+                double* As = Abuf + (g & 1) * RA * EB_LD;
+                double* Bs = Bbuf + (g & 1) * 64 * EB_LD;
+#pragma unroll
+                for (int q = 0; q < RT; ++q) {
+                    *reinterpret_cast<f64x2*>(As + (srow + 64 * q) * EB_LD + sk) = f64x2{ra[q][0], ra[q][1]};
+                    *reinterpret_cast<f64x2*>(As + (srow + 64 * q) * EB_LD + sk + 2) = f64x2{ra[q][2], ra[q][3]};
                 }
+                *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk) = f64x2{(double)rb[0], (double)rb[1]};
+                *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk + 2) = f64x2{(double)rb[2], (double)rb[3]};
+                __syncthreads();
+                // the buffer written above was last read two stages ago, and every wave has passed a barrier since
+                if (f_tile < total) EB_FETCH()
+#pragma unroll
+                for (int ks = 0; ks < EB_BK / 4; ++ks) {
+                    const int kk = ks * 4 + (lane >> 4);
+                    double av[RT], bv[4];
+#pragma unroll
+                    for (int a_ = 0; a_ < RT; ++a_) av[a_] = As[(wave * 16 * RT + a_ * 16 + (lane & 15)) * EB_LD + kk];
+#pragma unroll
+                    for (int c_ = 0; c_ < 4; ++c_) bv[c_] = Bs[(c_ * 16 + (lane & 15)) * EB_LD + kk];
+#pragma unroll
+                    for (int a_ = 0; a_ < RT; ++a_)
+#pragma unroll
+                        for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = mfma_f64_16x16x4(av[a_], bv[c_], acc[a_][c_]);
+                }
+            }
+            // ---- row-group epilogue: optional K-major store, squares into the column sums (fixed order), maxima
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                const int j = j0 + c_ * 16 + (lane & 15);
+#pragma unroll
+                for (int a_ = 0; a_ < RT; ++a_)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = rg * RA + wave * 16 * RT + a_ * 16 + (lane >> 4) + 4 * r;
+                        const double v = (i < kr && j < N) ? acc[a_][c_][r] : 0.0;
+                        if (STORE && i < kr && j < N) E[(long long)i * Npad + j] = v;
+                        csum[c_] = fma(v, v, csum[c_]);
+                        amax = fmax(amax, fabs(v));
+                    }
+            }
+        }
+        // ---- tile epilogue: the four row groups of a wave (xor tree: the same order in every lane), then the four waves
+#pragma unroll
+        for (int c_ = 0; c_ < 4; ++c_) {
             csum[c_] += __shfl_xor(csum[c_], 16);
             csum[c_] += __shfl_xor(csum[c_], 32);
         }
@@ -285,13 +293,13 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
     if (embT && zero_first && (kr != krpad || N != Npad))
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
-    if (kr > 256) return dm_fail(ctx, DM_EINVAL, "embed: more than 256 rows");
-    const int RT = dm_cdiv(kr, 64);
+    const int RT = kr <= 64 ? 1 : 2;                        // 64 RT rows per row group: two workgroups per CU at RT = 2
+    const int nrg = dm_cdiv(kr, 64 * RT);
     const int ntile_j = dm_cdiv(Npad, DM_EMB_COLS), total = B * ntile_j;
     const size_t lds = embed_lds(RT);
     const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     // resident workgroups per CU: registers (RT x 32 accumulator registers per lane) and LDS
-    const int by_regs = RT == 1 ? 3 : (RT == 2 ? 2 : 1), by_lds = (int)((size_t)160 * 1024 / lds);
+    const int by_regs = RT == 1 ? 3 : 2, by_lds = (int)((size_t)160 * 1024 / lds);
     const int per_cu = by_regs < by_lds ? by_regs : by_lds;
     const int grid = total < ncu * per_cu ? total : ncu * per_cu;
 #define EB_LAUNCH(RT_)                                                                                                 \
@@ -300,20 +308,15 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
             int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, true>, lds);                                \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, true>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
-                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total);             \
+                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg);        \
         } else {                                                                                                       \
             int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, false>, lds);                               \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, false>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
-                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total);             \
+                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg);        \
         }                                                                                                              \
     }
-    switch (RT) {
-        case 1: EB_LAUNCH(1) break;
-        case 2: EB_LAUNCH(2) break;
-        case 3: EB_LAUNCH(3) break;
-        default: EB_LAUNCH(4) break;
-    }
+    if (RT == 1) EB_LAUNCH(1) else EB_LAUNCH(2)
 #undef EB_LAUNCH
     return DM_OK;
 }
