@@ -58,6 +58,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] similarity-kernel block of the default workload")
+    ap.add_argument("--p2p-split", type=int, default=None,
+                    help="code path of the four maps (dm_set_option p2p_split): 0 float64 kernel, 1 two fp16 passes, 2 one pass in both "
+                         "directions; default: the library's")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal of the N > 1 path on a 1-GPU box: every rank uses cuda:0, gloo carries the barrier")
@@ -153,6 +156,8 @@ def main():
         w["B"] = args.batch
     host = make_batch(w, rank)
     eng = MatchEngine(local_rank)
+    if args.p2p_split is not None:
+        eng.set_option("p2p_split", args.p2p_split)
     dev = {n: torch.as_tensor(v).to(eng.device) for n, v in host.items()}
     N = w["nu"] * w["nv"]
     B, D, k = w["B"], w["D"], w["k"]
@@ -163,13 +168,15 @@ def main():
             return eng.match(dev, k=k)
         split = eng.p2p_split_active(N, N, k)
         if split:
-            kernel, dtype = "simnn2_f16_mfma", "f16"
+            kernel, dtype = ("simnn4_f16_mfma" if split == 2 else "simnn2_f16_mfma"), "f16"
             kd = -(-3 * k // 32) * 32
             flops_per_launch = 2.0 * N * N * kd * B
-            extra = {"launches_per_step": 2, "algorithmic_f64_flops_per_step": 2.0 * N * N * k * B,
-                     "note": "four maps = two passes of the two-key fp16 tile kernel (knn21+ind21, knn12+ind12) + exact float64 "
-                             "re-evaluation of the ambiguous rows; achieved/peak count the fp16 flops one pass executes (3 products "
-                             "per contraction index, padded to 32); algorithmic_f64_flops_per_step is SURVEY 8(d)'s 2 N^2 k"}
+            extra = {"launches_per_step": 1 if split == 2 else 2, "algorithmic_f64_flops_per_step": 2.0 * N * N * k * B,
+                     "note": ("four maps = ONE pass of the fp16 tile kernel reducing every tile in both directions (knn21+ind21 along "
+                              "the sources, knn12+ind12 along the targets, transposed through LDS)" if split == 2 else
+                              "four maps = two passes of the two-key fp16 tile kernel (knn21+ind21, knn12+ind12)") +
+                             " + exact float64 re-evaluation of the ambiguous rows; achieved/peak count the fp16 flops one pass executes "
+                             "(3 products per contraction index, padded to 32); algorithmic_f64_flops_per_step is SURVEY 8(d)'s 2 N^2 k"}
         else:
             kernel, dtype = "gred_f64", "f64"
             flops_per_launch = 2.0 * N * N * k * B                  # G = Phi2 C Phi1^T, SURVEY 8(d): 2 N^2 k per pair
@@ -298,10 +305,11 @@ def pmc_traffic_bytes(kernel, workload):
     """HBM bytes per launch of the dominant kernel, measured in separate rocprofv3 --pmc passes of this same command
     (PMC collection cannot run inside the timed region); summaries committed under profiles/."""
     import csv
-    dual = lambda name: name.rstrip('"').endswith(", 1>(simnn_params)") or name.rstrip('"').endswith(", 2>(simnn_params)")
+    dual = lambda name: any(name.rstrip('"').endswith(f", {d}>(simnn_params)") for d in (1, 2, 3))
     match = {"gred_f64": lambda n: "gred_kernel" in n,
              "simnn_f16_mfma": lambda n: "simnn_pipe_kernel" in n and not dual(n),
-             "simnn2_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 1>(simnn_params)")}.get(kernel, lambda n: kernel in n)
+             "simnn2_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 1>(simnn_params)"),
+             "simnn4_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 3>(simnn_params)")}.get(kernel, lambda n: kernel in n)
     for rnd in ("r02", "r01"):
         fname = f"{rnd}_{workload}_hbm_traffic_pmc.csv"
         path = os.path.join(REPO, "profiles", fname)

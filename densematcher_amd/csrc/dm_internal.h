@@ -37,7 +37,7 @@ struct dm_ctx {
     int opt_simnn_pipe = 1;      // 0: every similarity tile goes through the bounds-checked register-staged kernel
     int opt_knn_split = 1;       // 0: knn21 (ZoomOut, ICP, knn_query) on the float64 G kernel instead of the fp16 split
     int opt_solve_packed = 0;    // 1: the packed-storage solver for every system size it supports
-    int opt_p2p_split = 1;       // 0: dm_fm_to_p2p on the float64 G kernel instead of the fp16 split first pass
+    int opt_p2p_split = 2;       // four maps: 0 the float64 G kernel, 1 two passes of the two-key fp16 tile kernel, 2 one pass reducing in both directions
     int opt_simnn_persist = 1;   // 0: one workgroup per similarity tile instead of one persistent workgroup per CU
     int n_cu = 0;                // multiProcessorCount of the device
 };
@@ -137,6 +137,12 @@ struct dm_simnn_queue {               // rows queued for exact re-evaluation and
 };
 // Second reduction of the same fp16 products in one pass (the four maps of dm_fm_to_p2p, dm_knnsplit.hip):
 //   key A = score + bias[j] (-> nn21 / q of dm_simnn_core),  key B = score * scale[j], or the plain score when scale is null
+struct dm_simnn_cols {                // both directions in one pass: two more reductions, per SOURCE row over the targets
+    const float* biasT;               // (B, N2) key A' = score + biasT[i]; key B' = score
+    const float* tau_add;             // (B) max_i |biasT_i|
+    int32_t* nn_a; int32_t* nn_b;     // (B, N1) arg-max of key A' / key B'
+    dm_simnn_queue* q_a; dm_simnn_queue* q_b;
+};
 struct dm_simnn_dual {
     const float* bias;                // (B, N1)
     const float* scale;               // (B, N1), nullable
@@ -144,6 +150,7 @@ struct dm_simnn_dual {
     const float* tau_mul;             // (B) max_j scale_j (nullable): the scaled key relative to |t| max|s| tau_mul
     int32_t* nn_b;                    // (B, N2) arg-max of key B
     dm_simnn_queue* q_b;              // its queue of ambiguous rows
+    const dm_simnn_cols* cols = nullptr;
 };
 size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual = 0);
 bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D);

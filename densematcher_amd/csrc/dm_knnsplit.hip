@@ -375,7 +375,7 @@ size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K) {
     const size_t D = fs_depth(K);
     return dm_align_up((size_t)B * N2 * D * 2) + dm_align_up((size_t)B * N1 * D * 2) +
            dm_align_up((size_t)B * N1 * 4) + dm_align_up((size_t)B * N2 * 4) +
-           dm_simnn_ws_bytes(B, N2, N1, 1) + dm_simnn_ws_bytes(B, N1, N2, 1) + 16384;
+           dm_simnn_ws_bytes(B, N2, N1, 3) + dm_simnn_ws_bytes(B, N1, N2, 1) + 16384;
 }
 // a: AT, BT (K-major f64), n1, n2, mass1 and all four outputs; amaxS: per-256-column maxima of |BT| (colnorm_kernel);
 // zeroed: dm_fm_split_zero_bytes block, zeroed before dm_launch_phiT(Phi2) filled its first part
@@ -409,6 +409,30 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
               amaxS, nS, (const float*)nullptr, biasB, bmaxB, (unsigned int*)nullptr);
     const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
+    if (ctx->opt_p2p_split == 2) {
+        // one pass, both directions: every tile reduces along its source rows (knn21, ind21) and, transposed through LDS,
+        // along its target rows (knn12, ind12)
+        dm_simnn_queue qa, qb, qc, qd;
+        dm_simnn_cols cols{biasB, reinterpret_cast<const float*>(bmaxB), a.knn12, a.ind12, &qc, &qd};
+        dm_simnn_dual dual{biasA, a.mass1, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols};
+        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
+        if (rc) return rc;
+        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
+                         qa.flag_count, qa.flag_list, qa.flag_thr, a.knn21};
+        ks_exact_args e1 = e0;
+        e1.n1 = nullptr; e1.massS = a.mass1; e1.pb32 = qb.pb32; e1.flag_count = qb.flag_count; e1.flag_list = qb.flag_list;
+        e1.flag_thr = qb.flag_thr; e1.nn = a.ind21;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1>), dim3(1024, 2), dim3(256), lds, e0, e1);
+        ks_exact_args f0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qc.pb32, qc.nsub, qc.N2pad,
+                         qc.flag_count, qc.flag_list, qc.flag_thr, a.knn12};
+        ks_exact_args f1 = f0;
+        f1.n1 = nullptr; f1.massT = a.mass1; f1.pb32 = qd.pb32; f1.flag_count = qd.flag_count; f1.flag_list = qd.flag_list;
+        f1.flag_thr = qd.flag_thr; f1.nn = a.ind12;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 2>), dim3(1024, 2), dim3(256), lds, f0, f1);
+        const long long n = (long long)B * N1;
+        DM_LAUNCH(ctx, "fm_split_zero_mass", fs_zero_mass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a.mass1, n, a.ind12);
+        return DM_OK;
+    }
     // pass A: targets = Phi2 rows, candidates = emb1 rows
     {
         dm_simnn_queue qa, qb;

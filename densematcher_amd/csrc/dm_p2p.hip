@@ -796,7 +796,7 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
 
 // which path dm_fm_to_p2p takes for these sizes on this context (bench.py names the dominant kernel accordingly)
 extern "C" int dm_fm_to_p2p_uses_split(const dm_ctx* ctx, int N2, int N1, int k) {
-    return (ctx && dm_fm_split_ok(ctx, N2, N1, k)) ? 1 : 0;
+    return (ctx && dm_fm_split_ok(ctx, N2, N1, k)) ? ctx->opt_p2p_split : 0;       // 1: two passes, 2: one pass in both directions
 }
 
 // ---- generic exact nearest neighbour (pyFM/spectral/nn_utils.py:4-38, k = 1) ---------------------------------

@@ -48,6 +48,13 @@ struct simnn_params {
     //   key A = score + bias[j]  -> pb / pj / ps / pb32;   key B = score * scale[j] (DUAL 1) or score (DUAL 2) -> the *_2 arrays
     const float* bias; const float* scale;   // (B, N1) per source row
     float* pb_2; int32_t* pj_2; float* ps_2; float* pb32_2;
+    // both directions in one pass (DUAL 3): besides the two row reductions above, every SOURCE row j gets two reductions
+    // over the targets: key A' = score + biasT[i], key B' = score.  Partials per (tile row, target quarter of the tile):
+    // (B, 4 tilesT, N1pad); block maxima over 32 targets: (B, N2pad / 32, N1pad); |s_j|^2 and max_i |t_i|^2 for the bound
+    const float* biasT;                      // (B, N2) per target row
+    float* cb[2]; int32_t* cj[2]; float* cs[2]; float* cb32[2];
+    float* snorm2; unsigned int* tmax2;
+    int N1pad, nsubT;                        // nsubT = N2pad / 32
     int dbg;                                 // DM_EXPERIMENTS builds only (0 in the product): see simnn_pipe_kernel
 };
 
@@ -212,6 +219,91 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
     }
 }
 
+// Column direction of a tile (DUAL 3, interior tiles): for every source row of the tile the top-2 over the tile's target
+// rows, for two keys (score + biasT[i], score).  A lane owns target columns of the accumulator tiles, so each 32 x 32 tile
+// goes through a wave-private LDS buffer (36-float row stride: 16-byte writes stay aligned, the transposed 4-byte reads are
+// conflict-free) and comes back with the lane owning a SOURCE row and 16 targets n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+// in registers -- the layout of the row direction with the roles swapped, reduced with the same key arithmetic.  Partials
+// are written per wave (target quarter of the tile): no cross-wave exchange.
+//   tb: this wave's 32 x 36 float buffer; bT: the tile's 256 target biases in LDS
+__device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
+                                                bool do_tn, bool do_sn, int b, int i0, int j0, int tt_, float* tb,
+                                                const float* bT, int lane, int wsrc, int wtgt) {
+    const int hi = lane >> 5, l31 = lane & 31;
+    if (do_sn) {                                          // |s_j|^2 of the tile's source rows (tiles of target tile row 0)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = nrm_s[x] + xhalf(nrm_s[x], hi != 0);
+            if (lane < 32) p.snorm2[(long long)b * p.N1 + j0 + wsrc * 128 + x * 32 + lane] = v;
+        }
+    }
+    if (do_tn) {                                          // max_i |t_i|^2 (tiles of source tile column 0)
+        float m = fmaxf(nrm_t[0] + xhalf(nrm_t[0], hi != 0), nrm_t[1] + xhalf(nrm_t[1], hi != 0));
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) atomicMax(p.tmax2 + b, __float_as_uint(m));
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int gj = j0 + wsrc * 128 + st * 32 + l31;  // this lane's source row
+        float Bk[2] = {DM_KEY_NONE, DM_KEY_NONE}, Sk[2] = {DM_KEY_NONE, DM_KEY_NONE};
+        int Bt[2] = {0, 0};
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            // transpose: lane (n, hi) holds sources m = 8 q + 4 hi + e of target n  ->  tb[n][m]
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(tb + l31 * 36 + 8 * q + 4 * hi) =
+                    f32x4{acc[st][tt][4 * q], acc[st][tt][4 * q + 1], acc[st][tt][4 * q + 2], acc[st][tt][4 * q + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float tr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[r] = tb[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + l31];
+            f32x4 w4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const f32x4*>(bT + wtgt * 64 + tt * 32 + 4 * hi + 8 * q);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();              // (the buffer is rewritten by the next tile: reads first)
+#pragma unroll
+            for (int kind = 0; kind < 2; ++kind) {
+                float k[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) k[r] = k_key(kind == 0 ? tr[r] + w4[r >> 2][r & 3] : tr[r], 15 - r);
+                float bk = k_max(k[0], k[1]), sk = k_min(k[0], k[1]);
+#pragma unroll
+                for (int r = 2; r < 16; r += 2) {
+                    const float m = k_med3(bk, k[r], k[r + 1]);
+                    bk = k_max3(bk, k[r], k[r + 1]);
+                    sk = k_max(sk, m);
+                }
+                const float m32 = xhalf_max(bk);          // maximum over this block of 32 targets
+                if (lane < 32)
+                    p.cb32[kind][((long long)b * p.nsubT + (i0 >> 5) + wtgt * 2 + tt) * p.N1pad + gj] = m32;
+                Sk[kind] = k_max3(Sk[kind], sk, k_min(Bk[kind], bk));
+                Bt[kind] = (bk > Bk[kind]) ? tt : Bt[kind];
+                Bk[kind] = k_max(Bk[kind], bk);
+            }
+        }
+#pragma unroll
+        for (int kind = 0; kind < 2; ++kind) {
+            const int kb = __float_as_int(Bk[kind]);
+            const int r_ = 15 - (kb & 15);
+            float bv = __int_as_float(kb & ~15), sv = __int_as_float(__float_as_int(Sk[kind]) & ~15);
+            int bi = i0 + wtgt * 64 + Bt[kind] * 32 + (r_ & 3) + 8 * (r_ >> 2) + 4 * hi;
+            const float ob = xhalf(bv, hi != 0);
+            const int oi = xhalf(bi, hi != 0);
+            const float os = xhalf(sv, hi != 0);
+            top2_merge(bv, bi, sv, ob, oi, os);
+            if (lane < 32) {
+                const long long o = ((long long)b * (p.tilesT * 4) + tt_ * 4 + wtgt) * p.N1pad + gj;
+                p.cb[kind][o] = bv; p.cj[kind][o] = bi; p.cs[kind][o] = sv;
+            }
+        }
+    }
+}
+
 // Bounds-checked kernel for edge tiles and contraction depths that are not a multiple of 32: one workgroup per
 // tile, operands staged through registers (two 64-deep LDS buffers), zero fill outside the matrices.
 // Tile = 256 target rows x 256 source rows per 512-thread workgroup (8 waves = 2 source halves x 4 target quarters,
@@ -354,8 +446,10 @@ constexpr int SIMNN_PRODUCT_WT = 4;
 #define DM_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | ((((n) >> 4) & 3) << 14))    /* vmcnt(n) lgkmcnt(0) */
 static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
     const int TT = 64 * WT, NBUF = WT == 4 ? 4 : 3;
-    // ring | reduction scratch (6 KiB per key set) | DUAL: two slots of (256 bias + 256 scale) floats
-    return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + (dual ? 2 : 1) * 3 * 2 * ST * 4 + (dual ? 2 * 512 * 4 : 0);
+    // ring | reduction scratch (6 KiB per key set) | DUAL: two slots of (256 bias + 256 scale [+ 256 target bias]) floats
+    // | DUAL 3: the eighth wave's transpose buffer (the other seven use the ring slot that is free during an epilogue)
+    return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + (dual ? 2 : 1) * 3 * 2 * ST * 4 +
+           (dual == 3 ? 2 * 768 * 4 + 32 * 36 * 4 : (dual ? 2 * 512 * 4 : 0));
 }
 
 __device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int& b, int& tt_, int& ts_) {
@@ -382,7 +476,9 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | scratch
     float* scratch = reinterpret_cast<float*>(smem + NBUF * PSTAGE);
-    float* bias_lds = scratch + 12 * TT;         // DUAL: [2 slots][256 bias | 256 scale], filled by LDS-DMA one tile ahead
+    constexpr int BSLOT = DUAL == 3 ? 768 : 512;  // floats per bias slot
+    float* bias_lds = scratch + 12 * TT;         // DUAL: [2 slots][256 bias | 256 scale | 256 target bias], filled by LDS-DMA one tile ahead
+    float* tb_extra = bias_lds + 2 * BSLOT;      // DUAL 3: transpose buffer of wave 7
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -414,12 +510,16 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         d_kp = STAG == 0 ? 0 : (STAG == 1 ? (ts_ + tt_) % ns : ((ts_ + tt_) * ns / p.tilesS) % ns);                    \
         d_s = 0;                                                                                                       \
         if (DUAL && wave == 0) {      /* the tile's per-source terms: one 1 KiB piece each, landed long before its epilogue */ \
-            float* dstB = bias_lds + (d_tile & 1) * 512;                                                               \
+            float* dstB = bias_lds + (d_tile & 1) * BSLOT;                                                             \
             const char* gb = reinterpret_cast<const char*>(p.bias + (long long)b_ * p.N1 + ts_ * ST) + lane * 16;      \
             __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)dstB, 16, 0, 0);                                      \
-            if (DUAL == 1) {                                                                                           \
+            if (DUAL == 1 || DUAL == 3) {                                                                              \
                 const char* gs = reinterpret_cast<const char*>(p.scale + (long long)b_ * p.N1 + ts_ * ST) + lane * 16; \
                 __builtin_amdgcn_global_load_lds((gptr_t)gs, (lptr_t)(dstB + 256), 16, 0, 0);                          \
+            }                                                                                                          \
+            if (DUAL == 3) {                                                                                           \
+                const char* gt2 = reinterpret_cast<const char*>(p.biasT + (long long)b_ * p.N2 + tt_ * TT) + lane * 16; \
+                __builtin_amdgcn_global_load_lds((gptr_t)gt2, (lptr_t)(dstB + 512), 16, 0, 0);                         \
             }                                                                                                          \
         }                                                                                                              \
     }
@@ -562,8 +662,19 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
             if (sacc == 1.2345f) p.pb[0] = sacc;
             continue;
         }
-        simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0, DUAL>(
-            p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt, bias_lds + (n & 1) * 512);
+        simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0, (DUAL == 3 ? 1 : DUAL)>(
+            p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt, bias_lds + (n & 1) * BSLOT);
+        if (DUAL == 3) {
+            // the ring slot of the stage computed last takes no LDS-DMA before the next tile's first stage: seven waves
+            // transpose through it, the eighth through its own buffer
+            const int free_slot = (r_slot + NBUF - 1) % NBUF;
+            float* tb = wave < 7 ? reinterpret_cast<float*>(smem + free_slot * PSTAGE) + wave * (32 * 36) : tb_extra;
+            simnn_tail_cols(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, tt_, tb, bias_lds + (n & 1) * BSLOT + 512, lane, wsrc, wtgt);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave is done with its buffer ...
+            __builtin_amdgcn_s_barrier();                // ... and no wave starts the next tile's DMA into the slot before all are
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0070);                          // nothing of this workgroup may still be in flight
 #undef SIMNN_TILE_LOOP
@@ -706,7 +817,12 @@ size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual) {
     const size_t N2pad = pad_to(N2, ST), tilesS = dm_cdiv(N1, ST);
     const size_t np = (size_t)B * tilesS * N2pad, np32 = (size_t)B * tilesS * (ST / 32) * N2pad;
     const size_t keyset = 3 * dm_align_up(np * 4) + dm_align_up(np32 * 4) + dm_align_up((size_t)B * N2 * 4) * 2 + 512;
-    return (dual ? 2 : 1) * keyset + dm_align_up((size_t)B * N2 * 4) + dm_align_up((size_t)B * 4) + 8192;
+    size_t total = (dual ? 2 : 1) * keyset + dm_align_up((size_t)B * N2 * 4) + 2 * dm_align_up((size_t)B * 4) + 8192;
+    if (dual == 3) {                                      // the two column-direction key sets
+        const size_t N1pad = pad_to(N1, ST), cp = (size_t)B * (N2pad / 64) * N1pad, cp32 = (size_t)B * (N2pad / 32) * N1pad;
+        total += 2 * (3 * dm_align_up(cp * 4) + dm_align_up(cp32 * 4) + 2 * dm_align_up((size_t)B * N1 * 4)) + dm_align_up((size_t)B * N1 * 4) + 4096;
+    }
+    return total;
 }
 
 // can the two-key pass run on these sizes (interior 256 x 256 tiles, contraction a multiple of a stage and deep enough
@@ -741,14 +857,18 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     p.tnorm2 = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* flag_list = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* flag_thr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    // per-pair source norm maxima and the queue counters: one block, one memset
-    const size_t ctl_bytes = dm_align_up((size_t)B * 4) + 512;
+    // per-pair norm maxima and the queue counters: one block, one memset
+    const size_t ctl_bytes = 2 * dm_align_up((size_t)B * 4) + 1024;
     char* ctl = (char*)dm_ws_take(ctx, ctl_bytes);
     if (!p.pb || !p.pj || !p.ps || !p.pb32 || !p.tnorm2 || !flag_list || !flag_thr || !ctl)
         return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
     p.smax2 = (unsigned int*)ctl;
-    int32_t* flag_count = (int32_t*)(ctl + dm_align_up((size_t)B * 4));
+    p.tmax2 = (unsigned int*)(ctl + dm_align_up((size_t)B * 4));
+    int32_t* flag_count = (int32_t*)(ctl + 2 * dm_align_up((size_t)B * 4));
     int32_t* flag_list2 = nullptr; float* flag_thr2 = nullptr; int32_t* flag_count2 = nullptr;
+    const dm_simnn_cols* cols = dual ? dual->cols : nullptr;
+    int32_t* cflag_list[2] = {nullptr, nullptr}; float* cflag_thr[2] = {nullptr, nullptr};
+    int32_t* cflag_count[2] = {flag_count + 128, flag_count + 192};
     if (dual) {
         if (!dm_simnn_dual_ok(ctx, N2, N1, D) || !dual->bias || !dual->nn_b || !dual->q_b)
             return dm_fail(ctx, DM_EINVAL, "simnn: the two-key pass needs interior tiles, D %% 32 == 0, D >= 160");
@@ -763,6 +883,25 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         if (!p.pb_2 || !p.pj_2 || !p.ps_2 || !p.pb32_2 || !flag_list2 || !flag_thr2)
             return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
     }
+    if (cols) {
+        if (!dual->scale || !cols->biasT || !cols->nn_a || !cols->nn_b || !cols->q_a || !cols->q_b)
+            return dm_fail(ctx, DM_EINVAL, "simnn: both-directions pass: missing operand");
+        p.biasT = cols->biasT;
+        p.N1pad = pad_to(N1, ST); p.nsubT = p.N2pad / 32;
+        const size_t cp = (size_t)B * (p.N2pad / 64) * p.N1pad, cp32 = (size_t)B * p.nsubT * p.N1pad;
+        for (int kd = 0; kd < 2; ++kd) {
+            p.cb[kd] = (float*)dm_ws_take(ctx, cp * 4);
+            p.cj[kd] = (int32_t*)dm_ws_take(ctx, cp * 4);
+            p.cs[kd] = (float*)dm_ws_take(ctx, cp * 4);
+            p.cb32[kd] = (float*)dm_ws_take(ctx, cp32 * 4);
+            cflag_list[kd] = (int32_t*)dm_ws_take(ctx, (size_t)B * N1 * 4);
+            cflag_thr[kd] = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
+            if (!p.cb[kd] || !p.cj[kd] || !p.cs[kd] || !p.cb32[kd] || !cflag_list[kd] || !cflag_thr[kd])
+                return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
+        }
+        p.snorm2 = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
+        if (!p.snorm2) return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
+    }
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, ctx->stream));
     const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16) + 3 * 2 * ST * 4;
@@ -774,7 +913,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         const int TT = 64 * WT;
         p.tilesT = p.N2pad / TT;
         p.total = B * p.tilesT * p.tilesS;
-        const size_t lds_pipe = simnn_pipe_lds(WT, dual ? 1 : 0);
+        const size_t lds_pipe = simnn_pipe_lds(WT, cols ? 3 : (dual ? 1 : 0));
         // workgroups that fit a CU at once walk the tiles (opt_simnn_persist: 0 = one workgroup per tile, 1 = as many
         // workgroups as are resident when there are more tiles than that, n > 1 = n workgroups (tests))
         const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
@@ -788,7 +927,9 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<XV_, WT_, DUAL_>), dim3(grid), dim3(128 * WT_), lds_pipe, p);     \
         }
-        if (dual) {
+        if (cols) {
+            SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 3, "simnn4_f16_mfma")
+        } else if (dual) {
             if (dual->scale) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 1, "simnn2_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 2, "simnn2_f16_mfma")
         } else {
@@ -832,6 +973,18 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         dm_simnn_queue* q2 = dual->q_b;
         q2->pb32 = p.pb32_2; q2->nsub = p.nsub; q2->N2pad = p.N2pad;
         q2->flag_count = flag_count2; q2->flag_list = flag_list2; q2->flag_thr = flag_thr2;
+    }
+    if (cols) {
+        // the column direction: "targets" are the source rows, partials per (tile row, target quarter), bound from |s_j| max |t_i|
+        simnn_merge_set c0{p.cb[0], p.cj[0], p.cs[0], cols->tau_add, nullptr, cols->nn_a, cflag_count[0], cflag_list[0], cflag_thr[0]};
+        simnn_merge_set c1{p.cb[1], p.cj[1], p.cs[1], nullptr, nullptr, cols->nn_b, cflag_count[1], cflag_list[1], cflag_thr[1]};
+        DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N1, 256), B, 2), dim3(256), 0, c0, c1, p.tilesT * 4, N1, p.N1pad,
+                  p.snorm2, p.tmax2, tau_scale, (float*)nullptr, (float*)nullptr, force_flag);
+        dm_simnn_queue* qs[2] = {cols->q_a, cols->q_b};
+        for (int kd = 0; kd < 2; ++kd) {
+            qs[kd]->pb32 = p.cb32[kd]; qs[kd]->nsub = p.nsubT; qs[kd]->N2pad = p.N1pad;
+            qs[kd]->flag_count = cflag_count[kd]; qs[kd]->flag_list = cflag_list[kd]; qs[kd]->flag_thr = cflag_thr[kd];
+        }
     }
     return DM_OK;
 }

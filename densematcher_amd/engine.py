@@ -70,7 +70,7 @@ class MatchEngine:
     def synchronize(self):
         self.stream.synchronize()
 
-    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 1, "solve_packed": 0}
+    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0}
 
     def set_option(self, name, value):
         """Choose between equivalent code paths of the library (include/densematch.h: dm_set_option); every setting
@@ -88,8 +88,9 @@ class MatchEngine:
         return max(96, -(-(8 + 3 * k) // 32) * 32)
 
     def p2p_split_active(self, N2, N1, k):
-        """True when fm_to_p2p takes the fp16-split first passes (bench.py names its dominant kernel accordingly)."""
-        return bool(self.lib.dm_fm_to_p2p_uses_split(self.ctx, int(N2), int(N1), int(k)))
+        """0 when fm_to_p2p runs the float64 kernel for these sizes, 1: two passes of the two-key fp16 tile kernel, 2: one
+        pass in both directions (bench.py names its dominant kernel accordingly)."""
+        return int(self.lib.dm_fm_to_p2p_uses_split(self.ctx, int(N2), int(N1), int(k)))
 
     def workspace_bytes(self):
         return int(self.lib.dm_workspace_bytes(self.ctx))
