@@ -21,13 +21,16 @@ typedef __attribute__((address_space(1))) const f32x4 dm_gf32x4;      // global 
 // TN form: a functor may define raw_t + load4raw / cvt / zero (same idea); otherwise load4 delivers doubles directly.
 template <class T, class = void> struct dm_tn_raw {
     struct type { double v[4]; };
-    static __device__ __forceinline__ void load(const T& op, int b, int n, int col0, type& r) { op.load4(b, n, col0, r.v); }
+    static __device__ __forceinline__ int pre(const T&, int, int) { return 0; }
+    static __device__ __forceinline__ void load(const T& op, int b, int n, int col0, int, type& r) { op.load4(b, n, col0, r.v); }
     static __device__ __forceinline__ void zero(type& r) { r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.0; }
     static __device__ __forceinline__ void cvt(const type& r, double (&v)[4]) { v[0] = r.v[0]; v[1] = r.v[1]; v[2] = r.v[2]; v[3] = r.v[3]; }
 };
 template <class T> struct dm_tn_raw<T, std::void_t<typename T::raw_t>> {
     typedef typename T::raw_t type;
-    static __device__ __forceinline__ void load(const T& op, int b, int n, int col0, type& r) { op.load4raw(b, n, col0, r); }
+    // pre(): a value the row's load depends on (a gather index), fetched one stage earlier than the row itself
+    static __device__ __forceinline__ int pre(const T& op, int b, int n) { return op.pre(b, n); }
+    static __device__ __forceinline__ void load(const T& op, int b, int n, int col0, int pv, type& r) { op.load4raw(b, n, col0, pv, r); }
     static __device__ __forceinline__ void zero(type& r) { T::zero(r); }
     static __device__ __forceinline__ void cvt(const type& r, double (&v)[4]) { T::cvt(r, v); }
 };
@@ -134,54 +137,85 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(OpX opx, OpY opy, Out out, in
         for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     const int ns = (kend - kbeg + TN_BK - 1) / TN_BK;
-    typename dm_tn_raw<OpX>::type rx;
-    typename dm_tn_raw<OpY>::type ry;
+    // Operands are fetched TWO stages ahead into two register sets (a stage is only 16 MFMAs per wave, ~0.4 us: shorter
+    // than a gathered row's round trip), gather indices one stage before their rows.
+    typename dm_tn_raw<OpX>::type rxa, rxb;
+    typename dm_tn_raw<OpY>::type rya, ryb;
     // (macros, not lambdas: by-reference lambda captures of the staging arrays end up in scratch)
-#define TN_FETCH(s_)                                                            \
+    int px = 0, py = 0;
+#define TN_PRE(s_)                                                              \
+    {                                                                           \
+        const int n_ = kbeg + (s_) * TN_BK + lrow;                              \
+        if (n_ < kend) { px = dm_tn_raw<OpX>::pre(opx, b, n_); py = dm_tn_raw<OpY>::pre(opy, b, n_); } \
+    }
+#define TN_FETCH(s_, rx_, ry_)                                                  \
     {                                                                           \
         const int n_ = kbeg + (s_) * TN_BK + lrow;                              \
         if (n_ < kend) {                                                        \
-            dm_tn_raw<OpX>::load(opx, b, n_, m0 + lc, rx);                      \
-            dm_tn_raw<OpY>::load(opy, b, n_, c0 + lc, ry);                      \
+            dm_tn_raw<OpX>::load(opx, b, n_, m0 + lc, px, rx_);                 \
+            dm_tn_raw<OpY>::load(opy, b, n_, c0 + lc, py, ry_);                 \
         } else {                                                                \
-            dm_tn_raw<OpX>::zero(rx);                                           \
-            dm_tn_raw<OpY>::zero(ry);                                           \
+            dm_tn_raw<OpX>::zero(rx_);                                          \
+            dm_tn_raw<OpY>::zero(ry_);                                          \
         }                                                                       \
     }
-#define TN_STASH(buf_)                                                          \
+#define TN_STASH(buf_, rx_, ry_)                                                \
     {                                                                           \
         double vx_[4], vy_[4];                                                  \
-        dm_tn_raw<OpX>::cvt(rx, vx_);                                           \
-        dm_tn_raw<OpY>::cvt(ry, vy_);                                           \
+        dm_tn_raw<OpX>::cvt(rx_, vx_);                                          \
+        dm_tn_raw<OpY>::cvt(ry_, vy_);                                          \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                         \
             Xs[buf_][lrow * TN_LD + lc + e] = vx_[e];                           \
             Ys[buf_][lrow * TN_LD + lc + e] = vy_[e];                           \
         }                                                                       \
     }
+#define TN_COMPUTE(buf_)                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < TN_BK / 4; ++ks) {                  \
+        const int kk = ks * 4 + (lane >> 4);                                    \
+        double a[2], bb[2];                                                     \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) a[mt] = Xs[buf_][kk * TN_LD + wm * 32 + mt * 16 + (lane & 15)];  \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) bb[nt] = Ys[buf_][kk * TN_LD + wn * 32 + nt * 16 + (lane & 15)]; \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)                        \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                    \
+                if (vm[mt] && vn[nt]) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);  \
+    }
+    // 16 x 16 blocks that lie completely outside the M x N result are skipped (wave-uniform): the result is rarely a
+    // multiple of the 64 x 64 tile (ZoomOut sweeps k = 51 .. 200) and the f64 matrix pipe is what bounds this kernel
+    const bool vm[2] = {m0 + wm * 32 < M, m0 + wm * 32 + 16 < M};
+    const bool vn[2] = {c0 + wn * 32 < N, c0 + wn * 32 + 16 < N};
+    // stage s lives in LDS buffer s & 1 and was staged in register set s & 1 (a: even, b: odd)
     if (ns > 0) {
-        TN_FETCH(0)
-        TN_STASH(0)
+        TN_PRE(0)
+        TN_FETCH(0, rxa, rya)
+        if (ns > 1) {
+            TN_PRE(1)
+            TN_FETCH(1, rxb, ryb)
+            if (ns > 2) TN_PRE(2)
+        }
+        TN_STASH(0, rxa, rya)
     }
     __syncthreads();
-    for (int s = 0; s < ns; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < ns) TN_FETCH(s + 1)
-#pragma unroll
-        for (int ks = 0; ks < TN_BK / 4; ++ks) {
-            const int kk = ks * 4 + (lane >> 4);
-            double a[2], bb[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[mt] = Xs[buf][kk * TN_LD + wm * 32 + mt * 16 + (lane & 15)];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bb[nt] = Ys[buf][kk * TN_LD + wn * 32 + nt * 16 + (lane & 15)];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
+    for (int s = 0; s < ns; s += 2) {
+        // even stage: rows of s + 2 into set a (its stage s is in LDS), compute, stash s + 1 from set b
+        if (s + 2 < ns) {
+            TN_FETCH(s + 2, rxa, rya)
+            if (s + 3 < ns) TN_PRE(s + 3)
         }
-        if (s + 1 < ns) TN_STASH(buf ^ 1)
+        TN_COMPUTE(0)
+        if (s + 1 < ns) TN_STASH(1, rxb, ryb)
+        __syncthreads();
+        if (s + 1 >= ns) break;
+        // odd stage
+        if (s + 3 < ns) {
+            TN_FETCH(s + 3, rxb, ryb)
+            if (s + 4 < ns) TN_PRE(s + 4)
+        }
+        TN_COMPUTE(1)
+        if (s + 2 < ns) TN_STASH(0, rxa, rya)
         __syncthreads();
     }
+#undef TN_COMPUTE
+#undef TN_PRE
 #undef TN_FETCH
 #undef TN_STASH
 #pragma unroll
@@ -204,7 +238,8 @@ struct RowsF32Scaled {
     typedef dm_f32x4_scaled raw_t;
     const float* p; long long stride_b; int ld; int ncols;
     const float* scale; long long scale_stride_b;   // nullable
-    __device__ __forceinline__ void load4raw(int b, int n, int col0, raw_t& r) const {
+    __device__ __forceinline__ int pre(int, int) const { return 0; }
+    __device__ __forceinline__ void load4raw(int b, int n, int col0, int, raw_t& r) const {
         const float* row = p + b * stride_b + (long long)n * ld;
         r.s = scale ? scale[b * scale_stride_b + n] : 1.0f;
         if (col0 + 3 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {
@@ -228,9 +263,9 @@ struct RowsF32GatherScaled {
     const float* p; long long stride_b; int ld; int ncols;
     const int32_t* idx; long long idx_stride_b; int nrows_src;
     const float* scale; long long scale_stride_b;
-    __device__ __forceinline__ void load4raw(int b, int n, int col0, raw_t& r) const {
-        int ri = idx[b * idx_stride_b + n];
-        ri = min(max(ri, 0), nrows_src - 1);
+    __device__ __forceinline__ int pre(int b, int n) const { return idx[b * idx_stride_b + n]; }
+    __device__ __forceinline__ void load4raw(int b, int n, int col0, int pv, raw_t& r) const {
+        const int ri = min(max(pv, 0), nrows_src - 1);
         const float* row = p + b * stride_b + (long long)ri * ld;
         r.s = scale[b * scale_stride_b + n];
         if (col0 + 3 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {

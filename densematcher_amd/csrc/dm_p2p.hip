@@ -238,8 +238,10 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
                     for (int c_ = 0; c_ < 4; ++c_) bv[c_] = Bs[(c_ * 16 + (lane & 15)) * EB_LD + kk];
 #pragma unroll
                     for (int a_ = 0; a_ < RT; ++a_)
+                        if (rg * RA + wave * 16 * RT + a_ * 16 < kr) {     // (wave-uniform: row blocks beyond kr are skipped)
 #pragma unroll
-                        for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = mfma_f64_16x16x4(av[a_], bv[c_], acc[a_][c_]);
+                            for (int c_ = 0; c_ < 4; ++c_) acc[a_][c_] = mfma_f64_16x16x4(av[a_], bv[c_], acc[a_][c_]);
+                        }
                 }
             }
             // ---- row-group epilogue: optional K-major store, squares into the column sums (fixed order), maxima

@@ -704,8 +704,20 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_set s0, si
     if (i >= N2) return;
     float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
     int bj = DM_IDX_NONE;
-#pragma unroll 4
-    for (int ts = 0; ts < tilesS; ++ts) {
+    // (loads of eight partials ahead of their merges: the loop is a chain of L2 round trips otherwise)
+    int ts = 0;
+    for (; ts + 8 <= tilesS; ts += 8) {
+        float vb[8], vs[8];
+        int vj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long o = ((long long)b * tilesS + ts + u) * N2pad + i;
+            vb[u] = s.pb[o]; vj[u] = s.pj[o]; vs[u] = s.ps[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) top2_merge(bv, bj, sv, vb[u], vj[u], vs[u]);
+    }
+    for (; ts < tilesS; ++ts) {
         const long long o = ((long long)b * tilesS + ts) * N2pad + i;
         top2_merge(bv, bj, sv, s.pb[o], s.pj[o], s.ps[o]);
     }
