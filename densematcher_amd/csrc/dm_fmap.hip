@@ -476,6 +476,16 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
     const double* l2 = lam2 + (long long)b * k2;
 
     DBG_T0()
+    // ---- image load, first thing: the gram kernel left P[1:,1:] in exactly the LDS layout (T_IK[kk][ii] = M[I*16+ii][K*16+kk]),
+    // so the copy is nblk * 2 contiguous 1 KiB pieces that go global -> LDS by LDS-DMA (no registers); they are in flight while
+    // the eigenvalue scale and the diagonal penalties are computed and are awaited in front of the first use
+    {
+        typedef __attribute__((address_space(1))) const void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const char* src = reinterpret_cast<const char*>(Timg + (long long)b * nblk * 256) + lane * 16;
+        for (int pc = wave; pc < nblk * 2; pc += 4)                   // piece = 1 KiB = half a block
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (long long)pc * 1024), (lptr_t)(T + pc * 128), 16, 0, 0);
+    }
     double mx = -DM_INF_F64;
     for (int q = t; q < k1; q += 256) mx = fmax(mx, l1[q]);
     for (int q = t; q < k2; q += 256) mx = fmax(mx, l2[q]);
@@ -501,30 +511,12 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
     __syncthreads();
     DBG_ACC(6)
 
-    // ---- load: the gram kernel left P[1:,1:] in exactly the LDS image layout (T_IK[kk][ii] = M[I*16+ii][K*16+kk]),
-    // so the copy is a contiguous, fully coalesced 16-byte stream; then the row's diagonal penalty is added and the
-    // padding rows/columns (>= n) are made identity.
-    {
-        const f64x2* src = reinterpret_cast<const f64x2*>(Timg + (long long)b * nblk * 256);
-        f64x2* dst = reinterpret_cast<f64x2*>(T);
-        const int nvec = nblk * 128;
-        for (int q0 = 0; q0 < nvec; q0 += 256 * 8) {
-            f64x2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int q = q0 + u * 256 + t;
-                v[u] = (q < nvec) ? src[q] : f64x2{0.0, 0.0};
-            }
-            DBG_ACC(8)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int q = q0 + u * 256 + t;
-                if (q < nvec) dst[q] = v[u];
-            }
-        }
-        for (int c = t; c < NB * 16; c += 256)
-            rhs[c] = (c < n) ? Q[(long long)i * k1 + (c + 1)] - P[(long long)(c + 1) * k1] * ci0 : 0.0;
-    }
+    // ---- right-hand side; then the image must have landed: the row's diagonal penalty is added and the padding rows /
+    // columns (>= n) are made identity
+    for (int c = t; c < NB * 16; c += 256)
+        rhs[c] = (c < n) ? Q[(long long)i * k1 + (c + 1)] - P[(long long)(c + 1) * k1] * ci0 : 0.0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's LDS-DMA pieces
+    DBG_ACC(8)
     __syncthreads();
     for (int c = t; c < NB * 16; c += 256) {
         const int I = c >> 4;
