@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] similarity-kernel block of the default workload")
     ap.add_argument("--p2p-split", type=int, default=None,
                     help="code path of the four maps (dm_set_option p2p_split): 0 float64 kernel, 1 two fp16 passes, 2 one pass in both "
-                         "directions; default: the library's")
+                         "directions (3: its 4-wave shape); default: the library's")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal of the N > 1 path on a 1-GPU box: every rank uses cuda:0, gloo carries the barrier")
@@ -168,12 +168,12 @@ def main():
             return eng.match(dev, k=k)
         split = eng.p2p_split_active(N, N, k)
         if split:
-            kernel, dtype = ("simnn4_f16_mfma" if split == 2 else "simnn2_f16_mfma"), "f16"
+            kernel, dtype = ("simnn4_f16_mfma" if split >= 2 else "simnn2_f16_mfma"), "f16"
             kd = -(-3 * k // 32) * 32
             flops_per_launch = 2.0 * N * N * kd * B
-            extra = {"launches_per_step": 1 if split == 2 else 2, "algorithmic_f64_flops_per_step": 2.0 * N * N * k * B,
+            extra = {"launches_per_step": 1 if split >= 2 else 2, "algorithmic_f64_flops_per_step": 2.0 * N * N * k * B,
                      "note": ("four maps = ONE pass of the fp16 tile kernel reducing every tile in both directions (knn21+ind21 along "
-                              "the sources, knn12+ind12 along the targets, transposed through LDS)" if split == 2 else
+                              "the sources, knn12+ind12 along the targets, transposed through LDS)" if split >= 2 else
                               "four maps = two passes of the two-key fp16 tile kernel (knn21+ind21, knn12+ind12)") +
                              " + exact float64 re-evaluation of the ambiguous rows; achieved/peak count the fp16 flops one pass executes "
                              "(3 products per contraction index, padded to 32); algorithmic_f64_flops_per_step is SURVEY 8(d)'s 2 N^2 k"}
@@ -305,7 +305,7 @@ def pmc_traffic_bytes(kernel, workload):
     """HBM bytes per launch of the dominant kernel, measured in separate rocprofv3 --pmc passes of this same command
     (PMC collection cannot run inside the timed region); summaries committed under profiles/."""
     import csv
-    dual = lambda name: any(name.rstrip('"').endswith(f", {d}>(simnn_params)") for d in (1, 2, 3))
+    dual = lambda name: any(name.rstrip('"').endswith(f", {d}>(simnn_params)") for d in (1, 2, 3))   # (4- and 8-wave shapes alike)
     match = {"gred_f64": lambda n: "gred_kernel" in n,
              "simnn_f16_mfma": lambda n: "simnn_pipe_kernel" in n and not dual(n),
              "simnn2_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 1>(simnn_params)"),

@@ -409,7 +409,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
               amaxS, nS, (const float*)nullptr, biasB, bmaxB, (unsigned int*)nullptr);
     const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
-    if (ctx->opt_p2p_split == 2) {
+    if (ctx->opt_p2p_split >= 2) {
         // one pass, both directions: every tile reduces along its source rows (knn21, ind21) and, transposed through LDS,
         // along its target rows (knn12, ind12)
         dm_simnn_queue qa, qb, qc, qd;

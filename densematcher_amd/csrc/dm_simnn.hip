@@ -226,6 +226,7 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
 // in registers -- the layout of the row direction with the roles swapped, reduced with the same key arithmetic.  Partials
 // are written per wave (target quarter of the tile): no cross-wave exchange.
 //   tb: this wave's 32 x 36 float buffer; bT: the tile's 256 target biases in LDS
+template <int WT>
 __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
                                                 bool do_tn, bool do_sn, int b, int i0, int j0, int tt_, float* tb,
                                                 const float* bT, int lane, int wsrc, int wtgt) {
@@ -297,7 +298,7 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
             const float os = xhalf(sv, hi != 0);
             top2_merge(bv, bi, sv, ob, oi, os);
             if (lane < 32) {
-                const long long o = ((long long)b * (p.tilesT * 4) + tt_ * 4 + wtgt) * p.N1pad + gj;
+                const long long o = ((long long)b * (p.tilesT * WT) + tt_ * WT + wtgt) * p.N1pad + gj;
                 p.cb[kind][o] = bv; p.cj[kind][o] = bi; p.cs[kind][o] = sv;
             }
         }
@@ -448,6 +449,7 @@ static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
     const int TT = 64 * WT, NBUF = WT == 4 ? 4 : 3;
     // ring | reduction scratch (6 KiB per key set) | DUAL: two slots of (256 bias + 256 scale [+ 256 target bias]) floats
     // | DUAL 3: the eighth wave's transpose buffer (the other seven use the ring slot that is free during an epilogue)
+    if (dual == 3 && WT == 2) return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + 2 * (512 + TT) * 4;
     return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + (dual ? 2 : 1) * 3 * 2 * ST * 4 +
            (dual == 3 ? 2 * 768 * 4 + 32 * 36 * 4 : (dual ? 2 * 512 * 4 : 0));
 }
@@ -462,7 +464,7 @@ __device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int&
 
 template <int XV, int WT, int DUAL = 0>
 __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p) {
-    static_assert(DUAL == 0 || WT == 4, "the two-key epilogue needs one thread per row and kind");
+    static_assert(DUAL == 0 || WT == 4 || DUAL == 3, "the two-key epilogue needs one thread per row and kind");
     constexpr int TT = 64 * WT;                  // target rows per tile
     constexpr int NW = 2 * WT;                   // waves
     constexpr int NBUF = WT == 4 ? 4 : 3;        // ring depth
@@ -475,10 +477,14 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     constexpr bool PINR = (XV & 64) != 0;
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | scratch
+    // Behind the ring: reduction scratch (6 TT floats per key set) | DUAL: two slots of per-tile terms | DUAL 3, 8 waves: the
+    // eighth wave's transpose buffer.  The 4-wave both-directions kernel (two workgroups per CU: 80 KiB each) keeps only the
+    // term slots there: its scratch and transpose buffers live in the ring slot that is free during an epilogue.
+    constexpr bool SCR_IN_RING = (DUAL == 3 && WT == 2);
     float* scratch = reinterpret_cast<float*>(smem + NBUF * PSTAGE);
-    constexpr int BSLOT = DUAL == 3 ? 768 : 512;  // floats per bias slot
-    float* bias_lds = scratch + 12 * TT;         // DUAL: [2 slots][256 bias | 256 scale | 256 target bias], filled by LDS-DMA one tile ahead
-    float* tb_extra = bias_lds + 2 * BSLOT;      // DUAL 3: transpose buffer of wave 7
+    constexpr int BSLOT = DUAL == 3 ? 512 + TT : 512;  // floats per slot: 256 bias | 256 scale | TT target bias
+    float* bias_lds = SCR_IN_RING ? scratch : scratch + 12 * TT;   // filled by LDS-DMA one tile ahead
+    float* tb_extra = bias_lds + 2 * BSLOT;      // DUAL 3, 8 waves: transpose buffer of wave 7
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
                 const char* gs = reinterpret_cast<const char*>(p.scale + (long long)b_ * p.N1 + ts_ * ST) + lane * 16; \
                 __builtin_amdgcn_global_load_lds((gptr_t)gs, (lptr_t)(dstB + 256), 16, 0, 0);                          \
             }                                                                                                          \
-            if (DUAL == 3) {                                                                                           \
+            if (DUAL == 3 && lane < TT / 4) {                                                                          \
                 const char* gt2 = reinterpret_cast<const char*>(p.biasT + (long long)b_ * p.N2 + tt_ * TT) + lane * 16; \
                 __builtin_amdgcn_global_load_lds((gptr_t)gt2, (lptr_t)(dstB + 512), 16, 0, 0);                         \
             }                                                                                                          \
@@ -662,14 +668,15 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
             if (sacc == 1.2345f) p.pb[0] = sacc;
             continue;
         }
+        // the ring slot of the stage computed last takes no LDS-DMA before the next tile's first stage
+        float* const free_slot = reinterpret_cast<float*>(smem + ((r_slot + NBUF - 1) % NBUF) * PSTAGE);
         simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0, (DUAL == 3 ? 1 : DUAL)>(
-            p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt, bias_lds + (n & 1) * BSLOT);
+            p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, SCR_IN_RING ? free_slot + NW * (32 * 36) : scratch, lane, wsrc, wtgt,
+            bias_lds + (n & 1) * BSLOT);
         if (DUAL == 3) {
-            // the ring slot of the stage computed last takes no LDS-DMA before the next tile's first stage: seven waves
-            // transpose through it, the eighth through its own buffer
-            const int free_slot = (r_slot + NBUF - 1) % NBUF;
-            float* tb = wave < 7 ? reinterpret_cast<float*>(smem + free_slot * PSTAGE) + wave * (32 * 36) : tb_extra;
-            simnn_tail_cols(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, tt_, tb, bias_lds + (n & 1) * BSLOT + 512, lane, wsrc, wtgt);
+            // transposes go through the free slot (8 waves: seven of them, the eighth has its own buffer)
+            float* tb = (WT == 4 && wave == 7) ? tb_extra : free_slot + wave * (32 * 36);
+            simnn_tail_cols<WT>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, tt_, tb, bias_lds + (n & 1) * BSLOT + 512, lane, wsrc, wtgt);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave is done with its buffer ...
             __builtin_amdgcn_s_barrier();                // ... and no wave starts the next tile's DMA into the slot before all are
@@ -919,7 +926,9 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16) + 3 * 2 * ST * 4;
     const bool interior = (N2 % ST == 0 && N1 % ST == 0);
     // DM_EXPERIMENTS: DM_SIMNN_DEBUG = variant bits XV (simnn_pipe_kernel) + 256 / 512 for the 8-wave / 4-wave shape
-    const int WT = dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT));
+    // (both directions: the 8-wave shape; p2p_split = 3 selects 4 waves x 2 workgroups per CU, whose second workgroup covers
+    // part of the epilogue but whose 1.5x operand traffic costs as much: config 2 1.737 vs 1.729 ms, config 5 20.0 vs 19.2 ms)
+    const int WT = cols ? (ctx->opt_p2p_split == 3 ? 2 : 4) : (dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT)));
     // (the stage loop peels its first and last stages: the contraction must be at least ring depth + 1 stages deep)
     if (interior && ctx->opt_simnn_pipe && D % PBK == 0 && D >= (WT == 4 ? 5 : 4) * PBK) {
         const int TT = 64 * WT;
@@ -940,7 +949,8 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<XV_, WT_, DUAL_>), dim3(grid), dim3(128 * WT_), lds_pipe, p);     \
         }
         if (cols) {
-            SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 3, "simnn4_f16_mfma")
+            if (WT == 4) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 3, "simnn4_f16_mfma")
+            else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 2, 3, "simnn4_f16_mfma")
         } else if (dual) {
             if (dual->scale) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 1, "simnn2_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 2, "simnn2_f16_mfma")
@@ -990,7 +1000,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         // the column direction: "targets" are the source rows, partials per (tile row, target quarter), bound from |s_j| max |t_i|
         simnn_merge_set c0{p.cb[0], p.cj[0], p.cs[0], cols->tau_add, nullptr, cols->nn_a, cflag_count[0], cflag_list[0], cflag_thr[0]};
         simnn_merge_set c1{p.cb[1], p.cj[1], p.cs[1], nullptr, nullptr, cols->nn_b, cflag_count[1], cflag_list[1], cflag_thr[1]};
-        DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N1, 256), B, 2), dim3(256), 0, c0, c1, p.tilesT * 4, N1, p.N1pad,
+        DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N1, 256), B, 2), dim3(256), 0, c0, c1, p.N2pad / 64, N1, p.N1pad,
                   p.snorm2, p.tmax2, tau_scale, (float*)nullptr, (float*)nullptr, force_flag);
         dm_simnn_queue* qs[2] = {cols->q_a, cols->q_b};
         for (int kd = 0; kd < 2; ++kd) {

@@ -63,7 +63,8 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *   "simnn_pipe"    1 | 0   feature-similarity tiles: LDS-DMA ring kernel | bounds-checked register-staged kernel
  *   "simnn_persist" 1 | 0 | n>1   one persistent workgroup per CU walking its tiles | one workgroup per tile | exactly n workgroups
  *   "knn_split"     1 | 0   knn21 of dm_zoomout / dm_icp / dm_knn_query_f64: fp16-split first pass | float64 G kernel
- *   "p2p_split"   2 | 1 | 0 dm_fm_to_p2p: one fp16 pass reducing in both directions | two two-key passes | float64 G kernel
+ *   "p2p_split" 2 | 3 | 1 | 0 dm_fm_to_p2p: one fp16 pass reducing in both directions (8 waves, 256 x 256 tiles) | the same with
+ *                           4 waves, 128 x 256 tiles, two workgroups per CU | two two-key passes | float64 G kernel
  *                           (all + exact float64 re-evaluation of the ambiguous rows; identical results)
  *   "solve_packed"  0 | 1   dm_fmap_solve: blocked LDS Cholesky when it fits | packed-storage solver always
  * Unknown names return DM_EINVAL.  The library never reads environment variables. */

@@ -478,12 +478,12 @@ def test_fm_to_p2p_split_equals_f64_kernel(eng, kind):
         Phi1, Phi2, a1, C = _split_case(rng, B, N1, N2, k1, k2, kind)
         assert eng.p2p_split_active(N2, N1, k2)
         res = {}
-        for split in (2, 1, 0):                              # 2: one pass, both directions; 1: two passes; 0: float64 kernel
+        for split in (3, 2, 1, 0):      # 3 / 2: one pass in both directions (4-wave / 8-wave shape); 1: two passes; 0: float64 kernel
             eng.set_option("p2p_split", split)
             res[split] = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
         eng.reset_options()
         for name in ("knn21", "knn12", "ind21", "ind12"):
-            for split in (1, 2):
+            for split in (1, 2, 3):
                 bad = int((res[split][name] != res[0][name]).sum())
                 assert bad == 0, (kind, name, split, bad, (B, N1, N2, k1, k2))
         for b in range(B):                                   # and the float64 kernel against the oracle, once per kind

@@ -10,7 +10,7 @@ from densematcher_amd import _build
 from densematcher_amd.engine import MatchEngine
 
 eng = MatchEngine(0, lib_path=_build.LIB_EXP)
-B, N, D = 64, 2048, 768
+B, N, D = 64, 2048, int(os.environ.get("SIMNN_EXP_D", "768"))
 g = torch.Generator(device="cuda").manual_seed(0)
 S = torch.randn(B, N, D, device="cuda", generator=g)
 T = S[:, torch.randperm(N, device="cuda", generator=g)] + torch.randn(B, N, D, device="cuda", generator=g)
