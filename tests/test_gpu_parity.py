@@ -481,9 +481,15 @@ def test_fm_to_p2p_split_equals_f64_kernel(eng, kind):
         for split in (3, 2, 1, 0):      # 3 / 2: one pass in both directions (4-wave / 8-wave shape); 1: two passes; 0: float64 kernel
             eng.set_option("p2p_split", split)
             res[split] = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
+        # the one-pass kernel launched one workgroup per tile / with an odd number of persistent workgroups (tile walks of
+        # different lengths, bias slots of both parities)
+        for tag, persist in (("pertile", 0), ("odd", 37)):
+            eng.set_option("p2p_split", 2)
+            eng.set_option("simnn_persist", persist)
+            res[tag] = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
         eng.reset_options()
         for name in ("knn21", "knn12", "ind21", "ind12"):
-            for split in (1, 2, 3):
+            for split in (1, 2, 3, "pertile", "odd"):
                 bad = int((res[split][name] != res[0][name]).sum())
                 assert bad == 0, (kind, name, split, bad, (B, N1, N2, k1, k2))
         for b in range(B):                                   # and the float64 kernel against the oracle, once per kind
