@@ -152,15 +152,19 @@ int dm_fmap_descr_ops(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi,
  *   knn12[j] = argmin_i |Phi2_i C|^2 - 2 G_ij      (pyFM/spectral/convert.py:134-136)
  *   ind21[i] = argmax_j G_ij mass1_j               (convert.py:144 + functional_map.py:49)
  *   ind12[j] = argmax_i G_ij mass1_j               (convert.py:144 + functional_map.py:50)
- * float64 arithmetic on the f64 matrix cores; lowest index on ties.
+ * The returned indices are those of the float64 arithmetic above, lowest index on ties.  When all four maps are
+ * asked for and N1, N2 are multiples of 256 (and 3 k2 >= 160) they come from one pass on the fp16 matrix cores over
+ * split operands with a rigorous error bound, every row inside the bound re-evaluated in float64; otherwise from a fused
+ * kernel on the f64 matrix cores ("p2p_split" option).
  * Any of the four outputs may be NULL.  knn21/ind21 (B,N2); knn12/ind12 (B,N1). */
 int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const float* Phi1, int ld1, const float* Phi2, int ld2,
                  const float* mass1, const double* C,
                  int32_t* knn21, int32_t* knn12, int32_t* ind21, int32_t* ind12);
 
-/* 1 when dm_fm_to_p2p would take the fp16-split passes for these sizes with the context's options, else 0 (the float64
- * G kernel).  Informational (bench.py reports the dominant kernel of the step); no reference counterpart. */
+/* The "p2p_split" mode (1, 2, 3) dm_fm_to_p2p would take for these sizes with the context's options when all four maps
+ * are requested, else 0 (the float64 G kernel).  Informational (bench.py reports the dominant kernel of the step); no
+ * reference counterpart. */
 int dm_fm_to_p2p_uses_split(const dm_ctx* ctx, int N2, int N1, int k);
 
 /* ---- exact nearest neighbour, k = 1 -----------------------------------------
