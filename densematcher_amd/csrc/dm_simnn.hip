@@ -435,7 +435,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // is applied on the source address.
 //
 // XV = compile-time variant bits; the product instantiates SIMNN_PRODUCT_XV only, a DM_EXPERIMENTS build a list of them
-// (the ablations give WRONG results): low 4 bits: 1 skip the epilogue, 3 no norms, 7 LDS-DMA only, 8 no LDS-DMA, 9 = 8 + 1;
+// (the ablations give WRONG results): low 4 bits: 1 skip the epilogue, 3 no norms, 5 no stage barriers, 7 LDS-DMA only, 8 no LDS-DMA, 9 = 8 + 1;
 // 16 / 32: K stagger by one stage / spread over the whole sweep; 64: fragment reads pinned in front of the MFMAs;
 // 128: the second wave of every SIMD runs its MFMAs first and its reads / DMA last inside each barrier interval.
 // Measured on config 3 (tools/simnn_experiment.py, profiles/r02_simnn_variants.txt): stagger helps the DMA-only
@@ -503,6 +503,10 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     // LDS-DMA source: per-lane part (row l >> 2 of a 16-row group, swizzled chunk) + uniform part (tile, wave, stage)
     const unsigned voffT = (unsigned)(((lane >> 2) * p.ldT + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
     const unsigned voffS = (unsigned)(((lane >> 2) * p.ldS + (((lane & 3) ^ ((lane >> 4) & 3)) << 3)) * 2);
+    // experiment STAG == 3 (wrong data placement, same bytes): every piece reads 8 rows x 128 bytes (whole cache lines) instead of
+    // 16 rows x 64; two consecutive stages cover the 16 rows of a piece
+    const unsigned voffT_x = (unsigned)(((lane >> 3) * p.ldT + ((lane & 7) << 3)) * 2);
+    const unsigned voffS_x = (unsigned)(((lane >> 3) * p.ldS + ((lane & 7) << 3)) * 2);
     // the stage stream being fetched (runs PD stages ahead of the one being computed)
     int d_tile = 0, d_s = 0, d_kp = 0, d_slot = 0;
     const char* d_T = nullptr;                   // rows wave*32 .. of the tile's target panel (2 x 16 rows per stage)
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         simnn_decode(p, base + slot + d_tile * nslot, b_, tt_, ts_);                                                   \
         d_T = reinterpret_cast<const char*>(p.Ftgt + ((long long)b_ * p.N2 + tt_ * TT + wave * 32) * p.ldT);           \
         d_S = reinterpret_cast<const char*>(p.Fsrc + ((long long)b_ * p.N1 + ts_ * ST + wave * 16 * NSI) * p.ldS);     \
-        d_kp = STAG == 0 ? 0 : (STAG == 1 ? (ts_ + tt_) % ns : ((ts_ + tt_) * ns / p.tilesS) % ns);                    \
+        d_kp = (STAG == 0 || STAG == 3) ? 0 : (STAG == 1 ? (ts_ + tt_) % ns : ((ts_ + tt_) * ns / p.tilesS) % ns);                    \
         d_s = 0;                                                                                                       \
         if (DUAL && wave == 0) {      /* the tile's per-source terms: one 1 KiB piece each, landed long before its epilogue */ \
             float* dstB = bias_lds + (d_tile & 1) * BSLOT;                                                             \
@@ -533,13 +537,15 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #define SIMNN_DMA1(H_)                                                                                                 \
     if (!(dbg & 8) || d_tile == 0) {                                                                                   \
         _Float16* dstT = smem + d_slot * PSTAGE + (wave * 32 + (H_) * 16) * PBK;                                       \
-        const char* gt = d_T + ((long long)((H_) * 16) * p.ldT + d_kp * PBK) * 2;                                      \
-        __builtin_amdgcn_global_load_lds((gptr_t)(gt + voffT), (lptr_t)dstT, 16, 0, 0);                                \
+        const char* gt = STAG == 3 ? d_T + ((long long)((H_) * 16 + (d_kp & 1) * 8) * p.ldT + (d_kp >> 1) * 64) * 2        \
+                                   : d_T + ((long long)((H_) * 16) * p.ldT + d_kp * PBK) * 2;                          \
+        __builtin_amdgcn_global_load_lds((gptr_t)(gt + (STAG == 3 ? voffT_x : voffT)), (lptr_t)dstT, 16, 0, 0);        \
         _Pragma("unroll") for (int u = 0; u < NSI / 2; ++u) {                                                          \
             const int piece = (H_) * (NSI / 2) + u;                                                                    \
             _Float16* dstS = smem + d_slot * PSTAGE + (TT + wave * 16 * NSI + piece * 16) * PBK;                       \
-            const char* gs = d_S + ((long long)(piece * 16) * p.ldS + d_kp * PBK) * 2;                                 \
-            __builtin_amdgcn_global_load_lds((gptr_t)(gs + voffS), (lptr_t)dstS, 16, 0, 0);                            \
+            const char* gs = STAG == 3 ? d_S + ((long long)(piece * 16 + (d_kp & 1) * 8) * p.ldS + (d_kp >> 1) * 64) * 2    \
+                                       : d_S + ((long long)(piece * 16) * p.ldS + d_kp * PBK) * 2;                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gs + (STAG == 3 ? voffS_x : voffS)), (lptr_t)dstS, 16, 0, 0);    \
         }                                                                                                              \
     }
 #define SIMNN_DMA_NEXT()                                                                                               \
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     if ((AFTER_EPI_) && n > 0 && !NOEPI) DM_WAIT_VM_LGKM0((n_) + EPI_ST);                                              \
     else DM_WAIT_VM_LGKM0(n_);                                                                                         \
-    __builtin_amdgcn_s_barrier();                                                                                      \
+    if ((dbg & 15) != 5) __builtin_amdgcn_s_barrier();      /* (ablation 5: no stage barriers -- wrong results) */    \
     __builtin_amdgcn_sched_barrier(0);
 #define SIMNN_PIN() if (PINR) __builtin_amdgcn_sched_barrier(0);
     // one stage: DMA_ = 1 in the steady state (stage g+PD exists), VM_ = loads allowed to stay in flight at the barrier,
@@ -960,8 +966,9 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
 #define SIMNN_CASE(XV_) case 512 + XV_: SIMNN_LAUNCH_XV(XV_, 2, 0, "simnn_f16_mfma") break; case 256 + XV_: SIMNN_LAUNCH_XV(XV_, 4, 0, "simnn_f16_mfma") break;
             SIMNN_CASE(0) SIMNN_CASE(1) SIMNN_CASE(7) SIMNN_CASE(9)
             SIMNN_CASE(16) SIMNN_CASE(32) SIMNN_CASE(64)
-            SIMNN_CASE(64 + 1) SIMNN_CASE(64 + 7) SIMNN_CASE(64 + 9) SIMNN_CASE(64 + 16) SIMNN_CASE(64 + 32)
+            SIMNN_CASE(64 + 1) SIMNN_CASE(64 + 5) SIMNN_CASE(64 + 7) SIMNN_CASE(64 + 9) SIMNN_CASE(64 + 16) SIMNN_CASE(64 + 32)
             SIMNN_CASE(64 + 32 + 1) SIMNN_CASE(64 + 32 + 7) SIMNN_CASE(64 + 32 + 9)
+            SIMNN_CASE(64 + 48) SIMNN_CASE(64 + 48 + 1) SIMNN_CASE(64 + 48 + 7)
             SIMNN_CASE(64 + 2) SIMNN_CASE(64 + 4) SIMNN_CASE(64 + 6)
             SIMNN_CASE(64 + 128) SIMNN_CASE(64 + 128 + 1) SIMNN_CASE(64 + 128 + 9)
 #undef SIMNN_CASE
