@@ -238,7 +238,16 @@ def main():
 
     if args.workload == "fmap" and not args.batch:
         if not args.no_secondary:
-            out["secondary"] = {"simnn": secondary_simnn(eng, rank, barrier, max_over_ranks, world)}
+            # the other kernel of the step that is as long as the tile pass: the batched SPD solves (a chain of serial
+            # pivots: latency-bound, priced here against the f64 matrix-core peak for what it is worth)
+            _, sl, sms = timed_kernel(eng, step, "fmap_solve_chol", 5, 0, barrier)
+            n_ = k - 1
+            sflops = B * k * (n_ ** 3 / 3.0 + 2.0 * n_ * n_)
+            solver = {"kernel": "fmap_solve_chol", "bound": "latency (serial pivots)", "avg_launch_ms": round(sms / max(sl, 1), 4),
+                      "launches": sl, "algorithmic_flops_per_launch": sflops, "unit": "TFLOP/s",
+                      "achieved": round(sflops / (sms / max(sl, 1) * 1e-3) / 1e12, 3) if sl else None, "peak": PEAK_TFLOPS["f64"]}
+            solver["frac"] = round(solver["achieved"] / solver["peak"], 4) if solver["achieved"] else None
+            out["secondary"] = {"simnn": secondary_simnn(eng, rank, barrier, max_over_ranks, world), "solver": solver}
         if rank == 0:
             out["parity"] = parity_block(eng)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
