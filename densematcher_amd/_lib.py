@@ -48,6 +48,11 @@ SIGNATURES = {
     "dm_zoomout": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
 }
 
+# the float64-basis forms (const double* Phi / mass): same argument lists
+for _n in ("dm_fmap_c00", "dm_fm_to_p2p", "dm_mapped_indicator", "dm_p2p_to_fm", "dm_precise_map", "dm_p2p_to_fm_lstsq", "dm_icp",
+           "dm_zoomout"):
+    SIGNATURES[_n + "_f64"] = SIGNATURES[_n]
+
 _libs = {}
 
 

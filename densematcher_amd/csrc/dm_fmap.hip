@@ -78,8 +78,9 @@ extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* 
 // =================================================================================================
 // dm_fmap_c00: sign(Phi1[0,0] Phi2[0,0]) sqrt(area2 / area1)          pyFM/functional.py:654-658
 // =================================================================================================
-__global__ __launch_bounds__(256) void c00_kernel(const float* __restrict__ Phi1, long long s1, const float* __restrict__ Phi2,
-                                                  long long s2, const float* __restrict__ mass1, const float* __restrict__ mass2,
+template <typename TR>
+__global__ __launch_bounds__(256) void c00_kernel(const TR* __restrict__ Phi1, long long s1, const TR* __restrict__ Phi2,
+                                                  long long s2, const TR* __restrict__ mass1, const TR* __restrict__ mass2,
                                                   int N1, int N2, double* __restrict__ c00) {
     __shared__ double red[2][4];
     const int b = blockIdx.x, t = threadIdx.x;
@@ -102,15 +103,24 @@ __global__ __launch_bounds__(256) void c00_kernel(const float* __restrict__ Phi1
     }
 }
 
-extern "C" int dm_fmap_c00(dm_ctx* ctx, int B, int N1, int N2, const float* Phi1, int ld1, const float* Phi2, int ld2,
-                           const float* mass1, const float* mass2, double* c00) {
+template <typename TR>
+static int c00_impl(dm_ctx* ctx, int B, int N1, int N2, const TR* Phi1, int ld1, const TR* Phi2, int ld2,
+                    const TR* mass1, const TR* mass2, double* c00) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && ld1 > 0 && ld2 > 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && mass2 && c00, "null pointer");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    DM_LAUNCH(ctx, "c00", c00_kernel, dim3(B), dim3(256), 0, Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2,
+    DM_LAUNCH(ctx, "c00", c00_kernel<TR>, dim3(B), dim3(256), 0, Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2,
               N1, N2, c00);
     return DM_OK;
+}
+extern "C" int dm_fmap_c00(dm_ctx* ctx, int B, int N1, int N2, const float* Phi1, int ld1, const float* Phi2, int ld2,
+                           const float* mass1, const float* mass2, double* c00) {
+    return c00_impl<float>(ctx, B, N1, N2, Phi1, ld1, Phi2, ld2, mass1, mass2, c00);
+}
+extern "C" int dm_fmap_c00_f64(dm_ctx* ctx, int B, int N1, int N2, const double* Phi1, int ld1, const double* Phi2, int ld2,
+                               const double* mass1, const double* mass2, double* c00) {
+    return c00_impl<double>(ctx, B, N1, N2, Phi1, ld1, Phi2, ld2, mass1, mass2, c00);
 }
 
 // =================================================================================================

@@ -34,7 +34,31 @@ template <class T> struct dm_tn_raw<T, std::void_t<typename T::raw_t>> {
     static __device__ __forceinline__ void zero(type& r) { T::zero(r); }
     static __device__ __forceinline__ void cvt(const type& r, double (&v)[4]) { T::cvt(r, v); }
 };
-struct dm_f32x4_scaled { f32x4 q; float s; };                         // four fp32 entries of a row and the row's scale
+// four consecutive entries of a row (kept in their memory type) and the row's scale
+template <typename TR, typename TS> struct dm_x4_scaled { TR q[4]; TS s; };
+typedef __attribute__((address_space(1))) const f64x2 dm_gf64x2;
+// four consecutive entries of a row: one 16-byte load (fp32) or two (fp64) when aligned, zero beyond ncols
+template <typename TR>
+__device__ __forceinline__ void dm_load_row4(const TR* row, int col0, int ncols, bool aligned, TR (&q)[4]) {
+    if (col0 + 3 < ncols && aligned) {
+        if constexpr (sizeof(TR) == 4) {
+            const f32x4 x = *(dm_gf32x4*)(row + col0);
+            q[0] = x[0]; q[1] = x[1]; q[2] = x[2]; q[3] = x[3];
+        } else {
+            const f64x2 x0 = ((dm_gf64x2*)(row + col0))[0], x1 = ((dm_gf64x2*)(row + col0))[1];
+            q[0] = x0[0]; q[1] = x0[1]; q[2] = x1[0]; q[3] = x1[1];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = (col0 + e < ncols) ? row[col0 + e] : (TR)0;
+    }
+}
+// can rows of a (B, rows, ld) matrix of TR be read with 16-byte loads at column offsets that are multiples of 4?
+template <typename TR>
+__device__ __forceinline__ bool dm_rows_aligned(const TR* p, long long stride_b, int ld) {
+    constexpr int m = sizeof(TR) == 4 ? 3 : 1;
+    return ((ld & m) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & m) == 0);
+}
 
 // ----------------------------------------------------------------------------------------------
 // NT form.  OpA/OpB: void load8(int b, int row, int k0, elem_t (&v)[8]) const  -- 8 consecutive k,
@@ -233,49 +257,43 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(OpX opx, OpY opy, Out out, in
 // ----------------------------------------------------------------------------------------------
 // common operand functors
 // ----------------------------------------------------------------------------------------------
-// rows of a float32 matrix (B, rows, ld), optionally scaled per row (mass), K-major use (load4)
-struct RowsF32Scaled {
-    typedef dm_f32x4_scaled raw_t;
-    const float* p; long long stride_b; int ld; int ncols;
-    const float* scale; long long scale_stride_b;   // nullable
+// rows of a real matrix (B, rows, ld) of TR = float | double, optionally scaled per row (mass, TS = float | double),
+// K-major use (load4).  The product scale * entry is formed in float64 (one rounding: what the reference's A @ Phi does).
+template <typename TR, typename TS>
+struct RowsScaled {
+    typedef dm_x4_scaled<TR, TS> raw_t;
+    const TR* p; long long stride_b; int ld; int ncols;
+    const TS* scale; long long scale_stride_b;   // nullable
     __device__ __forceinline__ int pre(int, int) const { return 0; }
     __device__ __forceinline__ void load4raw(int b, int n, int col0, int, raw_t& r) const {
-        const float* row = p + b * stride_b + (long long)n * ld;
-        r.s = scale ? scale[b * scale_stride_b + n] : 1.0f;
-        if (col0 + 3 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {
-            r.q = *(dm_gf32x4*)(row + col0);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r.q[e] = (col0 + e < ncols) ? row[col0 + e] : 0.0f;
-        }
+        const TR* row = p + b * stride_b + (long long)n * ld;
+        r.s = scale ? scale[b * scale_stride_b + n] : (TS)1;
+        dm_load_row4<TR>(row, col0, ncols, dm_rows_aligned<TR>(p, stride_b, ld), r.q);
     }
-    static __device__ __forceinline__ void zero(raw_t& r) { r.q = f32x4{0.f, 0.f, 0.f, 0.f}; r.s = 0.f; }
+    static __device__ __forceinline__ void zero(raw_t& r) { r.q[0] = r.q[1] = r.q[2] = r.q[3] = (TR)0; r.s = (TS)0; }
     static __device__ __forceinline__ void cvt(const raw_t& r, double (&v)[4]) {
         const double s = (double)r.s;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = s * (double)r.q[e];
     }
 };
+typedef RowsScaled<float, float> RowsF32Scaled;
 
-// gathered, scaled rows of a float32 matrix: row n of the operand is scale[b][n] * p[b][idx[b][n]][:]
-struct RowsF32GatherScaled {
-    typedef dm_f32x4_scaled raw_t;
-    const float* p; long long stride_b; int ld; int ncols;
+// gathered, scaled rows: row n of the operand is scale[b][n] * p[b][idx[b][n]][:]
+template <typename TR, typename TS>
+struct RowsGatherScaled {
+    typedef dm_x4_scaled<TR, TS> raw_t;
+    const TR* p; long long stride_b; int ld; int ncols;
     const int32_t* idx; long long idx_stride_b; int nrows_src;
-    const float* scale; long long scale_stride_b;
+    const TS* scale; long long scale_stride_b;
     __device__ __forceinline__ int pre(int b, int n) const { return idx[b * idx_stride_b + n]; }
     __device__ __forceinline__ void load4raw(int b, int n, int col0, int pv, raw_t& r) const {
         const int ri = min(max(pv, 0), nrows_src - 1);
-        const float* row = p + b * stride_b + (long long)ri * ld;
+        const TR* row = p + b * stride_b + (long long)ri * ld;
         r.s = scale[b * scale_stride_b + n];
-        if (col0 + 3 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {
-            r.q = *(dm_gf32x4*)(row + col0);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r.q[e] = (col0 + e < ncols) ? row[col0 + e] : 0.0f;
-        }
+        dm_load_row4<TR>(row, col0, ncols, dm_rows_aligned<TR>(p, stride_b, ld), r.q);
     }
-    static __device__ __forceinline__ void zero(raw_t& r) { r.q = f32x4{0.f, 0.f, 0.f, 0.f}; r.s = 0.f; }
+    static __device__ __forceinline__ void zero(raw_t& r) { r.q[0] = r.q[1] = r.q[2] = r.q[3] = (TR)0; r.s = (TS)0; }
     static __device__ __forceinline__ void cvt(const raw_t& r, double (&v)[4]) {
         const double s = (double)r.s;
 #pragma unroll
@@ -300,24 +318,28 @@ struct RowsF16Scaled {
     }
 };
 
-// K-contiguous rows (NT form) of a float32 matrix, rows [0, nrows), columns [0, ncols)
-struct KRowsF32 {
-    typedef float elem_t;
-    const float* p; long long stride_b; int ld; int nrows; int ncols;
-    __device__ __forceinline__ void load8(int b, int row, int k0, float (&v)[8]) const {
+// K-contiguous rows (NT form) of a real matrix (TR = float | double), rows [0, nrows), columns [0, ncols)
+template <typename TR>
+struct KRows {
+    typedef TR elem_t;
+    const TR* p; long long stride_b; int ld; int nrows; int ncols;
+    __device__ __forceinline__ void load8(int b, int row, int k0, TR (&v)[8]) const {
         // rows beyond the operand only feed outputs the caller masks or rows of zeros: clamp instead of branching
-        const float* r = p + b * stride_b + (long long)min(row, nrows - 1) * ld;
+        const TR* r = p + b * stride_b + (long long)min(row, nrows - 1) * ld;
         const bool in = row < nrows;
-        if (k0 + 7 < ncols && ((ld & 3) == 0) && ((((uintptr_t)p) & 15) == 0) && ((stride_b & 3) == 0)) {
-            const f32x4 q0 = *(dm_gf32x4*)(r + k0), q1 = *(dm_gf32x4*)(r + k0 + 4);
+        if (k0 + 7 < ncols && dm_rows_aligned<TR>(p, stride_b, ld)) {
+            TR q0[4], q1[4];
+            dm_load_row4<TR>(r, k0, ncols, true, q0);
+            dm_load_row4<TR>(r, k0 + 4, ncols, true, q1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = in ? q0[e] : 0.0f; v[4 + e] = in ? q1[e] : 0.0f; }
+            for (int e = 0; e < 4; ++e) { v[e] = in ? q0[e] : (TR)0; v[4 + e] = in ? q1[e] : (TR)0; }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (in && k0 + e < ncols) ? r[k0 + e] : 0.0f;
+            for (int e = 0; e < 8; ++e) v[e] = (in && k0 + e < ncols) ? r[k0 + e] : (TR)0;
         }
     }
 };
+typedef KRows<float> KRowsF32;
 
 // two fp32 matrices stacked: rows 0 .. k1-1 = A (B, k1, D), rows k1 .. k1+k2-1 = Bm (B, k2, D); K = D contiguous
 struct KRowsStackedF32 {

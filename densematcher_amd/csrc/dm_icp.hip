@@ -24,11 +24,11 @@ constexpr int NS_LIFT = 12, NS_POLISH = 8;
 constexpr double NS_A = 3.4445, NS_B = -4.7750, NS_C = 2.0315;
 
 // ---- helpers ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void iota_ones_kernel(int32_t* __restrict__ idx, float* __restrict__ ones, int N, int B) {
+__global__ __launch_bounds__(256) void iota_ones_kernel(int32_t* __restrict__ idx, double* __restrict__ ones, int N, int B) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)N * B) return;
     idx[i] = (int32_t)(i % N);
-    ones[i] = 1.0f;
+    ones[i] = 1.0;
 }
 
 // row-major symmetric matrix G (B, n, n) -> blocked transposed LDS image (see dm_chol.h), padding = identity
@@ -232,8 +232,9 @@ static int gram_inverse(dm_ctx* ctx, int B, int k2, const double* G, double* Gin
 
 // ---- least-squares vertex map -> functional map ------------------------------------------------------------------
 // C = argmin |Phi2[:, :k2] X - Phi1[p21, :k1]|_F  (no mass): normal equations (Phi2^T Phi2) C = Phi2^T Phi1[p21].
-extern "C" int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const float* Phi1,
-                                  int ld1, const float* Phi2, int ld2, double* C, int32_t* info) {
+template <typename TR>
+static int p2p_to_fm_lstsq_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
+                                int ld1, const TR* Phi2, int ld2, double* C, int32_t* info) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
     DM_REQUIRE(ctx, p21 && Phi1 && Phi2 && C && info, "null pointer");
@@ -242,7 +243,7 @@ extern "C" int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, in
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bG = (size_t)B * k2 * k2 * 8, bC = (size_t)B * k2 * k1 * 8;
     const int NB = (k2 + 15) / 16;
-    const size_t need = 2 * dm_align_up(bG) + dm_align_up(bC) + gram_inverse_ws_bytes(B, k2) + 2 * dm_align_up((size_t)B * N2 * 4) +
+    const size_t need = 2 * dm_align_up(bG) + dm_align_up(bC) + gram_inverse_ws_bytes(B, k2) + 3 * dm_align_up((size_t)B * N2 * 4) +
                         dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
@@ -253,17 +254,17 @@ extern "C" int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, in
     if (NB <= 11) img = (double*)dm_ws_take(ctx, (size_t)B * (NB * (NB + 1) / 2) * 256 * 8);
     else { Gx = (double*)dm_ws_take(ctx, bG); Gt = (double*)dm_ws_take(ctx, bG); }
     int32_t* iota = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    float* ones = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    double* ones = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
     if (!G || !Ginv || !R || (NB <= 11 ? !img : (!Gx || !Gt)) || !iota || !ones) return dm_fail(ctx, DM_ENOMEM, "p2p_to_fm_lstsq: workspace not reserved");
     DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
     DM_LAUNCH(ctx, "iota_ones", iota_ones_kernel, dim3((unsigned)(((long long)B * N2 + 255) / 256)), dim3(256), 0, iota, ones, N2, B);
     const size_t ws_mark = ctx->ws_off;
-    rc = dm_launch_p2p_to_fm(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
+    rc = dm_launch_p2p_to_fm<TR>(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
     if (rc) return rc;
     rc = gram_inverse(ctx, B, k2, G, Ginv, img, Gx, Gt, info);
     if (rc) return rc;
     ctx->ws_off = ws_mark;
-    rc = dm_launch_p2p_to_fm(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);
+    rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);
     if (rc) return rc;
     KRowsF64 ga{Ginv, (long long)k2 * k2, k2, k2, k2, 0};
     KRowsF64 rb{R, (long long)k2 * k1, k1, k1, k2, 1};
@@ -272,9 +273,18 @@ extern "C" int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, in
               dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ga, rb, oc, k2, k1, k2);
     return DM_OK;
 }
+extern "C" int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const float* Phi1,
+                                  int ld1, const float* Phi2, int ld2, double* C, int32_t* info) {
+    return p2p_to_fm_lstsq_impl<float>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, C, info);
+}
+extern "C" int dm_p2p_to_fm_lstsq_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const double* Phi1,
+                                      int ld1, const double* Phi2, int ld2, double* C, int32_t* info) {
+    return p2p_to_fm_lstsq_impl<double>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, C, info);
+}
 
-extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1, const float* Phi2,
-                      int ld2, const double* C0, int nit, double* Cout, double* resid, int32_t* info) {
+template <typename TR>
+static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR* Phi1, int ld1, const TR* Phi2,
+                    int ld2, const double* C0, int nit, double* Cout, double* resid, int32_t* info) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0 && nit >= 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi1 && Phi2 && C0 && Cout && info, "null pointer");
@@ -290,7 +300,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     const size_t bC = (size_t)B * k2 * k1 * 8, bG = (size_t)B * k2 * k2 * 8, bImg = (size_t)B * nblk * 256 * 8;
     const size_t bT = (size_t)B * k1 * k1 * 8;
     const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + 4 * dm_align_up(bG) + dm_align_up(bImg) +
-                        2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 3 * dm_align_up((size_t)B * N2 * 4) +
+                        2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 4 * dm_align_up((size_t)B * N2 * 4) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, k2) + dm_knn_split_ws_bytes(B, N2, N1, k2) +
                         dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
     int rc = dm_ws_reserve(ctx, need);
@@ -309,7 +319,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
     int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* iota = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    float* ones = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    double* ones = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
     double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / DM_EMB_COLS + 1) * 8);
     double* Gx = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
     double* Gt = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
@@ -321,13 +331,13 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     DM_CHECK_HIP(ctx, hipMemcpyAsync(Ccur, C0, bC, hipMemcpyDeviceToDevice, ctx->stream));
     DM_LAUNCH(ctx, "iota_ones", iota_ones_kernel, dim3((unsigned)(((long long)B * N2 + 255) / 256)), dim3(256), 0, iota, ones, N2, B);
     // iteration independent: Phi2^T (K-major f64) and the Gram matrix Phi2^T Phi2 with its blocked image
-    rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad);
+    rc = dm_launch_phiT<TR>(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad);
     if (rc) return rc;
     dm_knn_split_state knn;                    // fp16 split of Phi2 for the nearest-neighbour searches, once
     rc = dm_knn_split_prepare(ctx, B, N2, N2pad, Kpad, k2, AT, &knn);
     if (rc) return rc;
     const size_t ws_mark = ctx->ws_off;
-    rc = dm_launch_p2p_to_fm(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
+    rc = dm_launch_p2p_to_fm<TR>(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
     if (rc) return rc;
     DM_CHECK_HIP(ctx, hipMemsetAsync(BT, 0, bBT, ctx->stream));
     // the Gram matrix does not change over the iterations: invert it once and apply the inverse by a GEMM per iteration
@@ -337,7 +347,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     for (int it = 0; it < nit; ++it) {
         ctx->ws_off = ws_mark;
         // p21 = NN(tree = Phi1 C^T, query = Phi2)
-        rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, Ccur, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 0, amaxS);
+        rc = dm_launch_embed<TR>(ctx, B, N1, k2, k1, Phi1, ld1, Ccur, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 0, amaxS);
         if (rc) return rc;
         dm_gred_args a;
         a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = Kpad;
@@ -348,7 +358,7 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
         rc = dm_launch_knn21(ctx, a, knn, amaxS, dm_cdiv(N1pad, DM_EMB_COLS));
         if (rc) return rc;
         // R = Phi2^T Phi1[p21]   (k2 x k1);   Chat = (Phi2^T Phi2)^-1 R
-        rc = dm_launch_p2p_to_fm(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);
+        rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);
         if (rc) return rc;
         {   // Chat = (Phi2^T Phi2)^-1 R with the inverse computed once before the loop
             KRowsF64 ga{Ginv, (long long)k2 * k2, k2, k2, k2, 0};
@@ -393,4 +403,12 @@ extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const 
     if (resid && nit == 0) DM_CHECK_HIP(ctx, hipMemsetAsync(resid, 0, (size_t)B * 8, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemcpyAsync(Cout, Ccur, bC, hipMemcpyDeviceToDevice, ctx->stream));
     return DM_OK;
+}
+extern "C" int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1, const float* Phi2,
+                      int ld2, const double* C0, int nit, double* Cout, double* resid, int32_t* info) {
+    return icp_impl<float>(ctx, B, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, C0, nit, Cout, resid, info);
+}
+extern "C" int dm_icp_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const double* Phi1, int ld1, const double* Phi2,
+                          int ld2, const double* C0, int nit, double* Cout, double* resid, int32_t* info) {
+    return icp_impl<double>(ctx, B, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, C0, nit, Cout, resid, info);
 }

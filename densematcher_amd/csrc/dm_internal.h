@@ -101,14 +101,22 @@ static inline int dm_cdiv(int a, int b) { return (a + b - 1) / b; }
 // (c < k), zero for padded entries; out is (B, kpad, Npad).
 // amax (nullable, zeroed by the caller): (B, DM_NCH) partial maxima of |Phi[:, :k]| (bit patterns of non-negative doubles)
 constexpr int DM_NCH = 32;
-int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld,
+// Real arrays at the ABI (eigenvectors Phi, lumped masses) come as fp32 or fp64 (the *_f64 entry points: the reference's
+// own dtype, pyFM/mesh/trimesh.py:118); the launchers below are templates over TR = float | double, instantiated for both
+// in their .hip.  Masses are always float64 inside the library (dm_widen_mass converts an fp32 vector once per call).
+template <typename TR>
+int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const TR* Phi, int ld,
                    double* out, int kpad, int Npad, double* amax = nullptr);
+// mass as float64: the pointer itself for TR = double, a converted copy in `buf` (n doubles of workspace) for float
+int dm_widen_mass(dm_ctx* ctx, long long n, const float* mass, double* buf, const double** out);
+int dm_widen_mass(dm_ctx* ctx, long long n, const double* mass, double* buf, const double** out);
 
 // embT[b][r][j] = sum_m Cm[b][r][m] * Phi[b][j][m]   (r < kr, m < km), K-major f64
 // (B, krpad, Npad); nrm[b][j] = sum_r embT[b][r][j]^2 (nullable).  Only entries (r < kr, j < N)
 // are written; zero_first clears the whole buffer before (padding must read as 0).
 // Cm is (B, kr, km) f64 with row stride ldc; if transC, Cm[b][m][r] is read instead.  embT may be null (norms only).
-int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld,
+template <typename TR>
+int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, int ld,
                     const double* Cm, int ldc, long long strideC, int transC,
                     double* embT, int krpad, int Npad, double* nrm, int zero_first,
                     double* amax_part = nullptr);   // amax_part: (B, ceil(Npad / DM_EMB_COLS)) max |embT| per block of columns (nullable)
@@ -124,7 +132,7 @@ struct dm_gred_args {
     int Kpad;
     const double* n1;                 // (B, N1pad) |emb1_j|^2          (knn21)
     const double* n2;                 // (B, N2pad) |Phi2_i C|^2        (knn12)
-    const float* mass1;               // (B, N1)                        (ind21, ind12)
+    const double* mass1;              // (B, N1)                        (ind21, ind12)
     int32_t* knn21; int32_t* knn12; int32_t* ind21; int32_t* ind12;   // any nullable
 };
 int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a);
@@ -176,11 +184,13 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K);
 size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K);
 size_t dm_fm_split_zero_bytes(int B);      // block the caller zeroes: (B, DM_NCH) maxima of |Phi2| (filled by dm_launch_phiT) + per-pair bounds
-int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const float* Phi2, int ld2);
+template <typename TR>
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const TR* Phi2, int ld2);
 
 // C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
+template <typename TR>
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,
-                        const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass2,
+                        const TR* Phi1, int ld1, const TR* Phi2, int ld2, const double* mass2,
                         double* C, int ldc, long long strideC);
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2);
 

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
 //   1  arg-max_j  g massS[j]        indicator row,    convert.py:144  ind21
 //   2  arg-max_j  g massT[i]        indicator column (the target's own mass)  ind12, operands swapped
 struct ks_exact_args {
-    const double* AT; const double* BT; const double* n1; const float* massS; const float* massT;
+    const double* AT; const double* BT; const double* n1; const double* massS; const double* massT;
     int K, N2, N2pad, N1, N1pad, Kpad;
     const float* pb32; int nsub, N2pad_s;
     const int32_t* flag_count; const int32_t* flag_list; const float* flag_thr; int32_t* nn;
@@ -143,7 +143,7 @@ struct ks_exact_args {
 template <int KIND>
 __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, int nwg) {
     const double* __restrict__ AT = a.AT; const double* __restrict__ BT = a.BT; const double* __restrict__ n1 = a.n1;
-    const float* __restrict__ massS = a.massS; const float* __restrict__ massT = a.massT;
+    const double* __restrict__ massS = a.massS; const double* __restrict__ massT = a.massT;
     const int K = a.K, N2 = a.N2, N2pad = a.N2pad, N1 = a.N1, N1pad = a.N1pad, Kpad = a.Kpad;
     const float* __restrict__ pb32 = a.pb32; const int nsub = a.nsub, N2pad_s = a.N2pad_s;
     const int32_t* __restrict__ flag_count = a.flag_count; const int32_t* __restrict__ flag_list = a.flag_list;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
         __syncthreads();
         double bv = KIND == 0 ? DM_INF_F64 : -DM_INF_F64;
         int bj = DM_IDX_NONE;
-        const double mt = KIND == 2 ? (double)massT[(long long)b * N2 + i] : 0.0;
+        const double mt = KIND == 2 ? massT[(long long)b * N2 + i] : 0.0;
         // candidate blocks: one gather of the row's block maxima (256 at a time), then only the blocks that can still
         // hold the optimum are visited, in ascending order
         for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
@@ -204,7 +204,7 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
                             const double v = n1[(long long)b * N1pad + j] - 2.0 * g;          // |y|^2 - 2 <x, y>
                             if (v < bv) { bv = v; bj = j; }
                         } else {
-                            const double v = g * (KIND == 1 ? (double)massS[(long long)b * N1 + j] : mt);
+                            const double v = g * (KIND == 1 ? massS[(long long)b * N1 + j] : mt);
                             if (v > bv) { bv = v; bj = j; }
                         }
                     }
@@ -293,9 +293,12 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 //                                   per-target factor; targets with a1_j == 0 score 0 everywhere: index 0, like np.argmax)
 // then the ambiguous rows of each of the four reductions are re-evaluated exactly (ks_exact_kernel) with the reference's
 // own float64 expressions.  Needs interior 256-tiles and 3 K >= 160 (dm_fm_split_ok); otherwise the float64 G kernel.
+// (mass, when given: also its fp32 rounding scale32, the per-source factor of the tile kernel's key B -- the rounding is
+//  part of the key's error bound, dm_simnn_core -- and the maximum of the ROUNDED values)
 __global__ __launch_bounds__(256) void fs_bias_kernel(const double* __restrict__ nrm, int N, int Npad, const double* __restrict__ amaxT,
-                                                      const double* __restrict__ amaxS, int nS, const float* __restrict__ mass,
-                                                      float* __restrict__ bias, unsigned int* __restrict__ bmax, unsigned int* __restrict__ mmax) {
+                                                      const double* __restrict__ amaxS, int nS, const double* __restrict__ mass,
+                                                      float* __restrict__ bias, unsigned int* __restrict__ bmax, unsigned int* __restrict__ mmax,
+                                                      float* __restrict__ scale32) {
     __shared__ float wb[4], wm[4];
     const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     const double sxy = ks_scale(amaxT + b * KS_NCH, KS_NCH) * ks_scale(amaxS + b * nS, nS);
@@ -304,7 +307,11 @@ __global__ __launch_bounds__(256) void fs_bias_kernel(const double* __restrict__
         const float v = (float)(-0.5 * nrm[(long long)b * Npad + j] * sxy);
         bias[(long long)b * N + j] = v;
         bb = fabsf(v);
-        if (mass) mm = fabsf(mass[(long long)b * N + j]);
+        if (mass) {
+            const float m32 = (float)mass[(long long)b * N + j];
+            scale32[(long long)b * N + j] = m32;
+            mm = fabsf(m32);
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { bb = fmaxf(bb, __shfl_xor(bb, off)); mm = fmaxf(mm, __shfl_xor(mm, off)); }
@@ -318,39 +325,54 @@ __global__ __launch_bounds__(256) void fs_bias_kernel(const double* __restrict__
     }
 }
 // ind12[j] = 0 where the target's mass is zero (the whole indicator column is 0: np.argmax returns the first index)
-__global__ __launch_bounds__(256) void fs_zero_mass_kernel(const float* __restrict__ mass, long long n, int32_t* __restrict__ ind12) {
+__global__ __launch_bounds__(256) void fs_zero_mass_kernel(const double* __restrict__ mass, long long n, int32_t* __restrict__ ind12) {
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (o < n && mass[o] == 0.0f) ind12[o] = 0;
+    if (o < n && mass[o] == 0.0) ind12[o] = 0;
 }
 
-// X feature rows straight from the fp32 basis (row-major: no transpose): thread (vertex, group of 8 contraction indices)
-// reads 32 contiguous bytes and writes 48; same values as ks_build_kernel<false> on the float64 copy of the same numbers
-__global__ __launch_bounds__(256) void fs_build_rows_kernel(const float* __restrict__ Phi, int N, int K, int ld, const double* __restrict__ amaxT,
+// X feature rows straight from the basis as it is in memory (row-major, fp32 or fp64: no transpose): thread (vertex, group
+// of 8 contraction indices) reads 32 / 64 contiguous bytes and writes 48; same values as ks_build_kernel<false> on the
+// float64 copy of the same numbers
+template <typename TR>
+__global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict__ Phi, int N, int K, int ld, const double* __restrict__ amaxT,
                                                             int D, _Float16* __restrict__ F) {
     const int b = blockIdx.y;
     const int ngrp = (D + 23) / 24;
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= (long long)N * ngrp) return;
     const int v = (int)(o / ngrp), q = (int)(o - (long long)v * ngrp);
-    // (x sx, |.| < 2, is exact in fp32 -- sx is a power of two --, and so is x sx - h: the pieces equal those of the float64 split)
+    // (fp32 basis: x sx, |.| < 2, is exact in fp32 -- sx is a power of two --, and so is x sx - h: the pieces equal those of
+    //  the float64 split; fp64 basis: the split itself runs in float64, split2)
     const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
-    const float* src = Phi + ((long long)b * N + v) * ld + 8 * q;
+    const TR* src = Phi + ((long long)b * N + v) * ld + 8 * q;
     _Float16* dst = F + ((long long)b * N + v) * D + 24 * q;
     _Float16 o24[24];
-    float xin[8];
-    if (8 * q + 8 <= K && ((ld & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {       // two 16-byte loads
-        typedef __attribute__((address_space(1))) const f32x4 gf32x4;
-        const f32x4 v0 = ((gf32x4*)src)[0], v1 = ((gf32x4*)src)[1];
+    TR xin[8];
+    constexpr int amask = sizeof(TR) == 4 ? 3 : 1;
+    if (8 * q + 8 <= K && ((ld & amask) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {   // 16-byte loads
+        if constexpr (sizeof(TR) == 4) {
+            typedef __attribute__((address_space(1))) const f32x4 gf32x4;
+            const f32x4 v0 = ((gf32x4*)src)[0], v1 = ((gf32x4*)src)[1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { xin[u] = v0[u]; xin[4 + u] = v1[u]; }
+            for (int u = 0; u < 4; ++u) { xin[u] = v0[u]; xin[4 + u] = v1[u]; }
+        } else {
+            typedef __attribute__((address_space(1))) const f64x2 gf64x2;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const f64x2 w = ((gf64x2*)src)[u]; xin[2 * u] = w[0]; xin[2 * u + 1] = w[1]; }
+        }
     } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xin[u] = (8 * q + u < K) ? src[u] : 0.0f;
+        for (int u = 0; u < 8; ++u) xin[u] = (8 * q + u < K) ? src[u] : (TR)0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const float x = (float)((double)xin[u] * sx);                 // exact (sx is a power of two); 0 beyond K
-        const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+        _Float16 h, l;
+        if constexpr (sizeof(TR) == 4) {
+            const float x = (float)((double)xin[u] * sx);             // exact (sx is a power of two); 0 beyond K
+            h = (_Float16)x; l = (_Float16)(x - (float)h);
+        } else {
+            split2((double)xin[u] * sx, h, l);
+        }
         o24[3 * u] = h; o24[3 * u + 1] = h; o24[3 * u + 2] = l;
     }
     if (24 * q + 24 <= D) {
@@ -374,12 +396,13 @@ bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K) {
 size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K) {
     const size_t D = fs_depth(K);
     return dm_align_up((size_t)B * N2 * D * 2) + dm_align_up((size_t)B * N1 * D * 2) +
-           dm_align_up((size_t)B * N1 * 4) + dm_align_up((size_t)B * N2 * 4) +
+           2 * dm_align_up((size_t)B * N1 * 4) + dm_align_up((size_t)B * N2 * 4) +
            dm_simnn_ws_bytes(B, N2, N1, 3) + dm_simnn_ws_bytes(B, N1, N2, 1) + 16384;
 }
 // a: AT, BT (K-major f64), n1, n2, mass1 and all four outputs; amaxS: per-256-column maxima of |BT| (colnorm_kernel);
 // zeroed: dm_fm_split_zero_bytes block, zeroed before dm_launch_phiT(Phi2) filled its first part
-int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const float* Phi2, int ld2) {
+template <typename TR>
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const TR* Phi2, int ld2) {
     const int B = a.B, N1 = a.N1, N2 = a.N2;
     const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop;
     if (!a.AT || !a.BT || !a.n1 || !a.n2 || !a.mass1 || !a.knn21 || !a.knn12 || !a.ind21 || !a.ind12 || !amaxS || !zeroed || !Phi2)
@@ -389,14 +412,15 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     _Float16* Fy = (_Float16*)dm_ws_take(ctx, (size_t)B * N1 * D * 2);
     float* biasA = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
     float* biasB = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    if (!Fx || !Fy || !biasA || !biasB) return dm_fail(ctx, DM_ENOMEM, "fm_split: workspace not reserved");
+    float* scale32 = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);       // fp32 rounding of mass1: key B of the tile kernel
+    if (!Fx || !Fy || !biasA || !biasB || !scale32) return dm_fail(ctx, DM_ENOMEM, "fm_split: workspace not reserved");
     const double* amaxT = (const double*)zeroed;
     const size_t mstride = dm_align_up((size_t)B * 4) / 4;
     unsigned int* bmaxA = reinterpret_cast<unsigned int*>((char*)zeroed + dm_align_up((size_t)B * KS_NCH * 8));
     unsigned int* mmax = bmaxA + mstride; unsigned int* bmaxB = bmaxA + 2 * mstride;
     {
         const long long n = (long long)N2 * ((D + 23) / 24);
-        DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
+        DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel<TR>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
                   amaxT, D, Fx);
     }
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
@@ -404,9 +428,9 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 64), B), dim3(256), ks_build_lds(D), a.BT,
               a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr);
     DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1, 256), B), dim3(256), 0, a.n1, N1, a.N1pad, amaxT,
-              amaxS, nS, a.mass1, biasA, bmaxA, mmax);
+              amaxS, nS, a.mass1, biasA, bmaxA, mmax, scale32);
     DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, a.n2, N2, a.N2pad, amaxT,
-              amaxS, nS, (const float*)nullptr, biasB, bmaxB, (unsigned int*)nullptr);
+              amaxS, nS, (const double*)nullptr, biasB, bmaxB, (unsigned int*)nullptr, (float*)nullptr);
     const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
     if (ctx->opt_p2p_split >= 2) {
@@ -414,7 +438,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         // along its target rows (knn12, ind12)
         dm_simnn_queue qa, qb, qc, qd;
         dm_simnn_cols cols{biasB, reinterpret_cast<const float*>(bmaxB), a.knn12, a.ind12, &qc, &qd};
-        dm_simnn_dual dual{biasA, a.mass1, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols};
+        dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
@@ -436,7 +460,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     // pass A: targets = Phi2 rows, candidates = emb1 rows
     {
         dm_simnn_queue qa, qb;
-        dm_simnn_dual dual{biasA, a.mass1, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb};
+        dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
@@ -463,3 +487,5 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     }
     return DM_OK;
 }
+template int dm_launch_fm_split<float>(dm_ctx*, const dm_gred_args&, const double*, int, void*, const float*, int);
+template int dm_launch_fm_split<double>(dm_ctx*, const dm_gred_args&, const double*, int, void*, const double*, int);

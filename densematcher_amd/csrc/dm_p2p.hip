@@ -54,16 +54,32 @@ __global__ __launch_bounds__(256) void phiT_kernel(const Tin* __restrict__ Phi, 
     }
 }
 
-int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const float* Phi, int ld, double* out, int kpad, int Npad, double* amax) {
+template <typename TR>
+int dm_launch_phiT(dm_ctx* ctx, int B, int N, int k, const TR* Phi, int ld, double* out, int kpad, int Npad, double* amax) {
     dim3 grid(dm_cdiv(Npad, 64), dm_cdiv(kpad, 64), B);
-    DM_LAUNCH(ctx, "phiT", phiT_kernel<float>, grid, dim3(256), 0, Phi, N, k, ld, out, kpad, Npad, amax);
+    DM_LAUNCH(ctx, "phiT", phiT_kernel<TR>, grid, dim3(256), 0, Phi, N, k, ld, out, kpad, Npad, amax);
     return DM_OK;
 }
+template int dm_launch_phiT<float>(dm_ctx*, int, int, int, const float*, int, double*, int, int, double*);
+template int dm_launch_phiT<double>(dm_ctx*, int, int, int, const double*, int, double*, int, int, double*);
+
+// fp32 lumped masses -> float64 (exact), once per call: every kernel of the library reads masses as float64
+__global__ __launch_bounds__(256) void widen_mass_kernel(const float* __restrict__ m, long long n, double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)m[i];
+}
+int dm_widen_mass(dm_ctx* ctx, long long n, const float* mass, double* buf, const double** out) {
+    *out = nullptr;
+    if (!mass) return DM_OK;
+    if (!buf) return dm_fail(ctx, DM_ENOMEM, "widen_mass: workspace not reserved");
+    DM_LAUNCH(ctx, "widen_mass", widen_mass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, mass, n, buf);
+    *out = buf;
+    return DM_OK;
+}
+int dm_widen_mass(dm_ctx*, long long, const double* mass, double*, const double** out) { *out = mass; return DM_OK; }
 
 static int launch_transpose_f64(dm_ctx* ctx, int B, int N, int k, const double* X, int ld, double* out, int kpad, int Npad) {
-    dim3 grid(dm_cdiv(Npad, 64), dm_cdiv(kpad, 64), B);
-    DM_LAUNCH(ctx, "phiT", phiT_kernel<double>, grid, dim3(256), 0, X, N, k, ld, out, kpad, Npad, (double*)nullptr);
-    return DM_OK;
+    return dm_launch_phiT<double>(ctx, B, N, k, X, ld, out, kpad, Npad, nullptr);
 }
 
 // =================================================================================================
@@ -120,9 +136,9 @@ constexpr int EB_BK = 16;     // contraction per stage
 constexpr int EB_LD = 18;     // LDS row stride (f64): 36 dwords -> the 16 rows of a fragment read start on distinct 4-bank groups
 static inline size_t embed_lds(int RT) { return ((size_t)2 * (64 * RT + 64) * EB_LD + 3 * 64 + 4) * sizeof(double); }
 
-template <int RT, bool STORE>
+template <int RT, bool STORE, typename TR>
 __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __restrict__ Cm, long long strideC, int ldc, int transC,
-                                                         const float* __restrict__ Phi, long long stridePhi, int ld,
+                                                         const TR* __restrict__ Phi, long long stridePhi, int ld,
                                                          double* __restrict__ embT, int krpad, int Npad, int kr, int N, int K,
                                                          double* __restrict__ nrm, double* __restrict__ amax_part, int ntile_j,
                                                          int total, int nrg) {
@@ -136,18 +152,19 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
     const int srow = t >> 2, sk = (t & 3) * 4;             // staging: row srow (+ 64 q), contraction entries sk .. sk+3
     const int ns = (K + EB_BK - 1) / EB_BK;
     const bool fastA = !transC && ((ldc & 1) == 0) && ((strideC & 1) == 0) && ((((uintptr_t)Cm) & 15) == 0);
-    const bool fastB = ((ld & 3) == 0) && ((stridePhi & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0);
+    constexpr int amask = sizeof(TR) == 4 ? 3 : 1;       // 16-byte loads of the basis rows
+    const bool fastB = ((ld & amask) == 0) && ((stridePhi & amask) == 0) && ((((uintptr_t)Phi) & 15) == 0);
 
     // staged operands: kept exactly as loaded (the fp32 -> fp64 conversion happens when they are written to LDS one stage
     // later: converting at load time would make every fetch wait for its own data); pointers carry the global address
     // space so that the loads are global_load, not flat_load (a flat load also counts on lgkmcnt and would be waited for
     // by the fragment reads' lgkmcnt(0))
     typedef __attribute__((address_space(1))) const double gdouble;
-    typedef __attribute__((address_space(1))) const float gfloat;
+    typedef __attribute__((address_space(1))) const TR gfloat;
     typedef __attribute__((address_space(1))) const f64x2 gf64x2;
     typedef __attribute__((address_space(1))) const f32x4 gf32x4;
     double ra[RT][4];
-    float rb[4];
+    TR rb[4];
     // The operand fetch is a stream of stages that runs one stage ahead of the compute loop, across tile boundaries.  Its
     // position is kept as running pointers (one 64-bit add per operand row and stage: f64 MFMA shares the vector ALU, every
     // address instruction in the loop is paid in full).  Rows >= kr and vertices >= N only feed accumulator entries that
@@ -181,14 +198,19 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) ra[q][e] = fa[q][(long long)e * ldc];                \
                 }                                                                                                      \
             }                                                                                                          \
-            const f32x4 x_ = *(gf32x4*)fb;                                                                             \
-            rb[0] = x_[0]; rb[1] = x_[1]; rb[2] = x_[2]; rb[3] = x_[3];                                                \
+            if constexpr (sizeof(TR) == 4) {                                                                           \
+                const f32x4 x_ = *(gf32x4*)fb;                                                                         \
+                rb[0] = x_[0]; rb[1] = x_[1]; rb[2] = x_[2]; rb[3] = x_[3];                                            \
+            } else {                                                                                                   \
+                const f64x2 y0_ = ((gf64x2*)fb)[0], y1_ = ((gf64x2*)fb)[1];                                            \
+                rb[0] = y0_[0]; rb[1] = y0_[1]; rb[2] = y1_[0]; rb[3] = y1_[1];                                        \
+            }                                                                                                          \
         } else {                                                                                                       \
             const int k0_ = f_s * EB_BK + sk;                                                                          \
             _Pragma("unroll") for (int q = 0; q < RT; ++q)                                                             \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                          \
                     ra[q][e] = (k0_ + e < K) ? (transC ? fa[q][(long long)e * ldc] : fa[q][e]) : 0.0;                  \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) rb[e] = (k0_ + e < K) ? fb[e] : 0.0f;                        \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) rb[e] = (k0_ + e < K) ? fb[e] : (TR)0;                       \
         }                                                                                                              \
         _Pragma("unroll") for (int q = 0; q < RT; ++q) fa[q] += a_step;                                                \
         fb += EB_BK;                                                                                                   \
@@ -289,7 +311,8 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
 #undef EB_SET_TILE
 }
 
-int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi, int ld, const double* Cm, int ldc,
+template <typename TR>
+int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, int ld, const double* Cm, int ldc,
                     long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first,
                     double* amax_part) {
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
@@ -307,14 +330,14 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
 #define EB_LAUNCH(RT_)                                                                                                 \
     {                                                                                                                  \
         if (embT) {                                                                                                    \
-            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, true>, lds);                                \
+            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, true, TR>, lds);                                \
             if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, true>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
+            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, true, TR>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
                       (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg);        \
         } else {                                                                                                       \
-            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, false>, lds);                               \
+            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, false, TR>, lds);                               \
             if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, false>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
+            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, false, TR>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
                       (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg);        \
         }                                                                                                              \
     }
@@ -322,6 +345,10 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const float* Phi,
 #undef EB_LAUNCH
     return DM_OK;
 }
+template int dm_launch_embed<float>(dm_ctx*, int, int, int, int, const float*, int, const double*, int, long long, int, double*, int, int,
+                                    double*, int, double*);
+template int dm_launch_embed<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, int, long long, int, double*, int,
+                                     int, double*, int, double*);
 
 // =================================================================================================
 // fused G tile + arg-reductions
@@ -334,7 +361,7 @@ static_assert((4 * 2 * 128 + 4 * 2 * 128 / 2 + 4 * GX_WAVE) <= 2 * 2 * GBK * GLD
 
 struct gred_params {
     const double* AT; const double* BT;
-    const double* n1; const double* n2; const float* mass1;
+    const double* n1; const double* n2; const double* mass1;
     // per-tile partial results
     double* rv_knn; int32_t* rj_knn; double* rv_ind; int32_t* rj_ind;   // (B, tilesN, N2pad)
     double* cv_knn; int32_t* ci_knn; double* cv_ind; int32_t* ci_ind;   // (B, tilesM, N1pad)
@@ -733,14 +760,15 @@ int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a) {
 // =================================================================================================
 // C ABI
 // =================================================================================================
-extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,
-                            const float* Phi2, int ld2, const float* mass1, const double* C, int32_t* knn21,
-                            int32_t* knn12, int32_t* ind21, int32_t* ind12) {
+template <typename TR>
+static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR* Phi1, int ld1,
+                          const TR* Phi2, int ld2, const TR* mass1_in, const double* C, int32_t* knn21,
+                          int32_t* knn12, int32_t* ind21, int32_t* ind12) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi1 && Phi2 && C, "null input");
     DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
-    DM_REQUIRE(ctx, (!ind21 && !ind12) || mass1, "mass1 is needed for the indicator maps");
+    DM_REQUIRE(ctx, (!ind21 && !ind12) || mass1_in, "mass1 is needed for the indicator maps");
     if (!knn21 && !knn12 && !ind21 && !ind12) return DM_OK;
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
 
@@ -751,12 +779,12 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     const bool all = knn12 || ind21 || ind12;      // anything beyond knn21 takes the four-reduction kernel
     const size_t bytes_E2 = 0;                     // emb2 = Phi2 C is only needed for its row norms: never stored (embed_norm_kernel)
     // all four maps on interior sizes: two passes of the two-key fp16 tile kernel + exact re-evaluation (dm_knnsplit.hip)
-    const bool split = knn21 && knn12 && ind21 && ind12 && mass1 && dm_fm_split_ok(ctx, N2, N1, k2);
+    const bool split = knn21 && knn12 && ind21 && ind12 && mass1_in && dm_fm_split_ok(ctx, N2, N1, k2);
     const size_t bytes_amax = (size_t)B * dm_cdiv(N1pad, DM_EMB_COLS) * 8;
     const size_t bytes_zero = split ? dm_fm_split_zero_bytes(B) : 0;    // |Phi2| maxima and the per-pair bounds: one memset
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + dm_align_up(bytes_E2) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2pad * 8) +
-                        dm_align_up((size_t)B * N1 * 4) + dm_align_up(bytes_amax) + dm_align_up(bytes_zero) +
+                        dm_align_up((size_t)B * N1 * 8) + dm_align_up(bytes_amax) + dm_align_up(bytes_zero) +
                         (split ? dm_fm_split_ws_bytes(B, N2, N1, k2) : dm_gred_ws_bytes(B, N2, N1));
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
@@ -767,6 +795,10 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     double* n2 = (double*)dm_ws_take(ctx, (size_t)B * N2pad * 8);
     double* amaxS = (double*)dm_ws_take(ctx, bytes_amax);
     void* zeroed = bytes_zero ? dm_ws_take(ctx, bytes_zero) : nullptr;
+    double* massbuf = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);      // float64 masses (or zeros when none were given)
+    const double* mass1 = nullptr;
+    rc = dm_widen_mass(ctx, (long long)B * N1, mass1_in, massbuf, &mass1);
+    if (rc) return rc;
     if (!AT || !BT || (bytes_E2 && !E2) || !n1 || !n2 || !amaxS || (bytes_zero && !zeroed))
         return dm_fail(ctx, DM_ENOMEM, "fm_to_p2p: workspace not reserved");
     if (zeroed) DM_CHECK_HIP(ctx, hipMemsetAsync(zeroed, 0, bytes_zero, ctx->stream));
@@ -787,13 +819,23 @@ extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, 
     a.AT = AT; a.N2pad = N2pad; a.BT = BT; a.N1pad = N1pad; a.Kpad = Kpad;
     a.n1 = n1; a.n2 = all ? n2 : nullptr; a.mass1 = mass1;
     if (all && !mass1) {                      // nearest-neighbour maps only: the indicator values are never read
-        float* ones = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
-        DM_CHECK_HIP(ctx, hipMemsetAsync(ones, 0, (size_t)B * N1 * 4, ctx->stream));
-        a.mass1 = ones;
+        if (!massbuf) return dm_fail(ctx, DM_ENOMEM, "fm_to_p2p: workspace not reserved");
+        DM_CHECK_HIP(ctx, hipMemsetAsync(massbuf, 0, (size_t)B * N1 * 8, ctx->stream));
+        a.mass1 = massbuf;
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
-    if (split) { a.Ktrue = k2; return dm_launch_fm_split(ctx, a, amaxS, dm_cdiv(N1pad, DM_EMB_COLS), zeroed, Phi2, ld2); }
+    if (split) { a.Ktrue = k2; return dm_launch_fm_split<TR>(ctx, a, amaxS, dm_cdiv(N1pad, DM_EMB_COLS), zeroed, Phi2, ld2); }
     return dm_launch_gred(ctx, a);
+}
+extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,
+                            const float* Phi2, int ld2, const float* mass1, const double* C, int32_t* knn21,
+                            int32_t* knn12, int32_t* ind21, int32_t* ind12) {
+    return fm_to_p2p_impl<float>(ctx, B, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, mass1, C, knn21, knn12, ind21, ind12);
+}
+extern "C" int dm_fm_to_p2p_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const double* Phi1, int ld1,
+                                const double* Phi2, int ld2, const double* mass1, const double* C, int32_t* knn21,
+                                int32_t* knn12, int32_t* ind21, int32_t* ind12) {
+    return fm_to_p2p_impl<double>(ctx, B, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, mass1, C, knn21, knn12, ind21, ind12);
 }
 
 // which path dm_fm_to_p2p takes for these sizes on this context (bench.py names the dominant kernel accordingly)
@@ -841,14 +883,16 @@ struct OutRowMajorF64 {
     double* p; long long stride_b; int ld;
     __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] = v; }
 };
+template <typename TR>
 struct OutIndicator {
-    double* p; long long stride_b; int ld; const float* mass1; int N1;
+    double* p; long long stride_b; int ld; const TR* mass1; int N1;
     __device__ __forceinline__ void store(int b, int i, int j, double v) const {
         p[b * stride_b + (long long)i * ld + j] = v * (double)mass1[(long long)b * N1 + j];
     }
 };
-extern "C" int dm_mapped_indicator(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,
-                                   const float* Phi2, int ld2, const float* mass1, const double* C, double* M) {
+template <typename TR>
+static int mapped_indicator_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR* Phi1, int ld1,
+                                 const TR* Phi2, int ld2, const TR* mass1, const double* C, double* M) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && C && M, "null pointer");
@@ -860,20 +904,28 @@ extern "C" int dm_mapped_indicator(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     double* E2 = (double*)dm_ws_take(ctx, bE);
     // emb2[i][m] = sum_c Phi2[i][c] C[c][m]  ==  NT product of rows Phi2_i and rows (C^T)_m
     {
-        KRowsF32 opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
+        KRows<TR> opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
         KRowsF64 opb{C, (long long)k2 * k1, k1, k1, k2, 1};
         OutRowMajorF64 out{E2, (long long)N2 * k1, k1};
         dim3 grid(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
-        DM_LAUNCH(ctx, "emb2_nt_f64", (gemm_nt_f64<KRowsF32, KRowsF64, OutRowMajorF64>), grid, dim3(256), 0, opa, opb, out,
+        DM_LAUNCH(ctx, "emb2_nt_f64", (gemm_nt_f64<KRows<TR>, KRowsF64, OutRowMajorF64>), grid, dim3(256), 0, opa, opb, out,
                   N2, k1, k2);
     }
     {
         KRowsF64 opa{E2, (long long)N2 * k1, k1, N2, k1, 0};
-        KRowsF32 opb{Phi1, (long long)N1 * ld1, ld1, N1, k1};
-        OutIndicator out{M, (long long)N2 * N1, N1, mass1, N1};
+        KRows<TR> opb{Phi1, (long long)N1 * ld1, ld1, N1, k1};
+        OutIndicator<TR> out{M, (long long)N2 * N1, N1, mass1, N1};
         dim3 grid(dm_cdiv(N2, NT_T) * dm_cdiv(N1, NT_T), 1, B);
-        DM_LAUNCH(ctx, "indicator_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF32, OutIndicator>), grid, dim3(256), 0, opa, opb, out,
+        DM_LAUNCH(ctx, "indicator_nt_f64", (gemm_nt_f64<KRowsF64, KRows<TR>, OutIndicator<TR>>), grid, dim3(256), 0, opa, opb, out,
                   N2, N1, k1);
     }
     return DM_OK;
+}
+extern "C" int dm_mapped_indicator(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,
+                                   const float* Phi2, int ld2, const float* mass1, const double* C, double* M) {
+    return mapped_indicator_impl<float>(ctx, B, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, mass1, C, M);
+}
+extern "C" int dm_mapped_indicator_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const double* Phi1, int ld1,
+                                       const double* Phi2, int ld2, const double* mass1, const double* C, double* M) {
+    return mapped_indicator_impl<double>(ctx, B, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, mass1, C, M);
 }

@@ -30,7 +30,8 @@ struct OutDist {
 };
 
 // E1[b][v][:] = (double) Phi1[b][v][:k1];  one thread per element
-__global__ __launch_bounds__(256) void widen_rows_kernel(const float* __restrict__ Phi, int N, int ld, int k, double* __restrict__ out) {
+template <typename TR>
+__global__ __launch_bounds__(256) void widen_rows_kernel(const TR* __restrict__ Phi, int N, int ld, int k, double* __restrict__ out) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
     if (e >= (long long)N * k) return;
@@ -243,9 +244,10 @@ __global__ __launch_bounds__(256) void precise_project_kernel(const double* __re
     }
 }
 
-extern "C" int dm_precise_map(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int nf, const float* Phi1, int ld1,
-                              const float* Phi2, int ld2, const double* C, const int32_t* faces1, int32_t* face_match,
-                              double* bary, double* dense, int32_t* info) {
+template <typename TR>
+static int precise_map_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int nf, const TR* Phi1, int ld1,
+                            const TR* Phi2, int ld2, const double* C, const int32_t* faces1, int32_t* face_match,
+                            double* bary, double* dense, int32_t* info) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0 && nf > 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi1 && Phi2 && C && faces1 && face_match && bary && info, "null pointer");
@@ -266,12 +268,12 @@ extern "C" int dm_precise_map(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2
     int32_t* overflow = info;
     if (!E1 || !E2 || !D || !vs || !ps || !fc) return dm_fail(ctx, DM_ENOMEM, "precise map: workspace not reserved");
     DM_CHECK_HIP(ctx, hipMemsetAsync(overflow, 0, (size_t)B * 4, ctx->stream));
-    DM_LAUNCH(ctx, "precise_widen", widen_rows_kernel, dim3((unsigned)(((long long)N1 * k1 + 255) / 256), B), dim3(256), 0, Phi1, N1, ld1, k1, E1);
+    DM_LAUNCH(ctx, "precise_widen", widen_rows_kernel<TR>, dim3((unsigned)(((long long)N1 * k1 + 255) / 256), B), dim3(256), 0, Phi1, N1, ld1, k1, E1);
     {   // emb2 = Phi2 C   (convert.py:220, use_adj)
-        KRowsF32 opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
+        KRows<TR> opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
         KRowsF64 opb{C, (long long)k2 * k1, k1, k1, k2, 1};
         OutNTd out{E2, (long long)N2 * k1, k1};
-        DM_LAUNCH(ctx, "emb2_nt_f64", (gemm_nt_f64<KRowsF32, KRowsF64, OutNTd>), dim3(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
+        DM_LAUNCH(ctx, "emb2_nt_f64", (gemm_nt_f64<KRows<TR>, KRowsF64, OutNTd>), dim3(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
                   dim3(256), 0, opa, opb, out, N2, k1, k2);
     }
     DM_LAUNCH(ctx, "precise_sqnorm", row_sqnorm_kernel, dim3(dm_cdiv(N1, 256), B), dim3(256), 0, E1, N1, k1, vs);
@@ -290,6 +292,16 @@ extern "C" int dm_precise_map(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2
     DM_LAUNCH(ctx, "precise_project", precise_project_kernel, dim3(N2, B), dim3(256), lds, D, E1, E2, faces1, fc, N1, N2, k1, nf,
               face_match, bary, dense, overflow);
     return DM_OK;
+}
+extern "C" int dm_precise_map(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int nf, const float* Phi1, int ld1,
+                              const float* Phi2, int ld2, const double* C, const int32_t* faces1, int32_t* face_match,
+                              double* bary, double* dense, int32_t* info) {
+    return precise_map_impl<float>(ctx, B, N1, N2, k1, k2, nf, Phi1, ld1, Phi2, ld2, C, faces1, face_match, bary, dense, info);
+}
+extern "C" int dm_precise_map_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int nf, const double* Phi1, int ld1,
+                                  const double* Phi2, int ld2, const double* C, const int32_t* faces1, int32_t* face_match,
+                                  double* bary, double* dense, int32_t* info) {
+    return precise_map_impl<double>(ctx, B, N1, N2, k1, k2, nf, Phi1, ld1, Phi2, ld2, C, faces1, face_match, bary, dense, info);
 }
 
 // ---- k nearest neighbours, k > 1 (pyFM/spectral/nn_utils.py:4-38) ----------------------------------------------------

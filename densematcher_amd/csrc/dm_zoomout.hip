@@ -46,8 +46,9 @@ size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2) {
     return nsplit > 1 ? dm_align_up((size_t)nsplit * B * k2 * k1 * 8) + 4096 : 4096;
 }
 
-int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const float* Phi1,
-                        int ld1, const float* Phi2, int ld2, const float* mass2, double* C, int ldc,
+template <typename TR>
+int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
+                        int ld1, const TR* Phi2, int ld2, const double* mass2, double* C, int ldc,
                         long long strideC) {
     const int nsplit = fm_split(B, N2, k1, k2);
     const int kchunk = FM_KCHUNK;
@@ -56,11 +57,11 @@ int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, cons
         partial = (double*)dm_ws_take(ctx, (size_t)nsplit * B * k2 * k1 * 8);
         if (!partial) return dm_fail(ctx, DM_ENOMEM, "p2p_to_fm: workspace not reserved");
     }
-    RowsF32Scaled opx{Phi2, (long long)N2 * ld2, ld2, k2, nullptr, 0};
-    RowsF32GatherScaled opy{Phi1, (long long)N1 * ld1, ld1, k1, p21, (long long)N2, N1, mass2, (long long)N2};
+    RowsScaled<TR, double> opx{Phi2, (long long)N2 * ld2, ld2, k2, nullptr, 0};
+    RowsGatherScaled<TR, double> opy{Phi1, (long long)N1 * ld1, ld1, k1, p21, (long long)N2, N1, mass2, (long long)N2};
     OutFM out{nsplit > 1 ? nullptr : C, ldc, strideC, partial, B, k2, k1};
     dim3 grid(dm_cdiv(k2, TN_T) * dm_cdiv(k1, TN_T), nsplit, B);
-    DM_LAUNCH(ctx, "p2pfm_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF32GatherScaled, OutFM>), grid, dim3(256), 0, opx,
+    DM_LAUNCH(ctx, "p2pfm_tn_f64", (gemm_tn_f64<RowsScaled<TR, double>, RowsGatherScaled<TR, double>, OutFM>), grid, dim3(256), 0, opx,
               opy, out, k2, k1, N2, kchunk);
     if (nsplit > 1) {
         const long long n = (long long)B * k2 * k1;
@@ -69,27 +70,44 @@ int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, cons
     }
     return DM_OK;
 }
+template int dm_launch_p2p_to_fm<float>(dm_ctx*, int, int, int, int, int, const int32_t*, const float*, int, const float*, int,
+                                        const double*, double*, int, long long);
+template int dm_launch_p2p_to_fm<double>(dm_ctx*, int, int, int, int, int, const int32_t*, const double*, int, const double*, int,
+                                         const double*, double*, int, long long);
 
-extern "C" int dm_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const float* Phi1,
-                            int ld1, const float* Phi2, int ld2, const float* mass2, double* C) {
+template <typename TR>
+static int p2p_to_fm_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
+                          int ld1, const TR* Phi2, int ld2, const TR* mass2_in, double* C) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
-    DM_REQUIRE(ctx, p21 && Phi1 && Phi2 && mass2 && C, "null pointer");
+    DM_REQUIRE(ctx, p21 && Phi1 && Phi2 && mass2_in && C, "null pointer");
     DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = dm_ws_reserve(ctx, dm_p2pfm_ws_bytes(B, N2, k1, k2));
+    int rc = dm_ws_reserve(ctx, dm_p2pfm_ws_bytes(B, N2, k1, k2) + dm_align_up((size_t)B * N2 * 8));
     if (rc) return rc;
-    return dm_launch_p2p_to_fm(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, mass2, C, k1, (long long)k2 * k1);
+    const double* mass2 = nullptr;
+    rc = dm_widen_mass(ctx, (long long)B * N2, mass2_in, (double*)dm_ws_take(ctx, (size_t)B * N2 * 8), &mass2);
+    if (rc) return rc;
+    return dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, mass2, C, k1, (long long)k2 * k1);
+}
+extern "C" int dm_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const float* Phi1,
+                            int ld1, const float* Phi2, int ld2, const float* mass2, double* C) {
+    return p2p_to_fm_impl<float>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, mass2, C);
+}
+extern "C" int dm_p2p_to_fm_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const double* Phi1,
+                                int ld1, const double* Phi2, int ld2, const double* mass2, double* C) {
+    return p2p_to_fm_impl<double>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, mass2, C);
 }
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
-extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step, const float* Phi1, int ld1,
-                          const float* Phi2, int ld2, const float* mass2, const double* C0, double* Cout,
-                          int32_t* p21_out) {
+template <typename TR>
+static int zoomout_impl(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step, const TR* Phi1, int ld1,
+                        const TR* Phi2, int ld2, const TR* mass2_in, const double* C0, double* Cout,
+                        int32_t* p21_out) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k0 > 0 && nit >= 0 && step > 0, "sizes must be positive");
-    DM_REQUIRE(ctx, Phi1 && Phi2 && mass2 && C0 && Cout, "null pointer");
+    DM_REQUIRE(ctx, Phi1 && Phi2 && mass2_in && C0 && Cout, "null pointer");
     const int kf = k0 + nit * step;
     DM_REQUIRE(ctx, ld1 >= kf && ld2 >= kf, "not enough eigenvectors for k0 + nit*step (zoomout.py:87-92)");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
@@ -100,8 +118,12 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + 2 * dm_align_up(bytes_C) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2 * 4) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, kf) + dm_knn_split_ws_bytes(B, N2, N1, kf) +
-                        dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, kf, kf);
+                        dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, kf, kf) +
+                        dm_align_up((size_t)B * N2 * 8);
     int rc = dm_ws_reserve(ctx, need);
+    if (rc) return rc;
+    const double* mass2 = nullptr;
+    rc = dm_widen_mass(ctx, (long long)B * N2, mass2_in, (double*)dm_ws_take(ctx, (size_t)B * N2 * 8), &mass2);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bytes_AT);
     double* BT = (double*)dm_ws_take(ctx, bytes_BT);
@@ -114,7 +136,7 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
 
     // Phi2^T for all kf columns, once.  Row c of AT only enters G when c < current k because the
     // matching row of BT (emb1^T) is zero beyond the current map size.
-    rc = dm_launch_phiT(ctx, B, N2, kf, Phi2, ld2, AT, Kpad, N2pad);
+    rc = dm_launch_phiT<TR>(ctx, B, N2, kf, Phi2, ld2, AT, Kpad, N2pad);
     if (rc) return rc;
     // target side of the nearest-neighbour search (fp16 split of Phi2, all kf columns), once for the whole call
     dm_knn_split_state knn;
@@ -133,7 +155,7 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
         if (last && !p21_out) break;
         ctx->ws_off = ws_mark;
         // emb1 = Phi1[:, :k] C^T  ->  BT (rows >= k zero), n1
-        rc = dm_launch_embed(ctx, B, N1, k, k, Phi1, ld1, cur, k, (long long)k * k, 0, BT, Kpad, N1pad, n1, 0, amaxS);
+        rc = dm_launch_embed<TR>(ctx, B, N1, k, k, Phi1, ld1, cur, k, (long long)k * k, 0, BT, Kpad, N1pad, n1, 0, amaxS);
         if (rc) return rc;
         dm_gred_args a;
         a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = pad_to(k, 16); a.Ktrue = k;
@@ -144,11 +166,21 @@ extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, i
         if (rc) return rc;
         if (last) break;
         const int kn = k + step;
-        rc = dm_launch_p2p_to_fm(ctx, B, N1, N2, kn, kn, p21, Phi1, ld1, Phi2, ld2, mass2, nxt, kn, (long long)kn * kn);
+        rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, kn, kn, p21, Phi1, ld1, Phi2, ld2, mass2, nxt, kn, (long long)kn * kn);
         if (rc) return rc;
         double* tmp = cur; cur = nxt; nxt = tmp;
         k = kn;
     }
     DM_CHECK_HIP(ctx, hipMemcpyAsync(Cout, cur, (size_t)B * kf * kf * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return DM_OK;
+}
+extern "C" int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step, const float* Phi1, int ld1,
+                          const float* Phi2, int ld2, const float* mass2, const double* C0, double* Cout,
+                          int32_t* p21_out) {
+    return zoomout_impl<float>(ctx, B, N1, N2, k0, nit, step, Phi1, ld1, Phi2, ld2, mass2, C0, Cout, p21_out);
+}
+extern "C" int dm_zoomout_f64(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step, const double* Phi1, int ld1,
+                              const double* Phi2, int ld2, const double* mass2, const double* C0, double* Cout,
+                              int32_t* p21_out) {
+    return zoomout_impl<double>(ctx, B, N1, N2, k0, nit, step, Phi1, ld1, Phi2, ld2, mass2, C0, Cout, p21_out);
 }

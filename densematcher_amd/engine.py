@@ -6,9 +6,11 @@ torch tensors that live on the engine's GPU and hands their `data_ptr()` to the
 C ABI (include/densematch.h).  All arithmetic of the path runs in the HIP kernels.
 
 Batch layout (B pairs; pairs are independent):
-    Phi1 (B,N1,ld1) f32   Phi2 (B,N2,ld2) f32    eigenvectors (first k columns are used)
-    lam1 (B,k1) f64       lam2 (B,k2) f64        eigenvalues
-    a1 (B,N1) f32         a2 (B,N2) f32          lumped masses
+    Phi1 (B,N1,ld1) f32|f64  Phi2 (B,N2,ld2) f32|f64   eigenvectors (first k columns are used)
+    lam1 (B,k1) f64          lam2 (B,k2) f64           eigenvalues
+    a1 (B,N1) f32|f64        a2 (B,N2) f32|f64         lumped masses
+  (float64 eigenvectors / masses -- the reference's own dtype, pyFM/mesh/trimesh.py:118 -- take the *_f64 entry points
+   of the vertex-map, refinement and conversion calls; the projection consumes fp32 like the reference's fit does)
     F1 (B,N1,D) f16|f32   F2 (B,N2,D) f16|f32    descriptors
     C  (B,k2,k1) f64                              functional maps
     maps int32 on the device
@@ -66,6 +68,16 @@ class MatchEngine:
         if t.device != self.device or t.dtype != dtype or not t.is_contiguous():
             t = t.to(device=self.device, dtype=dtype).contiguous()
         return t
+
+    def _reals(self, *arrays):
+        """Eigenvector / mass arrays of one call on the device in ONE dtype: float64 if any of them is float64 (then the
+        *_f64 entry points run: the reference's arithmetic on its own inputs), else float32.  None entries pass through.
+        Returns (suffix, arrays...) with suffix "" or "_f64"."""
+        def dt(a):
+            return a.dtype if isinstance(a, torch.Tensor) else getattr(a, "dtype", None)
+        f64 = any(a is not None and str(dt(a)).endswith("float64") for a in arrays)
+        tdt = torch.float64 if f64 else torch.float32
+        return ("_f64" if f64 else "",) + tuple(None if a is None else self._dev(a, tdt, "real") for a in arrays)
 
     def synchronize(self):
         self.stream.synchronize()
@@ -140,14 +152,11 @@ class MatchEngine:
         return out
 
     def c00(self, Phi1, Phi2, a1, a2):
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
-        a1 = self._dev(a1, torch.float32, "a1")
-        a2 = self._dev(a2, torch.float32, "a2")
+        sfx, Phi1, Phi2, a1, a2 = self._reals(Phi1, Phi2, a1, a2)
         B, N1, ld1 = Phi1.shape
         _, N2, ld2 = Phi2.shape
         out = torch.empty((B,), dtype=torch.float64, device=self.device)
-        self._chk(self.lib.dm_fmap_c00(self.ctx, B, N1, N2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(a2), _ptr(out)))
+        self._chk(getattr(self.lib, "dm_fmap_c00" + sfx)(self.ctx, B, N1, N2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(a2), _ptr(out)))
         return out
 
     def fmap_solve(self, A, Bm, lam1, lam2, c00, w_descr, w_lap, check=True):
@@ -270,10 +279,8 @@ class MatchEngine:
 
     def fm_to_p2p(self, Phi1, Phi2, a1, Cm, k1=None, k2=None, knn=True, ind=True):
         """Returns dict with knn21, knn12 (kd-tree maps of the reference) and ind21, ind12 (indicator arg-max)."""
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        sfx, Phi1, Phi2, a1 = self._reals(Phi1, Phi2, a1)
         Cm = self._dev(Cm, torch.float64, "C")
-        a1 = self._dev(a1, torch.float32, "a1") if a1 is not None else None
         B, N1, ld1 = Phi1.shape
         _, N2, ld2 = Phi2.shape
         k2_, k1_ = Cm.shape[1], Cm.shape[2]
@@ -284,21 +291,19 @@ class MatchEngine:
         mk = lambda n: torch.empty((B, n), dtype=torch.int32, device=self.device)
         out = {"knn21": mk(N2) if knn else None, "knn12": mk(N1) if knn else None,
                "ind21": mk(N2) if ind else None, "ind12": mk(N1) if ind else None}
-        self._chk(self.lib.dm_fm_to_p2p(self.ctx, B, N1, N2, k1_, k2_, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(Cm),
+        self._chk(getattr(self.lib, "dm_fm_to_p2p" + sfx)(self.ctx, B, N1, N2, k1_, k2_, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(Cm),
                                         _ptr(out["knn21"]), _ptr(out["knn12"]), _ptr(out["ind21"]), _ptr(out["ind12"])))
         return out
 
     def p2p_to_fm(self, p21, Phi1, Phi2, a2, k1, k2):
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
-        a2 = self._dev(a2, torch.float32, "a2")
+        sfx, Phi1, Phi2, a2 = self._reals(Phi1, Phi2, a2)
         p21 = self._dev(p21, torch.int32, "p21")
         B, N1, ld1 = Phi1.shape
         _, N2, ld2 = Phi2.shape
         if p21.shape != (B, N2):
             raise ValueError("p2p_to_fm: p21 must be (B,N2)")
         Cm = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
-        self._chk(self.lib.dm_p2p_to_fm(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2), _ptr(Cm)))
+        self._chk(getattr(self.lib, "dm_p2p_to_fm" + sfx)(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2), _ptr(Cm)))
         return Cm
 
     def eigenbasis(self, W_list, mass, k, guard=32, degree=30, tol=1e-9, max_rounds=12, seed=0):
@@ -350,8 +355,7 @@ class MatchEngine:
     def precise_map(self, Phi1, Phi2, Cm, faces1, dense=False):
         """Barycentric projection of every vertex of mesh 2 onto the faces of mesh 1 in the spectral embedding (reference
         get_precise_map, functional.py:221-251).  Returns (face_match (B,N2) int32, bary (B,N2,3) f64[, dense (B,N2,N1) f64])."""
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        sfx, Phi1, Phi2 = self._reals(Phi1, Phi2)
         Cm = self._dev(Cm, torch.float64, "C")
         faces1 = self._dev(faces1, torch.int32, "faces1")
         B, N1, ld1 = Phi1.shape
@@ -364,7 +368,7 @@ class MatchEngine:
         bary = torch.empty((B, N2, 3), dtype=torch.float64, device=self.device)
         M = torch.empty((B, N2, N1), dtype=torch.float64, device=self.device) if dense else None
         info = torch.empty((B,), dtype=torch.int32, device=self.device)
-        self._chk(self.lib.dm_precise_map(self.ctx, B, N1, N2, k1, k2, nf, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(Cm), _ptr(faces1),
+        self._chk(getattr(self.lib, "dm_precise_map" + sfx)(self.ctx, B, N1, N2, k1, k2, nf, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(Cm), _ptr(faces1),
                                           _ptr(fm), _ptr(bary), _ptr(M), _ptr(info)))
         return (fm, bary, M) if dense else (fm, bary)
 
@@ -381,8 +385,7 @@ class MatchEngine:
 
     def p2p_to_fm_lstsq(self, p21, Phi1, Phi2, k1, k2):
         """argmin_X |Phi2[:, :k2] X - Phi1[p21, :k1]|_F (reference convert.py:51, no mass matrix) -> (B,k2,k1) f64."""
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        sfx, Phi1, Phi2 = self._reals(Phi1, Phi2)
         p21 = self._dev(p21, torch.int32, "p21")
         B, N1, ld1 = Phi1.shape
         _, N2, ld2 = Phi2.shape
@@ -390,7 +393,7 @@ class MatchEngine:
             raise ValueError("p2p_to_fm_lstsq: p21 must be (B,N2)")
         Cm = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
         info = torch.empty((B,), dtype=torch.int32, device=self.device)
-        self._chk(self.lib.dm_p2p_to_fm_lstsq(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(Cm),
+        self._chk(getattr(self.lib, "dm_p2p_to_fm_lstsq" + sfx)(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(Cm),
                                               _ptr(info)))
         bad = torch.nonzero(info).flatten()
         if bad.numel():
@@ -398,9 +401,7 @@ class MatchEngine:
         return Cm
 
     def zoomout(self, Phi1, Phi2, a2, C0, nit, step=1, return_p2p=False):
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
-        a2 = self._dev(a2, torch.float32, "a2")
+        sfx, Phi1, Phi2, a2 = self._reals(Phi1, Phi2, a2)
         C0 = self._dev(C0, torch.float64, "C0")
         B, N1, ld1 = Phi1.shape
         _, N2, ld2 = Phi2.shape
@@ -412,14 +413,13 @@ class MatchEngine:
         assert kf <= ld2, f"Not enough eigenvectors on target : {kf} are needed when {ld2} are provided"
         Cout = torch.empty((B, kf, kf), dtype=torch.float64, device=self.device)
         p21 = torch.empty((B, N2), dtype=torch.int32, device=self.device) if return_p2p else None
-        self._chk(self.lib.dm_zoomout(self.ctx, B, N1, N2, k0, nit, step, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2),
+        self._chk(getattr(self.lib, "dm_zoomout" + sfx)(self.ctx, B, N1, N2, k0, nit, step, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2),
                                       _ptr(C0), _ptr(Cout), _ptr(p21)))
         return (Cout, p21) if return_p2p else Cout
 
     def icp(self, Phi1, Phi2, C0, nit=10, return_resid=False):
         """Spectral ICP (reference pyFM/refine/icp.py) -> C (B,k2,k1) f64 with orthonormal columns."""
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
+        sfx, Phi1, Phi2 = self._reals(Phi1, Phi2)
         C0 = self._dev(C0, torch.float64, "C0")
         B, N1, ld1 = Phi1.shape
         _, N2, ld2 = Phi2.shape
@@ -427,7 +427,7 @@ class MatchEngine:
         Cout = torch.empty_like(C0)
         resid = torch.empty((B,), dtype=torch.float64, device=self.device)
         info = torch.empty((B,), dtype=torch.int32, device=self.device)
-        self._chk(self.lib.dm_icp(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(C0), int(nit), _ptr(Cout),
+        self._chk(getattr(self.lib, "dm_icp" + sfx)(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(C0), int(nit), _ptr(Cout),
                                   _ptr(resid), _ptr(info)))
         return (Cout, resid, info) if return_resid else Cout
 
@@ -456,15 +456,13 @@ class MatchEngine:
 
     def mapped_indicator(self, Phi1, Phi2, a1, Cm):
         """Dense (B,N2,N1) float64 indicator ((Phi2 C) Phi1^T) * a1 -- only for callers that want the matrix."""
-        Phi1 = self._dev(Phi1, torch.float32, "Phi1")
-        Phi2 = self._dev(Phi2, torch.float32, "Phi2")
-        a1 = self._dev(a1, torch.float32, "a1")
+        sfx, Phi1, Phi2, a1 = self._reals(Phi1, Phi2, a1)
         Cm = self._dev(Cm, torch.float64, "C")
         B, N1, ld1 = Phi1.shape
         _, N2, ld2 = Phi2.shape
         k2, k1 = Cm.shape[1], Cm.shape[2]
         M = torch.empty((B, N2, N1), dtype=torch.float64, device=self.device)
-        self._chk(self.lib.dm_mapped_indicator(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1),
+        self._chk(getattr(self.lib, "dm_mapped_indicator" + sfx)(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1),
                                                _ptr(Cm), _ptr(M)))
         return M
 

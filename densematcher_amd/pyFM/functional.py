@@ -168,7 +168,9 @@ class FunctionalMapping:
         else:
             A = eng.project(dev["Phi1"], dev["a1"], dev["F1"])
             B = eng.project(dev["Phi2"], dev["a2"], dev["F2"])
-            c00 = eng.c00(dev["Phi1"], dev["Phi2"], dev["a1"], dev["a2"])
+            # pinned entry from the float64 spectrum and masses (get_x0 is float64 host code in the reference, :654-658)
+            c00 = eng.c00(np.ascontiguousarray(m1.eigenvectors)[None], np.ascontiguousarray(m2.eigenvectors)[None],
+                        np.ascontiguousarray(m1.A.diagonal())[None], np.ascontiguousarray(m2.A.diagonal())[None])
             C = eng.fmap_solve(A, B, dev["lam1"], dev["lam2"], c00, w_descr, w_lap, check=True)
             self.FM = C[0].cpu().numpy()
         self.eta = np.ones(m2.eigenvectors.shape[0])                           # functional.py:483
@@ -207,8 +209,9 @@ class FunctionalMapping:
         """get_precise_map().toarray() kept on the GPU (compute_surface_map feeds it to the assignment kernel)"""
         from ..engine import default_engine
         k2, k1 = self.FM.shape
-        return default_engine().precise_map(np.ascontiguousarray(self.mesh1.eigenvectors[:, :k1], dtype=np.float32)[None],
-                                            np.ascontiguousarray(self.mesh2.eigenvectors[:, :k2], dtype=np.float32)[None],
+        from .spectral.convert import _basis, _real_dtype
+        dt = _real_dtype(self.mesh1.eigenvectors, self.mesh2.eigenvectors)
+        return default_engine().precise_map(_basis(self.mesh1.eigenvectors, k1, dt), _basis(self.mesh2.eigenvectors, k2, dt),
                                             np.asarray(self.FM, dtype=np.float64)[None],
                                             np.ascontiguousarray(self.mesh1.facelist, dtype=np.int32)[None], dense=True)[2][0]
 

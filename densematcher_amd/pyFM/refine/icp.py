@@ -6,11 +6,12 @@ import numpy as np
 
 def _run(FM_12, evects1, evects2, nit):
     from ...engine import default_engine
+    from ..spectral.convert import _basis, _real_dtype
     FM_12 = np.asarray(FM_12, dtype=np.float64)
     k2, k1 = FM_12.shape
     eng = default_engine()
-    C, resid, info = eng.icp(np.ascontiguousarray(evects1[:, :k1], dtype=np.float32)[None],
-                             np.ascontiguousarray(evects2[:, :k2], dtype=np.float32)[None], FM_12[None], nit, return_resid=True)
+    dt = _real_dtype(evects1, evects2)            # float64 eigenvectors: the float64-basis kernels (reference icp.py:36-40)
+    C, resid, info = eng.icp(_basis(evects1, k1, dt), _basis(evects2, k2, dt), FM_12[None], nit, return_resid=True)
     if int(info[0]) != 0:
         raise np.linalg.LinAlgError("ICP: Phi2^T Phi2 is not positive definite")
     if float(resid[0]) > 1e-8:

@@ -18,9 +18,10 @@ def _steps(step):
 
 def _knn21(eng, FM, evects1, evects2):
     """p2p_21 of upstream-pyFM FM_to_p2p: NN(tree = Phi1[:, :k1] C^T, query = Phi2[:, :k2])"""
+    from ..spectral.convert import _basis, _real_dtype
     k2, k1 = FM.shape
-    out = eng.fm_to_p2p(np.ascontiguousarray(evects1[:, :k1], dtype=np.float32)[None],
-                        np.ascontiguousarray(evects2[:, :k2], dtype=np.float32)[None], None, np.ascontiguousarray(FM)[None], knn=True, ind=False)
+    dt = _real_dtype(evects1, evects2)
+    out = eng.fm_to_p2p(_basis(evects1, k1, dt), _basis(evects2, k2, dt), None, np.ascontiguousarray(FM)[None], knn=True, ind=False)
     return out["knn21"]
 
 
@@ -29,27 +30,26 @@ def _run(FM_12, evects1, evects2, nit, step, A2, return_p2p):
     two step sizes, or A2 = None (least-squares p2p_to_FM, what the reference does on subsampled vertices): the same two
     GPU kernels per iteration, chained from the host like the reference chains its two calls (zoomout.py:40-42)."""
     from ...engine import default_engine
-    from ..spectral.convert import _diag_of
+    from ..spectral.convert import _basis, _diag_of, _real_dtype
+    dt = _real_dtype(evects1, evects2)
     step1, step2 = _steps(step)
     k2_0, k1_0 = FM_12.shape
     eng = default_engine()
     FM_12 = np.ascontiguousarray(FM_12, dtype=np.float64)
     if A2 is not None and step1 == step2 and k1_0 == k2_0:
-        a2 = _diag_of(A2, evects2.shape[0])
+        a2 = _diag_of(A2, evects2.shape[0]).astype(dt)
         kf = k1_0 + nit * step1
-        res = eng.zoomout(np.ascontiguousarray(evects1[:, :kf], dtype=np.float32)[None],
-                          np.ascontiguousarray(evects2[:, :kf], dtype=np.float32)[None], a2[None], FM_12[None], nit, step1,
-                          return_p2p=return_p2p)
+        res = eng.zoomout(_basis(evects1, kf, dt), _basis(evects2, kf, dt), a2[None], FM_12[None], nit, step1, return_p2p=return_p2p)
         if return_p2p:
             return res[0][0].cpu().numpy(), res[1][0].cpu().numpy().astype(np.int64)
         return res[0].cpu().numpy()
-    a2 = None if A2 is None else _diag_of(A2, evects2.shape[0])
+    a2 = None if A2 is None else _diag_of(A2, evects2.shape[0]).astype(dt)
     FM = FM_12
     for _ in range(nit):
         k2, k1 = FM.shape
         p21 = _knn21(eng, FM, evects1, evects2)
-        E1 = np.ascontiguousarray(evects1[:, :k1 + step1], dtype=np.float32)[None]
-        E2 = np.ascontiguousarray(evects2[:, :k2 + step2], dtype=np.float32)[None]
+        E1 = _basis(evects1, k1 + step1, dt)
+        E2 = _basis(evects2, k2 + step2, dt)
         if a2 is None:
             FM = eng.p2p_to_fm_lstsq(p21, E1, E2, k1 + step1, k2 + step2)[0].cpu().numpy()
         else:

@@ -16,7 +16,16 @@ def _diag_of(A, n):
         d = A if A.ndim == 1 else np.diag(A)
     if d.shape[0] != n:
         raise ValueError("Can't compute exact pseudo inverse with subsampled eigenvectors")
-    return np.ascontiguousarray(d, dtype=np.float32)
+    return np.ascontiguousarray(d, dtype=_real_dtype(d))
+
+
+def _real_dtype(*arrays):
+    """float64 inputs stay float64 (the reference's dtype; the *_f64 entry points of the library), anything else is fp32"""
+    return np.float64 if any(np.asarray(a).dtype == np.float64 for a in arrays if a is not None) else np.float32
+
+
+def _basis(evects, k, dtype):
+    return np.ascontiguousarray(np.asarray(evects)[:, :k], dtype=dtype)[None]
 
 
 class MappedIndicator:
@@ -71,9 +80,13 @@ def FM_to_p2p(FM_12, evects1, evects2, A1, use_adj=False, n_jobs=1):
     assert k1 <= evects1.shape[1], f'At least {k1} should be provided, here only {evects1.shape[1]} are given'
     assert k2 <= evects2.shape[1], f'At least {k2} should be provided, here only {evects2.shape[1]} are given'
     eng = default_engine()
-    Phi1 = eng._dev(np.ascontiguousarray(evects1[:, :k1], dtype=np.float32)[None], __import__("torch").float32, "Phi1")
-    Phi2 = eng._dev(np.ascontiguousarray(evects2[:, :k2], dtype=np.float32)[None], __import__("torch").float32, "Phi2")
     a1 = _diag_of(A1, evects1.shape[0])
+    # float64 eigenvectors (what TriMesh holds, like the reference) run the float64-basis kernels: the maps are those of
+    # convert.py:134-144 on the same numbers; an fp32 basis takes the fp32 entry points
+    dt = _real_dtype(evects1, evects2)
+    _, Phi1, Phi2 = eng._reals(_basis(evects1, k1, dt), _basis(evects2, k2, dt))
+    if a1 is not None:
+        a1 = a1.astype(dt)
     out = eng.fm_to_p2p(Phi1, Phi2, None if a1 is None else a1[None], FM_12[None], knn=True, ind=a1 is not None)
     p2p_21 = out["knn21"][0].cpu().numpy().astype(np.int64)
     p2p_12 = out["knn12"][0].cpu().numpy().astype(np.int64)
@@ -103,8 +116,8 @@ def mesh_FM_to_p2p_precise(FM_12, mesh1, mesh2, precompute_dmin=True, use_adj=Tr
     FM_12 = np.asarray(FM_12, dtype=np.float64)
     k2, k1 = FM_12.shape
     faces = np.ascontiguousarray(mesh1.facelist, dtype=np.int32)
-    fm, bary = default_engine().precise_map(np.ascontiguousarray(mesh1.eigenvectors[:, :k1], dtype=np.float32)[None],
-                                            np.ascontiguousarray(mesh2.eigenvectors[:, :k2], dtype=np.float32)[None], FM_12[None], faces[None])
+    dt = _real_dtype(mesh1.eigenvectors, mesh2.eigenvectors)
+    fm, bary = default_engine().precise_map(_basis(mesh1.eigenvectors, k1, dt), _basis(mesh2.eigenvectors, k2, dt), FM_12[None], faces[None])
     fm, bary = fm[0].cpu().numpy().astype(np.int64), bary[0].cpu().numpy()
     n2, n1 = mesh2.eigenvectors.shape[0], mesh1.eigenvectors.shape[0]
     rows = np.tile(np.arange(n2), 3)                                         # projection_utils.py:360-399
@@ -127,11 +140,12 @@ def p2p_to_FM(p2p_21, evects1, evects2, A2=None):
         idx = np.arange(pulled.shape[0], dtype=np.int32)
     else:
         pulled, idx = evects1, np.ascontiguousarray(p2p_21, dtype=np.int32)
-    P1 = np.ascontiguousarray(pulled, dtype=np.float32)[None]
-    P2 = np.ascontiguousarray(evects2, dtype=np.float32)[None]
+    dt = _real_dtype(pulled, evects2)
+    P1 = np.ascontiguousarray(pulled, dtype=dt)[None]
+    P2 = np.ascontiguousarray(evects2, dtype=dt)[None]
     if A2 is None:
         return eng.p2p_to_fm_lstsq(idx[None], P1, P2, k1, k2)[0].cpu().numpy()
-    a2 = _diag_of(A2, evects2.shape[0])
+    a2 = _diag_of(A2, evects2.shape[0]).astype(dt)
     return eng.p2p_to_fm(idx[None], P1, P2, a2[None], k1, k2)[0].cpu().numpy()
 
 

@@ -20,6 +20,11 @@
  *     mass-orthonormal Laplace-Beltrami eigenvectors, mass1/mass2 the diagonals
  *     of the lumped mass matrices, C is (k2 x k1) and maps basis-1
  *     coefficients to basis 2 (reference convention, pyFM/functional.py:482).
+ *   - eigenvectors and masses are fp32 in the plain entry points and fp64 in the `*_f64` ones (same argument lists,
+ *     `const double*` for Phi1 / Phi2 / mass): float64 is what the reference holds (pyFM/mesh/trimesh.py:118 float64
+ *     vertices -> float64 spectrum) and what its FM_to_p2p / p2p_to_FM / ICP / ZoomOut consume
+ *     (pyFM/spectral/convert.py:134-144), so the integer outputs of the `*_f64` forms equal the reference's on ITS inputs;
+ *     fp32 halves the operand traffic and is exact for bases that were rounded to fp32 anyway.
  *   - integer maps are int32 on the device (the Python layer widens to int64).
  *   - calls are asynchronous on the context's stream; the caller synchronises
  *     the stream before reading results.  A context is not thread-safe;
@@ -110,6 +115,9 @@ int dm_project(dm_ctx* ctx, int B, int N, int D, int k,
 int dm_fmap_c00(dm_ctx* ctx, int B, int N1, int N2,
                 const float* Phi1, int ld1, const float* Phi2, int ld2,
                 const float* mass1, const float* mass2, double* c00 /* B */);
+int dm_fmap_c00_f64(dm_ctx* ctx, int B, int N1, int N2,
+                    const double* Phi1, int ld1, const double* Phi2, int ld2,
+                    const double* mass1, const double* mass2, double* c00 /* B */);
 
 /* ---- functional-map solve -----------------------------------------------
  * Minimiser of  w_descr/2 |C A - Bm|^2 + w_lap/2 sum C_ij^2 ev_ij  with column
@@ -161,6 +169,13 @@ int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const float* Phi1, int ld1, const float* Phi2, int ld2,
                  const float* mass1, const double* C,
                  int32_t* knn21, int32_t* knn12, int32_t* ind21, int32_t* ind12);
+/* float64 eigenvectors and masses: the reference's own inputs (convert.py:134-144 runs on float64 evects and a float64
+ * sparse A1).  The fp16 first pass splits the float64 values directly; its error bound and the exact float64
+ * re-evaluation are the same, the masses enter the re-evaluation unrounded. */
+int dm_fm_to_p2p_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                     const double* Phi1, int ld1, const double* Phi2, int ld2,
+                     const double* mass1, const double* C,
+                     int32_t* knn21, int32_t* knn12, int32_t* ind21, int32_t* ind12);
 
 /* The "p2p_split" mode (1, 2, 3) dm_fm_to_p2p would take for these sizes with the context's options when all four maps
  * are requested, else 0 (the float64 G kernel).  Informational (bench.py reports the dominant kernel of the step); no
@@ -190,6 +205,9 @@ int dm_knn_query_topk_f64(dm_ctx* ctx, int B, int nx, int ny, int p, int k,
 int dm_mapped_indicator(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                         const float* Phi1, int ld1, const float* Phi2, int ld2,
                         const float* mass1, const double* C, double* M);
+int dm_mapped_indicator_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                            const double* Phi1, int ld1, const double* Phi2, int ld2,
+                            const double* mass1, const double* C, double* M);
 
 /* ---- vertex map -> functional map -----------------------------------------
  * C[b] = Phi2[b][:, :k2]^T (mass2[b] * Phi1[b][p21[b], :k1])   (k2 x k1) fp64.
@@ -197,6 +215,9 @@ int dm_mapped_indicator(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
 int dm_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const int32_t* p21, const float* Phi1, int ld1, const float* Phi2, int ld2,
                  const float* mass2, double* C);
+int dm_p2p_to_fm_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                     const int32_t* p21, const double* Phi1, int ld1, const double* Phi2, int ld2,
+                     const double* mass2, double* C);
 
 /* ---- Laplace-Beltrami eigenbasis -----------------------------------------------------
  * The k smallest eigenpairs of  W phi = lambda A phi  (Phi^T A Phi = I) for B meshes of N vertices each.
@@ -224,6 +245,9 @@ int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* ell_cols, c
 int dm_precise_map(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int nf,
                    const float* Phi1, int ld1, const float* Phi2, int ld2, const double* C,
                    const int32_t* faces1, int32_t* face_match, double* bary, double* dense /*nullable*/, int32_t* info);
+int dm_precise_map_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int nf,
+                       const double* Phi1, int ld1, const double* Phi2, int ld2, const double* C,
+                       const int32_t* faces1, int32_t* face_match, double* bary, double* dense /*nullable*/, int32_t* info);
 
 /* ---- linear assignment ------------------------------------------------------------
  * col_of_row[b][r] = column assigned to row r of cost[b] (nr x nc fp64, device), -1 for an unassigned row (nr > nc).
@@ -243,6 +267,9 @@ int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, const double* c
 int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                        const int32_t* p21, const float* Phi1, int ld1, const float* Phi2, int ld2,
                        double* C, int32_t* info);
+int dm_p2p_to_fm_lstsq_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+                           const int32_t* p21, const double* Phi1, int ld1, const double* Phi2, int ld2,
+                           double* C, int32_t* info);
 
 /* ---- ZoomOut ----------------------------------------------------------------
  * nit times: p21 = knn21(C_k); C_{k+step} = p2p_to_fm(p21) with k+step columns.
@@ -252,6 +279,9 @@ int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
 int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step,
                const float* Phi1, int ld1, const float* Phi2, int ld2,
                const float* mass2, const double* C0, double* Cout, int32_t* p21_out /*nullable*/);
+int dm_zoomout_f64(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step,
+                   const double* Phi1, int ld1, const double* Phi2, int ld2,
+                   const double* mass2, const double* C0, double* Cout, int32_t* p21_out /*nullable*/);
 
 /* ---- spectral ICP -------------------------------------------------------------
  * nit times: p21 = knn21(C); Chat = argmin |Phi2[:, :k2] X - Phi1[p21, :k1]|_F (no mass);
@@ -263,6 +293,9 @@ int dm_zoomout(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step,
 int dm_icp(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
            const float* Phi1, int ld1, const float* Phi2, int ld2,
            const double* C0, int nit, double* Cout, double* resid /*nullable*/, int32_t* info);
+int dm_icp_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
+               const double* Phi1, int ld1, const double* Phi2, int ld2,
+               const double* C0, int nit, double* Cout, double* resid /*nullable*/, int32_t* info);
 
 #ifdef __cplusplus
 }

@@ -64,3 +64,16 @@ def fx_cfg1_precise():
 @pytest.fixture(scope="session")
 def fx_cfg1_notebook_call():
     return load_golden("fx_cfg1_notebook_call.npz")
+
+
+@pytest.fixture(scope="session")
+def fx_cfg2_f64():
+    """config-2 shape on the reference's un-rounded float64 spectrum (tools/make_golden_r03.py)"""
+    fx = load_golden("fx_cfg2_f64.npz")
+    from densematcher_amd import synth
+    n = fx["Phi1"].shape[0]
+    s1, s2 = (int(x) for x in fx["feat_seeds"])
+    F1, F2, _ = synth.feature_pair(n, n, int(fx["D"]), s1, s2, sigma=float(fx["feat_sigma"]), perm="identity")
+    assert synth.sha256_of(F1, F2) == str(fx["feat_sha256"]), "regenerated descriptors differ from the fixture's"
+    fx["F1"], fx["F2"] = F1, F2
+    return fx
