@@ -28,6 +28,7 @@ SIGNATURES = {
     "dm_set_option": (_i, [_p, C.c_char_p, _i]),
     "dm_profile_kernel": (_i, [_p, C.c_char_p]),
     "dm_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(_d)]),
+    "dm_profile_report": (_i, [_p, C.c_char_p, C.c_size_t]),
     "dm_simnn_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dm_project": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
     "dm_fmap_c00": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),

@@ -72,6 +72,7 @@ extern "C" int dm_set_option(dm_ctx* ctx, const char* name, int value) {
     if (n == "simnn_pipe") ctx->opt_simnn_pipe = value;
     else if (n == "knn_split") ctx->opt_knn_split = value;
     else if (n == "solve_packed") ctx->opt_solve_packed = value;
+    else if (n == "solve_reg") ctx->opt_solve_reg = value;
     else if (n == "p2p_split") ctx->opt_p2p_split = value;
     else if (n == "simnn_persist") ctx->opt_simnn_persist = value;
     else return dm_fail(ctx, DM_EINVAL, "dm_set_option: unknown option '%s'", name);
@@ -118,7 +119,7 @@ extern "C" int dm_profile_kernel(dm_ctx* ctx, const char* name) {
 }
 
 int dm_prof_begin(dm_ctx* ctx, const char* name) {
-    if (ctx->prof_name.empty() || ctx->prof_name != name) return -1;
+    if (ctx->prof_name.empty() || (ctx->prof_name != "*" && ctx->prof_name != name)) return -1;
     if (ctx->prof_used + 2 > ctx->prof_events.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
@@ -127,6 +128,8 @@ int dm_prof_begin(dm_ctx* ctx, const char* name) {
         }
     }
     int tok = (int)ctx->prof_used;
+    if (ctx->prof_names.size() < ctx->prof_events.size() / 2) ctx->prof_names.resize(ctx->prof_events.size() / 2);
+    ctx->prof_names[tok / 2] = name;
     (void)hipEventRecord(ctx->prof_events[tok], ctx->stream);
     ctx->prof_used += 2;
     return tok;
@@ -151,6 +154,35 @@ extern "C" int dm_profile_read(dm_ctx* ctx, int* launches, double* total_ms) {
     }
     *launches = n;
     *total_ms = tot;
+    ctx->prof_used = 0;
+    return DM_OK;
+}
+
+// every launch since dm_profile_kernel(ctx, "*") (or the one named kernel), aggregated by name in order of first launch
+extern "C" int dm_profile_report(dm_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || cap == 0) return DM_EINVAL;
+    DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::string> names;
+    std::vector<int> count;
+    std::vector<double> total;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        float ms = 0.f;
+        DM_CHECK_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
+        const std::string n = ctx->prof_names[i / 2] ? ctx->prof_names[i / 2] : "?";
+        size_t q = 0;
+        while (q < names.size() && names[q] != n) ++q;
+        if (q == names.size()) { names.push_back(n); count.push_back(0); total.push_back(0.0); }
+        count[q] += 1;
+        total[q] += ms;
+    }
+    std::string out;
+    for (size_t q = 0; q < names.size(); ++q) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\t%d\t%.6f\n", names[q].c_str(), count[q], total[q]);
+        out += line;
+    }
+    if (out.size() + 1 > cap) return dm_fail(ctx, DM_EINVAL, "dm_profile_report: buffer of %zu bytes too small (%zu needed)", cap, out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
     ctx->prof_used = 0;
     return DM_OK;
 }

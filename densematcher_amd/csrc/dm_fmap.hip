@@ -723,6 +723,102 @@ __global__ __launch_bounds__(256) void fmap_solve_2phase_kernel(const double* __
     }
 }
 
+// =================================================================================================
+// Register-resident variant (n <= 128): one WAVE per system, the block triangle in VGPRs (dm_chol_reg.h), four independent
+// systems per CU (one per SIMD), no LDS image, no barriers.  NBT = block rows of the instantiation (the system is padded
+// with identity up to 16 NBT); the image the Gram kernel wrote has NBimg = ceil(n / 16) <= NBT block rows.
+// =================================================================================================
+#include "dm_chol_reg.h"
+
+template <int NBT>
+__global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __restrict__ PQ, const double* __restrict__ Timg,
+                                                                const double* __restrict__ lam1, const double* __restrict__ lam2,
+                                                                const double* __restrict__ c00, double w_lap, int k1, int k2, int NBimg,
+                                                                long long nsys, double* __restrict__ C, int32_t* __restrict__ info) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long sys = (long long)blockIdx.x * 4 + wave;
+    if (sys >= nsys) return;                                 // (no barriers in this kernel: waves are independent)
+    const int b = (int)(sys / k2), i = (int)(sys - (long long)b * k2);
+    const int n = k1 - 1, c = lane & 15, g = lane >> 4;
+    const double* P = PQ + (long long)b * (k1 + k2) * k1;
+    const double* Q = P + (long long)k1 * k1;
+    const double* l1 = lam1 + (long long)b * k1;
+    const double* l2 = lam2 + (long long)b * k2;
+    f64x4 T[NBT * (NBT + 1) / 2];
+    // ---- image: block (I, K), register r of lane l = entry 64 r + l of the block (the accumulator layout of the transposed block)
+    {
+        const double* img = Timg + (long long)b * (NBimg * (NBimg + 1) / 2) * 256 + lane;
+#pragma unroll
+        for (int I = 0; I < NBT; ++I)
+#pragma unroll
+            for (int K = 0; K <= I; ++K) {
+                f64x4 v = {0.0, 0.0, 0.0, 0.0};
+                if (I < NBimg) {                             // uniform
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = img[(long long)dmreg::blk(I, K) * 256 + 64 * r];
+                }
+                T[dmreg::blk(I, K)] = v;
+            }
+    }
+    // scale = max(lam1.max(), lam2.max())   (functional.py:404)
+    double mx = -DM_INF_F64;
+    for (int q = lane; q < k1; q += 64) mx = fmax(mx, l1[q]);
+    for (int q = lane; q < k2; q += 64) mx = fmax(mx, l2[q]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    const double scale = mx;
+    const double ci0 = (i == 0) ? c00[b] : 0.0;             // get_x0: column 0 is (c00, 0, ..., 0)^T
+    const double l2i = l2[i] / scale;
+    // ---- diagonal penalty w_lap ev[i][idx + 1] on the diagonal entries (lane (c, c & 3), register c >> 2 of block (I, I)),
+    // identity on the padding; right-hand side in the first row of block row NBT (lanes c == 0)
+#pragma unroll
+    for (int I = 0; I < NBT; ++I) {
+        const int idx = I * 16 + c;
+        double pen = 1.0;
+        if (idx < n) {
+            const double d = l1[idx + 1] / scale - l2i;
+            pen = w_lap * (d * d);
+        }
+        const bool mine = g == (c & 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool hit = mine && (c >> 2) == r;
+            const double cur = T[dmreg::blk(I, I)][r];
+            T[dmreg::blk(I, I)][r] = hit ? (idx < n ? cur + pen : 1.0) : cur;
+        }
+    }
+    double* Crow = C + ((long long)b * k2 + i) * k1;
+    // the right-hand side is fetched now, with the image, and waits in LDS (1 KiB per wave; wave-private, no barrier) until
+    // the forward substitution: loading it there would expose a global round trip in front of a dependent chain
+    __shared__ double sh_rhs[4][NBT * 16];
+    for (int q = lane; q < NBT * 16; q += 64)
+        sh_rhs[wave][q] = (q < n) ? Q[(long long)i * k1 + (q + 1)] - P[(long long)(q + 1) * k1] * ci0 : 0.0;
+    auto rhs = [&](int J) {
+        f64x4 rv = {0.0, 0.0, 0.0, 0.0};
+        if (c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = sh_rhs[wave][J * 16 + g + 4 * r];
+        }
+        return rv;
+    };
+    auto store = [&](int J, const f64x4& x) {
+        if (c == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ix = J * 16 + g + 4 * r;
+                if (ix < n) Crow[ix + 1] = x[r];
+            }
+        }
+    };
+    const bool solved = dmreg::solve<NBT>(T, rhs, store, lane);
+    if (!solved) {
+        if (lane == 0) atomicMax(&info[b], i + 1);
+        for (int q = lane; q < k1; q += 64) Crow[q] = (q == 0) ? ci0 : 0.0;
+        return;
+    }
+    if (lane == 0) Crow[0] = ci0;
+}
+
 extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const float* A, const float* Bm,
                              const double* lam1, const double* lam2, const double* c00, double w_descr, double w_lap,
                              double* C, int32_t* info) {
@@ -765,6 +861,20 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
         const long long nsys = (long long)B * k2;
         DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_2phase_kernel, dim3((unsigned)(nsys < grid2 ? nsys : grid2)), dim3(256), lds, PQ, Timg,
                   lam1, lam2, c00, w_lap, k1, k2, NB, B, spill, C, info);
+        return DM_OK;
+    }
+    if (blocked && !two_phase && NB <= 8 && ctx->opt_solve_reg) {
+        // register-resident solver: one wave per system, four systems per CU (dm_chol_reg.h)
+        const long long nsys = (long long)B * k2;
+        const dim3 grid((unsigned)((nsys + 3) / 4));
+#define DM_SOLVE_REG(NBT_)                                                                                             \
+        DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_reg_kernel<NBT_>, grid, dim3(256), 0, PQ, Timg, lam1, lam2, c00, w_lap, k1, k2, \
+                  NB, nsys, C, info)
+        if (NB <= 2) DM_SOLVE_REG(2);
+        else if (NB <= 4) DM_SOLVE_REG(4);
+        else if (NB <= 6) DM_SOLVE_REG(6);
+        else DM_SOLVE_REG(8);
+#undef DM_SOLVE_REG
         return DM_OK;
     }
     if (blocked) {

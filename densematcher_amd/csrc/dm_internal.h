@@ -28,6 +28,7 @@ struct dm_ctx {
     // kernel timing
     std::string prof_name;
     std::vector<hipEvent_t> prof_events;   // pairs (start, stop)
+    std::vector<const char*> prof_names;   // name of the launch each pair brackets (string literals of DM_LAUNCH)
     size_t prof_used = 0;                  // events used so far
 
     // largest dynamic-LDS size already granted to each kernel on this device (hipFuncSetAttribute is per device)
@@ -37,6 +38,7 @@ struct dm_ctx {
     int opt_simnn_pipe = 1;      // 0: every similarity tile goes through the bounds-checked register-staged kernel
     int opt_knn_split = 1;       // 0: knn21 (ZoomOut, ICP, knn_query) on the float64 G kernel instead of the fp16 split
     int opt_solve_packed = 0;    // 1: the packed-storage solver for every system size it supports
+    int opt_solve_reg = 1;       // 0: the LDS-resident blocked solver also where the register-resident one (n <= 128) would run
     int opt_p2p_split = 2;       // four maps: 0 the float64 G kernel, 1 two passes of the two-key fp16 tile kernel, 2 one pass reducing in both directions (3: 4-wave shape)
     int opt_simnn_persist = 1;   // 0: one workgroup per similarity tile instead of one persistent workgroup per CU
     int n_cu = 0;                // multiProcessorCount of the device

@@ -82,7 +82,7 @@ class MatchEngine:
     def synchronize(self):
         self.stream.synchronize()
 
-    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0}
+    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0, "solve_reg": 1}
 
     def set_option(self, name, value):
         """Choose between equivalent code paths of the library (include/densematch.h: dm_set_option); every setting
@@ -114,6 +114,16 @@ class MatchEngine:
         n, ms = C.c_int(0), C.c_double(0.0)
         self._chk(self.lib.dm_profile_read(self.ctx, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def profile_report(self):
+        """after profile_kernel("*"): {kernel name: (launches, total ms)} of every launch since, in order of first launch"""
+        buf = C.create_string_buffer(1 << 16)
+        self._chk(self.lib.dm_profile_report(self.ctx, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split("\t")
+            out[name] = (int(n), float(ms))
+        return out
 
     # ------------------------------------------------------------------ ops
     def simnn(self, Ftgt, Fsrc, return_scores=False):

@@ -72,6 +72,7 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *                           4 waves, 128 x 256 tiles, two workgroups per CU | two two-key passes | float64 G kernel
  *                           (all + exact float64 re-evaluation of the ambiguous rows; identical results)
  *   "solve_packed"  0 | 1   dm_fmap_solve: blocked LDS Cholesky when it fits | packed-storage solver always
+ *   "solve_reg"     1 | 0   dm_fmap_solve, k1 <= 129: register-resident solver (one wave per system) | the LDS-resident blocked one
  * Unknown names return DM_EINVAL.  The library never reads environment variables. */
 int dm_set_option(dm_ctx* ctx, const char* name, int value);
 
@@ -82,6 +83,11 @@ int dm_set_option(dm_ctx* ctx, const char* name, int value);
  * the last dm_profile_kernel call. */
 int dm_profile_kernel(dm_ctx* ctx, const char* name);
 int dm_profile_read(dm_ctx* ctx, int* launches, double* total_ms);
+/* dm_profile_kernel(ctx, "*") brackets EVERY launch; dm_profile_report then writes one line per kernel name,
+ * "name\tlaunches\ttotal_ms\n" in order of first launch, into buf (NUL-terminated; DM_EINVAL if cap is too small) and
+ * resets the record.  (The event pairs add a few microseconds between launches: bench.py times its K steps with one kernel
+ * bracketed and collects the per-kernel table in a separate, untimed pass.) */
+int dm_profile_report(dm_ctx* ctx, char* buf, size_t cap);
 
 /* ---- config 3: feature-similarity nearest neighbour ---------------------
  * nn21[b,i] = argmax_j <Ftgt[b,i,:], Fsrc[b,j,:]>   (lowest j on ties)
