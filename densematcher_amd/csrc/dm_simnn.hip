@@ -44,6 +44,7 @@ struct simnn_params {
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
     int ldT, ldS;                            // row strides (halves) of Ftgt / Fsrc, >= D, multiples of 8
+    int band;                                // tile rows per band of the tile order (simnn_decode)
     // two reductions of the same products (DUAL kernels, dm_knnsplit.hip: dm_launch_fm_split):
     //   key A = score + bias[j]  -> pb / pj / ps / pb32;   key B = score * scale[j] (DUAL 1) or score (DUAL 2) -> the *_2 arrays
     const float* bias; const float* scale;   // (B, N1) per source row
@@ -454,12 +455,23 @@ static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
            (dual == 3 ? 2 * 768 * 4 + 32 * 36 * 4 : (dual ? 2 * 512 * 4 : 0));
 }
 
+// Tile order inside a pair: bands of p.band tile rows, column-major inside a band.  The ~32 workgroups of an XCD work on
+// consecutive ids, i.e. on a (band x 32 / band) block of tiles that shares band + 32 / band operand panels (12 for band = 4,
+// 3.7 MB at a contraction depth of 608: inside the XCD's 4 MiB L2) and walks along the band, so a band's target panels stay
+// resident while each source panel is fetched once per band.  Row-major order (one tile row x 32 columns = 33 panels, 10 MB)
+// re-fetched every source panel for every tile row: 22.8 GB per launch at N = 8192 (profiles/r02_stress_hbm_traffic_pmc.csv).
+// The pass is NOT bound by that traffic, though: the banded order is 5 % faster at N = 8192 (dm_set_option "simnn_band");
+// the four reductions of the epilogue are half of the pass (tools/simnn4_experiment.py).
 __device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int& b, int& tt_, int& ts_) {
     const int tiles = p.tilesT * p.tilesS;
     b = id / tiles;
     const int tts = id - b * tiles;
-    tt_ = tts / p.tilesS;
-    ts_ = tts - tt_ * p.tilesS;
+    const int per_band = p.band * p.tilesS;
+    const int band = tts / per_band;
+    const int brow0 = band * p.band, brows = min(p.band, p.tilesT - brow0);
+    const int brem = tts - band * per_band;
+    ts_ = brem / brows;
+    tt_ = brow0 + (brem - ts_ * brows);
 }
 
 template <int XV, int WT, int DUAL = 0>
@@ -676,9 +688,19 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         }
         // the ring slot of the stage computed last takes no LDS-DMA before the next tile's first stage
         float* const free_slot = reinterpret_cast<float*>(smem + ((r_slot + NBUF - 1) % NBUF) * PSTAGE);
+#ifdef DM_EXPERIMENTS
+        if (DUAL && (p.dbg & 0x1000)) {                  // ablation (wrong results): no row-direction reduction
+            if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
+        } else
+#endif
         simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0, (DUAL == 3 ? 1 : DUAL)>(
             p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, SCR_IN_RING ? free_slot + NW * (32 * 36) : scratch, lane, wsrc, wtgt,
             bias_lds + (n & 1) * BSLOT);
+#ifdef DM_EXPERIMENTS
+        if (DUAL == 3 && (p.dbg & 0x2000)) {             // ablation (wrong results): no column-direction reduction
+            if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
+        } else
+#endif
         if (DUAL == 3) {
             // transposes go through the free slot (8 waves: seven of them, the eighth has its own buffer)
             float* tb = (WT == 4 && wave == 7) ? tb_extra : free_slot + wave * (32 * 36);
@@ -871,6 +893,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     p.ldT = ldT; p.ldS = ldS;
     p.tilesT = p.N2pad / ST; p.tilesS = dm_cdiv(N1, ST);
     p.total = B * p.tilesT * p.tilesS;
+    p.band = p.tilesT;                       // (edge kernel: row-major)
     p.dbg = dm_knob("DM_SIMNN_DEBUG", 0);
     const size_t np = (size_t)B * p.tilesS * p.N2pad;
     p.nsub = p.tilesS * (ST / 32);
@@ -940,6 +963,8 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         const int TT = 64 * WT;
         p.tilesT = p.N2pad / TT;
         p.total = B * p.tilesT * p.tilesS;
+        // tile order: bands of opt_simnn_band tile rows, column-major inside (0: one tile row per band = row-major order)
+        p.band = ctx->opt_simnn_band <= 0 ? 1 : (p.tilesT < ctx->opt_simnn_band ? p.tilesT : ctx->opt_simnn_band);
         const size_t lds_pipe = simnn_pipe_lds(WT, cols ? 3 : (dual ? 1 : 0));
         // workgroups that fit a CU at once walk the tiles (opt_simnn_persist: 0 = one workgroup per tile, 1 = as many
         // workgroups as are resident when there are more tiles than that, n > 1 = n workgroups (tests))

@@ -72,6 +72,7 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *                           4 waves, 128 x 256 tiles, two workgroups per CU | two two-key passes | float64 G kernel
  *                           (all + exact float64 re-evaluation of the ambiguous rows; identical results)
  *   "solve_packed"  0 | 1   dm_fmap_solve: blocked LDS Cholesky when it fits | packed-storage solver always
+ *   "simnn_band"    4 | n   tile order of the similarity kernels: bands of n tile rows, column-major inside (0: row-major)
  *   "solve_reg"     1 | 0   dm_fmap_solve, k1 <= 129: register-resident solver (one wave per system) | the LDS-resident blocked one
  * Unknown names return DM_EINVAL.  The library never reads environment variables. */
 int dm_set_option(dm_ctx* ctx, const char* name, int value);
