@@ -16,9 +16,14 @@ data-path collective); the process group (RCCL) is used only for the timing barr
 external torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
 Prints ONE JSON line (rank 0) with the driver's contract keys plus
-    roofline      dominant kernel of the workload, HIP-event timed inside the timed region
-    secondary     (default workload only) the feature-similarity kernel of configs[2] measured the same way:
-                  north_star's ">= 60 % of the 16-bit MFMA roofline" target refers to that kernel
+    roofline      the kernel that takes the largest share of the step (per-kernel HIP-event table of an untimed pass of the
+                  same step; its launch time inside the timed region), priced on SURVEY 8(d)'s ALGORITHMIC flops against the
+                  spec peak of the arithmetic it runs in, with
+                    .peak_measured     on-box probes (dm_measure_peak): fp16 MFMA on zero and on N(0,1) operands, f64 MFMA, copy
+                    .kernels[]         every kernel above 2 % of the step: avg ms, share, algorithmic / executed flops, frac
+                    .config3_simnn     (default workload) the feature-similarity kernel of configs[2], same method:
+                                       north_star's ">= 60 % of the 16-bit MFMA roofline" target refers to that kernel
+                    .config5_stress    (default workload) configs[4] (N = 8192, k = 200), 3 steps
     parity        (default workload only) |C_gpu - C_f64| and |C_gpu - C_fit| on the committed config-2 fixture
     cpu_baseline  the NumPy oracle timed on this box's host cores on a bounded sample of the same workload:
                   the closed-form port and a reference-faithful variant (kd-tree NN, dense indicator, L-BFGS-B)
@@ -56,6 +61,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="fmap", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--basis", default="f64", choices=["f64", "f32"],
+                    help="dtype of the eigenvectors and masses handed to the path: f64 = what the reference holds and consumes "
+                         "(TriMesh / FM_to_p2p run on float64; the *_f64 entry points), f32 = pre-rounded inputs (round-1/2 benches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] similarity-kernel block of the default workload")
     ap.add_argument("--p2p-split", type=int, default=None,
@@ -80,14 +88,15 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def make_batch(w, rank):
+def make_batch(w, rank, basis="f64"):
     from densematcher_amd import synth
     n = w["nu"] * w["nv"]
+    rdt = np.float64 if basis == "f64" else np.float32
     if w["k"]:
         # N = 8192: a mass-orthonormalised seeded Gaussian stands in for the eigenbasis (throughput-only
         # runs; an ARPACK solve per mesh would dominate the set-up and the arithmetic does not depend on it)
         batch = synth.make_pair_batch(w["B"], w["nu"], w["nv"], max(w["D"], 8), w["k"], sigma=0.1, n_distinct_meshes=2,
-                                      seed0=100 * rank, basis="eig" if n <= 4096 else "random")
+                                      seed0=100 * rank, basis="eig" if n <= 4096 else "random", real_dtype=rdt)
     else:
         batch = simnn_features(w["B"], n, w["D"], rank)
     return batch
@@ -102,6 +111,77 @@ def simnn_features(B, n, D, rank):
 
 
 PREHEAT_S = 0.25
+
+
+def kernel_models(N, D, k, B, eng):
+    """SURVEY.md 8(d) algorithmic work of the step's kernels, per LAUNCH (B pairs), keyed by the DM_LAUNCH name.
+    dtype = the arithmetic the kernel runs in (its spec peak prices `frac`); executed = what the matrix cores actually
+    issue where that differs from the algorithmic count (fp16 split: three products per float64 index, padded)."""
+    n = k - 1
+    kd = -(-3 * k // 32) * 32 if k else 0
+    return {
+        "fmap_solve_chol": dict(dtype="f64", bound="mfma", what="k2 SPD solves of order k1-1 per pair: k (n^3/3 + 2 n^2)",
+                                flops=B * k * (n ** 3 / 3.0 + 2.0 * n * n)),
+        "simnn4_f16_mfma": dict(dtype="f16", bound="mfma", what="G = Phi2 C Phi1^T and its four arg-reductions: 2 N^2 k (float64 flops of the reference)",
+                                flops=2.0 * N * N * k * B, executed=2.0 * N * N * kd * B),
+        "simnn2_f16_mfma": dict(dtype="f16", bound="mfma", what="one direction of G: 2 N^2 k", flops=2.0 * N * N * k * B, executed=2.0 * N * N * kd * B),
+        "gred_f64": dict(dtype="f64", bound="mfma", what="G = Phi2 C Phi1^T: 2 N^2 k", flops=2.0 * N * N * k * B),
+        "simnn_f16_mfma": dict(dtype="f16", bound="mfma", what="S = Ftgt Fsrc^T: 2 N^2 D", flops=2.0 * N * N * D * B),
+        "embed_nt_f64": dict(dtype="f64", bound="mfma", what="one embedding Phi C^T (or Phi C): 2 N k^2", flops=2.0 * N * k * k * B),
+        "project_f16split_mfma": dict(dtype="f16", bound="mfma", what="one projection Phi^T (a F): 2 k N D", flops=2.0 * k * N * D * B,
+                                      executed=4.0 * k * N * D * B),
+        "gram_nt_f64": dict(dtype="f64", bound="mfma", what="[A; B] A^T: 2 (2 k^2 D)", flops=4.0 * k * k * D * B),
+        "p2pfm_tn_f64": dict(dtype="f64", bound="mfma", what="Phi2^T (a2 Phi1[p]): 2 N k^2", flops=2.0 * N * k * k * B),
+    }
+
+
+def kernel_table(eng, step, n_steps, models, workload, min_share=0.02):
+    """Untimed pass of the same step with every launch bracketed by HIP events (dm_profile_kernel "*"): per kernel name the
+    launches per step, average duration, share of the summed kernel time and -- where SURVEY 8(d) gives the kernel's
+    algorithmic work -- achieved rate and fraction of the spec peak."""
+    import torch
+    step()
+    torch.cuda.synchronize()
+    eng.profile_kernel("*")
+    for _ in range(n_steps):
+        step()
+    rep = eng.profile_report()
+    eng.profile_kernel("")
+    total = sum(ms for _, ms in rep.values()) or 1.0
+    rows = []
+    for name, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
+        avg = ms / n
+        row = {"name": name, "launches_per_step": round(n / n_steps, 2), "avg_launch_ms": round(avg, 4), "share_of_step": round(ms / total, 4)}
+        m = models.get(name)
+        if m:
+            peak = PEAK_TFLOPS[m["dtype"]]
+            ach = m["flops"] / (avg * 1e-3) / 1e12
+            row.update(bound=m["bound"], dtype=m["dtype"], algorithmic_flops_per_launch=m["flops"], achieved=round(ach, 3),
+                       peak=peak, frac=round(ach / peak, 4), algorithmic_work=m["what"])
+            if "executed" in m:
+                row["executed_flops_per_launch"] = m["executed"]
+                row["frac_executed"] = round(m["executed"] / (avg * 1e-3) / 1e12 / peak, 4)
+        traffic, tfile = pmc_traffic_bytes(name, workload) if workload else (None, None)
+        if traffic:
+            row["traffic"] = traffic
+            row["traffic_file"] = "profiles/" + tfile
+        if ms / total >= min_share:
+            rows.append(row)
+    return rows, total / n_steps, sum(n for n, _ in rep.values()) / n_steps
+
+
+_PEAKS = {}
+
+
+def measured_peaks(eng):
+    """on-box probes, once per process (about 0.2 s): TFLOP/s and GB/s"""
+    if not _PEAKS:
+        for nm in ("mfma_f16_zero_operands", "mfma_f16_random_operands", "mfma_f64"):
+            _PEAKS[nm + "_tflops"] = round(eng.measure_peak(nm) / 1e12, 1)
+        _PEAKS["hbm_copy_gbs"] = round(eng.measure_peak("hbm_copy") / 1e9, 0)
+        _PEAKS["note"] = ("fp16 MFMA: zero operands run at 2.4 GHz (issue ceiling = the guide's 2.5 PF), N(0,1) operands at ~1.7 GHz "
+                          "(power): the second is the ceiling of a kernel that multiplies real data (tools/ubench_mfma_clock.hip)")
+    return dict(_PEAKS)
 
 
 def timed_kernel(eng, step, kernel, steps, warmup, barrier):
@@ -154,7 +234,7 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.batch:
         w["B"] = args.batch
-    host = make_batch(w, rank)
+    host = make_batch(w, rank, args.basis)
     eng = MatchEngine(local_rank)
     if args.p2p_split is not None:
         eng.set_option("p2p_split", args.p2p_split)
@@ -163,28 +243,17 @@ def main():
     B, D, k = w["B"], w["D"], w["k"]
     extra = {}
 
+    models = kernel_models(N, max(D, 1), k, B, eng)
     if args.workload in ("fmap", "stress"):
         def step():
             return eng.match(dev, k=k)
         split = eng.p2p_split_active(N, N, k)
-        if split:
-            kernel, dtype = ("simnn4_f16_mfma" if split >= 2 else "simnn2_f16_mfma"), "f16"
-            kd = -(-3 * k // 32) * 32
-            flops_per_launch = 2.0 * N * N * kd * B
-            extra = {"launches_per_step": 1 if split >= 2 else 2, "algorithmic_f64_flops_per_step": 2.0 * N * N * k * B,
-                     "note": ("four maps = ONE pass of the fp16 tile kernel reducing every tile in both directions (knn21+ind21 along "
-                              "the sources, knn12+ind12 along the targets, transposed through LDS)" if split >= 2 else
-                              "four maps = two passes of the two-key fp16 tile kernel (knn21+ind21, knn12+ind12)") +
-                             " + exact float64 re-evaluation of the ambiguous rows; achieved/peak count the fp16 flops one pass executes "
-                             "(3 products per contraction index, padded to 32); algorithmic_f64_flops_per_step is SURVEY 8(d)'s 2 N^2 k"}
-        else:
-            kernel, dtype = "gred_f64", "f64"
-            flops_per_launch = 2.0 * N * N * k * B                  # G = Phi2 C Phi1^T, SURVEY 8(d): 2 N^2 k per pair
+        maps_kernel = ("simnn4_f16_mfma" if split >= 2 else "simnn2_f16_mfma") if split else "gred_f64"
+        dtype = "f16" if split else "f64"
     elif args.workload == "simnn":
         def step():
             return eng.simnn(dev["F2"], dev["F1"])
-        kernel, dtype = "simnn_f16_mfma", "f16"
-        flops_per_launch = 2.0 * N * N * D * B                      # 2 N2 N1 D per pair
+        dtype = "f16"
     elif args.workload == "icp":
         gen = torch.Generator(device=eng.device).manual_seed(1 + rank)
         C0 = torch.eye(k, dtype=torch.float64, device=eng.device).repeat(B, 1, 1) \
@@ -192,22 +261,26 @@ def main():
 
         def step():
             return eng.icp(dev["Phi1"], dev["Phi2"], C0, nit=10)
-        kernel, dtype = "simnn_f16_mfma", "f16"
-        flops_per_launch = 2.0 * N * N * eng.split_depth(k) * B     # fp16 depth of the split features (dm_knnsplit.hip)
+        dtype = "f16"
+        models["simnn_f16_mfma"] = dict(dtype="f16", bound="mfma", what="nearest-neighbour search of one ICP iteration: 2 N^2 k (float64 flops of the reference)",
+                                         flops=2.0 * N * N * k * B, executed=2.0 * N * N * eng.split_depth(k) * B)
     else:
         k0, nit = 50, 150
         C0 = torch.eye(k0, dtype=torch.float64, device=eng.device).repeat(B, 1, 1)
 
         def step():
             return eng.zoomout(dev["Phi1"], dev["Phi2"], dev["a2"], C0, nit=nit, step=1)
-        # dominant kernel: the fp16-split first pass of the nearest-neighbour search (dm_knnsplit.hip)
-        kernel, dtype = "simnn_f16_mfma", "f16"
+        dtype = "f16"
         ks = range(50, 200)
-        # what the fp16 matrix cores execute: three fp16 products per contraction index (hi*hi, hi*lo, lo*hi) plus
-        # three bias entries, padded to the 32-wide stage
-        flops_per_launch = sum(2.0 * N * N * eng.split_depth(kk) * B for kk in ks) / 150.0
-        extra = {"algorithmic_f64_flops_per_launch": sum(2.0 * N * N * kk * B for kk in ks) / 150.0,   # 2 N^2 k
-                 "note": "achieved/peak count the fp16 flops the split executes (3x the algorithmic 2N^2k + padding)"}
+        # the fp16-split first pass of the nearest-neighbour search (dm_knnsplit.hip): algorithmic 2 N^2 k per iteration,
+        # executed three fp16 products per contraction index plus the bias entries, padded to the 32-wide stage
+        models["simnn_f16_mfma"] = dict(dtype="f16", bound="mfma", what="nearest-neighbour search of one ZoomOut iteration: 2 N^2 k, mean over k = 50 .. 199",
+                                         flops=sum(2.0 * N * N * kk * B for kk in ks) / 150.0,
+                                         executed=sum(2.0 * N * N * eng.split_depth(kk) * B for kk in ks) / 150.0)
+        models["p2pfm_tn_f64"] = dict(dtype="f64", bound="mfma", what="p2p_to_FM of one iteration: 2 N (k+1)^2, mean over k",
+                                       flops=sum(2.0 * N * (kk + 1) ** 2 * B for kk in ks) / 150.0)
+        models["embed_nt_f64"] = dict(dtype="f64", bound="mfma", what="embedding of one iteration: 2 N k^2, mean over k",
+                                       flops=sum(2.0 * N * kk * kk * B for kk in ks) / 150.0)
 
     def barrier():
         if dist is not None:
@@ -221,7 +294,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    elapsed, launches, kernel_ms = timed_kernel(eng, step, kernel, args.steps, args.warmup, barrier)
+    # which kernel dominates the step: per-kernel table of an untimed pass (every launch bracketed by HIP events)
+    table_steps = 1 if args.workload == "zoomout" else 5
+    wl_tag = args.workload if not args.batch else None
+    table, kernel_ms_per_step, launches_per_step = kernel_table(eng, step, table_steps, models, wl_tag)
+    dominant = table[0]["name"]
+
+    elapsed, launches, kernel_ms = timed_kernel(eng, step, dominant, args.steps, args.warmup, barrier)
     elapsed = max_over_ranks(elapsed)
 
     value = B * world * args.steps / elapsed
@@ -232,22 +311,18 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "ms_per_pair": round(1e3 * elapsed / (B * args.steps), 5),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": w["cfg"], "pairs_per_gpu": B, "N": N, "D": D, "k": k,
+                   "basis_dtype": str(host["Phi1"].dtype) if "Phi1" in host else None,
                    "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective"},
-        "roofline": roofline_block(kernel, dtype, flops_per_launch, launches, avg_ms, args.workload if not args.batch else None, extra),
+        "roofline": roofline_block(dominant, models.get(dominant), launches, avg_ms, wl_tag, table, kernel_ms_per_step, launches_per_step, eng),
     }
 
     if args.workload == "fmap" and not args.batch:
         if not args.no_secondary:
-            # the other kernel of the step that is as long as the tile pass: the batched SPD solves (a chain of serial
-            # pivots: latency-bound, priced here against the f64 matrix-core peak for what it is worth)
-            _, sl, sms = timed_kernel(eng, step, "fmap_solve_chol", 5, 0, barrier)
-            n_ = k - 1
-            sflops = B * k * (n_ ** 3 / 3.0 + 2.0 * n_ * n_)
-            solver = {"kernel": "fmap_solve_chol", "bound": "latency (serial pivots)", "avg_launch_ms": round(sms / max(sl, 1), 4),
-                      "launches": sl, "algorithmic_flops_per_launch": sflops, "unit": "TFLOP/s",
-                      "achieved": round(sflops / (sms / max(sl, 1) * 1e-3) / 1e12, 3) if sl else None, "peak": PEAK_TFLOPS["f64"]}
-            solver["frac"] = round(solver["achieved"] / solver["peak"], 4) if solver["achieved"] else None
-            out["secondary"] = {"simnn": secondary_simnn(eng, rank, barrier, max_over_ranks, world), "solver": solver}
+            out["roofline"]["config3_simnn"] = secondary_simnn(eng, rank, barrier, max_over_ranks, world)
+            if world == 1:
+                del dev
+                torch.cuda.empty_cache()
+                out["roofline"]["config5_stress"] = secondary_stress(eng, rank, barrier)
         if rank == 0:
             out["parity"] = parity_block(eng)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -258,15 +333,33 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_block(kernel, dtype, flops_per_launch, launches, avg_ms, workload, extra):
-    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None
-    peak = PEAK_TFLOPS[dtype]
+def roofline_block(kernel, model, launches, avg_ms, workload, table, kernel_ms_per_step, launches_per_step, eng):
+    """`achieved` = SURVEY 8(d) ALGORITHMIC flops of one launch / its average duration inside the timed region; `peak` = the spec
+    peak of the arithmetic the kernel runs in (MI355X_MICROARCH.md); the flops the matrix cores really execute (fp16 split) and
+    the on-box measured peaks are separate keys."""
     traffic, traffic_file = pmc_traffic_bytes(kernel, workload) if workload else (None, None)
-    return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 3) if achieved else None, "peak": peak,
-            "unit": "TFLOP/s", "frac": round(achieved / peak, 4) if achieved else None, "traffic": traffic,
-            "traffic_source": f"HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/{traffic_file}: "
-                              "2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)" if traffic else None,
-            "launches": launches, "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops_per_launch, **extra}
+    out = {"bound": "mfma", "kernel": kernel, "launches": launches, "avg_launch_ms": round(avg_ms, 4),
+           "kernel_ms_per_step": round(kernel_ms_per_step, 4), "launches_per_step": round(launches_per_step, 1)}
+    if model and launches:
+        peak = PEAK_TFLOPS[model["dtype"]]
+        ach = model["flops"] / (avg_ms * 1e-3) / 1e12
+        out.update(achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), dtype=model["dtype"],
+                   algorithmic_flops_per_launch=model["flops"], algorithmic_work=model["what"])
+        if "executed" in model:
+            out["executed_flops_per_launch"] = model["executed"]
+            out["frac_executed"] = round(model["executed"] / (avg_ms * 1e-3) / 1e12 / peak, 4)
+    else:
+        out.update(achieved=None, peak=None, unit="TFLOP/s", frac=None)
+    out["traffic"] = traffic
+    out["traffic_source"] = (f"HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/{traffic_file}: 2 x FETCH_SIZE + "
+                             "WRITE_SIZE, gfx950 correction)") if traffic else None
+    out["peak_measured"] = measured_peaks(eng)
+    if out.get("achieved") and model["dtype"] == "f16":
+        out["frac_of_measured_peak_random_operands"] = round(out["achieved"] / out["peak_measured"]["mfma_f16_random_operands_tflops"], 4)
+    if out.get("achieved") and model["dtype"] == "f64":
+        out["frac_of_measured_peak"] = round(out["achieved"] / out["peak_measured"]["mfma_f64_tflops"], 4)
+    out["kernels"] = table
+    return out
 
 
 def secondary_simnn(eng, rank, barrier, max_over_ranks, world):
@@ -282,9 +375,38 @@ def secondary_simnn(eng, rank, barrier, max_over_ranks, world):
     elapsed, launches, kernel_ms = timed_kernel(eng, lambda: eng.simnn(F2, F1), "simnn_f16_mfma", steps, warmup, barrier)
     elapsed = max_over_ranks(elapsed)
     avg_ms = kernel_ms / max(launches, 1)
+    flops = 2.0 * n * n * D * B
+    ach = flops / (avg_ms * 1e-3) / 1e12
+    traffic, tfile = pmc_traffic_bytes("simnn_f16_mfma", "simnn")
+    pk = measured_peaks(eng)
     return {"value": round(B * world * steps / elapsed, 2), "unit": "mesh-pairs/s", "ms_per_step": round(1e3 * elapsed / steps, 4),
             "steps": steps, "warmup": warmup, "dtype": "f16", "config": {"workload": w["cfg"], "pairs_per_gpu": B, "N": n, "D": D},
-            "roofline": roofline_block("simnn_f16_mfma", "f16", 2.0 * n * n * D * B, launches, avg_ms, "simnn", {})}
+            "kernel": "simnn_f16_mfma", "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops, "achieved": round(ach, 3),
+            "peak": PEAK_TFLOPS["f16"], "unit_roofline": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["f16"], 4),
+            "frac_of_measured_peak_random_operands": round(ach / pk["mfma_f16_random_operands_tflops"], 4),
+            "traffic": traffic, "traffic_file": ("profiles/" + tfile) if tfile else None}
+
+
+def secondary_stress(eng, rank, barrier):
+    """configs[4] (64 pairs, N = 8192, D = 384, k = 200), 3 timed steps in the same process: value and its kernel table."""
+    import torch
+    w = dict(WORKLOADS["stress"])
+    host = make_batch(w, rank)
+    dev = {n: torch.as_tensor(v).to(eng.device) for n, v in host.items()}
+    N, B, D, k = w["nu"] * w["nv"], w["B"], w["D"], w["k"]
+
+    def step():
+        return eng.match(dev, k=k)
+    models = kernel_models(N, D, k, B, eng)
+    table, kms, nl = kernel_table(eng, step, 2, models, "stress")
+    steps = 3
+    elapsed, launches, kernel_ms = timed_kernel(eng, step, table[0]["name"], steps, 1, barrier)
+    out = {"value": round(B * steps / elapsed, 2), "unit": "mesh-pairs/s", "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps,
+           "config": {"workload": w["cfg"], "pairs_per_gpu": B, "N": N, "D": D, "k": k}, "kernel_ms_per_step": round(kms, 3),
+           "launches_per_step": round(nl, 1), "workspace_bytes": eng.workspace_bytes(), "kernels": table}
+    del dev
+    torch.cuda.empty_cache()
+    return out
 
 
 def parity_block(eng):
@@ -316,10 +438,15 @@ def pmc_traffic_bytes(kernel, workload):
     import csv
     dual = lambda name: any(name.rstrip('"').endswith(f", {d}>(simnn_params)") for d in (1, 2, 3))   # (4- and 8-wave shapes alike)
     match = {"gred_f64": lambda n: "gred_kernel" in n,
+             "fmap_solve_chol": lambda n: "fmap_solve" in n,
+             "embed_nt_f64": lambda n: "embed_tile_kernel" in n,
+             "project_f16split_mfma": lambda n: "proj_f16split_kernel" in n,
+             "gram_nt_f64": lambda n: "gemm_nt_f64" in n and "OutScaled" in n,
+             "p2pfm_tn_f64": lambda n: "gemm_tn_f64" in n and "OutFM" in n,
              "simnn_f16_mfma": lambda n: "simnn_pipe_kernel" in n and not dual(n),
              "simnn2_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 1>(simnn_params)"),
              "simnn4_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 3>(simnn_params)")}.get(kernel, lambda n: kernel in n)
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         fname = f"{rnd}_{workload}_hbm_traffic_pmc.csv"
         path = os.path.join(REPO, "profiles", fname)
         try:

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dm_profile_kernel": (_i, [_p, C.c_char_p]),
     "dm_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(_d)]),
     "dm_profile_report": (_i, [_p, C.c_char_p, C.c_size_t]),
+    "dm_measure_peak": (_i, [_p, _i, C.POINTER(_d)]),
     "dm_simnn_f16": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dm_project": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
     "dm_fmap_c00": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
@@ -50,7 +51,7 @@ SIGNATURES = {
 }
 
 # the float64-basis forms (const double* Phi / mass): same argument lists
-for _n in ("dm_fmap_c00", "dm_fm_to_p2p", "dm_mapped_indicator", "dm_p2p_to_fm", "dm_precise_map", "dm_p2p_to_fm_lstsq", "dm_icp",
+for _n in ("dm_project", "dm_fmap_c00", "dm_fm_to_p2p", "dm_mapped_indicator", "dm_p2p_to_fm", "dm_precise_map", "dm_p2p_to_fm_lstsq", "dm_icp",
            "dm_zoomout"):
     SIGNATURES[_n + "_f64"] = SIGNATURES[_n]
 

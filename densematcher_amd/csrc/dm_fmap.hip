@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const double* __
     out[i] = (float)s;
 }
 
-extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass,
-                          const void* F, int f_dtype, float* Ared) {
+template <typename TR>
+static int project_impl(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
+                        const void* F, int f_dtype, float* Ared) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && N > 0 && D > 0 && k > 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi && mass && F && Ared, "null pointer");
@@ -43,7 +44,7 @@ extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* 
     f_dtype &= ~DM_PROJECT_F64;
     DM_REQUIRE(ctx, f_dtype == DM_F16 || f_dtype == DM_F32, "f_dtype must be DM_F16 or DM_F32 (| DM_PROJECT_F64)");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    if (f_dtype == DM_F16 && !want_f64) return dm_project_f16split(ctx, B, N, D, k, Phi, ld, mass, F, Ared);
+    if (f_dtype == DM_F16 && !want_f64) return dm_project_f16split<TR>(ctx, B, N, D, k, Phi, ld, mass, F, Ared);
     const int tiles = dm_cdiv(k, TN_T) * dm_cdiv(D, TN_T);
     // split-K by a fixed chunk of vertices: the summation order of a pair must not depend on the batch it is in
     const int kchunk = 512;
@@ -55,16 +56,16 @@ extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* 
         partial = (double*)dm_ws_take(ctx, (size_t)nsplit * B * k * D * 8);
     }
     // the mass multiplies the descriptor rows, as in the reference (A @ descr), the basis stays unscaled
-    RowsF32Scaled opx{Phi, (long long)N * ld, ld, k, nullptr, 0};
+    RowsScaled<TR, TR> opx{Phi, (long long)N * ld, ld, k, nullptr, 0};
     OutProj out{nsplit > 1 ? nullptr : Ared, partial, B, k, D};
     dim3 grid(tiles, nsplit, B);
     if (f_dtype == DM_F16) {
-        RowsF16Scaled opy{(const _Float16*)F, (long long)N * D, D, D, mass, (long long)N};
-        DM_LAUNCH(ctx, "project_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF16Scaled, OutProj>), grid, dim3(256), 0, opx,
+        RowsF16Scaled<TR> opy{(const _Float16*)F, (long long)N * D, D, D, mass, (long long)N};
+        DM_LAUNCH(ctx, "project_tn_f64", (gemm_tn_f64<RowsScaled<TR, TR>, RowsF16Scaled<TR>, OutProj>), grid, dim3(256), 0, opx,
                   opy, out, k, D, N, kchunk);
     } else {
-        RowsF32Scaled opy{(const float*)F, (long long)N * D, D, D, mass, (long long)N};
-        DM_LAUNCH(ctx, "project_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF32Scaled, OutProj>), grid, dim3(256), 0, opx,
+        RowsScaled<float, TR> opy{(const float*)F, (long long)N * D, D, D, mass, (long long)N};
+        DM_LAUNCH(ctx, "project_tn_f64", (gemm_tn_f64<RowsScaled<TR, TR>, RowsScaled<float, TR>, OutProj>), grid, dim3(256), 0, opx,
                   opy, out, k, D, N, kchunk);
     }
     if (nsplit > 1) {
@@ -74,6 +75,15 @@ extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* 
     }
     return DM_OK;
 }
+extern "C" int dm_project(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass,
+                          const void* F, int f_dtype, float* Ared) {
+    return project_impl<float>(ctx, B, N, D, k, Phi, ld, mass, F, f_dtype, Ared);
+}
+extern "C" int dm_project_f64(dm_ctx* ctx, int B, int N, int D, int k, const double* Phi, int ld, const double* mass,
+                              const void* F, int f_dtype, float* Ared) {
+    return project_impl<double>(ctx, B, N, D, k, Phi, ld, mass, F, f_dtype, Ared);
+}
+
 
 // =================================================================================================
 // dm_fmap_c00: sign(Phi1[0,0] Phi2[0,0]) sqrt(area2 / area1)          pyFM/functional.py:654-658

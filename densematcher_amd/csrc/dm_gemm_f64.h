@@ -302,9 +302,10 @@ struct RowsGatherScaled {
 };
 
 // rows of an fp16 matrix (B, rows, ld), optionally scaled per row, K-major use
+template <typename TS = float>
 struct RowsF16Scaled {
     const _Float16* p; long long stride_b; int ld; int ncols;
-    const float* scale; long long scale_stride_b;   // nullable
+    const TS* scale; long long scale_stride_b;   // nullable
     __device__ __forceinline__ void load4(int b, int n, int col0, double (&v)[4]) const {
         const _Float16* row = p + b * stride_b + (long long)n * ld;
         const double s = scale ? (double)scale[b * scale_stride_b + n] : 1.0;

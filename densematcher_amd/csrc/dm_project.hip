@@ -43,14 +43,20 @@ __device__ __forceinline__ f16x8 tr_frag(const _Float16* base, int row0, int col
 
 // max |mass[n] * Phi[n][c]| per pair -> power-of-two scale.  The basis is streamed as one flat float4 array (all ld
 // columns: entries beyond k can only make the scale more conservative), four loads in flight per thread.
-__global__ __launch_bounds__(256) void proj_absmax_kernel(const float* __restrict__ Phi, const float* __restrict__ mass, int N,
-                                                          int ld, float* __restrict__ amax_part) {
+// (TR = float | double: a float64 basis / mass is rounded to fp32 as it is loaded -- what the reference's fit does before it
+//  projects, pyFM/functional.py:410-414 -- so both forms compute the same numbers)
+// A float64 basis is also WRITTEN BACK as fp32 by this pass (phi32 / mass32, nullable): the tile kernel re-reads every slab
+// of the basis once per descriptor tile from L2 and is bound by that traffic (87 us on fp32, 127 us straight from float64).
+template <typename TR>
+__global__ __launch_bounds__(256) void proj_absmax_kernel(const TR* __restrict__ Phi, const TR* __restrict__ mass, int N,
+                                                          int ld, float* __restrict__ amax_part, float* __restrict__ phi32,
+                                                          float* __restrict__ mass32) {
     const int b = blockIdx.y;
-    const float* P = Phi + (long long)b * N * ld;
-    const float* a = mass + (long long)b * N;
+    const TR* P = Phi + (long long)b * N * ld;
+    const TR* a = mass + (long long)b * N;
     const unsigned total = (unsigned)N * (unsigned)ld;           // < 2^31 per pair (checked by the caller)
     float m = 0.f;
-    if (((ld & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {
+    if (sizeof(TR) == 4 && ((ld & 3) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {
         const unsigned nvec = total >> 2, ld4 = (unsigned)ld >> 2;
         const float4* P4 = reinterpret_cast<const float4*>(P);
         // each workgroup streams contiguous 16 KiB chunks (4 consecutive float4 per lane would be 64 B per lane; the
@@ -64,15 +70,41 @@ __global__ __launch_bounds__(256) void proj_absmax_kernel(const float* __restric
                 const unsigned e = c0 + u * 256 + threadIdx.x;
                 const bool ok = e < nvec;
                 v[u] = ok ? P4[e] : float4{0.f, 0.f, 0.f, 0.f};
-                an[u] = ok ? fabsf(a[e / ld4]) : 0.f;              // 32-bit division (a 64-bit one dominated this kernel)
+                an[u] = ok ? fabsf((float)a[e / ld4]) : 0.f;       // 32-bit division (a 64-bit one dominated this kernel)
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 m = fmaxf(m, an[u] * fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
         }
+    } else if (sizeof(TR) == 8 && ((ld & 1) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {
+        const unsigned nvec = total >> 1, ld2 = (unsigned)ld >> 1;
+        const f64x2* P2 = reinterpret_cast<const f64x2*>(P);
+        for (unsigned c0 = blockIdx.x * 1024; c0 < nvec; c0 += gridDim.x * 1024) {
+            f64x2 v[4];
+            float an[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned e = c0 + u * 256 + threadIdx.x;
+                const bool ok = e < nvec;
+                v[u] = ok ? P2[e] : f64x2{0.0, 0.0};
+                an[u] = ok ? fabsf((float)a[e / ld2]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x0 = (float)v[u][0], x1 = (float)v[u][1];
+                m = fmaxf(m, an[u] * fmaxf(fabsf(x0), fabsf(x1)));
+                const unsigned e = c0 + u * 256 + threadIdx.x;
+                if (phi32 && e < nvec) reinterpret_cast<float2*>(phi32 + (long long)b * N * ld)[e] = float2{x0, x1};
+            }
+        }
     } else {
-        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256)
-            m = fmaxf(m, fabsf(a[e / (unsigned)ld]) * fabsf(P[e]));
+        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+            m = fmaxf(m, fabsf((float)a[e / (unsigned)ld]) * fabsf((float)P[e]));
+            if (sizeof(TR) == 8 && phi32) phi32[(long long)b * N * ld + e] = (float)P[e];
+        }
+    }
+    if (sizeof(TR) == 8 && mass32) {
+        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < (unsigned)N; e += gridDim.x * 256) mass32[(long long)b * N + e] = (float)a[e];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -83,13 +115,15 @@ __global__ __launch_bounds__(256) void proj_absmax_kernel(const float* __restric
     if (threadIdx.x == 0) amax_part[b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
+template <typename TR>
 struct proj_params {
-    const float* Phi; const float* mass; const _Float16* F; const float* amax_part; int n_part;
+    const TR* Phi; const TR* mass; const _Float16* F; const float* amax_part; int n_part;
     float* partial;          // (nsplit, B, k, D) fp32
     int B, N, D, k, ld, nsplit, kchunk, tiles_m, tiles_d;
 };
 
-__global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
+template <typename TR>
+__global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];               // [2 buffers][Xhi | Xlo | F], 76 KiB
     // 1-D grid, XCD-aware: the d-tiles that share one (pair, vertex chunk) slab of the basis are neighbours in the
     // logical order and therefore meet in the same XCD's L2 (otherwise every tile re-fetches the slab from HBM)
@@ -111,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
     if (amax > 0.f) (void)frexpf(amax, &ex);                 // amax = f * 2^ex, f in [0.5, 1)
     const float scale = ldexpf(1.0f, 14 - ex);
 
-    const float* Phi = p.Phi + (long long)b * p.N * p.ld;
-    const float* mass = p.mass + (long long)b * p.N;
+    const TR* Phi = p.Phi + (long long)b * p.N * p.ld;
+    const TR* mass = p.mass + (long long)b * p.N;
     const _Float16* F = p.F + (long long)b * p.N * p.D;
 
     f32x16 acc[2][4];                                        // wave tile 64 (m) x 128 (d)
@@ -125,29 +159,37 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
 
     const int srow = t >> 3, scol = (t & 7) * 16;            // staging: row of the stage, 16 consecutive basis columns
     const int fcol = (t & 7) * 32;                           //          and 32 consecutive descriptor channels
-    const bool xvec = ((p.ld & 3) == 0) && ((((uintptr_t)p.Phi) & 15) == 0);
+    const bool xvec = ((p.ld & (sizeof(TR) == 4 ? 3 : 1)) == 0) && ((((uintptr_t)p.Phi) & 15) == 0);
     const bool fvec = ((p.D & 7) == 0) && ((((uintptr_t)p.F) & 15) == 0);
     // staged exactly as loaded: the mass scaling and the hi / lo split happen in PROJ_STASH, one stage later (arithmetic on
     // the loaded values inside PROJ_FETCH would make every fetch wait for its own data)
-    float xr[16], an_raw = 0.f;
+    TR xr[16], an_raw = (TR)0;
     u32x4 fr[4];
     typedef __attribute__((address_space(1))) const f32x4 gf32x4;
     typedef __attribute__((address_space(1))) const u32x4 gu32x4;
-    typedef __attribute__((address_space(1))) const float gfloat;
+    typedef __attribute__((address_space(1))) const TR gfloat;
+    typedef __attribute__((address_space(1))) const f64x2 gf64x2;
 #define PROJ_FETCH(s_)                                                                                        \
     {                                                                                                         \
         const int n_ = nbeg + (s_) * PBK + srow;                                                              \
         const bool rv = n_ < nend;                                                                            \
-        an_raw = rv ? ((gfloat*)mass)[n_] : 0.f;                                                              \
-        const float* xrow = Phi + (long long)n_ * p.ld + m0 + scol;                                           \
+        an_raw = rv ? ((gfloat*)mass)[n_] : (TR)0;                                                            \
+        const TR* xrow = Phi + (long long)n_ * p.ld + m0 + scol;                                              \
         if (rv && xvec && m0 + scol + 15 < p.k) {                                                             \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
-                const f32x4 v = *(gf32x4*)(xrow + 4 * q);                                                     \
-                xr[4 * q] = v[0]; xr[4 * q + 1] = v[1]; xr[4 * q + 2] = v[2]; xr[4 * q + 3] = v[3];           \
+            if constexpr (sizeof(TR) == 4) {                                                                  \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                               \
+                    const f32x4 v = *(gf32x4*)(xrow + 4 * q);                                                 \
+                    xr[4 * q] = v[0]; xr[4 * q + 1] = v[1]; xr[4 * q + 2] = v[2]; xr[4 * q + 3] = v[3];       \
+                }                                                                                             \
+            } else {                                                                                          \
+                _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                               \
+                    const f64x2 v = *(gf64x2*)(xrow + 2 * q);                                                 \
+                    xr[2 * q] = v[0]; xr[2 * q + 1] = v[1];                                                   \
+                }                                                                                             \
             }                                                                                                 \
         } else {                                                                                              \
             _Pragma("unroll") for (int q = 0; q < 16; ++q)                                                    \
-                xr[q] = (rv && m0 + scol + q < p.k) ? xrow[q] : 0.f;                                          \
+                xr[q] = (rv && m0 + scol + q < p.k) ? xrow[q] : (TR)0;                                        \
         }                                                                                                     \
         const _Float16* frow = F + (long long)n_ * p.D + d0 + fcol;                                           \
         if (rv && fvec && d0 + fcol + 31 < p.D) {                                                             \
@@ -167,9 +209,9 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params p) {
         _Float16* Xl = Xh + PBK * PLD;                                                                        \
         _Float16* Fs = smem + (buf_) * PSTAGE + 2 * PBK * PLD + srow * PLDF + fcol;                           \
         f16x8 h[2], l[2];                                                                                     \
-        const float an = an_raw * scale;                                                                      \
+        const float an = (float)an_raw * scale;                                                               \
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {                                                      \
-            float xs_ = xr[q] * an;                                                                           \
+            float xs_ = (float)xr[q] * an;                                                                         \
             /* the product must be ONE rounded value for both pieces: left visible, the compiler contracts it into the */ \
             /* conversion of hi (v_fma_mix, single rounding) but not into the one it stores, and hi + lo is off by an */ \
             /* ulp of hi on ties */                                                                           \
@@ -245,9 +287,10 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
     out[i] = (float)s;
 }
 
-int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi, int ld, const float* mass,
+template <typename TR>
+int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
                         const void* F, float* Ared) {
-    proj_params p;
+    proj_params<TR> p;
     p.Phi = Phi; p.mass = mass; p.F = (const _Float16*)F;
     p.B = B; p.N = N; p.D = D; p.k = k; p.ld = ld;
     p.tiles_m = dm_cdiv(k, PT); p.tiles_d = dm_cdiv(D, PTD);
@@ -257,19 +300,37 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const float* Ph
     p.nsplit = nsplit;
     if ((long long)N * ld >= (1ll << 31)) return dm_fail(ctx, DM_EINVAL, "dm_project: N * ld must be below 2^31");
     const size_t pbytes = (size_t)nsplit * B * k * D * 4;
-    int rc = dm_ws_reserve(ctx, dm_align_up(pbytes) + (size_t)B * 64 * 4 + 4096);
+    int rc = dm_ws_reserve(ctx, dm_align_up(pbytes) + (size_t)B * 64 * 4 + 4096 +
+                                    (sizeof(TR) == 8 ? dm_align_up((size_t)B * N * ld * 4) + dm_align_up((size_t)B * N * 4) : 0));
     if (rc) return rc;
     p.partial = (float*)dm_ws_take(ctx, pbytes);
     const int n_part = max(1, min(64, (int)(((long long)N * ld) / 4096)));
     float* amax_part = (float*)dm_ws_take(ctx, (size_t)B * n_part * 4);
     p.amax_part = amax_part; p.n_part = n_part;
-    DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel, dim3(n_part, B), dim3(256), 0, Phi, mass, N, ld, amax_part);
     const size_t lds = (size_t)2 * PSTAGE * sizeof(_Float16);
-    rc = dm_grant_lds(ctx, (const void*)proj_f16split_kernel, lds);
-    if (rc) return rc;
-    DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), lds, p);
+    if constexpr (sizeof(TR) == 8) {
+        // float64 basis: the scale pass also leaves an fp32 copy (the rounding the reference's fit applies), the tile kernel runs on it
+        float* phi32 = (float*)dm_ws_take(ctx, (size_t)B * N * ld * 4);
+        float* mass32 = (float*)dm_ws_take(ctx, (size_t)B * N * 4);
+        if (!phi32 || !mass32) return dm_fail(ctx, DM_ENOMEM, "dm_project: workspace not reserved");
+        DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel<TR>, dim3(n_part, B), dim3(256), 0, Phi, mass, N, ld, amax_part, phi32, mass32);
+        proj_params<float> pf;
+        pf.Phi = phi32; pf.mass = mass32; pf.F = p.F; pf.amax_part = p.amax_part; pf.n_part = p.n_part; pf.partial = p.partial;
+        pf.B = B; pf.N = N; pf.D = D; pf.k = k; pf.ld = ld; pf.nsplit = p.nsplit; pf.kchunk = p.kchunk; pf.tiles_m = p.tiles_m; pf.tiles_d = p.tiles_d;
+        rc = dm_grant_lds(ctx, (const void*)proj_f16split_kernel<float>, lds);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel<float>, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), lds, pf);
+    } else {
+        DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel<TR>, dim3(n_part, B), dim3(256), 0, Phi, mass, N, ld, amax_part, (float*)nullptr,
+                  (float*)nullptr);
+        rc = dm_grant_lds(ctx, (const void*)proj_f16split_kernel<TR>, lds);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel<TR>, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), lds, p);
+    }
     const long long n = (long long)B * k * D;
     DM_LAUNCH(ctx, "project_reduce", proj_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.partial, nsplit, n,
               Ared);
     return DM_OK;
 }
+template int dm_project_f16split<float>(dm_ctx*, int, int, int, int, const float*, int, const float*, const void*, float*);
+template int dm_project_f16split<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, const void*, float*);

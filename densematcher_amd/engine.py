@@ -115,6 +115,14 @@ class MatchEngine:
         self._chk(self.lib.dm_profile_read(self.ctx, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    PEAK_PROBES = {"mfma_f16_zero_operands": 0, "mfma_f16_random_operands": 1, "mfma_f64": 2, "hbm_copy": 3}
+
+    def measure_peak(self, which):
+        """on-box peak probe (include/densematch.h: dm_measure_peak): FLOP/s, or bytes/s for "hbm_copy" """
+        v = C.c_double(0.0)
+        self._chk(self.lib.dm_measure_peak(self.ctx, self.PEAK_PROBES[which], C.byref(v)))
+        return v.value
+
     def profile_report(self):
         """after profile_kernel("*"): {kernel name: (launches, total ms)} of every launch since, in order of first launch"""
         buf = C.create_string_buffer(1 << 16)
@@ -143,8 +151,7 @@ class MatchEngine:
     def project(self, Phi, mass, F, k=None, out=None, exact=False):
         """Phi[:, :k]^T (mass * F)  ->  (B,k,D) f32.  fp16 descriptors use the fp16 matrix cores (split basis,
         relative error ~1e-6); exact=True or fp32 descriptors use the float64 matrix cores."""
-        Phi = self._dev(Phi, torch.float32, "Phi")
-        mass = self._dev(mass, torch.float32, "mass")
+        sfx, Phi, mass = self._reals(Phi, mass)
         if not isinstance(F, torch.Tensor):
             F = torch.as_tensor(F)
         fdt = torch.float16 if F.dtype == torch.float16 else torch.float32
@@ -156,7 +163,7 @@ class MatchEngine:
         D = F.shape[2]
         if out is None:
             out = torch.empty((B, k, D), dtype=torch.float32, device=self.device)
-        self._chk(self.lib.dm_project(self.ctx, B, N, D, k, _ptr(Phi), ld, _ptr(mass), _ptr(F),
+        self._chk(getattr(self.lib, "dm_project" + sfx)(self.ctx, B, N, D, k, _ptr(Phi), ld, _ptr(mass), _ptr(F),
                                       (_lib.DM_F16 if fdt == torch.float16 else _lib.DM_F32) |
                                       (_lib.DM_PROJECT_F64 if exact else 0), _ptr(out)))
         return out

@@ -140,7 +140,8 @@ class TriMesh:
         one_d = func.ndim == 1
         F = (func[:, None] if one_d else func).astype(np.float32)
         kk = self.eigenvectors.shape[1] if k is None else k
-        out = default_engine().project(self.eigenvectors[None].astype(np.float32), self.A.diagonal()[None].astype(np.float32),
+        # float64 eigenvectors / masses go in unrounded (dm_project_f64, float64 matrix cores); the result is fp32
+        out = default_engine().project(np.ascontiguousarray(self.eigenvectors)[None], np.ascontiguousarray(self.A.diagonal())[None],
                                        F[None], kk, exact=True)[0].cpu().numpy().astype(np.float64)
         return out[:, 0] if one_d else out
 

@@ -168,10 +168,11 @@ def sha256_of(*arrays):
 # --------------------------------------------------------------------------- #
 # whole batches (bench.py / tests)
 # --------------------------------------------------------------------------- #
-def make_pair_batch(B, nu, nv, d, k, sigma=0.1, n_distinct_meshes=2, basis="eig", seed0=0, perm="identity"):
+def make_pair_batch(B, nu, nv, d, k, sigma=0.1, n_distinct_meshes=2, basis="eig", seed0=0, perm="identity", real_dtype=np.float32):
     """A batch of B pairs in the layout the C ABI takes (batch-major,
     row-major, contiguous): Phi1/Phi2 (B,N,k) f32, lam1/lam2 (B,k) f64,
-    a1/a2 (B,N) f32, F1/F2 (B,N,d) f16.  Pair i uses descriptor seeds
+    a1/a2 (B,N) f32, F1/F2 (B,N,d) f16.  real_dtype = np.float64 keeps the eigenvectors and masses in the
+    float64 the eigensolver produced (the reference's dtype; the *_f64 entry points).  Pair i uses descriptor seeds
     (1000+i, 2000+i).  Eigenbases are computed for
     `n_distinct_meshes` shape pairs and cycled over the batch."""
     n = nu * nv
@@ -187,9 +188,9 @@ def make_pair_batch(B, nu, nv, d, k, sigma=0.1, n_distinct_meshes=2, basis="eig"
             b2 = random_basis(n, k, seed0 + 10 * m + 1)
         bases.append((b1, b2))
     out = {
-        "Phi1": np.empty((B, n, k), np.float32), "Phi2": np.empty((B, n, k), np.float32),
+        "Phi1": np.empty((B, n, k), real_dtype), "Phi2": np.empty((B, n, k), real_dtype),
         "lam1": np.empty((B, k), np.float64), "lam2": np.empty((B, k), np.float64),
-        "a1": np.empty((B, n), np.float32), "a2": np.empty((B, n), np.float32),
+        "a1": np.empty((B, n), real_dtype), "a2": np.empty((B, n), real_dtype),
         "F1": np.empty((B, n, d), np.float16), "F2": np.empty((B, n, d), np.float16),
     }
     for i in range(B):

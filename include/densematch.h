@@ -90,6 +90,13 @@ int dm_profile_read(dm_ctx* ctx, int* launches, double* total_ms);
  * bracketed and collects the per-kernel table in a separate, untimed pass.) */
 int dm_profile_report(dm_ctx* ctx, char* buf, size_t cap);
 
+/* ---- on-box peak probes (bench.py: measured peak beside the spec peak of the roofline block) -------------------
+ * value = FLOP/s (matrix-core probes) or bytes/s read + written (copy).  The fp16 probe comes in two flavours because the
+ * part is power-limited: all-zero operands run at the full 2.4 GHz (the instruction-issue ceiling, ~2.48 PFLOP/s), N(0,1)
+ * operands pull the shader clock to ~1.7 GHz (~1.72 PFLOP/s): the ceiling of a kernel that multiplies real data. */
+enum { DM_PEAK_MFMA_F16_ZERO = 0, DM_PEAK_MFMA_F16_RANDOM = 1, DM_PEAK_MFMA_F64 = 2, DM_PEAK_HBM_COPY = 3 };
+int dm_measure_peak(dm_ctx* ctx, int which, double* value);
+
 /* ---- config 3: feature-similarity nearest neighbour ---------------------
  * nn21[b,i] = argmax_j <Ftgt[b,i,:], Fsrc[b,j,:]>   (lowest j on ties)
  * No reference symbol; defined by oracle/dm_oracle.py:simnn.
@@ -113,6 +120,12 @@ int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D,
 int dm_project(dm_ctx* ctx, int B, int N, int D, int k,
                const float* Phi, int ld, const float* mass,
                const void* F, int f_dtype, float* Ared /* B*k*D */);
+/* float64 basis and masses: rounded to fp32 as they are loaded by the fp16-split path (exactly what the reference's fit does
+ * before it projects, pyFM/functional.py:410-414: same result as converting first, without the extra pass over Phi); the
+ * DM_PROJECT_F64 path uses them unrounded (TriMesh.project, pyFM/mesh/trimesh.py:533-556, is float64 NumPy). */
+int dm_project_f64(dm_ctx* ctx, int B, int N, int D, int k,
+                   const double* Phi, int ld, const double* mass,
+                   const void* F, int f_dtype, float* Ared /* B*k*D */);
 
 /* ---- pinned first column ---------------------------------------------------
  * c00[b] = sign(Phi1[b][0,0] * Phi2[b][0,0]) * sqrt(sum(mass2[b]) / sum(mass1[b]))

@@ -13,12 +13,8 @@ from densematcher_amd.engine import MatchEngine  # noqa: E402
 
 wl = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "fmap"
 w = dict(bench.WORKLOADS[wl])
-host = bench.make_batch(w, 0)
+host = bench.make_batch(w, 0, "f32" if "--f32" in sys.argv else "f64")
 eng = MatchEngine(0)
-if "--f64" in sys.argv:
-    for n in ("Phi1", "Phi2", "a1", "a2"):
-        if n in host:
-            host[n] = host[n].astype(np.float64)
 dev = {n: torch.as_tensor(v).to(eng.device) for n, v in host.items()}
 k, B = w["k"], w["B"]
 if wl in ("fmap", "stress"):
@@ -41,6 +37,6 @@ for _ in range(reps):
 rep = eng.profile_report()
 eng.profile_kernel("")
 tot = sum(ms for _, ms in rep.values())
-print(f"# {wl}{' (float64 basis)' if '--f64' in sys.argv else ''}: {tot / reps:.4f} ms of kernel time per step, {sum(n for n, _ in rep.values()) // reps} launches")
+print(f"# {wl}{' (fp32 basis)' if '--f32' in sys.argv else ' (float64 basis)'}: {tot / reps:.4f} ms of kernel time per step, {sum(n for n, _ in rep.values()) // reps} launches")
 for name, (n, ms) in sorted(rep.items(), key=lambda kv: -kv[1][1]):
     print(f"{name:28s} {n // reps:4d} x {1e3 * ms / n:9.2f} us = {ms / reps:8.4f} ms  {100 * ms / tot:5.1f} %")
