@@ -11,10 +11,9 @@
 //   gradient: the analytic derivative of the above (what torch autograd returns there), dE/dC = Phi2^T (dE/dM) (A1 Phi1)
 //   for the M terms; column 0 is zeroed (:759).
 //
-// Everything is float64 on the f64 matrix cores.  The mapped indicator IS materialised here (B N2 N1 doubles in the
-// context workspace: 32 MiB per pair at N = 2048): these terms need two passes over it (row / column statistics, then
-// the element-wise derivative) and one evaluation is a few milliseconds against the reference's seconds; the arg-max
-// maps (dm_fm_to_p2p) never form it.  All reductions use fixed orders: the same input gives the same bits.
+// Everything is float64 on the f64 matrix cores.  The mapped indicator is NOT materialised: its tiles are produced twice
+// (row / column statistics, then the element-wise derivative contracted with Phi1 on the spot), workspace O(N k).  All
+// reductions use fixed orders: the same input gives the same bits.
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
 
@@ -162,30 +161,6 @@ __global__ __launch_bounds__(256) void quad_terms_kernel(const double* __restric
 }
 
 // ---- statistics of the mapped indicator ------------------------------------------------------------------------------
-// one wave per row: rs[i] = sum_j M_ij, rsq[i] = sum_j M_ij^2
-__global__ __launch_bounds__(256) void m_row_stats_kernel(const double* __restrict__ M, int N2, int N1, double* __restrict__ rs,
-                                                          double* __restrict__ rsq) {
-    const int b = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= N2) return;
-    const double* row = M + ((long long)b * N2 + i) * N1;
-    double s = 0.0, q = 0.0;
-    for (int j = lane; j < N1; j += 64) { const double m = row[j]; s += m; q += m * m; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
-    if (lane == 0) { rs[(long long)b * N2 + i] = s; rsq[(long long)b * N2 + i] = q; }
-}
-// column sums over chunks of 256 rows: pcs / pcsq (B, nchunk, N1)
-__global__ __launch_bounds__(256) void m_col_stats_kernel(const double* __restrict__ M, int N2, int N1, int nchunk,
-                                                          double* __restrict__ pcs, double* __restrict__ pcsq) {
-    const int b = blockIdx.z, ch = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N1) return;
-    const int i0 = ch * 256, i1 = min(N2, i0 + 256);
-    const double* col = M + (long long)b * N2 * N1 + j;
-    double s = 0.0, q = 0.0;
-    for (int i = i0; i < i1; ++i) { const double m = col[(long long)i * N1]; s += m; q += m * m; }
-    pcs[((long long)b * nchunk + ch) * N1 + j] = s;
-    pcsq[((long long)b * nchunk + ch) * N1 + j] = q;
-}
 // cs / csq from the chunk partials, and the means of rs and cs: stat[b] = {mean rs, mean cs}   (one workgroup per pair)
 __global__ __launch_bounds__(256) void m_finish_stats_kernel(const double* __restrict__ pcs, const double* __restrict__ pcsq, int nchunk,
                                                              int N2, int N1, const double* __restrict__ rs, double* __restrict__ cs,
@@ -206,48 +181,262 @@ __global__ __launch_bounds__(256) void m_finish_stats_kernel(const double* __res
     if (t == 0) { stat[2 * b] = tot_r / (double)N2; stat[2 * b + 1] = tot_c / (double)N1; }
 }
 
-// ---- element-wise derivative -----------------------------------------------------------------------------------------
-// M_ij <- (dE/dM_ij) * mass1_j in place; pe[b][block] = this workgroup's share of the energy.  One workgroup per 4 rows.
-__global__ __launch_bounds__(256) void m_derivative_kernel(double* __restrict__ M, int N2, int N1, const float* __restrict__ mass1,
-                                                           const double* __restrict__ rs, const double* __restrict__ rsq,
-                                                           const double* __restrict__ cs, const double* __restrict__ csq,
-                                                           const double* __restrict__ stat, mterm_weights w, double* __restrict__ pe) {
-    __shared__ double sh[4];
-    const int b = blockIdx.y, t = threadIdx.x;
-    const double mean_r = stat[2 * b], mean_c = stat[2 * b + 1];
-    const double n2_over_n1 = (double)N2 / (double)N1;
-    double acc = 0.0;
-    for (int r = 0; r < 4; ++r) {
-        const int i = blockIdx.x * 4 + r;
-        if (i >= N2) break;
-        double* row = M + ((long long)b * N2 + i) * N1;
-        const double dr_s = (w.sumto1 > 0.0) ? rs[(long long)b * N2 + i] - mean_r : 0.0;
-        const double dr_q = (w.stoch > 0.0) ? rsq[(long long)b * N2 + i] - 1.0 : 0.0;
-        for (int j = t; j < N1; j += 256) {
-            const double m = row[j];
-            double d = 0.0;
-            if (w.p2p > 0.0) { const double q = m * m - m; acc += w.p2p * q * q; d += w.p2p * 2.0 * q * (2.0 * m - 1.0); }
-            if (w.stoch > 0.0) d += w.stoch * (2.0 * (csq[(long long)b * N1 + j] - n2_over_n1) + 2.0 * dr_q) * 2.0 * m;
-            if (w.ent > 0.0) {
-                const double c = fmin(fmax(m, 0.0), 1.0);
-                const double lg = log(c + 1e-10);
-                acc += w.ent * (-c * lg);
-                if (m >= 0.0 && m <= 1.0) d += w.ent * (-lg - c / (c + 1e-10));   // torch.clamp passes the gradient on [0, 1]
-            }
-            if (w.range01 > 0.0) {
-                const double lo = fmax(-m, 0.0), hi = fmax(m - 1.0, 0.0);
-                acc += w.range01 * (lo * lo + hi * hi);
-                d += w.range01 * (-2.0 * lo + 2.0 * hi);
-            }
-            if (w.sumto1 > 0.0) d += w.sumto1 * (2.0 * (cs[(long long)b * N1 + j] - mean_c) + 2.0 * dr_s);
-            row[j] = d * (double)mass1[(long long)b * N1 + j];
-        }
-        // the row's share of the row-statistics terms (once per row)
-        if (t == 0) acc += w.stoch * dr_q * dr_q + w.sumto1 * dr_s * dr_s;
+// ---- tile-fused passes over the mapped indicator (M is never stored) ------------------------------------------------------
+// M_ij = (E2_i . Phi1_j) a1_j is produced 64 x 64 tile by tile on the f64 matrix cores from E2 = Phi2 C (N2 x k1) and the
+// rows of Phi1, consumed in registers and dropped:
+//   pass 1 (only when w_stochastic or w_sumto1 > 0): row sums / row sums of squares (complete inside a workgroup, which
+//          owns EM_RG rows and sweeps every column tile) and column sums per row group (N2 / EM_RG partials per column);
+//   pass 2: the tile again, the element-wise derivative dE/dM * a1_j, the energy, and at once the product of that tile
+//          with the same Phi1 rows, Y_i += sum_j D'_ij Phi1_j (64 x k1 accumulators per workgroup) -- the gradient is then
+//          Phi2^T Y.  Workspace O(N k) instead of the N2 x N1 matrix (32 MiB per pair at N = 2048, 537 MiB at N = 8192).
+// Every sum has a fixed order (lane trees, then waves, then tiles ascending): the same input gives the same bits.
+constexpr int EM_T = 64;       // tile edge
+constexpr int EM_BK = 32;      // contraction chunk of the first product
+constexpr int EM_LDA = 34;     // LDS row stride (doubles) of the staged E2 chunk
+constexpr int EM_LDD = 66;     // LDS row stride of the derivative tile
+constexpr int EM_RG = 512;     // rows per workgroup of pass 1
+
+struct em_params {
+    const double* E2; const float* Phi1; int ld1; const float* mass1;
+    int N1, N2, k1, ldp;                       // ldp: LDS row stride (floats) of the Phi1 tile, >= k1 rounded up to 32, = 4 (mod 32)
+    double* rs; double* rsq;                   // (B, N2)
+    double* pcs; double* pcsq; int ngroups;    // (B, ngroups, N1)
+    const double* cs; const double* csq; const double* stat;
+    mterm_weights w;
+    double* Y;                                 // (B, N2, k1)
+    double* pe;                                // (B, N2 / 64) energy shares
+};
+
+// Phi1 rows j0 .. j0+63 (all k1 columns, zero padded) -> Ps[64][ldp], kept in fp32 (its memory type; widened at the
+// fragment reads) so that the tile fits beside the other buffers up to k1 = 256
+__device__ __forceinline__ void em_load_phi_tile(const em_params& p, int b, int j0, float* Ps, int t) {
+    const float* P = p.Phi1 + (long long)b * p.N1 * p.ld1;
+    const int kq = p.ldp;                      // fill the padding too (the second product reads whole 16-column tiles)
+    for (int e = t; e < EM_T * kq; e += 256) {
+        const int r = e / kq, c = e - r * kq;
+        const int j = j0 + r;
+        Ps[e] = (j < p.N1 && c < p.k1) ? P[(long long)j * p.ld1 + c] : 0.0f;
     }
-    const double tot = block_sum_256(acc, sh);
-    if (t == 0) pe[(long long)b * gridDim.x + blockIdx.x] = tot;
 }
+// acc[mt][nt] = E2[r0 + wm*32 + mt*16 + ., :] . Phi1[j0 + wn*32 + nt*16 + ., :]   (64 x 64 tile, 4 waves 2 x 2)
+__device__ __forceinline__ void em_tile_product(const em_params& p, int b, int r0, const float* Ps, double* As, f64x4 (&acc)[2][2],
+                                                int t, int lane, int wm, int wn) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const double* E = p.E2 + (long long)b * p.N2 * p.k1;
+    const int lrow = t >> 2, lk = (t & 3) * 8;
+    for (int kc = 0; kc < p.k1; kc += EM_BK) {
+        double ra[8];
+        const int i = r0 + lrow;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[e] = (i < p.N2 && kc + lk + e < p.k1) ? E[(long long)i * p.k1 + kc + lk + e] : 0.0;
+        __syncthreads();                       // (the previous chunk's fragment reads are done)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) As[lrow * EM_LDA + lk + e] = ra[e];
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < EM_BK / 4; ++ks) {
+            const int kk = ks * 4 + (lane >> 4);
+            double a[2], bb[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[mt] = As[(wm * 32 + mt * 16 + (lane & 15)) * EM_LDA + kk];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bb[nt] = (double)Ps[(wn * 32 + nt * 16 + (lane & 15)) * p.ldp + kc + kk];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
+        }
+    }
+}
+__device__ __forceinline__ double em_row16_allsum(double x) {       // sum over the 16 lanes of a DPP row, fixed order
+    x += __shfl_xor(x, 8); x += __shfl_xor(x, 4); x += __shfl_xor(x, 2); x += __shfl_xor(x, 1);
+    return x;
+}
+
+// pass 1: grid (ngroups, B)
+__global__ __launch_bounds__(256) void em_stats_kernel(em_params p) {
+    extern __shared__ __attribute__((aligned(16))) double em_sm[];
+    double* As = em_sm;                                   // [64][EM_LDA]
+    double* rsacc = As + EM_T * EM_LDA;                   // [EM_RG] row sums, [EM_RG] row sums of squares
+    double* rqacc = rsacc + EM_RG;
+    double* rowpart = rqacc + EM_RG;                      // [2 wn][2][64]
+    double* colpart = rowpart + 2 * 2 * 64;               // [2 wm][2][64]
+    float* Ps = reinterpret_cast<float*>(colpart + 2 * 2 * 64);   // [64][ldp]
+    const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int g0 = g * EM_RG, nrb = min(EM_RG, p.N2 - g0 + EM_T - 1) / EM_T;
+    for (int r = t; r < EM_RG; r += 256) { rsacc[r] = 0.0; rqacc[r] = 0.0; }
+    const float* a1 = p.mass1 + (long long)b * p.N1;
+    for (int j0 = 0; j0 < p.N1; j0 += EM_T) {
+        __syncthreads();
+        em_load_phi_tile(p, b, j0, Ps, t);
+        double cacc = 0.0, cqacc = 0.0;                   // threads 64..127: column j0 + t - 64, over this group's rows
+        double a1c[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int j = j0 + wn * 32 + nt * 16 + (lane & 15);
+            a1c[nt] = j < p.N1 ? (double)a1[j] : 0.0;
+        }
+        for (int rb = 0; rb < nrb; ++rb) {
+            f64x4 acc[2][2];
+            em_tile_product(p, b, g0 + rb * EM_T, Ps, As, acc, t, lane, wm, wn);
+            double cs_[2] = {0.0, 0.0}, cq_[2] = {0.0, 0.0};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int il = wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
+                    const bool rv = g0 + rb * EM_T + il < p.N2;
+                    double s = 0.0, q = 0.0;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        const double m = rv ? acc[mt][nt][r] * a1c[nt] : 0.0;
+                        s += m; q += m * m;
+                        cs_[nt] += m; cq_[nt] += m * m;
+                    }
+                    s = em_row16_allsum(s); q = em_row16_allsum(q);
+                    if ((lane & 15) == 0) { rowpart[(wn * 2 + 0) * 64 + il] = s; rowpart[(wn * 2 + 1) * 64 + il] = q; }
+                }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                double s = cs_[nt], q = cq_[nt];
+                s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+                q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+                if (lane < 16) { colpart[(wm * 2 + 0) * 64 + wn * 32 + nt * 16 + lane] = s; colpart[(wm * 2 + 1) * 64 + wn * 32 + nt * 16 + lane] = q; }
+            }
+            __syncthreads();
+            if (t < 64) {
+                rsacc[rb * EM_T + t] += rowpart[(0 * 2 + 0) * 64 + t] + rowpart[(1 * 2 + 0) * 64 + t];
+                rqacc[rb * EM_T + t] += rowpart[(0 * 2 + 1) * 64 + t] + rowpart[(1 * 2 + 1) * 64 + t];
+            } else if (t < 128) {
+                const int c = t - 64;
+                cacc += colpart[(0 * 2 + 0) * 64 + c] + colpart[(1 * 2 + 0) * 64 + c];
+                cqacc += colpart[(0 * 2 + 1) * 64 + c] + colpart[(1 * 2 + 1) * 64 + c];
+            }
+            // (rowpart / colpart are rewritten only after the next tile's staging barriers)
+        }
+        if (t >= 64 && t < 128 && j0 + t - 64 < p.N1) {
+            const long long o = ((long long)b * p.ngroups + g) * p.N1 + j0 + t - 64;
+            p.pcs[o] = cacc; p.pcsq[o] = cqacc;
+        }
+    }
+    __syncthreads();
+    for (int r = t; r < EM_RG; r += 256)
+        if (g0 + r < p.N2) { p.rs[(long long)b * p.N2 + g0 + r] = rsacc[r]; p.rsq[(long long)b * p.N2 + g0 + r] = rqacc[r]; }
+}
+
+// pass 2: grid (N2 / 64, B); NT2 = 16-column tiles of Y per wave (k1 <= 64 NT2)
+template <int NT2>
+__global__ __launch_bounds__(256) void em_deriv_kernel(em_params p) {
+    extern __shared__ __attribute__((aligned(16))) double em_sm[];
+    __shared__ double sh[4];
+    double* As = em_sm;                                   // [64][EM_LDA]
+    double* Ds = As + EM_T * EM_LDA;                      // [64][EM_LDD]
+    float* Ps = reinterpret_cast<float*>(Ds + EM_T * EM_LDD);     // [64][ldp]
+    const int b = blockIdx.y, rb = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int r0 = rb * EM_T;
+    const float* a1 = p.mass1 + (long long)b * p.N1;
+    const mterm_weights w = p.w;
+    const bool stats = w.stoch > 0.0 || w.sumto1 > 0.0;
+    const double mean_r = stats ? p.stat[2 * b] : 0.0, mean_c = stats ? p.stat[2 * b + 1] : 0.0;
+    const double n2_over_n1 = (double)p.N2 / (double)p.N1;
+    // this lane's rows: statistics terms
+    double dr_s[2][4], dr_q[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r0 + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
+            const bool rv = stats && i < p.N2;
+            dr_s[mt][r] = (rv && w.sumto1 > 0.0) ? p.rs[(long long)b * p.N2 + i] - mean_r : 0.0;
+            dr_q[mt][r] = (rv && w.stoch > 0.0) ? p.rsq[(long long)b * p.N2 + i] - 1.0 : 0.0;
+        }
+    f64x4 Yacc[4][NT2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < NT2; ++q) Yacc[mt][q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    double eacc = 0.0;
+    for (int j0 = 0; j0 < p.N1; j0 += EM_T) {
+        __syncthreads();                                   // the previous tile's second product has read Ps / Ds
+        em_load_phi_tile(p, b, j0, Ps, t);
+        f64x4 acc[2][2];
+        em_tile_product(p, b, r0, Ps, As, acc, t, lane, wm, wn);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int jl = wn * 32 + nt * 16 + (lane & 15), j = j0 + jl;
+            const bool cv = j < p.N1;
+            const double a1j = cv ? (double)a1[j] : 0.0;
+            const double dc_q = (cv && w.stoch > 0.0) ? p.csq[(long long)b * p.N1 + j] - n2_over_n1 : 0.0;
+            const double dc_s = (cv && w.sumto1 > 0.0) ? p.cs[(long long)b * p.N1 + j] - mean_c : 0.0;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int il = wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
+                    double d = 0.0;
+                    if (cv && r0 + il < p.N2) {
+                        const double m = acc[mt][nt][r] * a1j;
+                        if (w.p2p > 0.0) { const double q = m * m - m; eacc += w.p2p * q * q; d += w.p2p * 2.0 * q * (2.0 * m - 1.0); }
+                        if (w.stoch > 0.0) d += w.stoch * (2.0 * dc_q + 2.0 * dr_q[mt][r]) * 2.0 * m;
+                        if (w.ent > 0.0) {
+                            const double c = fmin(fmax(m, 0.0), 1.0);
+                            const double lg = log(c + 1e-10);
+                            eacc += w.ent * (-c * lg);
+                            if (m >= 0.0 && m <= 1.0) d += w.ent * (-lg - c / (c + 1e-10));   // torch.clamp passes the gradient on [0, 1]
+                        }
+                        if (w.range01 > 0.0) {
+                            const double lo = fmax(-m, 0.0), hi = fmax(m - 1.0, 0.0);
+                            eacc += w.range01 * (lo * lo + hi * hi);
+                            d += w.range01 * (-2.0 * lo + 2.0 * hi);
+                        }
+                        if (w.sumto1 > 0.0) d += w.sumto1 * (2.0 * dc_s + 2.0 * dr_s[mt][r]);
+                        d *= a1j;
+                    }
+                    Ds[il * EM_LDD + jl] = d;
+                }
+        }
+        __syncthreads();
+        // Y[64 x k1] += D'[64 x 64] Phi1tile[64 x k1]: wave `wave` owns the 16-column tiles wave, wave + 4, ...
+#pragma unroll 4
+        for (int ks = 0; ks < EM_T / 4; ++ks) {
+            const int kk = ks * 4 + (lane >> 4);
+            double a[4], bb[NT2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[mt] = Ds[(mt * 16 + (lane & 15)) * EM_LDD + kk];
+#pragma unroll
+            for (int q = 0; q < NT2; ++q) {
+                const int n = (wave + 4 * q) * 16 + (lane & 15);
+                bb[q] = n < p.ldp ? (double)Ps[kk * p.ldp + n] : 0.0;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int q = 0; q < NT2; ++q) Yacc[mt][q] = mfma_f64_16x16x4(a[mt], bb[q], Yacc[mt][q]);
+        }
+    }
+    // the rows' shares of the row-statistics terms (once per row), then the workgroup's energy share
+    if (stats && t < 64 && r0 + t < p.N2) {
+        const double ds = (w.sumto1 > 0.0) ? p.rs[(long long)b * p.N2 + r0 + t] - mean_r : 0.0;
+        const double dq = (w.stoch > 0.0) ? p.rsq[(long long)b * p.N2 + r0 + t] - 1.0 : 0.0;
+        eacc += w.stoch * dq * dq + w.sumto1 * ds * ds;
+    }
+    const double tot = block_sum_256(eacc, sh);
+    if (t == 0) p.pe[(long long)b * gridDim.x + rb] = tot;
+    double* Yb = p.Y + (long long)b * p.N2 * p.k1;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int q = 0; q < NT2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = r0 + mt * 16 + (lane >> 4) + 4 * r, n = (wave + 4 * q) * 16 + (lane & 15);
+                if (i < p.N2 && n < p.k1) Yb[(long long)i * p.k1 + n] = Yacc[mt][q][r];
+            }
+}
+
 // e_m[b] = sum of the workgroup shares + the column-statistics terms   (one workgroup per pair)
 __global__ __launch_bounds__(256) void m_finish_energy_kernel(const double* __restrict__ pe, int nblk, int N1, int N2,
                                                               const double* __restrict__ cs, const double* __restrict__ csq,
@@ -312,15 +501,14 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
 
     const size_t bKK = (size_t)B * k2 * k1 * 8;
-    const int nchunk = dm_cdiv(N2, 256), nblk = dm_cdiv(N2, 4);
-    const int N1pad = pad_to(N1, 64), k1pad = pad_to(k1, 64);
+    DM_REQUIRE(ctx, !m_terms || k1 <= 256, "the indicator terms need k1 <= 256");
     const int nsplit_m = dm_cdiv(N2, 512);
     const int nsplit_d = dcomm ? dm_cdiv(n_ops * k2, 512) : 0;
     size_t need = dm_align_up((size_t)B * (k1 + k2) * k1 * 8) + 4 * dm_align_up(bKK) + 4 * dm_align_up((size_t)B * 8) + 65536;
-    if (m_terms)
-        need += dm_align_up((size_t)B * N2 * N1 * 8) + dm_align_up((size_t)B * N2 * k1 * 8) + dm_align_up((size_t)B * k1pad * N1pad * 8) +
-                2 * dm_align_up((size_t)B * N2 * 8) + 2 * dm_align_up((size_t)B * N1 * 8) + 2 * dm_align_up((size_t)B * nchunk * N1 * 8) +
-                dm_align_up((size_t)B * 2 * 8) + dm_align_up((size_t)B * nblk * 8) + dm_align_up((size_t)nsplit_m * bKK);
+    if (m_terms)      // O(N k): the mapped indicator is never stored (em_stats_kernel / em_deriv_kernel)
+        need += 2 * dm_align_up((size_t)B * N2 * k1 * 8) + 2 * dm_align_up((size_t)B * N2 * 8) + 2 * dm_align_up((size_t)B * N1 * 8) +
+                2 * dm_align_up((size_t)B * dm_cdiv(N2, EM_RG) * N1 * 8) + dm_align_up((size_t)B * 2 * 8) +
+                dm_align_up((size_t)B * dm_cdiv(N2, EM_T) * 8) + dm_align_up((size_t)nsplit_m * bKK);
     if (dcomm) need += dm_align_up((size_t)B * n_ops * k2 * k1 * 8) + dm_align_up((size_t)nsplit_d * bKK);
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
@@ -352,47 +540,57 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
 
     // ---- terms in the mapped indicator
     if (m_terms) {
-        double* M = (double*)dm_ws_take(ctx, (size_t)B * N2 * N1 * 8);
-        double* E2 = (double*)dm_ws_take(ctx, (size_t)B * N2 * k1 * 8);            // Phi2 C, later Y = D' Phi1
-        double* P1T = (double*)dm_ws_take(ctx, (size_t)B * k1pad * N1pad * 8);     // Phi1^T (K-major float64)
+        const int ngroups = dm_cdiv(N2, EM_RG), nrb = dm_cdiv(N2, EM_T);
+        const bool stats = mw.stoch > 0 || mw.sumto1 > 0;
+        double* E2 = (double*)dm_ws_take(ctx, (size_t)B * N2 * k1 * 8);            // Phi2 C
+        double* Yv = (double*)dm_ws_take(ctx, (size_t)B * N2 * k1 * 8);            // Y = D' Phi1
         double* rs = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
         double* rsq = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
         double* cs = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);
         double* csq = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);
-        double* pcs = (double*)dm_ws_take(ctx, (size_t)B * nchunk * N1 * 8);
-        double* pcsq = (double*)dm_ws_take(ctx, (size_t)B * nchunk * N1 * 8);
+        double* pcs = (double*)dm_ws_take(ctx, (size_t)B * ngroups * N1 * 8);
+        double* pcsq = (double*)dm_ws_take(ctx, (size_t)B * ngroups * N1 * 8);
         double* stat = (double*)dm_ws_take(ctx, (size_t)B * 2 * 8);
-        double* pe = (double*)dm_ws_take(ctx, (size_t)B * nblk * 8);
+        double* pe = (double*)dm_ws_take(ctx, (size_t)B * nrb * 8);
         double* part = (double*)dm_ws_take(ctx, (size_t)nsplit_m * bKK);
-        if (!M || !E2 || !P1T || !rs || !rsq || !cs || !csq || !pcs || !pcsq || !stat || !pe || !part)
+        if (!E2 || !Yv || !rs || !rsq || !cs || !csq || !pcs || !pcsq || !stat || !pe || !part)
             return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
-        {   // E2 = Phi2 C;  M = (E2 Phi1^T) * mass1   (convert.py:144)
+        {   // E2 = Phi2 C   (the left factor of the mapped indicator, convert.py:144)
             KRowsF32 opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
             KRowsF64 opb{C, (long long)k2 * k1, k1, k1, k2, 1};
             OutNT out{E2, (long long)N2 * k1, k1};
             DM_LAUNCH(ctx, "emb2_nt_f64", (gemm_nt_f64<KRowsF32, KRowsF64, OutNT>), dim3(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
                       dim3(256), 0, opa, opb, out, N2, k1, k2);
-            KRowsF64 ea{E2, (long long)N2 * k1, k1, N2, k1, 0};
-            KRowsF32 pb{Phi1, (long long)N1 * ld1, ld1, N1, k1};
-            OutNTScaledCols om{M, (long long)N2 * N1, N1, mass1, N1};
-            DM_LAUNCH(ctx, "indicator_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF32, OutNTScaledCols>),
-                      dim3(dm_cdiv(N2, NT_T) * dm_cdiv(N1, NT_T), 1, B), dim3(256), 0, ea, pb, om, N2, N1, k1);
         }
-        DM_LAUNCH(ctx, "energy_row_stats", m_row_stats_kernel, dim3(dm_cdiv(N2, 4), B), dim3(256), 0, M, N2, N1, rs, rsq);
-        DM_LAUNCH(ctx, "energy_col_stats", m_col_stats_kernel, dim3(dm_cdiv(N1, 256), nchunk, B), dim3(256), 0, M, N2, N1, nchunk, pcs, pcsq);
-        DM_LAUNCH(ctx, "energy_finish_stats", m_finish_stats_kernel, dim3(B), dim3(256), 0, pcs, pcsq, nchunk, N2, N1, rs, cs, csq, stat);
-        DM_LAUNCH(ctx, "energy_derivative", m_derivative_kernel, dim3(nblk, B), dim3(256), 0, M, N2, N1, mass1, rs, rsq, cs, csq, stat, mw, pe);
-        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, nblk, N1, N2, cs, csq, stat, mw, e_m);
-        {   // Y = D' Phi1 (N2 x k1);  Gm = Phi2^T Y
-            rc = dm_launch_phiT(ctx, B, N1, k1, Phi1, ld1, P1T, k1pad, N1pad);
+        em_params ep;
+        memset(&ep, 0, sizeof(ep));
+        ep.E2 = E2; ep.Phi1 = Phi1; ep.ld1 = ld1; ep.mass1 = mass1; ep.N1 = N1; ep.N2 = N2; ep.k1 = k1;
+        ep.ldp = pad_to(k1, 32) + 4;
+        ep.rs = rs; ep.rsq = rsq; ep.pcs = pcs; ep.pcsq = pcsq; ep.ngroups = ngroups; ep.cs = cs; ep.csq = csq; ep.stat = stat;
+        ep.w = mw; ep.Y = Yv; ep.pe = pe;
+        if (stats) {
+            const size_t lds1 = ((size_t)EM_T * EM_LDA + 2 * EM_RG + 2 * 2 * 2 * 64) * 8 + (size_t)EM_T * ep.ldp * 4;
+            rc = dm_grant_lds(ctx, (const void*)em_stats_kernel, lds1);
             if (rc) return rc;
-            KRowsF64 da{M, (long long)N2 * N1, N1, N2, N1, 0};
-            KRowsF64 pb{P1T, (long long)k1pad * N1pad, N1pad, k1, N1, 0};
-            OutNT oy{E2, (long long)N2 * k1, k1};
-            DM_LAUNCH(ctx, "energy_back_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutNT>), dim3(dm_cdiv(N2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
-                      dim3(256), 0, da, pb, oy, N2, k1, N1);
+            DM_LAUNCH(ctx, "energy_stats_tiles", em_stats_kernel, dim3(ngroups, B), dim3(256), lds1, ep);
+            DM_LAUNCH(ctx, "energy_finish_stats", m_finish_stats_kernel, dim3(B), dim3(256), 0, pcs, pcsq, ngroups, N2, N1, rs, cs, csq, stat);
+        }
+        {
+            const size_t lds2 = ((size_t)EM_T * EM_LDA + EM_T * EM_LDD) * 8 + (size_t)EM_T * ep.ldp * 4;
+            const int nt2 = dm_cdiv(dm_cdiv(k1, 16), 4);
+#define EM_DERIV(NT2_)                                                                                                  \
+            {                                                                                                          \
+                rc = dm_grant_lds(ctx, (const void*)em_deriv_kernel<NT2_>, lds2);                                      \
+                if (rc) return rc;                                                                                     \
+                DM_LAUNCH(ctx, "energy_deriv_tiles", em_deriv_kernel<NT2_>, dim3(nrb, B), dim3(256), lds2, ep);        \
+            }
+            if (nt2 <= 1) EM_DERIV(1) else if (nt2 <= 2) EM_DERIV(2) else EM_DERIV(4)
+#undef EM_DERIV
+        }
+        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, nrb, N1, N2, cs, csq, stat, mw, e_m);
+        {   // Gm = Phi2^T Y
             RowsF32Scaled opx{Phi2, (long long)N2 * ld2, ld2, k2, nullptr, 0};
-            RowsF64TN opy{E2, (long long)N2 * k1, k1, k1};
+            RowsF64TN opy{Yv, (long long)N2 * k1, k1, k1};
             OutTNPartial op{nsplit_m > 1 ? part : Gm, B, k2, k1};
             DM_LAUNCH(ctx, "energy_back_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF64TN, OutTNPartial>),
                       dim3(dm_cdiv(k2, TN_T) * dm_cdiv(k1, TN_T), nsplit_m, B), dim3(256), 0, opx, opy, op, k2, k1, N2, 512);

@@ -161,7 +161,8 @@ int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D,
  * energy (B) fp64 = the reference's energy value; grad (B,k2,k1) fp64 = its gradient with column 0 zeroed (:759).
  * A (B,k1,D), Bm (B,k2,D) fp32 = the projections (dm_project); ops1 (B,n_ops,k1,k1), ops2 (B,n_ops,k2,k2) fp64 =
  * dm_fmap_descr_ops of the two meshes (needed only when w_dcomm > 0; n_ops = number of descriptors).  The terms in the
- * mapped indicator (last five weights) need Phi1, Phi2, mass1 and B*N2*N1 doubles of context workspace. */
+ * mapped indicator (last five weights) need Phi1, Phi2, mass1; the indicator itself is never stored (its tiles are formed twice on
+ * the float64 matrix cores, statistics then derivative): workspace O(B N k), k1 <= 256. */
 int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D,
                         const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass1,
                         const float* A, const float* Bm, const double* lam1, const double* lam2,

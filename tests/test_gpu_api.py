@@ -486,3 +486,54 @@ def test_function_space_helpers(fx_cfg1):
     tr = model.transfer(g, reverse=True)
     assert tr.shape == (m1.n_vertices, 2)
     assert np.abs(tr - m1.eigenvectors[:, :k] @ (np.linalg.pinv(model.FM) @ want2)).max() < 1e-5 * np.abs(tr).max()
+
+
+@pytest.mark.parametrize("N1,N2,k1,k2", [(300, 517, 20, 33), (1000, 777, 70, 50), (640, 576, 200, 190), (129, 65, 15, 15)])
+def test_energy_indicator_terms_ragged(N1, N2, k1, k2):
+    """the tile-fused indicator terms (the N2 x N1 matrix is never stored) on sizes that are multiples of no tile, rectangular
+    maps, k1 from 15 to 200 (one to four 16-column tiles of Y per wave): value and gradient against the oracle"""
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(N1 + 3 * N2 + k1)
+    B, D = 2, 8
+    e1 = (rng.standard_normal((B, N1, k1)) / np.sqrt(N1)).astype(np.float32)
+    e2 = (rng.standard_normal((B, N2, k2)) / np.sqrt(N2)).astype(np.float32)
+    a1 = (rng.uniform(0.5, 1.5, (B, N1)) / N1).astype(np.float32)
+    C = rng.standard_normal((B, k2, k1)) * 3.0
+    A = rng.standard_normal((B, k1, D)).astype(np.float32)
+    Bm = rng.standard_normal((B, k2, D)).astype(np.float32)
+    lam1, lam2 = np.sort(rng.uniform(0, 50, (B, k1)), axis=1), np.sort(rng.uniform(0, 50, (B, k2)), axis=1)
+    for w in ({"w_ent": 0.3}, {"w_sumto1": 2.0}, {"w_stochastic": 0.7}, {"w_p2p": 0.5, "w_range01": 1.5},
+              {"w_p2p": 0.5, "w_stochastic": 0.7, "w_ent": 0.3, "w_range01": 1.5, "w_sumto1": 2.0, "w_descr": 1.0, "w_lap": 0.1}):
+        E, G = eng.energy_grad(C, A, Bm, lam1, lam2, w, e1, e2, a1)
+        for b in range(B):
+            ev = orc.ev_sqdiff(lam1[b], lam2[b])
+            Eo, Go = orc.energy_grad_general(C[b], A[b].astype(np.float64), Bm[b].astype(np.float64), ev, e1[b], e2[b], a1[b], w)
+            assert abs(float(E[b]) - Eo) <= 1e-11 * abs(Eo), (w, b, float(E[b]), Eo)
+            assert np.abs(G[b].cpu().numpy() - Go).max() <= 1e-11 * np.abs(Go).max(), (w, b)
+
+
+def test_energy_indicator_terms_never_materialise_the_indicator():
+    """N = 8192, four pairs: the old form needed B N2 N1 doubles (2.1 GB here, 34 GB for a batch of 64); the tile-fused one
+    runs in O(N k) -- and pair 0 equals the oracle (which does build the 537 MB matrix, once)"""
+    import torch
+    from densematcher_amd.engine import MatchEngine
+    eng = MatchEngine()                                   # a fresh context: its arena shows what this call alone needs
+    rng = np.random.default_rng(8192)
+    B, N, k, D = 4, 8192, 50, 8
+    e1 = (rng.standard_normal((B, N, k)) / np.sqrt(N)).astype(np.float32)
+    e2 = (rng.standard_normal((B, N, k)) / np.sqrt(N)).astype(np.float32)
+    a1 = (rng.uniform(0.5, 1.5, (B, N)) / N).astype(np.float32)
+    C = rng.standard_normal((B, k, k))
+    A = rng.standard_normal((B, k, D)).astype(np.float32)
+    Bm = rng.standard_normal((B, k, D)).astype(np.float32)
+    lam = np.sort(rng.uniform(0, 50, (B, k)), axis=1)
+    w = {"w_ent": 0.1, "w_sumto1": 10.0, "w_descr": 1e4, "w_lap": 1e3}
+    E, G = eng.energy_grad(C, A, Bm, lam, lam, w, e1, e2, a1)
+    torch.cuda.synchronize()
+    assert eng.workspace_bytes() < (1 << 30) // 8, eng.workspace_bytes()        # 128 MiB for four pairs
+    Eo, Go = orc.energy_grad_general(C[0], A[0].astype(np.float64), Bm[0].astype(np.float64), orc.ev_sqdiff(lam[0], lam[0]), e1[0], e2[0],
+                                     a1[0], w)
+    assert abs(float(E[0]) - Eo) <= 1e-11 * abs(Eo)
+    assert np.abs(G[0].cpu().numpy() - Go).max() <= 1e-10 * np.abs(Go).max()
+    eng.close()
