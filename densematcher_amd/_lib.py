@@ -35,6 +35,10 @@ SIGNATURES = {
     "dm_fmap_c00": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_fmap_solve": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _d, _d, _p, _p]),
     "dm_fmap_energy_grad": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "dm_lbfgs_state_bytes": (C.c_size_t, [_i, _i, _i]),
+    "dm_lbfgs_init": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "dm_lbfgs_advance": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _d, _d, _i, _i, _i]),
+    "dm_lbfgs_result": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "dm_fmap_descr_ops": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
     "dm_fm_to_p2p": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_fm_to_p2p_uses_split": (_i, [_p, _i, _i, _i]),

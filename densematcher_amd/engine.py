@@ -255,14 +255,24 @@ class MatchEngine:
                                                C.cast(w, C.c_void_p), _ptr(Cm), _ptr(energy), _ptr(grad)))
         return energy, grad
 
-    def fit_general(self, batch, weights, x0, k=None, maxiter=1000000, lbfgs_options=None):
-        """FunctionalMapping.fit for any of the implemented energy terms, a whole batch at once: L-BFGS-B
-        (scipy.optimize.minimize, as the reference, functional.py:477) on the sum of the pairs' energies -- the pairs are
-        independent, so the minimiser of the sum is the tuple of the pairs' minimisers -- with energy and gradient
-        evaluated on the GPU (one dm_fmap_energy_grad call per evaluation for the whole batch, float64).
-        x0 (B,k2,k1): start, its first column is the pinned one.  Returns (C (B,k2,k1) numpy, scipy result)."""
+    # SciPy's L-BFGS-B defaults, i.e. what the reference's `minimize(..., options={'maxiter': maxiter})` runs with (functional.py:477)
+    LBFGS_REFERENCE = {"maxcor": 10, "ftol": 2.220446049250313e-09, "gtol": 1e-5, "maxfun": 15000, "maxls": 20}
+    LBFGS_STATUS = {0: "running", 1: "CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL", 2: "CONVERGENCE: REL_REDUCTION_OF_F <= FACTR*EPSMCH",
+                    3: "STOP: TOTAL NO. of ITERATIONS REACHED LIMIT", 4: "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT",
+                    5: "ABNORMAL_TERMINATION_IN_LNSRCH"}
+
+    def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4):
+        """FunctionalMapping.fit for any of the implemented energy terms, a whole batch at once (reference: L-BFGS-B through
+        scipy.optimize.minimize, one pair per call, functional.py:477).  Every pair runs its OWN limited-memory BFGS iteration --
+        history, step length, stopping test -- so a pair's result does not depend on the batch it is in; the optimiser state
+        lives on the device (dm_lbfgs_*), energy and gradient of all pairs come from one dm_fmap_energy_grad call per
+        evaluation, and the host reads the status words every `check_every` evaluations.
+        lbfgs_options: maxcor, ftol, gtol, maxfun, maxls with SciPy's names; default = SciPy's defaults (LBFGS_REFERENCE).
+        driver="scipy" (single pair only): the same evaluations driven by scipy.optimize.minimize on the host, as the reference.
+        x0 (B,k2,k1): start, its first column is the pinned one.  Returns (C (B,k2,k1) numpy, result) with result.x, .fun (B),
+        .status (B), .nit (B), .nfev (B), .message (list)."""
+        import types
         import numpy as np
-        import scipy.optimize
         k1 = k if k is not None else batch["lam1"].shape[1]
         k2 = k if k is not None else batch["lam2"].shape[1]
         Phi1, Phi2 = batch["Phi1"], batch["Phi2"]
@@ -279,20 +289,51 @@ class MatchEngine:
         a1 = self._dev(batch["a1"], torch.float32, "a1")
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         B = x0.shape[0]
-        cache = {}
-
-        def fg(x):
-            key = x.tobytes()
-            if key not in cache:
-                cache.clear()
-                e, g = self.energy_grad(torch.from_numpy(x.reshape(B, k2, k1)), A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
-                cache[key] = (float(e.sum().item()), g.cpu().numpy().ravel())
-            return cache[key]
-
-        opts = {"maxiter": maxiter, "maxfun": 10 * maxiter}
+        opts = dict(self.LBFGS_REFERENCE)
         opts.update(lbfgs_options or {})
-        res = scipy.optimize.minimize(lambda x: fg(x)[0], x0.ravel(), jac=lambda x: fg(x)[1], method="L-BFGS-B", options=opts)
-        return res.x.reshape(B, k2, k1), res
+        if driver == "scipy":
+            import scipy.optimize
+            if B != 1:
+                raise ValueError("driver='scipy' optimises one pair per call (the summed energy of a batch would couple the pairs)")
+            cache = {}
+
+            def fg(x):
+                key = x.tobytes()
+                if key not in cache:
+                    cache.clear()
+                    e, g = self.energy_grad(torch.from_numpy(x.reshape(B, k2, k1)), A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
+                    cache[key] = (float(e.sum().item()), g.cpu().numpy().ravel())
+                return cache[key]
+            res = scipy.optimize.minimize(lambda x: fg(x)[0], x0.ravel(), jac=lambda x: fg(x)[1], method="L-BFGS-B",
+                                          options={"maxiter": maxiter, **opts})
+            return res.x.reshape(B, k2, k1), res
+        n, m = k2 * k1, int(opts["maxcor"])
+        nbytes = int(self.lib.dm_lbfgs_state_bytes(B, n, m))
+        state = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
+        xt = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        x0d = self._dev(x0, torch.float64, "x0")
+        self._chk(self.lib.dm_lbfgs_init(self.ctx, B, n, m, _ptr(x0d), _ptr(state), _ptr(xt)))
+        # the per-pair integer state (status first) sits behind the float64 blocks of the state buffer
+        n_f64 = 3 * B * n + 2 * B * m * n + 2 * B * m + 16 * B
+        ints = state[n_f64:n_f64 + (8 * B * 4 + 7) // 8].view(torch.int32)[:8 * B].view(B, 8)
+        nev, maxfun = 0, int(opts["maxfun"])
+        while True:
+            e, g = self.energy_grad(xt, A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
+            self._chk(self.lib.dm_lbfgs_advance(self.ctx, B, n, m, _ptr(state), _ptr(e), _ptr(g), _ptr(xt), float(opts["ftol"]),
+                                                float(opts["gtol"]), int(maxiter), maxfun, int(opts["maxls"])))
+            nev += 1
+            if nev % check_every == 0 or nev > maxfun + 2:
+                if bool((ints[:, 0] != 0).all()) or nev > maxfun + 2:        # (one host synchronisation per check_every evaluations)
+                    break
+        xo = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        fo = torch.empty((B,), dtype=torch.float64, device=self.device)
+        info = torch.empty((B, 4), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_lbfgs_result(self.ctx, B, n, m, _ptr(state), _ptr(xo), _ptr(fo), _ptr(info)))
+        info = info.cpu().numpy()
+        res = types.SimpleNamespace(x=xo.cpu().numpy(), fun=fo.cpu().numpy(), status=info[:, 0].copy(), nit=info[:, 1].copy(),
+                                    nfev=info[:, 2].copy(), message=[self.LBFGS_STATUS.get(int(q), "?") for q in info[:, 0]],
+                                    success=bool(np.all((info[:, 0] == 1) | (info[:, 0] == 2))), evaluations=nev)
+        return res.x, res
 
     def fm_to_p2p(self, Phi1, Phi2, a1, Cm, k1=None, k2=None, knn=True, ind=True):
         """Returns dict with knn21, knn12 (kd-tree maps of the reference) and ind21, ind12 (indicator arg-max)."""

@@ -9,10 +9,11 @@ import numpy as np
 from . import refine, signatures as sg, spectral
 
 _OPTIMIZERS = ("L-BFGS-B", "fmin_l_bfgs_b", "l-bfgs-b")
-# L-BFGS-B stopping rule of the iterative fit.  The reference passes only maxiter (SciPy defaults ftol = 2.2e-9, gtol = 1e-5)
-# and evaluates in float32, which stops 1e-4 .. 1e-3 short of the minimiser; the float64 evaluation here
-# makes a tight rule meaningful, and the 1e-4 parity bar on C needs it.
-LBFGS_OPTIONS = {"ftol": 1e-15, "gtol": 1e-9, "maxcor": 30}
+# L-BFGS stopping rule of the iterative fit.  The reference passes only maxiter (SciPy defaults ftol = 2.2e-9, gtol = 1e-5,
+# maxcor = 10) and evaluates in float32, which stops 1e-4 .. 1e-3 short of the minimiser.  The float64
+# evaluation here makes a tight rule meaningful and the 1e-4 parity bar on C needs it: tight by default (bounded by SciPy's
+# maxfun = 15000); fit(..., stopping="reference") runs SciPy's default rule instead.
+LBFGS_OPTIONS = {"ftol": 1e-15, "gtol": 1e-9, "maxcor": 30, "maxfun": 15000}
 
 
 class FunctionalMapping:
@@ -120,7 +121,7 @@ class FunctionalMapping:
     # ---------------------------------------------------------------- fit (functional.py:352-487)
     def fit(self, w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_orient=0, w_area=0, w_conformal=0, w_p2p=0, w_stochastic=0, w_ent=0,
             w_range01=0, w_sumto1=0, w_area_difference=0, w_mumford_shah=0, mumford_shah_var=0.1, w_eta_entropy=0,
-            orient_reversing=False, optinit='zeros', verbose=False, maxiter=1000000, device=None):
+            orient_reversing=False, optinit='zeros', verbose=False, maxiter=1000000, device=None, stopping="tight", driver="device"):
         """reference functional.py:352-487.  With only w_descr / w_lap > 0 the minimiser (what the reference's L-BFGS-B
         converges to, first column pinned) is obtained in closed form on the GPU.  With
         w_dcomm, w_p2p, w_stochastic, w_ent, w_range01 or w_sumto1 > 0 the reference's own scheme runs: L-BFGS-B
@@ -160,8 +161,11 @@ class FunctionalMapping:
                                np.float64: __import__("torch").float64}[v.dtype.type], n) for n, v in batch.items()}
         if iterative:
             weights = dict(w_descr=w_descr, w_lap=w_lap, **general)
-            C, res = eng.fit_general(dev, weights, self.get_x0(optinit=optinit)[None], maxiter=maxiter, lbfgs_options=LBFGS_OPTIONS)
-            self.FM = C[0]
+            if stopping not in ("tight", "reference"):
+                raise ValueError("stopping must be 'tight' or 'reference'")
+            C, res = eng.fit_general(dev, weights, self.get_x0(optinit=optinit)[None], maxiter=maxiter,
+                                     lbfgs_options=LBFGS_OPTIONS if stopping == "tight" else None, driver=driver)
+            self.FM = np.asarray(C[0], dtype=np.float64)
             self.fit_result = res
             if verbose:
                 print(f"\tTask funcall : {res.nfev}, nit : {res.nit}, warnflag : {res.message}")

@@ -169,6 +169,24 @@ int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int 
                         const double* ops1 /*nullable*/, const double* ops2 /*nullable*/, int n_ops,
                         const double* weights /*host, 8*/, const double* C, double* energy, double* grad);
 
+/* ---- batched L-BFGS on the device --------------------------------------------------------------------------------
+ * The optimiser FunctionalMapping.fit runs for the non-quadratic terms: replaces scipy.optimize.minimize(method = "L-BFGS-B")
+ * of pyFM/functional.py:477 (no bounds are set there: plain limited-memory BFGS with L-BFGS-B's line-search constants and
+ * stopping tests).  The state of every pair (iterate, gradient, direction, m history pairs, line-search bracket, counters)
+ * lives in `state` (dm_lbfgs_state_bytes bytes of device memory owned by the caller); pairs are independent of one another.
+ *   dm_lbfgs_init     x0 (B,n) -> state, x_trial = x0
+ *   dm_lbfgs_advance  energy (B) and grad (B,n) of x_trial (dm_fmap_energy_grad) -> the pairs' next trial points in x_trial;
+ *                     ftol: stop when (f_k - f_k+1) <= ftol max(|f_k|, |f_k+1|, 1) (SciPy: factr * eps = 2.2e-9), pgtol: max |g_i|
+ *                     (SciPy 1e-5), maxiter, maxfun (SciPy 15000), maxls (SciPy 20).  Finished pairs keep x_trial at their result.
+ *   dm_lbfgs_result   x (B,n), f (B), info (B,4) = status (0 running, 1 gradient, 2 energy decrease, 3 maxiter, 4 maxfun, 5 line
+ *                     search failed), iterations, evaluations, history length
+ * The host alternates dm_fmap_energy_grad and dm_lbfgs_advance and reads info every few evaluations. */
+size_t dm_lbfgs_state_bytes(int B, int n, int m);
+int dm_lbfgs_init(dm_ctx* ctx, int B, int n, int m, const double* x0, void* state, double* x_trial);
+int dm_lbfgs_advance(dm_ctx* ctx, int B, int n, int m, void* state, const double* energy, const double* grad, double* x_trial,
+                     double ftol, double pgtol, int maxiter, int maxfun, int maxls);
+int dm_lbfgs_result(dm_ctx* ctx, int B, int n, int m, const void* state, double* x, double* f, int32_t* info);
+
 /* ops[b][d] = Phi[b][:, :k]^T diag(mass[b] * F[b][:, d]) Phi[b][:, :k]   (B, D, k, k) fp64: the multiplication operator
  * of descriptor d in the reduced basis.  Replaces commute_left / commute_right of base_functions.py:550-555
  * (pinv @ (descr[:, i, None] * evects), pinv = evects^T A, pyFM/functional.py:416-417).  B * D <= 65535 per call. */

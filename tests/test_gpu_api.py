@@ -537,3 +537,50 @@ def test_energy_indicator_terms_never_materialise_the_indicator():
     assert abs(float(E[0]) - Eo) <= 1e-11 * abs(Eo)
     assert np.abs(G[0].cpu().numpy() - Go).max() <= 1e-10 * np.abs(Go).max()
     eng.close()
+
+
+def test_fit_general_batched_device_lbfgs(fx_cfg1, oracle_cfg1_fits):
+    """The iterative fit on the device-resident batched L-BFGS (dm_lbfgs_*): every pair of a batch has its own optimiser
+    state, so a pair's C is bit-identical whatever batch it is in; the result is the minimiser the
+    oracle's tight float64 L-BFGS-B finds (1e-4), also with SciPy driving the same GPU evaluations, and the reference's
+    default stopping rule lands inside the reference's own noise floor of it."""
+    import torch
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    fx = fx_cfg1
+    k = int(fx["k"])
+    w = {n: v for n, v in NOTEBOOK.items() if n.startswith("w_")}
+    x0 = orc.get_x0(k, k, float(fx["Phi1"][0, 0]), float(fx["Phi2"][0, 0]), float(fx["a1"].astype(np.float64).sum()),
+                    float(fx["a2"].astype(np.float64).sum()))
+    rng = np.random.default_rng(3)
+
+    def pair(scale, perm_seed):
+        F2 = fx["F2"].copy()
+        if perm_seed:
+            F2 = F2[:, np.random.default_rng(perm_seed).permutation(F2.shape[1])]
+        return {"Phi1": fx["Phi1"][:, :k], "Phi2": fx["Phi2"][:, :k], "lam1": fx["lam1"][:k], "lam2": fx["lam2"][:k], "a1": fx["a1"], "a2": fx["a2"],
+                "F1": (fx["F1"].astype(np.float32) * scale).astype(np.float16), "F2": (F2.astype(np.float32) * scale).astype(np.float16)}
+    pairs = [pair(1.0, 0), pair(0.5, 11), pair(1.0, 12)]        # pair 0 = the fixture; the others converge after different iteration counts
+    batch = {n: np.stack([p[n] for p in pairs]) for n in pairs[0]}
+    tight = {"ftol": 1e-15, "gtol": 1e-9, "maxcor": 30, "maxfun": 15000}
+    C3, r3 = eng.fit_general(batch, w, np.stack([x0] * 3), lbfgs_options=tight)
+    print("batched device L-BFGS: iterations", r3.nit, "evaluations", r3.nfev, "status", r3.status, "host loop", r3.evaluations)
+    assert np.all((r3.status == 1) | (r3.status == 2)) and len(set(r3.nit.tolist())) > 1
+    for b in range(3):
+        one = {n: v[b:b + 1] for n, v in batch.items()}
+        C1, r1 = eng.fit_general(one, w, x0[None], lbfgs_options=tight)
+        assert np.array_equal(C1[0], C3[b]), f"pair {b}: result depends on the batch"
+        assert r1.nit[0] == r3.nit[b] and r1.nfev[0] == r3.nfev[b]
+    assert np.abs(C3[0] - oracle_cfg1_fits["C_nb"]).max() <= 1e-4
+    assert np.array_equal(C3[0][:, 0], x0[:, 0])                  # pinned column
+    # SciPy driving the same GPU evaluations (the reference's own optimiser), one pair
+    one = {n: v[0:1] for n, v in batch.items()}
+    Cs, rs = eng.fit_general(one, w, x0[None], lbfgs_options=tight, driver="scipy")
+    print("scipy driver:", rs.nit, "iterations,", rs.nfev, "evaluations; |C_device - C_scipy| =", np.abs(Cs[0] - C3[0]).max())
+    assert np.abs(Cs[0] - C3[0]).max() <= 1e-4
+    # SciPy's default stopping rule (what the reference's call runs with): inside the reference's own noise floor
+    Cr, rr = eng.fit_general(one, w, x0[None])
+    print("reference stopping rule:", rr.nit, "iterations,", rr.nfev, "evaluations, status", rr.status, "; |C - C_tight| =", np.abs(Cr[0] - C3[0]).max())
+    assert np.abs(Cr[0] - C3[0]).max() <= 2e-3 and rr.nfev[0] < r3.nfev[0]
+    with pytest.raises(ValueError):
+        eng.fit_general(batch, w, np.stack([x0] * 3), driver="scipy")
