@@ -51,6 +51,10 @@ WORKLOADS = {
     "zoomout": dict(nu=64, nv=32, D=0, k=200, B=32, cfg="configs[3]: 32 pairs/GPU, N=2048, k=50->200 ZoomOut refinement"),
     "stress": dict(nu=128, nv=64, D=384, k=200, B=64, cfg="configs[4]: batch=64 pairs, N=8192, D=384, k=200 (HBM-bound stress)"),
     "icp": dict(nu=64, nv=32, D=0, k=128, B=64, cfg="SURVEY 8(f) next #1: spectral ICP, 10 iterations, 64 pairs/GPU, N=2048, k=128"),
+    "surface_map": dict(nu=64, nv=32, D=512, k=15, B=1,
+                        cfg="the reference's one documented call: compute_surface_map with the notebook's parameters (example.ipynb cell 11: "
+                            "n_ev=15, w_descr=1e4, w_lap=1e3, w_ent=0.1, w_sumto1=10, compute_extra=True) on one raw mesh pair, N=2048, D=512 "
+                            "(BASELINE.md section 2: 39.8 s/pair for the reference on 8 CPU cores)"),
 }
 
 
@@ -208,10 +212,132 @@ def timed_kernel(eng, step, kernel, steps, warmup, barrier):
     return elapsed, launches, kernel_ms
 
 
+NOTEBOOK_FIT = dict(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_ent=1e-1, w_sumto1=1e1, optinit="zeros", maxiter=5000)   # example.ipynb cell 11
+
+
+class _Duck:
+    """what compute_surface_map needs of a pytorch3d Meshes object (functional_map.py:17-18)"""
+    def __init__(self, v, f):
+        self.v, self.f = v, f
+
+    def verts_list(self):
+        return [self.v]
+
+    def faces_list(self):
+        return [self.f]
+
+
+def surface_map_workload(args):
+    """Latency of the API the reference exposes: one compute_surface_map call (raw meshes in, 14-tuple out), per-stage times.
+    value = calls per second of ONE pair at a time (the reference's own use); a step is one call."""
+    import torch
+    from densematcher_amd import functional_map as fmod, synth
+    from densematcher_amd.pyFM.functional import FunctionalMapping
+    w = WORKLOADS["surface_map"]
+    nu, nv, D, k = w["nu"], w["nv"], w["D"], w["k"]
+    (v1, f1), (v2, f2) = synth.torus_mesh(nu, nv, perturb=0.03, seed=3), synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
+    F1, F2, _ = synth.feature_pair(nu * nv, nu * nv, D, 1000, 2000, sigma=0.5, perm="identity")
+    stages = {}
+
+    def timed(name, fn):
+        def wrapper(*a, **kw):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn(*a, **kw)
+            torch.cuda.synchronize()
+            stages[name] = stages.get(name, 0.0) + time.perf_counter() - t0
+            return out
+        return wrapper
+    patched = [(FunctionalMapping, "preprocess", "eigenbases (2 meshes: assembly on the host, eigensolve on the GPU)"),
+               (FunctionalMapping, "fit", "fit (L-BFGS, notebook energy terms)"), (FunctionalMapping, "get_p2p", "vertex maps (2 x 4 maps)"),
+               (FunctionalMapping, "_precise_map_device", "precise map"), (FunctionalMapping, "icp_refine", "ICP (10 iterations)"),
+               (fmod, "_assign_many", "linear assignment (3 matrices, one batched call)")]
+    saved = [(o, n, getattr(o, n)) for o, n, _ in patched]
+    for o, n, label in patched:
+        setattr(o, n, timed(label, getattr(o, n)))
+    import warnings
+    try:
+        times = []
+        for rep in range(args.warmup + args.steps):
+            stages.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res = fmod.compute_surface_map(_Duck(v1, f1), _Duck(v2, f2), F1, F2, n_ev=k, compute_extra=True, optimizer="L-BFGS-B",
+                                               fit_params=dict(NOTEBOOK_FIT))
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        last_stages = dict(stages)
+    finally:
+        for o, n, fn in saved:
+            setattr(o, n, fn)
+    t = float(np.median(times[args.warmup:]))
+    model = res[7]
+    out = {"metric": "compute_surface_map calls/sec (one pair at a time, notebook parameters)", "value": round(1.0 / t, 4), "unit": "mesh-pairs/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t, 2), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": w["cfg"], "pairs_per_gpu": 1, "N": nu * nv, "D": D, "k": k},
+           "stages_ms": {n: round(1e3 * v, 2) for n, v in last_stages.items()},
+           "fit": {"iterations": int(model.fit_result.nit[0]), "evaluations": int(model.fit_result.nfev[0]), "status": model.fit_result.message[0]},
+           "roofline": {"bound": "latency", "kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                        "note": "a single pair cannot fill the chip: this workload reports the latency of the API; the throughput kernels are in the default workload"}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_surface_map(v1, f1, v2, f2, F1, F2, k)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_surface_map(v1, f1, v2, f2, F1, F2, k):
+    """the same call restated on the host with the oracle (one pair): dense eigensolve of the same Laplacians, float64 L-BFGS-B
+    with SciPy's default stopping rule (the reference's), kd-tree-free maps, SciPy's linear_sum_assignment x 3, precise map, ICP"""
+    import scipy.linalg
+    import scipy.optimize
+    from densematcher_amd import synth
+    from oracle import dm_oracle as orc
+    t_all = time.perf_counter()
+    st = {}
+
+    def tick(name, t0):
+        st[name] = round(1e3 * (time.perf_counter() - t0), 1)
+    t0 = time.perf_counter()
+    bases = []
+    for v, f in ((v1, f1), (v2, f2)):
+        W, m = synth.cotan_laplacian(v, f)
+        lam, phi = scipy.linalg.eigh(W.toarray(), np.diag(m), subset_by_index=[0, max(20, k) - 1])
+        bases.append((lam[:k], phi[:, :k], m))
+    tick("eigenbases (dense eigh)", t0)
+    (l1, e1, m1), (l2, e2, m2) = bases
+    t0 = time.perf_counter()
+    wts = {n: v for n, v in NOTEBOOK_FIT.items() if n.startswith("w_")}
+    C, _ = orc.fit_general(e1, e2, l1, l2, m1, m2, F1, F2, wts, tight=False)
+    tick("fit", t0)
+    t0 = time.perf_counter()
+    orc.fm_to_p2p_all(C, e1, e2, m1)
+    M0 = orc.mapped_indicator(C, e1, e2, m1)
+    tick("vertex maps + indicator", t0)
+    t0 = time.perf_counter()
+    scipy.optimize.linear_sum_assignment(M0, maximize=True)
+    P0, _, _ = orc.precise_map_dense(C, e1, e2, f1)
+    scipy.optimize.linear_sum_assignment(P0, maximize=True)
+    tick("assignment x 2 + precise map", t0)
+    t0 = time.perf_counter()
+    Ci = orc.icp_refine(C, e1, e2, nit=10)
+    orc.fm_to_p2p_all(Ci, e1, e2, m1)
+    scipy.optimize.linear_sum_assignment(orc.mapped_indicator(Ci, e1, e2, m1), maximize=True)
+    tick("ICP + maps + assignment", t0)
+    tot = time.perf_counter() - t_all
+    return {"value": round(1.0 / tot, 4), "unit": "mesh-pairs/s", "cores": os.cpu_count() or 1, "kind": "port", "stages_ms": st,
+            "sample": f"one pair, the same call on the oracle (NumPy / SciPy float64, BLAS threads on {os.cpu_count()} cores), {tot:.1f} s"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if args.workload == "surface_map":
+        if args.steps == 20:
+            args.steps, args.warmup = 3, 1
+        return surface_map_workload(args)
 
     import torch
     from densematcher_amd.engine import MatchEngine

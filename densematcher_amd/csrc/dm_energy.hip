@@ -162,8 +162,10 @@ __global__ __launch_bounds__(256) void quad_terms_kernel(const double* __restric
 
 // ---- statistics of the mapped indicator ------------------------------------------------------------------------------
 // cs / csq from the chunk partials, and the means of rs and cs: stat[b] = {mean rs, mean cs}   (one workgroup per pair)
+// (rs / rsq arrive as ncs partial sets, one per column split, set q at offset q * B * N2: summed into set 0 here, fixed order)
 __global__ __launch_bounds__(256) void m_finish_stats_kernel(const double* __restrict__ pcs, const double* __restrict__ pcsq, int nchunk,
-                                                             int N2, int N1, const double* __restrict__ rs, double* __restrict__ cs,
+                                                             int N2, int N1, double* __restrict__ rs, double* __restrict__ rsq, int ncs,
+                                                             long long split_stride, double* __restrict__ cs,
                                                              double* __restrict__ csq, double* __restrict__ stat) {
     __shared__ double sh[4];
     const int b = blockIdx.x, t = threadIdx.x;
@@ -176,7 +178,12 @@ __global__ __launch_bounds__(256) void m_finish_stats_kernel(const double* __res
     }
     const double tot_c = block_sum_256(sc, sh);
     double sr = 0.0;
-    for (int i = t; i < N2; i += 256) sr += rs[(long long)b * N2 + i];
+    for (int i = t; i < N2; i += 256) {
+        double s = rs[(long long)b * N2 + i], q = rsq[(long long)b * N2 + i];
+        for (int c = 1; c < ncs; ++c) { s += rs[c * split_stride + (long long)b * N2 + i]; q += rsq[c * split_stride + (long long)b * N2 + i]; }
+        rs[(long long)b * N2 + i] = s; rsq[(long long)b * N2 + i] = q;
+        sr += s;
+    }
     const double tot_r = block_sum_256(sr, sh);
     if (t == 0) { stat[2 * b] = tot_r / (double)N2; stat[2 * b + 1] = tot_c / (double)N1; }
 }
@@ -199,12 +206,15 @@ constexpr int EM_RG = 512;     // rows per workgroup of pass 1
 struct em_params {
     const double* E2; const float* Phi1; int ld1; const float* mass1;
     int N1, N2, k1, ldp;                       // ldp: LDS row stride (floats) of the Phi1 tile, >= k1 rounded up to 32, = 4 (mod 32)
-    double* rs; double* rsq;                   // (B, N2)
+    double* rs; double* rsq;                   // (ncs, B, N2): one set per column split (summed by m_finish_stats_kernel)
     double* pcs; double* pcsq; int ngroups;    // (B, ngroups, N1)
+    int rg;                                    // rows per workgroup of pass 1 (multiple of 64, <= EM_RG)
+    int ncs, cchunk;                           // column splits of both passes, columns per split (multiple of 64)
+    int Bn;                                    // pairs in the batch (stride of the split partials)
     const double* cs; const double* csq; const double* stat;
     mterm_weights w;
-    double* Y;                                 // (B, N2, k1)
-    double* pe;                                // (B, N2 / 64) energy shares
+    double* Y;                                 // (ncs, B, N2, k1): one partial per column split
+    double* pe;                                // (B, ncs * N2 / 64) energy shares
 };
 
 // Phi1 rows j0 .. j0+63 (all k1 columns, zero padded) -> Ps[64][ldp], kept in fp32 (its memory type; widened at the
@@ -256,7 +266,8 @@ __device__ __forceinline__ double em_row16_allsum(double x) {       // sum over 
     return x;
 }
 
-// pass 1: grid (ngroups, B)
+// pass 1: grid (ngroups, ncs, B): workgroup = p.rg rows x one column split.  (A batch fills the chip with whole-row workgroups;
+// a single pair -- the reference's one-pair-per-call use -- gets small row groups and column splits instead of 4 workgroups.)
 __global__ __launch_bounds__(256) void em_stats_kernel(em_params p) {
     extern __shared__ __attribute__((aligned(16))) double em_sm[];
     double* As = em_sm;                                   // [64][EM_LDA]
@@ -265,11 +276,12 @@ __global__ __launch_bounds__(256) void em_stats_kernel(em_params p) {
     double* rowpart = rqacc + EM_RG;                      // [2 wn][2][64]
     double* colpart = rowpart + 2 * 2 * 64;               // [2 wm][2][64]
     float* Ps = reinterpret_cast<float*>(colpart + 2 * 2 * 64);   // [64][ldp]
-    const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int g0 = g * EM_RG, nrb = min(EM_RG, p.N2 - g0 + EM_T - 1) / EM_T;
+    const int b = blockIdx.z, cs_ = blockIdx.y, g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int g0 = g * p.rg, nrb = min(p.rg, p.N2 - g0 + EM_T - 1) / EM_T;
     for (int r = t; r < EM_RG; r += 256) { rsacc[r] = 0.0; rqacc[r] = 0.0; }
     const float* a1 = p.mass1 + (long long)b * p.N1;
-    for (int j0 = 0; j0 < p.N1; j0 += EM_T) {
+    const int jbeg = cs_ * p.cchunk, jend = min(p.N1, jbeg + p.cchunk);
+    for (int j0 = jbeg; j0 < jend; j0 += EM_T) {
         __syncthreads();
         em_load_phi_tile(p, b, j0, Ps, t);
         double cacc = 0.0, cqacc = 0.0;                   // threads 64..127: column j0 + t - 64, over this group's rows
@@ -323,11 +335,14 @@ __global__ __launch_bounds__(256) void em_stats_kernel(em_params p) {
         }
     }
     __syncthreads();
-    for (int r = t; r < EM_RG; r += 256)
-        if (g0 + r < p.N2) { p.rs[(long long)b * p.N2 + g0 + r] = rsacc[r]; p.rsq[(long long)b * p.N2 + g0 + r] = rqacc[r]; }
+    for (int r = t; r < p.rg; r += 256)
+        if (g0 + r < p.N2) {
+            const long long o = ((long long)cs_ * p.Bn + b) * p.N2 + g0 + r;
+            p.rs[o] = rsacc[r]; p.rsq[o] = rqacc[r];
+        }
 }
 
-// pass 2: grid (N2 / 64, B); NT2 = 16-column tiles of Y per wave (k1 <= 64 NT2)
+// pass 2: grid (N2 / 64, ncs, B); NT2 = 16-column tiles of Y per wave (k1 <= 64 NT2)
 template <int NT2>
 __global__ __launch_bounds__(256) void em_deriv_kernel(em_params p) {
     extern __shared__ __attribute__((aligned(16))) double em_sm[];
@@ -335,8 +350,9 @@ __global__ __launch_bounds__(256) void em_deriv_kernel(em_params p) {
     double* As = em_sm;                                   // [64][EM_LDA]
     double* Ds = As + EM_T * EM_LDA;                      // [64][EM_LDD]
     float* Ps = reinterpret_cast<float*>(Ds + EM_T * EM_LDD);     // [64][ldp]
-    const int b = blockIdx.y, rb = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z, cs_ = blockIdx.y, rb = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     const int r0 = rb * EM_T;
+    const int jbeg = cs_ * p.cchunk, jend = min(p.N1, jbeg + p.cchunk);
     const float* a1 = p.mass1 + (long long)b * p.N1;
     const mterm_weights w = p.w;
     const bool stats = w.stoch > 0.0 || w.sumto1 > 0.0;
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256) void em_deriv_kernel(em_params p) {
 #pragma unroll
         for (int q = 0; q < NT2; ++q) Yacc[mt][q] = f64x4{0.0, 0.0, 0.0, 0.0};
     double eacc = 0.0;
-    for (int j0 = 0; j0 < p.N1; j0 += EM_T) {
+    for (int j0 = jbeg; j0 < jend; j0 += EM_T) {
         __syncthreads();                                   // the previous tile's second product has read Ps / Ds
         em_load_phi_tile(p, b, j0, Ps, t);
         f64x4 acc[2][2];
@@ -418,14 +434,14 @@ __global__ __launch_bounds__(256) void em_deriv_kernel(em_params p) {
         }
     }
     // the rows' shares of the row-statistics terms (once per row), then the workgroup's energy share
-    if (stats && t < 64 && r0 + t < p.N2) {
+    if (stats && cs_ == 0 && t < 64 && r0 + t < p.N2) {
         const double ds = (w.sumto1 > 0.0) ? p.rs[(long long)b * p.N2 + r0 + t] - mean_r : 0.0;
         const double dq = (w.stoch > 0.0) ? p.rsq[(long long)b * p.N2 + r0 + t] - 1.0 : 0.0;
         eacc += w.stoch * dq * dq + w.sumto1 * ds * ds;
     }
     const double tot = block_sum_256(eacc, sh);
-    if (t == 0) p.pe[(long long)b * gridDim.x + rb] = tot;
-    double* Yb = p.Y + (long long)b * p.N2 * p.k1;
+    if (t == 0) p.pe[((long long)b * gridDim.y + cs_) * gridDim.x + rb] = tot;
+    double* Yb = p.Y + ((long long)cs_ * p.Bn + b) * p.N2 * p.k1;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -435,6 +451,15 @@ __global__ __launch_bounds__(256) void em_deriv_kernel(em_params p) {
                 const int i = r0 + mt * 16 + (lane >> 4) + 4 * r, n = (wave + 4 * q) * 16 + (lane & 15);
                 if (i < p.N2 && n < p.k1) Yb[(long long)i * p.k1 + n] = Yacc[mt][q][r];
             }
+}
+
+// Y (set 0) += the other column splits' partials (fixed order)
+__global__ __launch_bounds__(256) void em_sum_splits_kernel(double* __restrict__ Y, long long n, int ncs) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = Y[i];
+    for (int c = 1; c < ncs; ++c) s += Y[c * n + i];
+    Y[i] = s;
 }
 
 // e_m[b] = sum of the workgroup shares + the column-statistics terms   (one workgroup per pair)
@@ -502,13 +527,25 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
 
     const size_t bKK = (size_t)B * k2 * k1 * 8;
     DM_REQUIRE(ctx, !m_terms || k1 <= 256, "the indicator terms need k1 <= 256");
+    // Work decomposition of the two indicator passes: a workgroup sweeps `rg` rows x one column split.  A batch fills the chip
+    // with whole-row sweeps (rg = 512, no splits); a single pair (the reference's use: one pair per call) would leave 252 of the
+    // 256 CUs idle that way, so the row groups shrink to one 64-row block and the columns are split until ~512 workgroups exist.
+    int rg = EM_RG, ncs = 1;
+    {
+        const int ncu2 = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+        while (rg > EM_T && (long long)B * dm_cdiv(N2, rg) < ncu2) rg >>= 1;
+        const int max_split = dm_cdiv(N1, 4 * EM_T) > 0 ? dm_cdiv(N1, 4 * EM_T) : 1;        // at least four column tiles per workgroup
+        while (ncs < max_split && (long long)B * dm_cdiv(N2, EM_T) * ncs < ncu2) ncs <<= 1;
+    }
+    const int cchunk = pad_to(dm_cdiv(N1, ncs), EM_T);
+    const int ngroups = dm_cdiv(N2, rg);
     const int nsplit_m = dm_cdiv(N2, 512);
     const int nsplit_d = dcomm ? dm_cdiv(n_ops * k2, 512) : 0;
     size_t need = dm_align_up((size_t)B * (k1 + k2) * k1 * 8) + 4 * dm_align_up(bKK) + 4 * dm_align_up((size_t)B * 8) + 65536;
     if (m_terms)      // O(N k): the mapped indicator is never stored (em_stats_kernel / em_deriv_kernel)
-        need += 2 * dm_align_up((size_t)B * N2 * k1 * 8) + 2 * dm_align_up((size_t)B * N2 * 8) + 2 * dm_align_up((size_t)B * N1 * 8) +
-                2 * dm_align_up((size_t)B * dm_cdiv(N2, EM_RG) * N1 * 8) + dm_align_up((size_t)B * 2 * 8) +
-                dm_align_up((size_t)B * dm_cdiv(N2, EM_T) * 8) + dm_align_up((size_t)nsplit_m * bKK);
+        need += dm_align_up((size_t)B * N2 * k1 * 8) + dm_align_up((size_t)ncs * B * N2 * k1 * 8) + 2 * dm_align_up((size_t)ncs * B * N2 * 8) +
+                2 * dm_align_up((size_t)B * N1 * 8) + 2 * dm_align_up((size_t)B * ngroups * N1 * 8) + dm_align_up((size_t)B * 2 * 8) +
+                dm_align_up((size_t)B * ncs * dm_cdiv(N2, EM_T) * 8) + dm_align_up((size_t)nsplit_m * bKK);
     if (dcomm) need += dm_align_up((size_t)B * n_ops * k2 * k1 * 8) + dm_align_up((size_t)nsplit_d * bKK);
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
@@ -540,18 +577,18 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
 
     // ---- terms in the mapped indicator
     if (m_terms) {
-        const int ngroups = dm_cdiv(N2, EM_RG), nrb = dm_cdiv(N2, EM_T);
+        const int nrb = dm_cdiv(N2, EM_T);
         const bool stats = mw.stoch > 0 || mw.sumto1 > 0;
         double* E2 = (double*)dm_ws_take(ctx, (size_t)B * N2 * k1 * 8);            // Phi2 C
-        double* Yv = (double*)dm_ws_take(ctx, (size_t)B * N2 * k1 * 8);            // Y = D' Phi1
-        double* rs = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
-        double* rsq = (double*)dm_ws_take(ctx, (size_t)B * N2 * 8);
+        double* Yv = (double*)dm_ws_take(ctx, (size_t)ncs * B * N2 * k1 * 8);      // Y = D' Phi1, one partial per column split
+        double* rs = (double*)dm_ws_take(ctx, (size_t)ncs * B * N2 * 8);
+        double* rsq = (double*)dm_ws_take(ctx, (size_t)ncs * B * N2 * 8);
         double* cs = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);
         double* csq = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);
         double* pcs = (double*)dm_ws_take(ctx, (size_t)B * ngroups * N1 * 8);
         double* pcsq = (double*)dm_ws_take(ctx, (size_t)B * ngroups * N1 * 8);
         double* stat = (double*)dm_ws_take(ctx, (size_t)B * 2 * 8);
-        double* pe = (double*)dm_ws_take(ctx, (size_t)B * nrb * 8);
+        double* pe = (double*)dm_ws_take(ctx, (size_t)B * ncs * nrb * 8);
         double* part = (double*)dm_ws_take(ctx, (size_t)nsplit_m * bKK);
         if (!E2 || !Yv || !rs || !rsq || !cs || !csq || !pcs || !pcsq || !stat || !pe || !part)
             return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
@@ -566,14 +603,16 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         memset(&ep, 0, sizeof(ep));
         ep.E2 = E2; ep.Phi1 = Phi1; ep.ld1 = ld1; ep.mass1 = mass1; ep.N1 = N1; ep.N2 = N2; ep.k1 = k1;
         ep.ldp = pad_to(k1, 32) + 4;
+        ep.rg = rg; ep.ncs = ncs; ep.cchunk = cchunk; ep.Bn = B;
         ep.rs = rs; ep.rsq = rsq; ep.pcs = pcs; ep.pcsq = pcsq; ep.ngroups = ngroups; ep.cs = cs; ep.csq = csq; ep.stat = stat;
         ep.w = mw; ep.Y = Yv; ep.pe = pe;
         if (stats) {
             const size_t lds1 = ((size_t)EM_T * EM_LDA + 2 * EM_RG + 2 * 2 * 2 * 64) * 8 + (size_t)EM_T * ep.ldp * 4;
             rc = dm_grant_lds(ctx, (const void*)em_stats_kernel, lds1);
             if (rc) return rc;
-            DM_LAUNCH(ctx, "energy_stats_tiles", em_stats_kernel, dim3(ngroups, B), dim3(256), lds1, ep);
-            DM_LAUNCH(ctx, "energy_finish_stats", m_finish_stats_kernel, dim3(B), dim3(256), 0, pcs, pcsq, ngroups, N2, N1, rs, cs, csq, stat);
+            DM_LAUNCH(ctx, "energy_stats_tiles", em_stats_kernel, dim3(ngroups, ncs, B), dim3(256), lds1, ep);
+            DM_LAUNCH(ctx, "energy_finish_stats", m_finish_stats_kernel, dim3(B), dim3(256), 0, pcs, pcsq, ngroups, N2, N1, rs, rsq, ncs,
+                      (long long)B * N2, cs, csq, stat);
         }
         {
             const size_t lds2 = ((size_t)EM_T * EM_LDA + EM_T * EM_LDD) * 8 + (size_t)EM_T * ep.ldp * 4;
@@ -582,12 +621,16 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
             {                                                                                                          \
                 rc = dm_grant_lds(ctx, (const void*)em_deriv_kernel<NT2_>, lds2);                                      \
                 if (rc) return rc;                                                                                     \
-                DM_LAUNCH(ctx, "energy_deriv_tiles", em_deriv_kernel<NT2_>, dim3(nrb, B), dim3(256), lds2, ep);        \
+                DM_LAUNCH(ctx, "energy_deriv_tiles", em_deriv_kernel<NT2_>, dim3(nrb, ncs, B), dim3(256), lds2, ep);   \
             }
             if (nt2 <= 1) EM_DERIV(1) else if (nt2 <= 2) EM_DERIV(2) else EM_DERIV(4)
 #undef EM_DERIV
         }
-        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, nrb, N1, N2, cs, csq, stat, mw, e_m);
+        if (ncs > 1) {
+            const long long ny = (long long)B * N2 * k1;
+            DM_LAUNCH(ctx, "energy_sum_splits", em_sum_splits_kernel, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, Yv, ny, ncs);
+        }
+        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, ncs * nrb, N1, N2, cs, csq, stat, mw, e_m);
         {   // Gm = Phi2^T Y
             RowsF32Scaled opx{Phi2, (long long)N2 * ld2, ld2, k2, nullptr, 0};
             RowsF64TN opy{Yv, (long long)N2 * k1, k1, k1};
