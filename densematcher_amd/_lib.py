@@ -48,7 +48,7 @@ SIGNATURES = {
     "dm_p2p_to_fm": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "dm_eigenbasis": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "dm_precise_map": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
-    "dm_linear_sum_assignment": (_i, [_p, _i, _i, _i, _p, _i, _p]),
+    "dm_linear_sum_assignment": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "dm_p2p_to_fm_lstsq": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "dm_icp": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_zoomout": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),

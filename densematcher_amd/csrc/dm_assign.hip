@@ -34,7 +34,7 @@ __device__ __forceinline__ lsa_cand lsa_better(const lsa_cand& a, const lsa_cand
 
 __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ costs, int nr, int nc, int negate, int use_lds,
                                                      double* __restrict__ g_f64, int* __restrict__ g_i32,
-                                                     int32_t* __restrict__ out_col4row) {
+                                                     int32_t* __restrict__ out_col4row, int32_t* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
     __shared__ double red_val[16];
     __shared__ int red_sink[16], red_it[16];
@@ -111,7 +111,10 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ 
             if (s_state[1] != -1) break;
         }
         const int sink = s_state[1];
-        if (sink < 0) break;                             // infeasible: rows from `cur` on stay unassigned
+        if (sink < 0) {                                  // infeasible (SciPy: ValueError "cost matrix is infeasible"): reported in info
+            if (t == 0) atomicMax(&info[b], 1);
+            break;
+        }
         const double min_val = s_min;
         // dual updates (every visited row / scanned column once: order free)
         for (int q = t; q < n_sr; q += LSA_NT) {
@@ -140,6 +143,18 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ 
     for (int i = t; i < nr; i += LSA_NT) out_col4row[(long long)b * nr + i] = col4row[i];
 }
 
+// info[b] = 2 when the matrix holds a NaN or an infinity of the sign SciPy rejects (-inf when minimising, +inf when
+// maximising: "matrix contains invalid numeric entries")
+__global__ __launch_bounds__(256) void lsa_validate_kernel(const double* __restrict__ cost, long long n, int negate, int32_t* __restrict__ info) {
+    const int b = blockIdx.y;
+    bool bad = false;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const double x = cost[(long long)b * n + e];
+        bad = bad || (x != x) || (negate ? x == DM_INF_F64 : x == -DM_INF_F64);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicMax(&info[b], 2);
+}
+
 // out (B, nc, nr) = in (B, nr, nc) transposed
 __global__ __launch_bounds__(256) void lsa_transpose_kernel(const double* __restrict__ in, int nr, int nc, double* __restrict__ out) {
     __shared__ double tile[32][33];
@@ -163,10 +178,11 @@ __global__ __launch_bounds__(256) void lsa_invert_kernel(const int32_t* __restri
     if (r >= 0 && r < nr) col_of_row[(long long)b * nr + r] = c;
 }
 
-extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, const double* cost, int maximize, int32_t* col_of_row) {
+extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, const double* cost, int maximize, int32_t* col_of_row,
+                                        int32_t* info) {
     if (!ctx) return DM_EINVAL;
     DM_REQUIRE(ctx, B > 0 && nr > 0 && nc > 0, "sizes must be positive");
-    DM_REQUIRE(ctx, cost && col_of_row, "null pointer");
+    DM_REQUIRE(ctx, cost && col_of_row && info, "null pointer");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     const bool transposed = nr > nc;                   // SciPy solves the transposed problem when there are more rows than columns
     const int R = transposed ? nc : nr, Cn = transposed ? nr : nc;
@@ -180,6 +196,12 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
     int* gi = (int*)dm_ws_take(ctx, bI);
     int32_t* tmp = transposed ? (int32_t*)dm_ws_take(ctx, bO) : nullptr;
     if ((transposed && (!Ct || !tmp)) || !gf || !gi) return dm_fail(ctx, DM_ENOMEM, "assignment: workspace not reserved");
+    DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
+    {
+        const long long nel = (long long)nr * nc;
+        const int gx = (int)((nel + 256 * 16 - 1) / (256 * 16)) < 1024 ? (int)((nel + 256 * 16 - 1) / (256 * 16)) : 1024;
+        DM_LAUNCH(ctx, "lsa_validate", lsa_validate_kernel, dim3(gx, B), dim3(256), 0, cost, nel, maximize ? 1 : 0, info);
+    }
     if (transposed)
         DM_LAUNCH(ctx, "lsa_transpose", lsa_transpose_kernel, dim3(dm_cdiv(nc, 32), dm_cdiv(nr, 32), B), dim3(256), 0, cost, nr, nc, Ct);
     const int use_lds = Cn <= LSA_LDS_MAX_COLS;
@@ -187,7 +209,7 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
     rc = dm_grant_lds(ctx, (const void*)lsa_kernel, lds);
     if (rc) return rc;
     DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", lsa_kernel, dim3(B), dim3(LSA_NT), lds, transposed ? Ct : cost, R, Cn, maximize ? 1 : 0,
-              use_lds, gf, gi, transposed ? tmp : col_of_row);
+              use_lds, gf, gi, transposed ? tmp : col_of_row, info);
     if (transposed) {
         DM_CHECK_HIP(ctx, hipMemsetAsync(col_of_row, 0xFF, (size_t)B * nr * 4, ctx->stream));
         DM_LAUNCH(ctx, "lsa_invert", lsa_invert_kernel, dim3(dm_cdiv(nc, 256), B), dim3(256), 0, tmp, nr, nc, col_of_row);

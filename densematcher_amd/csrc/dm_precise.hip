@@ -137,7 +137,8 @@ __device__ void point_triangle(double a, double b, double c, double d, double e,
 #undef PT_RET
 }
 
-constexpr int PM_MAXCAND = 4096;          // candidate faces kept per point (a point typically has a few dozen)
+constexpr int PM_MAXCAND = 4096;          // candidate faces LISTED per point (a point typically has a few dozen); a point with more
+                                          // (far from the surface: a poor C) re-tests every face instead: nothing is dropped
 
 __global__ __launch_bounds__(256) void precise_project_kernel(const double* __restrict__ dist, const double* __restrict__ E1,
                                                               const double* __restrict__ E2, const int32_t* __restrict__ faces,
@@ -199,14 +200,22 @@ __global__ __launch_bounds__(256) void precise_project_kernel(const double* __re
         }
     }
     __syncthreads();
-    int ncand = s_ncand;
-    if (ncand > PM_MAXCAND) { if (t == 0) overflow[b] = 1; ncand = PM_MAXCAND; }
+    const int ncand = s_ncand;
+    const bool listed = ncand <= PM_MAXCAND;          // else: every face is visited and the candidate test repeated (uniform per wave)
+    if (!listed && t == 0) overflow[b] = 1;           // informational: the slow route was taken for some point of this pair
     const bool multi = ncand > 1;
-    // project on every candidate: one candidate per wave at a time
+    // project on every candidate: one candidate per wave at a time (the result is the lexicographic minimum of (distance,
+    // face index): independent of the order the list was filled in)
     double bd = DM_INF_F64, bs = 0.0, bt = 0.0;
     int bf = DM_IDX_NONE;
-    for (int q = wave; q < ncand; q += 4) {
-        const int f = cand[q];
+    const int nloop = listed ? ncand : nf;
+    for (int q = wave; q < nloop; q += 4) {
+        const int f = listed ? cand[q] : q;
+        if (!listed) {
+            const int32_t* fw = faces + ((long long)b * nf + f) * 3;
+            const double dmin = fmin(fmin(drow[fw[0]], drow[fw[1]]), drow[fw[2]]);
+            if (!(dmin - fc[((long long)b * nf + f) * 4 + 3] < Deltamin)) continue;
+        }
         const int32_t* fv = faces + ((long long)b * nf + f) * 3;
         const double* p0 = E1 + ((long long)b * N1 + fv[0]) * k;
         const double* p1 = E1 + ((long long)b * N1 + fv[1]) * k;

@@ -422,6 +422,8 @@ class MatchEngine:
         nf = faces1.shape[1]
         if faces1.shape != (B, nf, 3) or Cm.shape[0] != B:
             raise ValueError("precise_map: faces1 must be (B,nf,3) and C (B,k2,k1)")
+        if nf and (int(faces1.min()) < 0 or int(faces1.max()) >= N1):
+            raise ValueError("precise_map: face indices must lie in [0, N1)")
         fm = torch.empty((B, N2), dtype=torch.int32, device=self.device)
         bary = torch.empty((B, N2, 3), dtype=torch.float64, device=self.device)
         M = torch.empty((B, N2, N1), dtype=torch.float64, device=self.device) if dense else None
@@ -438,7 +440,13 @@ class MatchEngine:
             raise ValueError("linear_sum_assignment expects (B,nr,nc)")
         B, nr, nc = cost.shape
         out = torch.empty((B, nr), dtype=torch.int32, device=self.device)
-        self._chk(self.lib.dm_linear_sum_assignment(self.ctx, B, nr, nc, _ptr(cost), 1 if maximize else 0, _ptr(out)))
+        info = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(self.lib.dm_linear_sum_assignment(self.ctx, B, nr, nc, _ptr(cost), 1 if maximize else 0, _ptr(out), _ptr(info)))
+        worst = int(info.max())                              # (the caller reads the result next: this synchronisation is not extra)
+        if worst == 2:
+            raise ValueError("matrix contains invalid numeric entries")          # SciPy's messages
+        if worst == 1:
+            raise ValueError("cost matrix is infeasible")
         return out
 
     def p2p_to_fm_lstsq(self, p21, Phi1, Phi2, k1, k2):

@@ -279,8 +279,9 @@ int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* ell_cols, c
  * of the projection: face_match (B,N2) int32, bary (B,N2,3) fp64; dense (B,N2,N1) fp64 optional = the same map as a
  * matrix with three weights per row (what get_precise_map().toarray() returns).  faces1 (B,nf,3) int32.
  * Replaces FunctionalMapping.get_precise_map (pyFM/functional.py:221-251 -> pyFM/spectral/convert.py:185-229 with
- * use_adj = True -> pyFM/spectral/projection_utils.py:16-115).  info (B): 1 if a point had more than 4096 candidate
- * faces (the list is cut there; does not happen on meshes of the reference's size).  N1 + k1 <= about 17000. */
+ * use_adj = True -> pyFM/spectral/projection_utils.py:16-115).  info (B): 1 if some point of the pair had more than 4096
+ * candidate faces (such a point re-tests every face instead of walking a list: slower, same result).  Face indices must lie in
+ * [0, N1) (the caller checks; the kernel indexes LDS with them).  N1 + k1 <= about 17000. */
 int dm_precise_map(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int nf,
                    const float* Phi1, int ld1, const float* Phi2, int ld2, const double* C,
                    const int32_t* faces1, int32_t* face_match, double* bary, double* dense /*nullable*/, int32_t* info);
@@ -293,9 +294,11 @@ int dm_precise_map_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int n
  * Replaces scipy.optimize.linear_sum_assignment(mapped_indicator, maximize=True) of densematcher/functional_map.py:57,66,78
  * (the `hungarian`, `hungarian_precise`, `hungarian_icp` outputs).  Same algorithm as SciPy's (Crouse 2016, shortest
  * augmenting paths), same floating-point steps and tie rules: the assignment equals SciPy's, not merely its objective.
- * One workgroup per matrix; matrices of a batch run concurrently. */
+ * One workgroup per matrix; matrices of a batch run concurrently.  info (B): 0 ok; 1 the matrix is infeasible (no complete
+ * assignment of finite cost: SciPy raises ValueError("cost matrix is infeasible")), 2 it holds NaN or an infinity of the
+ * rejected sign (SciPy: "matrix contains invalid numeric entries"); col_of_row of such a matrix is not meaningful. */
 int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, const double* cost, int maximize,
-                             int32_t* col_of_row /* B*nr */);
+                             int32_t* col_of_row /* B*nr */, int32_t* info /* B */);
 
 /* ---- vertex map -> functional map, least squares -------------------------------
  * C[b] = argmin_X |Phi2[b][:, :k2] X - Phi1[b][p21[b], :k1]|_F   (k2 x k1) fp64, no mass matrix.

@@ -445,6 +445,28 @@ def test_zoomout_split_equals_f64_kernel(eng):
     assert np.array_equal(res["1"][0], res["0"][0])
 
 
+def _ulp_tie(C, P1, P2, a1, name, idx, got, want):
+    """both candidates of a mismatching entry score within a few float64 ulps of each other (extended precision)"""
+    ld = np.longdouble
+    k2, k1 = C.shape
+    e1, e2, Cl = P1[:, :k1].astype(ld), P2[:, :k2].astype(ld), C.astype(ld)
+
+    def score(i, j):                                   # the value the reference compares for target i / candidate j
+        g = e2[i] @ Cl @ e1[j]
+        if name == "knn21":
+            y = Cl @ e1[j]
+            return float(y @ y - 2 * g), float(abs(y @ y) + 2 * abs(g))
+        if name == "knn12":
+            x = e2[i] @ Cl
+            return float(x @ x - 2 * g), float(abs(x @ x) + 2 * abs(g))
+        return float(g * ld(a1[j])), float(abs(g) * float(a1[j]))
+    if name in ("knn21", "ind21"):
+        (sg, sc), (sw, _) = score(idx, got), score(idx, want)
+    else:
+        (sg, sc), (sw, _) = score(got, idx), score(want, idx)
+    return abs(sg - sw) <= 64 * np.finfo(np.float64).eps * max(sc, 1e-300)
+
+
 def _split_case(rng, B, N1, N2, k1, k2, kind):
     """operands for dm_fm_to_p2p that stress the fp16-split path: near-delta maps, exact duplicates, zero / spread masses"""
     Phi1 = rng.standard_normal((B, N1, k1)).astype(np.float32)
@@ -492,11 +514,19 @@ def test_fm_to_p2p_split_equals_f64_kernel(eng, kind):
             for split in (1, 2, 3, "pertile", "odd"):
                 bad = int((res[split][name] != res[0][name]).sum())
                 assert bad == 0, (kind, name, split, bad, (B, N1, N2, k1, k2))
-        for b in range(B):                                   # and the float64 kernel against the oracle, once per kind
+        # ... and against the oracle, every kind, EXACTLY: a different entry is accepted only where the two candidates score
+        # within a few float64 ulps of each other (two summation orders of the same float64 arithmetic), judged in extended
+        # precision, and is counted
+        ties = 0
+        for b in range(B):
             want = orc.fm_to_p2p_all(C[b], Phi1[b].astype(np.float64), Phi2[b].astype(np.float64), a1[b].astype(np.float64))
-            if kind in ("random", "masses"):
-                for name, w in zip(("knn21", "knn12", "ind21", "ind12"), want):
-                    assert (res[1][name][b] != w).mean() < 1e-3, (kind, name)
+            for name, w in zip(("knn21", "knn12", "ind21", "ind12"), want):
+                got = res[2][name][b].astype(np.int64)
+                for idx in np.nonzero(got != w)[0]:
+                    assert _ulp_tie(C[b], Phi1[b], Phi2[b], a1[b], name, int(idx), int(got[idx]), int(w[idx])), \
+                        (kind, name, b, int(idx), int(got[idx]), int(w[idx]))
+                    ties += 1
+        print(f"{kind} {(B, N1, N2, k1, k2)}: equal to the oracle except {ties} few-ulp ties")
 
 
 def test_fuzz_knn_query(eng):
@@ -576,6 +606,61 @@ def test_linear_sum_assignment_equals_scipy(eng):
                 r0, c0 = scipy.optimize.linear_sum_assignment(c, maximize=mx)
                 rows = np.nonzero(got[q] >= 0)[0]
                 assert np.array_equal(rows, r0) and np.array_equal(got[q][rows], c0), (nr, nc, q, mx)
+
+
+def test_linear_sum_assignment_rejects_what_scipy_rejects(eng):
+    """NaN / wrong-signed infinity -> "invalid numeric entries"; no finite complete assignment -> "infeasible" (SciPy raises
+    ValueError in both cases; the kernel reports them in its info array instead of returning a short assignment)"""
+    import scipy.optimize
+    rng = np.random.default_rng(9)
+    good = rng.standard_normal((2, 40, 40))
+    assert np.array_equal(_np(eng.linear_sum_assignment(good))[1], scipy.optimize.linear_sum_assignment(good[1])[1])
+    for mx, bad_val in ((False, -np.inf), (True, np.inf), (False, np.nan)):
+        c = good.copy()
+        c[1, 3, 7] = bad_val
+        with pytest.raises(ValueError, match="invalid numeric"):
+            eng.linear_sum_assignment(c, maximize=mx)
+        with pytest.raises(ValueError):
+            scipy.optimize.linear_sum_assignment(c[1], maximize=mx)
+    c = good.copy()
+    c[0, :, :5] = np.inf                                     # ...only 35 usable columns for 40 rows
+    c[0, 5:, 5:] = np.inf
+    with pytest.raises(ValueError, match="infeasible"):
+        eng.linear_sum_assignment(c)
+    with pytest.raises(ValueError, match="infeasible"):
+        scipy.optimize.linear_sum_assignment(c[0])
+    finite_inf = good.copy()
+    finite_inf[1, 2, :39] = np.inf                           # +inf entries are fine when minimising as long as an assignment exists
+    assert np.array_equal(_np(eng.linear_sum_assignment(finite_inf))[1], scipy.optimize.linear_sum_assignment(finite_inf[1])[1])
+
+
+def test_precise_map_with_more_candidates_than_the_list_holds(eng):
+    """a point far from the embedded surface has every face as a candidate (> 4096 here): the kernel then re-tests all faces
+    instead of cutting its candidate list -- same result as the oracle, run to run identical; bad face indices are refused"""
+    from densematcher_amd import synth
+    nu, nv, k = 72, 40, 6
+    v, f = synth.torus_mesh(nu, nv)
+    assert f.shape[0] > 4096
+    rng = np.random.default_rng(4)
+    N = nu * nv
+    e1 = (rng.standard_normal((N, k)) * 0.05).astype(np.float32)
+    e2 = (rng.standard_normal((200, k)) * 0.05).astype(np.float32)
+    e2[:50] += 40.0                                           # far away: Deltamin exceeds every face's bound
+    C = np.eye(k)
+    fm1, bary1 = eng.precise_map(_b(e1), _b(e2), _b(C), _b(f.astype(np.int32)))
+    fm2, bary2 = eng.precise_map(_b(e1), _b(e2), _b(C), _b(f.astype(np.int32)))
+    assert np.array_equal(_np(fm1), _np(fm2)) and np.array_equal(_np(bary1), _np(bary2))
+    P, fo, bo = orc.precise_map_dense(C, e1.astype(np.float64), e2.astype(np.float64), f)
+    d_gpu = np.linalg.norm((_np(bary1)[0][:, :, None] * e1.astype(np.float64)[f[_np(fm1)[0]]]).sum(1) - e2, axis=1)
+    d_orc = np.linalg.norm((bo[:, :, None] * e1.astype(np.float64)[f[fo]]).sum(1) - e2, axis=1)
+    assert np.abs(d_gpu - d_orc).max() <= 1e-9 * max(1.0, d_orc.max())
+    # (in a random embedding most points project onto a vertex or an edge that several faces share at the same distance up to the
+    #  last bits: the face NAME is a tie there, the projected point is not)
+    print("precise map, > 4096 candidates: same face named for", float((np.asarray(_np(fm1)[0]) == fo).mean()), "of the points; distances equal")
+    bad = f.astype(np.int32).copy()
+    bad[7, 1] = N
+    with pytest.raises(ValueError):
+        eng.precise_map(_b(e1), _b(e2), _b(C), _b(bad))
 
 
 def test_hungarian_of_mapped_indicator(eng, fx_cfg1):
