@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void eig_reduce_partials_kernel(const double* 
 __global__ __launch_bounds__(256) void spmm_ell_kernel(const double* __restrict__ vals, const int32_t* __restrict__ cols, int N, int nnz,
                                                        const double* __restrict__ Y, const double* __restrict__ Yprev,
                                                        double* __restrict__ Ynew, int m, const double* __restrict__ coef, int step) {
-    const int b = blockIdx.z, i = blockIdx.y;
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z, i = blockIdx.x;              // (the row index rides on grid x: meshes above 65535 vertices)
+    const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= m) return;
     const double* Yb = Y + (long long)b * N * m;
     const double* vr = vals + ((long long)b * N + i) * nnz;
@@ -359,7 +359,7 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
     if (!Ya || !Yb || !Yc || !H || !V || !Q || !w.T || !w.W || !w.part || !theta || !coef || !lmax || !rbits)
         return dm_fail(ctx, DM_ENOMEM, "eigenbasis: workspace not reserved");
     DM_LAUNCH(ctx, "eig_gershgorin", gershgorin_kernel, dim3(B), dim3(256), 0, ell_vals, N, nnz, lmax);
-    const dim3 gsp(dm_cdiv(m, 256), N, B);
+    const dim3 gsp(N, dm_cdiv(m, 256), B);
     const double* Xcur = X;
 
     if (!warm_start) {      // the caller's X holds a random block: orthonormalise it (unit columns / sqrt(m): singular values <= 1)

@@ -523,6 +523,8 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     const bool dcomm = w[W_DCOMM] > 0.0 && n_ops > 0;
     DM_REQUIRE(ctx, !m_terms || (Phi1 && Phi2 && mass1 && ld1 >= k1 && ld2 >= k2), "the indicator terms need Phi1, Phi2, mass1");
     DM_REQUIRE(ctx, !(w[W_DCOMM] > 0.0) || (ops1 && ops2 && n_ops > 0), "w_dcomm > 0 needs the descriptor operators (dm_fmap_descr_ops)");
+    DM_REQUIRE(ctx, !(w[W_DCOMM] > 0.0) || (long long)B * n_ops <= 65535, "too many (pair, descriptor) slots for one launch: split the batch");
+    DM_REQUIRE(ctx, B <= 65535, "batch too large for one launch");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
 
     const size_t bKK = (size_t)B * k2 * k1 * 8;

@@ -271,6 +271,19 @@ static int p2p_to_fm_lstsq_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int 
     OutPlainNT oc{C, (long long)k2 * k1, k1};
     DM_LAUNCH(ctx, "icp_apply_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutPlainNT>),
               dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ga, rb, oc, k2, k1, k2);
+    // one step of iterative refinement on the normal equations, C += G^-1 (R - G C): removes what the explicit inverse lost
+    // (Cholesky on unit right-hand sides / Newton-Schulz); the conditioning of G = Phi2^T Phi2 itself (cond(Phi2)^2) remains
+    {
+        KRowsF64 gg{G, (long long)k2 * k2, k2, k2, k2, 0};
+        KRowsF64 cT{C, (long long)k2 * k1, k1, k1, k2, 1};
+        OutAxpby orho{R, R, (long long)k2 * k1, k1, 1.0, -1.0};                 // R <- R - G C
+        DM_LAUNCH(ctx, "lstsq_residual_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutAxpby>),
+                  dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, gg, cT, orho, k2, k1, k2);
+        KRowsF64 rT{R, (long long)k2 * k1, k1, k1, k2, 1};
+        OutAxpby ocx{C, C, (long long)k2 * k1, k1, 1.0, 1.0};                   // C <- C + G^-1 rho
+        DM_LAUNCH(ctx, "icp_apply_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutAxpby>),
+                  dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ga, rT, ocx, k2, k1, k2);
+    }
     return DM_OK;
 }
 extern "C" int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const float* Phi1,

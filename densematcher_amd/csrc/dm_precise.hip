@@ -332,8 +332,12 @@ __global__ __launch_bounds__(256) void row_sumsq_kernel(const double* __restrict
     for (int c = 0; c < k; ++c) s += row[c] * row[c];
     sq[(long long)b * N + r] = s;
 }
+// The k nearest are SELECTED on the expanded form |x|^2 - 2 <x, y> + |y|^2 (a matrix product); their distances are then
+// re-evaluated directly as |x - y| (what sklearn returns) and the k results put in the order of those exact distances, lowest
+// index first on equal ones -- the expanded form is only good to ~1e-16 |x|^2, which can misorder and misreport near-ties.
 __global__ __launch_bounds__(256) void topk_rows_kernel(const double* __restrict__ D2, int nx, int ny, int k, int32_t* __restrict__ idx,
-                                                        double* __restrict__ dist) {
+                                                        double* __restrict__ dist, const double* __restrict__ X,
+                                                        const double* __restrict__ Y, int p) {
     extern __shared__ __attribute__((aligned(16))) double tk_row[];
     __shared__ double w_v[4];
     __shared__ int w_j[4];
@@ -356,10 +360,31 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const double* __restrict
             for (int w = 1; w < 4; ++w) argmin_merge(v0, j0, w_v[w], w_j[w]);
             const long long o = ((long long)b * ny + i) * k + r;
             idx[o] = (j0 == DM_IDX_NONE) ? 0 : j0;
-            if (dist) dist[o] = (j0 == DM_IDX_NONE) ? DM_INF_F64 : sqrt(v0);
             if (j0 != DM_IDX_NONE) tk_row[j0] = DM_INF_F64;            // taken: out of the next passes
         }
         __syncthreads();
+    }
+    // exact distances of the k selected rows (one wave per neighbour at a time), kept in tk_row[0 .. k)
+    __syncthreads();
+    const double* yq = Y + ((long long)b * ny + i) * p;
+    int32_t* ir = idx + ((long long)b * ny + i) * k;
+    for (int r = wave; r < k; r += 4) {
+        const double* xr = X + ((long long)b * nx + ir[r]) * p;
+        double acc = 0.0;
+        for (int c = lane; c < p; c += 64) { const double dlt = xr[c] - yq[c]; acc = fma(dlt, dlt, acc); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) tk_row[r] = sqrt(acc);
+    }
+    __syncthreads();
+    if (t == 0) {                                                     // insertion sort of the k results by (distance, index)
+        for (int a = 1; a < k; ++a) {
+            const double dv = tk_row[a]; const int32_t jv = ir[a];
+            int q = a - 1;
+            while (q >= 0 && (tk_row[q] > dv || (tk_row[q] == dv && ir[q] > jv))) { tk_row[q + 1] = tk_row[q]; ir[q + 1] = ir[q]; --q; }
+            tk_row[q + 1] = dv; ir[q + 1] = jv;
+        }
+        if (dist) for (int a = 0; a < k; ++a) dist[((long long)b * ny + i) * k + a] = tk_row[a];
     }
 }
 extern "C" int dm_knn_query_topk_f64(dm_ctx* ctx, int B, int nx, int ny, int p, int k, const double* X, const double* Y,
@@ -383,9 +408,9 @@ extern "C" int dm_knn_query_topk_f64(dm_ctx* ctx, int B, int nx, int ny, int p, 
     OutSqDist out{D2, (long long)ny * nx, nx, xs, nx, ys, ny};
     DM_LAUNCH(ctx, "knn_dist_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutSqDist>), dim3(dm_cdiv(ny, NT_T) * dm_cdiv(nx, NT_T), 1, B), dim3(256), 0,
               ya, xb, out, ny, nx, p);
-    const size_t lds = (size_t)nx * 8;
+    const size_t lds = (size_t)(nx > k ? nx : k) * 8;
     rc = dm_grant_lds(ctx, (const void*)topk_rows_kernel, lds);
     if (rc) return rc;
-    DM_LAUNCH(ctx, "knn_topk", topk_rows_kernel, dim3(ny, B), dim3(256), lds, (const double*)D2, nx, ny, k, idx, dist);
+    DM_LAUNCH(ctx, "knn_topk", topk_rows_kernel, dim3(ny, B), dim3(256), lds, (const double*)D2, nx, ny, k, idx, dist, X, Y, p);
     return DM_OK;
 }

@@ -232,9 +232,11 @@ class FunctionalMapping:
         """functional.py:588-617"""
         if not self.fitted:
             raise ValueError("The Functional map must be fit before refining it")
-        if subsample is not None and subsample != 0:
-            raise NotImplementedError("farthest-point subsampling is outside the matching path")
-        self._FM_zo = refine.mesh_zoomout_refine(self.FM, self.mesh1, self.mesh2, nit, step=step, subsample=None, verbose=verbose)
+        if subsample is None or (np.issubdtype(type(subsample), np.integer) and subsample == 0):   # functional.py:607-610
+            sub = None
+        else:
+            sub = subsample                                                     # int: farthest point sampling of that size; or (sub1, sub2)
+        self._FM_zo = refine.mesh_zoomout_refine(self.FM, self.mesh1, self.mesh2, nit, step=step, subsample=sub, verbose=verbose)
         if overwrite:
             self.FM_type = 'zoomout'
 

@@ -130,6 +130,39 @@ class TriMesh:
             self.laplacian_spectrum(k, return_spectrum=False, intrinsic=intrinsic, robust=robust, verbose=verbose)
         return self
 
+    # ------------------------------------------------------------- vertex sampling (input of the subsampled ZoomOut)
+    def extract_fps(self, size, random_init=True, geodesic=True, no_load=False, verbose=False, rng=None):
+        """Farthest point sampling (trimesh.py:847-893 -> geometry.py:813-845): start at a random vertex, then repeatedly
+        take the vertex farthest from the ones taken.  geodesic=False: Euclidean distances, the reference's arithmetic.
+        geodesic=True: the reference measures with the heat method of the external potpourri3d wheel (`geod_from`); here the
+        distance is the shortest path along mesh edges (Dijkstra on the edge graph) and a warning says so: the samples
+        spread the same way, they are not the same vertices.  `rng`: numpy Generator for the start vertex (the reference
+        draws from an unseeded one: its samples are not reproducible either).  Host code: it selects inputs of the path."""
+        rng = np.random.default_rng() if rng is None else rng
+        n = self.n_vertices
+        if not geodesic:
+            def dist_from(i):
+                return np.linalg.norm(self.vertlist - self.vertlist[i, None, :], axis=1)
+        else:
+            import scipy.sparse.csgraph as csgraph
+            warnings.warn("extract_fps(geodesic=True): potpourri3d's heat-method geodesics are not available; using shortest paths "
+                          "along the mesh edges")
+            f = self.facelist
+            e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+            w = np.linalg.norm(self.vertlist[e[:, 0]] - self.vertlist[e[:, 1]], axis=1)
+            G = sparse.coo_matrix((w, (e[:, 0], e[:, 1])), shape=(n, n)).tocsr()
+            G = G.maximum(G.T)
+
+            def dist_from(i):
+                return csgraph.dijkstra(G, directed=False, indices=i)
+        inds = [int(rng.integers(n))]                                           # geometry.py:833
+        dists = dist_from(inds[0])
+        for _ in range(size - 1):                                               # geometry.py:838-843
+            newid = int(np.argmax(dists))
+            inds.append(newid)
+            dists = np.minimum(dists, dist_from(newid))
+        return np.asarray(inds)
+
     # ------------------------------------------------------------- spectral helpers
     def project(self, func, k=None):
         """Phi[:, :k]^T (A func) (trimesh.py:533-556), on the GPU."""

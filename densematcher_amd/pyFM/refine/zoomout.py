@@ -86,9 +86,10 @@ def zoomout_refine(FM_12, evects1, evects2, nit=10, step=1, A2=None, subsample=N
 
 def mesh_zoomout_refine(FM_12, mesh1, mesh2, nit=10, step=1, subsample=None, return_p2p=False, n_jobs=1, verbose=False):
     """reference zoomout.py:118-161"""
-    if np.issubdtype(type(subsample), np.integer):
-        raise NotImplementedError("farthest-point sampling (mesh.extract_fps) is outside the matching path: pass the two "
-                                  "index arrays as subsample=(sub1, sub2)")
+    if np.issubdtype(type(subsample), np.integer):                              # zoomout.py:151-155
+        if verbose:
+            print(f'Computing farthest point sampling of size {subsample}')
+        subsample = (mesh1.extract_fps(subsample), mesh2.extract_fps(subsample))
     return zoomout_refine(FM_12, mesh1.eigenvectors, mesh2.eigenvectors, nit, step=step, A2=mesh2.A, subsample=subsample,
                           return_p2p=return_p2p, n_jobs=n_jobs, verbose=verbose)
 

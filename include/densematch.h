@@ -303,8 +303,10 @@ int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, const double* c
 /* ---- vertex map -> functional map, least squares -------------------------------
  * C[b] = argmin_X |Phi2[b][:, :k2] X - Phi1[b][p21[b], :k1]|_F   (k2 x k1) fp64, no mass matrix.
  * Replaces pyFM/spectral/convert.py:51 (p2p_to_FM with A2 = None: scipy.linalg.lstsq), the form ICP and ZoomOut on
- * subsampled vertices use.  Normal equations (Phi2^T Phi2) C = Phi2^T Phi1[p21]; info (B): 0 ok, else the Gram
- * matrix was not positive definite / its inverse did not converge.  k2 <= 256.  Phi1 rows may be any (N1 x ld1)
+ * subsampled vertices use.  Normal equations (Phi2^T Phi2) C = Phi2^T Phi1[p21] with one step of iterative refinement; info (B):
+ * 0 ok, else the Gram matrix was not positive definite / its inverse did not converge.  Needs N2 >= k2 and Phi2 of full column
+ * rank, cond(Phi2) up to ~1e4 (the reference's SVD-based lstsq also returns the minimum-norm solution of rank-deficient
+ * problems: those are reported here, not solved).  k2 <= 256.  Phi1 rows may be any (N1 x ld1)
  * matrix (a pulled-back basis P Phi1 with p21 = identity gives the sparse-map form of convert.py:39). */
 int dm_p2p_to_fm_lstsq(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                        const int32_t* p21, const float* Phi1, int ld1, const float* Phi2, int ld2,

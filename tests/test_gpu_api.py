@@ -584,3 +584,37 @@ def test_fit_general_batched_device_lbfgs(fx_cfg1, oracle_cfg1_fits):
     assert np.abs(Cr[0] - C3[0]).max() <= 2e-3 and rr.nfev[0] < r3.nfev[0]
     with pytest.raises(ValueError):
         eng.fit_general(batch, w, np.stack([x0] * 3), driver="scipy")
+
+
+def test_zoomout_with_farthest_point_subsample_from_the_model(fx_cfg1):
+    """FunctionalMapping.zoomout_refine(subsample=int) (functional.py:588-617): farthest point sampling of both meshes
+    (TriMesh.extract_fps), the iterations on the samples with the least-squares p2p_to_FM, equal to the oracle's ZoomOut run
+    on the same samples; Euclidean sampling follows the reference's arithmetic (geometry.py:813-845)"""
+    import warnings
+    from densematcher_amd.pyFM import FunctionalMapping, refine
+    fx = fx_cfg1
+    m1, m2 = _mesh(fx, 1, 48), _mesh(fx, 2, 48)
+    s = m1.extract_fps(60, geodesic=False, rng=np.random.default_rng(5))
+    assert len(set(s.tolist())) == 60
+    V = m1.vertlist                                          # the reference's loop, restated
+    d = np.linalg.norm(V - V[s[0]], axis=1)
+    for q in range(1, 60):
+        assert s[q] == int(np.argmax(d))
+        d = np.minimum(d, np.linalg.norm(V - V[s[q]], axis=1))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        g = m1.extract_fps(40, rng=np.random.default_rng(6))       # geodesic=True: edge-graph shortest paths, said loudly
+    assert len(set(g.tolist())) == 40 and any("potpourri3d" in str(w.message) for w in caught)
+    sub = (m1.extract_fps(300, geodesic=False, rng=np.random.default_rng(1)), m2.extract_fps(320, geodesic=False, rng=np.random.default_rng(2)))
+    C0 = fx["C20"]
+    Cs, ps = refine.mesh_zoomout_refine(C0, m1, m2, nit=6, step=2, subsample=sub, return_p2p=True)
+    Cso, pso = orc.zoomout_refine(C0, fx["Phi1"].astype(np.float64), fx["Phi2"].astype(np.float64), nit=6, step=2, a2=fx["a2"],
+                                  subsample=sub, return_p2p=True)
+    assert np.abs(Cs - Cso).max() < 1e-8 and np.array_equal(ps, pso)
+    model = FunctionalMapping(_mesh(fx, 1, 48), _mesh(fx, 2, 48), partial=False, optimizer="L-BFGS-B")
+    model.preprocess(n_ev=(20, 20), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
+    model.FM = C0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.zoomout_refine(nit=5, step=2, subsample=200)
+    assert model.FM_type == "zoomout" and model.FM.shape == (30, 30) and np.isfinite(model.FM).all()
