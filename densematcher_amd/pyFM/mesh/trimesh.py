@@ -7,8 +7,9 @@ Producing the spectrum: the stiffness / mass matrices 
 reference (trimesh.py:440-531 -> laplacian.py:143-182); the eigensolve -- ARPACK shift-invert there -- runs on the GPU
 (dm_eigenbasis: Chebyshev-filtered subspace iteration).
 The reference's `robust=True` uses the external `robust_laplacian` wheel (tufted intrinsic-Delaunay Laplacian with
-mollification); it is used here too when it can be imported.  When it cannot, the classical cotangent Laplacian with
-lumped masses is used and a warning says so: the two agree on Delaunay triangulations without degenerate faces only.
+mollification); it is used here too when it can be imported.  When it cannot, this package's own implementation of the same
+construction runs (pyFM/mesh/laplacian.py: mollified lengths, tufted cover, intrinsic Delaunay flips) and a warning says that
+its parity with the wheel is unpinned.  `robust=False` is the classical cotangent Laplacian with lumped masses.
 """
 import warnings
 
@@ -102,8 +103,11 @@ class TriMesh:
                 self.W = sparse.csr_matrix(self.W)
                 mass = np.asarray(Am.diagonal())
             except ImportError:
-                warnings.warn("robust=True asked for, but the robust_laplacian package is not installed: using the classical "
-                              "cotangent Laplacian with lumped masses (identical on Delaunay meshes without degenerate faces only)")
+                from . import laplacian as _lap
+                warnings.warn("robust=True: the robust_laplacian package is not installed; using this package's own tufted "
+                              "intrinsic-Delaunay Laplacian (same construction, parity with the wheel unpinned)")
+                self.W, Am = _lap.robust_mesh_laplacian(self.vertlist, self.facelist, mollify_factor=1e-5)
+                mass = np.asarray(Am.diagonal())
         if mass is None:
             self.W, mass = synth.cotan_laplacian(self.vertlist, self.facelist)
         if np.any(mass <= 0):

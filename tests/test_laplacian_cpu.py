@@ -1,0 +1,110 @@
+"""CPU: the tufted intrinsic-Delaunay Laplacian (densematcher_amd/pyFM/mesh/laplacian.py), the stand-in for the external
+robust_laplacian wheel the reference calls with robust=True.  The wheel is not installed and the reference holds no fixture of
+its output, so parity with the wheel itself is unpinned; these tests pin the properties that define the construction."""
+import numpy as np
+import scipy.spatial
+
+from densematcher_amd import synth
+from densematcher_amd.pyFM.mesh import laplacian as lap
+
+
+def _planar(n, seed):
+    rng = np.random.default_rng(seed)
+    P = rng.uniform(0, 1, (n, 2))
+    tri = scipy.spatial.Delaunay(P)
+    F = tri.simplices.astype(np.int64)
+    # consistent counter-clockwise orientation
+    a, b, c = P[F[:, 0]], P[F[:, 1]], P[F[:, 2]]
+    neg = ((b - a)[:, 0] * (c - a)[:, 1] - (b - a)[:, 1] * (c - a)[:, 0]) < 0
+    F[neg] = F[neg][:, [0, 2, 1]]
+    return np.c_[P, np.zeros(n)], F
+
+
+def _flip_some_edges(V, F, nflip, seed):
+    """flip interior edges whose two triangles form a strictly convex quad: same points, same domain, worse triangles"""
+    rng = np.random.default_rng(seed)
+    F = F.copy()
+    done = 0
+    for _ in range(50 * nflip):
+        if done == nflip:
+            break
+        edges = {}
+        for f, (a, b, c) in enumerate(F):
+            for s, (p, q) in enumerate(((a, b), (b, c), (c, a))):
+                edges.setdefault((min(p, q), max(p, q)), []).append((f, s))
+        inner = [e for e, v in edges.items() if len(v) == 2]
+        e = inner[rng.integers(len(inner))]
+        (f1, s1), (f2, s2) = edges[e]
+        i, j, k = F[f1][s1], F[f1][(s1 + 1) % 3], F[f1][(s1 + 2) % 3]
+        m = F[f2][(s2 + 2) % 3]
+
+        def cross(o, p, q):
+            return (V[p, 0] - V[o, 0]) * (V[q, 1] - V[o, 1]) - (V[p, 1] - V[o, 1]) * (V[q, 0] - V[o, 0])
+        if cross(k, i, m) > 1e-9 and cross(m, j, k) > 1e-9:             # both new triangles counter-clockwise: convex quad
+            F[f1] = (k, i, m)
+            F[f2] = (m, j, k)
+            done += 1
+    assert done == nflip
+    return F
+
+
+def test_equals_cotangent_laplacian_on_closed_delaunay_meshes():
+    """closed mesh, every edge Delaunay, no mollification: nothing flips, front and back copies are two copies of the mesh"""
+    V, F = synth.torus_mesh(24, 16)                                    # regular torus grid: opposite angles sum to <= 180 degrees
+    rng = np.random.default_rng(0)
+    P = rng.standard_normal((200, 3))
+    P /= np.linalg.norm(P, axis=1, keepdims=True)
+    hull = scipy.spatial.ConvexHull(P)                                  # points on a sphere: the hull is their Delaunay triangulation
+    Fs = hull.simplices.astype(np.int64)
+    c = P[Fs].mean(axis=1)
+    nrm = np.cross(P[Fs[:, 1]] - P[Fs[:, 0]], P[Fs[:, 2]] - P[Fs[:, 0]])
+    Fs[(nrm * c).sum(axis=1) < 0] = Fs[(nrm * c).sum(axis=1) < 0][:, [0, 2, 1]]
+    for Vm, Fm in ((V, F), (P, Fs)):
+        W, M = lap.robust_mesh_laplacian(Vm, Fm, mollify_factor=0.0)
+        Wc, mc = synth.cotan_laplacian(Vm, Fm)
+        assert lap.robust_mesh_laplacian.last_info["flips"] == 0
+        assert np.abs((W - Wc).toarray()).max() <= 1e-10 * np.abs(Wc.toarray()).max()
+        assert np.abs(M.diagonal() - mc).max() <= 1e-12 * mc.max()
+
+
+def test_invariant_under_edge_flips_of_a_planar_triangulation():
+    """the intrinsic Delaunay triangulation of a planar point set is unique: a badly triangulated copy of the same domain has
+    the same robust Laplacian (its cotangent Laplacian differs, and has negative weights)"""
+    V, F = _planar(400, 2)
+    Wd, Md = lap.robust_mesh_laplacian(V, F, mollify_factor=0.0)
+    Fb = _flip_some_edges(V, F, 60, 3)
+    Wb_cot, _ = synth.cotan_laplacian(V, Fb)
+    assert np.abs((Wb_cot - Wd).toarray()).max() > 1e-3               # the plain cotangent Laplacian does change
+    W, M = lap.robust_mesh_laplacian(V, Fb, mollify_factor=0.0)
+    info = lap.robust_mesh_laplacian.last_info
+    assert info["converged"] and info["flips"] >= 60                    # (every flip happens in the front AND the back copy)
+    assert np.abs((W - Wd).toarray()).max() <= 1e-9 * np.abs(Wd.toarray()).max()
+    assert np.abs(M.diagonal() - Md.diagonal()).max() <= 1e-12
+
+
+def test_properties_on_a_perturbed_torus_and_a_nonmanifold_book():
+    V, F = synth.torus_mesh(40, 24, perturb=0.25, seed=5)               # strongly perturbed: obtuse triangles
+    W, M = lap.robust_mesh_laplacian(V, F)
+    D = W.toarray()
+    assert np.abs(D - D.T).max() <= 1e-12 and np.abs(D.sum(axis=1)).max() <= 1e-10
+    off = D - np.diag(np.diag(D))
+    assert off.max() <= 1e-12                                           # every edge weight (cot a + cot b) / 2 >= 0: W_ij <= 0
+    _, mc = synth.cotan_laplacian(V, F)
+    assert M.diagonal().min() > 0 and abs(M.diagonal().sum() - mc.sum()) <= 1e-3 * mc.sum()
+    Wc, _ = synth.cotan_laplacian(V, F)
+    assert (Wc.toarray() - np.diag(np.diag(Wc.toarray()))).max() > 1e-6   # ... which the cotangent Laplacian of this mesh violates
+    # three triangles around one edge (non-manifold) plus a dangling one
+    Vb = np.array([[0, 0, 0], [1, 0, 0], [0.5, 1, 0], [0.5, -1, 0.2], [0.5, 0.3, 1.0], [2, 0.5, 0]], dtype=float)
+    Fb = np.array([[0, 1, 2], [1, 0, 3], [0, 1, 4], [1, 5, 2]])
+    Wn, Mn = lap.robust_mesh_laplacian(Vb, Fb)
+    Dn = Wn.toarray()
+    assert np.abs(Dn - Dn.T).max() <= 1e-12 and np.abs(Dn.sum(axis=1)).max() <= 1e-12
+    assert np.linalg.eigvalsh(Dn).min() >= -1e-12 and Mn.diagonal().min() > 0
+
+
+def test_mollification_rescues_a_degenerate_face():
+    V = np.array([[0, 0, 0], [1, 0, 0], [0.5, 0, 0], [0.5, 1, 0]], dtype=float)     # vertex 2 lies ON edge 0-1: a zero-area face
+    F = np.array([[0, 2, 3], [2, 1, 3], [0, 1, 2]])
+    W, M = lap.robust_mesh_laplacian(V, F, mollify_factor=1e-5)
+    assert lap.robust_mesh_laplacian.last_info["mollify_eps"] > 0
+    assert np.isfinite(W.toarray()).all() and M.diagonal().min() > 0
