@@ -613,7 +613,7 @@ def test_zoomout_with_farthest_point_subsample_from_the_model(fx_cfg1):
                                   subsample=sub, return_p2p=True)
     assert np.abs(Cs - Cso).max() < 1e-8 and np.array_equal(ps, pso)
     model = FunctionalMapping(_mesh(fx, 1, 48), _mesh(fx, 2, 48), partial=False, optimizer="L-BFGS-B")
-    model.preprocess(n_ev=(20, 20), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
+    model.preprocess(n_ev=(20, 20), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1, k_process=40)   # ZoomOut needs 30 columns
     model.FM = C0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
