@@ -32,6 +32,19 @@ __device__ __forceinline__ lsa_cand lsa_better(const lsa_cand& a, const lsa_cand
     return (a.it < b.it) ? a : b;                       // else the first in scan order is kept
 }
 
+// the same rule on separate scalars (a struct passed by value ended up in scratch memory: a memory round trip per merge):
+// (v, sk, it, j) <- the better of itself and (ov, osk, oit, oj)
+__device__ __forceinline__ void lsa_merge(double& v, int& sk, int& it, int& j, double ov, int osk, int oit, int oj) {
+    bool take;
+    if (it < 0) take = true;
+    else if (oit < 0) take = false;
+    else if (v != ov) take = ov < v;
+    else if (sk != osk) take = osk != 0;
+    else if (sk) take = oit > it;
+    else take = oit < it;
+    v = take ? ov : v; sk = take ? osk : sk; it = take ? oit : it; j = take ? oj : j;
+}
+
 __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ costs, int nr, int nc, int negate, int use_lds,
                                                      double* __restrict__ g_f64, int* __restrict__ g_i32,
                                                      int32_t* __restrict__ out_col4row, int32_t* __restrict__ info) {
@@ -143,6 +156,245 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ 
     for (int i = t; i < nr; i += LSA_NT) out_col4row[(long long)b * nr + i] = col4row[i];
 }
 
+// ---- the same search with the column state in registers ---------------------------------------------------------------------
+// Thread t owns the columns t, t + 1024, ... (CPT of them, nc <= 1024 CPT): their dual v, tentative cost, "scanned" flag and
+// POSITION IN SCIPY'S `remaining` LIST live in registers, the cost row is read coalesced, and a step needs ONE barrier:
+// every wave leaves its best candidate in a double-buffered LDS slot and every thread folds the 16 slots itself.  The
+// list is never stored: SciPy removes the chosen entry by moving the last one into its place, so the only column whose
+// position changes is the one at position nrem - 1, and its owner sees that in its own registers.  The arithmetic, the
+// scan order used for ties and therefore the assignment are those of lsa_kernel (and SciPy).
+//   WARM = 1: start from the column minima as duals with every column whose minimum sits in a still free row assigned to it
+//   (Jonker-Volgenant's column reduction; a feasible dual pair with tight assigned edges, so the augmentations continue from
+//   there to an optimum).  Fewer and shorter searches, but not SciPy's order: the caller accepts the result only when
+//   lsa_unique_kernel finds the optimum unique (no slack-free edge outside the assignment), else it reruns with WARM = 0.
+template <int CPT, int WARM>
+__global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restrict__ costs, int nr, int nc, int negate,
+                                                         double* __restrict__ g_u, double* __restrict__ g_v,
+                                                         int32_t* __restrict__ out_col4row, int32_t* __restrict__ info,
+                                                         const int32_t* __restrict__ run_if) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
+    if (run_if && run_if[blockIdx.x] == 0) return;        // (the exact-order rerun: only for matrices whose optimum may not be unique)
+    // LDS: u (nr) doubles | row4col (nc), path (nc), col4row (nr) ints | slots
+    double* u = reinterpret_cast<double*>(lsa_smem);
+    int* row4col = reinterpret_cast<int*>(u + nr);
+    int* path = row4col + nc;
+    int* col4row = path + nc;
+    __shared__ double sl_val[2][16];
+    __shared__ int sl_sink[2][16], sl_it[2][16], sl_j[2][16];
+    __shared__ int s_claim_dummy;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const double* cost = costs + (long long)b * nr * nc;
+    const double sgn = negate ? -1.0 : 1.0;
+    double v[CPT], spc[CPT];
+    int pos[CPT];
+    bool sc[CPT];
+    int r4c[CPT];                                         // row4col of the owned columns (refreshed after every path flip)
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) { v[q] = 0.0; spc[q] = DM_INF_F64; pos[q] = 0; sc[q] = false; r4c[q] = -1; }
+    for (int i = t; i < nr; i += LSA_NT) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = t; j < nc; j += LSA_NT) { row4col[j] = -1; path[j] = -1; }
+    __syncthreads();
+    if (WARM) {
+        // v_j = min_i c_ij (lowest i on ties); the column takes that row if no lower column claimed it
+        int arg[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) { v[q] = DM_INF_F64; arg[q] = -1; }
+        for (int i = 0; i < nr; ++i) {
+            const double* crow = cost + (long long)i * nc;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = t + LSA_NT * q;
+                if (j < nc) { const double c = sgn * crow[j]; if (c < v[q]) { v[q] = c; arg[q] = i; } }
+            }
+        }
+        // claim: col4row[i] = the lowest column whose minimum is in row i (LDS atomics), then the winners record themselves
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = t + LSA_NT * q;
+            if (j < nc && arg[q] >= 0 && v[q] < DM_INF_F64) atomicMin(reinterpret_cast<unsigned int*>(&col4row[arg[q]]), (unsigned int)j);
+        }
+        __syncthreads();                                  // (col4row was -1 = 0xffffffff: any column index is smaller as unsigned)
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = t + LSA_NT * q;
+            if (j < nc && arg[q] >= 0 && col4row[arg[q]] == j) row4col[j] = arg[q];
+            if (j < nc && !(v[q] < DM_INF_F64)) v[q] = 0.0;     // a column without a finite entry: no usable minimum
+        }
+        __syncthreads();
+        (void)s_claim_dummy;
+    }
+    for (int cur = 0; cur < nr; ++cur) {
+        if (WARM && col4row[cur] != -1) continue;         // (uniform) assigned by the column reduction
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = t + LSA_NT * q;
+            spc[q] = DM_INF_F64; sc[q] = false; pos[q] = nc - 1 - j;          // remaining[it] = nc - it - 1
+            r4c[q] = j < nc ? row4col[j] : -1;
+        }
+        int i = cur, nrem = nc, sink = -1, step = 0;
+        double min_val = 0.0;
+        bool infeasible = false;
+        while (true) {
+            const double ui = u[i];
+            const double* crow = cost + (long long)i * nc;
+            double bval = DM_INF_F64;
+            int bsink = 0, bit = -1, bestj = -1;
+            double cv[CPT];
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {                // all the row's loads first (independent), then the relaxations
+                const int j = t + LSA_NT * q;
+                cv[q] = (j < nc && !sc[q]) ? crow[j] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = t + LSA_NT * q;
+                if (j < nc && !sc[q]) {
+                    const double r = ((min_val + sgn * cv[q]) - ui) - v[q];     // SciPy's operation order
+                    if (r < spc[q]) { spc[q] = r; path[j] = i; }
+                    lsa_merge(bval, bsink, bit, bestj, spc[q], r4c[q] == -1 ? 1 : 0, pos[q], j);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                lsa_merge(bval, bsink, bit, bestj, __shfl_xor(bval, off), __shfl_xor(bsink, off), __shfl_xor(bit, off), __shfl_xor(bestj, off));
+            const int par = step & 1;
+            if (lane == 0) { sl_val[par][wave] = bval; sl_sink[par][wave] = bsink; sl_it[par][wave] = bit; sl_j[par][wave] = bestj; }
+            __syncthreads();
+            // every thread folds the 16 wave results itself (lane q < 16 takes slot q, then a 4-level butterfly inside the wave:
+            // the rule is a total order on distinct positions, so every lane ends with the same winner)
+            double wv = lane < 16 ? sl_val[par][lane & 15] : DM_INF_F64;
+            int wsk = lane < 16 ? sl_sink[par][lane & 15] : 0, wit = lane < 16 ? sl_it[par][lane & 15] : -1, wj = lane < 16 ? sl_j[par][lane & 15] : -1;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1)
+                lsa_merge(wv, wsk, wit, wj, __shfl_xor(wv, off), __shfl_xor(wsk, off), __shfl_xor(wit, off), __shfl_xor(wj, off));
+            wv = __shfl(wv, 0); wsk = __shfl(wsk, 0); wit = __shfl(wit, 0); wj = __shfl(wj, 0);
+            ++step;
+            if (wit < 0 || !(wv < DM_INF_F64)) { infeasible = true; break; }
+            min_val = wv;
+            // remove the chosen column from the list: the column at the last position takes its place
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = t + LSA_NT * q;
+                if (j == wj) sc[q] = true;
+                else if (!sc[q] && pos[q] == nrem - 1) pos[q] = wit;
+            }
+            --nrem;
+            if (wsk) { sink = wj; break; }
+            i = row4col[wj];
+        }
+        if (infeasible) {                                 // (uniform) SciPy: ValueError "cost matrix is infeasible"
+            if (t == 0) atomicMax(&info[b], 1);
+            break;
+        }
+        // dual updates: every scanned column once; the row it was assigned to (if any) is a visited row
+        if (t == 0) u[cur] += min_val;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            if (sc[q]) {
+                const double dlt = min_val - spc[q];
+                if (r4c[q] != -1) u[r4c[q]] += dlt;       // (distinct rows: one column each)
+                v[q] -= dlt;
+            }
+        }
+        __syncthreads();
+        if (t == 0) {                                     // flip the augmenting path
+            int j = sink;
+            while (true) {
+                const int i2 = path[j];
+                row4col[j] = i2;
+                const int jn = col4row[i2];
+                col4row[i2] = j;
+                j = jn;
+                if (i2 == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < nr; i += LSA_NT) {
+        out_col4row[(long long)b * nr + i] = col4row[i];
+        if (g_u) g_u[(long long)b * nr + i] = u[i];
+    }
+    if (g_v) {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = t + LSA_NT * q;
+            if (j < nc) g_v[(long long)b * nc + j] = v[q];
+        }
+    }
+}
+
+// ---- is the optimum unique? ---------------------------------------------------------------------------------------------------
+// Given optimal duals (u, v) and the assignment, another assignment of the same cost exists exactly when the "equality graph"
+// has an alternating cycle: with r(j) the row assigned to column j, the directed graph on the rows with an edge i -> r(j) for
+// every edge (i, j) OUTSIDE the assignment without slack (c_ij - u_i - v_j = 0) has a directed cycle.  (Slack-free edges by
+// themselves are the rule, not the exception: the assignment polytope is degenerate, every search tree leaves them behind.)
+// A slack-free edge into an UNASSIGNED column (rectangular problems) is reported as a possible tie without further analysis.
+//   lsa_rowofcol_kernel  r(j)
+//   lsa_tight_kernel     adjacency bit matrix adj[i][i'] (nr x ceil(nr / 32) words per matrix), zeroed by the caller
+//   lsa_acyclic_kernel   one workgroup per matrix peels rows of in-degree zero (Kahn); rows left over = a cycle: tie[b] = 1
+__global__ __launch_bounds__(256) void lsa_rowofcol_kernel(const int32_t* __restrict__ col4row, int nr, int nc, int32_t* __restrict__ row4col) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nr) return;
+    const int j = col4row[(long long)b * nr + i];
+    if (j >= 0 && j < nc) row4col[(long long)b * nc + j] = i;
+}
+__global__ __launch_bounds__(256) void lsa_tight_kernel(const double* __restrict__ costs, int nr, int nc, int negate, const double* __restrict__ g_u,
+                                                        const double* __restrict__ g_v, const int32_t* __restrict__ col4row,
+                                                        const int32_t* __restrict__ row4col, unsigned int* __restrict__ adj, int nw,
+                                                        int32_t* __restrict__ tie) {
+    const int b = blockIdx.y;
+    const double sgn = negate ? -1.0 : 1.0;
+    const double* cost = costs + (long long)b * nr * nc;
+    bool freecol = false;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)nr * nc; e += (long long)gridDim.x * 256) {
+        const int i = (int)(e / nc), j = (int)(e - (long long)i * nc);
+        if (col4row[(long long)b * nr + i] == j) continue;
+        const double c = sgn * cost[e], ui = g_u[(long long)b * nr + i], vj = g_v[(long long)b * nc + j];
+        const double slack = (c - ui) - vj;
+        // (relative to the magnitudes that formed it: a few hundred ulps count as "no slack")
+        if (!(slack > 1e-13 * (fabs(c) + fabs(ui) + fabs(vj)))) {
+            const int r = row4col[(long long)b * nc + j];
+            if (r < 0) freecol = true;
+            else atomicOr(&adj[((long long)b * nr + i) * nw + (r >> 5)], 1u << (r & 31));
+        }
+    }
+    if (__any(freecol) && (threadIdx.x & 63) == 0) atomicMax(&tie[b], 1);
+}
+__global__ __launch_bounds__(1024) void lsa_acyclic_kernel(const unsigned int* __restrict__ adj, int nr, int nw, int* __restrict__ indeg_ws,
+                                                           int32_t* __restrict__ tie) {
+    __shared__ int s_removed, s_front;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const unsigned int* A = adj + (long long)b * nr * nw;
+    int* indeg = indeg_ws + (long long)b * 2 * nr;       // in-degree, then -1 once removed
+    int* front = indeg + nr;                              // the rows removed in the current round
+    for (int i = t; i < nr; i += 1024) indeg[i] = 0;
+    if (t == 0) s_removed = 0;
+    __syncthreads();
+    for (int i = t; i < nr; i += 1024)
+        for (int w = 0; w < nw; ++w) {
+            unsigned int m = A[(long long)i * nw + w];
+            while (m) { const int r = (w << 5) + __ffs((int)m) - 1; m &= m - 1; atomicAdd(&indeg[r], 1); }
+        }
+    __syncthreads();
+    for (int round = 0; round <= nr; ++round) {
+        if (t == 0) s_front = 0;
+        __syncthreads();
+        for (int i = t; i < nr; i += 1024)
+            if (indeg[i] == 0) { indeg[i] = -1; front[atomicAdd(&s_front, 1)] = i; }
+        __syncthreads();
+        const int nfront = s_front;
+        if (nfront == 0) break;
+        if (t == 0) s_removed += nfront;
+        for (int q = t; q < nfront * nw; q += 1024) {      // the out-edges of the removed rows
+            const int i = front[q / nw], w = q % nw;
+            unsigned int m = A[(long long)i * nw + w];
+            while (m) { const int r = (w << 5) + __ffs((int)m) - 1; m &= m - 1; atomicSub(&indeg[r], 1); }
+        }
+        __syncthreads();
+    }
+    if (t == 0 && s_removed < nr) atomicMax(&tie[b], 1);   // rows that never reach in-degree zero sit on or behind a cycle
+}
+
 // info[b] = 2 when the matrix holds a NaN or an infinity of the sign SciPy rejects (-inf when minimising, +inf when
 // maximising: "matrix contains invalid numeric entries")
 __global__ __launch_bounds__(256) void lsa_validate_kernel(const double* __restrict__ cost, long long n, int negate, int32_t* __restrict__ info) {
@@ -189,7 +441,8 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
     const size_t bT = transposed ? (size_t)B * nr * nc * 8 : 0;
     const size_t bF = (size_t)B * (R + 2 * (size_t)Cn) * 8, bI = (size_t)B * (2 * (size_t)R + 4 * (size_t)Cn) * 4;
     const size_t bO = transposed ? (size_t)B * R * 4 : 0;
-    int rc = dm_ws_reserve(ctx, dm_align_up(bT) + dm_align_up(bF) + dm_align_up(bI) + dm_align_up(bO) + 4096);
+    int rc = dm_ws_reserve(ctx, dm_align_up(bT) + dm_align_up(bF) + dm_align_up(bI) + dm_align_up(bO) + dm_align_up((size_t)B * 4) +
+                                    dm_align_up((size_t)B * R * dm_cdiv(R, 32) * 4) + dm_align_up((size_t)B * Cn * 4) + dm_align_up((size_t)B * 2 * R * 4) + 8192);
     if (rc) return rc;
     double* Ct = transposed ? (double*)dm_ws_take(ctx, bT) : nullptr;
     double* gf = (double*)dm_ws_take(ctx, bF);
@@ -204,6 +457,54 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
     }
     if (transposed)
         DM_LAUNCH(ctx, "lsa_transpose", lsa_transpose_kernel, dim3(dm_cdiv(nc, 32), dm_cdiv(nr, 32), B), dim3(256), 0, cost, nr, nc, Ct);
+    // register-resident search (columns owned by threads) when the columns fit 8 per thread and the row state fits the LDS
+    const size_t lds_reg = (size_t)R * 8 + ((size_t)2 * Cn + R) * 4 + 64;
+    if (ctx->opt_lsa_reg && Cn <= 8 * LSA_NT && lds_reg <= 150 * 1024) {
+        const double* Cm = transposed ? Ct : cost;
+        int32_t* outp = transposed ? tmp : col_of_row;
+        int32_t* tie = (int32_t*)dm_ws_take(ctx, (size_t)B * 4);
+        if (!tie) return dm_fail(ctx, DM_ENOMEM, "assignment: workspace not reserved");
+        double* gu = gf;
+        double* gv = gf + (size_t)B * R;
+        const int cpt = Cn <= LSA_NT ? 1 : (Cn <= 2 * LSA_NT ? 2 : (Cn <= 4 * LSA_NT ? 4 : 8));
+#define LSA_REG(CPT_, WARM_, RUNIF_)                                                                                   \
+        {                                                                                                              \
+            rc = dm_grant_lds(ctx, (const void*)lsa_reg_kernel<CPT_, WARM_>, lds_reg);                                 \
+            if (rc) return rc;                                                                                         \
+            DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", (lsa_reg_kernel<CPT_, WARM_>), dim3(B), dim3(LSA_NT), lds_reg, Cm, R, Cn,   \
+                      maximize ? 1 : 0, gu, gv, outp, info, RUNIF_);                                                   \
+        }
+#define LSA_REG_CPT(WARM_, RUNIF_)                                                                                     \
+        if (cpt == 1) LSA_REG(1, WARM_, RUNIF_) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_) else if (cpt == 4) LSA_REG(4, WARM_, RUNIF_) else LSA_REG(8, WARM_, RUNIF_)
+        if (ctx->opt_lsa_reg >= 2) {
+            // column-reduction start (not SciPy's order), accepted per matrix when its optimum is provably unique, else redone exactly
+            DM_CHECK_HIP(ctx, hipMemsetAsync(tie, 0, (size_t)B * 4, ctx->stream));
+            LSA_REG_CPT(1, (const int32_t*)nullptr)
+            const long long nel = (long long)R * Cn;
+            const int gx = (int)((nel + 256 * 16 - 1) / (256 * 16)) < 2048 ? (int)((nel + 256 * 16 - 1) / (256 * 16)) : 2048;
+            const int nw = dm_cdiv(R, 32);
+            unsigned int* adj = (unsigned int*)dm_ws_take(ctx, (size_t)B * R * nw * 4);
+            int32_t* r4c = (int32_t*)dm_ws_take(ctx, (size_t)B * Cn * 4);
+            int* indeg = (int*)dm_ws_take(ctx, (size_t)B * 2 * R * 4);
+            if (!adj || !r4c || !indeg) return dm_fail(ctx, DM_ENOMEM, "assignment: workspace not reserved");
+            DM_CHECK_HIP(ctx, hipMemsetAsync(adj, 0, (size_t)B * R * nw * 4, ctx->stream));
+            DM_CHECK_HIP(ctx, hipMemsetAsync(r4c, 0xFF, (size_t)B * Cn * 4, ctx->stream));
+            DM_LAUNCH(ctx, "lsa_unique", lsa_rowofcol_kernel, dim3(dm_cdiv(R, 256), B), dim3(256), 0, (const int32_t*)outp, R, Cn, r4c);
+            DM_LAUNCH(ctx, "lsa_unique", lsa_tight_kernel, dim3(gx, B), dim3(256), 0, Cm, R, Cn, maximize ? 1 : 0, (const double*)gu,
+                      (const double*)gv, (const int32_t*)outp, (const int32_t*)r4c, adj, nw, tie);
+            DM_LAUNCH(ctx, "lsa_unique", lsa_acyclic_kernel, dim3(B), dim3(1024), 0, (const unsigned int*)adj, R, nw, indeg, tie);
+            LSA_REG_CPT(0, (const int32_t*)tie)
+        } else {
+            LSA_REG_CPT(0, (const int32_t*)nullptr)
+        }
+#undef LSA_REG_CPT
+#undef LSA_REG
+        if (transposed) {
+            DM_CHECK_HIP(ctx, hipMemsetAsync(col_of_row, 0xFF, (size_t)B * nr * 4, ctx->stream));
+            DM_LAUNCH(ctx, "lsa_invert", lsa_invert_kernel, dim3(dm_cdiv(nc, 256), B), dim3(256), 0, tmp, nr, nc, col_of_row);
+        }
+        return DM_OK;
+    }
     const int use_lds = Cn <= LSA_LDS_MAX_COLS;
     const size_t lds = use_lds ? (size_t)Cn * 28 + 64 : 0;
     rc = dm_grant_lds(ctx, (const void*)lsa_kernel, lds);

@@ -73,6 +73,8 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *                           (all + exact float64 re-evaluation of the ambiguous rows; identical results)
  *   "solve_packed"  0 | 1   dm_fmap_solve: blocked LDS Cholesky when it fits | packed-storage solver always
  *   "simnn_band"    4 | n   tile order of the similarity kernels: bands of n tile rows, column-major inside (0: row-major)
+ *   "lsa_reg"       2 | 1 | 0   dm_linear_sum_assignment: column state in registers, started from a column reduction (kept per
+ *                           matrix only when its optimum is provably unique, else redone) | the same in SciPy's order | LDS state
  *   "solve_reg"     1 | 0   dm_fmap_solve, k1 <= 129: register-resident solver (one wave per system) | the LDS-resident blocked one
  * Unknown names return DM_EINVAL.  The library never reads environment variables. */
 int dm_set_option(dm_ctx* ctx, const char* name, int value);

@@ -600,12 +600,18 @@ def test_linear_sum_assignment_equals_scipy(eng):
             if q == 2:
                 c = c * (rng.random((nr, nc)) < 0.02)
             mats.append(c)
-        for mx in (False, True):
-            got = _np(eng.linear_sum_assignment(np.stack(mats), maximize=mx))
-            for q, c in enumerate(mats):
-                r0, c0 = scipy.optimize.linear_sum_assignment(c, maximize=mx)
-                rows = np.nonzero(got[q] >= 0)[0]
-                assert np.array_equal(rows, r0) and np.array_equal(got[q][rows], c0), (nr, nc, q, mx)
+        # every implementation (dm_set_option "lsa_reg"): 2 = register state + column-reduction start, kept only where the
+        # optimum is provably unique (the integer / sparse matrices here have ties: they are redone in SciPy's order),
+        # 1 = register state in SciPy's order, 0 = LDS state
+        for mode in (2, 1, 0):
+            eng.set_option("lsa_reg", mode)
+            for mx in (False, True):
+                got = _np(eng.linear_sum_assignment(np.stack(mats), maximize=mx))
+                for q, c in enumerate(mats):
+                    r0, c0 = scipy.optimize.linear_sum_assignment(c, maximize=mx)
+                    rows = np.nonzero(got[q] >= 0)[0]
+                    assert np.array_equal(rows, r0) and np.array_equal(got[q][rows], c0), (nr, nc, q, mx, mode)
+        eng.reset_options()
 
 
 def test_linear_sum_assignment_rejects_what_scipy_rejects(eng):
