@@ -76,30 +76,65 @@ __device__ __forceinline__ double readlane_f64(double x, int srclane) {
     return __hiloint2double(hi, lo);
 }
 
+// 1 / piv: v_rcp_f64 is good to 2^-24.4 (tools/ubench_solve_reg.hip); one cubic step r (1 + e + e^2), e = 1 - piv r, leaves
+// e^3 = 2^-73: three dependent fused multiply-adds on the pivot chain instead of the four of two Newton steps
+__device__ __forceinline__ double rcp_refined(double piv) {
+    const double rp = __builtin_amdgcn_rcp(piv);
+    const double er = fma(-piv, rp, 1.0);
+    return fma(rp, fma(er, er, er), rp);
+}
+
 // One step of the square-root-free elimination of a symmetric 16 x 16 block S held as s[e] = S[c][g + 4 e]; the same row
 // operations are applied to E (identity at the start): after the 16 steps E = Ltilde^-1 (unit lower triangular) and
 // W = diag(piv^-1/2) E = L^-1.  Row J reaches the lanes of a row through DPP row_newbcast, column J (the value S[c][J] of
 // this lane's row) lives in group J & 3 and comes across the groups through one ds_bpermute.
+// The step is ISSUE-bound, not latency-bound (one wave per SIMD, float64 VALU instructions take 8 cycles each: ~200 cycles per
+// pivot): a software-pipelined form that fetched column J + 1 and the next pivot ahead of the row updates (six more lane reads,
+// three more multiply-adds) measured the same 26 k cycles per system (tools/ubench_solve_reg.hip, profiles/r03_solver_reg_phases.txt).
 template <int J>
 __device__ __forceinline__ void elim_step(double (&s)[4], double (&w)[4], double& pv, int c, int lane, bool& ok) {
     constexpr int gj = J & 3, ej = J >> 2;
     const double piv = readlane_f64(s[ej], J | (gj << 4));                   // S[J][J], wave uniform
     ok = ok && (piv > 0.0);
-    // 1 / piv: v_rcp_f64 is good to 2^-24.4 (tools/ubench_solve_reg.hip); one cubic step r (1 + e + e^2), e = 1 - piv r, leaves
-    // e^3 = 2^-73: three dependent fused multiply-adds on the pivot chain instead of the four of two Newton steps
-    double rp = __builtin_amdgcn_rcp(piv);
-    const double er = fma(-piv, rp, 1.0);
-    rp = fma(rp, fma(er, er, er), rp);
+    const double rp = rcp_refined(piv);
     pv = (c == J) ? piv : pv;                                                // the lanes of row J keep pivot J
     const double v = __shfl(s[ej], c | (gj << 4));                           // S[c][J]
-    const double vr = -v * rp;
-    const double vrE = (c == J) ? 0.0 : vr;                                  // row J of E is final (pivot row)
-    // rows c < J: v is the rounding-level residue of their own elimination, they stay as they are up to O(1e-16)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (4 * e + 3 > J) fmac_row_bcast<J>(s[e], vr);                      // S[c][g + 4 e] -= v S[J][g + 4 e] / piv, live columns only
-        if (4 * e <= J) fmac_row_bcast<J>(w[e], vrE);                        // E[J][g + 4 e] can be non-zero only for g + 4 e <= J
-    }
+    double vr = -v * rp;
+    double vrE = (c == J) ? 0.0 : vr;                                        // row J of E is final (pivot row)
+    // rows c < J: v is the rounding-level residue of their own elimination (row J itself takes vr = -1 and is cleared), they
+    // stay as they are up to O(1e-16).
+    // S[c][g + 4 e] -= v S[J][g + 4 e] / piv for the live columns (4 e + 3 > J); E[J][g + 4 e] can be non-zero only for
+    // g + 4 e <= J (4 e <= J): always five updates, issued as one group behind a single hazard wait (each reads, through DPP,
+    // only the register it accumulates into, written by the previous step)
+    constexpr int E0 = J >> 2;                                               // s[E0 .. 3], w[0 .. E0]
+    if constexpr (E0 == 0)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %1, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %3, %3, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %4, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                     : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(w[0]) : "v"(vr), "v"(vrE), "n"(J));
+    else if constexpr (E0 == 1)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %1, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %3, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %4, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                     : "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(w[0]), "+v"(w[1]) : "v"(vr), "v"(vrE), "n"(J));
+    else if constexpr (E0 == 2)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %1, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %3, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %4, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                     : "+v"(s[2]), "+v"(s[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : "v"(vr), "v"(vrE), "n"(J));
+    else
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %1, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %3, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %4, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+                     : "+v"(s[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : "v"(vr), "v"(vrE), "n"(J));
 }
 
 // diagonal block (accumulator registers) -> W = L^-1 as W[c][g + 4 e]; ok = every pivot positive
@@ -141,8 +176,24 @@ constexpr int blk(int I, int K) { return I * (I + 1) / 2 + K; }
 // layout restricted to the lanes c == 0 (register r = rhs[16 J + g + 4 r] there, 0 elsewhere); store(J, x) receives the
 // solution, x[r] = x[16 J + g + 4 r] in every lane (column layout).  Returns false when a pivot was not positive (nothing
 // is stored then).
-template <int NB, class Rhs, class Store>
-__device__ __forceinline__ bool solve(f64x4 (&T)[NB * (NB + 1) / 2], Rhs rhs, Store store, int lane) {
+//
+// EV > 0: the finished panel blocks L_IJ (I > J) of the first EV block columns are parked in `ev` (wave-private LDS, 2 KiB per
+// block) between their trailing update and the back substitution -- nothing reads them in between.  At NB = 8 the 36 blocks,
+// the right-hand sides and the elimination state exceed what the register allocator fits into 256 + 256 registers; without
+// this it spilled 89 dwords per lane to scratch (190 MB of HBM writes per 8192 systems).
+constexpr int ev_slot(int NB, int J, int I) { return J * (NB - 1) - J * (J - 1) / 2 + (I - J - 1); }
+__device__ __forceinline__ void ev_put(double* ev, int slot, const f64x4& v, int lane) {
+    double* p = ev + slot * 256 + lane * 2;
+    *reinterpret_cast<f64x2*>(p) = f64x2{v[0], v[1]};
+    *reinterpret_cast<f64x2*>(p + 128) = f64x2{v[2], v[3]};
+}
+__device__ __forceinline__ f64x4 ev_get(const double* ev, int slot, int lane) {
+    const double* p = ev + slot * 256 + lane * 2;
+    const f64x2 a = *reinterpret_cast<const f64x2*>(p), b = *reinterpret_cast<const f64x2*>(p + 128);
+    return f64x4{a[0], a[1], b[0], b[1]};
+}
+template <int NB, int EV = 0, class Rhs, class Store>
+__device__ __forceinline__ bool solve(f64x4 (&T)[NB * (NB + 1) / 2], Rhs rhs, Store store, int lane, double* ev = nullptr) {
     const int c = lane & 15, g = lane >> 4;
     bool ok = true;
     f64x4 W;
@@ -205,6 +256,10 @@ __device__ __forceinline__ bool solve(f64x4 (&T)[NB * (NB + 1) / 2], Rhs rhs, St
                 T[blk(I, K)] = acc;
             }
         }
+        if (J < EV) {
+#pragma unroll
+            for (int I = J + 1; I < NB; ++I) ev_put(ev, ev_slot(NB, J, I), T[blk(I, J)], lane);
+        }
         DMREG_MARK(3)
     }
     if (!ok) return false;
@@ -222,9 +277,11 @@ __device__ __forceinline__ bool solve(f64x4 (&T)[NB * (NB + 1) / 2], Rhs rhs, St
         if (J + 1 < NB) {
             f64x4 u = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int I = J + 1; I < NB; ++I)
+            for (int I = J + 1; I < NB; ++I) {
+                const f64x4 Lij = (J < EV) ? ev_get(ev, ev_slot(NB, J, I), lane) : T[blk(I, J)];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) u[r] = fma(T[blk(I, J)][r], xrow[I], u[r]);
+                for (int r = 0; r < 4; ++r) u[r] = fma(Lij[r], xrow[I], u[r]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) z[r] -= row_allsum(u[r]);
         }

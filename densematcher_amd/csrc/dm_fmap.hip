@@ -739,6 +739,16 @@ __global__ __launch_bounds__(256) void fmap_solve_2phase_kernel(const double* __
 // with identity up to 16 NBT); the image the Gram kernel wrote has NBimg = ceil(n / 16) <= NBT block rows.
 // =================================================================================================
 #include "dm_chol_reg.h"
+#ifndef DM_SOLVE_REG_EV
+#define DM_SOLVE_REG_EV 3                  // block columns of the NBT = 8 instantiation whose panel blocks wait in LDS
+#endif
+
+constexpr int solve_reg_ev(int NBT) { return NBT == 8 ? DM_SOLVE_REG_EV : 0; }
+constexpr size_t solve_reg_lds(int NBT) {                  // the larger of: the pair's image (staging), the parked panel blocks of 4 waves
+    const size_t img = (size_t)(NBT * (NBT + 1) / 2) * 256 * sizeof(double);
+    const size_t ev = (size_t)4 * dmreg::ev_slot(NBT, solve_reg_ev(NBT), solve_reg_ev(NBT) + 1) * 256 * sizeof(double);
+    return img > ev ? img : ev;
+}
 
 template <int NBT>
 __global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __restrict__ PQ, const double* __restrict__ Timg,
@@ -746,29 +756,46 @@ __global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __
                                                                 const double* __restrict__ c00, double w_lap, int k1, int k2, int NBimg,
                                                                 long long nsys, double* __restrict__ C, int32_t* __restrict__ info) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long sys = (long long)blockIdx.x * 4 + wave;
-    if (sys >= nsys) return;                                 // (no barriers in this kernel: waves are independent)
+    const long long sys0 = (long long)blockIdx.x * 4;
+    const long long sys = min(sys0 + wave, nsys - 1);        // (a wave past the end repeats the last system: it takes part in the barriers)
     const int b = (int)(sys / k2), i = (int)(sys - (long long)b * k2);
     const int n = k1 - 1, c = lane & 15, g = lane >> 4;
     const double* P = PQ + (long long)b * (k1 + k2) * k1;
     const double* Q = P + (long long)k1 * k1;
     const double* l1 = lam1 + (long long)b * k1;
     const double* l2 = lam2 + (long long)b * k2;
+    extern __shared__ __attribute__((aligned(16))) double sh_dyn[];      // image staging, later the parked panel blocks (host: solve_reg_lds)
     f64x4 T[NBT * (NBT + 1) / 2];
-    // ---- image: block (I, K), register r of lane l = entry 64 r + l of the block (the accumulator layout of the transposed block)
+    // ---- image: block (I, K), register r of lane l = entry 64 r + l of the block (the accumulator layout of the transposed block).
+    // The four systems of a workgroup normally belong to one pair and share its image: it is fetched from L2 ONCE per workgroup
+    // into LDS and distributed from there (four private fetches of 72 KiB per CU and round were 10 % of the kernel).
     {
-        const double* img = Timg + (long long)b * (NBimg * (NBimg + 1) / 2) * 256 + lane;
+        const int nblk = NBimg * (NBimg + 1) / 2;
+        const bool one_pair = (int)(sys0 / k2) == (int)(min(sys0 + 3, nsys - 1) / k2);          // uniform over the workgroup
+        const double* imgb = Timg + (long long)b * nblk * 256;
+        if (one_pair) {
+            const f64x2* src = reinterpret_cast<const f64x2*>(imgb);
+            f64x2* dst = reinterpret_cast<f64x2*>(sh_dyn);
+            for (int q = threadIdx.x; q < nblk * 128; q += 256) dst[q] = src[q];
+            __syncthreads();
+        }
 #pragma unroll
         for (int I = 0; I < NBT; ++I)
 #pragma unroll
             for (int K = 0; K <= I; ++K) {
                 f64x4 v = {0.0, 0.0, 0.0, 0.0};
                 if (I < NBimg) {                             // uniform
+                    if (one_pair) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = img[(long long)dmreg::blk(I, K) * 256 + 64 * r];
+                        for (int r = 0; r < 4; ++r) v[r] = sh_dyn[dmreg::blk(I, K) * 256 + 64 * r + lane];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = imgb[(long long)dmreg::blk(I, K) * 256 + 64 * r + lane];
+                    }
                 }
                 T[dmreg::blk(I, K)] = v;
             }
+        __syncthreads();                                     // every wave has its copy before any wave parks blocks in the same LDS
     }
     // scale = max(lam1.max(), lam2.max())   (functional.py:404)
     double mx = -DM_INF_F64;
@@ -802,7 +829,7 @@ __global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __
     // the forward substitution: loading it there would expose a global round trip in front of a dependent chain
     __shared__ double sh_rhs[4][NBT * 16];
     for (int q = lane; q < NBT * 16; q += 64)
-        sh_rhs[wave][q] = (q < n) ? Q[(long long)i * k1 + (q + 1)] - P[(long long)(q + 1) * k1] * ci0 : 0.0;
+        sh_rhs[wave][q] = (q < n) ? Q[(long long)i * k1 + (q + 1)] - (i == 0 ? P[(long long)(q + 1) * k1] * ci0 : 0.0) : 0.0;   // (ci0 = 0 for i > 0)
     auto rhs = [&](int J) {
         f64x4 rv = {0.0, 0.0, 0.0, 0.0};
         if (c == 0) {
@@ -820,7 +847,10 @@ __global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __
             }
         }
     };
-    const bool solved = dmreg::solve<NBT>(T, rhs, store, lane);
+    // NBT = 8: the panel blocks of the first block column wait in LDS for the back substitution (dm_chol_reg.h, EV)
+    constexpr int EV = solve_reg_ev(NBT);
+    if (sys0 + wave >= nsys) return;                         // (no barrier below)
+    const bool solved = dmreg::solve<NBT, EV>(T, rhs, store, lane, sh_dyn + wave * (dmreg::ev_slot(NBT, EV, EV + 1) * 256));
     if (!solved) {
         if (lane == 0) atomicMax(&info[b], i + 1);
         for (int q = lane; q < k1; q += 64) Crow[q] = (q == 0) ? ci0 : 0.0;
@@ -878,12 +908,16 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
         const long long nsys = (long long)B * k2;
         const dim3 grid((unsigned)((nsys + 3) / 4));
 #define DM_SOLVE_REG(NBT_)                                                                                             \
-        DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_reg_kernel<NBT_>, grid, dim3(256), 0, PQ, Timg, lam1, lam2, c00, w_lap, k1, k2, \
-                  NB, nsys, C, info)
-        if (NB <= 2) DM_SOLVE_REG(2);
-        else if (NB <= 4) DM_SOLVE_REG(4);
-        else if (NB <= 6) DM_SOLVE_REG(6);
-        else DM_SOLVE_REG(8);
+        {                                                                                                              \
+            rc = dm_grant_lds(ctx, (const void*)fmap_solve_reg_kernel<NBT_>, solve_reg_lds(NBT_));                     \
+            if (rc) return rc;                                                                                         \
+            DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_reg_kernel<NBT_>, grid, dim3(256), solve_reg_lds(NBT_), PQ, Timg, lam1, lam2, \
+                      c00, w_lap, k1, k2, NB, nsys, C, info);                                                          \
+        }
+        if (NB <= 2) DM_SOLVE_REG(2)
+        else if (NB <= 4) DM_SOLVE_REG(4)
+        else if (NB <= 6) DM_SOLVE_REG(6)
+        else DM_SOLVE_REG(8)
 #undef DM_SOLVE_REG
         return DM_OK;
     }

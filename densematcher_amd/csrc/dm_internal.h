@@ -145,10 +145,28 @@ int dm_launch_gred(dm_ctx* ctx, const dm_gred_args& a);
 size_t dm_gred_ws_bytes(int B, int N2, int N1);
 
 // fp16 tile kernel + merge of the feature-similarity NN, reusable as a first pass (dm_simnn.hip)
-struct dm_simnn_queue {               // rows queued for exact re-evaluation and the 32-source block maxima that prune it
-    const float* pb32; int nsub; int N2pad;
+// Rows queued for exact re-evaluation, and what prunes it: the tile pass's own per-partial top-2.  Partial q of row i covers the
+// candidates [q pw, (q + 1) pw) and holds (best fp32 score, its index, second-best score).  A candidate whose fp32 score
+// reaches the row's threshold is either the best of its partial or not above the partial's second-best score, so
+//   second >= thr  -> every candidate of the partial is re-scored;   else best >= thr -> only the best one's block of 32.
+// (Round 2 kept a separate plane of maxima per block of 32 candidates for this, N^2 / 32 floats per key: 40 % of the HBM writes
+//  of the four-map pass and four more VALU instructions per accumulator block in its epilogue.)
+struct dm_simnn_queue {
+    const float* pb; const int32_t* pj; const float* ps;      // (B, nparts, Npad)
+    int nparts; int pw; int Npad;
     const int32_t* flag_count; const int32_t* flag_list; const float* flag_thr;
 };
+// does block `sb` (32 candidates) of row i (pair b) have to be re-scored?  (device code of the exact kernels)
+#ifdef __HIPCC__
+__device__ __forceinline__ bool dm_simnn_keep(const float* __restrict__ pb, const int32_t* __restrict__ pj, const float* __restrict__ ps,
+                                              int nparts, int pw, int Npad, int b, int i, int sb, float thr) {
+    const int q = (sb * 32) / pw;
+    if (q >= nparts) return false;
+    const long long o = ((long long)b * nparts + q) * Npad + i;
+    if (ps[o] >= thr) return true;
+    return pb[o] >= thr && (pj[o] >> 5) == sb;
+}
+#endif
 // Second reduction of the same fp16 products in one pass (the four maps of dm_fm_to_p2p, dm_knnsplit.hip):
 //   key A = score + bias[j] (-> nn21 / q of dm_simnn_core),  key B = score * scale[j], or the plain score when scale is null
 struct dm_simnn_cols {                // both directions in one pass: two more reductions, per SOURCE row over the targets
@@ -156,6 +174,7 @@ struct dm_simnn_cols {                // both directions in one pass: two more r
     const float* tau_add;             // (B) max_i |biasT_i|
     int32_t* nn_a; int32_t* nn_b;     // (B, N1) arg-max of key A' / key B'
     dm_simnn_queue* q_a; dm_simnn_queue* q_b;
+    const double* zero_b = nullptr;   // (B, N1) nullable: nn_b[j] = 0 where zero_b[j] == 0 (a zero indicator column: first index)
 };
 struct dm_simnn_dual {
     const float* bias;                // (B, N1)

@@ -137,17 +137,18 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
 struct ks_exact_args {
     const double* AT; const double* BT; const double* n1; const double* massS; const double* massT;
     int K, N2, N2pad, N1, N1pad, Kpad;
-    const float* pb32; int nsub, N2pad_s;
-    const int32_t* flag_count; const int32_t* flag_list; const float* flag_thr; int32_t* nn;
+    dm_simnn_queue q;                                  // flagged rows + the partials that prune their candidates
+    int32_t* nn;
 };
 template <int KIND>
 __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, int nwg) {
     const double* __restrict__ AT = a.AT; const double* __restrict__ BT = a.BT; const double* __restrict__ n1 = a.n1;
     const double* __restrict__ massS = a.massS; const double* __restrict__ massT = a.massT;
     const int K = a.K, N2 = a.N2, N2pad = a.N2pad, N1 = a.N1, N1pad = a.N1pad, Kpad = a.Kpad;
-    const float* __restrict__ pb32 = a.pb32; const int nsub = a.nsub, N2pad_s = a.N2pad_s;
-    const int32_t* __restrict__ flag_count = a.flag_count; const int32_t* __restrict__ flag_list = a.flag_list;
-    const float* __restrict__ flag_thr = a.flag_thr; int32_t* __restrict__ nn = a.nn;
+    const float* __restrict__ qpb = a.q.pb; const int32_t* __restrict__ qpj = a.q.pj; const float* __restrict__ qps = a.q.ps;
+    const int nparts = a.q.nparts, pw = a.q.pw, Npad_s = a.q.Npad, nsub = nparts * (pw / 32);
+    const int32_t* __restrict__ flag_count = a.q.flag_count; const int32_t* __restrict__ flag_list = a.q.flag_list;
+    const float* __restrict__ flag_thr = a.q.flag_thr; int32_t* __restrict__ nn = a.nn;
     extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums + 32 scores
     __shared__ unsigned long long cmask[4];
     double* part_s = xrow + K;
@@ -165,11 +166,11 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
         double bv = KIND == 0 ? DM_INF_F64 : -DM_INF_F64;
         int bj = DM_IDX_NONE;
         const double mt = KIND == 2 ? massT[(long long)b * N2 + i] : 0.0;
-        // candidate blocks: one gather of the row's block maxima (256 at a time), then only the blocks that can still
-        // hold the optimum are visited, in ascending order
+        // candidate blocks: one gather of the row's partials (256 blocks at a time), then only the blocks that can still
+        // hold the optimum are visited, in ascending order (dm_simnn_keep)
         for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
             const int sbt = sb0 + t;
-            const bool keep = sbt < nsub && pb32[((long long)b * nsub + sbt) * N2pad_s + i] >= thr;
+            const bool keep = sbt < nsub && dm_simnn_keep(qpb, qpj, qps, nparts, pw, Npad_s, b, i, sbt, thr);
             const unsigned long long km = __ballot(keep);
             if ((t & 63) == 0) cmask[t >> 6] = km;
             __syncthreads();
@@ -225,11 +226,13 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
     }
 }
 
-// one launch for one or two reductions of a pass: blockIdx.y selects the queue (and the value kind)
-template <int K0, int K1>
-__global__ __launch_bounds__(256) void ks_exact_kernel(ks_exact_args a0, ks_exact_args a1) {
+// one launch for up to four reductions of a pass: blockIdx.y selects the queue (and the value kind)
+template <int K0, int K1, int K2 = 0, int K3 = 0>
+__global__ __launch_bounds__(256) void ks_exact_kernel(ks_exact_args a0, ks_exact_args a1, ks_exact_args a2, ks_exact_args a3) {
     if (blockIdx.y == 0) ks_exact_body<K0>(a0, blockIdx.x, gridDim.x);
-    else ks_exact_body<K1>(a1, blockIdx.x, gridDim.x);
+    else if (blockIdx.y == 1) ks_exact_body<K1>(a1, blockIdx.x, gridDim.x);
+    else if (blockIdx.y == 2) ks_exact_body<K2>(a2, blockIdx.x, gridDim.x);
+    else ks_exact_body<K3>(a3, blockIdx.x, gridDim.x);
 }
 
 static inline size_t ks_build_lds(int fill) { return (size_t)64 * (fill + 8) * sizeof(_Float16); }
@@ -279,9 +282,8 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int rc = dm_simnn_core(ctx, a.B, a.N2, a.N1, D, st.Ft, st.ldT, Fs, D, rel_extra, overflow, a.knn21, nullptr, nullptr, &q);
     if (rc) return rc;
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
-    ks_exact_args ea{a.AT, a.BT, a.n1, nullptr, nullptr, K, a.N2, a.N2pad, a.N1, a.N1pad, a.Kpad, q.pb32, q.nsub, q.N2pad,
-                     q.flag_count, q.flag_list, q.flag_thr, a.knn21};
-    DM_LAUNCH(ctx, "knn_split_exact_f64", (ks_exact_kernel<0, 0>), dim3(2048, 1), dim3(256), lds, ea, ea);
+    ks_exact_args ea{a.AT, a.BT, a.n1, nullptr, nullptr, K, a.N2, a.N2pad, a.N1, a.N1pad, a.Kpad, q, a.knn21};
+    DM_LAUNCH(ctx, "knn_split_exact_f64", (ks_exact_kernel<0, 0>), dim3(2048, 1), dim3(256), lds, ea, ea, ea, ea);
     return DM_OK;
 }
 
@@ -295,21 +297,24 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 // own float64 expressions.  Needs interior 256-tiles and 3 K >= 160 (dm_fm_split_ok); otherwise the float64 G kernel.
 // (mass, when given: also its fp32 rounding scale32, the per-source factor of the tile kernel's key B -- the rounding is
 //  part of the key's error bound, dm_simnn_core -- and the maximum of the ROUNDED values)
-__global__ __launch_bounds__(256) void fs_bias_kernel(const double* __restrict__ nrm, int N, int Npad, const double* __restrict__ amaxT,
-                                                      const double* __restrict__ amaxS, int nS, const double* __restrict__ mass,
-                                                      float* __restrict__ bias, unsigned int* __restrict__ bmax, unsigned int* __restrict__ mmax,
-                                                      float* __restrict__ scale32) {
+struct fs_bias_set {
+    const double* nrm; int N, Npad; const double* mass; float* bias; unsigned int* bmax; unsigned int* mmax; float* scale32;
+};
+__global__ __launch_bounds__(256) void fs_bias_kernel(fs_bias_set s0, fs_bias_set s1, const double* __restrict__ amaxT,
+                                                      const double* __restrict__ amaxS, int nS) {
+    const fs_bias_set& s = blockIdx.z ? s1 : s0;             // (one launch for both operands)
     __shared__ float wb[4], wm[4];
     const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= s.N) return;                     // uniform
     const double sxy = ks_scale(amaxT + b * KS_NCH, KS_NCH) * ks_scale(amaxS + b * nS, nS);
     float bb = 0.f, mm = 0.f;
-    if (j < N) {
-        const float v = (float)(-0.5 * nrm[(long long)b * Npad + j] * sxy);
-        bias[(long long)b * N + j] = v;
+    if (j < s.N) {
+        const float v = (float)(-0.5 * s.nrm[(long long)b * s.Npad + j] * sxy);
+        s.bias[(long long)b * s.N + j] = v;
         bb = fabsf(v);
-        if (mass) {
-            const float m32 = (float)mass[(long long)b * N + j];
-            scale32[(long long)b * N + j] = m32;
+        if (s.mass) {
+            const float m32 = (float)s.mass[(long long)b * s.N + j];
+            s.scale32[(long long)b * s.N + j] = m32;
             mm = fabsf(m32);
         }
     }
@@ -320,8 +325,8 @@ __global__ __launch_bounds__(256) void fs_bias_kernel(const double* __restrict__
     if (threadIdx.x == 0) {
         bb = fmaxf(fmaxf(wb[0], wb[1]), fmaxf(wb[2], wb[3]));
         mm = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        atomicMax(bmax + b, __float_as_uint(bb));
-        if (mass) atomicMax(mmax + b, __float_as_uint(mm));
+        atomicMax(s.bmax + b, __float_as_uint(bb));
+        if (s.mass) atomicMax(s.mmax + b, __float_as_uint(mm));
     }
 }
 // ind12[j] = 0 where the target's mass is zero (the whole indicator column is 0: np.argmax returns the first index)
@@ -427,34 +432,29 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 64), B), dim3(256), ks_build_lds(D), a.BT,
               a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr);
-    DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1, 256), B), dim3(256), 0, a.n1, N1, a.N1pad, amaxT,
-              amaxS, nS, a.mass1, biasA, bmaxA, mmax, scale32);
-    DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, a.n2, N2, a.N2pad, amaxT,
-              amaxS, nS, (const double*)nullptr, biasB, bmaxB, (unsigned int*)nullptr, (float*)nullptr);
+    {
+        const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32};
+        const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr};
+        DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1 > N2 ? N1 : N2, 256), B, 2), dim3(256), 0, sA, sB, amaxT, amaxS, nS);
+    }
     const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
     if (ctx->opt_p2p_split >= 2) {
         // one pass, both directions: every tile reduces along its source rows (knn21, ind21) and, transposed through LDS,
         // along its target rows (knn12, ind12)
         dm_simnn_queue qa, qb, qc, qd;
-        dm_simnn_cols cols{biasB, reinterpret_cast<const float*>(bmaxB), a.knn12, a.ind12, &qc, &qd};
+        // (ind12[j] = 0 where mass1[j] = 0: the whole indicator column is 0 and np.argmax returns the first index)
+        dm_simnn_cols cols{biasB, reinterpret_cast<const float*>(bmaxB), a.knn12, a.ind12, &qc, &qd, a.mass1};
         dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
-                         qa.flag_count, qa.flag_list, qa.flag_thr, a.knn21};
+        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21};
         ks_exact_args e1 = e0;
-        e1.n1 = nullptr; e1.massS = a.mass1; e1.pb32 = qb.pb32; e1.flag_count = qb.flag_count; e1.flag_list = qb.flag_list;
-        e1.flag_thr = qb.flag_thr; e1.nn = a.ind21;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1>), dim3(1024, 2), dim3(256), lds, e0, e1);
-        ks_exact_args f0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qc.pb32, qc.nsub, qc.N2pad,
-                         qc.flag_count, qc.flag_list, qc.flag_thr, a.knn12};
+        e1.n1 = nullptr; e1.massS = a.mass1; e1.q = qb; e1.nn = a.ind21;
+        ks_exact_args f0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qc, a.knn12};
         ks_exact_args f1 = f0;
-        f1.n1 = nullptr; f1.massT = a.mass1; f1.pb32 = qd.pb32; f1.flag_count = qd.flag_count; f1.flag_list = qd.flag_list;
-        f1.flag_thr = qd.flag_thr; f1.nn = a.ind12;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 2>), dim3(1024, 2), dim3(256), lds, f0, f1);
-        const long long n = (long long)B * N1;
-        DM_LAUNCH(ctx, "fm_split_zero_mass", fs_zero_mass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a.mass1, n, a.ind12);
+        f1.n1 = nullptr; f1.massT = a.mass1; f1.q = qd; f1.nn = a.ind12;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1, 0, 2>), dim3(512, 4), dim3(256), lds, e0, e1, f0, f1);
         return DM_OK;
     }
     // pass A: targets = Phi2 rows, candidates = emb1 rows
@@ -463,12 +463,10 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
-                         qa.flag_count, qa.flag_list, qa.flag_thr, a.knn21};
+        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21};
         ks_exact_args e1 = e0;
-        e1.n1 = nullptr; e1.massS = a.mass1; e1.pb32 = qb.pb32; e1.flag_count = qb.flag_count; e1.flag_list = qb.flag_list;
-        e1.flag_thr = qb.flag_thr; e1.nn = a.ind21;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1>), dim3(1024, 2), dim3(256), lds, e0, e1);
+        e1.n1 = nullptr; e1.massS = a.mass1; e1.q = qb; e1.nn = a.ind21;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1>), dim3(1024, 2), dim3(256), lds, e0, e1, e0, e1);
     }
     // pass B: targets = emb1 rows, candidates = Phi2 rows
     {
@@ -476,12 +474,10 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_dual dual{biasB, nullptr, reinterpret_cast<const float*>(bmaxB), nullptr, a.ind12, &qb};
         int rc = dm_simnn_core(ctx, B, N1, N2, D, Fy, D, Fx, D, rel_extra, nullptr, a.knn12, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        ks_exact_args e0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa.pb32, qa.nsub, qa.N2pad,
-                         qa.flag_count, qa.flag_list, qa.flag_thr, a.knn12};
+        ks_exact_args e0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa, a.knn12};
         ks_exact_args e1 = e0;
-        e1.n1 = nullptr; e1.massT = a.mass1; e1.pb32 = qb.pb32; e1.flag_count = qb.flag_count; e1.flag_list = qb.flag_list;
-        e1.flag_thr = qb.flag_thr; e1.nn = a.ind12;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 2>), dim3(1024, 2), dim3(256), lds, e0, e1);
+        e1.n1 = nullptr; e1.massT = a.mass1; e1.q = qb; e1.nn = a.ind12;
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 2>), dim3(1024, 2), dim3(256), lds, e0, e1, e0, e1);
         const long long n = (long long)B * N1;
         DM_LAUNCH(ctx, "fm_split_zero_mass", fs_zero_mass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a.mass1, n, a.ind12);
     }

@@ -37,25 +37,24 @@ __device__ __forceinline__ int lds_off_halves(int row, int chunk) {
 
 struct simnn_params {
     const _Float16* Ftgt; const _Float16* Fsrc;
-    float* pb; int32_t* pj; float* ps;       // partials (B, tilesS, N2pad)
-    float* pb32;                             // (B, N1pad/32, N2pad) fp32 maximum over each block of 32 source rows (fix-up filter)
-    int nsub;                                // N1pad / 32
+    float* pb; int32_t* pj; float* ps;       // partials (B, 2 tilesS, N2pad): top-2 of a target row over each half (128 source rows)
+                                             // of a tile = the candidates one wave holds; they also prune the exact fix-up (dm_simnn_queue)
     float* tnorm2;                           // (B, N2)  |t_i|^2, written by the workgroups of source tile 0
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
     int ldT, ldS;                            // row strides (halves) of Ftgt / Fsrc, >= D, multiples of 8
     int band;                                // tile rows per band of the tile order (simnn_decode)
     // two reductions of the same products (DUAL kernels, dm_knnsplit.hip: dm_launch_fm_split):
-    //   key A = score + bias[j]  -> pb / pj / ps / pb32;   key B = score * scale[j] (DUAL 1) or score (DUAL 2) -> the *_2 arrays
+    //   key A = score + bias[j]  -> pb / pj / ps;   key B = score * scale[j] (DUAL 1) or score (DUAL 2) -> the *_2 arrays
     const float* bias; const float* scale;   // (B, N1) per source row
-    float* pb_2; int32_t* pj_2; float* ps_2; float* pb32_2;
+    float* pb_2; int32_t* pj_2; float* ps_2;
     // both directions in one pass (DUAL 3): besides the two row reductions above, every SOURCE row j gets two reductions
-    // over the targets: key A' = score + biasT[i], key B' = score.  Partials per (tile row, target quarter of the tile):
-    // (B, 4 tilesT, N1pad); block maxima over 32 targets: (B, N2pad / 32, N1pad); |s_j|^2 and max_i |t_i|^2 for the bound
+    // over the targets: key A' = score + biasT[i], key B' = score.  Partials per (tile row, target quarter of the tile = 64
+    // targets = one wave): (B, N2pad / 64, N1pad); |s_j|^2 and max_i |t_i|^2 for the bound
     const float* biasT;                      // (B, N2) per target row
-    float* cb[2]; int32_t* cj[2]; float* cs[2]; float* cb32[2];
+    float* cb[2]; int32_t* cj[2]; float* cs[2];
     float* snorm2; unsigned int* tmax2;
-    int N1pad, nsubT;                        // nsubT = N2pad / 32
+    int N1pad;
     int dbg;                                 // DM_EXPERIMENTS builds only (0 in the product): see simnn_pipe_kernel
 };
 
@@ -96,9 +95,11 @@ __device__ __forceinline__ float xhalf_max(float v) {
 // (truncated) positive scores the earliest position is the largest key
 __device__ __forceinline__ float k_key(float v, int code) { return __int_as_float((__float_as_int(v) & ~15) | code); }
 
-// Shared epilogue: row norms, top-2 reduction of the accumulators over the tile's 256 source rows, 32-row block
-// maxima for the fix-up filter.  `scratch` is 6 KiB of LDS that no in-flight LDS-DMA targets; the barrier inside is a
-// raw s_barrier (lgkmcnt only) so that LDS-DMA of the next tile stays in flight across it.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Shared epilogue: row norms and, per wave, the top-2 of every target row over the wave's 128 source rows.  Each wave writes
+// its own partial (no exchange between the two source halves of a tile: no LDS scratch, no barrier in the epilogue); the
+// merge kernel reduces the 2 tilesS partials of a row.
 //   acc[st][tt][r] = <src j, tgt i>,  j = j0 + wsrc*128 + st*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),
 //                                     i = i0 + wtgt*64 + tt*32 + (lane&31)
 // Per lane and target row the 64 candidates are reduced as KEYS (k_key): 16 v_and_or + 23 max/med3 per block of
@@ -106,12 +107,12 @@ __device__ __forceinline__ float k_key(float v, int code) { return __int_as_floa
 // for any candidate j other than the winner  fp32(best) - fp32(j) >= (bv - sv) - 3 * 2^-19 |t||s|  (one for bv, one
 // for the second key, one for its truncation), which is part of the bound that sends a row to the exact fix-up.
 // DUAL (1 / 2): two key sets from the same accumulators, A = score + bias[j], B = score * scale[j] (1) or score (2);
-// `bsl` = this tile's 256 bias values followed by its 256 scale values, in LDS; scratch is then 12 KiB.
-template <bool FULL, int TT, int SKIP = 0, int DUAL = 0>     // SKIP (experiments): 2 no block-maxima stores, 4 no merge / partial stores
+// `bsl` = this tile's 256 bias values followed by its 256 scale values, in LDS.  The per-source terms are applied two
+// accumulators at a time (v_pk_add_f32 / v_pk_mul_f32).
+template <bool FULL, int TT, int SKIP = 0, int DUAL = 0>     // SKIP (experiments): 4 no partial stores
 __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
-                                           bool do_tn, bool do_sn, int b, int i0, int j0, int ts_, float* scratch,
+                                           bool do_tn, bool do_sn, int b, int i0, int j0, int ts_,
                                            int lane, int wsrc, int wtgt, const float* bsl = nullptr) {
-    const int t = threadIdx.x;
     const int hi = lane >> 5;
     if (do_tn) {
 #pragma unroll
@@ -137,15 +138,10 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
     constexpr int NKIND = DUAL ? 2 : 1;
 #pragma unroll
     for (int kind = 0; kind < NKIND; ++kind) {
-    float* sb = scratch + kind * 6 * TT;                 // [2 wsrc][TT]
-    int* sj = reinterpret_cast<int*>(sb) + 2 * TT;
-    float* ss = sb + 4 * TT;
-    float* pb32k = kind ? p.pb32_2 : p.pb32;
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
         float Bk = DM_KEY_NONE, Sk = DM_KEY_NONE;        // running best / second-best key of this lane
         int Bst = 0;                                     // block (of 16 candidates) the best key came from
-        const int gi32 = i0 + wtgt * 64 + tt * 32 + (lane & 31);
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             float k[16];
@@ -156,15 +152,18 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
                     w4[q] = *reinterpret_cast<const f32x4*>(bsl + kind * 256 + wsrc * 128 + st * 32 + 4 * hi + 8 * q);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[st][tt][r];
-                if (DUAL && kind == 0) v = v + w4[r >> 2][r & 3];
-                if (DUAL == 1 && kind == 1) v = v * w4[r >> 2][r & 3];
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 v = {acc[st][tt][r], acc[st][tt][r + 1]};
+                const f32x2 w = {w4[r >> 2][r & 3], w4[r >> 2][(r & 3) + 1]};
+                if (DUAL && kind == 0) v = v + w;
+                if (DUAL == 1 && kind == 1) v = v * w;
                 if (!FULL) {
                     const int j = j0 + wsrc * 128 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    v = (j < p.N1) ? v : DM_KEY_NONE;
+                    v[0] = (j < p.N1) ? v[0] : DM_KEY_NONE;
+                    v[1] = (j + 1 < p.N1) ? v[1] : DM_KEY_NONE;
                 }
-                k[r] = k_key(v, 15 - r);                 // position r ascends with j inside the block
+                k[r] = k_key(v[0], 15 - r);              // position r ascends with j inside the block
+                k[r + 1] = k_key(v[1], 14 - r);
             }
             float bk = k_max(k[0], k[1]), sk = k_min(k[0], k[1]);
 #pragma unroll
@@ -173,15 +172,11 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
                 bk = k_max3(bk, k[r], k[r + 1]);
                 sk = k_max(sk, m);
             }
-            // maximum over this block of 32 source rows (both half-waves), an upper bound of its fp32 scores up to 2^-19
-            const float m32 = xhalf_max(bk);
-            if (!(SKIP & 2) && lane < 32 && gi32 < p.N2)
-                pb32k[((long long)b * p.nsub + (j0 >> 5) + wsrc * 4 + st) * p.N2pad + gi32] = m32;
             Sk = k_max3(Sk, sk, k_min(Bk, bk));
             Bst = (bk > Bk) ? st : Bst;                  // (equal truncated scores: either block; such a row is re-scored exactly)
             Bk = k_max(Bk, bk);
         }
-        // keys -> (value, source index, second value)
+        // keys -> (value, source index, second value), merged over the two half-waves
         const int kb = __float_as_int(Bk);
         const int r_ = 15 - (kb & 15);
         float bv = __int_as_float(kb & ~15), sv = __int_as_float(__float_as_int(Sk) & ~15);
@@ -193,30 +188,13 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
         const float os = xhalf(sv, hi != 0);
         top2_merge(bv, bj, sv, ob, oj, os);
         if ((SKIP & 4) && bv == 1.2345f) p.pb[lane] = sv + bj;
-        if (!(SKIP & 4) && lane < 32) {
-            const int li = wtgt * 64 + tt * 32 + lane;
-            sb[wsrc * TT + li] = bv; sj[wsrc * TT + li] = bj; ss[wsrc * TT + li] = sv;
-        }
-    }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the scratch writes; vmcnt untouched
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (!(SKIP & 4) && t < NKIND * TT) {                 // (DUAL: the workgroup has 2 TT threads, one per row and kind)
-        const int kind = t / TT, tr = t - kind * TT;
-        const float* sb = scratch + kind * 6 * TT;
-        const int* sj = reinterpret_cast<const int*>(sb) + 2 * TT;
-        const float* ss = sb + 4 * TT;
-        const int gi = i0 + tr;
-        if (gi < p.N2) {
-            float bv = sb[tr], sv = ss[tr];
-            int bj = sj[tr];
-            top2_merge(bv, bj, sv, sb[TT + tr], sj[TT + tr], ss[TT + tr]);
-            const long long o = ((long long)b * p.tilesS + ts_) * p.N2pad + gi;
+        const int gi = i0 + wtgt * 64 + tt * 32 + lane;
+        if (!(SKIP & 4) && lane < 32 && (FULL || gi < p.N2)) {
+            const long long o = ((long long)b * (2 * p.tilesS) + 2 * ts_ + wsrc) * p.N2pad + gi;
             if (kind == 0) { p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv; }
             else { p.pb_2[o] = bv; p.pj_2[o] = bj; p.ps_2[o] = sv; }
         }
+    }
     }
 }
 
@@ -272,7 +250,12 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
             for (int kind = 0; kind < 2; ++kind) {
                 float k[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) k[r] = k_key(kind == 0 ? tr[r] + w4[r >> 2][r & 3] : tr[r], 15 - r);
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 v = {tr[r], tr[r + 1]};
+                    if (kind == 0) v = v + f32x2{w4[r >> 2][r & 3], w4[r >> 2][(r & 3) + 1]};
+                    k[r] = k_key(v[0], 15 - r);
+                    k[r + 1] = k_key(v[1], 14 - r);
+                }
                 float bk = k_max(k[0], k[1]), sk = k_min(k[0], k[1]);
 #pragma unroll
                 for (int r = 2; r < 16; r += 2) {
@@ -280,9 +263,6 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
                     bk = k_max3(bk, k[r], k[r + 1]);
                     sk = k_max(sk, m);
                 }
-                const float m32 = xhalf_max(bk);          // maximum over this block of 32 targets
-                if (lane < 32)
-                    p.cb32[kind][((long long)b * p.nsubT + (i0 >> 5) + wtgt * 2 + tt) * p.N1pad + gj] = m32;
                 Sk[kind] = k_max3(Sk[kind], sk, k_min(Bk[kind], bk));
                 Bt[kind] = (bk > Bk[kind]) ? tt : Bt[kind];
                 Bk[kind] = k_max(Bk[kind], bk);
@@ -311,10 +291,9 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
 // Tile = 256 target rows x 256 source rows per 512-thread workgroup (8 waves = 2 source halves x 4 target quarters,
 // each wave 128 source x 64 target = 4 x 2 MFMA tiles, 128 accumulator registers).
 __global__ __launch_bounds__(512, 2) void simnn_edge_kernel(simnn_params p) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB, scratch
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // T[2] | S[2], 2 x 2 x 32 KiB
     _Float16* Ts = smem;
     _Float16* Ss = smem + 2 * ST * SBK;
-    float* scratch = reinterpret_cast<float*>(smem + 4 * ST * SBK);           // 6 KiB behind the staging buffers
 
     const int id = xcd_remap(blockIdx.x, p.total);
     const int tiles = p.tilesT * p.tilesS;
@@ -403,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void simnn_edge_kernel(simnn_params p) {
     }
 #undef SIMNN_FETCH
 #undef SIMNN_STASH
-    simnn_tail<false, ST>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, scratch, lane, wsrc, wtgt);
+    simnn_tail<false, ST>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, lane, wsrc, wtgt);
 }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -448,11 +427,12 @@ constexpr int SIMNN_PRODUCT_WT = 4;
 #define DM_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | ((((n) >> 4) & 3) << 14))    /* vmcnt(n) lgkmcnt(0) */
 static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
     const int TT = 64 * WT, NBUF = WT == 4 ? 4 : 3;
-    // ring | reduction scratch (6 KiB per key set) | DUAL: two slots of (256 bias + 256 scale [+ 256 target bias]) floats
-    // | DUAL 3: the eighth wave's transpose buffer (the other seven use the ring slot that is free during an epilogue)
-    if (dual == 3 && WT == 2) return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + 2 * (512 + TT) * 4;
-    return (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16) + (dual ? 2 : 1) * 3 * 2 * ST * 4 +
-           (dual == 3 ? 2 * 768 * 4 + 32 * 36 * 4 : (dual ? 2 * 512 * 4 : 0));
+    // ring | DUAL: two slots of (256 bias + 256 scale [+ TT target bias]) floats | DUAL 3, 8 waves: the eighth wave's transpose
+    // buffer (the other seven use the ring slot that is free during an epilogue)
+    size_t n = (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16);
+    if (dual) n += (size_t)2 * (dual == 3 ? 512 + TT : 512) * 4;
+    if (dual == 3 && WT == 4) n += 32 * 36 * 4;
+    return n;
 }
 
 // Tile order inside a pair: bands of p.band tile rows, column-major inside a band.  The ~32 workgroups of an XCD work on
@@ -488,14 +468,12 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     constexpr int STAG = (XV >> 4) & 3;
     constexpr bool PINR = (XV & 64) != 0;
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | scratch
-    // Behind the ring: reduction scratch (6 TT floats per key set) | DUAL: two slots of per-tile terms | DUAL 3, 8 waves: the
-    // eighth wave's transpose buffer.  The 4-wave both-directions kernel (two workgroups per CU: 80 KiB each) keeps only the
-    // term slots there: its scratch and transpose buffers live in the ring slot that is free during an epilogue.
-    constexpr bool SCR_IN_RING = (DUAL == 3 && WT == 2);
-    float* scratch = reinterpret_cast<float*>(smem + NBUF * PSTAGE);
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | per-tile terms | transpose buffer
+    // Behind the ring: DUAL: two slots of per-tile terms | DUAL 3, 8 waves: the eighth wave's transpose buffer (the transposes of
+    // the other waves go through the ring slot that is free during an epilogue; the 4-wave both-directions kernel, two
+    // workgroups per CU with 80 KiB each, has room for all of its four there).
     constexpr int BSLOT = DUAL == 3 ? 512 + TT : 512;  // floats per slot: 256 bias | 256 scale | TT target bias
-    float* bias_lds = SCR_IN_RING ? scratch : scratch + 12 * TT;   // filled by LDS-DMA one tile ahead
+    float* bias_lds = reinterpret_cast<float*>(smem + NBUF * PSTAGE);   // filled by LDS-DMA one tile ahead
     float* tb_extra = bias_lds + 2 * BSLOT;      // DUAL 3, 8 waves: transpose buffer of wave 7
 
     const int t = threadIdx.x, lane = t & 63;
@@ -594,7 +572,9 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     constexpr bool NOEPI = (dbg & 7) == 1 || (dbg & 7) == 7;
-    constexpr int EPI_ST = DUAL ? 16 : 8;         // stores every wave issues in an epilogue: the 2 x 4 block maxima per key set
+    // stores EVERY wave issues in an epilogue: its row partials (2 target blocks x 3 arrays per key set) and, both directions,
+    // its column partials (4 source blocks x 2 key sets x 3 arrays)
+    constexpr int EPI_ST = (DUAL ? 12 : 6) + (DUAL == 3 ? 24 : 0);
     int r_slot = 0;                               // ring slot of the stage being computed
     const bool late = FLIP && wave >= NW / 2;
 #define SIMNN_READ(fs_, ft_, slot_, fo_)                                                                               \
@@ -693,9 +673,8 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
             if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
         } else
 #endif
-        simnn_tail<true, TT, ((dbg & 7) == 2 || (dbg & 7) == 4 || (dbg & 7) == 6) ? (dbg & 7) : 0, (DUAL == 3 ? 1 : DUAL)>(
-            p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, SCR_IN_RING ? free_slot + NW * (32 * 36) : scratch, lane, wsrc, wtgt,
-            bias_lds + (n & 1) * BSLOT);
+        simnn_tail<true, TT, ((dbg & 7) == 4 || (dbg & 7) == 6) ? 4 : 0, (DUAL == 3 ? 1 : DUAL)>(
+            p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, lane, wsrc, wtgt, bias_lds + (n & 1) * BSLOT);
 #ifdef DM_EXPERIMENTS
         if (DUAL == 3 && (p.dbg & 0x2000)) {             // ablation (wrong results): no column-direction reduction
             if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
@@ -723,47 +702,50 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #undef SIMNN_DMA_TILE
 }
 
-// one key set of a tile pass: its per-tile partials in, the arg-max and the queue of ambiguous rows out
+// one key set of a tile pass: its partials in, the arg-max and the queue of ambiguous rows out.  Up to four key sets (the four
+// maps of dm_fm_to_p2p: two per direction, with their own geometry) are merged by ONE launch: blockIdx.z selects the set.
 struct simnn_merge_set {
-    const float* pb; const int32_t* pj; const float* ps;
-    const float* tau_add; const float* tau_mul;      // two-key pass: max_j |bias_j| for the biased key, max_j scale_j for the scaled key
+    const float* pb; const int32_t* pj; const float* ps;   // (B, nparts, Npad)
+    int nparts, N, Npad;
+    const float* norm2;                              // (B, N) |row|^2 of the rows being reduced
+    const unsigned int* max2;                        // (B) max |row|^2 of the other operand, float bits
+    const float* tau_add; const float* tau_mul;      // two-key pass: max |bias| for the biased key, max scale for the scaled key
+    const double* zero_if;                           // nullable (B, N): the answer is index 0 where this is 0 (an all-zero column)
     int32_t* nn; int32_t* flag_count; int32_t* flag_list; float* flag_thr;
+    float* best; float* margin;                      // nullable (B, N)
 };
-__global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_set s0, simnn_merge_set s1, int tilesS, int N2, int N2pad,
-                                                          const float* __restrict__ tnorm2, const unsigned int* __restrict__ smax2,
-                                                          float tau_scale, float* __restrict__ best, float* __restrict__ margin,
-                                                          const int32_t* __restrict__ force_flag) {
-    const simnn_merge_set& s = blockIdx.z ? s1 : s0;      // (gridDim.z = number of key sets)
+struct simnn_merge_sets { simnn_merge_set s[4]; };
+__global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_sets sets, float tau_scale, const int32_t* __restrict__ force_flag) {
+    const simnn_merge_set& s = sets.s[blockIdx.z];
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N2) return;
+    if (i >= s.N) return;
     float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
     int bj = DM_IDX_NONE;
     // (loads of eight partials ahead of their merges: the loop is a chain of L2 round trips otherwise)
-    int ts = 0;
-    for (; ts + 8 <= tilesS; ts += 8) {
+    int q = 0;
+    for (; q + 8 <= s.nparts; q += 8) {
         float vb[8], vs[8];
         int vj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const long long o = ((long long)b * tilesS + ts + u) * N2pad + i;
+            const long long o = ((long long)b * s.nparts + q + u) * s.Npad + i;
             vb[u] = s.pb[o]; vj[u] = s.pj[o]; vs[u] = s.ps[o];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) top2_merge(bv, bj, sv, vb[u], vj[u], vs[u]);
     }
-    for (; ts < tilesS; ++ts) {
-        const long long o = ((long long)b * tilesS + ts) * N2pad + i;
+    for (; q < s.nparts; ++q) {
+        const long long o = ((long long)b * s.nparts + q) * s.Npad + i;
         top2_merge(bv, bj, sv, s.pb[o], s.pj[o], s.ps[o]);
     }
-    const long long o = (long long)b * N2 + i;
+    const long long o = (long long)b * s.N + i;
+    if (s.zero_if && s.zero_if[o] == 0.0) { s.nn[o] = 0; return; }
     s.nn[o] = (bj == DM_IDX_NONE) ? 0 : bj;
     const float m = bv - sv;
-    if (blockIdx.z == 0) {
-        if (best) best[o] = bv;
-        if (margin) margin[o] = m;
-    }
-    const float tau = tau_scale * (sqrtf(tnorm2[o] * __uint_as_float(smax2[b])) * (s.tau_mul ? s.tau_mul[b] : 1.0f) + (s.tau_add ? s.tau_add[b] : 0.0f));
+    if (s.best) s.best[o] = bv;
+    if (s.margin) s.margin[o] = m;
+    const float tau = tau_scale * (sqrtf(s.norm2[o] * __uint_as_float(s.max2[b])) * (s.tau_mul ? s.tau_mul[b] : 1.0f) + (s.tau_add ? s.tau_add[b] : 0.0f));
     const bool forced = force_flag && force_flag[b] != 0;   // the caller could not bound the error for this pair: re-score everything
     if (forced || !(m > tau)) {
         const int pos = atomicAdd(s.flag_count, 1);
@@ -773,12 +755,14 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_set s0, si
 }
 
 // float64 re-evaluation of the flagged rows: one workgroup per flagged row (grid-stride over the list).  Only the
-// blocks of 32 source rows whose fp32 maximum reaches (best - tau) can contain the float64 argmax (every fp32 score
-// is within tau/2 of the exact one).  Such a block is re-scored exactly by the whole workgroup: 8 lanes per
+// blocks of 32 source rows that can hold a candidate whose fp32 score reaches (best - tau) can contain the float64 argmax
+// (every fp32 score is within tau/2 of the exact one): dm_simnn_keep, from the pass's own partials.  Such a block is re-scored
+// exactly by the whole workgroup: 8 lanes per
 // candidate, each wave instruction reads 8 x 128 contiguous bytes (fully used cache lines); fp16 products are exact
 // in f64 and the summation order is fixed, so duplicated rows give identical scores and the lowest index wins.
 __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __restrict__ Ftgt, const _Float16* __restrict__ Fsrc,
-                                                          int N2, int N1, int D, const float* __restrict__ pb32, int nsub,
+                                                          int N2, int N1, int D, const float* __restrict__ qpb,
+                                                          const int32_t* __restrict__ qpj, const float* __restrict__ qps, int nparts, int pw,
                                                           int N2pad, const int32_t* __restrict__ flag_count,
                                                           const int32_t* __restrict__ flag_list,
                                                           const float* __restrict__ flag_thr, int32_t* __restrict__ nn) {
@@ -799,11 +783,12 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
         __syncthreads();
         double bv = -DM_INF_F64;
         int bj = DM_IDX_NONE;
-        // candidate blocks: one gather of the row's block maxima (256 at a time), then only the blocks that can still
+        // candidate blocks: one gather of the row's partials (256 blocks at a time), then only the blocks that can still
         // hold the arg-max are visited, in ascending order
+        const int nsub = nparts * (pw / 32);
         for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
             const int sbt = sb0 + (int)threadIdx.x;
-            const bool keep = sbt < nsub && pb32[((long long)b * nsub + sbt) * N2pad + i] >= thr;
+            const bool keep = sbt < nsub && dm_simnn_keep(qpb, qpj, qps, nparts, pw, N2pad, b, i, sbt, thr);
             const unsigned long long km = __ballot(keep);
             if (lane == 0) cmask[wave] = km;
             __syncthreads();
@@ -862,12 +847,12 @@ static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
 size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual) {
     const size_t N2pad = pad_to(N2, ST), tilesS = dm_cdiv(N1, ST);
-    const size_t np = (size_t)B * tilesS * N2pad, np32 = (size_t)B * tilesS * (ST / 32) * N2pad;
-    const size_t keyset = 3 * dm_align_up(np * 4) + dm_align_up(np32 * 4) + dm_align_up((size_t)B * N2 * 4) * 2 + 512;
+    const size_t np = (size_t)B * 2 * tilesS * N2pad;          // row partials: two source halves per tile
+    const size_t keyset = 3 * dm_align_up(np * 4) + dm_align_up((size_t)B * N2 * 4) * 2 + 512;
     size_t total = (dual ? 2 : 1) * keyset + dm_align_up((size_t)B * N2 * 4) + 2 * dm_align_up((size_t)B * 4) + 8192;
     if (dual == 3) {                                      // the two column-direction key sets
-        const size_t N1pad = pad_to(N1, ST), cp = (size_t)B * (N2pad / 64) * N1pad, cp32 = (size_t)B * (N2pad / 32) * N1pad;
-        total += 2 * (3 * dm_align_up(cp * 4) + dm_align_up(cp32 * 4) + 2 * dm_align_up((size_t)B * N1 * 4)) + dm_align_up((size_t)B * N1 * 4) + 4096;
+        const size_t N1pad = pad_to(N1, ST), cp = (size_t)B * (N2pad / 64) * N1pad;
+        total += 2 * (3 * dm_align_up(cp * 4) + 2 * dm_align_up((size_t)B * N1 * 4)) + dm_align_up((size_t)B * N1 * 4) + 4096;
     }
     return total;
 }
@@ -895,20 +880,18 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     p.total = B * p.tilesT * p.tilesS;
     p.band = p.tilesT;                       // (edge kernel: row-major)
     p.dbg = dm_knob("DM_SIMNN_DEBUG", 0);
-    const size_t np = (size_t)B * p.tilesS * p.N2pad;
-    p.nsub = p.tilesS * (ST / 32);
-    const size_t np32 = (size_t)B * p.nsub * p.N2pad;
+    const int nparts = 2 * p.tilesS;                  // row partials: one per wave = per half (128 source rows) of a tile
+    const size_t np = (size_t)B * nparts * p.N2pad;
     p.pb = (float*)dm_ws_take(ctx, np * 4);
     p.pj = (int32_t*)dm_ws_take(ctx, np * 4);
     p.ps = (float*)dm_ws_take(ctx, np * 4);
-    p.pb32 = (float*)dm_ws_take(ctx, np32 * 4);
     p.tnorm2 = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     int32_t* flag_list = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* flag_thr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     // per-pair norm maxima and the queue counters: one block, one memset
     const size_t ctl_bytes = 2 * dm_align_up((size_t)B * 4) + 1024;
     char* ctl = (char*)dm_ws_take(ctx, ctl_bytes);
-    if (!p.pb || !p.pj || !p.ps || !p.pb32 || !p.tnorm2 || !flag_list || !flag_thr || !ctl)
+    if (!p.pb || !p.pj || !p.ps || !p.tnorm2 || !flag_list || !flag_thr || !ctl)
         return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
     p.smax2 = (unsigned int*)ctl;
     p.tmax2 = (unsigned int*)(ctl + dm_align_up((size_t)B * 4));
@@ -924,27 +907,25 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         p.pb_2 = (float*)dm_ws_take(ctx, np * 4);
         p.pj_2 = (int32_t*)dm_ws_take(ctx, np * 4);
         p.ps_2 = (float*)dm_ws_take(ctx, np * 4);
-        p.pb32_2 = (float*)dm_ws_take(ctx, np32 * 4);
         flag_list2 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
         flag_thr2 = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
         flag_count2 = flag_count + 64;
-        if (!p.pb_2 || !p.pj_2 || !p.ps_2 || !p.pb32_2 || !flag_list2 || !flag_thr2)
+        if (!p.pb_2 || !p.pj_2 || !p.ps_2 || !flag_list2 || !flag_thr2)
             return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
     }
     if (cols) {
         if (!dual->scale || !cols->biasT || !cols->nn_a || !cols->nn_b || !cols->q_a || !cols->q_b)
             return dm_fail(ctx, DM_EINVAL, "simnn: both-directions pass: missing operand");
         p.biasT = cols->biasT;
-        p.N1pad = pad_to(N1, ST); p.nsubT = p.N2pad / 32;
-        const size_t cp = (size_t)B * (p.N2pad / 64) * p.N1pad, cp32 = (size_t)B * p.nsubT * p.N1pad;
+        p.N1pad = pad_to(N1, ST);
+        const size_t cp = (size_t)B * (p.N2pad / 64) * p.N1pad;
         for (int kd = 0; kd < 2; ++kd) {
             p.cb[kd] = (float*)dm_ws_take(ctx, cp * 4);
             p.cj[kd] = (int32_t*)dm_ws_take(ctx, cp * 4);
             p.cs[kd] = (float*)dm_ws_take(ctx, cp * 4);
-            p.cb32[kd] = (float*)dm_ws_take(ctx, cp32 * 4);
             cflag_list[kd] = (int32_t*)dm_ws_take(ctx, (size_t)B * N1 * 4);
             cflag_thr[kd] = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
-            if (!p.cb[kd] || !p.cj[kd] || !p.cs[kd] || !p.cb32[kd] || !cflag_list[kd] || !cflag_thr[kd])
+            if (!p.cb[kd] || !p.cj[kd] || !p.cs[kd] || !cflag_list[kd] || !cflag_thr[kd])
                 return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
         }
         p.snorm2 = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
@@ -952,7 +933,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     }
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, ctx->stream));
-    const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16) + 3 * 2 * ST * 4;
+    const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16);
     const bool interior = (N2 % ST == 0 && N1 % ST == 0);
     // DM_EXPERIMENTS: DM_SIMNN_DEBUG = variant bits XV (simnn_pipe_kernel) + 256 / 512 for the 8-wave / 4-wave shape
     // (both directions: the 8-wave shape; p2p_split = 3 selects 4 waves x 2 workgroups per CU, whose second workgroup covers
@@ -1011,34 +992,35 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     }
     // twice the error bound of a score, relative to |t_i| max_j |s_j|: fp32 accumulation (D exact products,
     // D (1 + 1/16) additions, unit roundoff 2^-23, safe for round-to-nearest and for truncating adders) + the caller's
-    // own term, plus 3 * 2^-19 for the 4 mantissa bits the reduction keys give up (simnn_tail); 1 % slack for the
+    // own term, plus 4 * 2^-19 for the 4 mantissa bits the reduction keys give up (simnn_tail: the best key, the second key,
+    // its truncation, and the truncated partials the fix-up filter compares with the threshold); 1 % slack for the
     // fp32 norms.  Two-key pass: one more rounding (2^-23 covers the fp32 bias / scale and the add / multiply); key A is
     // bounded relative to |t_i| max|s_j| + max|bias_j|, key B relative to |t_i| max|s_j| max scale_j.
-    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 1.5f * 1.9073486e-6f + rel_extra +
+    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 2.0f * 1.9073486e-6f + rel_extra +
                                             (dual ? 1.1920929e-7f : 0.0f));
-    simnn_merge_set s0{p.pb, p.pj, p.ps, dual ? dual->tau_add : nullptr, nullptr, nn21, flag_count, flag_list, flag_thr};
-    simnn_merge_set s1 = s0;
-    if (dual) s1 = simnn_merge_set{p.pb_2, p.pj_2, p.ps_2, nullptr, dual->tau_mul, dual->nn_b, flag_count2, flag_list2, flag_thr2};
-    DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N2, 256), B, dual ? 2 : 1), dim3(256), 0, s0, s1, p.tilesS, N2,
-              p.N2pad, p.tnorm2, p.smax2, tau_scale, best, margin, force_flag);
-    q->pb32 = p.pb32; q->nsub = p.nsub; q->N2pad = p.N2pad;
-    q->flag_count = flag_count; q->flag_list = flag_list; q->flag_thr = flag_thr;
-    if (dual) {
-        dm_simnn_queue* q2 = dual->q_b;
-        q2->pb32 = p.pb32_2; q2->nsub = p.nsub; q2->N2pad = p.N2pad;
-        q2->flag_count = flag_count2; q2->flag_list = flag_list2; q2->flag_thr = flag_thr2;
-    }
+    simnn_merge_sets sets;
+    memset(&sets, 0, sizeof(sets));
+    int nsets = 0, maxN = N2;
+    sets.s[nsets++] = simnn_merge_set{p.pb, p.pj, p.ps, nparts, N2, p.N2pad, p.tnorm2, p.smax2, dual ? dual->tau_add : nullptr, nullptr,
+                                      nullptr, nn21, flag_count, flag_list, flag_thr, best, margin};
+    if (dual)
+        sets.s[nsets++] = simnn_merge_set{p.pb_2, p.pj_2, p.ps_2, nparts, N2, p.N2pad, p.tnorm2, p.smax2, nullptr, dual->tau_mul,
+                                          nullptr, dual->nn_b, flag_count2, flag_list2, flag_thr2, nullptr, nullptr};
     if (cols) {
         // the column direction: "targets" are the source rows, partials per (tile row, target quarter), bound from |s_j| max |t_i|
-        simnn_merge_set c0{p.cb[0], p.cj[0], p.cs[0], cols->tau_add, nullptr, cols->nn_a, cflag_count[0], cflag_list[0], cflag_thr[0]};
-        simnn_merge_set c1{p.cb[1], p.cj[1], p.cs[1], nullptr, nullptr, cols->nn_b, cflag_count[1], cflag_list[1], cflag_thr[1]};
-        DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(N1, 256), B, 2), dim3(256), 0, c0, c1, p.N2pad / 64, N1, p.N1pad,
-                  p.snorm2, p.tmax2, tau_scale, (float*)nullptr, (float*)nullptr, force_flag);
-        dm_simnn_queue* qs[2] = {cols->q_a, cols->q_b};
-        for (int kd = 0; kd < 2; ++kd) {
-            qs[kd]->pb32 = p.cb32[kd]; qs[kd]->nsub = p.nsubT; qs[kd]->N2pad = p.N1pad;
-            qs[kd]->flag_count = cflag_count[kd]; qs[kd]->flag_list = cflag_list[kd]; qs[kd]->flag_thr = cflag_thr[kd];
-        }
+        const int cparts = p.N2pad / 64;
+        sets.s[nsets++] = simnn_merge_set{p.cb[0], p.cj[0], p.cs[0], cparts, N1, p.N1pad, p.snorm2, p.tmax2, cols->tau_add, nullptr,
+                                          nullptr, cols->nn_a, cflag_count[0], cflag_list[0], cflag_thr[0], nullptr, nullptr};
+        sets.s[nsets++] = simnn_merge_set{p.cb[1], p.cj[1], p.cs[1], cparts, N1, p.N1pad, p.snorm2, p.tmax2, nullptr, nullptr,
+                                          cols->zero_b, cols->nn_b, cflag_count[1], cflag_list[1], cflag_thr[1], nullptr, nullptr};
+        maxN = N1 > N2 ? N1 : N2;
+    }
+    DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(maxN, 256), B, nsets), dim3(256), 0, sets, tau_scale, force_flag);
+    *q = dm_simnn_queue{p.pb, p.pj, p.ps, nparts, 128, p.N2pad, flag_count, flag_list, flag_thr};
+    if (dual) *dual->q_b = dm_simnn_queue{p.pb_2, p.pj_2, p.ps_2, nparts, 128, p.N2pad, flag_count2, flag_list2, flag_thr2};
+    if (cols) {
+        *cols->q_a = dm_simnn_queue{p.cb[0], p.cj[0], p.cs[0], p.N2pad / 64, 64, p.N1pad, cflag_count[0], cflag_list[0], cflag_thr[0]};
+        *cols->q_b = dm_simnn_queue{p.cb[1], p.cj[1], p.cs[1], p.N2pad / 64, 64, p.N1pad, cflag_count[1], cflag_list[1], cflag_thr[1]};
     }
     return DM_OK;
 }
@@ -1063,6 +1045,6 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
         if (rc) return rc;
     }
     DM_LAUNCH(ctx, "simnn_fixup_f64", simnn_fixup_kernel, dim3(2048), dim3(256), lds, (const _Float16*)Ftgt,
-              (const _Float16*)Fsrc, N2, N1, D, q.pb32, q.nsub, q.N2pad, q.flag_count, q.flag_list, q.flag_thr, nn21);
+              (const _Float16*)Fsrc, N2, N1, D, q.pb, q.pj, q.ps, q.nparts, q.pw, q.Npad, q.flag_count, q.flag_list, q.flag_thr, nn21);
     return DM_OK;
 }

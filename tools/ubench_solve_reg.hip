@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256, 1) void k_solve(const double* __restrict__ img
     auto store = [&](int J, const f64x4& v) {
         if (c == 0) { for (int r = 0; r < 4; ++r) xo[J * 16 + g + 4 * r] = v[r]; }
     };
-    if (!dmreg::solve<NB>(T, rhs, store, lane)) xo[0] = -1.0;
+#ifndef UB_EV
+#define UB_EV 0
+#endif
+    extern __shared__ __attribute__((aligned(16))) double sh_ev[];       // -DUB_EV=n: panel blocks of the first n block columns parked in LDS
+    if (!dmreg::solve<NB, UB_EV>(T, rhs, store, lane, sh_ev + wave * (dmreg::ev_slot(NB, UB_EV, UB_EV + 1) * 256))) xo[0] = -1.0;
 }
 
 // relative error of v_rcp_f64 (how many Newton steps does the pivot reciprocal need?)
@@ -88,7 +92,9 @@ int main() {
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(k_solve<NB>, dim3((nsys + 3) / 4), dim3(256), 0, 0, dimg, drhs, dx, nsys);
+            const size_t evb = (size_t)4 * dmreg::ev_slot(NB, UB_EV, UB_EV + 1) * 256 * sizeof(double);
+            CK(hipFuncSetAttribute((const void*)k_solve<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)evb));
+            hipLaunchKernelGGL(k_solve<NB>, dim3((nsys + 3) / 4), dim3(256), evb, 0, dimg, drhs, dx, nsys);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
         }
         long long t[8];
