@@ -122,7 +122,7 @@ def kernel_models(N, D, k, B, eng):
     dtype = the arithmetic the kernel runs in (its spec peak prices `frac`); executed = what the matrix cores actually
     issue where that differs from the algorithmic count (fp16 split: three products per float64 index, padded)."""
     n = k - 1
-    kd = -(-3 * k // 32) * 32 if k else 0
+    kd = 3 * 16 * (-(-k // 16)) if k else 0        # split rows: three fp16 products per index, indices padded to 16
     return {
         "fmap_solve_chol": dict(dtype="f64", bound="mfma", what="k2 SPD solves of order k1-1 per pair: k (n^3/3 + 2 n^2)",
                                 flops=B * k * (n ** 3 / 3.0 + 2.0 * n * n)),

@@ -167,7 +167,9 @@ __device__ __forceinline__ bool dm_simnn_keep(const float* __restrict__ pb, cons
     return pb[o] >= thr && (pj[o] >> 5) == sb;
 }
 #endif
-// Second reduction of the same fp16 products in one pass (the four maps of dm_fm_to_p2p, dm_knnsplit.hip):
+// Second reduction of the same fp16 products in one pass (the four maps of dm_fm_to_p2p, dm_knnsplit.hip).  A pass with key
+// sets reads SPLIT rows: per 16 contraction indices [16 high halves | 16 low halves] of both operands, from which the kernel
+// forms hx.hy + hx.ly + lx.hy (three k-steps per 32-halves stage); D = 32 ceil(K / 16).
 //   key A = score + bias[j] (-> nn21 / q of dm_simnn_core),  key B = score * scale[j], or the plain score when scale is null
 struct dm_simnn_cols {                // both directions in one pass: two more reductions, per SOURCE row over the targets
     const float* biasT;               // (B, N2) key A' = score + biasT[i]; key B' = score

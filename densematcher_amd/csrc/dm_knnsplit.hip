@@ -65,7 +65,7 @@ template <bool SRC>
 __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict__ M, const double* __restrict__ n1,
                                                        const double* __restrict__ amaxT, const double* __restrict__ amaxS, int nS,
                                                        int K, int N, int Npad, int Kpad, int ld, int fill, int head,
-                                                       _Float16* __restrict__ F, int32_t* __restrict__ overflow) {
+                                                       _Float16* __restrict__ F, int32_t* __restrict__ overflow, int paired) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ks_img[];       // 64 rows x (fill + 8) halves
     const int ldl = fill + 8;
     const int b = blockIdx.y, v0 = blockIdx.x * 64;
@@ -74,7 +74,34 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
     const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
     const double sc = SRC ? ks_scale(amaxS + b * nS, nS) : sx;
     _Float16* row = ks_img + vl * ldl;
-    if (v < N) {
+    if (v < N && paired) {
+        // split rows of the key-set tile kernels (dm_simnn.hip, SPLIT): per 16 contraction indices [16 high | 16 low], targets and
+        // sources alike (head = 0, fill = 32 ceil(K / 16)); the kernel forms hx.hy + hx.ly + lx.hy from them
+        for (int r0 = rg * 16; r0 < K; r0 += 64) {
+            const double* col = M + ((long long)b * Kpad + r0) * Npad + v;
+            _Float16* dst = row + 2 * r0;
+            f16x8 o[4];
+            if (r0 + 16 <= K) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    _Float16 h, l;
+                    split2(col[(long long)q * Npad] * sc, h, l);
+                    o[q >> 3][q & 7] = h;
+                    o[2 + (q >> 3)][q & 7] = l;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    _Float16 h = (_Float16)0.0f, l = (_Float16)0.0f;
+                    if (r0 + q < K) split2(col[(long long)q * Npad] * sc, h, l);
+                    o[q >> 3][q & 7] = h;
+                    o[2 + (q >> 3)][q & 7] = l;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f16x8*>(dst + 8 * q) = o[q];
+        }
+    } else if (v < N) {
         for (int r0 = rg * 16; r0 < K; r0 += 64) {
             const double* col = M + ((long long)b * Kpad + r0) * Npad + v;
             _Float16* dst = row + head + 3 * r0;
@@ -257,7 +284,7 @@ int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 64), B), dim3(256), ks_build_lds(st->ldT), AT,
               (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, KS_BIAS, st->Ft,
-              (int32_t*)nullptr);
+              (int32_t*)nullptr, 0);
     return DM_OK;
 }
 
@@ -274,7 +301,7 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 64), a.B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow);
+              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow, 0);
     dm_simnn_queue q;
     // error of the split on top of the fp32 accumulation, relative to |t_i| max_j |s_j|: the dropped <xl, yl> and the two
     // residuals (3 * 2^-22), the fp16 subnormal floor (2 sqrt(K) 2^-25), 25 % slack; 2^-19 at K = 200
@@ -335,14 +362,15 @@ __global__ __launch_bounds__(256) void fs_zero_mass_kernel(const double* __restr
     if (o < n && mass[o] == 0.0) ind12[o] = 0;
 }
 
-// X feature rows straight from the basis as it is in memory (row-major, fp32 or fp64: no transpose): thread (vertex, group
-// of 8 contraction indices) reads 32 / 64 contiguous bytes and writes 48; same values as ks_build_kernel<false> on the
-// float64 copy of the same numbers
+// X feature rows straight from the basis as it is in memory (row-major, fp32 or fp64: no transpose), in the split-row layout
+// of the key-set tile kernels ([16 high | 16 low] per 16 contraction indices): thread (vertex, group of 8 indices) reads
+// 32 / 64 contiguous bytes and writes two 16-byte chunks; same values as ks_build_kernel (paired) on the float64 copy of
+// the same numbers
 template <typename TR>
 __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict__ Phi, int N, int K, int ld, const double* __restrict__ amaxT,
                                                             int D, _Float16* __restrict__ F) {
     const int b = blockIdx.y;
-    const int ngrp = (D + 23) / 24;
+    const int ngrp = D / 16;                                    // groups of 8 indices (D = 32 ceil(K / 16))
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
     if (o >= (long long)N * ngrp) return;
     const int v = (int)(o / ngrp), q = (int)(o - (long long)v * ngrp);
@@ -350,8 +378,7 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
     //  the float64 split; fp64 basis: the split itself runs in float64, split2)
     const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
     const TR* src = Phi + ((long long)b * N + v) * ld + 8 * q;
-    _Float16* dst = F + ((long long)b * N + v) * D + 24 * q;
-    _Float16 o24[24];
+    _Float16* dst = F + ((long long)b * N + v) * D + 32 * (q >> 1) + 8 * (q & 1);
     TR xin[8];
     constexpr int amask = sizeof(TR) == 4 ? 3 : 1;
     if (8 * q + 8 <= K && ((ld & amask) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {   // 16-byte loads
@@ -369,6 +396,7 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) xin[u] = (8 * q + u < K) ? src[u] : (TR)0;
     }
+    f16x8 hv, lv;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         _Float16 h, l;
@@ -378,22 +406,13 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
         } else {
             split2((double)xin[u] * sx, h, l);
         }
-        o24[3 * u] = h; o24[3 * u + 1] = h; o24[3 * u + 2] = l;
+        hv[u] = h; lv[u] = l;
     }
-    if (24 * q + 24 <= D) {
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            f16x8 w;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = o24[8 * e + u];
-            *reinterpret_cast<f16x8*>(dst + 8 * e) = w;
-        }
-    } else {
-        for (int e = 0; 24 * q + e < D; ++e) dst[e] = o24[e];
-    }
+    *reinterpret_cast<f16x8*>(dst) = hv;
+    *reinterpret_cast<f16x8*>(dst + 16) = lv;
 }
 
-static inline int fs_depth(int K) { return pad_to(3 * K, 32); }
+static inline int fs_depth(int K) { return 32 * ((K + 15) / 16); }    // halves per split row
 size_t dm_fm_split_zero_bytes(int B) { return dm_align_up((size_t)B * KS_NCH * 8) + 3 * dm_align_up((size_t)B * 4); }
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K) {
     return ctx->opt_p2p_split != 0 && dm_simnn_dual_ok(ctx, N2, N1, fs_depth(K)) && N1 % 256 == 0 && N2 % 256 == 0;
@@ -424,14 +443,14 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     unsigned int* bmaxA = reinterpret_cast<unsigned int*>((char*)zeroed + dm_align_up((size_t)B * KS_NCH * 8));
     unsigned int* mmax = bmaxA + mstride; unsigned int* bmaxB = bmaxA + 2 * mstride;
     {
-        const long long n = (long long)N2 * ((D + 23) / 24);
+        const long long n = (long long)N2 * (D / 16);
         DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel<TR>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
                   amaxT, D, Fx);
     }
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 64), B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr);
+              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1);
     {
         const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32};
         const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr};

@@ -97,6 +97,15 @@ __device__ __forceinline__ float k_key(float v, int code) { return __int_as_floa
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// the lane id, recomputed where it is used: values derived from the kernel's own `lane` are loop invariants of the tile loop,
+// and the register allocator spilled some of them to scratch around the main loop -- every scratch reload then waits
+// vmcnt(0), i.e. for the whole LDS-DMA queue.  An asm volatile cannot be hoisted or merged.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // Shared epilogue: row norms and, per wave, the top-2 of every target row over the wave's 128 source rows.  Each wave writes
 // its own partial (no exchange between the two source halves of a tile: no LDS scratch, no barrier in the epilogue); the
 // merge kernel reduces the 2 tilesS partials of a row.
@@ -112,7 +121,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool FULL, int TT, int SKIP = 0, int DUAL = 0>     // SKIP (experiments): 4 no partial stores
 __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
                                            bool do_tn, bool do_sn, int b, int i0, int j0, int ts_,
-                                           int lane, int wsrc, int wtgt, const float* bsl = nullptr) {
+                                           int lane_, int wsrc, int wtgt, const float* bsl = nullptr) {
+    const int lane = FULL ? fresh_lane() : lane_;
     const int hi = lane >> 5;
     if (do_tn) {
 #pragma unroll
@@ -208,7 +218,8 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
 template <int WT>
 __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
                                                 bool do_tn, bool do_sn, int b, int i0, int j0, int tt_, float* tb,
-                                                const float* bT, int lane, int wsrc, int wtgt) {
+                                                const float* bT, int lane_, int wsrc, int wtgt) {
+    const int lane = fresh_lane();
     const int hi = lane >> 5, l31 = lane & 31;
     if (do_sn) {                                          // |s_j|^2 of the tile's source rows (tiles of target tile row 0)
 #pragma unroll
@@ -468,6 +479,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     constexpr int STAG = (XV >> 4) & 3;
     constexpr bool PINR = (XV & 64) != 0;
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
+    constexpr bool SPLIT = DUAL != 0;            // the key-set kernels read split rows [16 high | 16 low] per stage (dm_knnsplit.hip)
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | per-tile terms | transpose buffer
     // Behind the ring: DUAL: two slots of per-tile terms | DUAL 3, 8 waves: the eighth wave's transpose buffer (the transposes of
     // the other waves go through the ring slot that is free during an epilogue; the 4-wave both-directions kernel, two
@@ -511,14 +523,15 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         d_s = 0;                                                                                                       \
         if (DUAL && wave == 0) {      /* the tile's per-source terms: one 1 KiB piece each, landed long before its epilogue */ \
             float* dstB = bias_lds + (d_tile & 1) * BSLOT;                                                             \
-            const char* gb = reinterpret_cast<const char*>(p.bias + (long long)b_ * p.N1 + ts_ * ST) + lane * 16;      \
+            const int lane16 = fresh_lane() * 16;                                                                      \
+            const char* gb = reinterpret_cast<const char*>(p.bias + (long long)b_ * p.N1 + ts_ * ST) + lane16;         \
             __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)dstB, 16, 0, 0);                                      \
             if (DUAL == 1 || DUAL == 3) {                                                                              \
-                const char* gs = reinterpret_cast<const char*>(p.scale + (long long)b_ * p.N1 + ts_ * ST) + lane * 16; \
+                const char* gs = reinterpret_cast<const char*>(p.scale + (long long)b_ * p.N1 + ts_ * ST) + lane16;    \
                 __builtin_amdgcn_global_load_lds((gptr_t)gs, (lptr_t)(dstB + 256), 16, 0, 0);                          \
             }                                                                                                          \
-            if (DUAL == 3 && lane < TT / 4) {                                                                          \
-                const char* gt2 = reinterpret_cast<const char*>(p.biasT + (long long)b_ * p.N2 + tt_ * TT) + lane * 16; \
+            if (DUAL == 3 && lane16 < TT * 4) {                                                                        \
+                const char* gt2 = reinterpret_cast<const char*>(p.biasT + (long long)b_ * p.N2 + tt_ * TT) + lane16;  \
                 __builtin_amdgcn_global_load_lds((gptr_t)gt2, (lptr_t)(dstB + 512), 16, 0, 0);                         \
             }                                                                                                          \
         }                                                                                                              \
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     // vmcnt before the barrier of iteration g: stage g+1 must have landed; younger are the stages g+2 .. g+PD-1 and the
     // first half of stage g+PD, fewer at the very end of the walk.  Stores of an epilogue in between only make the
     // count conservative (it bounds loads + stores in flight).
-    f16x8 fsa[4], fta[2], fsb[4], ftb[2];
+    f16x8 fsa[4], fta[2], fsb[4], ftb[2], ftn[2];
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
@@ -608,6 +621,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #define SIMNN_STAGE(NORMS, DMA_, VM_, NEXT_, ZERO_, AFTER_EPI_)                                                        \
     {                                                                                                                  \
         const int n_slot = (r_slot + 1 == NBUF) ? 0 : r_slot + 1;                                                      \
+        if constexpr (!SPLIT) {                                                                                        \
         if (!late) { SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } SIMNN_PIN() }                       \
         SIMNN_MMA(fsa, fta, NORMS, ZERO_)                                                                              \
         if (late) { SIMNN_PIN() SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } }                        \
@@ -619,6 +633,39 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
            the compiler, merging the loop back-edge, waits lgkmcnt(0) in FRONT of the next MFMAs -- i.e. for the reads   \
            that were only just issued there */                                                                         \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        } else {                                                                                                       \
+        /* split rows: a stage holds 16 contraction indices as [16 high halves | 16 low halves] of both operands and     \
+           feeds THREE k-steps, hs.ht + hs.lt + ls.ht, from the same 12 fragment reads and the same 32 KiB of LDS-DMA    \
+           that fed two before (the (h,h,l) x (h,l,h) rows stored every high half twice): the LDS pipe -- fragment     \
+           reads + DMA writes -- is what the main loop is bound by.  fsa / fta = high parts, fsb / ftb = low parts.     \
+           The next stage's target high parts land in ftn (fta is an operand of the stage's last k-step).  */          \
+        SIMNN_READ(fsb, ftb, r_slot, foff1)                                                                            \
+        if (DMA_) { SIMNN_DMA1(0) }                                                                                    \
+        SIMNN_PIN()                                                                                                    \
+        if (NORMS) {   /* |row|^2 of the rows the products stand for: (h, h, l) resp. (h, l, h) */                     \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(fta[x], sumsq8(fta[x], nrm_t[x])); } \
+            if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsa[x], sumsq8(fsa[x], nrm_s[x])); } \
+        }                                                                                                              \
+        SIMNN_MMA(fsa, fta, false, ZERO_)                                                                              \
+        SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
+        if (NORMS) {                                                                                                   \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ftb[x], nrm_t[x]); }          \
+            if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsb[x], nrm_s[x]); }          \
+        }                                                                                                              \
+        SIMNN_MMA(fsa, ftb, false, false)                                                                              \
+        if (NEXT_ && (dbg & 7) != 7) {                                                                                 \
+            const _Float16* Bn = smem + n_slot * PSTAGE;                                                               \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                              \
+                fsa[x] = *reinterpret_cast<const f16x8*>(Bn + sbase + x * 32 * PBK + foff0);                           \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                              \
+                ftn[x] = *reinterpret_cast<const f16x8*>(Bn + tbase + x * 32 * PBK + foff0);                           \
+        }                                                                                                              \
+        if (DMA_) { SIMNN_DMA1(1) }                                                                                    \
+        SIMNN_PIN()                                                                                                    \
+        SIMNN_MMA(fsb, fta, false, false)                                                                              \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        if (NEXT_) { fta[0] = ftn[0]; fta[1] = ftn[1]; }                                                               \
+        }                                                                                                              \
         r_slot = n_slot;                                                                                               \
         if (DMA_) SIMNN_DMA_NEXT()                                                                                     \
     }
@@ -639,10 +686,15 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         }                                                                                                              \
     }
 
+    constexpr bool DEFER_READ = DUAL != 0;
     SIMNN_READ(fsa, fta, 0, foff0)
     for (int n = 0; n < ntile; ++n) {
         int b, tt_, ts_;
         simnn_decode(p, base + slot + n * nslot, b, tt_, ts_);
+        // The key-set kernels do not carry the next tile's first fragments across their epilogue (24 registers that pushed the
+        // epilogue into scratch, and every scratch reload waits vmcnt(0), i.e. for the whole LDS-DMA queue): the copies fetched by
+        // the last stage die there and are read again here.
+        if (DEFER_READ && n > 0) { SIMNN_READ(fsa, fta, r_slot, foff0) }
         const int i0 = tt_ * TT, j0 = ts_ * ST;
         f32x16 acc[4][2];
         // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that own
@@ -996,7 +1048,9 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     // its truncation, and the truncated partials the fix-up filter compares with the threshold); 1 % slack for the
     // fp32 norms.  Two-key pass: one more rounding (2^-23 covers the fp32 bias / scale and the add / multiply); key A is
     // bounded relative to |t_i| max|s_j| + max|bias_j|, key B relative to |t_i| max|s_j| max scale_j.
-    const float tau_scale = 2.0f * 1.01f * ((float)D * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 2.0f * 1.9073486e-6f + rel_extra +
+    // (key-set passes read split rows: D halves per row stand for 3 D / 2 products, hx.hy + hx.ly + lx.hy per index)
+    const float nprod = dual ? 1.5f * (float)D : (float)D;
+    const float tau_scale = 2.0f * 1.01f * (nprod * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 2.0f * 1.9073486e-6f + rel_extra +
                                             (dual ? 1.1920929e-7f : 0.0f));
     simnn_merge_sets sets;
     memset(&sets, 0, sizeof(sets));
