@@ -125,7 +125,8 @@ template <typename TR>
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, int ld,
                     const double* Cm, int ldc, long long strideC, int transC,
                     double* embT, int krpad, int Npad, double* nrm, int zero_first,
-                    double* amax_part = nullptr);   // amax_part: (B, ceil(Npad / DM_EMB_COLS)) max |embT| per block of columns (nullable)
+                    double* amax_part = nullptr,    // amax_part: (B, ceil(Npad / DM_EMB_COLS)) max |embT| per block of columns (nullable)
+                    double* amax_in_part = nullptr);   // same shape: max |Phi[:, :km]| over the block's vertices (nullable)
 constexpr int DM_EMB_COLS = 64;
 
 // Fused G = A^T B tile kernel with the arg-reductions (see dm_p2p.hip).
@@ -210,9 +211,10 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 // all four maps of dm_fm_to_p2p: two passes of the two-key fp16 tile kernel + exact float64 re-evaluation (dm_knnsplit.hip)
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K);
 size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K);
-size_t dm_fm_split_zero_bytes(int B);      // block the caller zeroes: (B, DM_NCH) maxima of |Phi2| (filled by dm_launch_phiT) + per-pair bounds
+size_t dm_fm_split_zero_bytes(int B);      // block the caller zeroes: the per-pair bounds (max |bias|, max mass) the pass accumulates with atomicMax
 template <typename TR>
-int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const TR* Phi2, int ld2);
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, const double* amaxT, int nT, void* zeroed,
+                       const TR* Phi2, int ld2);
 
 // C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
 template <typename TR>

@@ -65,13 +65,13 @@ template <bool SRC>
 __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict__ M, const double* __restrict__ n1,
                                                        const double* __restrict__ amaxT, const double* __restrict__ amaxS, int nS,
                                                        int K, int N, int Npad, int Kpad, int ld, int fill, int head,
-                                                       _Float16* __restrict__ F, int32_t* __restrict__ overflow, int paired) {
+                                                       _Float16* __restrict__ F, int32_t* __restrict__ overflow, int paired, int nT) {
     extern __shared__ __attribute__((aligned(16))) _Float16 ks_img[];       // 64 rows x (fill + 8) halves
     const int ldl = fill + 8;
     const int b = blockIdx.y, v0 = blockIdx.x * 64;
     const int vl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int v = v0 + vl;
-    const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
+    const double sx = ks_scale(amaxT + b * nT, nT);
     const double sc = SRC ? ks_scale(amaxS + b * nS, nS) : sx;
     _Float16* row = ks_img + vl * ldl;
     if (v < N && paired) {
@@ -166,8 +166,11 @@ struct ks_exact_args {
     int K, N2, N2pad, N1, N1pad, Kpad;
     dm_simnn_queue q;                                  // flagged rows + the partials that prune their candidates
     int32_t* nn;
+    // one operand may be read where the caller keeps it, row-major (B, N, ldrow) of the kernel's TR, instead of from a K-major
+    // float64 copy: Trow replaces AT (targets), Crow replaces BT (candidates).  Same values, same summation schedule.
+    const void* Trow = nullptr; const void* Crow = nullptr; int ldrow = 0;
 };
-template <int KIND>
+template <int KIND, typename TR>
 __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, int nwg) {
     const double* __restrict__ AT = a.AT; const double* __restrict__ BT = a.BT; const double* __restrict__ n1 = a.n1;
     const double* __restrict__ massS = a.massS; const double* __restrict__ massT = a.massT;
@@ -180,15 +183,22 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
     __shared__ unsigned long long cmask[4];
     double* part_s = xrow + K;
     const int count = *flag_count;
-    const int t = threadIdx.x, c = t & 31, part = t >> 5;
+    const TR* __restrict__ Trow = reinterpret_cast<const TR*>(a.Trow);
+    const TR* __restrict__ Crow = reinterpret_cast<const TR*>(a.Crow);
+    const int ldrow = a.ldrow;
+    // thread = (candidate c of a block of 32, part of the contraction).  Row-major candidates: the eight parts of a candidate
+    // sit in neighbouring lanes, so one load instruction reads eight 64-byte runs instead of 64 scattered elements.
+    const int t = threadIdx.x;
+    const int c = Crow ? (t >> 3) : (t & 31), part = Crow ? (t & 7) : (t >> 5);
     for (int e = wg; e < count; e += nwg) {
         const int o = flag_list[e];
         const float thr = flag_thr[e];
         const int b = o / N2, i = o - b * N2;
-        const double* A = AT + (long long)b * Kpad * N2pad + i;
-        const double* Bm = BT + (long long)b * Kpad * N1pad;
+        const double* A = AT ? AT + (long long)b * Kpad * N2pad + i : nullptr;
+        const double* Bm = BT ? BT + (long long)b * Kpad * N1pad : nullptr;
         __syncthreads();
-        for (int r = t; r < K; r += 256) xrow[r] = A[(long long)r * N2pad];
+        if (Trow) { for (int r = t; r < K; r += 256) xrow[r] = (double)Trow[((long long)b * N2 + i) * ldrow + r]; }
+        else { for (int r = t; r < K; r += 256) xrow[r] = A[(long long)r * N2pad]; }
         __syncthreads();
         double bv = KIND == 0 ? DM_INF_F64 : -DM_INF_F64;
         int bj = DM_IDX_NONE;
@@ -208,7 +218,18 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
                     mm &= mm - 1;
                     const int j = sb * 32 + c;
                     double sacc = 0.0;
-                    if (j < N1) {
+                    if (j < N1 && Crow) {
+                        const TR* Cr = Crow + ((long long)b * N1 + j) * ldrow;
+                        int r = part;
+                        for (; r + 56 < K; r += 64) {
+                            TR y[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) y[u] = Cr[r + 8 * u];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) sacc = fma(xrow[r + 8 * u], (double)y[u], sacc);
+                        }
+                        for (; r < K; r += 8) sacc = fma(xrow[r], (double)Cr[r], sacc);
+                    } else if (j < N1) {
                         // loads in batches of eight ahead of their (ordered) fma chain: a plain loop would take one L2 round
                         // trip per term
                         int r = part;
@@ -223,10 +244,11 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
                     }
                     part_s[part * 32 + c] = sacc;
                     __syncthreads();
-                    if (t < 32 && j < N1) {
-                        double g = part_s[c];
+                    if (t < 32 && sb * 32 + t < N1) {
+                        const int j = sb * 32 + t;                      // (thread t < 32 finishes candidate t of the block)
+                        double g = part_s[t];
 #pragma unroll
-                        for (int q = 1; q < 8; ++q) g += part_s[q * 32 + c];
+                        for (int q = 1; q < 8; ++q) g += part_s[q * 32 + t];
                         // blocks ascend: strict comparisons keep the lowest index
                         if (KIND == 0) {
                             const double v = n1[(long long)b * N1pad + j] - 2.0 * g;          // |y|^2 - 2 <x, y>
@@ -254,12 +276,12 @@ __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, in
 }
 
 // one launch for up to four reductions of a pass: blockIdx.y selects the queue (and the value kind)
-template <int K0, int K1, int K2 = 0, int K3 = 0>
+template <int K0, int K1, int K2 = 0, int K3 = 0, typename TR = double>
 __global__ __launch_bounds__(256) void ks_exact_kernel(ks_exact_args a0, ks_exact_args a1, ks_exact_args a2, ks_exact_args a3) {
-    if (blockIdx.y == 0) ks_exact_body<K0>(a0, blockIdx.x, gridDim.x);
-    else if (blockIdx.y == 1) ks_exact_body<K1>(a1, blockIdx.x, gridDim.x);
-    else if (blockIdx.y == 2) ks_exact_body<K2>(a2, blockIdx.x, gridDim.x);
-    else ks_exact_body<K3>(a3, blockIdx.x, gridDim.x);
+    if (blockIdx.y == 0) ks_exact_body<K0, TR>(a0, blockIdx.x, gridDim.x);
+    else if (blockIdx.y == 1) ks_exact_body<K1, TR>(a1, blockIdx.x, gridDim.x);
+    else if (blockIdx.y == 2) ks_exact_body<K2, TR>(a2, blockIdx.x, gridDim.x);
+    else ks_exact_body<K3, TR>(a3, blockIdx.x, gridDim.x);
 }
 
 static inline size_t ks_build_lds(int fill) { return (size_t)64 * (fill + 8) * sizeof(_Float16); }
@@ -284,7 +306,7 @@ int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 64), B), dim3(256), ks_build_lds(st->ldT), AT,
               (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, KS_BIAS, st->Ft,
-              (int32_t*)nullptr, 0);
+              (int32_t*)nullptr, 0, KS_NCH);
     return DM_OK;
 }
 
@@ -301,7 +323,7 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 64), a.B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow, 0);
+              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow, 0, KS_NCH);
     dm_simnn_queue q;
     // error of the split on top of the fp32 accumulation, relative to |t_i| max_j |s_j|: the dropped <xl, yl> and the two
     // residuals (3 * 2^-22), the fp16 subnormal floor (2 sqrt(K) 2^-25), 25 % slack; 2^-19 at K = 200
@@ -327,13 +349,13 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 struct fs_bias_set {
     const double* nrm; int N, Npad; const double* mass; float* bias; unsigned int* bmax; unsigned int* mmax; float* scale32;
 };
-__global__ __launch_bounds__(256) void fs_bias_kernel(fs_bias_set s0, fs_bias_set s1, const double* __restrict__ amaxT,
+__global__ __launch_bounds__(256) void fs_bias_kernel(fs_bias_set s0, fs_bias_set s1, const double* __restrict__ amaxT, int nT,
                                                       const double* __restrict__ amaxS, int nS) {
     const fs_bias_set& s = blockIdx.z ? s1 : s0;             // (one launch for both operands)
     __shared__ float wb[4], wm[4];
     const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x * 256 >= s.N) return;                     // uniform
-    const double sxy = ks_scale(amaxT + b * KS_NCH, KS_NCH) * ks_scale(amaxS + b * nS, nS);
+    const double sxy = ks_scale(amaxT + b * nT, nT) * ks_scale(amaxS + b * nS, nS);
     float bb = 0.f, mm = 0.f;
     if (j < s.N) {
         const float v = (float)(-0.5 * s.nrm[(long long)b * s.Npad + j] * sxy);
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(256) void fs_zero_mass_kernel(const double* __restr
 // the same numbers
 template <typename TR>
 __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict__ Phi, int N, int K, int ld, const double* __restrict__ amaxT,
-                                                            int D, _Float16* __restrict__ F) {
+                                                            int nT, int D, _Float16* __restrict__ F) {
     const int b = blockIdx.y;
     const int ngrp = D / 16;                                    // groups of 8 indices (D = 32 ceil(K / 16))
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -376,7 +398,7 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
     const int v = (int)(o / ngrp), q = (int)(o - (long long)v * ngrp);
     // (fp32 basis: x sx, |.| < 2, is exact in fp32 -- sx is a power of two --, and so is x sx - h: the pieces equal those of
     //  the float64 split; fp64 basis: the split itself runs in float64, split2)
-    const double sx = ks_scale(amaxT + b * KS_NCH, KS_NCH);
+    const double sx = ks_scale(amaxT + b * nT, nT);
     const TR* src = Phi + ((long long)b * N + v) * ld + 8 * q;
     _Float16* dst = F + ((long long)b * N + v) * D + 32 * (q >> 1) + 8 * (q & 1);
     TR xin[8];
@@ -413,7 +435,7 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
 }
 
 static inline int fs_depth(int K) { return 32 * ((K + 15) / 16); }    // halves per split row
-size_t dm_fm_split_zero_bytes(int B) { return dm_align_up((size_t)B * KS_NCH * 8) + 3 * dm_align_up((size_t)B * 4); }
+size_t dm_fm_split_zero_bytes(int B) { return 3 * dm_align_up((size_t)B * 4); }
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K) {
     return ctx->opt_p2p_split != 0 && dm_simnn_dual_ok(ctx, N2, N1, fs_depth(K)) && N1 % 256 == 0 && N2 % 256 == 0;
 }
@@ -426,10 +448,11 @@ size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K) {
 // a: AT, BT (K-major f64), n1, n2, mass1 and all four outputs; amaxS: per-256-column maxima of |BT| (colnorm_kernel);
 // zeroed: dm_fm_split_zero_bytes block, zeroed before dm_launch_phiT(Phi2) filled its first part
 template <typename TR>
-int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, void* zeroed, const TR* Phi2, int ld2) {
+int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, const double* amaxT, int nT, void* zeroed,
+                       const TR* Phi2, int ld2) {
     const int B = a.B, N1 = a.N1, N2 = a.N2;
     const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop;
-    if (!a.AT || !a.BT || !a.n1 || !a.n2 || !a.mass1 || !a.knn21 || !a.knn12 || !a.ind21 || !a.ind12 || !amaxS || !zeroed || !Phi2)
+    if (!a.BT || !a.n1 || !a.n2 || !a.mass1 || !a.knn21 || !a.knn12 || !a.ind21 || !a.ind12 || !amaxS || !amaxT || !zeroed || !Phi2)
         return dm_fail(ctx, DM_EINVAL, "fm_split: missing operand");
     const int D = fs_depth(K);
     _Float16* Fx = (_Float16*)dm_ws_take(ctx, (size_t)B * N2 * D * 2);
@@ -438,23 +461,22 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     float* biasB = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* scale32 = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);       // fp32 rounding of mass1: key B of the tile kernel
     if (!Fx || !Fy || !biasA || !biasB || !scale32) return dm_fail(ctx, DM_ENOMEM, "fm_split: workspace not reserved");
-    const double* amaxT = (const double*)zeroed;
     const size_t mstride = dm_align_up((size_t)B * 4) / 4;
-    unsigned int* bmaxA = reinterpret_cast<unsigned int*>((char*)zeroed + dm_align_up((size_t)B * KS_NCH * 8));
+    unsigned int* bmaxA = reinterpret_cast<unsigned int*>(zeroed);
     unsigned int* mmax = bmaxA + mstride; unsigned int* bmaxB = bmaxA + 2 * mstride;
     {
         const long long n = (long long)N2 * (D / 16);
         DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel<TR>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
-                  amaxT, D, Fx);
+                  amaxT, nT, D, Fx);
     }
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 64), B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1);
+              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1, nT);
     {
         const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32};
         const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr};
-        DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1 > N2 ? N1 : N2, 256), B, 2), dim3(256), 0, sA, sB, amaxT, amaxS, nS);
+        DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1 > N2 ? N1 : N2, 256), B, 2), dim3(256), 0, sA, sB, amaxT, nT, amaxS, nS);
     }
     const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
@@ -467,13 +489,14 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21};
+        // (Phi2 is read where the caller keeps it: targets of e0 / e1, candidates of f0 / f1)
+        ks_exact_args e0{nullptr, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21, Phi2, nullptr, ld2};
         ks_exact_args e1 = e0;
         e1.n1 = nullptr; e1.massS = a.mass1; e1.q = qb; e1.nn = a.ind21;
-        ks_exact_args f0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qc, a.knn12};
+        ks_exact_args f0{a.BT, nullptr, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qc, a.knn12, nullptr, Phi2, ld2};
         ks_exact_args f1 = f0;
         f1.n1 = nullptr; f1.massT = a.mass1; f1.q = qd; f1.nn = a.ind12;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1, 0, 2>), dim3(512, 4), dim3(256), lds, e0, e1, f0, f1);
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1, 0, 2, TR>), dim3(512, 4), dim3(256), lds, e0, e1, f0, f1);
         return DM_OK;
     }
     // pass A: targets = Phi2 rows, candidates = emb1 rows
@@ -482,10 +505,10 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        ks_exact_args e0{a.AT, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21};
+        ks_exact_args e0{nullptr, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21, Phi2, nullptr, ld2};
         ks_exact_args e1 = e0;
         e1.n1 = nullptr; e1.massS = a.mass1; e1.q = qb; e1.nn = a.ind21;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1>), dim3(1024, 2), dim3(256), lds, e0, e1, e0, e1);
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 1, 0, 0, TR>), dim3(1024, 2), dim3(256), lds, e0, e1, e0, e1);
     }
     // pass B: targets = emb1 rows, candidates = Phi2 rows
     {
@@ -493,14 +516,14 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_dual dual{biasB, nullptr, reinterpret_cast<const float*>(bmaxB), nullptr, a.ind12, &qb};
         int rc = dm_simnn_core(ctx, B, N1, N2, D, Fy, D, Fx, D, rel_extra, nullptr, a.knn12, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
-        ks_exact_args e0{a.BT, a.AT, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa, a.knn12};
+        ks_exact_args e0{a.BT, nullptr, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa, a.knn12, nullptr, Phi2, ld2};
         ks_exact_args e1 = e0;
         e1.n1 = nullptr; e1.massT = a.mass1; e1.q = qb; e1.nn = a.ind12;
-        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 2>), dim3(1024, 2), dim3(256), lds, e0, e1, e0, e1);
+        DM_LAUNCH(ctx, "fm_split_exact_f64", (ks_exact_kernel<0, 2, 0, 0, TR>), dim3(1024, 2), dim3(256), lds, e0, e1, e0, e1);
         const long long n = (long long)B * N1;
         DM_LAUNCH(ctx, "fm_split_zero_mass", fs_zero_mass_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a.mass1, n, a.ind12);
     }
     return DM_OK;
 }
-template int dm_launch_fm_split<float>(dm_ctx*, const dm_gred_args&, const double*, int, void*, const float*, int);
-template int dm_launch_fm_split<double>(dm_ctx*, const dm_gred_args&, const double*, int, void*, const double*, int);
+template int dm_launch_fm_split<float>(dm_ctx*, const dm_gred_args&, const double*, int, const double*, int, void*, const float*, int);
+template int dm_launch_fm_split<double>(dm_ctx*, const dm_gred_args&, const double*, int, const double*, int, void*, const double*, int);

@@ -134,20 +134,20 @@ __global__ __launch_bounds__(256) void colnorm_kernel(const double* __restrict__
 // of the current one, so no load latency is exposed between tiles (the contraction is only 4-13 stages deep).
 constexpr int EB_BK = 16;     // contraction per stage
 constexpr int EB_LD = 18;     // LDS row stride (f64): 36 dwords -> the 16 rows of a fragment read start on distinct 4-bank groups
-static inline size_t embed_lds(int RT) { return ((size_t)2 * (64 * RT + 64) * EB_LD + 3 * 64 + 4) * sizeof(double); }
+static inline size_t embed_lds(int RT) { return ((size_t)2 * (64 * RT + 64) * EB_LD + 3 * 64 + 8) * sizeof(double); }
 
 template <int RT, bool STORE, typename TR>
 __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __restrict__ Cm, long long strideC, int ldc, int transC,
                                                          const TR* __restrict__ Phi, long long stridePhi, int ld,
                                                          double* __restrict__ embT, int krpad, int Npad, int kr, int N, int K,
                                                          double* __restrict__ nrm, double* __restrict__ amax_part, int ntile_j,
-                                                         int total, int nrg) {
+                                                         int total, int nrg, double* __restrict__ amax_in_part) {
     extern __shared__ __attribute__((aligned(16))) double eb_sm[];
     constexpr int RA = 64 * RT;
     double* Abuf = eb_sm;                                   // [2][RA][EB_LD]
     double* Bbuf = eb_sm + 2 * RA * EB_LD;                  // [2][64][EB_LD]
     double* xs = Bbuf + 2 * 64 * EB_LD;                     // [3][64] column sums of waves 1-3
-    double* wmax = xs + 3 * 64;                             // [4]
+    double* wmax = xs + 3 * 64;                             // [4] output maxima | [4] input maxima
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int srow = t >> 2, sk = (t & 3) * 4;             // staging: row srow (+ 64 q), contraction entries sk .. sk+3
     const int ns = (K + EB_BK - 1) / EB_BK;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
     while (tile < total) {
         const int b = tile / ntile_j, j0 = (tile - b * ntile_j) * 64;
         double* E = STORE ? embT + (long long)b * krpad * Npad : nullptr;
-        double csum[4] = {0.0, 0.0, 0.0, 0.0}, amax = 0.0;
+        double csum[4] = {0.0, 0.0, 0.0, 0.0}, amax = 0.0, inmax = 0.0;   // inmax: max |Phi| over the tile's vertex slab
         // more than 64 RT rows: the tile is walked in row groups (the vertex slab is streamed again from L2 for each), the
         // column sums run on across the groups
         for (int rg = 0; rg < nrg; ++rg) {
@@ -247,6 +247,8 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
                 }
                 *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk) = f64x2{(double)rb[0], (double)rb[1]};
                 *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk + 2) = f64x2{(double)rb[2], (double)rb[3]};
+                if (amax_in_part)                           // (uniform) the basis entries this stage consumes, as they pass by
+                    inmax = fmax(fmax(inmax, fmax(fabs((double)rb[0]), fabs((double)rb[1]))), fmax(fabs((double)rb[2]), fabs((double)rb[3])));
                 __syncthreads();
                 // the buffer written above was last read two stages ago, and every wave has passed a barrier since
                 if (f_tile < total) EB_FETCH()
@@ -294,7 +296,11 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
 #pragma unroll
             for (int c_ = 0; c_ < 4; ++c_) xs[(wave - 1) * 64 + c_ * 16 + lane] = csum[c_];
         }
-        if (lane == 0) wmax[wave] = amax;
+        if (amax_in_part) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) inmax = fmax(inmax, __shfl_xor(inmax, off));
+        }
+        if (lane == 0) { wmax[wave] = amax; wmax[4 + wave] = inmax; }
         __syncthreads();
         if (wave == 0 && lane < 16 && nrm) {
 #pragma unroll
@@ -304,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
             }
         }
         if (t == 0 && amax_part) amax_part[(long long)b * ntile_j + (j0 >> 6)] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+        if (t == 0 && amax_in_part) amax_in_part[(long long)b * ntile_j + (j0 >> 6)] = fmax(fmax(wmax[4], wmax[5]), fmax(wmax[6], wmax[7]));
         // (xs / wmax are rewritten only after the next tile's stage barriers)
         tile += (int)gridDim.x;
     }
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
 template <typename TR>
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, int ld, const double* Cm, int ldc,
                     long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first,
-                    double* amax_part) {
+                    double* amax_part, double* amax_in_part) {
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
     if (embT && zero_first && (kr != krpad || N != Npad))
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
@@ -333,12 +340,12 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, in
             int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, true, TR>, lds);                                \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, true, TR>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
-                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg);        \
+                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg, amax_in_part); \
         } else {                                                                                                       \
             int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, false, TR>, lds);                               \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, false, TR>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
-                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg);        \
+                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg, amax_in_part); \
         }                                                                                                              \
     }
     if (RT == 1) EB_LAUNCH(1) else EB_LAUNCH(2)
@@ -346,9 +353,9 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, in
     return DM_OK;
 }
 template int dm_launch_embed<float>(dm_ctx*, int, int, int, int, const float*, int, const double*, int, long long, int, double*, int, int,
-                                    double*, int, double*);
+                                    double*, int, double*, double*);
 template int dm_launch_embed<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, int, long long, int, double*, int,
-                                     int, double*, int, double*);
+                                     int, double*, int, double*, double*);
 
 // =================================================================================================
 // fused G tile + arg-reductions
@@ -775,12 +782,14 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
     const int N1pad = pad_to(N1, GT), N2pad = pad_to(N2, GT);
     const int Kpad = pad_to(k2, GBK);          // contraction of G = Phi2 (k2) . emb1 (k2)
     const int K1pad = pad_to(k1, GBK);
-    const size_t bytes_AT = (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;
     const bool all = knn12 || ind21 || ind12;      // anything beyond knn21 takes the four-reduction kernel
     const size_t bytes_E2 = 0;                     // emb2 = Phi2 C is only needed for its row norms: never stored (embed_norm_kernel)
-    // all four maps on interior sizes: two passes of the two-key fp16 tile kernel + exact re-evaluation (dm_knnsplit.hip)
+    // all four maps on interior sizes: one pass of the four-key fp16 tile kernel + exact re-evaluation (dm_knnsplit.hip).  That
+    // path reads Phi2 where it lies (row-major, fp32 or fp64): no K-major copy of it is made.
     const bool split = knn21 && knn12 && ind21 && ind12 && mass1_in && dm_fm_split_ok(ctx, N2, N1, k2);
-    const size_t bytes_amax = (size_t)B * dm_cdiv(N1pad, DM_EMB_COLS) * 8;
+    const size_t bytes_AT = split ? 0 : (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;
+    const int nS = dm_cdiv(N1pad, DM_EMB_COLS), nT = dm_cdiv(N2pad, DM_EMB_COLS);
+    const size_t bytes_amax = (size_t)B * (nS + nT) * 8;
     const size_t bytes_zero = split ? dm_fm_split_zero_bytes(B) : 0;    // |Phi2| maxima and the per-pair bounds: one memset
     const size_t need = dm_align_up(bytes_AT) + dm_align_up(bytes_BT) + dm_align_up(bytes_E2) +
                         dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N2pad * 8) +
@@ -788,7 +797,7 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
                         (split ? dm_fm_split_ws_bytes(B, N2, N1, k2) : dm_gred_ws_bytes(B, N2, N1));
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
-    double* AT = (double*)dm_ws_take(ctx, bytes_AT);
+    double* AT = bytes_AT ? (double*)dm_ws_take(ctx, bytes_AT) : nullptr;
     double* BT = (double*)dm_ws_take(ctx, bytes_BT);
     double* E2 = bytes_E2 ? (double*)dm_ws_take(ctx, bytes_E2) : nullptr;
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
@@ -799,19 +808,23 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
     const double* mass1 = nullptr;
     rc = dm_widen_mass(ctx, (long long)B * N1, mass1_in, massbuf, &mass1);
     if (rc) return rc;
-    if (!AT || !BT || (bytes_E2 && !E2) || !n1 || !n2 || !amaxS || (bytes_zero && !zeroed))
+    double* amaxT = amaxS + (size_t)B * nS;            // (B, nT) max |Phi2| per 64 vertices, written by the second embedding
+    if ((bytes_AT && !AT) || !BT || (bytes_E2 && !E2) || !n1 || !n2 || !amaxS || (bytes_zero && !zeroed))
         return dm_fail(ctx, DM_ENOMEM, "fm_to_p2p: workspace not reserved");
     if (zeroed) DM_CHECK_HIP(ctx, hipMemsetAsync(zeroed, 0, bytes_zero, ctx->stream));
 
-    // AT = Phi2[:, :k2]^T (K-major f64)
-    rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad, (double*)zeroed);
-    if (rc) return rc;
+    // AT = Phi2[:, :k2]^T (K-major f64) for the float64 kernel
+    if (!split) {
+        rc = dm_launch_phiT(ctx, B, N2, k2, Phi2, ld2, AT, Kpad, N2pad, (double*)nullptr);
+        if (rc) return rc;
+    }
     // BT = emb1^T, emb1 = Phi1[:, :k1] C^T (N1 x k2): emb1T[c][j] = sum_m C[c][m] Phi1[j][m];  n1_j = |emb1_j|^2
     rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, C, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 1, amaxS);
     if (rc) return rc;
     if (all) {
         // emb2 = Phi2[:, :k2] C (N2 x k1): emb2T[m][i] = sum_c C[c][m] Phi2[i][c];  only n2_i = |emb2_i|^2 is used
-        rc = dm_launch_embed(ctx, B, N2, k1, k2, Phi2, ld2, C, k1, (long long)k2 * k1, 1, (double*)nullptr, K1pad, N2pad, n2, 1);
+        rc = dm_launch_embed(ctx, B, N2, k1, k2, Phi2, ld2, C, k1, (long long)k2 * k1, 1, (double*)nullptr, K1pad, N2pad, n2, 1,
+                             (double*)nullptr, split ? amaxT : nullptr);
         if (rc) return rc;
     }
     dm_gred_args a;
@@ -824,7 +837,7 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
         a.mass1 = massbuf;
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
-    if (split) { a.Ktrue = k2; return dm_launch_fm_split<TR>(ctx, a, amaxS, dm_cdiv(N1pad, DM_EMB_COLS), zeroed, Phi2, ld2); }
+    if (split) { a.Ktrue = k2; return dm_launch_fm_split<TR>(ctx, a, amaxS, nS, amaxT, nT, zeroed, Phi2, ld2); }
     return dm_launch_gred(ctx, a);
 }
 extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,
