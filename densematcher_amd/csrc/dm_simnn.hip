@@ -118,17 +118,18 @@ __device__ __forceinline__ int fresh_lane() {
 // DUAL (1 / 2): two key sets from the same accumulators, A = score + bias[j], B = score * scale[j] (1) or score (2);
 // `bsl` = this tile's 256 bias values followed by its 256 scale values, in LDS.  The per-source terms are applied two
 // accumulators at a time (v_pk_add_f32 / v_pk_mul_f32).
-template <bool FULL, int TT, int SKIP = 0, int DUAL = 0>     // SKIP (experiments): 4 no partial stores
-__device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
+// TB = 32-row target blocks per wave (2: eight waves x 128 x 64; 4: four waves x 128 x 128, accumulators in AGPRs)
+template <bool FULL, int TT, int SKIP = 0, int DUAL = 0, int TB = 2>     // SKIP (experiments): 4 no partial stores
+__device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][TB], float (&nrm_t)[TB], float (&nrm_s)[4],
                                            bool do_tn, bool do_sn, int b, int i0, int j0, int ts_,
                                            int lane_, int wsrc, int wtgt, const float* bsl = nullptr) {
     const int lane = FULL ? fresh_lane() : lane_;
     const int hi = lane >> 5;
     if (do_tn) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < TB; ++x) {
             const float v = nrm_t[x] + xhalf(nrm_t[x], hi != 0);
-            const int gi = i0 + wtgt * 64 + x * 32 + (lane & 31);
+            const int gi = i0 + wtgt * (32 * TB) + x * 32 + (lane & 31);
             if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
         }
     }
@@ -149,7 +150,7 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
 #pragma unroll
     for (int kind = 0; kind < NKIND; ++kind) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < TB; ++tt) {
         float Bk = DM_KEY_NONE, Sk = DM_KEY_NONE;        // running best / second-best key of this lane
         int Bst = 0;                                     // block (of 16 candidates) the best key came from
 #pragma unroll
@@ -198,7 +199,7 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
         const float os = xhalf(sv, hi != 0);
         top2_merge(bv, bj, sv, ob, oj, os);
         if ((SKIP & 4) && bv == 1.2345f) p.pb[lane] = sv + bj;
-        const int gi = i0 + wtgt * 64 + tt * 32 + lane;
+        const int gi = i0 + wtgt * (32 * TB) + tt * 32 + lane;
         if (!(SKIP & 4) && lane < 32 && (FULL || gi < p.N2)) {
             const long long o = ((long long)b * (2 * p.tilesS) + 2 * ts_ + wsrc) * p.N2pad + gi;
             if (kind == 0) { p.pb[o] = bv; p.pj[o] = bj; p.ps[o] = sv; }
@@ -215,8 +216,8 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
 // in registers -- the layout of the row direction with the roles swapped, reduced with the same key arithmetic.  Partials
 // are written per wave (target quarter of the tile): no cross-wave exchange.
 //   tb: this wave's 32 x 36 float buffer; bT: the tile's 256 target biases in LDS
-template <int WT>
-__device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&acc)[4][2], float (&nrm_t)[2], float (&nrm_s)[4],
+template <int NWT, int TB>            // NWT waves along the targets, each TB blocks of 32: partials per (tile row, wave)
+__device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&acc)[4][TB], float (&nrm_t)[TB], float (&nrm_s)[4],
                                                 bool do_tn, bool do_sn, int b, int i0, int j0, int tt_, float* tb,
                                                 const float* bT, int lane_, int wsrc, int wtgt) {
     const int lane = fresh_lane();
@@ -229,7 +230,9 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
         }
     }
     if (do_tn) {                                          // max_i |t_i|^2 (tiles of source tile column 0)
-        float m = fmaxf(nrm_t[0] + xhalf(nrm_t[0], hi != 0), nrm_t[1] + xhalf(nrm_t[1], hi != 0));
+        float m = 0.f;
+#pragma unroll
+        for (int x = 0; x < TB; ++x) m = fmaxf(m, nrm_t[x] + xhalf(nrm_t[x], hi != 0));
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if (lane == 0) atomicMax(p.tmax2 + b, __float_as_uint(m));
@@ -240,7 +243,7 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
         float Bk[2] = {DM_KEY_NONE, DM_KEY_NONE}, Sk[2] = {DM_KEY_NONE, DM_KEY_NONE};
         int Bt[2] = {0, 0};
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+        for (int tt = 0; tt < TB; ++tt) {
             // transpose: lane (n, hi) holds sources m = 8 q + 4 hi + e of target n  ->  tb[n][m]
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -254,7 +257,7 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
             for (int r = 0; r < 16; ++r) tr[r] = tb[((r & 3) + 8 * (r >> 2) + 4 * hi) * 36 + l31];
             f32x4 w4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const f32x4*>(bT + wtgt * 64 + tt * 32 + 4 * hi + 8 * q);
+            for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const f32x4*>(bT + wtgt * (32 * TB) + tt * 32 + 4 * hi + 8 * q);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();              // (the buffer is rewritten by the next tile: reads first)
 #pragma unroll
@@ -284,13 +287,13 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
             const int kb = __float_as_int(Bk[kind]);
             const int r_ = 15 - (kb & 15);
             float bv = __int_as_float(kb & ~15), sv = __int_as_float(__float_as_int(Sk[kind]) & ~15);
-            int bi = i0 + wtgt * 64 + Bt[kind] * 32 + (r_ & 3) + 8 * (r_ >> 2) + 4 * hi;
+            int bi = i0 + wtgt * (32 * TB) + Bt[kind] * 32 + (r_ & 3) + 8 * (r_ >> 2) + 4 * hi;
             const float ob = xhalf(bv, hi != 0);
             const int oi = xhalf(bi, hi != 0);
             const float os = xhalf(sv, hi != 0);
             top2_merge(bv, bi, sv, ob, oi, os);
             if (lane < 32) {
-                const long long o = ((long long)b * (p.tilesT * WT) + tt_ * WT + wtgt) * p.N1pad + gj;
+                const long long o = ((long long)b * (p.tilesT * NWT) + tt_ * NWT + wtgt) * p.N1pad + gj;
                 p.cb[kind][o] = bv; p.cj[kind][o] = bi; p.cs[kind][o] = sv;
             }
         }
@@ -465,16 +468,22 @@ __device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int&
     tt_ = brow0 + (brem - ts_ * brows);
 }
 
-template <int XV, int WT, int DUAL = 0>
-__global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p) {
-    static_assert(DUAL == 0 || WT == 4 || DUAL == 3, "the two-key epilogue needs one thread per row and kind");
+// TB = 32-row target blocks per wave.  TB = 2: waves of 128 source x 64 target rows (128 accumulator registers, two waves per
+// SIMD).  TB = 4 (WT = 4 only): FOUR waves of 128 x 128, 256 accumulators per lane in the AGPR half of the register file, one
+// wave per SIMD: 8 fragment reads per 16 matrix instructions instead of 6 per 8 -- a third less traffic on the LDS pipe,
+// which is what the main loop is bound by.
+template <int XV, int WT, int DUAL = 0, int TB = 2>
+__global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn_pipe_kernel(simnn_params p) {
+    static_assert(TB == 2 || (TB == 4 && WT == 4), "128 x 128 waves only for the 256-row tile");
     constexpr int TT = 64 * WT;                  // target rows per tile
-    constexpr int NW = 2 * WT;                   // waves
+    constexpr int NWT = TT / (32 * TB);          // waves along the target rows
+    constexpr int NW = 2 * NWT;                  // waves
     constexpr int NBUF = WT == 4 ? 4 : 3;        // ring depth
     constexpr int PD = NBUF - 1;                 // stages the DMA runs ahead
     constexpr int PSTAGE = (TT + ST) * PBK;      // halves per ring slot: T image then S image
-    constexpr int NSI = 16 / NW;                 // DMA instructions per wave and stage for S (T: always 2)
-    constexpr int VM_STEADY = (PD - 2) * (2 + NSI) + 1 + NSI / 2;   // loads that may stay in flight at the barrier
+    constexpr int NSI = 16 / NW;                 // DMA instructions per wave and stage for S ...
+    constexpr int NTI = TT / 16 / NW;            // ... and for T
+    constexpr int VM_STEADY = (PD - 2) * (NTI + NSI) + (NTI + NSI) / 2;   // loads that may stay in flight at the barrier
     constexpr int dbg = XV & 15;
     constexpr int STAG = (XV >> 4) & 3;
     constexpr bool PINR = (XV & 64) != 0;
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wsrc = wave & 1, wtgt = wave >> 1;
+    static_assert(NTI % 2 == 0 && NSI % 2 == 0, "the DMA of a stage is issued in two halves");
 
     // tiles of this workgroup: ids base + slot, base + slot + nslot, ... of the XCD's range [base, base + cnt)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     {                                                                                                                  \
         int b_, tt_, ts_;                                                                                              \
         simnn_decode(p, base + slot + d_tile * nslot, b_, tt_, ts_);                                                   \
-        d_T = reinterpret_cast<const char*>(p.Ftgt + ((long long)b_ * p.N2 + tt_ * TT + wave * 32) * p.ldT);           \
+        d_T = reinterpret_cast<const char*>(p.Ftgt + ((long long)b_ * p.N2 + tt_ * TT + wave * 16 * NTI) * p.ldT);     \
         d_S = reinterpret_cast<const char*>(p.Fsrc + ((long long)b_ * p.N1 + ts_ * ST + wave * 16 * NSI) * p.ldS);     \
         d_kp = (STAG == 0 || STAG == 3) ? 0 : (STAG == 1 ? (ts_ + tt_) % ns : ((ts_ + tt_) * ns / p.tilesS) % ns);                    \
         d_s = 0;                                                                                                       \
@@ -539,10 +549,13 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     // half H_ (0 / 1) of the DMA instructions of the stage stream's current stage: T piece H_, S pieces H_*NSI/2 ..
 #define SIMNN_DMA1(H_)                                                                                                 \
     if (!(dbg & 8) || d_tile == 0) {                                                                                   \
-        _Float16* dstT = smem + d_slot * PSTAGE + (wave * 32 + (H_) * 16) * PBK;                                       \
-        const char* gt = STAG == 3 ? d_T + ((long long)((H_) * 16 + (d_kp & 1) * 8) * p.ldT + (d_kp >> 1) * 64) * 2        \
-                                   : d_T + ((long long)((H_) * 16) * p.ldT + d_kp * PBK) * 2;                          \
-        __builtin_amdgcn_global_load_lds((gptr_t)(gt + (STAG == 3 ? voffT_x : voffT)), (lptr_t)dstT, 16, 0, 0);        \
+        _Pragma("unroll") for (int u = 0; u < NTI / 2; ++u) {                                                          \
+            const int piece = (H_) * (NTI / 2) + u;                                                                    \
+            _Float16* dstT = smem + d_slot * PSTAGE + (wave * 16 * NTI + piece * 16) * PBK;                            \
+            const char* gt = STAG == 3 ? d_T + ((long long)(piece * 16 + (d_kp & 1) * 8) * p.ldT + (d_kp >> 1) * 64) * 2    \
+                                       : d_T + ((long long)(piece * 16) * p.ldT + d_kp * PBK) * 2;                     \
+            __builtin_amdgcn_global_load_lds((gptr_t)(gt + (STAG == 3 ? voffT_x : voffT)), (lptr_t)dstT, 16, 0, 0);    \
+        }                                                                                                              \
         _Pragma("unroll") for (int u = 0; u < NSI / 2; ++u) {                                                          \
             const int piece = (H_) * (NSI / 2) + u;                                                                    \
             _Float16* dstS = smem + d_slot * PSTAGE + (TT + wave * 16 * NSI + piece * 16) * PBK;                       \
@@ -565,12 +578,15 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     const int c0 = (lane >> 5) ^ swz;
     const int frow = (lane & 31) * PBK;
     const int foff0 = frow + (c0 << 3), foff1 = frow + ((c0 ^ 2) << 3);
-    const int sbase = TT * PBK + wsrc * 128 * PBK, tbase = wtgt * 64 * PBK;
+    const int sbase = TT * PBK + wsrc * 128 * PBK, tbase = wtgt * (32 * TB) * PBK;
 
     SIMNN_DMA_TILE()
 #pragma unroll
     for (int q = 0; q < PD; ++q) { SIMNN_DMA1(0) SIMNN_DMA1(1) SIMNN_DMA_NEXT() }
-    __builtin_amdgcn_s_waitcnt(0x0F70 | ((PD - 1) * (2 + NSI)));     // vmcnt: stage 0 has landed; the others in flight
+    {                                                                // vmcnt: stage 0 has landed; the others in flight
+        constexpr int n0 = (PD - 1) * (NTI + NSI);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (n0 & 15) | (((n0 >> 4) & 3) << 14));
+    }
     __builtin_amdgcn_s_barrier();
 
     // The stage loop is rotated by half a stage: the barrier that publishes stage g+1 sits between the two k-steps of
@@ -580,14 +596,14 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
     // vmcnt before the barrier of iteration g: stage g+1 must have landed; younger are the stages g+2 .. g+PD-1 and the
     // first half of stage g+PD, fewer at the very end of the walk.  Stores of an epilogue in between only make the
     // count conservative (it bounds loads + stores in flight).
-    f16x8 fsa[4], fta[2], fsb[4], ftb[2], ftn[2];
+    f16x8 fsa[4], fta[TB], fsb[4], ftb[TB], ftn[TB];
     f32x16 zero16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     constexpr bool NOEPI = (dbg & 7) == 1 || (dbg & 7) == 7;
     // stores EVERY wave issues in an epilogue: its row partials (2 target blocks x 3 arrays per key set) and, both directions,
     // its column partials (4 source blocks x 2 key sets x 3 arrays)
-    constexpr int EPI_ST = (DUAL ? 12 : 6) + (DUAL == 3 ? 24 : 0);
+    constexpr int EPI_ST = (DUAL ? 2 : 1) * 3 * TB + (DUAL == 3 ? 24 : 0);
     int r_slot = 0;                               // ring slot of the stage being computed
     const bool late = FLIP && wave >= NW / 2;
 #define SIMNN_READ(fs_, ft_, slot_, fo_)                                                                               \
@@ -595,17 +611,17 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         const _Float16* Bs = smem + (slot_) * PSTAGE;                                                                  \
         _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                                  \
             fs_[x] = *reinterpret_cast<const f16x8*>(Bs + sbase + x * 32 * PBK + (fo_));                               \
-        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                                  \
+        _Pragma("unroll") for (int x = 0; x < TB; ++x)                                                                 \
             ft_[x] = *reinterpret_cast<const f16x8*>(Bs + tbase + x * 32 * PBK + (fo_));                               \
     }
 #define SIMNN_MMA(fs_, ft_, NORMS, ZERO_)                                                                              \
     if ((dbg & 7) != 7) {                                                                                              \
         if (NORMS) {                                                                                                   \
-            if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ft_[x], nrm_t[x]); }          \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(ft_[x], nrm_t[x]); }         \
             if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs_[x], nrm_s[x]); }          \
         }                                                                                                              \
         _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
-            _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                           \
+            _Pragma("unroll") for (int tt = 0; tt < TB; ++tt)                                                          \
                 acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], (ZERO_) ? zero16 : acc[st][tt], 0, 0, 0); \
     }
 #define SIMNN_SYNC(n_, AFTER_EPI_)                                                                                     \
@@ -643,13 +659,13 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         if (DMA_) { SIMNN_DMA1(0) }                                                                                    \
         SIMNN_PIN()                                                                                                    \
         if (NORMS) {   /* |row|^2 of the rows the products stand for: (h, h, l) resp. (h, l, h) */                     \
-            if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(fta[x], sumsq8(fta[x], nrm_t[x])); } \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(fta[x], sumsq8(fta[x], nrm_t[x])); } \
             if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsa[x], sumsq8(fsa[x], nrm_s[x])); } \
         }                                                                                                              \
         SIMNN_MMA(fsa, fta, false, ZERO_)                                                                              \
         SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
         if (NORMS) {                                                                                                   \
-            if (do_tn) { _Pragma("unroll") for (int x = 0; x < 2; ++x) nrm_t[x] = sumsq8(ftb[x], nrm_t[x]); }          \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(ftb[x], nrm_t[x]); }         \
             if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsb[x], nrm_s[x]); }          \
         }                                                                                                              \
         SIMNN_MMA(fsa, ftb, false, false)                                                                              \
@@ -657,14 +673,14 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
             const _Float16* Bn = smem + n_slot * PSTAGE;                                                               \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                              \
                 fsa[x] = *reinterpret_cast<const f16x8*>(Bn + sbase + x * 32 * PBK + foff0);                           \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                              \
+            _Pragma("unroll") for (int x = 0; x < TB; ++x)                                                             \
                 ftn[x] = *reinterpret_cast<const f16x8*>(Bn + tbase + x * 32 * PBK + foff0);                           \
         }                                                                                                              \
         if (DMA_) { SIMNN_DMA1(1) }                                                                                    \
         SIMNN_PIN()                                                                                                    \
         SIMNN_MMA(fsb, fta, false, false)                                                                              \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
-        if (NEXT_) { fta[0] = ftn[0]; fta[1] = ftn[1]; }                                                               \
+        if (NEXT_) { _Pragma("unroll") for (int x = 0; x < TB; ++x) fta[x] = ftn[x]; }                                 \
         }                                                                                                              \
         r_slot = n_slot;                                                                                               \
         if (DMA_) SIMNN_DMA_NEXT()                                                                                     \
@@ -680,7 +696,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         if (PD == 3) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, true)                                                  \
         for (int s = PD - 1; s < nsteady; ++s) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, false)                       \
         if (n + 1 == ntile) {                                                                                          \
-            if (PD == 3) SIMNN_STAGE(NORMS, 0, 2 + NSI, 1, false, false)                                               \
+            if (PD == 3) SIMNN_STAGE(NORMS, 0, NTI + NSI, 1, false, false)                                             \
             SIMNN_STAGE(NORMS, 0, 0, 1, false, false)                                                                  \
             SIMNN_STAGE(NORMS, 0, 0, 0, false, false)                                                                  \
         }                                                                                                              \
@@ -696,14 +712,16 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
         // the last stage die there and are read again here.
         if (DEFER_READ && n > 0) { SIMNN_READ(fsa, fta, r_slot, foff0) }
         const int i0 = tt_ * TT, j0 = ts_ * ST;
-        f32x16 acc[4][2];
+        f32x16 acc[4][TB];
         // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that own
         // the first tile of the other operand (every row of T / S is seen exactly once that way).  Those tiles run a
         // second copy of the loop, so the hot copy has no conditional inside a k-step.
         constexpr bool want_n = (dbg & 7) != 3 && (dbg & 7) != 7;
         const bool do_tn = (ts_ == 0) && (wsrc == 0) && want_n;
         const bool do_sn = (tt_ == 0) && (wtgt == 0) && want_n;
-        float nrm_t[2] = {0.f, 0.f}, nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
+        float nrm_t[TB], nrm_s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < TB; ++x) nrm_t[x] = 0.f;
 
         if ((ts_ == 0 || tt_ == 0) && want_n) { SIMNN_TILE_LOOP(true) } else { SIMNN_TILE_LOOP(false) }
 
@@ -712,7 +730,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < TB; ++c)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sacc += acc[a][c][r];
             if (sacc == 1.2345f) p.pb[0] = sacc;
@@ -725,7 +743,7 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
             if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
         } else
 #endif
-        simnn_tail<true, TT, ((dbg & 7) == 4 || (dbg & 7) == 6) ? 4 : 0, (DUAL == 3 ? 1 : DUAL)>(
+        simnn_tail<true, TT, ((dbg & 7) == 4 || (dbg & 7) == 6) ? 4 : 0, (DUAL == 3 ? 1 : DUAL), TB>(
             p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, lane, wsrc, wtgt, bias_lds + (n & 1) * BSLOT);
 #ifdef DM_EXPERIMENTS
         if (DUAL == 3 && (p.dbg & 0x2000)) {             // ablation (wrong results): no column-direction reduction
@@ -734,8 +752,8 @@ __global__ __launch_bounds__(128 * WT, 2) void simnn_pipe_kernel(simnn_params p)
 #endif
         if (DUAL == 3) {
             // transposes go through the free slot (8 waves: seven of them, the eighth has its own buffer)
-            float* tb = (WT == 4 && wave == 7) ? tb_extra : free_slot + wave * (32 * 36);
-            simnn_tail_cols<WT>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, tt_, tb, bias_lds + (n & 1) * BSLOT + 512, lane, wsrc, wtgt);
+            float* tb = (NW == 8 && wave == 7) ? tb_extra : free_slot + wave * (32 * 36);
+            simnn_tail_cols<NWT, TB>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, tt_, tb, bias_lds + (n & 1) * BSLOT + 512, lane, wsrc, wtgt);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave is done with its buffer ...
             __builtin_amdgcn_s_barrier();                // ... and no wave starts the next tile's DMA into the slot before all are
@@ -990,8 +1008,14 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     // DM_EXPERIMENTS: DM_SIMNN_DEBUG = variant bits XV (simnn_pipe_kernel) + 256 / 512 for the 8-wave / 4-wave shape
     // (both directions: the 8-wave shape; p2p_split = 3 selects 4 waves x 2 workgroups per CU, whose second workgroup covers
     // part of the epilogue but whose 1.5x operand traffic costs as much: config 2 1.737 vs 1.729 ms, config 5 20.0 vs 19.2 ms)
-    const int WT = cols ? (ctx->opt_p2p_split == 3 ? 2 : 4) : (dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT)));
+    // both directions: the 4-wave shape (two workgroups per CU: one's epilogue runs under the other's main loop, at 1.5x the operand
+    // traffic) wins while a pair's operands stay in an XCD's L2 (-5 % at N = 2048, +2.5 % at N = 8192); p2p_split = 3 / 4 force
+    // the 4-wave / 8-wave shape
+    const bool ops_in_l2 = ((size_t)N2 * ldT + (size_t)N1 * ldS) * 2 <= ((size_t)3 << 20);
+    const int WT = cols ? ((ctx->opt_p2p_split == 3 || (ctx->opt_p2p_split == 2 && ops_in_l2 && !ctx->opt_simnn_big)) ? 2 : 4)
+                        : (dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT)));
     // (the stage loop peels its first and last stages: the contraction must be at least ring depth + 1 stages deep)
+    const int TB = (WT == 4 && ctx->opt_simnn_big) ? 4 : 2;          // 32-row target blocks per wave
     if (interior && ctx->opt_simnn_pipe && D % PBK == 0 && D >= (WT == 4 ? 5 : 4) * PBK) {
         const int TT = 64 * WT;
         p.tilesT = p.N2pad / TT;
@@ -1012,7 +1036,18 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<XV_, WT_, DUAL_>), dim3(grid), dim3(128 * WT_), lds_pipe, p);     \
         }
-        if (cols) {
+#define SIMNN_LAUNCH_BIG(DUAL_, NAME_)                                                                                 \
+        {                                                                                                              \
+            rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<SIMNN_PRODUCT_XV, 4, DUAL_, 4>, lds_pipe);           \
+            if (rc) return rc;                                                                                         \
+            DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<SIMNN_PRODUCT_XV, 4, DUAL_, 4>), dim3(grid), dim3(256), lds_pipe, p); \
+        }
+        if (TB == 4) {
+            if (cols) SIMNN_LAUNCH_BIG(3, "simnn4_f16_mfma")
+            else if (dual && dual->scale) SIMNN_LAUNCH_BIG(1, "simnn2_f16_mfma")
+            else if (dual) SIMNN_LAUNCH_BIG(2, "simnn2_f16_mfma")
+            else SIMNN_LAUNCH_BIG(0, "simnn_f16_mfma")
+        } else if (cols) {
             if (WT == 4) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 3, "simnn4_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 2, 3, "simnn4_f16_mfma")
         } else if (dual) {
@@ -1036,6 +1071,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma")
 #endif
         }
+#undef SIMNN_LAUNCH_BIG
 #undef SIMNN_LAUNCH_XV
     } else {
         int rc = dm_grant_lds(ctx, (const void*)simnn_edge_kernel, lds_edge);
@@ -1062,7 +1098,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
                                           nullptr, dual->nn_b, flag_count2, flag_list2, flag_thr2, nullptr, nullptr};
     if (cols) {
         // the column direction: "targets" are the source rows, partials per (tile row, target quarter), bound from |s_j| max |t_i|
-        const int cparts = p.N2pad / 64;
+        const int cparts = p.N2pad / (32 * TB);          // one partial per wave along the targets
         sets.s[nsets++] = simnn_merge_set{p.cb[0], p.cj[0], p.cs[0], cparts, N1, p.N1pad, p.snorm2, p.tmax2, cols->tau_add, nullptr,
                                           nullptr, cols->nn_a, cflag_count[0], cflag_list[0], cflag_thr[0], nullptr, nullptr};
         sets.s[nsets++] = simnn_merge_set{p.cb[1], p.cj[1], p.cs[1], cparts, N1, p.N1pad, p.snorm2, p.tmax2, nullptr, nullptr,
@@ -1073,8 +1109,8 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     *q = dm_simnn_queue{p.pb, p.pj, p.ps, nparts, 128, p.N2pad, flag_count, flag_list, flag_thr};
     if (dual) *dual->q_b = dm_simnn_queue{p.pb_2, p.pj_2, p.ps_2, nparts, 128, p.N2pad, flag_count2, flag_list2, flag_thr2};
     if (cols) {
-        *cols->q_a = dm_simnn_queue{p.cb[0], p.cj[0], p.cs[0], p.N2pad / 64, 64, p.N1pad, cflag_count[0], cflag_list[0], cflag_thr[0]};
-        *cols->q_b = dm_simnn_queue{p.cb[1], p.cj[1], p.cs[1], p.N2pad / 64, 64, p.N1pad, cflag_count[1], cflag_list[1], cflag_thr[1]};
+        *cols->q_a = dm_simnn_queue{p.cb[0], p.cj[0], p.cs[0], p.N2pad / (32 * TB), 32 * TB, p.N1pad, cflag_count[0], cflag_list[0], cflag_thr[0]};
+        *cols->q_b = dm_simnn_queue{p.cb[1], p.cj[1], p.cs[1], p.N2pad / (32 * TB), 32 * TB, p.N1pad, cflag_count[1], cflag_list[1], cflag_thr[1]};
     }
     return DM_OK;
 }

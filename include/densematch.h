@@ -68,11 +68,13 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *   "simnn_pipe"    1 | 0   feature-similarity tiles: LDS-DMA ring kernel | bounds-checked register-staged kernel
  *   "simnn_persist" 1 | 0 | n>1   one persistent workgroup per CU walking its tiles | one workgroup per tile | exactly n workgroups
  *   "knn_split"     1 | 0   knn21 of dm_zoomout / dm_icp / dm_knn_query_f64: fp16-split first pass | float64 G kernel
- *   "p2p_split" 2 | 3 | 1 | 0 dm_fm_to_p2p: one fp16 pass reducing in both directions (8 waves, 256 x 256 tiles) | the same with
- *                           4 waves, 128 x 256 tiles, two workgroups per CU | two two-key passes | float64 G kernel
+ *   "p2p_split" 2 | 3 | 4 | 1 | 0 dm_fm_to_p2p: one fp16 pass reducing in both directions, tile shape by size (4 waves, 128 x 256
+ *                           tiles, two workgroups per CU while a pair's operands fit an XCD's L2, else 8 waves, 256 x 256) |
+ *                           always the 4-wave shape | always the 8-wave shape | two two-key passes | float64 G kernel
  *                           (all + exact float64 re-evaluation of the ambiguous rows; identical results)
  *   "solve_packed"  0 | 1   dm_fmap_solve: blocked LDS Cholesky when it fits | packed-storage solver always
  *   "simnn_band"    4 | n   tile order of the similarity kernels: bands of n tile rows, column-major inside (0: row-major)
+ *   "simnn_big"     0 | 1   tile kernels as four waves of 128 x 128 (accumulators in AGPRs) instead of eight waves of 128 x 64
  *   "lsa_reg"       2 | 1 | 0   dm_linear_sum_assignment: column state in registers, started from a column reduction (kept per
  *                           matrix only when its optimum is provably unique, else redone) | the same in SciPy's order | LDS state
  *   "solve_reg"     1 | 0   dm_fmap_solve, k1 <= 129: register-resident solver (one wave per system) | the LDS-resident blocked one

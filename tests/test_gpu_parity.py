@@ -208,13 +208,14 @@ def test_refine_ragged(eng, N1, N2, k0, nit, step):
 # --------------------------------------------------------------------------- #
 @pytest.mark.parametrize("B,N2,N1,D", [(1, 128, 128, 64), (2, 300, 517, 96), (3, 1000, 777, 384), (1, 2048, 2048, 768),
                                        (2, 256, 512, 96), (2, 512, 256, 64), (1, 768, 512, 160), (1, 512, 512, 136), (3, 512, 768, 128), (5, 256, 256, 96)])
-@pytest.mark.parametrize("pipe", ["persist", "pertile", "edge"])
+@pytest.mark.parametrize("pipe", ["persist", "pertile", "edge", "big"])
 def test_simnn_random(eng, B, N2, N1, D, pipe):
     # interior shapes (N % 256 == 0) take the ring-buffered LDS-DMA kernel when D % 32 == 0 and D >= 96 (one persistent
     # workgroup per CU when there are more tiles than CUs, else -- or with simnn_persist = 0 -- one workgroup per tile);
     # everything else, and everything with simnn_pipe = 0, the bounds-checked register-staged kernel
     eng.set_option("simnn_pipe", 0 if pipe == "edge" else 1)
     eng.set_option("simnn_persist", 8 if pipe == "persist" else 0)      # 8 workgroups walk all the tiles
+    eng.set_option("simnn_big", 1 if pipe == "big" else 0)              # four waves of 128 x 128 instead of eight of 128 x 64
     rng = np.random.default_rng(B * 1000 + N2)
     S = rng.standard_normal((B, N1, D)).astype(np.float16)
     T = rng.standard_normal((B, N2, D)).astype(np.float16)
@@ -500,18 +501,22 @@ def test_fm_to_p2p_split_equals_f64_kernel(eng, kind):
         Phi1, Phi2, a1, C = _split_case(rng, B, N1, N2, k1, k2, kind)
         assert eng.p2p_split_active(N2, N1, k2)
         res = {}
-        for split in (3, 2, 1, 0):      # 3 / 2: one pass in both directions (4-wave / 8-wave shape); 1: two passes; 0: float64 kernel
+        for split in (4, 3, 2, 1, 0):   # 2: one pass in both directions (shape by size), 3 / 4: its 4-wave / 8-wave shape; 1: two passes; 0: float64 kernel
             eng.set_option("p2p_split", split)
             res[split] = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
         # the one-pass kernel launched one workgroup per tile / with an odd number of persistent workgroups (tile walks of
         # different lengths, bias slots of both parities)
         for tag, persist in (("pertile", 0), ("odd", 37)):
-            eng.set_option("p2p_split", 2)
+            eng.set_option("p2p_split", 4)
             eng.set_option("simnn_persist", persist)
             res[tag] = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
         eng.reset_options()
+        # four waves of 128 x 128 (accumulators in AGPRs) instead of eight of 128 x 64
+        eng.set_option("simnn_big", 1)
+        res["big"] = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
+        eng.reset_options()
         for name in ("knn21", "knn12", "ind21", "ind12"):
-            for split in (1, 2, 3, "pertile", "odd"):
+            for split in (1, 2, 3, 4, "pertile", "odd", "big"):
                 bad = int((res[split][name] != res[0][name]).sum())
                 assert bad == 0, (kind, name, split, bad, (B, N1, N2, k1, k2))
         # ... and against the oracle, every kind, EXACTLY: a different entry is accepted only where the two candidates score
