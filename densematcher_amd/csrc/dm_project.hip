@@ -21,10 +21,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 constexpr int PT = 128;      // output tile: PT basis functions x PTD descriptor channels.  The fp32 -> hi/lo split of the
-constexpr int PTD = 256;     // basis slab is VALU work repeated by every d-tile of a (pair, chunk): wide d-tiles amortise it
+constexpr int PTD = 192;     // basis slab is VALU work repeated by every d-tile of a (pair, chunk): wide d-tiles amortise it;
+                             // 192 (not 256): D = 768 gives 4 d-tiles x 2 chunks x 64 pairs = 512 workgroups = every slot of
+                             // the chip (two per CU) in ONE round; 256-wide tiles filled 384 of the 512 slots
+constexpr int PNT = PTD / 64;   // 32-channel accumulator blocks per wave (the two waves along d own PTD / 2 channels each)
+constexpr int PFV = PTD / 64;   // 16-byte vectors of descriptor channels a staging thread moves (PTD / 8 channels)
 constexpr int PBK = 32;      // vertices per stage
 constexpr int PLD = 160;     // LDS row stride in halves (320 B): rows land 16 banks apart -> conflict-free tr reads
-constexpr int PLDF = 288;    // same property for the 256-wide descriptor rows (576 B = 144 dwords = 16 mod 64)
+constexpr int PLDF = 224;    // same property for the 192-wide descriptor rows (448 B = 112 dwords = 48 mod 64)
 constexpr int PSTAGE = 2 * PBK * PLD + PBK * PLDF;   // halves per stage buffer: Xhi | Xlo | F
 
 template <int LD>
@@ -124,7 +128,7 @@ struct proj_params {
 
 template <typename TR>
 __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];               // [2 buffers][Xhi | Xlo | F], 76 KiB
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];               // [2 buffers][Xhi | Xlo | F], 68 KiB
     // 1-D grid, XCD-aware: the d-tiles that share one (pair, vertex chunk) slab of the basis are neighbours in the
     // logical order and therefore meet in the same XCD's L2 (otherwise every tile re-fetches the slab from HBM)
     const int ntile = p.tiles_m * p.tiles_d;
@@ -149,22 +153,22 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p
     const TR* mass = p.mass + (long long)b * p.N;
     const _Float16* F = p.F + (long long)b * p.N * p.D;
 
-    f32x16 acc[2][4];                                        // wave tile 64 (m) x 128 (d)
+    f32x16 acc[2][PNT];                                      // wave tile 64 (m) x PTD / 2 (d)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < PNT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
     const int srow = t >> 3, scol = (t & 7) * 16;            // staging: row of the stage, 16 consecutive basis columns
-    const int fcol = (t & 7) * 32;                           //          and 32 consecutive descriptor channels
+    const int fcol = (t & 7) * (PTD / 8);                    //          and PTD / 8 consecutive descriptor channels
     const bool xvec = ((p.ld & (sizeof(TR) == 4 ? 3 : 1)) == 0) && ((((uintptr_t)p.Phi) & 15) == 0);
     const bool fvec = ((p.D & 7) == 0) && ((((uintptr_t)p.F) & 15) == 0);
     // staged exactly as loaded: the mass scaling and the hi / lo split happen in PROJ_STASH, one stage later (arithmetic on
     // the loaded values inside PROJ_FETCH would make every fetch wait for its own data)
     TR xr[16], an_raw = (TR)0;
-    u32x4 fr[4];
+    u32x4 fr[PFV];
     typedef __attribute__((address_space(1))) const f32x4 gf32x4;
     typedef __attribute__((address_space(1))) const u32x4 gu32x4;
     typedef __attribute__((address_space(1))) const TR gfloat;
@@ -192,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p
                 xr[q] = (rv && m0 + scol + q < p.k) ? xrow[q] : (TR)0;                                        \
         }                                                                                                     \
         const _Float16* frow = F + (long long)n_ * p.D + d0 + fcol;                                           \
-        if (rv && fvec && d0 + fcol + 31 < p.D) {                                                             \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) fr[q] = *(gu32x4*)(frow + 8 * q);                   \
+        if (rv && fvec && d0 + fcol + PTD / 8 - 1 < p.D) {                                                    \
+            _Pragma("unroll") for (int q = 0; q < PFV; ++q) fr[q] = *(gu32x4*)(frow + 8 * q);                 \
         } else {                                                                                              \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+            _Pragma("unroll") for (int q = 0; q < PFV; ++q) {                                                 \
                 f16x8 tmp;                                                                                    \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                 \
                     tmp[e] = (rv && d0 + fcol + 8 * q + e < p.D) ? frow[8 * q + e] : (_Float16)0.f;           \
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p
         }                                                                                                     \
         *reinterpret_cast<f16x8*>(Xh) = h[0]; *reinterpret_cast<f16x8*>(Xh + 8) = h[1];                       \
         *reinterpret_cast<f16x8*>(Xl) = l[0]; *reinterpret_cast<f16x8*>(Xl + 8) = l[1];                       \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(Fs + 8 * q) = fr[q];          \
+        _Pragma("unroll") for (int q = 0; q < PFV; ++q) *reinterpret_cast<u32x4*>(Fs + 8 * q) = fr[q];        \
     }
 
     const int ns = (nend - nbeg + PBK - 1) / PBK;
@@ -241,18 +245,18 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p
         for (int ks = 0; ks < PBK / 16; ++ks) {
             const int row0 = ks * 16 + 8 * (lane >> 5);
             const int sub = 16 * ((lane >> 4) & 1) + (lane & 15) - (lane & 15);   // 16-column half of the 32-wide tile
-            f16x8 ah[2], al[2], bf[4];
+            f16x8 ah[2], al[2], bf[PNT];
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 ah[x] = tr_frag<PLD>(Xh, row0, wm * 64 + x * 32 + sub, lane);
                 al[x] = tr_frag<PLD>(Xl, row0, wm * 64 + x * 32 + sub, lane);
             }
 #pragma unroll
-            for (int x = 0; x < 4; ++x) bf[x] = tr_frag<PLDF>(Fs, row0, wn * 128 + x * 32 + sub, lane);
+            for (int x = 0; x < PNT; ++x) bf[x] = tr_frag<PLDF>(Fs, row0, wn * (PTD / 2) + x * 32 + sub, lane);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < PNT; ++nt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bf[nt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bf[nt], acc[mt][nt], 0, 0, 0);
                 }
@@ -269,11 +273,11 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < PNT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int d = d0 + wn * 128 + nt * 32 + (lane & 31);
+                const int d = d0 + wn * (PTD / 2) + nt * 32 + (lane & 31);
                 if (m < p.k && d < p.D) out[(long long)m * p.D + d] = acc[mt][nt][r] * inv_scale;
             }
 }
