@@ -188,9 +188,11 @@ struct dm_simnn_dual {
     int32_t* nn_b;                    // (B, N2) arg-max of key B
     dm_simnn_queue* q_b;              // its queue of ambiguous rows
     const dm_simnn_cols* cols = nullptr;
+    bool padded = false;              // Ftgt / Fsrc hold pad256(N2) / pad256(N1) rows per pair (zero rows behind the real ones) and
+                                      // bias / scale / biasT the same number of entries: any N2, N1 (edge tiles mask the padding)
 };
 size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual = 0);
-bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D);
+bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D, bool padded = false);
 int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, int ldT, const _Float16* Fsrc, int ldS,
                   float rel_extra,
                   const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q,

@@ -8,9 +8,10 @@
 //     so that one fp16 inner product (exact products, fp32 accumulation) is
 //         sx sy (<x_i, y_j> - n1_j / 2) - <xl, yl> - split residuals
 //     and the arg-max of it over j is the wanted arg-min up to a bounded error.  The tile kernel, the top-2 bookkeeping
-//     and the 32-source block maxima are those of dm_simnn_f16 (dm_simnn_core).
+//     and the per-wave top-2 partials are those of dm_simnn_f16 (dm_simnn_core).
 //  2. every row whose (best - second) is inside twice the error bound is re-evaluated exactly: float64 products of
-//     the original operands, only over the 32-source blocks whose fp32 maximum can still win, lowest index on ties.
+//     the original operands, only over the 32-source blocks that the partials cannot rule out (dm_simnn_keep), lowest
+//     index on ties.
 //     Bound, relative to |t_i| max_j |s_j| (>= |x~_i| |y~_j|): fp32 accumulation D (1 + 1/16) 2^-23 (dm_simnn_core)
 //     + for the split: dropped <xl, yl> <= 2^-22, two residuals <= 2^-22 each, fp16 subnormal floor <= 2 sqrt(K) 2^-25
 //     (computed from the depth K of the search, 25 % slack; about 2^-19 at K = 200), bias pieces 2^-32.
@@ -65,7 +66,8 @@ template <bool SRC>
 __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict__ M, const double* __restrict__ n1,
                                                        const double* __restrict__ amaxT, const double* __restrict__ amaxS, int nS,
                                                        int K, int N, int Npad, int Kpad, int ld, int fill, int head,
-                                                       _Float16* __restrict__ F, int32_t* __restrict__ overflow, int paired, int nT) {
+                                                       _Float16* __restrict__ F, int32_t* __restrict__ overflow, int paired, int nT,
+                                                       int rows_out) {        // rows per pair of F (>= N: padded outputs)
     extern __shared__ __attribute__((aligned(16))) _Float16 ks_img[];       // 64 rows x (fill + 8) halves
     const int ldl = fill + 8;
     const int b = blockIdx.y, v0 = blockIdx.x * 64;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
     const int nrow = min(64, N - v0);
     for (int c = threadIdx.x; c < nrow * cpr; c += 256) {
         const int r = c / cpr, q = c - r * cpr;
-        *reinterpret_cast<f16x8*>(F + ((long long)b * N + v0 + r) * ld + 8 * q) = *reinterpret_cast<const f16x8*>(ks_img + r * ldl + 8 * q);
+        *reinterpret_cast<f16x8*>(F + ((long long)b * rows_out + v0 + r) * ld + 8 * q) = *reinterpret_cast<const f16x8*>(ks_img + r * ldl + 8 * q);
     }
 }
 
@@ -306,7 +308,7 @@ int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 64), B), dim3(256), ks_build_lds(st->ldT), AT,
               (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, KS_BIAS, st->Ft,
-              (int32_t*)nullptr, 0, KS_NCH);
+              (int32_t*)nullptr, 0, KS_NCH, N2);
     return DM_OK;
 }
 
@@ -323,7 +325,7 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 64), a.B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow, 0, KS_NCH);
+              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow, 0, KS_NCH, a.N1);
     dm_simnn_queue q;
     // error of the split on top of the fp32 accumulation, relative to |t_i| max_j |s_j|: the dropped <xl, yl> and the two
     // residuals (3 * 2^-22), the fp16 subnormal floor (2 sqrt(K) 2^-25), 25 % slack; 2^-19 at K = 200
@@ -337,17 +339,21 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 }
 
 // ---- all four maps of dm_fm_to_p2p on the fp16 matrix cores ---------------------------------------------------------
-// Two passes of the two-key tile kernel over the split operands X = Phi2 rows (h, h, l) and Y = emb1 rows (h, l, h)
-// (no bias slots: 3 K halves per row, the fp16 inner product is sx sy <x_i, y_j> up to the split error):
-//   pass A, targets X, sources Y:   key A = s - n1_j sx sy / 2  -> knn21,   key B = s a1_j -> ind21
-//   pass B, targets Y, sources X:   key A = s - n2_i sx sy / 2  -> knn12,   key B = s      -> ind12   (a1_j > 0 is a
-//                                   per-target factor; targets with a1_j == 0 score 0 everywhere: index 0, like np.argmax)
+// The operands X = Phi2 rows and Y = emb1 rows are scaled by powers of two (sx, sy) and stored as SPLIT rows: per 16
+// contraction indices [16 high fp16 halves | 16 low halves]; the tile kernel forms hx.hy + hx.ly + lx.hy from them (three
+// k-steps per 32-halves stage), i.e. sx sy <x_i, y_j> up to the split error.  ONE pass, targets X, sources Y, reduces every
+// tile in both directions (p2p_split >= 2; p2p_split = 1: two passes of the two-key kernel with the operands swapped):
+//   along the sources j:  key A  = s - n1_j sx sy / 2 -> knn21,   key B  = s a1_j -> ind21
+//   along the targets i:  key A' = s - n2_i sx sy / 2 -> knn12,   key B' = s      -> ind12   (a1_j > 0 is a per-column factor;
+//                                                  columns with a1_j == 0 score 0 everywhere: index 0, like np.argmax)
 // then the ambiguous rows of each of the four reductions are re-evaluated exactly (ks_exact_kernel) with the reference's
-// own float64 expressions.  Needs interior 256-tiles and 3 K >= 160 (dm_fm_split_ok); otherwise the float64 G kernel.
+// own float64 expressions -- emb1 from its K-major float64 copy, Phi2 from the caller's row-major array.
+// Needs interior 256-tiles and K >= 65 (five stages of 16 indices: dm_fm_split_ok); otherwise the float64 G kernel.
 // (mass, when given: also its fp32 rounding scale32, the per-source factor of the tile kernel's key B -- the rounding is
 //  part of the key's error bound, dm_simnn_core -- and the maximum of the ROUNDED values)
 struct fs_bias_set {
     const double* nrm; int N, Npad; const double* mass; float* bias; unsigned int* bmax; unsigned int* mmax; float* scale32;
+    int rows_out;                                            // entries per pair of bias / scale32 (>= N: padded to whole tiles)
 };
 __global__ __launch_bounds__(256) void fs_bias_kernel(fs_bias_set s0, fs_bias_set s1, const double* __restrict__ amaxT, int nT,
                                                       const double* __restrict__ amaxS, int nS) {
@@ -359,11 +365,11 @@ __global__ __launch_bounds__(256) void fs_bias_kernel(fs_bias_set s0, fs_bias_se
     float bb = 0.f, mm = 0.f;
     if (j < s.N) {
         const float v = (float)(-0.5 * s.nrm[(long long)b * s.Npad + j] * sxy);
-        s.bias[(long long)b * s.N + j] = v;
+        s.bias[(long long)b * s.rows_out + j] = v;
         bb = fabsf(v);
         if (s.mass) {
             const float m32 = (float)s.mass[(long long)b * s.N + j];
-            s.scale32[(long long)b * s.N + j] = m32;
+            s.scale32[(long long)b * s.rows_out + j] = m32;
             mm = fabsf(m32);
         }
     }
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void fs_zero_mass_kernel(const double* __restr
 // the same numbers
 template <typename TR>
 __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict__ Phi, int N, int K, int ld, const double* __restrict__ amaxT,
-                                                            int nT, int D, _Float16* __restrict__ F) {
+                                                            int nT, int D, _Float16* __restrict__ F, int rows_out) {
     const int b = blockIdx.y;
     const int ngrp = D / 16;                                    // groups of 8 indices (D = 32 ceil(K / 16))
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
     //  the float64 split; fp64 basis: the split itself runs in float64, split2)
     const double sx = ks_scale(amaxT + b * nT, nT);
     const TR* src = Phi + ((long long)b * N + v) * ld + 8 * q;
-    _Float16* dst = F + ((long long)b * N + v) * D + 32 * (q >> 1) + 8 * (q & 1);
+    _Float16* dst = F + ((long long)b * rows_out + v) * D + 32 * (q >> 1) + 8 * (q & 1);
     TR xin[8];
     constexpr int amask = sizeof(TR) == 4 ? 3 : 1;
     if (8 * q + 8 <= K && ((ld & amask) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {   // 16-byte loads
@@ -437,12 +443,12 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
 static inline int fs_depth(int K) { return 32 * ((K + 15) / 16); }    // halves per split row
 size_t dm_fm_split_zero_bytes(int B) { return 3 * dm_align_up((size_t)B * 4); }
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K) {
-    return ctx->opt_p2p_split != 0 && dm_simnn_dual_ok(ctx, N2, N1, fs_depth(K)) && N1 % 256 == 0 && N2 % 256 == 0;
+    return ctx->opt_p2p_split != 0 && dm_simnn_dual_ok(ctx, N2, N1, fs_depth(K), true) && N1 >= 256 && N2 >= 256;
 }
 size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K) {
-    const size_t D = fs_depth(K);
-    return dm_align_up((size_t)B * N2 * D * 2) + dm_align_up((size_t)B * N1 * D * 2) +
-           2 * dm_align_up((size_t)B * N1 * 4) + dm_align_up((size_t)B * N2 * 4) +
+    const size_t D = fs_depth(K), R2 = pad_to(N2, 256), R1 = pad_to(N1, 256);
+    return dm_align_up((size_t)B * R2 * D * 2) + dm_align_up((size_t)B * R1 * D * 2) +
+           2 * dm_align_up((size_t)B * R1 * 4) + dm_align_up((size_t)B * R2 * 4) +
            dm_simnn_ws_bytes(B, N2, N1, 3) + dm_simnn_ws_bytes(B, N1, N2, 1) + 16384;
 }
 // a: AT, BT (K-major f64), n1, n2, mass1 and all four outputs; amaxS: per-256-column maxima of |BT| (colnorm_kernel);
@@ -455,27 +461,37 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     if (!a.BT || !a.n1 || !a.n2 || !a.mass1 || !a.knn21 || !a.knn12 || !a.ind21 || !a.ind12 || !amaxS || !amaxT || !zeroed || !Phi2)
         return dm_fail(ctx, DM_EINVAL, "fm_split: missing operand");
     const int D = fs_depth(K);
-    _Float16* Fx = (_Float16*)dm_ws_take(ctx, (size_t)B * N2 * D * 2);
-    _Float16* Fy = (_Float16*)dm_ws_take(ctx, (size_t)B * N1 * D * 2);
-    float* biasA = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);
-    float* biasB = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
-    float* scale32 = (float*)dm_ws_take(ctx, (size_t)B * N1 * 4);       // fp32 rounding of mass1: key B of the tile kernel
+    // Any N2, N1: the split rows and the per-row terms are padded to whole 256-tiles (zero rows; the tiles that reach into the
+    // padding mask it in their reductions), so a mesh with 2000 vertices takes the same path as one with 2048.
+    const int R2 = pad_to(N2, 256), R1 = pad_to(N1, 256);
+    _Float16* Fx = (_Float16*)dm_ws_take(ctx, (size_t)B * R2 * D * 2);
+    _Float16* Fy = (_Float16*)dm_ws_take(ctx, (size_t)B * R1 * D * 2);
+    float* biasA = (float*)dm_ws_take(ctx, (size_t)B * R1 * 4);
+    float* biasB = (float*)dm_ws_take(ctx, (size_t)B * R2 * 4);
+    float* scale32 = (float*)dm_ws_take(ctx, (size_t)B * R1 * 4);       // fp32 rounding of mass1: key B of the tile kernel
     if (!Fx || !Fy || !biasA || !biasB || !scale32) return dm_fail(ctx, DM_ENOMEM, "fm_split: workspace not reserved");
+    if (R2 != N2) DM_CHECK_HIP(ctx, hipMemsetAsync(Fx, 0, (size_t)B * R2 * D * 2, ctx->stream));
+    if (R1 != N1) DM_CHECK_HIP(ctx, hipMemsetAsync(Fy, 0, (size_t)B * R1 * D * 2, ctx->stream));
+    if (R1 != N1) {                                           // (padded terms reach LDS and masked lanes: keep them finite)
+        DM_CHECK_HIP(ctx, hipMemsetAsync(biasA, 0, (size_t)B * R1 * 4, ctx->stream));
+        DM_CHECK_HIP(ctx, hipMemsetAsync(scale32, 0, (size_t)B * R1 * 4, ctx->stream));
+    }
+    if (R2 != N2) DM_CHECK_HIP(ctx, hipMemsetAsync(biasB, 0, (size_t)B * R2 * 4, ctx->stream));
     const size_t mstride = dm_align_up((size_t)B * 4) / 4;
     unsigned int* bmaxA = reinterpret_cast<unsigned int*>(zeroed);
     unsigned int* mmax = bmaxA + mstride; unsigned int* bmaxB = bmaxA + 2 * mstride;
     {
         const long long n = (long long)N2 * (D / 16);
         DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel<TR>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
-                  amaxT, nT, D, Fx);
+                  amaxT, nT, D, Fx, R2);
     }
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 64), B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1, nT);
+              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1, nT, R1);
     {
-        const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32};
-        const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr};
+        const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32, R1};
+        const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr, R2};
         DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1 > N2 ? N1 : N2, 256), B, 2), dim3(256), 0, sA, sB, amaxT, nT, amaxS, nS);
     }
     const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
@@ -486,7 +502,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         dm_simnn_queue qa, qb, qc, qd;
         // (ind12[j] = 0 where mass1[j] = 0: the whole indicator column is 0 and np.argmax returns the first index)
         dm_simnn_cols cols{biasB, reinterpret_cast<const float*>(bmaxB), a.knn12, a.ind12, &qc, &qd, a.mass1};
-        dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols};
+        dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols, true};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         // (Phi2 is read where the caller keeps it: targets of e0 / e1, candidates of f0 / f1)
@@ -502,7 +518,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     // pass A: targets = Phi2 rows, candidates = emb1 rows
     {
         dm_simnn_queue qa, qb;
-        dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb};
+        dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, nullptr, true};
         int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         ks_exact_args e0{nullptr, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21, Phi2, nullptr, ld2};
@@ -513,7 +529,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     // pass B: targets = emb1 rows, candidates = Phi2 rows
     {
         dm_simnn_queue qa, qb;
-        dm_simnn_dual dual{biasB, nullptr, reinterpret_cast<const float*>(bmaxB), nullptr, a.ind12, &qb};
+        dm_simnn_dual dual{biasB, nullptr, reinterpret_cast<const float*>(bmaxB), nullptr, a.ind12, &qb, nullptr, true};
         int rc = dm_simnn_core(ctx, B, N1, N2, D, Fy, D, Fx, D, rel_extra, nullptr, a.knn12, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         ks_exact_args e0{a.BT, nullptr, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa, a.knn12, nullptr, Phi2, ld2};

@@ -43,7 +43,11 @@ struct simnn_params {
     unsigned int* smax2;                     // (B)      max_j |s_j|^2 as float bits (atomicMax), by target tile 0
     int N2, N1, D, N2pad, tilesT, tilesS, total;
     int ldT, ldS;                            // row strides (halves) of Ftgt / Fsrc, >= D, multiples of 8
+    int rowsT, rowsS;                        // rows per pair of Ftgt / Fsrc and of the per-row term arrays: N2 / N1, or the padded
+                                             // counts when the caller's buffers are padded to whole tiles (key-set passes on any size)
     int band;                                // tile rows per band of the tile order (simnn_decode)
+    int rt0, rnT, rs0, rnS;                  // the rectangle of tiles (per pair) this launch walks: rows rt0 .. rt0 + rnT - 1 of the
+                                             // tilesT x tilesS grid, columns rs0 .. rs0 + rnS - 1; total = B rnT rnS
     // two reductions of the same products (DUAL kernels, dm_knnsplit.hip: dm_launch_fm_split):
     //   key A = score + bias[j]  -> pb / pj / ps;   key B = score * scale[j] (DUAL 1) or score (DUAL 2) -> the *_2 arrays
     const float* bias; const float* scale;   // (B, N1) per source row
@@ -123,7 +127,8 @@ template <bool FULL, int TT, int SKIP = 0, int DUAL = 0, int TB = 2>     // SKIP
 __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[4][TB], float (&nrm_t)[TB], float (&nrm_s)[4],
                                            bool do_tn, bool do_sn, int b, int i0, int j0, int ts_,
                                            int lane_, int wsrc, int wtgt, const float* bsl = nullptr) {
-    const int lane = FULL ? fresh_lane() : lane_;
+    (void)lane_;
+    const int lane = fresh_lane();
     const int hi = lane >> 5;
     if (do_tn) {
 #pragma unroll
@@ -216,7 +221,8 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
 // in registers -- the layout of the row direction with the roles swapped, reduced with the same key arithmetic.  Partials
 // are written per wave (target quarter of the tile): no cross-wave exchange.
 //   tb: this wave's 32 x 36 float buffer; bT: the tile's 256 target biases in LDS
-template <int NWT, int TB>            // NWT waves along the targets, each TB blocks of 32: partials per (tile row, wave)
+template <int NWT, int TB, bool FULL>  // NWT waves along the targets, each TB blocks of 32: partials per (tile row, wave);
+                                       // FULL = false: the tile reaches into the padding (targets >= N2 / sources >= N1 are masked)
 __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&acc)[4][TB], float (&nrm_t)[TB], float (&nrm_s)[4],
                                                 bool do_tn, bool do_sn, int b, int i0, int j0, int tt_, float* tb,
                                                 const float* bT, int lane_, int wsrc, int wtgt) {
@@ -226,7 +232,8 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const float v = nrm_s[x] + xhalf(nrm_s[x], hi != 0);
-            if (lane < 32) p.snorm2[(long long)b * p.N1 + j0 + wsrc * 128 + x * 32 + lane] = v;
+            if (lane < 32 && (FULL || j0 + wsrc * 128 + x * 32 + lane < p.N1))
+                p.snorm2[(long long)b * p.N1 + j0 + wsrc * 128 + x * 32 + lane] = v;
         }
     }
     if (do_tn) {                                          // max_i |t_i|^2 (tiles of source tile column 0)
@@ -267,6 +274,11 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
                 for (int r = 0; r < 16; r += 2) {
                     f32x2 v = {tr[r], tr[r + 1]};
                     if (kind == 0) v = v + f32x2{w4[r >> 2][r & 3], w4[r >> 2][(r & 3) + 1]};
+                    if (!FULL) {
+                        const int i = i0 + wtgt * (32 * TB) + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        v[0] = (i < p.N2) ? v[0] : DM_KEY_NONE;
+                        v[1] = (i + 1 < p.N2) ? v[1] : DM_KEY_NONE;
+                    }
                     k[r] = k_key(v[0], 15 - r);
                     k[r + 1] = k_key(v[1], 14 - r);
                 }
@@ -288,11 +300,13 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
             const int r_ = 15 - (kb & 15);
             float bv = __int_as_float(kb & ~15), sv = __int_as_float(__float_as_int(Sk[kind]) & ~15);
             int bi = i0 + wtgt * (32 * TB) + Bt[kind] * 32 + (r_ & 3) + 8 * (r_ >> 2) + 4 * hi;
+            if (!FULL && !(bv > -1.0e38f)) { bv = DM_NEG_INF_F32; bi = DM_IDX_NONE; }
+            if (!FULL && !(sv > -1.0e38f)) sv = DM_NEG_INF_F32;
             const float ob = xhalf(bv, hi != 0);
             const int oi = xhalf(bi, hi != 0);
             const float os = xhalf(sv, hi != 0);
             top2_merge(bv, bi, sv, ob, oi, os);
-            if (lane < 32) {
+            if (lane < 32 && (FULL || gj < p.N1)) {
                 const long long o = ((long long)b * (p.tilesT * NWT) + tt_ * NWT + wtgt) * p.N1pad + gj;
                 p.cb[kind][o] = bv; p.cj[kind][o] = bi; p.cs[kind][o] = sv;
             }
@@ -457,22 +471,26 @@ static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
 // The pass is NOT bound by that traffic, though: the banded order is 5 % faster at N = 8192 (dm_set_option "simnn_band");
 // the four reductions of the epilogue are half of the pass (tools/simnn4_experiment.py).
 __device__ __forceinline__ void simnn_decode(const simnn_params& p, int id, int& b, int& tt_, int& ts_) {
-    const int tiles = p.tilesT * p.tilesS;
+    const int tiles = p.rnT * p.rnS;
     b = id / tiles;
     const int tts = id - b * tiles;
-    const int per_band = p.band * p.tilesS;
+    const int per_band = p.band * p.rnS;
     const int band = tts / per_band;
-    const int brow0 = band * p.band, brows = min(p.band, p.tilesT - brow0);
+    const int brow0 = band * p.band, brows = min(p.band, p.rnT - brow0);
     const int brem = tts - band * per_band;
-    ts_ = brem / brows;
-    tt_ = brow0 + (brem - ts_ * brows);
+    const int cs = brem / brows;
+    ts_ = p.rs0 + cs;
+    tt_ = p.rt0 + brow0 + (brem - cs * brows);
 }
 
 // TB = 32-row target blocks per wave.  TB = 2: waves of 128 source x 64 target rows (128 accumulator registers, two waves per
 // SIMD).  TB = 4 (WT = 4 only): FOUR waves of 128 x 128, 256 accumulators per lane in the AGPR half of the register file, one
 // wave per SIMD: 8 fragment reads per 16 matrix instructions instead of 6 per 8 -- a third less traffic on the LDS pipe,
 // which is what the main loop is bound by.
-template <int XV, int WT, int DUAL = 0, int TB = 2>
+// EDGE: the launch walks tiles that reach into the padding of operands padded to whole tiles (key-set passes on sizes that
+// are not multiples of 256): its reductions mask targets >= N2 and sources >= N1.  Whole tiles run the EDGE = false kernel,
+// the same code as for aligned sizes.
+template <int XV, int WT, int DUAL = 0, int TB = 2, bool EDGE = false>
 __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn_pipe_kernel(simnn_params p) {
     static_assert(TB == 2 || (TB == 4 && WT == 4), "128 x 128 waves only for the 256-row tile");
     constexpr int TT = 64 * WT;                  // target rows per tile
@@ -527,21 +545,21 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     {                                                                                                                  \
         int b_, tt_, ts_;                                                                                              \
         simnn_decode(p, base + slot + d_tile * nslot, b_, tt_, ts_);                                                   \
-        d_T = reinterpret_cast<const char*>(p.Ftgt + ((long long)b_ * p.N2 + tt_ * TT + wave * 16 * NTI) * p.ldT);     \
-        d_S = reinterpret_cast<const char*>(p.Fsrc + ((long long)b_ * p.N1 + ts_ * ST + wave * 16 * NSI) * p.ldS);     \
+        d_T = reinterpret_cast<const char*>(p.Ftgt + ((long long)b_ * p.rowsT + tt_ * TT + wave * 16 * NTI) * p.ldT);  \
+        d_S = reinterpret_cast<const char*>(p.Fsrc + ((long long)b_ * p.rowsS + ts_ * ST + wave * 16 * NSI) * p.ldS);  \
         d_kp = (STAG == 0 || STAG == 3) ? 0 : (STAG == 1 ? (ts_ + tt_) % ns : ((ts_ + tt_) * ns / p.tilesS) % ns);                    \
         d_s = 0;                                                                                                       \
         if (DUAL && wave == 0) {      /* the tile's per-source terms: one 1 KiB piece each, landed long before its epilogue */ \
             float* dstB = bias_lds + (d_tile & 1) * BSLOT;                                                             \
             const int lane16 = fresh_lane() * 16;                                                                      \
-            const char* gb = reinterpret_cast<const char*>(p.bias + (long long)b_ * p.N1 + ts_ * ST) + lane16;         \
+            const char* gb = reinterpret_cast<const char*>(p.bias + (long long)b_ * p.rowsS + ts_ * ST) + lane16;      \
             __builtin_amdgcn_global_load_lds((gptr_t)gb, (lptr_t)dstB, 16, 0, 0);                                      \
             if (DUAL == 1 || DUAL == 3) {                                                                              \
-                const char* gs = reinterpret_cast<const char*>(p.scale + (long long)b_ * p.N1 + ts_ * ST) + lane16;    \
+                const char* gs = reinterpret_cast<const char*>(p.scale + (long long)b_ * p.rowsS + ts_ * ST) + lane16; \
                 __builtin_amdgcn_global_load_lds((gptr_t)gs, (lptr_t)(dstB + 256), 16, 0, 0);                          \
             }                                                                                                          \
             if (DUAL == 3 && lane16 < TT * 4) {                                                                        \
-                const char* gt2 = reinterpret_cast<const char*>(p.biasT + (long long)b_ * p.N2 + tt_ * TT) + lane16;  \
+                const char* gt2 = reinterpret_cast<const char*>(p.biasT + (long long)b_ * p.rowsT + tt_ * TT) + lane16; \
                 __builtin_amdgcn_global_load_lds((gptr_t)gt2, (lptr_t)(dstB + 512), 16, 0, 0);                         \
             }                                                                                                          \
         }                                                                                                              \
@@ -738,12 +756,13 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
         }
         // the ring slot of the stage computed last takes no LDS-DMA before the next tile's first stage
         float* const free_slot = reinterpret_cast<float*>(smem + ((r_slot + NBUF - 1) % NBUF) * PSTAGE);
+        constexpr bool full = !EDGE;         // (EDGE launches: the masked variants of the reductions)
 #ifdef DM_EXPERIMENTS
         if (DUAL && (p.dbg & 0x1000)) {                  // ablation (wrong results): no row-direction reduction
             if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
         } else
 #endif
-        simnn_tail<true, TT, ((dbg & 7) == 4 || (dbg & 7) == 6) ? 4 : 0, (DUAL == 3 ? 1 : DUAL), TB>(
+        simnn_tail<full, TT, ((dbg & 7) == 4 || (dbg & 7) == 6) ? 4 : 0, (DUAL == 3 ? 1 : DUAL), TB>(
             p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, lane, wsrc, wtgt, bias_lds + (n & 1) * BSLOT);
 #ifdef DM_EXPERIMENTS
         if (DUAL == 3 && (p.dbg & 0x2000)) {             // ablation (wrong results): no column-direction reduction
@@ -753,7 +772,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
         if (DUAL == 3) {
             // transposes go through the free slot (8 waves: seven of them, the eighth has its own buffer)
             float* tb = (NW == 8 && wave == 7) ? tb_extra : free_slot + wave * (32 * 36);
-            simnn_tail_cols<NWT, TB>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, tt_, tb, bias_lds + (n & 1) * BSLOT + 512, lane, wsrc, wtgt);
+            simnn_tail_cols<NWT, TB, full>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, tt_, tb, bias_lds + (n & 1) * BSLOT + 512, lane, wsrc, wtgt);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave is done with its buffer ...
             __builtin_amdgcn_s_barrier();                // ... and no wave starts the next tile's DMA into the slot before all are
@@ -929,8 +948,8 @@ size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual) {
 
 // can the two-key pass run on these sizes (interior 256 x 256 tiles, contraction a multiple of a stage and deep enough
 // for the ring)?
-bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D) {
-    return ctx->opt_simnn_pipe && N2 % ST == 0 && N1 % ST == 0 && D % PBK == 0 && D >= 5 * PBK;
+bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D, bool padded) {
+    return ctx->opt_simnn_pipe && (padded || (N2 % ST == 0 && N1 % ST == 0)) && D % PBK == 0 && D >= 5 * PBK;
 }
 
 // Tile kernel + merge: fp32 scores, top-2 per target row, the rows whose margin is inside the error bound queued for an
@@ -946,6 +965,9 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     p.Ftgt = Ftgt; p.Fsrc = Fsrc;
     p.N2 = N2; p.N1 = N1; p.D = D; p.N2pad = pad_to(N2, ST);
     p.ldT = ldT; p.ldS = ldS;
+    // key-set passes may run on operands (and per-row term arrays) padded to whole 256-tiles: any N2, N1
+    const bool padded = dual && dual->padded;
+    p.rowsT = padded ? pad_to(N2, ST) : N2; p.rowsS = padded ? pad_to(N1, ST) : N1;
     p.tilesT = p.N2pad / ST; p.tilesS = dm_cdiv(N1, ST);
     p.total = B * p.tilesT * p.tilesS;
     p.band = p.tilesT;                       // (edge kernel: row-major)
@@ -971,7 +993,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     int32_t* cflag_list[2] = {nullptr, nullptr}; float* cflag_thr[2] = {nullptr, nullptr};
     int32_t* cflag_count[2] = {flag_count + 128, flag_count + 192};
     if (dual) {
-        if (!dm_simnn_dual_ok(ctx, N2, N1, D) || !dual->bias || !dual->nn_b || !dual->q_b)
+        if (!dm_simnn_dual_ok(ctx, N2, N1, D, padded) || !dual->bias || !dual->nn_b || !dual->q_b)
             return dm_fail(ctx, DM_EINVAL, "simnn: the two-key pass needs interior tiles, D %% 32 == 0, D >= 160");
         p.bias = dual->bias; p.scale = dual->scale;
         p.pb_2 = (float*)dm_ws_take(ctx, np * 4);
@@ -1004,7 +1026,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, ctx->stream));
     const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16);
-    const bool interior = (N2 % ST == 0 && N1 % ST == 0);
+    const bool interior = padded || (N2 % ST == 0 && N1 % ST == 0);
     // DM_EXPERIMENTS: DM_SIMNN_DEBUG = variant bits XV (simnn_pipe_kernel) + 256 / 512 for the 8-wave / 4-wave shape
     // (both directions: the 8-wave shape; p2p_split = 3 selects 4 waves x 2 workgroups per CU, whose second workgroup covers
     // part of the epilogue but whose 1.5x operand traffic costs as much: config 2 1.737 vs 1.729 ms, config 5 20.0 vs 19.2 ms)
@@ -1015,26 +1037,28 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     const int WT = cols ? ((ctx->opt_p2p_split == 3 || (ctx->opt_p2p_split == 2 && ops_in_l2 && !ctx->opt_simnn_big)) ? 2 : 4)
                         : (dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT)));
     // (the stage loop peels its first and last stages: the contraction must be at least ring depth + 1 stages deep)
-    const int TB = (WT == 4 && ctx->opt_simnn_big) ? 4 : 2;          // 32-row target blocks per wave
+    const bool aligned = (N2 % ST == 0 && N1 % ST == 0);
+    const int TB = (WT == 4 && ctx->opt_simnn_big && aligned) ? 4 : 2;       // 32-row target blocks per wave
     if (interior && ctx->opt_simnn_pipe && D % PBK == 0 && D >= (WT == 4 ? 5 : 4) * PBK) {
         const int TT = 64 * WT;
         p.tilesT = p.N2pad / TT;
-        p.total = B * p.tilesT * p.tilesS;
-        // tile order: bands of opt_simnn_band tile rows, column-major inside (0: one tile row per band = row-major order)
-        p.band = ctx->opt_simnn_band <= 0 ? 1 : (p.tilesT < ctx->opt_simnn_band ? p.tilesT : ctx->opt_simnn_band);
         const size_t lds_pipe = simnn_pipe_lds(WT, cols ? 3 : (dual ? 1 : 0));
         // workgroups that fit a CU at once walk the tiles (opt_simnn_persist: 0 = one workgroup per tile, 1 = as many
         // workgroups as are resident when there are more tiles than that, n > 1 = n workgroups (tests))
         const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
         const int resident = ncu * (WT == 4 ? 1 : 2);
-        const int want = ctx->opt_simnn_persist > 1 ? ctx->opt_simnn_persist : (ctx->opt_simnn_persist ? resident : p.total);
-        const int grid = want < p.total ? want : p.total;
-        int rc = DM_OK;
+        int rc = DM_OK, grid = 0;
 #define SIMNN_LAUNCH_XV(XV_, WT_, DUAL_, NAME_)                                                                        \
         {                                                                                                              \
             rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<XV_, WT_, DUAL_>, lds_pipe);                         \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<XV_, WT_, DUAL_>), dim3(grid), dim3(128 * WT_), lds_pipe, p);     \
+        }
+#define SIMNN_LAUNCH_EDGE(WT_, DUAL_, NAME_)                                                                           \
+        {                                                                                                              \
+            rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<SIMNN_PRODUCT_XV, WT_, DUAL_, 2, true>, lds_pipe);   \
+            if (rc) return rc;                                                                                         \
+            DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<SIMNN_PRODUCT_XV, WT_, DUAL_, 2, true>), dim3(grid), dim3(128 * WT_), lds_pipe, p); \
         }
 #define SIMNN_LAUNCH_BIG(DUAL_, NAME_)                                                                                 \
         {                                                                                                              \
@@ -1042,6 +1066,25 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<SIMNN_PRODUCT_XV, 4, DUAL_, 4>), dim3(grid), dim3(256), lds_pipe, p); \
         }
+        // One launch walks a rectangle of the tilesT x tilesS tile grid.  Aligned sizes: the whole grid.  Padded operands: the
+        // whole tiles first, then the strips that reach into the padding with the masking (EDGE) instantiation.
+        const int fullT = padded ? N2 / TT : p.tilesT, fullS = padded ? N1 / ST : p.tilesS;
+        const int rects[3][5] = {{0, fullT, 0, fullS, 0}, {fullT, p.tilesT - fullT, 0, p.tilesS, 1}, {0, fullT, fullS, p.tilesS - fullS, 1}};
+        for (int rq = 0; rq < 3; ++rq) {
+            p.rt0 = rects[rq][0]; p.rnT = rects[rq][1]; p.rs0 = rects[rq][2]; p.rnS = rects[rq][3];
+            const bool edge = rects[rq][4] != 0;
+            if (p.rnT <= 0 || p.rnS <= 0) continue;
+            p.total = B * p.rnT * p.rnS;
+            // tile order: bands of opt_simnn_band tile rows, column-major inside (0: one tile row per band = row-major order)
+            p.band = ctx->opt_simnn_band <= 0 ? 1 : (p.rnT < ctx->opt_simnn_band ? p.rnT : ctx->opt_simnn_band);
+            const int want = ctx->opt_simnn_persist > 1 ? ctx->opt_simnn_persist : (ctx->opt_simnn_persist ? resident : p.total);
+            grid = want < p.total ? want : p.total;
+            if (edge) {
+                if (cols) { if (WT == 4) SIMNN_LAUNCH_EDGE(4, 3, "simnn4_f16_mfma") else SIMNN_LAUNCH_EDGE(2, 3, "simnn4_f16_mfma") }
+                else if (dual->scale) SIMNN_LAUNCH_EDGE(4, 1, "simnn2_f16_mfma")
+                else SIMNN_LAUNCH_EDGE(4, 2, "simnn2_f16_mfma")
+                continue;
+            }
         if (TB == 4) {
             if (cols) SIMNN_LAUNCH_BIG(3, "simnn4_f16_mfma")
             else if (dual && dual->scale) SIMNN_LAUNCH_BIG(1, "simnn2_f16_mfma")
@@ -1071,7 +1114,9 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma")
 #endif
         }
+        }
 #undef SIMNN_LAUNCH_BIG
+#undef SIMNN_LAUNCH_EDGE
 #undef SIMNN_LAUNCH_XV
     } else {
         int rc = dm_grant_lds(ctx, (const void*)simnn_edge_kernel, lds_edge);

@@ -166,7 +166,7 @@ def test_float64_basis_adversarial_equals_oracle(eng, kind):
     mismatch is tolerated only where both candidates tie to a few float64 ulps, and is printed); the float32 entry points
     on the rounded operands do not -- their disagreement rate is printed"""
     rng = np.random.default_rng({"random": 11, "near_duplicates": 12, "near_masses": 13, "permuted": 14, "scales": 15, "zero_masses": 16}[kind])
-    for (B, N1, N2, k1, k2) in ((2, 512, 768, 64, 80), (1, 1024, 512, 72, 100)):
+    for (B, N1, N2, k1, k2) in ((2, 512, 768, 64, 80), (1, 1024, 512, 72, 100), (1, 777, 1000, 72, 90)):
         Phi1, Phi2, a1, C = _adversarial(rng, B, N1, N2, k1, k2, kind)
         assert eng.p2p_split_active(N2, N1, k2)
         want = [orc.fm_to_p2p_all(C[b], Phi1[b], Phi2[b], a1[b]) for b in range(B)]
