@@ -348,7 +348,8 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 //                                                  columns with a1_j == 0 score 0 everywhere: index 0, like np.argmax)
 // then the ambiguous rows of each of the four reductions are re-evaluated exactly (ks_exact_kernel) with the reference's
 // own float64 expressions -- emb1 from its K-major float64 copy, Phi2 from the caller's row-major array.
-// Needs interior 256-tiles and K >= 65 (five stages of 16 indices: dm_fm_split_ok); otherwise the float64 G kernel.
+// Any N1, N2 >= 256 (operands padded to whole tiles, edge tiles masked) and K >= 65 (five stages of 16 indices:
+// dm_fm_split_ok); otherwise the float64 G kernel.
 // (mass, when given: also its fp32 rounding scale32, the per-source factor of the tile kernel's key B -- the rounding is
 //  part of the key's error bound, dm_simnn_core -- and the maximum of the ROUNDED values)
 struct fs_bias_set {

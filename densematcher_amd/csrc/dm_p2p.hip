@@ -784,7 +784,7 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
     const int K1pad = pad_to(k1, GBK);
     const bool all = knn12 || ind21 || ind12;      // anything beyond knn21 takes the four-reduction kernel
     const size_t bytes_E2 = 0;                     // emb2 = Phi2 C is only needed for its row norms: never stored (embed_norm_kernel)
-    // all four maps on interior sizes: one pass of the four-key fp16 tile kernel + exact re-evaluation (dm_knnsplit.hip).  That
+    // all four maps: one pass of the four-key fp16 tile kernel + exact re-evaluation (dm_knnsplit.hip).  That
     // path reads Phi2 where it lies (row-major, fp32 or fp64): no K-major copy of it is made.
     const bool split = knn21 && knn12 && ind21 && ind12 && mass1_in && dm_fm_split_ok(ctx, N2, N1, k2);
     const size_t bytes_AT = split ? 0 : (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;

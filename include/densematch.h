@@ -204,9 +204,9 @@ int dm_fmap_descr_ops(dm_ctx* ctx, int B, int N, int D, int k, const float* Phi,
  *   ind21[i] = argmax_j G_ij mass1_j               (convert.py:144 + functional_map.py:49)
  *   ind12[j] = argmax_i G_ij mass1_j               (convert.py:144 + functional_map.py:50)
  * The returned indices are those of the float64 arithmetic above, lowest index on ties.  When all four maps are
- * asked for and N1, N2 are multiples of 256 (and 3 k2 >= 160) they come from one pass on the fp16 matrix cores over
- * split operands with a rigorous error bound, every row inside the bound re-evaluated in float64; otherwise from a fused
- * kernel on the f64 matrix cores ("p2p_split" option).
+ * asked for, N1, N2 >= 256 (any values: operands are padded to whole tiles internally) and k2 >= 65, they come from one pass
+ * on the fp16 matrix cores over split operands with a rigorous error bound, every row inside the bound re-evaluated in
+ * float64; otherwise from a fused kernel on the f64 matrix cores ("p2p_split" option).
  * Any of the four outputs may be NULL.  knn21/ind21 (B,N2); knn12/ind12 (B,N1). */
 int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
                  const float* Phi1, int ld1, const float* Phi2, int ld2,
