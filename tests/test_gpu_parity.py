@@ -361,6 +361,32 @@ def test_fuzz_fm_to_p2p(eng):
     run()
 
 
+def test_fuzz_fm_to_p2p_split_sizes(eng):
+    """the fp16 split path on arbitrary mesh sizes (padded operands, masked edge strips, both tile shapes) against the float64 G
+    kernel: identical maps"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=int(__import__("os").environ.get("DM_FUZZ_EXAMPLES", "12")), deadline=None, derandomize=True)
+    @given(st.integers(1, 2), st.integers(256, 1400), st.integers(256, 1400), st.integers(65, 140), st.integers(20, 140),
+           st.sampled_from([2, 3, 4, 1]), st.integers(0, 2 ** 31 - 1))
+    def run(B, N1, N2, k2, k1, split, seed):
+        rng = np.random.default_rng(seed)
+        Phi1 = (rng.standard_normal((B, N1, k1)) * 0.1).astype(np.float64)
+        Phi2 = (rng.standard_normal((B, N2, k2)) * 0.1).astype(np.float64)
+        a1 = rng.uniform(0.1, 2.0, (B, N1))
+        a1[:, rng.integers(0, N1, 3)] = 0.0                  # a few zero masses: ind12 = 0 there
+        C = rng.standard_normal((B, k2, k1)) / np.sqrt(k1)
+        assert eng.p2p_split_active(N2, N1, k2)
+        eng.set_option("p2p_split", split)
+        got = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
+        eng.set_option("p2p_split", 0)
+        want = {k: _np(v) for k, v in eng.fm_to_p2p(Phi1, Phi2, a1, C).items()}
+        eng.reset_options()
+        for name in ("knn21", "knn12", "ind21", "ind12"):
+            assert np.array_equal(got[name], want[name]), (name, B, N1, N2, k1, k2, split, int((got[name] != want[name]).sum()))
+    run()
+
+
 def test_fuzz_simnn(eng):
     from hypothesis import given, strategies as st
 
