@@ -157,7 +157,7 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ 
 }
 
 // ---- the same search with the column state in registers ---------------------------------------------------------------------
-// Thread t owns the columns t, t + 1024, ... (CPT of them, nc <= 1024 CPT): their dual v, tentative cost, "scanned" flag and
+// Thread t owns the columns t, t + NT, ... (CPT of them, nc <= NT CPT): their dual v, tentative cost, "scanned" flag and
 // POSITION IN SCIPY'S `remaining` LIST live in registers, the cost row is read coalesced, and a step needs ONE barrier:
 // every wave leaves its best candidate in a double-buffered LDS slot and every thread folds the 16 slots itself.  The
 // list is never stored: SciPy removes the chosen entry by moving the last one into its place, so the only column whose
@@ -167,8 +167,8 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ 
 //   (Jonker-Volgenant's column reduction; a feasible dual pair with tight assigned edges, so the augmentations continue from
 //   there to an optimum).  Fewer and shorter searches, but not SciPy's order: the caller accepts the result only when
 //   lsa_unique_kernel finds the optimum unique (no slack-free edge outside the assignment), else it reruns with WARM = 0.
-template <int CPT, int WARM>
-__global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restrict__ costs, int nr, int nc, int negate,
+template <int CPT, int WARM, int NT>
+__global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ costs, int nr, int nc, int negate,
                                                          double* __restrict__ g_u, double* __restrict__ g_v,
                                                          int32_t* __restrict__ out_col4row, int32_t* __restrict__ info,
                                                          const int32_t* __restrict__ run_if) {
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restric
     int r4c[CPT];                                         // row4col of the owned columns (refreshed after every path flip)
 #pragma unroll
     for (int q = 0; q < CPT; ++q) { v[q] = 0.0; spc[q] = DM_INF_F64; pos[q] = 0; sc[q] = false; r4c[q] = -1; }
-    for (int i = t; i < nr; i += LSA_NT) { u[i] = 0.0; col4row[i] = -1; }
-    for (int j = t; j < nc; j += LSA_NT) { row4col[j] = -1; path[j] = -1; }
+    for (int i = t; i < nr; i += NT) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = t; j < nc; j += NT) { row4col[j] = -1; path[j] = -1; }
     __syncthreads();
     if (WARM) {
         // v_j = min_i c_ij (lowest i on ties); the column takes that row if no lower column claimed it
@@ -203,20 +203,20 @@ __global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restric
             const double* crow = cost + (long long)i * nc;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
-                const int j = t + LSA_NT * q;
+                const int j = t + NT * q;
                 if (j < nc) { const double c = sgn * crow[j]; if (c < v[q]) { v[q] = c; arg[q] = i; } }
             }
         }
         // claim: col4row[i] = the lowest column whose minimum is in row i (LDS atomics), then the winners record themselves
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
-            const int j = t + LSA_NT * q;
+            const int j = t + NT * q;
             if (j < nc && arg[q] >= 0 && v[q] < DM_INF_F64) atomicMin(reinterpret_cast<unsigned int*>(&col4row[arg[q]]), (unsigned int)j);
         }
         __syncthreads();                                  // (col4row was -1 = 0xffffffff: any column index is smaller as unsigned)
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
-            const int j = t + LSA_NT * q;
+            const int j = t + NT * q;
             if (j < nc && arg[q] >= 0 && col4row[arg[q]] == j) row4col[j] = arg[q];
             if (j < nc && !(v[q] < DM_INF_F64)) v[q] = 0.0;     // a column without a finite entry: no usable minimum
         }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restric
         if (WARM && col4row[cur] != -1) continue;         // (uniform) assigned by the column reduction
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
-            const int j = t + LSA_NT * q;
+            const int j = t + NT * q;
             spc[q] = DM_INF_F64; sc[q] = false; pos[q] = nc - 1 - j;          // remaining[it] = nc - it - 1
             r4c[q] = j < nc ? row4col[j] : -1;
         }
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restric
             double cv[CPT];
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {                // all the row's loads first (independent), then the relaxations
-                const int j = t + LSA_NT * q;
+                const int j = t + NT * q;
                 cv[q] = (j < nc && !sc[q]) ? crow[j] : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
-                const int j = t + LSA_NT * q;
+                const int j = t + NT * q;
                 if (j < nc && !sc[q]) {
                     const double r = ((min_val + sgn * cv[q]) - ui) - v[q];     // SciPy's operation order
                     if (r < spc[q]) { spc[q] = r; path[j] = i; }
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restric
             __syncthreads();
             // every thread folds the 16 wave results itself (lane q < 16 takes slot q, then a 4-level butterfly inside the wave:
             // the rule is a total order on distinct positions, so every lane ends with the same winner)
-            double wv = lane < 16 ? sl_val[par][lane & 15] : DM_INF_F64;
-            int wsk = lane < 16 ? sl_sink[par][lane & 15] : 0, wit = lane < 16 ? sl_it[par][lane & 15] : -1, wj = lane < 16 ? sl_j[par][lane & 15] : -1;
+            double wv = lane < NT / 64 ? sl_val[par][lane & 15] : DM_INF_F64;
+            int wsk = lane < NT / 64 ? sl_sink[par][lane & 15] : 0, wit = lane < NT / 64 ? sl_it[par][lane & 15] : -1, wj = lane < NT / 64 ? sl_j[par][lane & 15] : -1;
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1)
                 lsa_merge(wv, wsk, wit, wj, __shfl_xor(wv, off), __shfl_xor(wsk, off), __shfl_xor(wit, off), __shfl_xor(wj, off));
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restric
             // remove the chosen column from the list: the column at the last position takes its place
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
-                const int j = t + LSA_NT * q;
+                const int j = t + NT * q;
                 if (j == wj) sc[q] = true;
                 else if (!sc[q] && pos[q] == nrem - 1) pos[q] = wit;
             }
@@ -310,14 +310,14 @@ __global__ __launch_bounds__(LSA_NT) void lsa_reg_kernel(const double* __restric
         }
         __syncthreads();
     }
-    for (int i = t; i < nr; i += LSA_NT) {
+    for (int i = t; i < nr; i += NT) {
         out_col4row[(long long)b * nr + i] = col4row[i];
         if (g_u) g_u[(long long)b * nr + i] = u[i];
     }
     if (g_v) {
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
-            const int j = t + LSA_NT * q;
+            const int j = t + NT * q;
             if (j < nc) g_v[(long long)b * nc + j] = v[q];
         }
     }
@@ -466,16 +466,23 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
         if (!tie) return dm_fail(ctx, DM_ENOMEM, "assignment: workspace not reserved");
         double* gu = gf;
         double* gv = gf + (size_t)B * R;
-        const int cpt = Cn <= LSA_NT ? 1 : (Cn <= 2 * LSA_NT ? 2 : (Cn <= 4 * LSA_NT ? 4 : 8));
-#define LSA_REG(CPT_, WARM_, RUNIF_)                                                                                   \
+        // 512 threads with twice the columns each up to 4096 columns (a step is a barrier, a 16-slot merge and one cost row: fewer
+        // waves make the barrier and the merge cheaper; 0.61 -> 0.54 s on the notebook's 2048 x 2048 indicator, 256 threads: 0.64 s)
+        const int nt = Cn <= 8 * 512 ? 512 : LSA_NT;
+        const int per = dm_cdiv(Cn, nt);
+        const int cpt = per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : 8));
+#define LSA_REG(CPT_, WARM_, RUNIF_, NT_)                                                                              \
         {                                                                                                              \
-            rc = dm_grant_lds(ctx, (const void*)lsa_reg_kernel<CPT_, WARM_>, lds_reg);                                 \
+            rc = dm_grant_lds(ctx, (const void*)lsa_reg_kernel<CPT_, WARM_, NT_>, lds_reg);                            \
             if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", (lsa_reg_kernel<CPT_, WARM_>), dim3(B), dim3(LSA_NT), lds_reg, Cm, R, Cn,   \
+            DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", (lsa_reg_kernel<CPT_, WARM_, NT_>), dim3(B), dim3(NT_), lds_reg, Cm, R, Cn, \
                       maximize ? 1 : 0, gu, gv, outp, info, RUNIF_);                                                   \
         }
+#define LSA_REG_NT(WARM_, RUNIF_, NT_)                                                                                 \
+        if (cpt == 1) LSA_REG(1, WARM_, RUNIF_, NT_) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_, NT_)                 \
+        else if (cpt == 4) LSA_REG(4, WARM_, RUNIF_, NT_) else LSA_REG(8, WARM_, RUNIF_, NT_)
 #define LSA_REG_CPT(WARM_, RUNIF_)                                                                                     \
-        if (cpt == 1) LSA_REG(1, WARM_, RUNIF_) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_) else if (cpt == 4) LSA_REG(4, WARM_, RUNIF_) else LSA_REG(8, WARM_, RUNIF_)
+        if (nt == 512) { LSA_REG_NT(WARM_, RUNIF_, 512) } else { LSA_REG_NT(WARM_, RUNIF_, 1024) }
         if (ctx->opt_lsa_reg >= 2 && R == Cn) {
             // column-reduction start (not SciPy's order; square problems only: the duals of columns that stay unassigned would have
             // to be zero), accepted per matrix when its optimum is provably unique, else redone exactly.  Measured and dropped:
@@ -501,6 +508,7 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
             LSA_REG_CPT(0, (const int32_t*)nullptr)
         }
 #undef LSA_REG_CPT
+#undef LSA_REG_NT
 #undef LSA_REG
         if (transposed) {
             DM_CHECK_HIP(ctx, hipMemsetAsync(col_of_row, 0xFF, (size_t)B * nr * 4, ctx->stream));
