@@ -156,6 +156,42 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ 
     for (int i = t; i < nr; i += LSA_NT) out_col4row[(long long)b * nr + i] = col4row[i];
 }
 
+// the same rule with (sink, it, column) folded into ONE integer that orders the candidates of equal cost: an unassigned
+// column beats an assigned one, among unassigned ones the LAST in scan order wins, among assigned ones the FIRST:
+//   key = ((sink ? 8192 + it : 8191 - it) << 14) | column      (it, column < 8192: nc <= 8192 on this path);  -1 = no candidate
+//   better = smaller cost, then larger key  (positions are distinct, so the column bits never decide)
+// -- two comparisons per merge instead of five, and three shuffled words per butterfly level instead of five
+__device__ __forceinline__ int lsa_key(int sink, int it, int j) { return ((sink ? 8192 + it : 8191 - it) << 14) | j; }
+// partner's word for the levels of an all-reduce inside a wave, on the vector ALU (DPP / half-swaps) instead of ds_bpermute
+// round trips: lanes i ^ 1, i ^ 2 (quad permutes), 7 - i within 8 (row_half_mirror), 15 - i within 16 (row_mirror), then the
+// neighbouring row of 16 and the other half of the wave.  Any pairing that joins the two groups works for a reduction
+// whose merge is a total order.
+template <int LEVEL>
+__device__ __forceinline__ int lsa_partner(int x) {
+    if constexpr (LEVEL == 0) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if constexpr (LEVEL == 1) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if constexpr (LEVEL == 2) return __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    else if constexpr (LEVEL == 3) return __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false);  // row_mirror
+    else if constexpr (LEVEL == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);     // r[0] = rows 0 0 2 2, r[1] = rows 1 1 3 3
+        return (int)((threadIdx.x & 16) ? r[0] : r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);     // r[0] = low half twice, r[1] = high half twice
+        return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+    }
+}
+template <int LEVEL>
+__device__ __forceinline__ void lsa_merge_level(double& v, int& key) {
+    const int olo = lsa_partner<LEVEL>(__double2loint(v)), ohi = lsa_partner<LEVEL>(__double2hiint(v)), okey = lsa_partner<LEVEL>(key);
+    const double ov = __hiloint2double(ohi, olo);
+    const bool take = (ov < v) || (ov == v && okey > key);
+    v = take ? ov : v; key = take ? okey : key;
+}
+__device__ __forceinline__ void lsa_merge_key(double& v, int& key, double ov, int okey) {
+    const bool take = (ov < v) || (ov == v && okey > key);
+    v = take ? ov : v; key = take ? okey : key;
+}
+
 // ---- the same search with the column state in registers ---------------------------------------------------------------------
 // Thread t owns the columns t, t + NT, ... (CPT of them, nc <= NT CPT): their dual v, tentative cost, "scanned" flag and
 // POSITION IN SCIPY'S `remaining` LIST live in registers, the cost row is read coalesced, and a step needs ONE barrier:
@@ -180,7 +216,7 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
     int* path = row4col + nc;
     int* col4row = path + nc;
     __shared__ double sl_val[2][16];
-    __shared__ int sl_sink[2][16], sl_it[2][16], sl_j[2][16];
+    __shared__ int sl_it[2][16];                          // (the candidates' tie keys, lsa_key)
     __shared__ int s_claim_dummy;
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const double* cost = costs + (long long)b * nr * nc;
@@ -238,7 +274,7 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
             const double ui = u[i];
             const double* crow = cost + (long long)i * nc;
             double bval = DM_INF_F64;
-            int bsink = 0, bit = -1, bestj = -1;
+            int bkey = -1;
             double cv[CPT];
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {                // all the row's loads first (independent), then the relaxations
@@ -251,23 +287,25 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
                 if (j < nc && !sc[q]) {
                     const double r = ((min_val + sgn * cv[q]) - ui) - v[q];     // SciPy's operation order
                     if (r < spc[q]) { spc[q] = r; path[j] = i; }
-                    lsa_merge(bval, bsink, bit, bestj, spc[q], r4c[q] == -1 ? 1 : 0, pos[q], j);
+                    lsa_merge_key(bval, bkey, spc[q], lsa_key(r4c[q] == -1 ? 1 : 0, pos[q], j));
                 }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1)
-                lsa_merge(bval, bsink, bit, bestj, __shfl_xor(bval, off), __shfl_xor(bsink, off), __shfl_xor(bit, off), __shfl_xor(bestj, off));
+            lsa_merge_level<0>(bval, bkey); lsa_merge_level<1>(bval, bkey); lsa_merge_level<2>(bval, bkey);
+            lsa_merge_level<3>(bval, bkey); lsa_merge_level<4>(bval, bkey); lsa_merge_level<5>(bval, bkey);
             const int par = step & 1;
-            if (lane == 0) { sl_val[par][wave] = bval; sl_sink[par][wave] = bsink; sl_it[par][wave] = bit; sl_j[par][wave] = bestj; }
+            if (lane == 0) { sl_val[par][wave] = bval; sl_it[par][wave] = bkey; }
             __syncthreads();
-            // every thread folds the 16 wave results itself (lane q < 16 takes slot q, then a 4-level butterfly inside the wave:
+            // every thread folds the wave results itself (lane q < NT / 64 takes slot q, then a 4-level butterfly inside the wave:
             // the rule is a total order on distinct positions, so every lane ends with the same winner)
             double wv = lane < NT / 64 ? sl_val[par][lane & 15] : DM_INF_F64;
-            int wsk = lane < NT / 64 ? sl_sink[par][lane & 15] : 0, wit = lane < NT / 64 ? sl_it[par][lane & 15] : -1, wj = lane < NT / 64 ? sl_j[par][lane & 15] : -1;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1)
-                lsa_merge(wv, wsk, wit, wj, __shfl_xor(wv, off), __shfl_xor(wsk, off), __shfl_xor(wit, off), __shfl_xor(wj, off));
-            wv = __shfl(wv, 0); wsk = __shfl(wsk, 0); wit = __shfl(wit, 0); wj = __shfl(wj, 0);
+            int wkey = lane < NT / 64 ? sl_it[par][lane & 15] : -1;
+            lsa_merge_level<0>(wv, wkey); lsa_merge_level<1>(wv, wkey); lsa_merge_level<2>(wv, wkey);     // lanes 0 .. 7
+            if (NT > 512) lsa_merge_level<3>(wv, wkey);                                                   // lanes 0 .. 15
+            wkey = __builtin_amdgcn_readfirstlane(wkey);
+            wv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(wv)), __builtin_amdgcn_readfirstlane(__double2loint(wv)));
+            const int wK = wkey >> 14, wj = wkey < 0 ? -1 : (wkey & 16383);
+            const int wsk = (wkey >= 0 && wK >= 8192) ? 1 : 0;
+            const int wit = wkey < 0 ? -1 : (wsk ? wK - 8192 : 8191 - wK);
             ++step;
             if (wit < 0 || !(wv < DM_INF_F64)) { infeasible = true; break; }
             min_val = wv;
