@@ -161,31 +161,53 @@ __global__ __launch_bounds__(256) void quad_terms_kernel(const double* __restric
 }
 
 // ---- statistics of the mapped indicator ------------------------------------------------------------------------------
-// cs / csq from the chunk partials, and the means of rs and cs: stat[b] = {mean rs, mean cs}   (one workgroup per pair)
+// cs / csq from the chunk partials, and the totals of rs and cs.  Workgroup g of a pair owns columns / rows 256 g .. 256 g + 255 and
+// leaves its share of the two totals in stat[(b * G + g) * 2 + {0: rows, 1: columns}]; the consumers add the G shares in order
+// (em_means).  (One workgroup per pair took 87 us for a single pair: 2 x 32 x 2048 dependent loads.)
 // (rs / rsq arrive as ncs partial sets, one per column split, set q at offset q * B * N2: summed into set 0 here, fixed order)
 __global__ __launch_bounds__(256) void m_finish_stats_kernel(const double* __restrict__ pcs, const double* __restrict__ pcsq, int nchunk,
                                                              int N2, int N1, double* __restrict__ rs, double* __restrict__ rsq, int ncs,
                                                              long long split_stride, double* __restrict__ cs,
                                                              double* __restrict__ csq, double* __restrict__ stat) {
     __shared__ double sh[4];
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
     double sc = 0.0;
-    for (int j = t; j < N1; j += 256) {
-        double s = 0.0, q = 0.0;
-        for (int ch = 0; ch < nchunk; ++ch) { s += pcs[((long long)b * nchunk + ch) * N1 + j]; q += pcsq[((long long)b * nchunk + ch) * N1 + j]; }
-        cs[(long long)b * N1 + j] = s; csq[(long long)b * N1 + j] = q;
-        sc += s;
+    {
+        const int j = g * 256 + t;
+        if (j < N1) {
+            double s = 0.0, q = 0.0;
+            int ch = 0;
+            for (; ch + 8 <= nchunk; ch += 8) {          // (eight loads of each array in flight, added in chunk order)
+                double a[8], c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a[u] = pcs[((long long)b * nchunk + ch + u) * N1 + j]; c[u] = pcsq[((long long)b * nchunk + ch + u) * N1 + j]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s += a[u]; q += c[u]; }
+            }
+            for (; ch < nchunk; ++ch) { s += pcs[((long long)b * nchunk + ch) * N1 + j]; q += pcsq[((long long)b * nchunk + ch) * N1 + j]; }
+            cs[(long long)b * N1 + j] = s; csq[(long long)b * N1 + j] = q;
+            sc = s;
+        }
     }
     const double tot_c = block_sum_256(sc, sh);
     double sr = 0.0;
-    for (int i = t; i < N2; i += 256) {
-        double s = rs[(long long)b * N2 + i], q = rsq[(long long)b * N2 + i];
-        for (int c = 1; c < ncs; ++c) { s += rs[c * split_stride + (long long)b * N2 + i]; q += rsq[c * split_stride + (long long)b * N2 + i]; }
-        rs[(long long)b * N2 + i] = s; rsq[(long long)b * N2 + i] = q;
-        sr += s;
+    {
+        const int i = g * 256 + t;
+        if (i < N2) {
+            double s = rs[(long long)b * N2 + i], q = rsq[(long long)b * N2 + i];
+            for (int c = 1; c < ncs; ++c) { s += rs[c * split_stride + (long long)b * N2 + i]; q += rsq[c * split_stride + (long long)b * N2 + i]; }
+            rs[(long long)b * N2 + i] = s; rsq[(long long)b * N2 + i] = q;
+            sr = s;
+        }
     }
     const double tot_r = block_sum_256(sr, sh);
-    if (t == 0) { stat[2 * b] = tot_r / (double)N2; stat[2 * b + 1] = tot_c / (double)N1; }
+    if (t == 0) { stat[((long long)b * G + g) * 2] = tot_r; stat[((long long)b * G + g) * 2 + 1] = tot_c; }
+}
+// mean of the row sums (which = 0, over N2 rows) / column sums (which = 1, over N1 columns) of pair b from the G shares
+__device__ __forceinline__ double em_mean(const double* __restrict__ stat, int b, int G, int which, int n) {
+    double s = 0.0;
+    for (int g = 0; g < G; ++g) s += stat[((long long)b * G + g) * 2 + which];
+    return s / (double)n;
 }
 
 // ---- tile-fused passes over the mapped indicator (M is never stored) ------------------------------------------------------
@@ -211,7 +233,7 @@ struct em_params {
     int rg;                                    // rows per workgroup of pass 1 (multiple of 64, <= EM_RG)
     int ncs, cchunk;                           // column splits of both passes, columns per split (multiple of 64)
     int Bn;                                    // pairs in the batch (stride of the split partials)
-    const double* cs; const double* csq; const double* stat;
+    const double* cs; const double* csq; const double* stat; int nstat;     // stat: (B, nstat, 2) shares of the totals (em_mean)
     mterm_weights w;
     double* Y;                                 // (ncs, B, N2, k1): one partial per column split
     double* pe;                                // (B, ncs * N2 / 64) energy shares
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(256) void em_deriv_kernel(em_params p) {
     const float* a1 = p.mass1 + (long long)b * p.N1;
     const mterm_weights w = p.w;
     const bool stats = w.stoch > 0.0 || w.sumto1 > 0.0;
-    const double mean_r = stats ? p.stat[2 * b] : 0.0, mean_c = stats ? p.stat[2 * b + 1] : 0.0;
+    const double mean_r = stats ? em_mean(p.stat, b, p.nstat, 0, p.N2) : 0.0, mean_c = stats ? em_mean(p.stat, b, p.nstat, 1, p.N1) : 0.0;
     const double n2_over_n1 = (double)p.N2 / (double)p.N1;
     // this lane's rows: statistics terms
     double dr_s[2][4], dr_q[2][4];
@@ -465,12 +487,12 @@ __global__ __launch_bounds__(256) void em_sum_splits_kernel(double* __restrict__
 // e_m[b] = sum of the workgroup shares + the column-statistics terms   (one workgroup per pair)
 __global__ __launch_bounds__(256) void m_finish_energy_kernel(const double* __restrict__ pe, int nblk, int N1, int N2,
                                                               const double* __restrict__ cs, const double* __restrict__ csq,
-                                                              const double* __restrict__ stat, mterm_weights w, double* __restrict__ e_m) {
+                                                              const double* __restrict__ stat, int nstat, mterm_weights w, double* __restrict__ e_m) {
     __shared__ double sh[4];
     const int b = blockIdx.x, t = threadIdx.x;
     double acc = 0.0;
     for (int q = t; q < nblk; q += 256) acc += pe[(long long)b * nblk + q];
-    const double mean_c = stat[2 * b + 1], n2_over_n1 = (double)N2 / (double)N1;
+    const double mean_c = em_mean(stat, b, nstat, 1, N1), n2_over_n1 = (double)N2 / (double)N1;
     if (w.stoch > 0.0 || w.sumto1 > 0.0)
         for (int j = t; j < N1; j += 256) {
             const double dq = csq[(long long)b * N1 + j] - n2_over_n1, ds = cs[(long long)b * N1 + j] - mean_c;
@@ -546,7 +568,7 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     size_t need = dm_align_up((size_t)B * (k1 + k2) * k1 * 8) + 4 * dm_align_up(bKK) + 4 * dm_align_up((size_t)B * 8) + 65536;
     if (m_terms)      // O(N k): the mapped indicator is never stored (em_stats_kernel / em_deriv_kernel)
         need += dm_align_up((size_t)B * N2 * k1 * 8) + dm_align_up((size_t)ncs * B * N2 * k1 * 8) + 2 * dm_align_up((size_t)ncs * B * N2 * 8) +
-                2 * dm_align_up((size_t)B * N1 * 8) + 2 * dm_align_up((size_t)B * ngroups * N1 * 8) + dm_align_up((size_t)B * 2 * 8) +
+                2 * dm_align_up((size_t)B * N1 * 8) + 2 * dm_align_up((size_t)B * ngroups * N1 * 8) + dm_align_up((size_t)B * dm_cdiv(N1 > N2 ? N1 : N2, 256) * 2 * 8) +
                 dm_align_up((size_t)B * ncs * dm_cdiv(N2, EM_T) * 8) + dm_align_up((size_t)nsplit_m * bKK);
     if (dcomm) need += dm_align_up((size_t)B * n_ops * k2 * k1 * 8) + dm_align_up((size_t)nsplit_d * bKK);
     int rc = dm_ws_reserve(ctx, need);
@@ -589,7 +611,8 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         double* csq = (double*)dm_ws_take(ctx, (size_t)B * N1 * 8);
         double* pcs = (double*)dm_ws_take(ctx, (size_t)B * ngroups * N1 * 8);
         double* pcsq = (double*)dm_ws_take(ctx, (size_t)B * ngroups * N1 * 8);
-        double* stat = (double*)dm_ws_take(ctx, (size_t)B * 2 * 8);
+        const int nstat = dm_cdiv(N1 > N2 ? N1 : N2, 256);
+        double* stat = (double*)dm_ws_take(ctx, (size_t)B * nstat * 2 * 8);
         double* pe = (double*)dm_ws_take(ctx, (size_t)B * ncs * nrb * 8);
         double* part = (double*)dm_ws_take(ctx, (size_t)nsplit_m * bKK);
         if (!E2 || !Yv || !rs || !rsq || !cs || !csq || !pcs || !pcsq || !stat || !pe || !part)
@@ -606,14 +629,14 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         ep.E2 = E2; ep.Phi1 = Phi1; ep.ld1 = ld1; ep.mass1 = mass1; ep.N1 = N1; ep.N2 = N2; ep.k1 = k1;
         ep.ldp = pad_to(k1, 32) + 4;
         ep.rg = rg; ep.ncs = ncs; ep.cchunk = cchunk; ep.Bn = B;
-        ep.rs = rs; ep.rsq = rsq; ep.pcs = pcs; ep.pcsq = pcsq; ep.ngroups = ngroups; ep.cs = cs; ep.csq = csq; ep.stat = stat;
+        ep.rs = rs; ep.rsq = rsq; ep.pcs = pcs; ep.pcsq = pcsq; ep.ngroups = ngroups; ep.cs = cs; ep.csq = csq; ep.stat = stat; ep.nstat = nstat;
         ep.w = mw; ep.Y = Yv; ep.pe = pe;
         if (stats) {
             const size_t lds1 = ((size_t)EM_T * EM_LDA + 2 * EM_RG + 2 * 2 * 2 * 64) * 8 + (size_t)EM_T * ep.ldp * 4;
             rc = dm_grant_lds(ctx, (const void*)em_stats_kernel, lds1);
             if (rc) return rc;
             DM_LAUNCH(ctx, "energy_stats_tiles", em_stats_kernel, dim3(ngroups, ncs, B), dim3(256), lds1, ep);
-            DM_LAUNCH(ctx, "energy_finish_stats", m_finish_stats_kernel, dim3(B), dim3(256), 0, pcs, pcsq, ngroups, N2, N1, rs, rsq, ncs,
+            DM_LAUNCH(ctx, "energy_finish_stats", m_finish_stats_kernel, dim3(nstat, B), dim3(256), 0, pcs, pcsq, ngroups, N2, N1, rs, rsq, ncs,
                       (long long)B * N2, cs, csq, stat);
         }
         {
@@ -632,7 +655,7 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
             const long long ny = (long long)B * N2 * k1;
             DM_LAUNCH(ctx, "energy_sum_splits", em_sum_splits_kernel, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, Yv, ny, ncs);
         }
-        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, ncs * nrb, N1, N2, cs, csq, stat, mw, e_m);
+        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, ncs * nrb, N1, N2, cs, csq, stat, nstat, mw, e_m);
         {   // Gm = Phi2^T Y
             RowsF32Scaled opx{Phi2, (long long)N2 * ld2, ld2, k2, nullptr, 0};
             RowsF64TN opy{Yv, (long long)N2 * k1, k1, k1};
