@@ -83,10 +83,65 @@ def robust_mesh_laplacian(verts, faces, mollify_factor=1e-5, max_flips=None):
     glue_s[plus_t[nxt], plus_s[nxt]] = minus_s
     assert (glue_t >= 0).all()
     # ---- 3. intrinsic Delaunay flips
+    flips, limit = 0, (20 * nt if max_flips is None else max_flips)
+    # 3a. vectorised rounds: all non-Delaunay edges at once, of which an independent set (no two flipped pairs share or
+    # neighbour a triangle, decided by random priorities) is flipped with array operations; the intrinsic Delaunay
+    # triangulation is unique, so the order of the flips does not matter.  A mesh of 4 k triangles needs ~2 k flips when its
+    # quads are close to cocircular: one by one in the interpreter that was 80 ms of the 150 ms a TriMesh.process call took.
+    rng = np.random.default_rng(0)
+    ar3 = np.arange(3)
+    for _round in range(200):
+        _, cot = _areas_and_cots(L)
+        bad = (cot + cot[glue_t, glue_s] < -1e-12) & (glue_t != np.arange(nt)[:, None])
+        bt, bs = np.nonzero(bad)
+        keep = bt < glue_t[bt, bs]                                        # each edge once (from its lower triangle)
+        bt, bs = bt[keep], bs[keep]
+        if len(bt) == 0 or flips >= limit:
+            break
+        t2, s2 = glue_t[bt, bs], glue_s[bt, bs]
+        s_1, s_2, q_1, q_2 = (bs + 1) % 3, (bs + 2) % 3, (s2 + 1) % 3, (s2 + 2) % 3
+        touched = np.stack([bt, t2, glue_t[bt, s_1], glue_t[bt, s_2], glue_t[t2, q_1], glue_t[t2, q_2]], axis=1)   # (c, 6)
+        prio = rng.permutation(len(bt)) + 1
+        best = np.zeros(nt, dtype=np.int64)
+        np.maximum.at(best, touched.ravel(), np.repeat(prio, 6))
+        win = (best[touched] == prio[:, None]).all(axis=1)
+        # (a pair whose two triangles coincide with a neighbour, e.g. tiny closed surfaces: left to the sequential loop)
+        distinct = (np.sort(touched, axis=1)[:, 1:] != np.sort(touched, axis=1)[:, :-1]).all(axis=1)
+        win &= distinct
+        if not win.any():
+            break
+        t, s, t2, s2 = bt[win], bs[win], t2[win], s2[win]
+        s_1, s_2, q_1, q_2 = s_1[win], s_2[win], q_1[win], q_2[win]
+        i, j, k, m = T[t, s], T[t, s_1], T[t, s_2], T[t2, q_2]
+        lij, ljk, lki, lim, lmj = L[t, s], L[t, s_1], L[t, s_2], L[t2, q_1], L[t2, q_2]
+        xk = (lki * lki - ljk * ljk + lij * lij) / (2.0 * lij)
+        yk = np.sqrt(np.maximum(lki * lki - xk * xk, 0.0))
+        xm = (lim * lim - lmj * lmj + lij * lij) / (2.0 * lij)
+        ym = -np.sqrt(np.maximum(lim * lim - xm * xm, 0.0))
+        lkm = np.hypot(xk - xm, yk - ym)
+        ok = lkm > 0.0
+        if not ok.all():
+            t, s, t2, s2, s_1, s_2, q_1, q_2 = (a[ok] for a in (t, s, t2, s2, s_1, s_2, q_1, q_2))
+            i, j, k, m, lij, ljk, lki, lim, lmj, lkm = (a[ok] for a in (i, j, k, m, lij, ljk, lki, lim, lmj, lkm))
+            if len(t) == 0:
+                break
+        g_jk = (glue_t[t, s_1].copy(), glue_s[t, s_1].copy()); g_ki = (glue_t[t, s_2].copy(), glue_s[t, s_2].copy())
+        g_im = (glue_t[t2, q_1].copy(), glue_s[t2, q_1].copy()); g_mj = (glue_t[t2, q_2].copy(), glue_s[t2, q_2].copy())
+        # new triangles: t = (k, i, m): k->i, i->m, m->k;   t2 = (m, j, k): m->j, j->k, k->m   (as in the sequential flip below)
+        T[t] = np.stack([k, i, m], axis=1); L[t] = np.stack([lki, lim, lkm], axis=1)
+        T[t2] = np.stack([m, j, k], axis=1); L[t2] = np.stack([lmj, ljk, lkm], axis=1)
+        for (ta, sa), (tb, sb) in (((t, 0), g_ki), ((t, 1), g_im), ((t2, 0), g_mj), ((t2, 1), g_jk)):
+            sa_ = np.full(len(ta), sa)
+            glue_t[ta, sa_], glue_s[ta, sa_] = tb, sb               # the neighbours are outside every flipped pair (independence)
+            glue_t[tb, sb], glue_s[tb, sb] = ta, sa_
+        two = np.full(len(t), 2)
+        glue_t[t, two], glue_s[t, two] = t2, two
+        glue_t[t2, two], glue_s[t2, two] = t, two
+        flips += len(t)
+    # 3b. whatever is left (pairs that touch themselves, the tail of a long flip sequence): one by one
     _, cot = _areas_and_cots(L)
     bad = cot + cot[glue_t, glue_s] < -1e-12
     stack = [(int(t), int(s)) for t, s in zip(*np.nonzero(bad))]
-    flips, limit = 0, (20 * nt if max_flips is None else max_flips)
 
     def cot_opp(t, s):
         a, b, c = L[t, s], L[t, (s + 1) % 3], L[t, (s + 2) % 3]
