@@ -419,9 +419,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // Interior tiles, D % 32 == 0, D >= 96: the main kernel, in two shapes (template WT = target quarters per workgroup):
 //   WT = 2: 4 waves, tile = 128 target x 256 source rows, ring of 3 stages (72 KiB) -> TWO workgroups per CU.  The two
 //           waves of a SIMD then belong to different workgroups: one workgroup's barrier / fragment-read bubbles and
-//           its whole reduction epilogue are covered by the other's MFMAs.  (default)
+//           its whole reduction epilogue are covered by the other's MFMAs.  (the four-map pass while a pair's operands fit an XCD's L2)
 //   WT = 4: 8 waves, tile = 256 x 256, ring of 4 stages (128 KiB), one workgroup per CU: a third less L2 -> LDS traffic,
-//           but both waves of a SIMD meet every barrier together and nothing covers the epilogue.
+//           but both waves of a SIMD meet every barrier together and nothing covers the epilogue.  (everything else)
 //
 // * Operands go L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs, no ds_write) through a ring of
 //   32-halves-deep stages; the DMA of stage g + NBUF - 1 is issued while stage g is computed and the wait before each
