@@ -34,6 +34,7 @@ SIGNATURES = {
     "dm_project": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
     "dm_fmap_c00": (_i, [_p, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_fmap_solve": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _d, _d, _p, _p]),
+    "dm_fmap_fit": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _d, _d, _p, _p]),
     "dm_fmap_energy_grad": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "dm_lbfgs_state_bytes": (C.c_size_t, [_i, _i, _i]),
     "dm_lbfgs_init": (_i, [_p, _i, _i, _i, _p, _p, _p]),
@@ -55,7 +56,7 @@ SIGNATURES = {
 }
 
 # the float64-basis forms (const double* Phi / mass): same argument lists
-for _n in ("dm_project", "dm_fmap_c00", "dm_fm_to_p2p", "dm_mapped_indicator", "dm_p2p_to_fm", "dm_precise_map", "dm_p2p_to_fm_lstsq", "dm_icp",
+for _n in ("dm_project", "dm_fmap_fit", "dm_fmap_c00", "dm_fm_to_p2p", "dm_mapped_indicator", "dm_p2p_to_fm", "dm_precise_map", "dm_p2p_to_fm_lstsq", "dm_icp",
            "dm_zoomout"):
     SIGNATURES[_n + "_f64"] = SIGNATURES[_n]
 

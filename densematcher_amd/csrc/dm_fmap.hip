@@ -859,15 +859,24 @@ __global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __
     if (lane == 0) Crow[0] = ci0;
 }
 
-extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const float* A, const float* Bm,
-                             const double* lam1, const double* lam2, const double* c00, double w_descr, double w_lap,
-                             double* C, int32_t* info) {
-    if (!ctx) return DM_EINVAL;
-    DM_REQUIRE(ctx, B > 0 && k1 > 0 && k2 > 0 && D > 0, "sizes must be positive");
-    DM_REQUIRE(ctx, A && Bm && lam1 && lam2 && c00 && C && info, "null pointer");
-    DM_REQUIRE(ctx, k1 <= 200, "k1 > 200 does not fit the in-LDS solver");
-    DM_REQUIRE(ctx, w_descr >= 0.0 && w_lap >= 0.0 && (w_descr > 0.0 || w_lap > 0.0), "weights must be >= 0 and not both 0");
-    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+// workspace of the closed-form solve (fmap_solve_core)
+static size_t fmap_solve_ws(const dm_ctx* ctx, int B, int k1, int k2) {
+    const size_t pq_bytes = (size_t)B * (k1 + k2) * k1 * 8;
+    const int n = k1 - 1, NB = (n + 15) / 16;
+    const bool two_phase = (NB == 12 || NB == 13) && !ctx->opt_solve_packed;
+    const bool blocked = ((n >= 1 && NB <= 11) && !ctx->opt_solve_packed) || two_phase;
+    const size_t img_bytes = blocked ? (size_t)B * (NB * (NB + 1) / 2) * 256 * 8 : 0;
+    const int NA = (NB + 1) / 2, grid2 = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    const size_t spill_bytes = two_phase ? (size_t)grid2 * (NA * (NA + 1) / 2) * 256 * 8 : 0;
+    return dm_align_up(pq_bytes) + dm_align_up(img_bytes) + dm_align_up(spill_bytes) + 4096;
+}
+
+// Gram matrices + the k2 solves per pair; OPA = the stacked rows [A; Bm], OPB = the rows of A (fp32 arrays, or the split-K
+// partials of the projections: dm_gemm_f64.h).  Workspace from what the caller reserved (fmap_solve_ws).
+template <class OPA, class OPB>
+static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA& opa, const OPB& opb,
+                           const double* lam1, const double* lam2, const double* c00, double w_descr, double w_lap,
+                           double* C, int32_t* info) {
     const size_t pq_bytes = (size_t)B * (k1 + k2) * k1 * 8;
     const int n = k1 - 1;
     const int NB = (n + 15) / 16;
@@ -877,8 +886,7 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     const int NA = (NB + 1) / 2;
     const int grid2 = ctx->n_cu > 0 ? ctx->n_cu : 256;
     const size_t spill_bytes = two_phase ? (size_t)grid2 * (NA * (NA + 1) / 2) * 256 * 8 : 0;
-    int rc = dm_ws_reserve(ctx, dm_align_up(pq_bytes) + dm_align_up(img_bytes) + dm_align_up(spill_bytes) + 4096);
-    if (rc) return rc;
+    int rc = DM_OK;
     double* PQ = (double*)dm_ws_take(ctx, pq_bytes);
     double* Timg = blocked ? (double*)dm_ws_take(ctx, img_bytes) : nullptr;
     double* spill = two_phase ? (double*)dm_ws_take(ctx, spill_bytes) : nullptr;
@@ -886,12 +894,9 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     if (blocked) DM_CHECK_HIP(ctx, hipMemsetAsync(Timg, 0, img_bytes, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
 
-    KRowsStackedF32 opa{A, Bm, k1, k2, D};
-    KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
     OutScaled out{PQ, (long long)(k1 + k2) * k1, k1, w_descr, Timg, (long long)(NB * (NB + 1) / 2) * 256, k1};
     dim3 grid(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
-    DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutScaled>), grid, dim3(256), 0, opa, opb, out,
-              k1 + k2, k1, D);
+    DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D);
 
     if (two_phase) {
         const int NBr = NB - NA;
@@ -937,4 +942,75 @@ extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const fl
     DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_kernel, dim3(k2, B), dim3(SP_NT), lds, PQ, lam1, lam2, c00, w_lap, k1, k2,
               C, info, dm_knob("DM_SOLVE_DEBUG", 0));
     return DM_OK;
+}
+
+extern "C" int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D, const float* A, const float* Bm,
+                             const double* lam1, const double* lam2, const double* c00, double w_descr, double w_lap,
+                             double* C, int32_t* info) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && k1 > 0 && k2 > 0 && D > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, A && Bm && lam1 && lam2 && c00 && C && info, "null pointer");
+    DM_REQUIRE(ctx, k1 <= 200, "k1 > 200 does not fit the in-LDS solver");
+    DM_REQUIRE(ctx, w_descr >= 0.0 && w_lap >= 0.0 && (w_descr > 0.0 || w_lap > 0.0), "weights must be >= 0 and not both 0");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = dm_ws_reserve(ctx, fmap_solve_ws(ctx, B, k1, k2));
+    if (rc) return rc;
+    KRowsStackedF32 opa{A, Bm, k1, k2, D};
+    KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
+    return fmap_solve_core(ctx, B, k1, k2, D, opa, opb, lam1, lam2, c00, w_descr, w_lap, C, info);
+}
+
+// =================================================================================================
+// dm_fmap_fit: FunctionalMapping.fit with the two quadratic terms in ONE call (projections, pinned column, Gram, solves)
+// =================================================================================================
+template <typename TR>
+static int fmap_fit_impl(dm_ctx* ctx, int B, int N1, int N2, int D, int k1, int k2, const TR* Phi1, int ld1, const TR* Phi2, int ld2,
+                         const TR* mass1, const TR* mass2, const void* F1, const void* F2, const double* lam1, const double* lam2,
+                         double w_descr, double w_lap, double* C, int32_t* info) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && D > 0 && k1 > 0 && k2 > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && mass2 && F1 && F2 && lam1 && lam2 && C && info, "null pointer");
+    DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than k");
+    DM_REQUIRE(ctx, k1 <= 200, "k1 > 200 does not fit the in-LDS solver");
+    DM_REQUIRE(ctx, w_descr >= 0.0 && w_lap >= 0.0 && (w_descr > 0.0 || w_lap > 0.0), "weights must be >= 0 and not both 0");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bA = (size_t)B * k1 * D * 4, bB = (size_t)B * k2 * D * 4;
+    int rc = dm_ws_reserve(ctx, dm_project_f16split_ws(B, N1, D, k1, ld1, (int)sizeof(TR)) + dm_project_f16split_ws(B, N2, D, k2, ld2, (int)sizeof(TR)) +
+                                    dm_align_up(bA) + dm_align_up(bB) + dm_align_up((size_t)B * 8) + fmap_solve_ws(ctx, B, k1, k2) + 8192);
+    if (rc) return rc;
+    double* c00 = (double*)dm_ws_take(ctx, (size_t)B * 8);
+    if (!c00) return dm_fail(ctx, DM_ENOMEM, "fmap_fit: workspace not reserved");
+    // the projections leave their split-K partials where they are when there are at most two of them: the Gram kernel adds them
+    // up as it reads (same values as the reduce kernel would store); more chunks are reduced first
+    const bool lazy = dm_cdiv(N1, 1024) <= 2 && dm_cdiv(N2, 1024) <= 2;
+    float* A = lazy ? nullptr : (float*)dm_ws_take(ctx, bA);
+    float* Bm = lazy ? nullptr : (float*)dm_ws_take(ctx, bB);
+    if (!lazy && (!A || !Bm)) return dm_fail(ctx, DM_ENOMEM, "fmap_fit: workspace not reserved");
+    const float* pA = nullptr; const float* pB = nullptr;
+    int nsA = 1, nsB = 1;
+    rc = dm_project_f16split_launch<TR>(ctx, B, N1, D, k1, Phi1, ld1, mass1, F1, A, &pA, &nsA);
+    if (rc) return rc;
+    rc = dm_project_f16split_launch<TR>(ctx, B, N2, D, k2, Phi2, ld2, mass2, F2, Bm, &pB, &nsB);
+    if (rc) return rc;
+    DM_LAUNCH(ctx, "c00", c00_kernel<TR>, dim3(B), dim3(256), 0, Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2,
+              N1, N2, c00);
+    if (lazy) {
+        const long long sA = nsA == 2 ? (long long)B * k1 * D : 0, sB = nsB == 2 ? (long long)B * k2 * D : 0;
+        KRowsStackedPart opa{pA, pB, sA, sB, k1, k2, D};
+        KRowsPart opb{pA, sA, k1, D};
+        return fmap_solve_core(ctx, B, k1, k2, D, opa, opb, lam1, lam2, c00, w_descr, w_lap, C, info);
+    }
+    KRowsStackedF32 opa{A, Bm, k1, k2, D};
+    KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
+    return fmap_solve_core(ctx, B, k1, k2, D, opa, opb, lam1, lam2, c00, w_descr, w_lap, C, info);
+}
+extern "C" int dm_fmap_fit(dm_ctx* ctx, int B, int N1, int N2, int D, int k1, int k2, const float* Phi1, int ld1, const float* Phi2,
+                           int ld2, const float* mass1, const float* mass2, const void* F1, const void* F2, const double* lam1,
+                           const double* lam2, double w_descr, double w_lap, double* C, int32_t* info) {
+    return fmap_fit_impl<float>(ctx, B, N1, N2, D, k1, k2, Phi1, ld1, Phi2, ld2, mass1, mass2, F1, F2, lam1, lam2, w_descr, w_lap, C, info);
+}
+extern "C" int dm_fmap_fit_f64(dm_ctx* ctx, int B, int N1, int N2, int D, int k1, int k2, const double* Phi1, int ld1,
+                               const double* Phi2, int ld2, const double* mass1, const double* mass2, const void* F1, const void* F2,
+                               const double* lam1, const double* lam2, double w_descr, double w_lap, double* C, int32_t* info) {
+    return fmap_fit_impl<double>(ctx, B, N1, N2, D, k1, k2, Phi1, ld1, Phi2, ld2, mass1, mass2, F1, F2, lam1, lam2, w_descr, w_lap, C, info);
 }

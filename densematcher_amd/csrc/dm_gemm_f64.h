@@ -361,6 +361,69 @@ struct KRowsStackedF32 {
     }
 };
 
+// The same two operands read from the split-K partials of the projections (dm_project.hip), BEFORE their reduction: the value
+// of an entry is float(double(p0) + double(p1)) -- exactly what the reduce kernel would have stored -- formed when the staged
+// pair is written to LDS (staging keeps the two floats as loaded).  Saves the reduce launches and their round trip through
+// HBM when a caller does not need the projected descriptors themselves (dm_fmap_fit).  One or two chunks per operand: the
+// stride to the second chunk is 0 when there is only one (its entries are then the stored values themselves).
+struct PartPair {
+    float p0, p1;
+    __device__ __forceinline__ operator double() const { return (double)(float)((double)p0 + (double)p1); }
+};
+struct KRowsStackedPart {
+    typedef PartPair elem_t;
+    const float* A; const float* Bm; long long nA, nB;     // second chunk of A at A + nA (= B k1 D; 0: none), of Bm at Bm + nB
+    int k1, k2, D;
+    __device__ __forceinline__ void load8(int b, int row, int k0, PartPair (&v)[8]) const {
+        const bool in = row < k1 + k2;
+        const int rc = in ? row : 0;
+        const bool isA = rc < k1;
+        const float* r = isA ? A + ((long long)b * k1 + rc) * D : Bm + ((long long)b * k2 + (rc - k1)) * D;
+        const long long nq = isA ? nA : nB;
+        const bool two = nq != 0;
+        if (k0 + 7 < D && ((D & 3) == 0) && (((((uintptr_t)A) | ((uintptr_t)Bm)) & 15) == 0) && ((nA | nB) & 3) == 0) {
+            const f32x4 a0 = *(dm_gf32x4*)(r + k0), a1 = *(dm_gf32x4*)(r + k0 + 4);
+            const f32x4 b0 = *(dm_gf32x4*)(r + nq + k0), b1 = *(dm_gf32x4*)(r + nq + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = PartPair{in ? a0[e] : 0.0f, (in && two) ? b0[e] : 0.0f};
+                v[4 + e] = PartPair{in ? a1[e] : 0.0f, (in && two) ? b1[e] : 0.0f};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = in && k0 + e < D;
+                v[e] = PartPair{ok ? r[k0 + e] : 0.0f, (ok && two) ? r[nq + k0 + e] : 0.0f};
+            }
+        }
+    }
+};
+struct KRowsPart {                                         // the rows of A alone (the second operand of the Gram product)
+    typedef PartPair elem_t;
+    const float* A; long long nA; int k1, D;               // nA: stride to the second chunk, 0: none
+    __device__ __forceinline__ void load8(int b, int row, int k0, PartPair (&v)[8]) const {
+        const bool in = row < k1;
+        const float* r = A + ((long long)b * k1 + min(row, k1 - 1)) * D;
+        const long long nq = nA;
+        const bool two = nq != 0;
+        if (k0 + 7 < D && ((D & 3) == 0) && ((((uintptr_t)A) & 15) == 0) && (nA & 3) == 0) {
+            const f32x4 a0 = *(dm_gf32x4*)(r + k0), a1 = *(dm_gf32x4*)(r + k0 + 4);
+            const f32x4 b0 = *(dm_gf32x4*)(r + nq + k0), b1 = *(dm_gf32x4*)(r + nq + k0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = PartPair{in ? a0[e] : 0.0f, (in && two) ? b0[e] : 0.0f};
+                v[4 + e] = PartPair{in ? a1[e] : 0.0f, (in && two) ? b1[e] : 0.0f};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = in && k0 + e < D;
+                v[e] = PartPair{ok ? r[k0 + e] : 0.0f, (ok && two) ? r[nq + k0 + e] : 0.0f};
+            }
+        }
+    }
+};
+
 // K-contiguous rows of a float64 matrix (B, nrows, ld); `trans` reads element (row,k) at p[k*ld + row]
 struct KRowsF64 {
     const double* p; long long stride_b; int ld; int nrows; int ncols; int trans;

@@ -227,6 +227,10 @@ int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, cons
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2);
 
 // fp16 split-operand MFMA projection (dm_project.hip); F must be fp16
+size_t dm_project_f16split_ws(int B, int N, int D, int k, int ld, int real_bytes);
+template <typename TR>
+int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass, const void* F,
+                               float* Ared, const float** partial_out, int* nsplit_out);
 template <typename TR>
 int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
                         const void* F, float* Ared);

@@ -291,9 +291,19 @@ __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restric
     out[i] = (float)s;
 }
 
+// workspace of one projection (dm_project_f16split_launch)
+size_t dm_project_f16split_ws(int B, int N, int D, int k, int ld, int real_bytes) {
+    const int nsplit = dm_cdiv(N, 1024);
+    return dm_align_up((size_t)nsplit * B * k * D * 4) + dm_align_up((size_t)B * 64 * 4) + 4096 +
+           (real_bytes == 8 ? dm_align_up((size_t)B * N * ld * 4) + dm_align_up((size_t)B * N * 4) : 0);
+}
+
+// The launches of one projection, workspace taken from what the caller reserved.  Ared != null: the split-K partials are
+// reduced into it.  Ared == null: they are left as they are, *partial_out (nsplit, B, k, D) / *nsplit_out tell where (dm_fmap_fit
+// hands them to the Gram kernel, which adds them up as it reads).
 template <typename TR>
-int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
-                        const void* F, float* Ared) {
+int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
+                               const void* F, float* Ared, const float** partial_out, int* nsplit_out) {
     proj_params<TR> p;
     p.Phi = Phi; p.mass = mass; p.F = (const _Float16*)F;
     p.B = B; p.N = N; p.D = D; p.k = k; p.ld = ld;
@@ -304,12 +314,11 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, 
     p.nsplit = nsplit;
     if ((long long)N * ld >= (1ll << 31)) return dm_fail(ctx, DM_EINVAL, "dm_project: N * ld must be below 2^31");
     const size_t pbytes = (size_t)nsplit * B * k * D * 4;
-    int rc = dm_ws_reserve(ctx, dm_align_up(pbytes) + (size_t)B * 64 * 4 + 4096 +
-                                    (sizeof(TR) == 8 ? dm_align_up((size_t)B * N * ld * 4) + dm_align_up((size_t)B * N * 4) : 0));
-    if (rc) return rc;
+    int rc = DM_OK;
     p.partial = (float*)dm_ws_take(ctx, pbytes);
     const int n_part = max(1, min(64, (int)(((long long)N * ld) / 4096)));
     float* amax_part = (float*)dm_ws_take(ctx, (size_t)B * n_part * 4);
+    if (!p.partial || !amax_part) return dm_fail(ctx, DM_ENOMEM, "dm_project: workspace not reserved");
     p.amax_part = amax_part; p.n_part = n_part;
     const size_t lds = (size_t)2 * PSTAGE * sizeof(_Float16);
     if constexpr (sizeof(TR) == 8) {
@@ -331,10 +340,24 @@ int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, 
         if (rc) return rc;
         DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel<TR>, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), lds, p);
     }
-    const long long n = (long long)B * k * D;
-    DM_LAUNCH(ctx, "project_reduce", proj_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.partial, nsplit, n,
-              Ared);
+    if (partial_out) *partial_out = p.partial;
+    if (nsplit_out) *nsplit_out = nsplit;
+    if (Ared) {
+        const long long n = (long long)B * k * D;
+        DM_LAUNCH(ctx, "project_reduce", proj_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p.partial, nsplit, n,
+                  Ared);
+    }
     return DM_OK;
+}
+template int dm_project_f16split_launch<float>(dm_ctx*, int, int, int, int, const float*, int, const float*, const void*, float*, const float**, int*);
+template int dm_project_f16split_launch<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, const void*, float*, const float**, int*);
+
+template <typename TR>
+int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
+                        const void* F, float* Ared) {
+    int rc = dm_ws_reserve(ctx, dm_project_f16split_ws(B, N, D, k, ld, (int)sizeof(TR)));
+    if (rc) return rc;
+    return dm_project_f16split_launch<TR>(ctx, B, N, D, k, Phi, ld, mass, F, Ared, nullptr, nullptr);
 }
 template int dm_project_f16split<float>(dm_ctx*, int, int, int, int, const float*, int, const float*, const void*, float*);
 template int dm_project_f16split<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, const void*, float*);

@@ -176,6 +176,35 @@ class MatchEngine:
         self._chk(getattr(self.lib, "dm_fmap_c00" + sfx)(self.ctx, B, N1, N2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(a2), _ptr(out)))
         return out
 
+    def fmap_fit(self, Phi1, Phi2, a1, a2, F1, F2, lam1, lam2, w_descr, w_lap, k1=None, k2=None, check=True):
+        """project(mesh 1) + project(mesh 2) + c00 + fmap_solve in one library call (dm_fmap_fit): the same C bit for bit; the
+        projected descriptors are not returned.  fp16 descriptors."""
+        sfx, Phi1, Phi2, a1, a2 = self._reals(Phi1, Phi2, a1, a2)
+        F1 = self._dev(F1, torch.float16, "F1")
+        F2 = self._dev(F2, torch.float16, "F2")
+        lam1 = self._dev(lam1, torch.float64, "lam1")
+        lam2 = self._dev(lam2, torch.float64, "lam2")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        k1 = lam1.shape[1] if k1 is None else k1
+        k2 = lam2.shape[1] if k2 is None else k2
+        D = F1.shape[2]
+        if (F1.shape[:2] != (B, N1) or F2.shape != (B, N2, D) or a1.shape != (B, N1) or a2.shape != (B, N2) or lam1.shape != (B, k1)
+                or lam2.shape != (B, k2)):
+            raise ValueError("fmap_fit: shapes do not agree")
+        Cm = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        info = torch.empty((B,), dtype=torch.int32, device=self.device)
+        self._chk(getattr(self.lib, "dm_fmap_fit" + sfx)(self.ctx, B, N1, N2, D, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(a2),
+                                                         _ptr(F1), _ptr(F2), _ptr(lam1), _ptr(lam2), float(w_descr), float(w_lap),
+                                                         _ptr(Cm), _ptr(info)))
+        if check:
+            bad = torch.nonzero(info).flatten()
+            if bad.numel():
+                raise _lib.DenseMatchError(
+                    f"functional-map system not positive definite for pairs {bad.tolist()[:8]} "
+                    f"(row {int(info[bad[0]]) - 1}): descriptors are rank deficient in the basis and w_lap cannot fix it")
+        return Cm
+
     def fmap_solve(self, A, Bm, lam1, lam2, c00, w_descr, w_lap, check=True):
         """Closed-form minimiser of the w_descr / w_lap energy -> C (B,k2,k1) f64."""
         A = self._dev(A, torch.float32, "A")
@@ -542,12 +571,15 @@ class MatchEngine:
         Phi1, Phi2 = batch["Phi1"], batch["Phi2"]
         k1 = k if k is not None else batch["lam1"].shape[1]
         k2 = k if k is not None else batch["lam2"].shape[1]
-        A = self.project(Phi1, batch["a1"], batch["F1"], k1)
-        Bm = self.project(Phi2, batch["a2"], batch["F2"], k2)
-        c00 = self.c00(Phi1, Phi2, batch["a1"], batch["a2"])
         lam1 = batch["lam1"][:, :k1].contiguous()
         lam2 = batch["lam2"][:, :k2].contiguous()
-        Cm = self.fmap_solve(A, Bm, lam1, lam2, c00, w_descr, w_lap, check=check)
+        if batch["F1"].dtype == torch.float16 and batch["F2"].dtype == torch.float16:
+            Cm = self.fmap_fit(Phi1, Phi2, batch["a1"], batch["a2"], batch["F1"], batch["F2"], lam1, lam2, w_descr, w_lap, k1, k2, check=check)
+        else:
+            A = self.project(Phi1, batch["a1"], batch["F1"], k1)
+            Bm = self.project(Phi2, batch["a2"], batch["F2"], k2)
+            c00 = self.c00(Phi1, Phi2, batch["a1"], batch["a2"])
+            Cm = self.fmap_solve(A, Bm, lam1, lam2, c00, w_descr, w_lap, check=check)
         out = self.fm_to_p2p(Phi1, Phi2, batch["a1"], Cm, knn=knn, ind=ind)
         out["C"] = Cm
         return out

@@ -156,6 +156,21 @@ int dm_fmap_solve(dm_ctx* ctx, int B, int k1, int k2, int D,
                   const double* lam1, const double* lam2, const double* c00,
                   double w_descr, double w_lap, double* C, int32_t* info);
 
+/* The same fit in ONE call: FunctionalMapping.fit with w_descr, w_lap > 0 and every other weight 0
+ * (pyFM/functional.py:352-487) = the two projections (dm_project), the pinned column (dm_fmap_c00) and dm_fmap_solve.
+ * Same C, bit for bit, as the three calls; the projected descriptors are not returned, which lets the library skip their
+ * split-K reduction pass (the Gram kernel adds the chunks up as it reads them).  F1 (B,N1,D), F2 (B,N2,D) fp16. */
+int dm_fmap_fit(dm_ctx* ctx, int B, int N1, int N2, int D, int k1, int k2,
+                const float* Phi1, int ld1, const float* Phi2, int ld2,
+                const float* mass1, const float* mass2, const void* F1, const void* F2,
+                const double* lam1, const double* lam2, double w_descr, double w_lap,
+                double* C, int32_t* info);
+int dm_fmap_fit_f64(dm_ctx* ctx, int B, int N1, int N2, int D, int k1, int k2,
+                    const double* Phi1, int ld1, const double* Phi2, int ld2,
+                    const double* mass1, const double* mass2, const void* F1, const void* F2,
+                    const double* lam1, const double* lam2, double w_descr, double w_lap,
+                    double* C, int32_t* info);
+
 /* ---- general functional-map energy and gradient -----------------------------------
  * What scipy's L-BFGS-B evaluates in FunctionalMapping.fit when energy terms beyond w_descr / w_lap are switched on:
  * replaces energy_func_std / grad_energy_std (pyFM/optimize/base_functions.py:480-763) for the terms

@@ -361,6 +361,28 @@ def test_fuzz_fm_to_p2p(eng):
     run()
 
 
+@pytest.mark.parametrize("B,N1,N2,D,k1,k2,dt", [(2, 2048, 2048, 256, 128, 128, np.float64), (3, 1500, 900, 128, 40, 33, np.float32),
+                                                (1, 700, 2500, 64, 17, 50, np.float64), (2, 4100, 800, 96, 30, 30, np.float32)])
+def test_fmap_fit_equals_the_three_calls(eng, B, N1, N2, D, k1, k2, dt):
+    """dm_fmap_fit (one call; the Gram kernel adds up the projections' split-K chunks as it reads them) returns the same C,
+    bit for bit, as dm_project x 2 + dm_fmap_c00 + dm_fmap_solve; one, two and more chunks per operand"""
+    rng = np.random.default_rng(N1 + N2)
+    Phi1 = (rng.standard_normal((B, N1, k1)) * 0.05).astype(dt)
+    Phi2 = (rng.standard_normal((B, N2, k2)) * 0.05).astype(dt)
+    a1 = (rng.uniform(0.5, 1.5, (B, N1)) / N1).astype(dt)
+    a2 = (rng.uniform(0.5, 1.5, (B, N2)) / N2).astype(dt)
+    F1 = rng.standard_normal((B, N1, D)).astype(np.float16)
+    F2 = rng.standard_normal((B, N2, D)).astype(np.float16)
+    lam1 = np.sort(rng.uniform(0, 50, (B, k1)), axis=1); lam1[:, 0] = 0
+    lam2 = np.sort(rng.uniform(0, 60, (B, k2)), axis=1); lam2[:, 0] = 0
+    A = eng.project(Phi1, a1, F1, k1)
+    Bm = eng.project(Phi2, a2, F2, k2)
+    c00 = eng.c00(Phi1, Phi2, a1, a2)
+    want = _np(eng.fmap_solve(A, Bm, lam1, lam2, c00, 1e4, 1e3))
+    got = _np(eng.fmap_fit(Phi1, Phi2, a1, a2, F1, F2, lam1, lam2, 1e4, 1e3))
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+
+
 def test_fuzz_fm_to_p2p_split_sizes(eng):
     """the fp16 split path on arbitrary mesh sizes (padded operands, masked edge strips, both tile shapes) against the float64 G
     kernel: identical maps"""
