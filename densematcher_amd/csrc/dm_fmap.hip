@@ -89,28 +89,9 @@ extern "C" int dm_project_f64(dm_ctx* ctx, int B, int N, int D, int k, const dou
 // dm_fmap_c00: sign(Phi1[0,0] Phi2[0,0]) sqrt(area2 / area1)          pyFM/functional.py:654-658
 // =================================================================================================
 template <typename TR>
-__global__ __launch_bounds__(256) void c00_kernel(const TR* __restrict__ Phi1, long long s1, const TR* __restrict__ Phi2,
-                                                  long long s2, const TR* __restrict__ mass1, const TR* __restrict__ mass2,
-                                                  int N1, int N2, double* __restrict__ c00) {
+__global__ __launch_bounds__(256) void c00_kernel(dm_c00_args<TR> z) {
     __shared__ double red[2][4];
-    const int b = blockIdx.x, t = threadIdx.x;
-    double a1 = 0.0, a2 = 0.0;
-    for (int i = t; i < N1; i += 256) a1 += (double)mass1[(long long)b * N1 + i];
-    for (int i = t; i < N2; i += 256) a2 += (double)mass2[(long long)b * N2 + i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a1 += __shfl_xor(a1, off);
-        a2 += __shfl_xor(a2, off);
-    }
-    if ((t & 63) == 0) { red[0][t >> 6] = a1; red[1][t >> 6] = a2; }
-    __syncthreads();
-    if (t == 0) {
-        const double area1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const double area2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        const double pr = (double)Phi1[b * s1] * (double)Phi2[b * s2];
-        const double sgn = (pr > 0.0) ? 1.0 : ((pr < 0.0) ? -1.0 : 0.0);      // np.sign
-        c00[b] = sgn * sqrt(area2 / area1);
-    }
+    dm_c00_body<TR>(z, blockIdx.x, threadIdx.x, red);
 }
 
 template <typename TR>
@@ -120,8 +101,8 @@ static int c00_impl(dm_ctx* ctx, int B, int N1, int N2, const TR* Phi1, int ld1,
     DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && ld1 > 0 && ld2 > 0, "sizes must be positive");
     DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && mass2 && c00, "null pointer");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    DM_LAUNCH(ctx, "c00", c00_kernel<TR>, dim3(B), dim3(256), 0, Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2,
-              N1, N2, c00);
+    DM_LAUNCH(ctx, "c00", c00_kernel<TR>, dim3(B), dim3(256), 0,
+              (dm_c00_args<TR>{Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2, N1, N2, c00}));
     return DM_OK;
 }
 extern "C" int dm_fmap_c00(dm_ctx* ctx, int B, int N1, int N2, const float* Phi1, int ld1, const float* Phi2, int ld2,
@@ -990,10 +971,10 @@ static int fmap_fit_impl(dm_ctx* ctx, int B, int N1, int N2, int D, int k1, int 
     int nsA = 1, nsB = 1;
     rc = dm_project_f16split_launch<TR>(ctx, B, N1, D, k1, Phi1, ld1, mass1, F1, A, &pA, &nsA);
     if (rc) return rc;
-    rc = dm_project_f16split_launch<TR>(ctx, B, N2, D, k2, Phi2, ld2, mass2, F2, Bm, &pB, &nsB);
+    // (the pinned column's entry comes out of the second projection's maxima pass: one more workgroup per pair, no launch)
+    const dm_c00_args<TR> cz{Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2, N1, N2, c00};
+    rc = dm_project_f16split_launch<TR>(ctx, B, N2, D, k2, Phi2, ld2, mass2, F2, Bm, &pB, &nsB, &cz);
     if (rc) return rc;
-    DM_LAUNCH(ctx, "c00", c00_kernel<TR>, dim3(B), dim3(256), 0, Phi1, (long long)N1 * ld1, Phi2, (long long)N2 * ld2, mass1, mass2,
-              N1, N2, c00);
     if (lazy) {
         const long long sA = nsA == 2 ? (long long)B * k1 * D : 0, sB = nsB == 2 ? (long long)B * k2 * D : 0;
         KRowsStackedPart opa{pA, pB, sA, sB, k1, k2, D};

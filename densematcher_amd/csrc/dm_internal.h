@@ -226,11 +226,41 @@ int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, cons
                         double* C, int ldc, long long strideC);
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2);
 
+// dm_fmap_c00: sign(Phi1[0,0] Phi2[0,0]) sqrt(area2 / area1) per pair (pyFM/functional.py:654-658).  One workgroup of 256
+// threads per pair; also run as an extra workgroup of a projection's maxima pass (dm_fmap_fit), same arithmetic.
+template <typename TR>
+struct dm_c00_args {
+    const TR* Phi1; long long s1; const TR* Phi2; long long s2; const TR* mass1; const TR* mass2; int N1, N2; double* c00;
+};
+#ifdef __HIPCC__
+template <typename TR>
+__device__ __forceinline__ void dm_c00_body(const dm_c00_args<TR>& z, int b, int t, double (&red)[2][4]) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = t; i < z.N1; i += 256) a1 += (double)z.mass1[(long long)b * z.N1 + i];
+    for (int i = t; i < z.N2; i += 256) a2 += (double)z.mass2[(long long)b * z.N2 + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a1 += __shfl_xor(a1, off);
+        a2 += __shfl_xor(a2, off);
+    }
+    if ((t & 63) == 0) { red[0][t >> 6] = a1; red[1][t >> 6] = a2; }
+    __syncthreads();
+    if (t == 0) {
+        const double area1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const double area2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double pr = (double)z.Phi1[b * z.s1] * (double)z.Phi2[b * z.s2];
+        const double sgn = (pr > 0.0) ? 1.0 : ((pr < 0.0) ? -1.0 : 0.0);      // np.sign
+        z.c00[b] = sgn * sqrt(area2 / area1);
+    }
+}
+#endif
+
 // fp16 split-operand MFMA projection (dm_project.hip); F must be fp16
 size_t dm_project_f16split_ws(int B, int N, int D, int k, int ld, int real_bytes);
+// cz (nullable): the maxima pass of this projection also computes the pinned entries c00 of the pairs (one more workgroup each)
 template <typename TR>
 int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass, const void* F,
-                               float* Ared, const float** partial_out, int* nsplit_out);
+                               float* Ared, const float** partial_out, int* nsplit_out, const dm_c00_args<TR>* cz = nullptr);
 template <typename TR>
 int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
                         const void* F, float* Ared);

@@ -54,8 +54,13 @@ __device__ __forceinline__ f16x8 tr_frag(const _Float16* base, int row0, int col
 template <typename TR>
 __global__ __launch_bounds__(256) void proj_absmax_kernel(const TR* __restrict__ Phi, const TR* __restrict__ mass, int N,
                                                           int ld, float* __restrict__ amax_part, float* __restrict__ phi32,
-                                                          float* __restrict__ mass32) {
+                                                          float* __restrict__ mass32, int n_part, dm_c00_args<TR> cz) {
     const int b = blockIdx.y;
+    if ((int)blockIdx.x >= n_part) {                          // (uniform) the extra workgroup of dm_fmap_fit: the pair's c00
+        __shared__ double red[2][4];
+        dm_c00_body<TR>(cz, b, threadIdx.x, red);
+        return;
+    }
     const TR* P = Phi + (long long)b * N * ld;
     const TR* a = mass + (long long)b * N;
     const unsigned total = (unsigned)N * (unsigned)ld;           // < 2^31 per pair (checked by the caller)
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256) void proj_absmax_kernel(const TR* __restrict__
         // each workgroup streams contiguous 16 KiB chunks (4 consecutive float4 per lane would be 64 B per lane; the
         // four loads of a lane are 4 KiB apart inside the chunk so that every wave instruction is one contiguous KiB):
         // large power-of-two strides between the loads in flight camp on a few HBM channels
-        for (unsigned c0 = blockIdx.x * 1024; c0 < nvec; c0 += gridDim.x * 1024) {
+        for (unsigned c0 = blockIdx.x * 1024; c0 < nvec; c0 += n_part * 1024) {
             float4 v[4];
             float an[4];
 #pragma unroll
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(256) void proj_absmax_kernel(const TR* __restrict__
     } else if (sizeof(TR) == 8 && ((ld & 1) == 0) && ((((uintptr_t)Phi) & 15) == 0)) {
         const unsigned nvec = total >> 1, ld2 = (unsigned)ld >> 1;
         const f64x2* P2 = reinterpret_cast<const f64x2*>(P);
-        for (unsigned c0 = blockIdx.x * 1024; c0 < nvec; c0 += gridDim.x * 1024) {
+        for (unsigned c0 = blockIdx.x * 1024; c0 < nvec; c0 += n_part * 1024) {
             f64x2 v[4];
             float an[4];
 #pragma unroll
@@ -102,13 +107,13 @@ __global__ __launch_bounds__(256) void proj_absmax_kernel(const TR* __restrict__
             }
         }
     } else {
-        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < total; e += n_part * 256) {
             m = fmaxf(m, fabsf((float)a[e / (unsigned)ld]) * fabsf((float)P[e]));
             if (sizeof(TR) == 8 && phi32) phi32[(long long)b * N * ld + e] = (float)P[e];
         }
     }
     if (sizeof(TR) == 8 && mass32) {
-        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < (unsigned)N; e += gridDim.x * 256) mass32[(long long)b * N + e] = (float)a[e];
+        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < (unsigned)N; e += n_part * 256) mass32[(long long)b * N + e] = (float)a[e];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void proj_absmax_kernel(const TR* __restrict__
     __shared__ float wmax[4];
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) amax_part[b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (threadIdx.x == 0) amax_part[b * n_part + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
 }
 
 template <typename TR>
@@ -303,7 +308,7 @@ size_t dm_project_f16split_ws(int B, int N, int D, int k, int ld, int real_bytes
 // hands them to the Gram kernel, which adds them up as it reads).
 template <typename TR>
 int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
-                               const void* F, float* Ared, const float** partial_out, int* nsplit_out) {
+                               const void* F, float* Ared, const float** partial_out, int* nsplit_out, const dm_c00_args<TR>* cz) {
     proj_params<TR> p;
     p.Phi = Phi; p.mass = mass; p.F = (const _Float16*)F;
     p.B = B; p.N = N; p.D = D; p.k = k; p.ld = ld;
@@ -326,7 +331,8 @@ int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR
         float* phi32 = (float*)dm_ws_take(ctx, (size_t)B * N * ld * 4);
         float* mass32 = (float*)dm_ws_take(ctx, (size_t)B * N * 4);
         if (!phi32 || !mass32) return dm_fail(ctx, DM_ENOMEM, "dm_project: workspace not reserved");
-        DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel<TR>, dim3(n_part, B), dim3(256), 0, Phi, mass, N, ld, amax_part, phi32, mass32);
+        DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel<TR>, dim3(n_part + (cz ? 1 : 0), B), dim3(256), 0, Phi, mass, N, ld, amax_part, phi32,
+                  mass32, n_part, cz ? *cz : dm_c00_args<TR>{});
         proj_params<float> pf;
         pf.Phi = phi32; pf.mass = mass32; pf.F = p.F; pf.amax_part = p.amax_part; pf.n_part = p.n_part; pf.partial = p.partial;
         pf.B = B; pf.N = N; pf.D = D; pf.k = k; pf.ld = ld; pf.nsplit = p.nsplit; pf.kchunk = p.kchunk; pf.tiles_m = p.tiles_m; pf.tiles_d = p.tiles_d;
@@ -334,8 +340,8 @@ int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR
         if (rc) return rc;
         DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel<float>, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), lds, pf);
     } else {
-        DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel<TR>, dim3(n_part, B), dim3(256), 0, Phi, mass, N, ld, amax_part, (float*)nullptr,
-                  (float*)nullptr);
+        DM_LAUNCH(ctx, "project_absmax", proj_absmax_kernel<TR>, dim3(n_part + (cz ? 1 : 0), B), dim3(256), 0, Phi, mass, N, ld, amax_part,
+                  (float*)nullptr, (float*)nullptr, n_part, cz ? *cz : dm_c00_args<TR>{});
         rc = dm_grant_lds(ctx, (const void*)proj_f16split_kernel<TR>, lds);
         if (rc) return rc;
         DM_LAUNCH(ctx, "project_f16split_mfma", proj_f16split_kernel<TR>, dim3(p.tiles_m * p.tiles_d * nsplit * B), dim3(256), lds, p);
@@ -349,15 +355,17 @@ int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR
     }
     return DM_OK;
 }
-template int dm_project_f16split_launch<float>(dm_ctx*, int, int, int, int, const float*, int, const float*, const void*, float*, const float**, int*);
-template int dm_project_f16split_launch<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, const void*, float*, const float**, int*);
+template int dm_project_f16split_launch<float>(dm_ctx*, int, int, int, int, const float*, int, const float*, const void*, float*, const float**, int*,
+                                               const dm_c00_args<float>*);
+template int dm_project_f16split_launch<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, const void*, float*, const float**, int*,
+                                                const dm_c00_args<double>*);
 
 template <typename TR>
 int dm_project_f16split(dm_ctx* ctx, int B, int N, int D, int k, const TR* Phi, int ld, const TR* mass,
                         const void* F, float* Ared) {
     int rc = dm_ws_reserve(ctx, dm_project_f16split_ws(B, N, D, k, ld, (int)sizeof(TR)));
     if (rc) return rc;
-    return dm_project_f16split_launch<TR>(ctx, B, N, D, k, Phi, ld, mass, F, Ared, nullptr, nullptr);
+    return dm_project_f16split_launch<TR>(ctx, B, N, D, k, Phi, ld, mass, F, Ared, nullptr, nullptr, nullptr);
 }
 template int dm_project_f16split<float>(dm_ctx*, int, int, int, int, const float*, int, const float*, const void*, float*);
 template int dm_project_f16split<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, const void*, float*);
