@@ -56,6 +56,43 @@ __device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (double)hi);
 }
 
+// Per-row terms of a key-set pass: bias[j] = fp32(-nrm_j sx sy / 2) and its per-pair maximum (atomicMax on float bits, zeroed by
+// the caller); with `mass`: its fp32 rounding scale32 (key B's per-source factor -- the rounding is part of the key's error
+// bound, dm_simnn_core) and the maximum of the ROUNDED values.  One workgroup per 256 rows; run as extra workgroups of the
+// launch that builds the source rows (ks_build_kernel), where both operands' norms are known.
+struct fs_bias_set {
+    const double* nrm; int N, Npad; const double* mass; float* bias; unsigned int* bmax; unsigned int* mmax; float* scale32;
+    int rows_out;                                            // entries per pair of bias / scale32 (>= N: padded to whole tiles)
+};
+__device__ __forceinline__ void fs_bias_body(const fs_bias_set& s, int b, int chunk, const double* __restrict__ amaxT, int nT,
+                                             const double* __restrict__ amaxS, int nS) {
+    __shared__ float wb[4], wm[4];
+    const int j = chunk * 256 + threadIdx.x;
+    if (chunk * 256 >= s.N) return;                          // uniform
+    const double sxy = ks_scale(amaxT + b * nT, nT) * ks_scale(amaxS + b * nS, nS);
+    float bb = 0.f, mm = 0.f;
+    if (j < s.N) {
+        const float v = (float)(-0.5 * s.nrm[(long long)b * s.Npad + j] * sxy);
+        s.bias[(long long)b * s.rows_out + j] = v;
+        bb = fabsf(v);
+        if (s.mass) {
+            const float m32 = (float)s.mass[(long long)b * s.N + j];
+            s.scale32[(long long)b * s.rows_out + j] = m32;
+            mm = fabsf(m32);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { bb = fmaxf(bb, __shfl_xor(bb, off)); mm = fmaxf(mm, __shfl_xor(mm, off)); }
+    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6] = bb; wm[threadIdx.x >> 6] = mm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bb = fmaxf(fmaxf(wb[0], wb[1]), fmaxf(wb[2], wb[3]));
+        mm = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        atomicMax(s.bmax + b, __float_as_uint(bb));
+        if (s.mass) atomicMax(s.mmax + b, __float_as_uint(mm));
+    }
+}
+
 // Feature rows, layout [ head: 8 bias slots (3 used) or none | 3 entries per contraction index | zero pad up to fill ],
 // row stride ld.  A workgroup builds 64 complete rows in LDS -- the K-major float64 operand is read coalesced over the
 // vertices (thread = vertex x group of 16 contraction indices) -- and writes them out as one contiguous run of 16-byte
@@ -67,10 +104,19 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
                                                        const double* __restrict__ amaxT, const double* __restrict__ amaxS, int nS,
                                                        int K, int N, int Npad, int Kpad, int ld, int fill, int head,
                                                        _Float16* __restrict__ F, int32_t* __restrict__ overflow, int paired, int nT,
-                                                       int rows_out) {        // rows per pair of F (>= N: padded outputs)
+                                                       int rows_out,          // rows per pair of F (>= N: padded outputs)
+                                                       int nbuild, fs_bias_set sA, fs_bias_set sB, int nbb) {
+    // the first 2 nbb workgroups of a pair (dm_launch_fm_split) write the per-row terms of the pass instead (first: they are
+    // short and would otherwise be the tail of the launch)
+    if ((int)blockIdx.x < 2 * nbb) {
+        const int e = (int)blockIdx.x;
+        fs_bias_body(e < nbb ? sA : sB, blockIdx.y, e < nbb ? e : e - nbb, amaxT, nT, amaxS, nS);
+        return;
+    }
+    (void)nbuild;
     extern __shared__ __attribute__((aligned(16))) _Float16 ks_img[];       // 64 rows x (fill + 8) halves
     const int ldl = fill + 8;
-    const int b = blockIdx.y, v0 = blockIdx.x * 64;
+    const int b = blockIdx.y, v0 = ((int)blockIdx.x - 2 * nbb) * 64;
     const int vl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int v = v0 + vl;
     const double sx = ks_scale(amaxT + b * nT, nT);
@@ -308,7 +354,7 @@ int dm_knn_split_prepare(dm_ctx* ctx, int B, int N2, int N2pad, int Kpad, int kf
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<false>, dim3(dm_cdiv(N2, 64), B), dim3(256), ks_build_lds(st->ldT), AT,
               (const double*)nullptr, st->amaxT, (const double*)nullptr, 0, kf, N2, N2pad, Kpad, st->ldT, st->ldT, KS_BIAS, st->Ft,
-              (int32_t*)nullptr, 0, KS_NCH, N2);
+              (int32_t*)nullptr, 0, KS_NCH, N2, dm_cdiv(N2, 64), fs_bias_set{}, fs_bias_set{}, 0);
     return DM_OK;
 }
 
@@ -325,7 +371,7 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
     DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(a.N1, 64), a.B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow, 0, KS_NCH, a.N1);
+              a.n1, st.amaxT, amaxS, nS, K, a.N1, a.N1pad, a.Kpad, D, D, KS_BIAS, Fs, overflow, 0, KS_NCH, a.N1, dm_cdiv(a.N1, 64), fs_bias_set{}, fs_bias_set{}, 0);
     dm_simnn_queue q;
     // error of the split on top of the fp32 accumulation, relative to |t_i| max_j |s_j|: the dropped <xl, yl> and the two
     // residuals (3 * 2^-22), the fp16 subnormal floor (2 sqrt(K) 2^-25), 25 % slack; 2^-19 at K = 200
@@ -352,39 +398,6 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 // dm_fm_split_ok); otherwise the float64 G kernel.
 // (mass, when given: also its fp32 rounding scale32, the per-source factor of the tile kernel's key B -- the rounding is
 //  part of the key's error bound, dm_simnn_core -- and the maximum of the ROUNDED values)
-struct fs_bias_set {
-    const double* nrm; int N, Npad; const double* mass; float* bias; unsigned int* bmax; unsigned int* mmax; float* scale32;
-    int rows_out;                                            // entries per pair of bias / scale32 (>= N: padded to whole tiles)
-};
-__global__ __launch_bounds__(256) void fs_bias_kernel(fs_bias_set s0, fs_bias_set s1, const double* __restrict__ amaxT, int nT,
-                                                      const double* __restrict__ amaxS, int nS) {
-    const fs_bias_set& s = blockIdx.z ? s1 : s0;             // (one launch for both operands)
-    __shared__ float wb[4], wm[4];
-    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= s.N) return;                     // uniform
-    const double sxy = ks_scale(amaxT + b * nT, nT) * ks_scale(amaxS + b * nS, nS);
-    float bb = 0.f, mm = 0.f;
-    if (j < s.N) {
-        const float v = (float)(-0.5 * s.nrm[(long long)b * s.Npad + j] * sxy);
-        s.bias[(long long)b * s.rows_out + j] = v;
-        bb = fabsf(v);
-        if (s.mass) {
-            const float m32 = (float)s.mass[(long long)b * s.N + j];
-            s.scale32[(long long)b * s.rows_out + j] = m32;
-            mm = fabsf(m32);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { bb = fmaxf(bb, __shfl_xor(bb, off)); mm = fmaxf(mm, __shfl_xor(mm, off)); }
-    if ((threadIdx.x & 63) == 0) { wb[threadIdx.x >> 6] = bb; wm[threadIdx.x >> 6] = mm; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        bb = fmaxf(fmaxf(wb[0], wb[1]), fmaxf(wb[2], wb[3]));
-        mm = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-        atomicMax(s.bmax + b, __float_as_uint(bb));
-        if (s.mass) atomicMax(s.mmax + b, __float_as_uint(mm));
-    }
-}
 // ind12[j] = 0 where the target's mass is zero (the whole indicator column is 0: np.argmax returns the first index)
 __global__ __launch_bounds__(256) void fs_zero_mass_kernel(const double* __restrict__ mass, long long n, int32_t* __restrict__ ind12) {
     const long long o = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -488,12 +501,13 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     }
     int rcb = dm_grant_lds(ctx, (const void*)ks_build_kernel<true>, ks_build_lds(D));
     if (rcb) return rcb;
-    DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(dm_cdiv(N1, 64), B), dim3(256), ks_build_lds(D), a.BT,
-              a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1, nT, R1);
     {
+        // (the same launch writes the per-row terms of the pass: 2 x ceil(N / 256) extra workgroups per pair)
         const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32, R1};
         const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr, R2};
-        DM_LAUNCH(ctx, "fm_split_bias", fs_bias_kernel, dim3(dm_cdiv(N1 > N2 ? N1 : N2, 256), B, 2), dim3(256), 0, sA, sB, amaxT, nT, amaxS, nS);
+        const int nbuild = dm_cdiv(N1, 64), nbb = dm_cdiv(N1 > N2 ? N1 : N2, 256);
+        DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(nbuild + 2 * nbb, B), dim3(256), ks_build_lds(D), a.BT,
+                  a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1, nT, R1, nbuild, sA, sB, nbb);
     }
     const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 2.0f * sqrtf((float)K) * 2.9802322e-8f);
     const size_t lds = ((size_t)K + 8 * 32 + 32) * sizeof(double);
