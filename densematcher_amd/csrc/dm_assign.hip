@@ -162,34 +162,31 @@ __global__ __launch_bounds__(LSA_NT) void lsa_kernel(const double* __restrict__ 
 //   better = smaller cost, then larger key  (positions are distinct, so the column bits never decide)
 // -- two comparisons per merge instead of five, and three shuffled words per butterfly level instead of five
 __device__ __forceinline__ int lsa_key(int sink, int it, int j) { return ((sink ? 8192 + it : 8191 - it) << 14) | j; }
-// partner's word for the levels of an all-reduce inside a wave, on the vector ALU (DPP / half-swaps) instead of ds_bpermute
-// round trips: lanes i ^ 1, i ^ 2 (quad permutes), 7 - i within 8 (row_half_mirror), 15 - i within 16 (row_mirror), then the
-// neighbouring row of 16 and the other half of the wave.  Any pairing that joins the two groups works for a reduction
-// whose merge is a total order.
-template <int LEVEL>
-__device__ __forceinline__ int lsa_partner(int x) {
-    if constexpr (LEVEL == 0) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
-    else if constexpr (LEVEL == 1) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-    else if constexpr (LEVEL == 2) return __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
-    else if constexpr (LEVEL == 3) return __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false);  // row_mirror
-    else if constexpr (LEVEL == 4) {
-        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);     // r[0] = rows 0 0 2 2, r[1] = rows 1 1 3 3
-        return (int)((threadIdx.x & 16) ? r[0] : r[1]);
-    } else {
-        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);     // r[0] = low half twice, r[1] = high half twice
-        return (int)((threadIdx.x & 32) ? r[0] : r[1]);
-    }
+// Reductions inside a wave on the vector ALU (DPP), in TWO phases: the smallest cost first, then the largest key among the
+// lanes that hold it -- one v_min_f64 / v_max_i32 per level and no divergent branch (a merged (cost, key) compare costs five
+// times that).  Levels: lanes i ^ 1, i ^ 2 (quad permutes), 7 - i within 8 (row_half_mirror), 15 - i within 16 (row_mirror)
+// leave every lane of a row of 16 with the row's result; row_bcast:15 into rows 1, 3 and row_bcast:31 into rows 2, 3 carry
+// it to lane 63, which a readlane hands to the scalar unit.
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ int lsa_dpp(int x) {
+    if constexpr (ROWS == 0xf) return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, false);      // (every lane has a source)
+    else return __builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xf, false);                      // rows outside the mask keep x
 }
-template <int LEVEL>
-__device__ __forceinline__ void lsa_merge_level(double& v, int& key) {
-    const int olo = lsa_partner<LEVEL>(__double2loint(v)), ohi = lsa_partner<LEVEL>(__double2hiint(v)), okey = lsa_partner<LEVEL>(key);
-    const double ov = __hiloint2double(ohi, olo);
-    const bool take = (ov < v) || (ov == v && okey > key);
-    v = take ? ov : v; key = take ? okey : key;
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double lsa_min_dpp(double v) {                                     // (costs are never NaN)
+    return __builtin_fmin(v, __hiloint2double(lsa_dpp<CTRL, ROWS>(__double2hiint(v)), lsa_dpp<CTRL, ROWS>(__double2loint(v))));
 }
-__device__ __forceinline__ void lsa_merge_key(double& v, int& key, double ov, int okey) {
-    const bool take = (ov < v) || (ov == v && okey > key);
-    v = take ? ov : v; key = take ? okey : key;
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ int lsa_max_dpp(int k) { const int o = lsa_dpp<CTRL, ROWS>(k); return o > k ? o : k; }
+__device__ __forceinline__ double lsa_wave_min(double v) {          // uniform result
+    v = lsa_min_dpp<0xB1>(v); v = lsa_min_dpp<0x4E>(v); v = lsa_min_dpp<0x141>(v); v = lsa_min_dpp<0x140>(v);
+    v = lsa_min_dpp<0x142, 0xa>(v); v = lsa_min_dpp<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ int lsa_wave_max(int k) {                // uniform result
+    k = lsa_max_dpp<0xB1>(k); k = lsa_max_dpp<0x4E>(k); k = lsa_max_dpp<0x141>(k); k = lsa_max_dpp<0x140>(k);
+    k = lsa_max_dpp<0x142, 0xa>(k); k = lsa_max_dpp<0x143, 0xc>(k);
+    return __builtin_amdgcn_readlane(k, 63);
 }
 
 // ---- the same search with the column state in registers ---------------------------------------------------------------------
@@ -207,7 +204,7 @@ template <int CPT, int WARM, int NT>
 __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ costs, int nr, int nc, int negate,
                                                          double* __restrict__ g_u, double* __restrict__ g_v,
                                                          int32_t* __restrict__ out_col4row, int32_t* __restrict__ info,
-                                                         const int32_t* __restrict__ run_if) {
+                                                         const int32_t* __restrict__ run_if, int32_t* __restrict__ skip_warm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
     if (run_if && run_if[blockIdx.x] == 0) return;        // (the exact-order rerun: only for matrices whose optimum may not be unique)
     // LDS: u (nr) doubles | row4col (nc), path (nc), col4row (nr) ints | slots
@@ -216,31 +213,61 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
     int* path = row4col + nc;
     int* col4row = path + nc;
     __shared__ double sl_val[2][16];
-    __shared__ int sl_it[2][16];                          // (the candidates' tie keys, lsa_key)
-    __shared__ int s_claim_dummy;
+    __shared__ int2 sl_it[2][16];                         // (the candidates' tie keys, lsa_key, and the rows their columns are assigned to)
+    __shared__ int s_count[2];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const double* cost = costs + (long long)b * nr * nc;
     const double sgn = negate ? -1.0 : 1.0;
     double v[CPT], spc[CPT];
     int pos[CPT];
-    bool sc[CPT];
+    int sc[CPT];
     int r4c[CPT];                                         // row4col of the owned columns (refreshed after every path flip)
 #pragma unroll
-    for (int q = 0; q < CPT; ++q) { v[q] = 0.0; spc[q] = DM_INF_F64; pos[q] = 0; sc[q] = false; r4c[q] = -1; }
+    for (int q = 0; q < CPT; ++q) { v[q] = 0.0; spc[q] = DM_INF_F64; pos[q] = 0; sc[q] = 0; r4c[q] = -1; }
     for (int i = t; i < nr; i += NT) { u[i] = 0.0; col4row[i] = -1; }
     for (int j = t; j < nc; j += NT) { row4col[j] = -1; path[j] = -1; }
     __syncthreads();
     if (WARM) {
         // v_j = min_i c_ij (lowest i on ties); the column takes that row if no lower column claimed it
-        int arg[CPT];
+        int arg[CPT], cnt[CPT];                           // (cnt: how many entries of the column equal its minimum)
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) { v[q] = DM_INF_F64; arg[q] = -1; }
+        for (int q = 0; q < CPT; ++q) { v[q] = DM_INF_F64; arg[q] = -1; cnt[q] = 0; }
         for (int i = 0; i < nr; ++i) {
             const double* crow = cost + (long long)i * nc;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
                 const int j = t + NT * q;
-                if (j < nc) { const double c = sgn * crow[j]; if (c < v[q]) { v[q] = c; arg[q] = i; } }
+                const double c = sgn * crow[j < nc ? j : nc - 1];
+                const bool lt = c < v[q];
+                cnt[q] = lt ? 1 : cnt[q] + (c == v[q] ? 1 : 0);
+                arg[q] = lt ? i : arg[q];
+                v[q] = lt ? c : v[q];
+            }
+        }
+        // A matrix full of ties gains nothing from this start: two constant columns can be swapped (the optimum is not unique,
+        // the result would be thrown away), and when many column minima are attained more than once the searches from these
+        // duals wander through sheets of slack-free edges (the precise map's matrix, three entries per row: 370 ms against
+        // 7 ms in SciPy's order).  Leave such a matrix to the exact rerun.
+        {
+            int tied = 0, flat = 0;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = t + NT * q;
+                tied += (j < nc && cnt[q] >= 2) ? 1 : 0; flat += (j < nc && cnt[q] == nr) ? 1 : 0;
+            }
+            if (t == 0) { s_count[0] = 0; s_count[1] = 0; }
+            __syncthreads();
+            if (tied) atomicAdd(&s_count[0], tied);
+            if (flat) atomicAdd(&s_count[1], flat);
+            __syncthreads();
+            if (s_count[0] * 8 > nc || (s_count[1] >= 2 && nr >= 2)) {            // (uniform)
+                for (int i = t; i < nr; i += NT) {
+                    out_col4row[(long long)b * nr + i] = -1;
+                    if (g_u) g_u[(long long)b * nr + i] = 0.0;
+                }
+                if (g_v) for (int j = t; j < nc; j += NT) g_v[(long long)b * nc + j] = 0.0;
+                if (t == 0 && skip_warm) skip_warm[b] = 1;
+                return;
             }
         }
         // claim: col4row[i] = the lowest column whose minimum is in row i (LDS atomics), then the winners record themselves
@@ -257,68 +284,140 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
             if (j < nc && !(v[q] < DM_INF_F64)) v[q] = 0.0;     // a column without a finite entry: no usable minimum
         }
         __syncthreads();
-        (void)s_claim_dummy;
     }
     for (int cur = 0; cur < nr; ++cur) {
         if (WARM && col4row[cur] != -1) continue;         // (uniform) assigned by the column reduction
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
             const int j = t + NT * q;
-            spc[q] = DM_INF_F64; sc[q] = false; pos[q] = nc - 1 - j;          // remaining[it] = nc - it - 1
+            spc[q] = DM_INF_F64; sc[q] = 0; pos[q] = nc - 1 - j;          // remaining[it] = nc - it - 1
             r4c[q] = j < nc ? row4col[j] : -1;
         }
         int i = cur, nrem = nc, sink = -1, step = 0;
         double min_val = 0.0;
         bool infeasible = false;
-        while (true) {
-            const double ui = u[i];
-            const double* crow = cost + (long long)i * nc;
-            double bval = DM_INF_F64;
-            int bkey = -1;
-            double cv[CPT];
+        // the tie key of column j at list position p is kb + p * ks (lsa_key): both fixed for the search.  After a warm start
+        // the order is free and kb is just the column with a "free" flag above it.
+        int kb[CPT], ks[CPT], pth[CPT];
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) {                // all the row's loads first (independent), then the relaxations
-                const int j = t + NT * q;
-                cv[q] = (j < nc && !sc[q]) ? crow[j] : 0.0;
-            }
+        for (int q = 0; q < CPT; ++q) {
+            const int j = t + NT * q;
+            const bool fr = r4c[q] == -1;
+            kb[q] = WARM ? ((fr ? 1 << 14 : 0) | j) : (((fr ? 8192 : 8191) << 14) | j);
+            ks[q] = fr ? (1 << 14) : -(1 << 14); pth[q] = -1;
+        }
+        double ui = u[i];
+        double cv[CPT];
+        {
+            const double* crow = cost + (long long)i * nc;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) { const int j = t + NT * q; cv[q] = crow[j < nc ? j : nc - 1]; }
+        }
+        while (true) {
+            // relax the open columns (no branch: a select per column; the predecessor stays in a register until the search ends)
+            double cand[CPT];
+            const double mu = min_val - ui;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
                 const int j = t + NT * q;
-                if (j < nc && !sc[q]) {
-                    const double r = ((min_val + sgn * cv[q]) - ui) - v[q];     // SciPy's operation order
-                    if (r < spc[q]) { spc[q] = r; path[j] = i; }
-                    lsa_merge_key(bval, bkey, spc[q], lsa_key(r4c[q] == -1 ? 1 : 0, pos[q], j));
+                const bool open = (j < nc) & (sc[q] == 0);
+                const double r = WARM ? (sgn * cv[q] + mu) - v[q] : ((min_val + sgn * cv[q]) - ui) - v[q];     // (WARM = 0: SciPy's operation order)
+                const bool better = open & (r < spc[q]);
+                spc[q] = better ? r : spc[q];
+                pth[q] = better ? i : pth[q];
+                cand[q] = open ? spc[q] : DM_INF_F64;
+            }
+            // the wave's smallest tentative cost, then WHICH column: SciPy's order needs the largest key among the columns at
+            // that cost (one lane almost always: a ballot finds it, the butterfly runs only on a real tie); after a warm start
+            // the order is free (the result is accepted only when the optimum is unique) and the first lane's column is taken
+            double tv = cand[0];
+#pragma unroll
+            for (int q = 1; q < CPT; ++q) tv = __builtin_fmin(tv, cand[q]);
+            const double wmin = lsa_wave_min(tv);
+            const bool feas = wmin < DM_INF_F64;
+            int tk = -1, trow = -1;
+#pragma unroll
+            for (int q = CPT - 1; q >= 0; --q) {
+                const int key = WARM ? kb[q] : kb[q] + pos[q] * ks[q];
+                const bool eq = (cand[q] == wmin) & feas;
+                const bool take = eq & (key > tk);         // (warm start: a free column first, any order otherwise)
+                tk = take ? key : tk; trow = take ? r4c[q] : trow;
+            }
+            int wsel = -1, wrow = -1;
+            {
+                const unsigned long long have = __builtin_amdgcn_ballot_w64(tk >= 0);
+                if (have) {
+                    int src = (int)__builtin_ctzll(have);
+                    if (WARM) {
+                        const unsigned long long fr = __builtin_amdgcn_ballot_w64(tk >= (1 << 14));
+                        if (fr) src = (int)__builtin_ctzll(fr);
+                    } else if ((have & (have - 1)) != 0) {
+                        const int best = lsa_wave_max(tk);
+                        src = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(tk == best));
+                    }
+                    wsel = __builtin_amdgcn_readlane(tk, src); wrow = __builtin_amdgcn_readlane(trow, src);
                 }
             }
-            lsa_merge_level<0>(bval, bkey); lsa_merge_level<1>(bval, bkey); lsa_merge_level<2>(bval, bkey);
-            lsa_merge_level<3>(bval, bkey); lsa_merge_level<4>(bval, bkey); lsa_merge_level<5>(bval, bkey);
             const int par = step & 1;
-            if (lane == 0) { sl_val[par][wave] = bval; sl_it[par][wave] = bkey; }
+            if (lane == 0) { sl_val[par][wave] = wmin; sl_it[par][wave] = make_int2(wsel, wrow); }
             __syncthreads();
-            // every thread folds the wave results itself (lane q < NT / 64 takes slot q, then a 4-level butterfly inside the wave:
-            // the rule is a total order on distinct positions, so every lane ends with the same winner)
-            double wv = lane < NT / 64 ? sl_val[par][lane & 15] : DM_INF_F64;
-            int wkey = lane < NT / 64 ? sl_it[par][lane & 15] : -1;
-            lsa_merge_level<0>(wv, wkey); lsa_merge_level<1>(wv, wkey); lsa_merge_level<2>(wv, wkey);     // lanes 0 .. 7
-            if (NT > 512) lsa_merge_level<3>(wv, wkey);                                                   // lanes 0 .. 15
-            wkey = __builtin_amdgcn_readfirstlane(wkey);
+            // every wave folds the NT / 64 wave results itself: slot (lane mod NT / 64), butterfly over those lanes
+            const double sv = sl_val[par][lane & (NT / 64 - 1)];
+            const int2 sk = sl_it[par][lane & (NT / 64 - 1)];
+            double wv = lsa_min_dpp<0xB1>(sv); wv = lsa_min_dpp<0x4E>(wv);
+            if (NT > 256) wv = lsa_min_dpp<0x141>(wv);
+            if (NT > 512) wv = lsa_min_dpp<0x140>(wv);
             wv = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(wv)), __builtin_amdgcn_readfirstlane(__double2loint(wv)));
-            const int wK = wkey >> 14, wj = wkey < 0 ? -1 : (wkey & 16383);
-            const int wsk = (wkey >= 0 && wK >= 8192) ? 1 : 0;
-            const int wit = wkey < 0 ? -1 : (wsk ? wK - 8192 : 8191 - wK);
+            int wkey = -1, inext = -1;
+            {
+                const bool mine = (sv == wv) & (sk.x >= 0);
+                const unsigned long long have = __builtin_amdgcn_ballot_w64(mine) & ((1ull << (NT / 64)) - 1);
+                if (have) {
+                    int src = (int)__builtin_ctzll(have);
+                    if (WARM) {
+                        const unsigned long long fr = __builtin_amdgcn_ballot_w64(mine & (sk.x >= (1 << 14))) & ((1ull << (NT / 64)) - 1);
+                        if (fr) src = (int)__builtin_ctzll(fr);
+                    } else if ((have & (have - 1)) != 0) {
+                        int m = mine ? sk.x : -1;
+                        m = lsa_max_dpp<0xB1>(m); m = lsa_max_dpp<0x4E>(m);
+                        if (NT > 256) m = lsa_max_dpp<0x141>(m);
+                        if (NT > 512) m = lsa_max_dpp<0x140>(m);
+                        src = (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(mine & (sk.x == m)));
+                    }
+                    wkey = __builtin_amdgcn_readlane(sk.x, src); inext = __builtin_amdgcn_readlane(sk.y, src);
+                }
+            }
+            int wj, wsk, wit;
+            if (WARM) { wj = wkey < 0 ? -1 : (wkey & 16383); wsk = wkey < 0 ? 0 : (wkey >> 14); wit = wkey < 0 ? -1 : 0; }
+            else {
+                const int wK = wkey >> 14;
+                wj = wkey < 0 ? -1 : (wkey & 16383);
+                wsk = (wkey >= 0 && wK >= 8192) ? 1 : 0;
+                wit = wkey < 0 ? -1 : (wsk ? wK - 8192 : 8191 - wK);
+            }
             ++step;
             if (wit < 0 || !(wv < DM_INF_F64)) { infeasible = true; break; }
             min_val = wv;
+            if (!wsk) {                                    // the next row's loads go out before the list is updated
+                i = inext;
+                const double* crow = cost + (long long)i * nc;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) { const int j = t + NT * q; cv[q] = crow[j < nc ? j : nc - 1]; }
+                ui = u[i];
+            }
             // remove the chosen column from the list: the column at the last position takes its place
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
                 const int j = t + NT * q;
-                if (j == wj) sc[q] = true;
-                else if (!sc[q] && pos[q] == nrem - 1) pos[q] = wit;
+                const bool hit = j == wj;
+                if (!WARM) {
+                    const bool moved = (sc[q] == 0) & !hit & (pos[q] == nrem - 1);
+                    pos[q] = moved ? wit : pos[q];
+                }
+                sc[q] = hit ? 1 : sc[q];
             }
             --nrem;
             if (wsk) { sink = wj; break; }
-            i = row4col[wj];
         }
         if (infeasible) {                                 // (uniform) SciPy: ValueError "cost matrix is infeasible"
             if (t == 0) atomicMax(&info[b], 1);
@@ -329,6 +428,7 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
 #pragma unroll
         for (int q = 0; q < CPT; ++q) {
             if (sc[q]) {
+                path[t + NT * q] = pth[q];                // (the flip walks scanned columns only)
                 const double dlt = min_val - spc[q];
                 if (r4c[q] != -1) u[r4c[q]] += dlt;       // (distinct rows: one column each)
                 v[q] -= dlt;
@@ -514,7 +614,7 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
             rc = dm_grant_lds(ctx, (const void*)lsa_reg_kernel<CPT_, WARM_, NT_>, lds_reg);                            \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", (lsa_reg_kernel<CPT_, WARM_, NT_>), dim3(B), dim3(NT_), lds_reg, Cm, R, Cn, \
-                      maximize ? 1 : 0, gu, gv, outp, info, RUNIF_);                                                   \
+                      maximize ? 1 : 0, gu, gv, outp, info, RUNIF_, WARM_ ? tie : (int32_t*)nullptr);                                                   \
         }
 #define LSA_REG_NT(WARM_, RUNIF_, NT_)                                                                                 \
         if (cpt == 1) LSA_REG(1, WARM_, RUNIF_, NT_) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_, NT_)                 \

@@ -647,15 +647,20 @@ def test_linear_sum_assignment_equals_scipy(eng):
     rng = np.random.default_rng(3)
     for trial, (nr, nc) in enumerate([(1, 1), (5, 9), (9, 5), (64, 64), (200, 230), (230, 200), (500, 500), (700, 512)]):
         mats = []
-        for q in range(3):
+        for q in range(5):
             c = rng.standard_normal((nr, nc))
             if q == 1:
                 c = np.round(3 * c)
             if q == 2:
                 c = c * (rng.random((nr, nc)) < 0.02)
+            if q == 3 and nc >= 2:                    # two constant columns: interchangeable, the warm start steps aside
+                c[:, [0, nc - 1]] = 0.25
+            if q == 4 and nr >= 5:                    # a few exact ties in otherwise generic data (warm start, then the rerun)
+                c[rng.integers(0, nr, 4), rng.integers(0, nc, 4)] = c[0, 0]
             mats.append(c)
         # every implementation (dm_set_option "lsa_reg"): 2 = register state + column-reduction start, kept only where the
-        # optimum is provably unique (the integer / sparse matrices here have ties: they are redone in SciPy's order),
+        # optimum is provably unique (the integer / sparse matrices here have ties: they are redone in SciPy's order; a matrix
+        # whose column minima are mostly tied, or with two constant columns, skips the warm start altogether),
         # 1 = register state in SciPy's order, 0 = LDS state
         for mode in (2, 1, 0):
             eng.set_option("lsa_reg", mode)
