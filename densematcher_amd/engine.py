@@ -394,32 +394,42 @@ class MatchEngine:
         return Cm
 
     def eigenbasis(self, W_list, mass, k, guard=32, degree=30, tol=1e-9, max_rounds=12, seed=0):
-        """k smallest eigenpairs of W phi = lambda A phi for a batch of meshes with the same vertex count (reference
-        TriMesh.process -> laplacian_spectrum: ARPACK on the host).  W_list: sparse stiffness matrices (host, SciPy);
-        mass (B,N) lumped masses.  The sparsity bookkeeping (ELL layout of A^-1/2 W A^-1/2) is host work, as assembling W
-        is in the reference; the iteration runs on the GPU (dm_eigenbasis) until max_j |L x_j - lam_j x_j| <= tol * lam_k.
+        """k smallest eigenpairs of W phi = lambda A phi for a batch of meshes (reference TriMesh.process ->
+        laplacian_spectrum: ARPACK on the host, one mesh at a time).  W_list: sparse stiffness matrices (host, SciPy);
+        mass (B,N) lumped masses, or a list of 1-D arrays when the vertex counts differ (Phi is then padded to the largest).
+        The sparsity bookkeeping (ELL layout of A^-1/2 W A^-1/2) is host work, as assembling W is in the reference; the
+        iteration runs on the GPU (dm_eigenbasis) until max_j |L x_j - lam_j x_j| <= tol * lam_k.
         Returns (lam (B,k) f64, Phi (B,N,k) f64, resid (B,), rounds)."""
         import numpy as np
         import scipy.sparse as sp
         # (the C ABI carries lumped masses as fp32, like every other entry point: the problem solved is the one with the
         #  rounded masses, so that Phi^T A Phi = I holds for the A the matching kernels will see)
-        mass = np.ascontiguousarray(mass, dtype=np.float32).astype(np.float64)
-        B, N = mass.shape
-        if np.any(mass <= 0):
+        # Meshes of DIFFERENT vertex counts share a call too (`mass` a list of 1-D arrays): the smaller ones are padded with
+        # decoupled vertices whose only entry is a diagonal one inside the upper spectrum (the largest diagonal entry of the
+        # mesh's own operator), so the filter damps them like every unwanted eigenvector; their rows of Phi come back ~0 and
+        # the caller slices them off.
+        masses = [np.ascontiguousarray(a, dtype=np.float32).astype(np.float64).ravel() for a in mass]
+        B, N = len(masses), max(a.shape[0] for a in masses)
+        if any(np.any(a <= 0) for a in masses):
             raise ValueError("eigenbasis: every vertex needs a positive lumped mass (isolated or degenerate vertices?)")
         mats = []
         for b in range(B):
-            d = sp.diags(1.0 / np.sqrt(mass[b]))
+            d = sp.diags(1.0 / np.sqrt(masses[b]))
             mats.append((d @ sp.csr_matrix(W_list[b]) @ d).tocsr())
         nnz = max(int(np.diff(Lm.indptr).max()) for Lm in mats)
         cols = np.tile(np.arange(N, dtype=np.int32)[None, :, None], (B, 1, nnz))
         vals = np.zeros((B, N, nnz))
+        mass = np.ones((B, N))
         for b, Lm in enumerate(mats):
+            nb = Lm.shape[0]
             cnt = np.diff(Lm.indptr)
             pos = np.arange(Lm.nnz) - np.repeat(Lm.indptr[:-1], cnt)
-            rows = np.repeat(np.arange(N), cnt)
+            rows = np.repeat(np.arange(nb), cnt)
             cols[b, rows, pos] = Lm.indices
             vals[b, rows, pos] = Lm.data
+            mass[b, :nb] = masses[b]
+            if nb < N:
+                vals[b, nb:, 0] = float(Lm.diagonal().max())
         m = min(k + guard, N)
         g = torch.Generator(device=self.device).manual_seed(seed)
         X = torch.randn((B, N, m), dtype=torch.float64, device=self.device, generator=g)

@@ -102,8 +102,13 @@ class FunctionalMapping:
         if k_process is None:
             k_process = 1
         use_lm = landmarks is not None and len(landmarks) > 0
-        self.mesh1.process(max(self.k1, k_process), verbose=verbose, robust=True, intrinsic=False)
-        self.mesh2.process(max(self.k2, k_process), verbose=verbose, robust=True, intrinsic=False)
+        # (functional.py:300-301: mesh1.process, mesh2.process; here the two eigensolves share one batched call)
+        ks = [max(self.k1, k_process), max(self.k2, k_process)]
+        if all(hasattr(m, "_assemble_laplacian") for m in (self.mesh1, self.mesh2)):
+            type(self.mesh1).process_many([self.mesh1, self.mesh2], ks, robust=True, verbose=verbose)
+        else:                                                                    # (duck-typed meshes bring their own process)
+            self.mesh1.process(ks[0], verbose=verbose, robust=True, intrinsic=False)
+            self.mesh2.process(ks[1], verbose=verbose, robust=True, intrinsic=False)
         if use_lm:
             lmks1, lmks2 = self._get_lmks(landmarks)
         if descr1 is not None and descr2 is not None:

@@ -91,8 +91,8 @@ class TriMesh:
         self._L = value
 
     # ------------------------------------------------------------- spectrum (host side input of the path)
-    def laplacian_spectrum(self, k, intrinsic=False, return_spectrum=True, robust=False, verbose=False):
-        """trimesh.py:440-496 -> laplacian.py:143-182.  W, A on the host; the k smallest eigenpairs on the GPU."""
+    def _assemble_laplacian(self, robust=False):
+        """W, A on the host (trimesh.py:440-482 -> laplacian.py:143-160); returns the lumped masses."""
         if self.facelist is None:
             raise NotImplementedError("point-cloud Laplacians are outside the matching path")
         mass = None
@@ -114,25 +114,67 @@ class TriMesh:
             raise ValueError("vertices with zero lumped mass (isolated vertices or degenerate faces): clean the mesh first")
         self.A = sparse.diags(mass).tocsr()
         self._L = None
+        return mass
+
+    def _n_eigs(self, k):
+        return min(max(20, k), self.n_vertices - 1)                           # laplacian.py:165 computes at least 20 pairs
+
+    def _store_spectrum(self, lam, phi, resid, k):
+        """lam (>= k,), phi (N, >= k): device tensors of the solver; keeps the first k pairs (laplacian.py:165-167)"""
+        if float(resid) > 1e-6 * max(1.0, float(lam[-1])):
+            raise RuntimeError(f"eigensolver did not converge (residual {float(resid):.2e})")
+        self.eigenvalues, self.eigenvectors = lam[:k].cpu().numpy(), phi[:self.n_vertices, :k].cpu().numpy()
+        if abs(self.eigenvalues[0]) < 1e-9 * max(1.0, self.eigenvalues[-1]):
+            self.eigenvalues[0] = max(self.eigenvalues[0], 0.0)
+
+    def _has_spectrum(self, k):
+        return (self.eigenvectors is not None) and (self.eigenvalues is not None) and (len(self.eigenvalues) >= k)
+
+    # ------------------------------------------------------------- spectrum (host side input of the path)
+    def laplacian_spectrum(self, k, intrinsic=False, return_spectrum=True, robust=False, verbose=False):
+        """trimesh.py:440-496 -> laplacian.py:143-182.  W, A on the host; the k smallest eigenpairs on the GPU."""
+        mass = self._assemble_laplacian(robust)
         if k > 0:
-            kk = min(max(20, k), self.n_vertices - 1)                          # laplacian.py:165 computes at least 20 pairs
+            kk = self._n_eigs(k)
             from ...engine import default_engine
             lam, phi, resid, _ = default_engine().eigenbasis([self.W], mass[None], kk, tol=1e-10)
-            if float(resid[0]) > 1e-6 * max(1.0, float(lam[0, -1])):
-                raise RuntimeError(f"eigensolver did not converge (residual {float(resid[0]):.2e})")
-            self.eigenvalues, self.eigenvectors = lam[0, :k].cpu().numpy(), phi[0, :, :k].cpu().numpy()   # laplacian.py:165-167
-            self.eigenvalues[0] = max(self.eigenvalues[0], 0.0) if abs(self.eigenvalues[0]) < 1e-9 * max(1.0, self.eigenvalues[-1]) else self.eigenvalues[0]
+            self._store_spectrum(lam[0], phi[0], resid[0], k)
             if return_spectrum:
                 return self.eigenvalues, self.eigenvectors
 
     def process(self, k=200, skip_normals=True, intrinsic=False, robust=False, verbose=False):
         """trimesh.py:498-531: reuse a stored spectrum when it is large enough, else compute it."""
-        if (self.eigenvectors is not None) and (self.eigenvalues is not None) and (len(self.eigenvalues) >= k):
+        if self._has_spectrum(k):
             self.eigenvectors = self.eigenvectors[:, :k]
             self.eigenvalues = self.eigenvalues[:k]
         else:
             self.laplacian_spectrum(k, return_spectrum=False, intrinsic=intrinsic, robust=robust, verbose=verbose)
         return self
+
+    @staticmethod
+    def process_many(meshes, ks, robust=False, verbose=False):
+        """mesh.process(k) for several meshes (FunctionalMapping.preprocess: functional.py:300-301 processes its two meshes one
+        after the other).  The eigensolver is a chain of small launches whose duration does not depend on how many meshes
+        ride along, so the meshes that still need a spectrum are solved in ONE batched call (engine.eigenbasis pads the
+        smaller ones); each keeps its own k pairs."""
+        todo = []
+        for mesh, k in zip(meshes, ks):
+            # (a subclass or a patched `process` -- a caller that supplies its own spectra -- keeps the say)
+            if mesh._has_spectrum(k) or k <= 0 or type(mesh).process is not _TRIMESH_PROCESS:
+                mesh.process(k, robust=robust, verbose=verbose)
+            else:
+                todo.append((mesh, k))
+        if len(todo) == 1 or (todo and max(m._n_eigs(k) for m, k in todo) > min(m.n_vertices for m, k in todo) - 1):
+            for mesh, k in todo:
+                mesh.process(k, robust=robust, verbose=verbose)
+        elif todo:
+            masses = [mesh._assemble_laplacian(robust) for mesh, _ in todo]
+            kk = max(mesh._n_eigs(k) for mesh, k in todo)
+            from ...engine import default_engine
+            lam, phi, resid, _ = default_engine().eigenbasis([mesh.W for mesh, _ in todo], masses, kk, tol=1e-10)
+            for q, (mesh, k) in enumerate(todo):
+                mesh._store_spectrum(lam[q], phi[q], resid[q], k)
+        return meshes
 
     # ------------------------------------------------------------- vertex sampling (input of the subsampled ZoomOut)
     def extract_fps(self, size, random_init=True, geodesic=True, no_load=False, verbose=False, rng=None):
@@ -197,3 +239,6 @@ class TriMesh:
 
     def integrate(self, func):
         return func.T @ self.A.diagonal()
+
+
+_TRIMESH_PROCESS = TriMesh.process

@@ -840,3 +840,50 @@ def test_engine_refuses_a_foreign_stream(eng):
         with pytest.raises(RuntimeError, match="bound to the stream"):
             eng.knn_query(X, X)
     assert np.array_equal(_np(eng.knn_query(X, X))[0], np.arange(300))
+
+
+@pytest.mark.gpu
+def test_eigenbasis_of_meshes_of_different_sizes_in_one_call(eng):
+    """FunctionalMapping.preprocess solves its two meshes in one batched call (TriMesh.process_many); meshes of different
+    vertex counts are padded with decoupled vertices: every mesh gets the eigenpairs of the dense solver on ITS OWN W, A
+    (eigenvalues 1e-9 relative, A-orthonormal vectors, residuals, the same invariant subspace), and the padding rows are ~0"""
+    import scipy.linalg
+    import scipy.sparse as sps
+    from densematcher_amd import synth
+    from densematcher_amd.pyFM.mesh import TriMesh
+    k = 30
+    meshes = [synth.torus_mesh(32, 20, perturb=0.05, seed=2), synth.torus_mesh(25, 20, perturb=0.08, seed=1), synth.torus_mesh(30, 17, perturb=0.03, seed=5)]
+    Ws, masses = zip(*[synth.cotan_laplacian(v, f) for v, f in meshes])
+    masses = [m_.astype(np.float32).astype(np.float64) for m_ in masses]
+    lam, Phi, resid, _ = eng.eigenbasis(list(Ws), list(masses), k, tol=1e-10)
+    lam, Phi = _np(lam), _np(Phi)
+    assert Phi.shape == (3, 640, k)
+    for b in range(3):
+        n = masses[b].shape[0]
+        w, V = scipy.linalg.eigh(Ws[b].toarray(), np.diag(masses[b]))
+        scale = w[k - 1]
+        assert np.abs(lam[b] - w[:k]).max() <= 1e-9 * scale, b
+        assert np.abs(Phi[b, n:]).max(initial=0.0) <= 1e-9, b
+        A = sps.diags(masses[b])
+        Pb = Phi[b, :n]
+        assert np.abs(Pb.T @ (A @ Pb) - np.eye(k)).max() <= 1e-9
+        assert np.abs(Ws[b] @ Pb - (A @ Pb) * lam[b][None, :]).max() <= 1e-7 * scale
+        cut = k
+        while cut > 1 and (w[cut] - w[cut - 1]) <= 1e-6 * scale:
+            cut -= 1
+        P = V[:, :cut].T @ (A @ Pb[:, :cut])
+        assert np.abs(P.T @ P - np.eye(cut)).max() <= 1e-7
+    # the model-level entry: both meshes processed by one call, each keeps its own k
+    import warnings
+    m1, m2 = TriMesh(*meshes[0]), TriMesh(*meshes[1])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        TriMesh.process_many([m1, m2], [12, 25], robust=False)
+    assert m1.eigenvectors.shape == (640, 12) and m2.eigenvectors.shape == (500, 25)
+    for mesh, b, kk in ((m1, 0, 12), (m2, 1, 25)):
+        w = scipy.linalg.eigh(Ws[b].toarray(), np.diag(masses[b]), eigvals_only=True, subset_by_index=[0, kk - 1])
+        assert np.abs(mesh.eigenvalues - w).max() <= 1e-8 * max(w[-1], 1.0)
+
+
+
+
