@@ -54,6 +54,7 @@ extern "C" int dm_destroy(dm_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->gram_keep) (void)hipFree(ctx->gram_keep);
     delete ctx;
     return DM_OK;
 }
@@ -78,6 +79,7 @@ extern "C" int dm_set_option(dm_ctx* ctx, const char* name, int value) {
     else if (n == "lsa_reg") ctx->opt_lsa_reg = value;
     else if (n == "p2p_split") ctx->opt_p2p_split = value;
     else if (n == "simnn_persist") ctx->opt_simnn_persist = value;
+    else if (n == "energy_keep_gram") { ctx->opt_energy_keep_gram = value; ctx->gram_valid = false; }
     else return dm_fail(ctx, DM_EINVAL, "dm_set_option: unknown option '%s'", name);
     return DM_OK;
 }

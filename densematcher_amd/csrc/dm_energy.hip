@@ -484,24 +484,6 @@ __global__ __launch_bounds__(256) void em_sum_splits_kernel(double* __restrict__
     Y[i] = s;
 }
 
-// e_m[b] = sum of the workgroup shares + the column-statistics terms   (one workgroup per pair)
-__global__ __launch_bounds__(256) void m_finish_energy_kernel(const double* __restrict__ pe, int nblk, int N1, int N2,
-                                                              const double* __restrict__ cs, const double* __restrict__ csq,
-                                                              const double* __restrict__ stat, int nstat, mterm_weights w, double* __restrict__ e_m) {
-    __shared__ double sh[4];
-    const int b = blockIdx.x, t = threadIdx.x;
-    double acc = 0.0;
-    for (int q = t; q < nblk; q += 256) acc += pe[(long long)b * nblk + q];
-    const double mean_c = em_mean(stat, b, nstat, 1, N1), n2_over_n1 = (double)N2 / (double)N1;
-    if (w.stoch > 0.0 || w.sumto1 > 0.0)
-        for (int j = t; j < N1; j += 256) {
-            const double dq = csq[(long long)b * N1 + j] - n2_over_n1, ds = cs[(long long)b * N1 + j] - mean_c;
-            acc += w.stoch * dq * dq + w.sumto1 * ds * ds;
-        }
-    const double tot = block_sum_256(acc, sh);
-    if (t == 0) e_m[b] = tot;
-}
-
 // e_dc[b] = 1/2 sum T^2 over the pair's nops * k2 * k1 entries   (one workgroup per pair)
 __global__ __launch_bounds__(256) void half_sumsq_kernel(const double* __restrict__ T, long long n, double* __restrict__ out) {
     __shared__ double sh[4];
@@ -512,20 +494,42 @@ __global__ __launch_bounds__(256) void half_sumsq_kernel(const double* __restric
     if (t == 0) out[b] = 0.5 * tot;
 }
 
-// grad += gm + w_dc (g1 - g2), column 0 zeroed; energy = e_quad + e_m + w_dc e_dc
-__global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad, const double* __restrict__ gm, const double* __restrict__ g1,
+// grad += gm + w_dc (g1 - g2), column 0 zeroed; energy = e_quad + e_m + w_dc e_dc.  gm arrives as the split-K partials of
+// Phi2^T Y (added here in split order, as reduce_partials_kernel would); e_m = the tile kernels' workgroup shares + the
+// column-statistics terms (what m_finish_energy_kernel computes), summed here by the pair's workgroup.
+struct combine_mterms {
+    const double* gm_part; int gm_nsplit;
+    const double* pe; int nblk, N1, N2; const double* cs; const double* csq; const double* stat; int nstat; mterm_weights mw;
+};
+__global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad, combine_mterms cm, long long n_all, const double* __restrict__ g1,
                                                       const double* __restrict__ g2, double w_dc, int k1, int k2,
-                                                      const double* __restrict__ e_quad, const double* __restrict__ e_m,
-                                                      const double* __restrict__ e_dc, double* __restrict__ energy) {
+                                                      const double* __restrict__ e_quad, const double* __restrict__ e_dc, double* __restrict__ energy) {
+    __shared__ double sh[4];
     const int b = blockIdx.x, t = threadIdx.x;
     for (int e = t; e < k2 * k1; e += 256) {
         const long long o = (long long)b * k2 * k1 + e;
         double g = grad[o];
-        if (gm) g += gm[o];
+        if (cm.gm_part) {
+            double s = 0.0;
+            for (int q = 0; q < cm.gm_nsplit; ++q) s += cm.gm_part[(long long)q * n_all + o];
+            g += s;
+        }
         if (g1) g += w_dc * (g1[o] - g2[o]);
         grad[o] = (e % k1 == 0) ? 0.0 : g;                              // base_functions.py:759
     }
-    if (t == 0) energy[b] = e_quad[b] + (e_m ? e_m[b] : 0.0) + (e_dc ? w_dc * e_dc[b] : 0.0);
+    double e_m = 0.0;
+    if (cm.pe) {                                                        // (uniform)
+        double acc = 0.0;
+        for (int q = t; q < cm.nblk; q += 256) acc += cm.pe[(long long)b * cm.nblk + q];
+        const double mean_c = em_mean(cm.stat, b, cm.nstat, 1, cm.N1), n2_over_n1 = (double)cm.N2 / (double)cm.N1;
+        if (cm.mw.stoch > 0.0 || cm.mw.sumto1 > 0.0)
+            for (int j = t; j < cm.N1; j += 256) {
+                const double dq = cm.csq[(long long)b * cm.N1 + j] - n2_over_n1, ds = cm.cs[(long long)b * cm.N1 + j] - mean_c;
+                acc += cm.mw.stoch * dq * dq + cm.mw.sumto1 * ds * ds;
+            }
+        e_m = block_sum_256(acc, sh);
+    }
+    if (t == 0) energy[b] = e_quad[b] + (cm.pe ? e_m : 0.0) + (e_dc ? w_dc * e_dc[b] : 0.0);
 }
 
 extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D, const float* Phi1, int ld1,
@@ -563,7 +567,10 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     }
     const int cchunk = pad_to(dm_cdiv(N1, ncs), EM_T);
     const int ngroups = dm_cdiv(N2, rg);
-    const int nsplit_m = dm_cdiv(N2, 512);
+    // split-K chunk of Gm = Phi2^T Y: by the map's size only (a pair's sums must not depend on the batch it is in); a map of one
+    // 64 x 64 tile has nothing else to fill the chip with, so its chunks are short (one pair, N2 = 2048: 4 -> 16 workgroups)
+    const int kc_m = (k1 <= TN_T && k2 <= TN_T) ? 128 : 512;
+    const int nsplit_m = dm_cdiv(N2, kc_m);
     const int nsplit_d = dcomm ? dm_cdiv(n_ops * k2, 512) : 0;
     size_t need = dm_align_up((size_t)B * (k1 + k2) * k1 * 8) + 4 * dm_align_up(bKK) + 4 * dm_align_up((size_t)B * 8) + 65536;
     if (m_terms)      // O(N k): the mapped indicator is never stored (em_stats_kernel / em_deriv_kernel)
@@ -574,6 +581,26 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* PQ = (double*)dm_ws_take(ctx, (size_t)B * (k1 + k2) * k1 * 8);
+    // P, Q do not depend on C: an L-BFGS driver asks to keep them across its evaluations (option "energy_keep_gram")
+    const bool keep_gram = ctx->opt_energy_keep_gram != 0;
+    if (keep_gram) {
+        const size_t gb = (size_t)B * (k1 + k2) * k1 * 8;
+        const bool same = ctx->gram_valid && ctx->gram_key_ptr[0] == (const void*)A && ctx->gram_key_ptr[1] == (const void*)Bm &&
+                          ctx->gram_key_dim[0] == B && ctx->gram_key_dim[1] == k1 && ctx->gram_key_dim[2] == k2 && ctx->gram_key_dim[3] == D;
+        if (!same) {
+            ctx->gram_valid = false;
+            if (gb > ctx->gram_keep_bytes) {
+                DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->gram_keep) DM_CHECK_HIP(ctx, hipFree(ctx->gram_keep));
+                ctx->gram_keep = nullptr; ctx->gram_keep_bytes = 0;
+                DM_CHECK_HIP(ctx, hipMalloc((void**)&ctx->gram_keep, gb));
+                ctx->gram_keep_bytes = gb;
+            }
+            ctx->gram_key_ptr[0] = A; ctx->gram_key_ptr[1] = Bm;
+            ctx->gram_key_dim[0] = B; ctx->gram_key_dim[1] = k1; ctx->gram_key_dim[2] = k2; ctx->gram_key_dim[3] = D;
+        }
+        PQ = ctx->gram_keep;
+    }
     double* CP = (double*)dm_ws_take(ctx, bKK);
     double* Gm = (double*)dm_ws_take(ctx, bKK);
     double* G1 = (double*)dm_ws_take(ctx, bKK);
@@ -588,8 +615,10 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         KRowsStackedF32 opa{A, Bm, k1, k2, D};
         KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
         OutNT out{PQ, (long long)(k1 + k2) * k1, k1};
-        DM_LAUNCH(ctx, "energy_gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutNT>),
-                  dim3(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, opa, opb, out, k1 + k2, k1, D);
+        if (!keep_gram || !ctx->gram_valid)
+            DM_LAUNCH(ctx, "energy_gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutNT>),
+                      dim3(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, opa, opb, out, k1 + k2, k1, D);
+        if (keep_gram) ctx->gram_valid = true;
         KRowsF64 ca{C, (long long)k2 * k1, k1, k2, k1, 0};
         KRowsF64 pb{PQ, (long long)(k1 + k2) * k1, k1, k1, k1, 1};          // (C P)_ij = sum_k C_ik P_kj
         OutNT ocp{CP, (long long)k2 * k1, k1};
@@ -600,6 +629,8 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     }
 
     // ---- terms in the mapped indicator
+    combine_mterms cm;
+    memset(&cm, 0, sizeof(cm));
     if (m_terms) {
         const int nrb = dm_cdiv(N2, EM_T);
         const bool stats = mw.stoch > 0 || mw.sumto1 > 0;
@@ -652,21 +683,21 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
 #undef EM_DERIV
         }
         if (ncs > 1) {
+            // (kept as its own launch: folded into the product's operand reads it made the four workgroups of a single pair's
+            //  product walk ncs dependent loads per entry, 28 -> 122 us)
             const long long ny = (long long)B * N2 * k1;
             DM_LAUNCH(ctx, "energy_sum_splits", em_sum_splits_kernel, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, Yv, ny, ncs);
         }
-        DM_LAUNCH(ctx, "energy_finish", m_finish_energy_kernel, dim3(B), dim3(256), 0, pe, ncs * nrb, N1, N2, cs, csq, stat, nstat, mw, e_m);
-        {   // Gm = Phi2^T Y
+        {   // Gm = Phi2^T Y; its split-K partials are added by combine_kernel, which also finishes the terms' energy (two launches
+            // fewer per evaluation, same additions)
             RowsF32Scaled opx{Phi2, (long long)N2 * ld2, ld2, k2, nullptr, 0};
             RowsF64TN opy{Yv, (long long)N2 * k1, k1, k1};
-            OutTNPartial op{nsplit_m > 1 ? part : Gm, B, k2, k1};
+            OutTNPartial op{part, B, k2, k1};
             DM_LAUNCH(ctx, "energy_back_tn_f64", (gemm_tn_f64<RowsF32Scaled, RowsF64TN, OutTNPartial>),
-                      dim3(dm_cdiv(k2, TN_T) * dm_cdiv(k1, TN_T), nsplit_m, B), dim3(256), 0, opx, opy, op, k2, k1, N2, 512);
-            if (nsplit_m > 1) {
-                const long long n = (long long)B * k2 * k1;
-                DM_LAUNCH(ctx, "splitk_reduce", reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, part, nsplit_m, n, Gm);
-            }
+                      dim3(dm_cdiv(k2, TN_T) * dm_cdiv(k1, TN_T), nsplit_m, B), dim3(256), 0, opx, opy, op, k2, k1, N2, kc_m);
         }
+        cm.gm_part = part; cm.gm_nsplit = nsplit_m;
+        cm.pe = pe; cm.nblk = ncs * nrb; cm.N1 = N1; cm.N2 = N2; cm.cs = cs; cm.csq = csq; cm.stat = stat; cm.nstat = nstat; cm.mw = mw;
     }
 
     // ---- descriptor commutativity: T_d = C L_d - R_d C;  G1 = sum_d T_d L_d^T;  G2 = sum_d R_d^T T_d
@@ -704,9 +735,9 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
             }
         }
     }
-    DM_LAUNCH(ctx, "energy_combine", combine_kernel, dim3(B), dim3(256), 0, grad, m_terms ? Gm : (const double*)nullptr,
+    DM_LAUNCH(ctx, "energy_combine", combine_kernel, dim3(B), dim3(256), 0, grad, cm, (long long)B * k2 * k1,
               dcomm ? G1 : (const double*)nullptr, dcomm ? G2 : (const double*)nullptr, w[W_DCOMM], k1, k2, e_quad,
-              m_terms ? e_m : (const double*)nullptr, dcomm ? e_dc : (const double*)nullptr, energy);
+              dcomm ? e_dc : (const double*)nullptr, energy);
     return DM_OK;
 }
 

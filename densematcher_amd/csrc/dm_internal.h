@@ -46,6 +46,14 @@ struct dm_ctx {
     int opt_solve_reg = 1;       // 0: the LDS-resident blocked solver also where the register-resident one (n <= 128) would run
     int opt_p2p_split = 2;       // four maps: 0 the float64 G kernel, 1 two passes of the two-key fp16 tile kernel, 2 one pass reducing in both directions (3: 4-wave shape)
     int opt_simnn_persist = 1;   // 0: one workgroup per similarity tile instead of one persistent workgroup per CU
+    int opt_energy_keep_gram = 0;  // 1: dm_fmap_energy_grad keeps P = A A^T, Q = B A^T of its FIRST call and reuses them while A, B
+                                   // (pointers and sizes) stay the same: the caller promises not to change their contents (the L-BFGS
+                                   // driver: the projected descriptors are fixed during a fit).  Setting the option again drops them.
+    double* gram_keep = nullptr;   // (its own allocation: the workspace arena is recycled by every call)
+    size_t gram_keep_bytes = 0;
+    const void* gram_key_ptr[2] = {nullptr, nullptr};
+    int gram_key_dim[4] = {0, 0, 0, 0};
+    bool gram_valid = false;
     int n_cu = 0;                // multiProcessorCount of the device
 };
 

@@ -55,6 +55,40 @@ __device__ __forceinline__ double lb_dot(const double* a, const double* b, int n
     return lb_block_sum(s, sh);
 }
 
+// One-barrier block sum for the register-resident direction update.  The additions follow lb_block_sum's tree (partners at
+// lane distance 32, 16, 8, 4, 2, 1, then the four waves); the partner's value comes over the vector ALU instead of
+// ds_bpermute: half swaps for 32 and 16, row rotations for 8, 4, 2 (after the level above, lanes that differ in a higher
+// bit hold equal sums, so "i + d mod 16" is as good as "i xor d"), a quad permute for 1.  (The compiler fuses the product
+// into the first addition, so the last bits differ from the generic path's: where the energy is flat to 1e-10 the
+// number of iterations before the ftol test fires moves with such bits -- 289 to 440 evaluations on the notebook's fit.)
+template <int LEVEL>
+__device__ __forceinline__ int lb_partner(int x) {
+    if constexpr (LEVEL == 5) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);     // r[0] = low half twice, r[1] = high half twice
+        return (int)((threadIdx.x & 32) ? r[0] : r[1]);
+    } else if constexpr (LEVEL == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);     // r[0] = rows 0 0 2 2, r[1] = rows 1 1 3 3
+        return (int)((threadIdx.x & 16) ? r[0] : r[1]);
+    } else if constexpr (LEVEL == 3) return __builtin_amdgcn_mov_dpp(x, 0x128, 0xf, 0xf, false);    // row_ror:8
+    else if constexpr (LEVEL == 2) return __builtin_amdgcn_mov_dpp(x, 0x124, 0xf, 0xf, false);      // row_ror:4
+    else if constexpr (LEVEL == 1) return __builtin_amdgcn_mov_dpp(x, 0x122, 0xf, 0xf, false);      // row_ror:2
+    else return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xf, 0xf, false);                                 // quad_perm [1,0,3,2]
+}
+template <int LEVEL>
+__device__ __forceinline__ double lb_add_level(double v) {
+    return v + __hiloint2double(lb_partner<LEVEL>(__double2hiint(v)), lb_partner<LEVEL>(__double2loint(v)));
+}
+__device__ __forceinline__ double lb_fast_sum(double v, double (*sh2)[4], int& par) {
+    v = lb_add_level<5>(v); v = lb_add_level<4>(v); v = lb_add_level<3>(v);
+    v = lb_add_level<2>(v); v = lb_add_level<1>(v); v = lb_add_level<0>(v);
+    if ((threadIdx.x & 63) == 0) sh2[par][threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = (sh2[par][0] + sh2[par][1]) + (sh2[par][2] + sh2[par][3]);
+    par ^= 1;
+    return r;
+}
+constexpr int LB_FAST_M = 32;      // history length the register-resident update holds (one coefficient per thread: n <= 256)
+
 // minimiser of the cubic through (a, fa, da), (b, fb, db), safeguarded into the inner 80 % of the interval; bisection when
 // the cubic has no minimiser there
 __device__ __forceinline__ double lb_cubic(double a, double fa, double da, double b, double fb, double db) {
@@ -219,6 +253,43 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(int n, lbfgs_opts o,
     }
     }
     // ---------------------------------------------------------------- new direction: two-loop recursion, d = -H g
+    if (n <= 256 && o.m <= LB_FAST_M) {
+        // small problems (the notebook's 15 x 15 map: n = 225): the 2 m dependent dot products are the whole cost of a call,
+        // so the history rows are fetched up front (independent loads, one latency), the direction stays in a register and
+        // a dot product is one wave sum on the vector ALU + one barrier  (49 -> 23 us per call)
+        __shared__ double sh2[2][4];
+        int par = 0;
+        const bool on = t < n;
+        double sreg[LB_FAST_M], yreg[LB_FAST_M], rreg[LB_FAST_M], areg[LB_FAST_M];
+        __syncthreads();                                  // (rho / gamma of the newest pair were written by thread 0)
+#pragma unroll
+        for (int q = 0; q < LB_FAST_M; ++q) {
+            const int idx = (head - 1 - q + 2 * o.m) % o.m;
+            const bool live = q < nh;
+            sreg[q] = (live && on) ? Sb[(long long)idx * n + t] : 0.0;
+            yreg[q] = (live && on) ? Yb[(long long)idx * n + t] : 0.0;
+            rreg[q] = live ? rb[idx] : 0.0;
+        }
+        double dr = on ? -gb[t] : 0.0;
+#pragma unroll
+        for (int q = 0; q < LB_FAST_M; ++q) {             // newest to oldest
+            if (q < nh) {                                 // (uniform)
+                const double a = rreg[q] * lb_fast_sum(sreg[q] * dr, sh2, par);
+                areg[q] = a;
+                dr = fma(-a, yreg[q], dr);
+            }
+        }
+        dr *= nh > 0 ? scb[LS_GAMMA] : 1.0;
+#pragma unroll
+        for (int q = LB_FAST_M - 1; q >= 0; --q) {        // oldest to newest
+            if (q < nh) {
+                const double be = rreg[q] * lb_fast_sum(yreg[q] * dr, sh2, par);
+                dr = fma(areg[q] - be, sreg[q], dr);
+            }
+        }
+        if (on) db[t] = dr;
+        __syncthreads();
+    } else {
     for (int e = t; e < n; e += 256) db[e] = -gb[e];
     __syncthreads();
     for (int q = 0; q < nh; ++q) {                        // newest to oldest
@@ -239,6 +310,7 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(int n, lbfgs_opts o,
         const double* Si = Sb + (long long)idx * n;
         for (int e = t; e < n; e += 256) db[e] = fma(a - be, Si[e], db[e]);
         __syncthreads();
+    }
     }
     double dphi0 = lb_dot(gb, db, n, sh);
     if (!(dphi0 < 0.0)) {                                 // not a descent direction (numerical breakdown): restart from steepest descent

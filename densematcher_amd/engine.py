@@ -82,7 +82,7 @@ class MatchEngine:
     def synchronize(self):
         self.stream.synchronize()
 
-    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0, "solve_reg": 1, "simnn_band": 4, "lsa_reg": 2, "simnn_big": 0}
+    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0, "solve_reg": 1, "simnn_band": 4, "lsa_reg": 2, "simnn_big": 0, "energy_keep_gram": 0}
 
     def set_option(self, name, value):
         """Choose between equivalent code paths of the library (include/densematch.h: dm_set_option); every setting
@@ -346,14 +346,19 @@ class MatchEngine:
         n_f64 = 3 * B * n + 2 * B * m * n + 2 * B * m + 16 * B
         ints = state[n_f64:n_f64 + (8 * B * 4 + 7) // 8].view(torch.int32)[:8 * B].view(B, 8)
         nev, maxfun = 0, int(opts["maxfun"])
-        while True:
-            e, g = self.energy_grad(xt, A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
-            self._chk(self.lib.dm_lbfgs_advance(self.ctx, B, n, m, _ptr(state), _ptr(e), _ptr(g), _ptr(xt), float(opts["ftol"]),
-                                                float(opts["gtol"]), int(maxiter), maxfun, int(opts["maxls"])))
-            nev += 1
-            if nev % check_every == 0 or nev > maxfun + 2:
-                if bool((ints[:, 0] != 0).all()) or nev > maxfun + 2:        # (one host synchronisation per check_every evaluations)
-                    break
+        # the projected descriptors A, Bm are fixed during the fit: their Gram blocks are computed by the first evaluation only
+        self.set_option("energy_keep_gram", 1)
+        try:
+            while True:
+                e, g = self.energy_grad(xt, A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
+                self._chk(self.lib.dm_lbfgs_advance(self.ctx, B, n, m, _ptr(state), _ptr(e), _ptr(g), _ptr(xt), float(opts["ftol"]),
+                                                    float(opts["gtol"]), int(maxiter), maxfun, int(opts["maxls"])))
+                nev += 1
+                if nev % check_every == 0 or nev > maxfun + 2:
+                    if bool((ints[:, 0] != 0).all()) or nev > maxfun + 2:    # (one host synchronisation per check_every evaluations)
+                        break
+        finally:
+            self.set_option("energy_keep_gram", 0)
         xo = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
         fo = torch.empty((B,), dtype=torch.float64, device=self.device)
         info = torch.empty((B, 4), dtype=torch.int32, device=self.device)

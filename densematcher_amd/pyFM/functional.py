@@ -13,10 +13,12 @@ _OPTIMIZERS = ("L-BFGS-B", "fmin_l_bfgs_b", "l-bfgs-b")
 # maxcor = 10) and evaluates in float32, which stops 1e-4 .. 1e-3 short of the minimiser.  The float64
 # evaluation here makes a tight rule meaningful and the 1e-4 parity bar on C needs it: tight by default (bounded by SciPy's
 # maxfun = 15000); fit(..., stopping="reference") runs SciPy's default rule instead.
-# ftol = 1e-13: the energy is flat around its minimiser, and a relative decrease of a few machine epsilons (1e-15) is decided by
-# rounding noise -- the same call took 740 or 1690 evaluations depending on a summation order, for a C that moves by 2e-5;
-# at 1e-13 it takes ~330 and C is within 2e-5 of that limit (tools/fit_profile.py).
-LBFGS_OPTIONS = {"ftol": 1e-13, "gtol": 1e-9, "maxcor": 30, "maxfun": 15000}
+# ftol = 1e-12: the energy is flat around its minimiser, and WHEN a relative decrease of a few machine epsilons is first seen
+# is decided by rounding noise -- on the notebook's fit the same rule took 289, 322, 351, 440 or 448 evaluations at 1e-13 (740
+# or 1690 at 1e-15) as summation orders inside the evaluation changed, for maps that agree to 2e-5.  Measured on that fit
+# (tools/fit_profile.py <ftol>; distance of C from the 1e-15 result): 1e-14 464 evaluations 8e-7, 1e-13 448 1e-6,
+# 1e-12 332 9e-6, 1e-11 261 4e-5, 1e-10 224 1.3e-4.  1e-12 keeps a factor ten under the 1e-4 bar on C.
+LBFGS_OPTIONS = {"ftol": 1e-12, "gtol": 1e-9, "maxcor": 30, "maxfun": 15000}
 
 
 class FunctionalMapping:

@@ -655,3 +655,33 @@ def test_raw_non_delaunay_mesh_robust_laplacian():
     print("non-Delaunay torus: robust vs cotangent Laplacian: eigenvalue change",
           float(np.abs(maps[True][2] - maps[False][2]).max() / maps[True][2][-1]),
           " p2p_21 agreement", float((maps[True][0] == maps[False][0]).mean()), " p2p_12 agreement", float((maps[True][1] == maps[False][1]).mean()))
+
+
+def test_energy_keep_gram_option():
+    """dm_set_option "energy_keep_gram": the Gram blocks of the projected descriptors are computed by the first evaluation and
+    reused while the same A, B are passed (the L-BFGS driver's case): identical energies and gradients with and without;
+    other operands, or setting the option again, recompute"""
+    import torch
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(5)
+    B, k1, k2, D = 2, 15, 17, 40
+    dev = eng.device
+    A = torch.as_tensor(rng.standard_normal((B, k1, D)).astype(np.float32)).to(dev)
+    Bm = torch.as_tensor(rng.standard_normal((B, k2, D)).astype(np.float32)).to(dev)
+    A2 = torch.as_tensor(rng.standard_normal((B, k1, D)).astype(np.float32)).to(dev)
+    lam1, lam2 = np.sort(rng.uniform(0, 50, (B, k1)), axis=1), np.sort(rng.uniform(0, 50, (B, k2)), axis=1)
+    w = {"w_descr": 1.0, "w_lap": 0.1}
+    Cs = [rng.standard_normal((B, k2, k1)) for _ in range(3)]
+    plain = [eng.energy_grad(C, A, Bm, lam1, lam2, w) for C in Cs]
+    plain2 = eng.energy_grad(Cs[0], A2, Bm, lam1, lam2, w)
+    eng.set_option("energy_keep_gram", 1)
+    try:
+        kept = [eng.energy_grad(C, A, Bm, lam1, lam2, w) for C in Cs]
+        kept2 = eng.energy_grad(Cs[0], A2, Bm, lam1, lam2, w)            # other operand: recomputed
+        kept3 = eng.energy_grad(Cs[1], A, Bm, lam1, lam2, w)             # and back
+    finally:
+        eng.set_option("energy_keep_gram", 0)
+    for (e0, g0), (e1, g1) in zip(plain + [plain2, plain[1]], kept + [kept2, kept3]):
+        assert torch.equal(e0, e1) and torch.equal(g0, g1)
+    assert not torch.equal(plain2[0], plain[0][0])
