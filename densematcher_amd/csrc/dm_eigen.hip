@@ -165,15 +165,24 @@ __global__ __launch_bounds__(256) void ritz_residual_kernel(const double* __rest
 // Cyclic two-sided Jacobi eigensolver of a symmetric m x m matrix (m <= 512), one workgroup of 1024 threads per matrix,
 // round-robin ordering (m/2 disjoint rotations per round: the row updates of a round are independent, then the column
 // updates of H and of the accumulated eigenvectors V).  H is overwritten (diagonal = eigenvalues), V (m x m, columns).
+// IN_LDS: both matrices live in the LDS for the duration (2 m^2 doubles; m <= 90): a round is three barriers around two
+// read-modify-write passes, and from global memory each pass waits for an L2 round trip: 1.58 -> 1.19 ms per call at m = 52
+// (5 to 10 sweeps of 51 rounds; 19 -> 14 of the 33 ms of the notebook pair's eigensolve; four waves instead of sixteen: 1.67 ms,
+// the passes want the threads).  Same rotations, same arithmetic.
+template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ Hs, double* __restrict__ Vs, int m, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) double jac_sm[];
     __shared__ double rc[256], rs[256];
     __shared__ int rp[256], rq[256];
     __shared__ unsigned long long s_off, s_diag;
-    const int b = blockIdx.x, t = threadIdx.x;
-    double* H = Hs + (long long)b * m * m;
-    double* V = Vs + (long long)b * m * m;
+    const int b = blockIdx.x, t = threadIdx.x, nthr = blockDim.x;
+    double* Hg = Hs + (long long)b * m * m;
+    double* Vg = Vs + (long long)b * m * m;
+    double* H = IN_LDS ? jac_sm : Hg;
+    double* V = IN_LDS ? jac_sm + m * m : Vg;
     const int mm = m + (m & 1), half = mm / 2;
-    for (int e = t; e < m * m; e += 1024) V[e] = (e / m == e % m) ? 1.0 : 0.0;
+    if (IN_LDS) for (int e = t; e < m * m; e += nthr) H[e] = Hg[e];
+    for (int e = t; e < m * m; e += nthr) V[e] = (e / m == e % m) ? 1.0 : 0.0;
     __syncthreads();
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (t == 0) { s_off = 0ull; s_diag = 0ull; }
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ 
                 rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = s;
             }
             __syncthreads();
-            for (int idx = t; idx < half * m; idx += 1024) {              // rows p, q <- J^T rows
+            for (int idx = t; idx < half * m; idx += nthr) {              // rows p, q <- J^T rows
                 const int pr = idx / m, j = idx - pr * m;
                 const double s = rs[pr];
                 if (s != 0.0) {
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ 
                 }
             }
             __syncthreads();
-            for (int idx = t; idx < half * m; idx += 1024) {              // columns p, q <- columns J   (H and V)
+            for (int idx = t; idx < half * m; idx += nthr) {              // columns p, q <- columns J   (H and V)
                 const int i = idx / half, pr = idx - i * half;
                 const double s = rs[pr];
                 if (s != 0.0) {
@@ -228,6 +237,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ 
         __syncthreads();
         if (off <= 1e-15 * dg) break;
     }
+    if (IN_LDS) for (int e = t; e < m * m; e += nthr) { Hg[e] = H[e]; Vg[e] = V[e]; }
 }
 
 // theta[b] = sorted diagonal of H; Q[b][:, rank] = V[b][:, j]   (ascending; equal values keep their index order)
@@ -376,7 +386,14 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
                   Ya, m, (const double*)nullptr, 0);
         rc = eig_gram(ctx, w, Xcur, Ya, H, 1);
         if (rc) return rc;
-        DM_LAUNCH(ctx, "eig_jacobi", jacobi_eigh_kernel, dim3(B), dim3(1024), 0, H, V, m, 30);
+        const size_t jac_lds = (size_t)2 * m * m * 8;
+        if (jac_lds <= 128 * 1024) {
+            int rc_ = dm_grant_lds(ctx, (const void*)jacobi_eigh_kernel<true>, jac_lds);
+            if (rc_) return rc_;
+            DM_LAUNCH(ctx, "eig_jacobi", jacobi_eigh_kernel<true>, dim3(B), dim3(1024), jac_lds, H, V, m, 30);
+        } else {
+            DM_LAUNCH(ctx, "eig_jacobi", jacobi_eigh_kernel<false>, dim3(B), dim3(1024), 0, H, V, m, 30);
+        }
         DM_LAUNCH(ctx, "eig_ritz_sort", ritz_sort_kernel, dim3(B), dim3(256), (size_t)m * 8 + (size_t)m * 4, (const double*)H, (const double*)V, m,
                   theta, Q);
         rc = eig_apply(ctx, w, Xcur, Q, 1, 0.0, 1.0, Yb);                            // Ritz vectors: (X Q)_ic = sum_k X_ik Q_kc
