@@ -557,12 +557,14 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     DM_REQUIRE(ctx, !m_terms || k1 <= 256, "the indicator terms need k1 <= 256");
     // Work decomposition of the two indicator passes: a workgroup sweeps `rg` rows x one column split.  A batch fills the chip
     // with whole-row sweeps (rg = 512, no splits); a single pair (the reference's use: one pair per call) would leave 252 of the
-    // 256 CUs idle that way, so the row groups shrink to one 64-row block and the columns are split until ~512 workgroups exist.
+    // 256 CUs idle that way, so the row groups shrink to one 64-row block and the columns are split until ~1024 workgroups exist
+    // (two per CU hide the other's log / divide chains; measured on the notebook fit, workgroups x column tiles each: 256 x 4
+    // 56.7 + 30.6 us for the two passes, 512 x 2 46.0 + 21.6, 1024 x 1 50.6 + 21.1 with twice the partials to add up).
     int rg = EM_RG, ncs = 1;
     {
-        const int ncu2 = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+        const int ncu2 = 4 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
         while (rg > EM_T && (long long)B * dm_cdiv(N2, rg) < ncu2) rg >>= 1;
-        const int max_split = dm_cdiv(N1, 4 * EM_T) > 0 ? dm_cdiv(N1, 4 * EM_T) : 1;        // at least four column tiles per workgroup
+        const int max_split = dm_cdiv(N1, 2 * EM_T) > 0 ? dm_cdiv(N1, 2 * EM_T) : 1;        // at least two column tiles per workgroup
         while (ncs < max_split && (long long)B * dm_cdiv(N2, EM_T) * ncs < ncu2) ncs <<= 1;
     }
     const int cchunk = pad_to(dm_cdiv(N1, ncs), EM_T);
