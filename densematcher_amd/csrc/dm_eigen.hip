@@ -58,18 +58,25 @@ __global__ __launch_bounds__(256) void eig_reduce_partials_kernel(const double* 
                                                                   double* __restrict__ out, int symmetrise_m) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    double s = 0.0;
-    for (int q = 0; q < nsplit; ++q) s += partial[(long long)q * n + i];
+    // (the element and its mirror image in flight together, eight partials at a time, added in split order)
+    long long j = i;
     if (symmetrise_m > 0) {         // (H + H^T) / 2: the Jacobi sweeps assume exact symmetry
         const long long mm = (long long)symmetrise_m * symmetrise_m;
         const long long b = i / mm, e = i - b * mm;
         const int r = (int)(e / symmetrise_m), c = (int)(e - (long long)r * symmetrise_m);
-        const long long j = b * mm + (long long)c * symmetrise_m + r;
-        double s2 = 0.0;
-        for (int q = 0; q < nsplit; ++q) s2 += partial[(long long)q * n + j];
-        s = 0.5 * (s + s2);
+        j = b * mm + (long long)c * symmetrise_m + r;
     }
-    out[i] = s;
+    double s = 0.0, s2 = 0.0;
+    int q = 0;
+    for (; q + 8 <= nsplit; q += 8) {
+        double a[8], c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a[u] = partial[(long long)(q + u) * n + i]; c[u] = partial[(long long)(q + u) * n + j]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += a[u]; s2 += c[u]; }
+    }
+    for (; q < nsplit; ++q) { s += partial[(long long)q * n + i]; s2 += partial[(long long)q * n + j]; }
+    out[i] = symmetrise_m > 0 ? 0.5 * (s + s2) : s;
 }
 
 // ---- sparse product with the fused three-term recurrence ------------------------------------------------------------------
@@ -167,8 +174,9 @@ __global__ __launch_bounds__(256) void ritz_residual_kernel(const double* __rest
 // updates of H and of the accumulated eigenvectors V).  H is overwritten (diagonal = eigenvalues), V (m x m, columns).
 // IN_LDS: both matrices live in the LDS for the duration (2 m^2 doubles; m <= 90): a round is three barriers around two
 // read-modify-write passes, and from global memory each pass waits for an L2 round trip: 1.58 -> 1.19 ms per call at m = 52
-// (5 to 10 sweeps of 51 rounds; 19 -> 14 of the 33 ms of the notebook pair's eigensolve; four waves instead of sixteen: 1.67 ms,
-// the passes want the threads).  Same rotations, same arithmetic.
+// (5 to 10 sweeps of 51 rounds; four waves instead of sixteen: 1.67 ms, the passes want the threads); the two sides of a round
+// applied to disjoint 2 x 2 blocks in one pass: 1.06 ms; the sweep's convergence measure kept in registers instead of two
+// 64-bit LDS atomicMax per pair and round: 0.37 ms.  Same rotations, same arithmetic.
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ Hs, double* __restrict__ Vs, int m, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) double jac_sm[];
@@ -183,21 +191,30 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ 
     const int mm = m + (m & 1), half = mm / 2;
     if (IN_LDS) for (int e = t; e < m * m; e += nthr) H[e] = Hg[e];
     for (int e = t; e < m * m; e += nthr) V[e] = (e / m == e % m) ? 1.0 : 0.0;
+    // this thread's work items of a round (the same every round): up to two 2 x 2 blocks of H (pair a, pair b) and up to four
+    // (row of V, pair) items  (IN_LDS: half <= 45, 1024 threads)
+    int blk_a[2], blk_b[2], vit_i[4], vit_p[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int e = t + u * nthr; blk_a[u] = e < half * half ? e / half : -1; blk_b[u] = e < half * half ? e % half : 0; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = t + u * nthr; vit_i[u] = e < half * m ? e / half : -1; vit_p[u] = e < half * m ? e % half : 0; }
     __syncthreads();
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         if (t == 0) { s_off = 0ull; s_diag = 0ull; }
         __syncthreads();
+        double my_off = 0.0, my_diag = 0.0;               // (this pair slot's largest pivot / diagonal entry of the sweep: one atomic per sweep)
+        int pc = t % (mm - 1), qc = (2 * (mm - 1) - t) % (mm - 1);       // (r + t) mod (mm - 1), (r - t) mod (mm - 1) at r = 0, advanced by one per round
         for (int r = 0; r < mm - 1; ++r) {
             if (t < half) {
                 int p, q;
                 if (t == 0) { p = mm - 1; q = r; }
-                else { p = (r + t) % (mm - 1); q = (r - t + (mm - 1)) % (mm - 1); }
+                else { p = pc; q = qc; }
                 if (p > q) { const int x = p; p = q; q = x; }
                 double c = 1.0, s = 0.0;
                 if (q < m) {
                     const double a = H[(long long)p * m + p], d = H[(long long)q * m + q], bq = H[(long long)p * m + q];
-                    atomicMax(&s_off, (unsigned long long)__double_as_longlong(fabs(bq)));
-                    atomicMax(&s_diag, (unsigned long long)__double_as_longlong(fmax(fabs(a), fabs(d))));
+                    my_off = fmax(my_off, fabs(bq));
+                    my_diag = fmax(my_diag, fmax(fabs(a), fabs(d)));
                     if (fabs(bq) > 1e-300) {
                         const double tau = (d - a) / (2.0 * bq);
                         const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
@@ -207,7 +224,54 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ 
                 }
                 rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = s;
             }
+            pc = pc + 1 == mm - 1 ? 0 : pc + 1; qc = qc + 1 == mm - 1 ? 0 : qc + 1;
             __syncthreads();
+            if constexpr (IN_LDS) {
+                // one pass: the 2 x 2 block (pair a, pair b) of H takes its row rotation, then its column rotation, in place
+                // (the blocks of a round are disjoint: no barrier between the two sides); V's columns in the same pass
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (blk_a[u] >= 0) {
+                        const int a = blk_a[u], bb = blk_b[u];
+                        const double sa = rs[a], sb = rs[bb];
+                        if (sa != 0.0 || sb != 0.0) {
+                            const double ca = rc[a], cb = rc[bb];
+                            const int pa = rp[a], qa = rq[a], pb = rp[bb], qb = rq[bb];
+                            const bool vqa = qa < m, vqb = qb < m;
+                            double h00 = H[pa * m + pb], h01 = vqb ? H[pa * m + qb] : 0.0;
+                            double h10 = vqa ? H[qa * m + pb] : 0.0, h11 = (vqa && vqb) ? H[qa * m + qb] : 0.0;
+                            if (sa != 0.0) {
+                                const double t00 = ca * h00 - sa * h10, t10 = sa * h00 + ca * h10;
+                                const double t01 = ca * h01 - sa * h11, t11 = sa * h01 + ca * h11;
+                                h00 = t00; h10 = t10; h01 = t01; h11 = t11;
+                            }
+                            if (sb != 0.0) {
+                                const double n00 = cb * h00 - sb * h01, n01 = sb * h00 + cb * h01;
+                                const double n10 = cb * h10 - sb * h11, n11 = sb * h10 + cb * h11;
+                                h00 = n00; h01 = n01; h10 = n10; h11 = n11;
+                            }
+                            H[pa * m + pb] = h00;
+                            if (vqb) H[pa * m + qb] = h01;
+                            if (vqa) H[qa * m + pb] = h10;
+                            if (vqa && vqb) H[qa * m + qb] = h11;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (vit_i[u] >= 0) {
+                        const int pr = vit_p[u];
+                        const double sv = rs[pr];
+                        if (sv != 0.0) {
+                            const double cv = rc[pr];
+                            const int op = vit_i[u] * m + rp[pr], oq = vit_i[u] * m + rq[pr];
+                            const double vp = V[op], vq = V[oq];
+                            V[op] = cv * vp - sv * vq; V[oq] = sv * vp + cv * vq;
+                        }
+                    }
+                }
+                __syncthreads();
+            } else {
             for (int idx = t; idx < half * m; idx += nthr) {              // rows p, q <- J^T rows
                 const int pr = idx / m, j = idx - pr * m;
                 const double s = rs[pr];
@@ -232,7 +296,13 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ 
                 }
             }
             __syncthreads();
+            }
         }
+        if (t < half) {
+            atomicMax(&s_off, (unsigned long long)__double_as_longlong(my_off));
+            atomicMax(&s_diag, (unsigned long long)__double_as_longlong(my_diag));
+        }
+        __syncthreads();
         const double off = __longlong_as_double((long long)s_off), dg = __longlong_as_double((long long)s_diag);
         __syncthreads();
         if (off <= 1e-15 * dg) break;
@@ -292,7 +362,7 @@ __global__ __launch_bounds__(256) void eig_finish_kernel(const double* __restric
 struct eig_ws {
     int B, N, m;
     double *T, *W, *part;           // m x m scratch (x2) and split-K partials
-    int nsplit;
+    int nsplit, kchunk;             // split-K of the Gram products: rows per chunk by the block size only (never by the batch)
 };
 // G (B, m, m) = P^T R over the N rows (split-K, fixed order); symmetrised when asked
 static int eig_gram(dm_ctx* ctx, const eig_ws& w, const double* P, const double* R, double* G, int symmetrise) {
@@ -300,7 +370,7 @@ static int eig_gram(dm_ctx* ctx, const eig_ws& w, const double* P, const double*
     EigRowsTN ry{R, (long long)w.N * w.m, w.m, w.m};
     EigOutTNPartial out{w.part, w.B, w.m, w.m};
     DM_LAUNCH(ctx, "eig_gram_tn_f64", (gemm_tn_f64<EigRowsTN, EigRowsTN, EigOutTNPartial>),
-              dim3(dm_cdiv(w.m, TN_T) * dm_cdiv(w.m, TN_T), w.nsplit, w.B), dim3(256), 0, px, ry, out, w.m, w.m, w.N, 512);
+              dim3(dm_cdiv(w.m, TN_T) * dm_cdiv(w.m, TN_T), w.nsplit, w.B), dim3(256), 0, px, ry, out, w.m, w.m, w.N, w.kchunk);
     const long long n = (long long)w.B * w.m * w.m;
     DM_LAUNCH(ctx, "eig_reduce", eig_reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w.part, w.nsplit, n, G,
               symmetrise ? w.m : 0);
@@ -349,7 +419,10 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bX = (size_t)B * N * m * 8, bM = (size_t)B * m * m * 8;
     eig_ws w;
-    w.B = B; w.N = N; w.m = m; w.nsplit = dm_cdiv(N, 512);
+    w.B = B; w.N = N; w.m = m;
+    // (a block of one 64 x 64 tile is four workgroups per mesh at 512 rows per chunk: 33 us per product, latency; 128 rows: 16)
+    w.kchunk = m <= TN_T ? 128 : 512;
+    w.nsplit = dm_cdiv(N, w.kchunk);
     int rc = dm_ws_reserve(ctx, 3 * dm_align_up(bX) + 5 * dm_align_up(bM) + dm_align_up((size_t)w.nsplit * bM) + dm_align_up((size_t)B * m * 8) +
                                     dm_align_up((size_t)B * EIG_MAX_DEG * 3 * 8) + 2 * dm_align_up((size_t)B * 8) + 4096);
     if (rc) return rc;
