@@ -562,16 +562,20 @@ def pmc_traffic_bytes(kernel, workload):
     """HBM bytes per launch of the dominant kernel, measured in separate rocprofv3 --pmc passes of this same command
     (PMC collection cannot run inside the timed region); summaries committed under profiles/."""
     import csv
-    dual = lambda name: any(name.rstrip('"').endswith(f", {d}>(simnn_params)") for d in (1, 2, 3))   # (4- and 8-wave shapes alike)
+    import re
+
+    def dual_of(name):           # third template argument of simnn_pipe_kernel<XV, WT, DUAL, ...>: 0 one key, 1 two keys, 3 both directions
+        mt = re.search(r"simnn_pipe_kernel<\d+, \d+, (\d+)", name)
+        return int(mt.group(1)) if mt else None
     match = {"gred_f64": lambda n: "gred_kernel" in n,
              "fmap_solve_chol": lambda n: "fmap_solve" in n,
              "embed_nt_f64": lambda n: "embed_tile_kernel" in n,
              "project_f16split_mfma": lambda n: "proj_f16split_kernel" in n,
              "gram_nt_f64": lambda n: "gemm_nt_f64" in n and "OutScaled" in n,
              "p2pfm_tn_f64": lambda n: "gemm_tn_f64" in n and "OutFM" in n,
-             "simnn_f16_mfma": lambda n: "simnn_pipe_kernel" in n and not dual(n),
-             "simnn2_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 1>(simnn_params)"),
-             "simnn4_f16_mfma": lambda n: "simnn_pipe_kernel" in n and n.rstrip('"').endswith(", 3>(simnn_params)")}.get(kernel, lambda n: kernel in n)
+             "simnn_f16_mfma": lambda n: dual_of(n) == 0,
+             "simnn2_f16_mfma": lambda n: dual_of(n) == 1,
+             "simnn4_f16_mfma": lambda n: dual_of(n) == 3}.get(kernel, lambda n: kernel in n)
     for rnd in ("r03", "r02", "r01"):
         fname = f"{rnd}_{workload}_hbm_traffic_pmc.csv"
         path = os.path.join(REPO, "profiles", fname)
