@@ -200,13 +200,11 @@ __device__ __forceinline__ int lsa_wave_max(int k) {                // uniform r
 //   (Jonker-Volgenant's column reduction; a feasible dual pair with tight assigned edges, so the augmentations continue from
 //   there to an optimum).  Fewer and shorter searches, but not SciPy's order: the caller accepts the result only when
 //   lsa_unique_kernel finds the optimum unique (no slack-free edge outside the assignment), else it reruns with WARM = 0.
+// returns true when the warm start stepped aside (nothing written): the caller runs the search in SciPy's order instead
 template <int CPT, int WARM, int NT>
-__global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ costs, int nr, int nc, int negate,
-                                                         double* __restrict__ g_u, double* __restrict__ g_v,
-                                                         int32_t* __restrict__ out_col4row, int32_t* __restrict__ info,
-                                                         const int32_t* __restrict__ run_if, int32_t* __restrict__ skip_warm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
-    if (run_if && run_if[blockIdx.x] == 0) return;        // (the exact-order rerun: only for matrices whose optimum may not be unique)
+__device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const double* __restrict__ costs, int nr, int nc, int negate,
+                                             double* __restrict__ g_u, double* __restrict__ g_v, int32_t* __restrict__ out_col4row,
+                                             int32_t* __restrict__ info) {
     // LDS: u (nr) doubles | row4col (nc), path (nc), col4row (nr) ints | slots
     double* u = reinterpret_cast<double*>(lsa_smem);
     int* row4col = reinterpret_cast<int*>(u + nr);
@@ -260,15 +258,7 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
             if (tied) atomicAdd(&s_count[0], tied);
             if (flat) atomicAdd(&s_count[1], flat);
             __syncthreads();
-            if (s_count[0] * 8 > nc || (s_count[1] >= 2 && nr >= 2)) {            // (uniform)
-                for (int i = t; i < nr; i += NT) {
-                    out_col4row[(long long)b * nr + i] = -1;
-                    if (g_u) g_u[(long long)b * nr + i] = 0.0;
-                }
-                if (g_v) for (int j = t; j < nc; j += NT) g_v[(long long)b * nc + j] = 0.0;
-                if (t == 0 && skip_warm) skip_warm[b] = 1;
-                return;
-            }
+            if (s_count[0] * 8 > nc || (s_count[1] >= 2 && nr >= 2)) return true;          // (uniform)
         }
         // claim: col4row[i] = the lowest column whose minimum is in row i (LDS atomics), then the winners record themselves
 #pragma unroll
@@ -458,6 +448,25 @@ __global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ 
             const int j = t + NT * q;
             if (j < nc) g_v[(long long)b * nc + j] = v[q];
         }
+    }
+    return false;
+}
+// run_if (the rerun in SciPy's order): only the matrices flagged 1 = "the warm start's optimum may not be unique".
+// skip_warm (the warm-start launch): a matrix the warm start steps aside from is searched in SciPy's order right here, by the
+// same workgroup (other matrices of the batch are still in their warm searches: no reason to wait for the rerun launch), and
+// flagged 2 = "done in order": the uniqueness check cannot lower that and the rerun passes it by.
+template <int CPT, int WARM, int NT>
+__global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ costs, int nr, int nc, int negate,
+                                                         double* __restrict__ g_u, double* __restrict__ g_v,
+                                                         int32_t* __restrict__ out_col4row, int32_t* __restrict__ info,
+                                                         const int32_t* __restrict__ run_if, int32_t* __restrict__ skip_warm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
+    if (run_if && run_if[blockIdx.x] != 1) return;
+    const bool aside = lsa_reg_body<CPT, WARM, NT>(lsa_smem, costs, nr, nc, negate, g_u, g_v, out_col4row, info);
+    if (WARM && aside) {                                  // (uniform)
+        __syncthreads();
+        lsa_reg_body<CPT, 0, NT>(lsa_smem, costs, nr, nc, negate, g_u, g_v, out_col4row, info);
+        if (threadIdx.x == 0 && skip_warm) skip_warm[blockIdx.x] = 2;
     }
 }
 

@@ -143,12 +143,19 @@ __global__ __launch_bounds__(256) void quad_terms_kernel(const double* __restric
     __syncthreads();
     const double scale = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
     const double* Cb = C + (long long)b * k2 * k1;
-    const double* CPb = CP + (long long)b * k2 * k1;
+    const double* CPb = CP ? CP + (long long)b * k2 * k1 : nullptr;
     const double* Q = PQ + ((long long)b * (k1 + k2) + k1) * k1;
     double acc = 0.0;
     for (int e = t; e < k2 * k1; e += 256) {
         const int i = e / k1, j = e - i * k1;
-        const double c = Cb[e], cp = CPb[e], q = Q[e];
+        double cp;
+        if (CP) cp = CPb[e];
+        else {                                            // small maps: (C P)_ij by this thread (P = the first k1 rows of PQ), a launch less
+            const double* Pm = PQ + (long long)b * (k1 + k2) * k1;
+            cp = 0.0;
+            for (int k = 0; k < k1; ++k) cp = fma(Cb[(long long)i * k1 + k], Pm[(long long)k * k1 + j], cp);
+        }
+        const double c = Cb[e], q = Q[e];
         const double dl = lam1[(long long)b * k1 + j] / scale - lam2[(long long)b * k2 + i] / scale;   // functional.py:404-405
         const double ev = dl * dl;
         grad[(long long)b * k2 * k1 + e] = w_d * (cp - q) + w_l * c * ev;
@@ -624,10 +631,12 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         KRowsF64 ca{C, (long long)k2 * k1, k1, k2, k1, 0};
         KRowsF64 pb{PQ, (long long)(k1 + k2) * k1, k1, k1, k1, 1};          // (C P)_ij = sum_k C_ik P_kj
         OutNT ocp{CP, (long long)k2 * k1, k1};
-        DM_LAUNCH(ctx, "energy_cp_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutNT>), dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
-                  dim3(256), 0, ca, pb, ocp, k2, k1, k1);
-        DM_LAUNCH(ctx, "energy_quad", quad_terms_kernel, dim3(B), dim3(256), 0, C, CP, PQ, Bm, lam1, lam2, k1, k2, D, w[W_DESCR], w[W_LAP],
-                  grad, e_quad);
+        const bool cp_inline = k1 <= 32 && k2 <= 32;      // (by the map's size only)
+        if (!cp_inline)
+            DM_LAUNCH(ctx, "energy_cp_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutNT>), dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
+                      dim3(256), 0, ca, pb, ocp, k2, k1, k1);
+        DM_LAUNCH(ctx, "energy_quad", quad_terms_kernel, dim3(B), dim3(256), 0, C, cp_inline ? (const double*)nullptr : (const double*)CP, PQ, Bm,
+                  lam1, lam2, k1, k2, D, w[W_DESCR], w[W_LAP], grad, e_quad);
     }
 
     // ---- terms in the mapped indicator
