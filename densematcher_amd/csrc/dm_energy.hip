@@ -210,6 +210,95 @@ __global__ __launch_bounds__(256) void m_finish_stats_kernel(const double* __res
     const double tot_r = block_sum_256(sr, sh);
     if (t == 0) { stat[((long long)b * G + g) * 2] = tot_r; stat[((long long)b * G + g) * 2 + 1] = tot_c; }
 }
+// Row and column SUMS of the mapped indicator are linear in it: with M_ij = (E2_i . Phi1_j) a1_j and E2 = Phi2 C,
+//   rs_i = E2_i . p,  p = sum_j a1_j Phi1_j (k1)        cs_j = a1_j Phi1_j . q,  q = sum_i E2_i = C^T s2,  s2 = sum_i Phi2_i (k2)
+// -- O(N k) instead of a pass over the N2 x N1 tiles.  When only w_sumto1 asks for statistics (the notebook's terms; the sums
+// of squares of w_stochastic still take the tile pass) two small kernels replace em_stats_kernel + m_finish_stats_kernel:
+//   em_basis_sums_kernel    p and s2: they do not depend on C (kept across an optimiser's evaluations, option "energy_keep_gram")
+//   em_stats_linear_kernel  a workgroup per 256 rows: q from s2 and C, then rs, cs and the block's shares of their totals
+// (fixed summation orders; rsq / csq are zeroed: their terms carry a zero weight).  A single workgroup per pair doing all
+// of it took 32 us -- nothing hides its loads -- against 22 + 12 us for the tile pass; this form takes 7.
+__global__ __launch_bounds__(1024) void em_basis_sums_kernel(const float* __restrict__ Phi1, int ld1, const float* __restrict__ mass1, int N1, int k1,
+                                                             const float* __restrict__ Phi2, int ld2, int N2, int k2, int cw,
+                                                             double* __restrict__ p_out, double* __restrict__ s2_out) {
+    __shared__ double part[1024];
+    const int b = blockIdx.x, t = threadIdx.x, c = t & (cw - 1), rl = t / cw, nrl = 1024 / cw;
+    for (int which = 0; which < 2; ++which) {
+        const float* P = which ? Phi2 + (long long)b * N2 * ld2 : Phi1 + (long long)b * N1 * ld1;
+        const int N = which ? N2 : N1, ld = which ? ld2 : ld1, k = which ? k2 : k1;
+        const float* a1 = which ? nullptr : mass1 + (long long)b * N1;
+        double s = 0.0;
+        if (c < k)
+            for (int j = rl; j < N; j += 8 * nrl) {          // (eight loads in flight, added in order)
+                float x[8], m8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int jj = j + u * nrl; x[u] = jj < N ? P[(long long)jj * ld + c] : 0.f; m8[u] = (jj < N && a1) ? a1[jj] : 1.f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = fma((double)m8[u], (double)x[u], s);
+            }
+        part[t] = s;
+        __syncthreads();
+        if (t < cw && t < k) {
+            double a = 0.0;
+            for (int r = 0; r < nrl; ++r) a += part[r * cw + t];
+            (which ? s2_out + (long long)b * k2 : p_out + (long long)b * k1)[t] = a;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void em_stats_linear_kernel(const double* __restrict__ E2, const float* __restrict__ Phi1, int ld1,
+                                                              const float* __restrict__ mass1, int N1, int N2, int k1, int k2,
+                                                              const double* __restrict__ C, const double* __restrict__ p_in,
+                                                              const double* __restrict__ s2_in, double* __restrict__ rs, double* __restrict__ rsq,
+                                                              double* __restrict__ cs, double* __restrict__ csq, double* __restrict__ stat) {
+    __shared__ double pv[256], qv[256];
+    __shared__ double sh[4];
+    const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
+    const double* E = E2 + (long long)b * N2 * k1;
+    const float* P = Phi1 + (long long)b * N1 * ld1;
+    const float* a1 = mass1 + (long long)b * N1;
+    if (t < k1) {
+        pv[t] = p_in[(long long)b * k1 + t];
+        const double* Cb = C + (long long)b * k2 * k1;
+        double a = 0.0;
+        for (int k = 0; k < k2; k += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = k + u < k2 ? Cb[(long long)(k + u) * k1 + t] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fma(k + u < k2 ? s2_in[(long long)b * k2 + k + u] : 0.0, x[u], a);
+        }
+        qv[t] = a;
+    }
+    __syncthreads();
+    const int i = g * 256 + t;
+    double r = 0.0, cc = 0.0;
+    if (i < N2) {
+        for (int k = 0; k < k1; k += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = k + u < k1 ? E[(long long)i * k1 + k + u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r = fma(x[u], k + u < k1 ? pv[k + u] : 0.0, r);
+        }
+        rs[(long long)b * N2 + i] = r; rsq[(long long)b * N2 + i] = 0.0;
+    }
+    if (i < N1) {
+        for (int k = 0; k < k1; k += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = k + u < k1 ? P[(long long)i * ld1 + k + u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cc = fma((double)x[u], k + u < k1 ? qv[k + u] : 0.0, cc);
+        }
+        cc *= (double)a1[i];
+        cs[(long long)b * N1 + i] = cc; csq[(long long)b * N1 + i] = 0.0;
+    }
+    const double tr = block_sum_256(r, sh);
+    const double tc = block_sum_256(cc, sh);
+    if (t == 0) { stat[((long long)b * G + g) * 2 + 0] = tr; stat[((long long)b * G + g) * 2 + 1] = tc; }
+}
+
 // mean of the row sums (which = 0, over N2 rows) / column sums (which = 1, over N1 columns) of pair b from the G shares
 __device__ __forceinline__ double em_mean(const double* __restrict__ stat, int b, int G, int which, int n) {
     double s = 0.0;
@@ -585,16 +674,18 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     if (m_terms)      // O(N k): the mapped indicator is never stored (em_stats_kernel / em_deriv_kernel)
         need += dm_align_up((size_t)B * N2 * k1 * 8) + dm_align_up((size_t)ncs * B * N2 * k1 * 8) + 2 * dm_align_up((size_t)ncs * B * N2 * 8) +
                 2 * dm_align_up((size_t)B * N1 * 8) + 2 * dm_align_up((size_t)B * ngroups * N1 * 8) + dm_align_up((size_t)B * dm_cdiv(N1 > N2 ? N1 : N2, 256) * 2 * 8) +
-                dm_align_up((size_t)B * ncs * dm_cdiv(N2, EM_T) * 8) + dm_align_up((size_t)nsplit_m * bKK);
+                dm_align_up((size_t)B * ncs * dm_cdiv(N2, EM_T) * 8) + dm_align_up((size_t)nsplit_m * bKK) + 2 * dm_align_up((size_t)B * (k1 + k2) * 8);
     if (dcomm) need += dm_align_up((size_t)B * n_ops * k2 * k1 * 8) + dm_align_up((size_t)nsplit_d * bKK);
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* PQ = (double*)dm_ws_take(ctx, (size_t)B * (k1 + k2) * k1 * 8);
     // P, Q do not depend on C: an L-BFGS driver asks to keep them across its evaluations (option "energy_keep_gram")
     const bool keep_gram = ctx->opt_energy_keep_gram != 0;
+    bool sums_valid = false;                               // (p, s2 of the indicator statistics ride along with P, Q)
     if (keep_gram) {
-        const size_t gb = (size_t)B * (k1 + k2) * k1 * 8;
-        const bool same = ctx->gram_valid && ctx->gram_key_ptr[0] == (const void*)A && ctx->gram_key_ptr[1] == (const void*)Bm &&
+        const size_t gb = (size_t)B * (k1 + k2) * k1 * 8 + (size_t)B * (k1 + k2) * 8;      // P, Q | p, s2 (em_basis_sums_kernel)
+        const bool same = ctx->gram_valid && ctx->gram_key_ptr[2] == (const void*)Phi1 && ctx->gram_key_ptr[3] == (const void*)Phi2 &&
+                          ctx->gram_key_ptr[4] == (const void*)mass1 && ctx->gram_key_dim[4] == N1 && ctx->gram_key_dim[5] == N2 && ctx->gram_key_ptr[0] == (const void*)A && ctx->gram_key_ptr[1] == (const void*)Bm &&
                           ctx->gram_key_dim[0] == B && ctx->gram_key_dim[1] == k1 && ctx->gram_key_dim[2] == k2 && ctx->gram_key_dim[3] == D;
         if (!same) {
             ctx->gram_valid = false;
@@ -605,10 +696,13 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
                 DM_CHECK_HIP(ctx, hipMalloc((void**)&ctx->gram_keep, gb));
                 ctx->gram_keep_bytes = gb;
             }
-            ctx->gram_key_ptr[0] = A; ctx->gram_key_ptr[1] = Bm;
+            ctx->gram_key_ptr[0] = A; ctx->gram_key_ptr[1] = Bm; ctx->gram_key_ptr[2] = Phi1; ctx->gram_key_ptr[3] = Phi2; ctx->gram_key_ptr[4] = mass1;
+            ctx->gram_key_dim[4] = N1; ctx->gram_key_dim[5] = N2;
             ctx->gram_key_dim[0] = B; ctx->gram_key_dim[1] = k1; ctx->gram_key_dim[2] = k2; ctx->gram_key_dim[3] = D;
         }
         PQ = ctx->gram_keep;
+        sums_valid = ctx->gram_valid && ctx->gram_sums_valid;
+        if (!ctx->gram_valid) ctx->gram_sums_valid = false;
     }
     double* CP = (double*)dm_ws_take(ctx, bKK);
     double* Gm = (double*)dm_ws_take(ctx, bKK);
@@ -673,7 +767,19 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         ep.rg = rg; ep.ncs = ncs; ep.cchunk = cchunk; ep.Bn = B;
         ep.rs = rs; ep.rsq = rsq; ep.pcs = pcs; ep.pcsq = pcsq; ep.ngroups = ngroups; ep.cs = cs; ep.csq = csq; ep.stat = stat; ep.nstat = nstat;
         ep.w = mw; ep.Y = Yv; ep.pe = pe;
-        if (stats) {
+        if (stats && !(mw.stoch > 0) && k2 <= 256) {
+            double* pv = keep_gram ? ctx->gram_keep + (size_t)B * (k1 + k2) * k1 : (double*)dm_ws_take(ctx, (size_t)B * k1 * 8);
+            double* s2 = keep_gram ? pv + (size_t)B * k1 : (double*)dm_ws_take(ctx, (size_t)B * k2 * 8);
+            if (!pv || !s2) return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
+            if (!keep_gram || !sums_valid) {
+                int cw = 16;
+                while (cw < k1 || cw < k2) cw <<= 1;           // (k1 <= 256; a wider k2 takes the tile pass below)
+                DM_LAUNCH(ctx, "energy_basis_sums", em_basis_sums_kernel, dim3(B), dim3(1024), 0, Phi1, ld1, mass1, N1, k1, Phi2, ld2, N2, k2, cw, pv, s2);
+                if (keep_gram) ctx->gram_sums_valid = true;
+            }
+            DM_LAUNCH(ctx, "energy_stats_linear", em_stats_linear_kernel, dim3(nstat, B), dim3(256), 0, (const double*)E2, Phi1, ld1, mass1, N1, N2, k1, k2,
+                      C, (const double*)pv, (const double*)s2, rs, rsq, cs, csq, stat);
+        } else if (stats) {
             const size_t lds1 = ((size_t)EM_T * EM_LDA + 2 * EM_RG + 2 * 2 * 2 * 64) * 8 + (size_t)EM_T * ep.ldp * 4;
             rc = dm_grant_lds(ctx, (const void*)em_stats_kernel, lds1);
             if (rc) return rc;

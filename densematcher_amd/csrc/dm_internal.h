@@ -51,9 +51,10 @@ struct dm_ctx {
                                    // driver: the projected descriptors are fixed during a fit).  Setting the option again drops them.
     double* gram_keep = nullptr;   // (its own allocation: the workspace arena is recycled by every call)
     size_t gram_keep_bytes = 0;
-    const void* gram_key_ptr[2] = {nullptr, nullptr};
-    int gram_key_dim[4] = {0, 0, 0, 0};
+    const void* gram_key_ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int gram_key_dim[6] = {0, 0, 0, 0, 0, 0};
     bool gram_valid = false;
+    bool gram_sums_valid = false;  // the basis sums p, s2 behind P, Q in the same block (written by the first evaluation that needs them)
     int n_cu = 0;                // multiProcessorCount of the device
 };
 

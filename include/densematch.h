@@ -78,9 +78,9 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *   "lsa_reg"       2 | 1 | 0   dm_linear_sum_assignment: column state in registers, started from a column reduction (kept per
  *                           matrix only when its optimum is provably unique, else redone) | the same in SciPy's order | LDS state
  *   "solve_reg"     1 | 0   dm_fmap_solve, k1 <= 129: register-resident solver (one wave per system) | the LDS-resident blocked one
- *   "energy_keep_gram" 0 | 1   dm_fmap_energy_grad: 1 = keep A A^T, B A^T of the next call and reuse them while the same A, B pointers and
- *                           sizes are passed; the caller promises not to change their CONTENTS meanwhile (an optimiser's evaluations
- *                           of one fit).  Setting the option (to any value) drops what is kept.
+ *   "energy_keep_gram" 0 | 1   dm_fmap_energy_grad: 1 = keep what does not depend on C (A A^T, B A^T, the mass-weighted column sums
+ *                           of the bases) from the next call and reuse it while the same A, B, Phi1, Phi2, mass1 pointers and sizes are
+ *                           passed; the caller promises not to change their CONTENTS meanwhile (an optimiser's evaluations of one fit).  Setting the option (to any value) drops what is kept.
  * Unknown names return DM_EINVAL.  The library never reads environment variables. */
 int dm_set_option(dm_ctx* ctx, const char* name, int value);
 
