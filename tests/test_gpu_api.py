@@ -688,3 +688,25 @@ def test_energy_keep_gram_option():
     for (e0, g0), (e1, g1) in zip(plain + [plain2, plain[1]], kept + [kept2, kept3]):
         assert torch.equal(e0, e1) and torch.equal(g0, g1)
     assert not torch.equal(plain2[0], plain[0][0])
+    # with the indicator statistics (w_sumto1: the bases' column sums ride along), other bases recompute
+    N1, N2 = 300, 260
+    e1 = torch.as_tensor((rng.standard_normal((B, N1, k1)) / np.sqrt(N1)).astype(np.float32)).to(dev)
+    e2 = torch.as_tensor((rng.standard_normal((B, N2, k2)) / np.sqrt(N2)).astype(np.float32)).to(dev)
+    e2b = torch.as_tensor((rng.standard_normal((B, N2, k2)) / np.sqrt(N2)).astype(np.float32)).to(dev)
+    a1 = torch.as_tensor((rng.uniform(0.5, 1.5, (B, N1)) / N1).astype(np.float32)).to(dev)
+    wm = {"w_descr": 1.0, "w_lap": 0.1, "w_sumto1": 2.0, "w_ent": 0.3}
+    calls = [(Cs[0], e2), (Cs[1], e2), (Cs[2], e2b), (Cs[0], e2)]
+    plain = [eng.energy_grad(C, A, Bm, lam1, lam2, wm, e1, p2, a1) for C, p2 in calls]
+    eng.set_option("energy_keep_gram", 1)
+    try:
+        kept = [eng.energy_grad(C, A, Bm, lam1, lam2, wm, e1, p2, a1) for C, p2 in calls]
+    finally:
+        eng.set_option("energy_keep_gram", 0)
+    for (e0, g0), (e1_, g1) in zip(plain, kept):
+        assert torch.equal(e0, e1_) and torch.equal(g0, g1)
+    for b in range(B):                                   # and the analytic sums against the oracle's dense indicator
+        ev = orc.ev_sqdiff(lam1[b], lam2[b])
+        Eo, Go = orc.energy_grad_general(Cs[0][b], A[b].cpu().numpy().astype(np.float64), Bm[b].cpu().numpy().astype(np.float64), ev,
+                                         e1[b].cpu().numpy(), e2[b].cpu().numpy(), a1[b].cpu().numpy(), wm)
+        assert abs(float(plain[0][0][b]) - Eo) <= 1e-11 * abs(Eo)
+        assert np.abs(plain[0][1][b].cpu().numpy() - Go).max() <= 1e-11 * np.abs(Go).max()
