@@ -127,13 +127,15 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
 
 // ---- quadratic terms -------------------------------------------------------------------------------------------------
 // grad = w_d (C P - Q) + w_l C * ev;  e_quad[b] = 1/2 w_d (sum C (CP - 2Q) + |B|^2) + 1/2 w_l sum C^2 ev      (one workgroup per pair)
-__global__ __launch_bounds__(256) void quad_terms_kernel(const double* __restrict__ C, const double* __restrict__ CP,
-                                                         const double* __restrict__ PQ, const float* __restrict__ Bm,
-                                                         const double* __restrict__ lam1, const double* __restrict__ lam2,
-                                                         int k1, int k2, int D, double w_d, double w_l, double* __restrict__ grad,
-                                                         double* __restrict__ e_quad) {
-    __shared__ double sh[4];
-    const int b = blockIdx.x, t = threadIdx.x;
+struct quad_args {
+    const double* C; const double* CP; const double* PQ; const float* Bm; const double* lam1; const double* lam2; int D; double w_d, w_l;
+};
+// (element e of the pair is written by thread e mod 256: a caller that goes on with the same mapping needs no barrier)
+__device__ __forceinline__ double quad_pair(const quad_args& qa, int b, int t, int k1, int k2, double* __restrict__ grad, double* sh) {
+    const double* C = qa.C; const double* CP = qa.CP; const double* PQ = qa.PQ; const float* Bm = qa.Bm;
+    const double* lam1 = qa.lam1; const double* lam2 = qa.lam2;
+    const int D = qa.D;
+    const double w_d = qa.w_d, w_l = qa.w_l;
     double mx = 0.0;
     for (int j = t; j < k1; j += 256) mx = fmax(mx, lam1[(long long)b * k1 + j]);
     for (int i = t; i < k2; i += 256) mx = fmax(mx, lam2[(long long)b * k2 + i]);
@@ -163,8 +165,12 @@ __global__ __launch_bounds__(256) void quad_terms_kernel(const double* __restric
     }
     double bn = 0.0;
     for (int e = t; e < k2 * D; e += 256) { const double x = (double)Bm[(long long)b * k2 * D + e]; bn += x * x; }
-    const double tot = block_sum_256(acc + 0.5 * w_d * bn, sh);
-    if (t == 0) e_quad[b] = tot;
+    return block_sum_256(acc + 0.5 * w_d * bn, sh);       // (its first barrier: every thread has read the maxima)
+}
+__global__ __launch_bounds__(256) void quad_terms_kernel(quad_args qa, int k1, int k2, double* __restrict__ grad, double* __restrict__ e_quad) {
+    __shared__ double sh[4];
+    const double tot = quad_pair(qa, blockIdx.x, threadIdx.x, k1, k2, grad, sh);
+    if (threadIdx.x == 0) e_quad[blockIdx.x] = tot;
 }
 
 // ---- statistics of the mapped indicator ------------------------------------------------------------------------------
@@ -246,15 +252,19 @@ __global__ __launch_bounds__(1024) void em_basis_sums_kernel(const float* __rest
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void em_stats_linear_kernel(const double* __restrict__ E2, const float* __restrict__ Phi1, int ld1,
+// Phi2 != null (maps up to 32 x 32): the block's rows of E2 = Phi2 C are produced here (C in the LDS, a row per thread) and
+// written for the derivative pass, instead of by a product launch of their own.
+__global__ __launch_bounds__(256) void em_stats_linear_kernel(double* __restrict__ E2, const float* __restrict__ Phi1, int ld1,
                                                               const float* __restrict__ mass1, int N1, int N2, int k1, int k2,
                                                               const double* __restrict__ C, const double* __restrict__ p_in,
                                                               const double* __restrict__ s2_in, double* __restrict__ rs, double* __restrict__ rsq,
-                                                              double* __restrict__ cs, double* __restrict__ csq, double* __restrict__ stat) {
+                                                              double* __restrict__ cs, double* __restrict__ csq, double* __restrict__ stat,
+                                                              const float* __restrict__ Phi2, int ld2) {
     __shared__ double pv[256], qv[256];
     __shared__ double sh[4];
+    __shared__ double Cs[32 * 32];
     const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x, t = threadIdx.x;
-    const double* E = E2 + (long long)b * N2 * k1;
+    double* E = E2 + (long long)b * N2 * k1;
     const float* P = Phi1 + (long long)b * N1 * ld1;
     const float* a1 = mass1 + (long long)b * N1;
     if (t < k1) {
@@ -270,10 +280,24 @@ __global__ __launch_bounds__(256) void em_stats_linear_kernel(const double* __re
         }
         qv[t] = a;
     }
+    if (Phi2) for (int e = t; e < k2 * k1; e += 256) Cs[e] = C[(long long)b * k2 * k1 + e];      // (uniform)
     __syncthreads();
     const int i = g * 256 + t;
     double r = 0.0, cc = 0.0;
-    if (i < N2) {
+    if (i < N2 && Phi2) {
+        const float* row = Phi2 + ((long long)b * N2 + i) * ld2;
+        float x[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) x[k] = k < k2 ? row[k] : 0.f;
+        for (int c = 0; c < k1; ++c) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a = fma((double)x[k], k < k2 ? Cs[k * k1 + c] : 0.0, a);
+            E[(long long)i * k1 + c] = a;
+            r = fma(a, pv[c], r);
+        }
+        rs[(long long)b * N2 + i] = r; rsq[(long long)b * N2 + i] = 0.0;
+    } else if (i < N2) {
         for (int k = 0; k < k1; k += 8) {
             double x[8];
 #pragma unroll
@@ -599,9 +623,13 @@ struct combine_mterms {
 };
 __global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad, combine_mterms cm, long long n_all, const double* __restrict__ g1,
                                                       const double* __restrict__ g2, double w_dc, int k1, int k2,
-                                                      const double* __restrict__ e_quad, const double* __restrict__ e_dc, double* __restrict__ energy) {
+                                                      const double* __restrict__ e_quad, const double* __restrict__ e_dc, double* __restrict__ energy,
+                                                      quad_args qa) {
     __shared__ double sh[4];
     const int b = blockIdx.x, t = threadIdx.x;
+    // small maps: the quadratic terms are evaluated here instead of by a launch of their own (qa.C != null)
+    double eq = 0.0;
+    if (qa.C) { eq = quad_pair(qa, b, t, k1, k2, grad, sh); __syncthreads(); }
     for (int e = t; e < k2 * k1; e += 256) {
         const long long o = (long long)b * k2 * k1 + e;
         double g = grad[o];
@@ -625,7 +653,7 @@ __global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad,
             }
         e_m = block_sum_256(acc, sh);
     }
-    if (t == 0) energy[b] = e_quad[b] + (cm.pe ? e_m : 0.0) + (e_dc ? w_dc * e_dc[b] : 0.0);
+    if (t == 0) energy[b] = (qa.C ? eq : e_quad[b]) + (cm.pe ? e_m : 0.0) + (e_dc ? w_dc * e_dc[b] : 0.0);
 }
 
 extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D, const float* Phi1, int ld1,
@@ -714,6 +742,7 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     if (!PQ || !CP || !Gm || !G1 || !G2 || !e_quad || !e_m || !e_dc) return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
 
     // ---- quadratic terms: P = A A^T, Q = Bm A^T (unscaled), C P
+    quad_args qz;
     {
         KRowsStackedF32 opa{A, Bm, k1, k2, D};
         KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
@@ -729,8 +758,11 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         if (!cp_inline)
             DM_LAUNCH(ctx, "energy_cp_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutNT>), dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
                       dim3(256), 0, ca, pb, ocp, k2, k1, k1);
-        DM_LAUNCH(ctx, "energy_quad", quad_terms_kernel, dim3(B), dim3(256), 0, C, cp_inline ? (const double*)nullptr : (const double*)CP, PQ, Bm,
-                  lam1, lam2, k1, k2, D, w[W_DESCR], w[W_LAP], grad, e_quad);
+        qz = quad_args{C, cp_inline ? (const double*)nullptr : (const double*)CP, PQ, Bm, lam1, lam2, D, w[W_DESCR], w[W_LAP]};
+        if (!cp_inline) {
+            DM_LAUNCH(ctx, "energy_quad", quad_terms_kernel, dim3(B), dim3(256), 0, qz, k1, k2, grad, e_quad);
+            qz.C = nullptr;                                // (done: combine_kernel reads grad / e_quad)
+        }
     }
 
     // ---- terms in the mapped indicator
@@ -753,7 +785,9 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
         double* part = (double*)dm_ws_take(ctx, (size_t)nsplit_m * bKK);
         if (!E2 || !Yv || !rs || !rsq || !cs || !csq || !pcs || !pcsq || !stat || !pe || !part)
             return dm_fail(ctx, DM_ENOMEM, "energy: workspace not reserved");
-        {   // E2 = Phi2 C   (the left factor of the mapped indicator, convert.py:144)
+        // (maps up to 32 x 32 whose statistics come from em_stats_linear_kernel: that kernel writes E2 as well)
+        const bool e2_inline = stats && !(mw.stoch > 0) && k1 <= 32 && k2 <= 32;
+        if (!e2_inline) {   // E2 = Phi2 C   (the left factor of the mapped indicator, convert.py:144)
             KRowsF32 opa{Phi2, (long long)N2 * ld2, ld2, N2, k2};
             KRowsF64 opb{C, (long long)k2 * k1, k1, k1, k2, 1};
             OutNT out{E2, (long long)N2 * k1, k1};
@@ -777,8 +811,8 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
                 DM_LAUNCH(ctx, "energy_basis_sums", em_basis_sums_kernel, dim3(B), dim3(1024), 0, Phi1, ld1, mass1, N1, k1, Phi2, ld2, N2, k2, cw, pv, s2);
                 if (keep_gram) ctx->gram_sums_valid = true;
             }
-            DM_LAUNCH(ctx, "energy_stats_linear", em_stats_linear_kernel, dim3(nstat, B), dim3(256), 0, (const double*)E2, Phi1, ld1, mass1, N1, N2, k1, k2,
-                      C, (const double*)pv, (const double*)s2, rs, rsq, cs, csq, stat);
+            DM_LAUNCH(ctx, "energy_stats_linear", em_stats_linear_kernel, dim3(nstat, B), dim3(256), 0, E2, Phi1, ld1, mass1, N1, N2, k1, k2,
+                      C, (const double*)pv, (const double*)s2, rs, rsq, cs, csq, stat, e2_inline ? Phi2 : (const float*)nullptr, ld2);
         } else if (stats) {
             const size_t lds1 = ((size_t)EM_T * EM_LDA + 2 * EM_RG + 2 * 2 * 2 * 64) * 8 + (size_t)EM_T * ep.ldp * 4;
             rc = dm_grant_lds(ctx, (const void*)em_stats_kernel, lds1);
@@ -854,7 +888,7 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     }
     DM_LAUNCH(ctx, "energy_combine", combine_kernel, dim3(B), dim3(256), 0, grad, cm, (long long)B * k2 * k1,
               dcomm ? G1 : (const double*)nullptr, dcomm ? G2 : (const double*)nullptr, w[W_DCOMM], k1, k2, e_quad,
-              dcomm ? e_dc : (const double*)nullptr, energy);
+              dcomm ? e_dc : (const double*)nullptr, energy, qz);
     return DM_OK;
 }
 
