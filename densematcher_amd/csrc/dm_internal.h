@@ -46,6 +46,8 @@ struct dm_ctx {
     int opt_solve_reg = 1;       // 0: the LDS-resident blocked solver also where the register-resident one (n <= 128) would run
     int opt_p2p_split = 2;       // four maps: 0 the float64 G kernel, 1 two passes of the two-key fp16 tile kernel, 2 one pass reducing in both directions (3: 4-wave shape)
     int opt_simnn_persist = 1;   // 0: one workgroup per similarity tile instead of one persistent workgroup per CU
+    int opt_p2pfm_direct = 1;    // 0: p2p_to_FM on the LDS-staged 64 x 64 tile kernel with split-K partials + a reduce launch
+    int opt_zoomout_fused = 1;   // 0: ZoomOut as six launches per iteration (embedding, row build, search, merge, exact, p2p_to_FM [+ reduce])
     int opt_energy_keep_gram = 0;  // 1: dm_fmap_energy_grad keeps P = A A^T, Q = B A^T of its FIRST call and reuses them while A, B
                                    // (pointers and sizes) stay the same: the caller promises not to change their contents (the L-BFGS
                                    // driver: the projected descriptors are fixed during a fit).  Setting the option again drops them.
@@ -110,7 +112,7 @@ int dm_prof_end(dm_ctx* ctx, int token);
         dm_prof_end(ctx, _tok);                                                        \
     } while (0)
 
-static inline int dm_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline __host__ __device__ int dm_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- internal building blocks (each in its own .hip) -------------------------
 // K-major float64 copy of the first k columns of Phi:  out[b][c][i] = Phi[b][i][c]
@@ -199,13 +201,22 @@ struct dm_simnn_dual {
     const dm_simnn_cols* cols = nullptr;
     bool padded = false;              // Ftgt / Fsrc hold pad256(N2) / pad256(N1) rows per pair (zero rows behind the real ones) and
                                       // bias / scale / biasT the same number of entries: any N2, N1 (edge tiles mask the padding)
+    bool single = false;              // key A alone on split rows (ZoomOut's search): scale, nn_b, q_b, cols unused
 };
+// optional: the caller owns the control block and / or the merge of a tile pass (the fused ZoomOut iteration, dm_zoomfuse.hip)
+struct dm_simnn_ext {
+    void* ctl = nullptr;              // a ZEROED block of dm_simnn_ctl_bytes(B) (per-pair maxima, queue counters): no memset per call
+    bool skip_merge = false;          // the tile pass only; what a merge needs comes back below
+    const float* pb = nullptr; const int32_t* pj = nullptr; const float* ps = nullptr; int nparts = 0, pw = 0, N2pad = 0;
+    const float* tnorm2 = nullptr; const unsigned int* smax2 = nullptr; float tau_scale = 0.f;
+};
+size_t dm_simnn_ctl_bytes(int B);
 size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual = 0);
 bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D, bool padded = false);
 int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, int ldT, const _Float16* Fsrc, int ldS,
                   float rel_extra,
                   const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q,
-                  const dm_simnn_dual* dual = nullptr);
+                  const dm_simnn_dual* dual = nullptr, dm_simnn_ext* ext = nullptr);
 
 // knn21 alone (ZoomOut, ICP, knn_query): fp16-split first pass on the fp16 matrix cores + exact float64 re-evaluation of
 // the ambiguous rows (dm_knnsplit.hip).  The target side (rows of AT) is prepared once for the largest contraction depth
@@ -228,7 +239,10 @@ template <typename TR>
 int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, const double* amaxT, int nT, void* zeroed,
                        const TR* Phi2, int ld2);
 
-// C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_p2pfm.hip)
+template <typename TR>
+int dm_fm_split_build_rows(dm_ctx* ctx, int B, int N, int K, const TR* Phi, int ld, const double* amaxT, int nT, int D, _Float16* F, int rows_out);
+
+// C[b] = Phi2[:, :k2]^T (mass2 * Phi1[p21, :k1]) (dm_zoomout.hip)
 template <typename TR>
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,
                         const TR* Phi1, int ld1, const TR* Phi2, int ld2, const double* mass2,

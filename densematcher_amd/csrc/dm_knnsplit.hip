@@ -19,6 +19,8 @@
 //     every row takes the exact path: slower, never wrong.
 #include "dm_device.h"
 #include "dm_internal.h"
+#include "dm_split.h"
+#include "dm_exact.h"
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -39,21 +41,6 @@ __global__ __launch_bounds__(256) void ks_absmax_kernel(const double* __restrict
     if ((t & 63) == 0) sh[t >> 6] = m;
     __syncthreads();
     if (t == 0) amax[b * KS_NCH + chunk] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
-}
-
-// power of two s with (max of the `count` partial maxima) * s in [1, 2)  (1 when the operand is all zero)
-__device__ __forceinline__ double ks_scale(const double* __restrict__ amax, int count) {
-    double m = 0.0;
-    for (int q = 0; q < count; ++q) m = fmax(m, amax[q]);
-    int ex = 0;
-    if (!(m > 0.0) || !(m < DM_INF_F64)) return 1.0;
-    (void)frexp(m, &ex);                                          // m = f 2^ex, f in [0.5, 1)
-    return ldexp(1.0, 1 - ex);
-}
-
-__device__ __forceinline__ void split2(double v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (double)hi);
 }
 
 // Per-row terms of a key-set pass: bias[j] = fp32(-nrm_j sx sy / 2) and its per-pair maximum (atomicMax on float bits, zeroed by
@@ -201,126 +188,13 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
     }
 }
 
-// exact re-evaluation: one workgroup per queued row.  Thread (part = t >> 5, c = t & 31) accumulates the contraction
-// rows r = part, part + 8, ... of candidate j = 32 block + c (each wave instruction reads two 256-byte runs of BT);
-// the eight partial sums are added in a fixed order, so duplicated columns score identically and the lowest index wins
-// -- and g(i, j) is the same number whichever operand plays the target (the four maps of dm_fm_to_p2p agree on it).
-// KIND (the value the reference compares, targets = columns of AT, candidates = columns of BT):
-//   0  arg-min_j  w[j] - 2 g        w = |candidate|^2                 knn21 (and knn12 with the operands swapped)
-//   1  arg-max_j  g massS[j]        indicator row,    convert.py:144  ind21
-//   2  arg-max_j  g massT[i]        indicator column (the target's own mass)  ind12, operands swapped
-struct ks_exact_args {
-    const double* AT; const double* BT; const double* n1; const double* massS; const double* massT;
-    int K, N2, N2pad, N1, N1pad, Kpad;
-    dm_simnn_queue q;                                  // flagged rows + the partials that prune their candidates
-    int32_t* nn;
-    // one operand may be read where the caller keeps it, row-major (B, N, ldrow) of the kernel's TR, instead of from a K-major
-    // float64 copy: Trow replaces AT (targets), Crow replaces BT (candidates).  Same values, same summation schedule.
-    const void* Trow = nullptr; const void* Crow = nullptr; int ldrow = 0;
-};
+// exact re-evaluation: one workgroup per queued row (dm_exact.h: ks_exact_row), grid-stride over the queue
 template <int KIND, typename TR>
 __device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, int nwg) {
-    const double* __restrict__ AT = a.AT; const double* __restrict__ BT = a.BT; const double* __restrict__ n1 = a.n1;
-    const double* __restrict__ massS = a.massS; const double* __restrict__ massT = a.massT;
-    const int K = a.K, N2 = a.N2, N2pad = a.N2pad, N1 = a.N1, N1pad = a.N1pad, Kpad = a.Kpad;
-    const float* __restrict__ qpb = a.q.pb; const int32_t* __restrict__ qpj = a.q.pj; const float* __restrict__ qps = a.q.ps;
-    const int nparts = a.q.nparts, pw = a.q.pw, Npad_s = a.q.Npad, nsub = nparts * (pw / 32);
-    const int32_t* __restrict__ flag_count = a.q.flag_count; const int32_t* __restrict__ flag_list = a.q.flag_list;
-    const float* __restrict__ flag_thr = a.q.flag_thr; int32_t* __restrict__ nn = a.nn;
     extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums + 32 scores
     __shared__ unsigned long long cmask[4];
-    double* part_s = xrow + K;
-    const int count = *flag_count;
-    const TR* __restrict__ Trow = reinterpret_cast<const TR*>(a.Trow);
-    const TR* __restrict__ Crow = reinterpret_cast<const TR*>(a.Crow);
-    const int ldrow = a.ldrow;
-    // thread = (candidate c of a block of 32, part of the contraction).  Row-major candidates: the eight parts of a candidate
-    // sit in neighbouring lanes, so one load instruction reads eight 64-byte runs instead of 64 scattered elements.
-    const int t = threadIdx.x;
-    const int c = Crow ? (t >> 3) : (t & 31), part = Crow ? (t & 7) : (t >> 5);
-    for (int e = wg; e < count; e += nwg) {
-        const int o = flag_list[e];
-        const float thr = flag_thr[e];
-        const int b = o / N2, i = o - b * N2;
-        const double* A = AT ? AT + (long long)b * Kpad * N2pad + i : nullptr;
-        const double* Bm = BT ? BT + (long long)b * Kpad * N1pad : nullptr;
-        __syncthreads();
-        if (Trow) { for (int r = t; r < K; r += 256) xrow[r] = (double)Trow[((long long)b * N2 + i) * ldrow + r]; }
-        else { for (int r = t; r < K; r += 256) xrow[r] = A[(long long)r * N2pad]; }
-        __syncthreads();
-        double bv = KIND == 0 ? DM_INF_F64 : -DM_INF_F64;
-        int bj = DM_IDX_NONE;
-        const double mt = KIND == 2 ? massT[(long long)b * N2 + i] : 0.0;
-        // candidate blocks: one gather of the row's partials (256 blocks at a time), then only the blocks that can still
-        // hold the optimum are visited, in ascending order (dm_simnn_keep)
-        for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
-            const int sbt = sb0 + t;
-            const bool keep = sbt < nsub && dm_simnn_keep(qpb, qpj, qps, nparts, pw, Npad_s, b, i, sbt, thr);
-            const unsigned long long km = __ballot(keep);
-            if ((t & 63) == 0) cmask[t >> 6] = km;
-            __syncthreads();
-            for (int w = 0; w < 4; ++w) {
-                unsigned long long mm = cmask[w];                 // uniform
-                while (mm) {
-                    const int sb = sb0 + w * 64 + __ffsll((long long)mm) - 1;
-                    mm &= mm - 1;
-                    const int j = sb * 32 + c;
-                    double sacc = 0.0;
-                    if (j < N1 && Crow) {
-                        const TR* Cr = Crow + ((long long)b * N1 + j) * ldrow;
-                        int r = part;
-                        for (; r + 56 < K; r += 64) {
-                            TR y[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) y[u] = Cr[r + 8 * u];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) sacc = fma(xrow[r + 8 * u], (double)y[u], sacc);
-                        }
-                        for (; r < K; r += 8) sacc = fma(xrow[r], (double)Cr[r], sacc);
-                    } else if (j < N1) {
-                        // loads in batches of eight ahead of their (ordered) fma chain: a plain loop would take one L2 round
-                        // trip per term
-                        int r = part;
-                        for (; r + 56 < K; r += 64) {
-                            double y[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) y[u] = Bm[(long long)(r + 8 * u) * N1pad + j];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) sacc = fma(xrow[r + 8 * u], y[u], sacc);
-                        }
-                        for (; r < K; r += 8) sacc = fma(xrow[r], Bm[(long long)r * N1pad + j], sacc);
-                    }
-                    part_s[part * 32 + c] = sacc;
-                    __syncthreads();
-                    if (t < 32 && sb * 32 + t < N1) {
-                        const int j = sb * 32 + t;                      // (thread t < 32 finishes candidate t of the block)
-                        double g = part_s[t];
-#pragma unroll
-                        for (int q = 1; q < 8; ++q) g += part_s[q * 32 + t];
-                        // blocks ascend: strict comparisons keep the lowest index
-                        if (KIND == 0) {
-                            const double v = n1[(long long)b * N1pad + j] - 2.0 * g;          // |y|^2 - 2 <x, y>
-                            if (v < bv) { bv = v; bj = j; }
-                        } else {
-                            const double v = g * (KIND == 1 ? massS[(long long)b * N1 + j] : mt);
-                            if (v > bv) { bv = v; bj = j; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-            __syncthreads();                                      // (cmask is rewritten by the next chunk of blocks)
-        }
-        if (t < 32) {
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
-                const double ov = __shfl_xor(bv, off);
-                const int oj = __shfl_xor(bj, off);
-                if (KIND == 0) argmin_merge(bv, bj, ov, oj); else argmax_merge(bv, bj, ov, oj);
-            }
-            if (t == 0 && bj != DM_IDX_NONE) nn[o] = bj;
-        }
-    }
+    const int count = *a.q.flag_count;
+    for (int e = wg; e < count; e += nwg) ks_exact_row<KIND, TR, TR>(a, a.q.flag_list[e], a.q.flag_thr[e], xrow, cmask);
 }
 
 // one launch for up to four reductions of a pass: blockIdx.y selects the queue (and the value kind)
@@ -453,6 +327,18 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
     *reinterpret_cast<f16x8*>(dst) = hv;
     *reinterpret_cast<f16x8*>(dst + 16) = lv;
 }
+
+// split rows of a row-major basis for the key-set tile kernels: D halves per row (>= 32 ceil(K / 16), zero beyond K), rows_out rows
+// per pair in F (the caller zeroes rows >= N)
+template <typename TR>
+int dm_fm_split_build_rows(dm_ctx* ctx, int B, int N, int K, const TR* Phi, int ld, const double* amaxT, int nT, int D, _Float16* F, int rows_out) {
+    const long long n = (long long)N * (D / 16);
+    DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel<TR>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi, N, K, ld,
+              amaxT, nT, D, F, rows_out);
+    return DM_OK;
+}
+template int dm_fm_split_build_rows<float>(dm_ctx*, int, int, int, const float*, int, const double*, int, int, _Float16*, int);
+template int dm_fm_split_build_rows<double>(dm_ctx*, int, int, int, const double*, int, const double*, int, int, _Float16*, int);
 
 static inline int fs_depth(int K) { return 32 * ((K + 15) / 16); }    // halves per split row
 size_t dm_fm_split_zero_bytes(int B) { return 3 * dm_align_up((size_t)B * 4); }

@@ -17,16 +17,11 @@
 
 #include "dm_device.h"
 #include "dm_internal.h"
+#include "dm_split.h"
 
 constexpr int ST = 256;    // tile: 256 target rows x 256 source rows per workgroup
 constexpr int SBK = 64;    // contraction (halves) per LDS stage of the register-staged kernel
-#define DM_NEG_INF_F32 (-__builtin_huge_valf())
 #define DM_KEY_NONE (-3.0e38f)   // finite "no candidate" score: its bit pattern stays finite with position bits OR-ed in
-
-__device__ __forceinline__ void top2_merge(float& b, int& i, float& s, float ob, int oi, float os) {
-    if (ob > b || (ob == b && oi < i)) { s = fmaxf(b, os); b = ob; i = oi; }
-    else { s = fmaxf(s, ob); }
-}
 
 // LDS image of a 128 x 64 fp16 tile: row r is one 128-byte line of eight 16-byte chunks; chunk c is
 // stored at slot c ^ ((r >> 1) & 7).  Two consecutive rows fill one 256-byte bank row, so the 16
@@ -151,7 +146,7 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
         if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
     }
 
-    constexpr int NKIND = DUAL ? 2 : 1;
+    constexpr int NKIND = (DUAL && DUAL != 4) ? 2 : 1;       // DUAL 4: key A alone (score + bias[j])
 #pragma unroll
     for (int kind = 0; kind < NKIND; ++kind) {
 #pragma unroll
@@ -621,7 +616,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     constexpr bool NOEPI = (dbg & 7) == 1 || (dbg & 7) == 7;
     // stores EVERY wave issues in an epilogue: its row partials (2 target blocks x 3 arrays per key set) and, both directions,
     // its column partials (4 source blocks x 2 key sets x 3 arrays)
-    constexpr int EPI_ST = (DUAL ? 2 : 1) * 3 * TB + (DUAL == 3 ? 24 : 0);
+    constexpr int EPI_ST = ((DUAL && DUAL != 4) ? 2 : 1) * 3 * TB + (DUAL == 3 ? 24 : 0);
     int r_slot = 0;                               // ring slot of the stage being computed
     const bool late = FLIP && wave >= NW / 2;
 #define SIMNN_READ(fs_, ft_, slot_, fo_)                                                                               \
@@ -934,6 +929,7 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
+size_t dm_simnn_ctl_bytes(int B) { return 2 * dm_align_up((size_t)B * 4) + 1024; }
 size_t dm_simnn_ws_bytes(int B, int N2, int N1, int dual) {
     const size_t N2pad = pad_to(N2, ST), tilesS = dm_cdiv(N1, ST);
     const size_t np = (size_t)B * 2 * tilesS * N2pad;          // row partials: two source halves per tile
@@ -959,7 +955,7 @@ bool dm_simnn_dual_ok(const dm_ctx* ctx, int N2, int N1, int D, bool padded) {
 int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftgt, int ldT, const _Float16* Fsrc, int ldS,
                   float rel_extra,
                   const int32_t* force_flag, int32_t* nn21, float* best, float* margin, dm_simnn_queue* q,
-                  const dm_simnn_dual* dual) {
+                  const dm_simnn_dual* dual, dm_simnn_ext* ext) {
     simnn_params p;
     memset(&p, 0, sizeof(p));
     p.Ftgt = Ftgt; p.Fsrc = Fsrc;
@@ -981,8 +977,8 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     int32_t* flag_list = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     float* flag_thr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     // per-pair norm maxima and the queue counters: one block, one memset
-    const size_t ctl_bytes = 2 * dm_align_up((size_t)B * 4) + 1024;
-    char* ctl = (char*)dm_ws_take(ctx, ctl_bytes);
+    const size_t ctl_bytes = dm_simnn_ctl_bytes(B);
+    char* ctl = (ext && ext->ctl) ? (char*)ext->ctl : (char*)dm_ws_take(ctx, ctl_bytes);
     if (!p.pb || !p.pj || !p.ps || !p.tnorm2 || !flag_list || !flag_thr || !ctl)
         return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
     p.smax2 = (unsigned int*)ctl;
@@ -992,7 +988,12 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     const dm_simnn_cols* cols = dual ? dual->cols : nullptr;
     int32_t* cflag_list[2] = {nullptr, nullptr}; float* cflag_thr[2] = {nullptr, nullptr};
     int32_t* cflag_count[2] = {flag_count + 128, flag_count + 192};
-    if (dual) {
+    const bool single = dual && dual->single;         // key A alone on split rows
+    if (single) {
+        if (!dm_simnn_dual_ok(ctx, N2, N1, D, padded) || !dual->bias || dual->cols || dual->scale)
+            return dm_fail(ctx, DM_EINVAL, "simnn: the biased-key pass needs interior tiles, D %% 32 == 0, D >= 160");
+        p.bias = dual->bias;
+    } else if (dual) {
         if (!dm_simnn_dual_ok(ctx, N2, N1, D, padded) || !dual->bias || !dual->nn_b || !dual->q_b)
             return dm_fail(ctx, DM_EINVAL, "simnn: the two-key pass needs interior tiles, D %% 32 == 0, D >= 160");
         p.bias = dual->bias; p.scale = dual->scale;
@@ -1024,7 +1025,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         if (!p.snorm2) return dm_fail(ctx, DM_ENOMEM, "simnn: workspace not reserved");
     }
 
-    DM_CHECK_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, ctx->stream));
+    if (!(ext && ext->ctl)) DM_CHECK_HIP(ctx, hipMemsetAsync(ctl, 0, ctl_bytes, ctx->stream));
     const size_t lds_edge = (size_t)4 * ST * SBK * sizeof(_Float16);
     const bool interior = padded || (N2 % ST == 0 && N1 % ST == 0);
     // DM_EXPERIMENTS: DM_SIMNN_DEBUG = variant bits XV (simnn_pipe_kernel) + 256 / 512 for the 8-wave / 4-wave shape
@@ -1081,6 +1082,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             grid = want < p.total ? want : p.total;
             if (edge) {
                 if (cols) { if (WT == 4) SIMNN_LAUNCH_EDGE(4, 3, "simnn4_f16_mfma") else SIMNN_LAUNCH_EDGE(2, 3, "simnn4_f16_mfma") }
+                else if (single) SIMNN_LAUNCH_EDGE(4, 4, "simnn1_f16_mfma")
                 else if (dual->scale) SIMNN_LAUNCH_EDGE(4, 1, "simnn2_f16_mfma")
                 else SIMNN_LAUNCH_EDGE(4, 2, "simnn2_f16_mfma")
                 continue;
@@ -1093,6 +1095,8 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         } else if (cols) {
             if (WT == 4) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 3, "simnn4_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 2, 3, "simnn4_f16_mfma")
+        } else if (single) {
+            SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 4, "simnn1_f16_mfma")
         } else if (dual) {
             if (dual->scale) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 1, "simnn2_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 2, "simnn2_f16_mfma")
@@ -1133,12 +1137,17 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     const float nprod = dual ? 1.5f * (float)D : (float)D;
     const float tau_scale = 2.0f * 1.01f * (nprod * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 2.0f * 1.9073486e-6f + rel_extra +
                                             (dual ? 1.1920929e-7f : 0.0f));
+    if (ext) {
+        ext->pb = p.pb; ext->pj = p.pj; ext->ps = p.ps; ext->nparts = nparts; ext->pw = 128; ext->N2pad = p.N2pad;
+        ext->tnorm2 = p.tnorm2; ext->smax2 = p.smax2; ext->tau_scale = tau_scale;
+        if (ext->skip_merge) return DM_OK;
+    }
     simnn_merge_sets sets;
     memset(&sets, 0, sizeof(sets));
     int nsets = 0, maxN = N2;
     sets.s[nsets++] = simnn_merge_set{p.pb, p.pj, p.ps, nparts, N2, p.N2pad, p.tnorm2, p.smax2, dual ? dual->tau_add : nullptr, nullptr,
                                       nullptr, nn21, flag_count, flag_list, flag_thr, best, margin};
-    if (dual)
+    if (dual && !single)
         sets.s[nsets++] = simnn_merge_set{p.pb_2, p.pj_2, p.ps_2, nparts, N2, p.N2pad, p.tnorm2, p.smax2, nullptr, dual->tau_mul,
                                           nullptr, dual->nn_b, flag_count2, flag_list2, flag_thr2, nullptr, nullptr};
     if (cols) {
@@ -1152,7 +1161,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     }
     DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(maxN, 256), B, nsets), dim3(256), 0, sets, tau_scale, force_flag);
     *q = dm_simnn_queue{p.pb, p.pj, p.ps, nparts, 128, p.N2pad, flag_count, flag_list, flag_thr};
-    if (dual) *dual->q_b = dm_simnn_queue{p.pb_2, p.pj_2, p.ps_2, nparts, 128, p.N2pad, flag_count2, flag_list2, flag_thr2};
+    if (dual && !single) *dual->q_b = dm_simnn_queue{p.pb_2, p.pj_2, p.ps_2, nparts, 128, p.N2pad, flag_count2, flag_list2, flag_thr2};
     if (cols) {
         *cols->q_a = dm_simnn_queue{p.cb[0], p.cj[0], p.cs[0], p.N2pad / (32 * TB), 32 * TB, p.N1pad, cflag_count[0], cflag_list[0], cflag_thr[0]};
         *cols->q_b = dm_simnn_queue{p.cb[1], p.cj[1], p.cs[1], p.N2pad / (32 * TB), 32 * TB, p.N1pad, cflag_count[1], cflag_list[1], cflag_thr[1]};

@@ -9,6 +9,7 @@
 // host synchronisation.
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
+#include "dm_zoomfuse.h"
 
 struct OutFM {
     double* direct; int ldc; long long strideC;     // nsplit == 1
@@ -41,15 +42,202 @@ static int fm_split(int B, int N2, int k1, int k2) {
     return dm_cdiv(N2, FM_KCHUNK);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// p2p_to_FM with register-resident output tiles and operands read straight from global memory (the default; the LDS-staged
+// 64 x 64 tile kernel above with its split-K partials and reduce launch stays as p2pfm_direct = 0).
+//
+// The result is small (k2 x k1 <= 208 x 208) and the contraction long (N2 vertices), both operands are K-major as they
+// lie in memory: row n of Phi2 is one contiguous run of the A operand of v_mfma_f64_16x16x4_f64 (lane l: A[m = l & 15][k = l >> 4]
+// = Phi2[n0 + (l >> 4)][16 mb + (l & 15)]: four 128-byte runs per wave load), row p21[n] of Phi1 of the B operand.  So there is
+// no LDS stage, no barrier and no operand conversion pass in the main loop: a wave owns RBW x (<= 7) blocks of 16 x 16
+// (<= 112 accumulator registers), streams its own slice of the vertices with the loads of the next k-step in flight under
+// the matrix instructions of the current one, and the S waves of a workgroup -- S slices of the same tile -- add their
+// tiles up through LDS in a FIXED order at the end (no split-K partials in HBM, no reduce launch, no atomics: the sum of
+// a pair is the same in every batch and every run).  All workgroups of a pair run on one XCD (block b -> XCD b % 8) and
+// walk the vertices in step, so every row of Phi1 / Phi2 is fetched into that XCD's L2 once per slice position.
+//   tiles: RBW = 1 row block x up to 7 column blocks and S = 8 slices while the map has at most 7 x 7 blocks (k <= 112: more,
+//   lighter waves), else RBW = 2 x up to 5 column blocks, S = 4.
+template <typename TR>
+struct p2pfm_args {
+    const TR* Phi1; long long s1; int ld1; int N1;
+    const TR* Phi2; long long s2; int ld2; int N2;
+    const int32_t* p21; const double* mass2;
+    int k1, k2;                       // columns (Phi1) / rows (Phi2) of the map
+    double* C; int ldc; long long strideC;
+    int B, TM, TC, rps;               // tiles = TM x TC per pair, vertices per slice (multiple of 4)
+};
+
+// RBW x CBW blocks per wave, exactly (no guard between the matrix instructions).  Where the blocks do not divide evenly the LAST
+// group of row / column blocks starts early and overlaps its neighbour: the shared blocks are computed twice, by the same
+// arithmetic in the same order, and stored twice with identical bits (a 16 x 16 block per 13 costs less than a branch per MFMA).
+template <typename TR, int RBW, int CBW, int S>
+__global__ __launch_bounds__(64 * S, 2) void p2pfm_direct_kernel(p2pfm_args<TR> a) {
+    __shared__ double red[2][S][64 * 4];                      // one 16 x 16 block of every wave, double-buffered
+    const int T = a.TM * a.TC;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = xcd + 8 * (slot / T);
+    if (b >= a.B) return;
+    const int tile = slot % T;
+    const int tm = tile / a.TC, tc = tile - tm * a.TC;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrb = dm_cdiv(a.k2, 16), ncb = dm_cdiv(a.k1, 16);
+    const int mb0 = max(0, min(tm * RBW, nrb - RBW)), cb0 = max(0, min(tc * CBW, ncb - CBW));
+
+    const TR* __restrict__ X = a.Phi2 + (long long)b * a.s2;
+    const TR* __restrict__ Y = a.Phi1 + (long long)b * a.s1;
+    const int32_t* __restrict__ idx = a.p21 + (long long)b * a.N2;
+    const double* __restrict__ msc = a.mass2 + (long long)b * a.N2;
+    // element offsets of this lane's column inside a row, clamped into the row (columns beyond the map only feed result
+    // entries that are not stored; they must not read past the array)
+    int colA[RBW], colB[CBW];
+#pragma unroll
+    for (int r = 0; r < RBW; ++r) colA[r] = min((mb0 + r) * 16 + l15, a.ld2 - 1);
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) colB[c] = min((cb0 + c) * 16 + l15, a.ld1 - 1);
+
+    f64x4 acc[RBW][CBW];
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[r][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    const int nb = wave * a.rps, ne = min(a.N2, nb + a.rps);
+    const int nks = ne > nb ? (ne - nb + 3) >> 2 : 0;
+    // k-step t covers vertices nb + 4 t + g.  Per step and lane: the gather index and the mass of its vertex (fetched two
+    // steps ahead), one entry of each A block and of each B block (one step ahead).  A vertex beyond the slice gets mass 0
+    // and the addresses of the last valid vertex.
+    TR fa0[RBW], fb0[CBW], fa1[RBW], fb1[CBW], fa2[RBW], fb2[CBW];
+    int pr0 = 0, pr1 = 0, pr2 = 0;                // gather indices as loaded (steps = 0 / 1 / 2 mod 3), clamped where they are used
+    double ma0 = 0.0, ma1 = 0.0, ma2 = 0.0;       // masses of the steps whose operands are in set 0 / 1 / 2
+#define PF_IDX(t_, p_) { p_ = idx[min(nb + 4 * (t_) + g, a.N2 - 1)]; }
+#define PF_LOAD(t_, p_, fa_, fb_, ma_)                                             \
+    {                                                                              \
+        const int n_ = min(nb + 4 * (t_) + g, a.N2 - 1);                           \
+        const TR* xr_ = X + (long long)n_ * a.ld2;                                 \
+        const TR* yr_ = Y + (long long)min(max(p_, 0), a.N1 - 1) * a.ld1;          \
+        _Pragma("unroll") for (int r = 0; r < RBW; ++r) fa_[r] = xr_[colA[r]];     \
+        _Pragma("unroll") for (int c = 0; c < CBW; ++c) fb_[c] = yr_[colB[c]];     \
+        ma_ = msc[n_];                                                             \
+    }
+#define PF_MASS(t_, m_) ((nb + 4 * (t_) + g < ne) ? (m_) : 0.0)
+#define PF_MMA(fa_, fb_, m_)                                                       \
+    {                                                                              \
+        _Pragma("unroll") for (int c = 0; c < CBW; ++c) {                          \
+            const double y_ = (m_) * (double)fb_[c];                               \
+            _Pragma("unroll") for (int r = 0; r < RBW; ++r)                        \
+                acc[r][c] = mfma_f64_16x16x4((double)fa_[r], y_, acc[r][c]);       \
+        }                                                                          \
+    }
+    // The loop body has no branch: steps beyond the slice load the (clamped) last vertex with mass 0 and add exact zeros, so the
+    // compiler can count the loads in flight (with a conditional fetch it waited vmcnt(0) -- for the operands it had only
+    // just requested -- in front of every group of matrix instructions).  Per half iteration: fetch the operands of the NEXT
+    // step (their gather index was requested two steps ago), request the index three steps ahead, then the matrix instructions
+    // of the current step.  A compiler-level memory barrier (an empty asm that clobbers memory) + a scheduling barrier follow
+    // every fetch: without the first the loads of read-only memory were sunk across the loop's back edge to their use (every
+    // group of matrix instructions then waited for operands requested just before it), without the second the matrix
+    // instructions were hoisted in front of the fetch.
+#define PF_FENCE() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    // THREE operand sets: the fetch of step t + 2 is issued before the matrix instructions of step t (one set ahead left
+    // 640 cycles between a request and its use: less than an L2 round trip under load).
+    if (nks > 0) {
+        PF_IDX(0, pr0)
+        PF_IDX(1, pr1)
+        PF_IDX(2, pr2)
+        PF_LOAD(0, pr0, fa0, fb0, ma0)
+        PF_IDX(3, pr0)
+        PF_LOAD(1, pr1, fa1, fb1, ma1)
+        PF_IDX(4, pr1)
+        const int nks3 = (nks + 2) / 3 * 3;
+        for (int t = 0; t < nks3; t += 3) {
+            PF_LOAD(t + 2, pr2, fa2, fb2, ma2)
+            PF_IDX(t + 5, pr2)
+            PF_FENCE()
+            PF_MMA(fa0, fb0, PF_MASS(t, ma0))
+            PF_LOAD(t + 3, pr0, fa0, fb0, ma0)
+            PF_IDX(t + 6, pr0)
+            PF_FENCE()
+            PF_MMA(fa1, fb1, PF_MASS(t + 1, ma1))
+            PF_LOAD(t + 4, pr1, fa1, fb1, ma1)
+            PF_IDX(t + 7, pr1)
+            PF_FENCE()
+            PF_MMA(fa2, fb2, PF_MASS(t + 2, ma2))
+        }
+    }
+#undef PF_MASS
+#undef PF_FENCE
+#undef PF_MMA
+#undef PF_LOAD
+#undef PF_IDX
+    // the S slices of every block, added in ascending slice order by wave (block number % S)
+    double* Cb = a.C + (long long)b * a.strideC;
+#pragma unroll
+    for (int r = 0; r < RBW; ++r)
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+            constexpr int dummy = 0; (void)dummy;
+            const int blk = r * CBW + c;
+            double* buf = &red[blk & 1][0][0];
+            *reinterpret_cast<f64x4*>(buf + (wave * 64 + lane) * 4) = acc[r][c];
+            __syncthreads();
+            if (wave == blk % S) {
+                f64x4 s = *reinterpret_cast<const f64x4*>(buf + lane * 4);
+#pragma unroll
+                for (int w = 1; w < S; ++w) {
+                    const f64x4 o = *reinterpret_cast<const f64x4*>(buf + (w * 64 + lane) * 4);
+                    s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+                }
+                const int cc = (cb0 + c) * 16 + l15;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = (mb0 + r) * 16 + g + 4 * q;
+                    if (m < a.k2 && cc < a.k1) Cb[(long long)m * a.ldc + cc] = s[q];
+                }
+            }
+        }
+}
+
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2) {
     const int nsplit = fm_split(B, N2, k1, k2);
     return nsplit > 1 ? dm_align_up((size_t)nsplit * B * k2 * k1 * 8) + 4096 : 4096;
+}
+
+template <typename TR, int RBW, int CBW, int S>
+static int p2pfm_launch(dm_ctx* ctx, const p2pfm_args<TR>& a, int grid) {
+    DM_LAUNCH(ctx, "p2pfm_tn_f64", (p2pfm_direct_kernel<TR, RBW, CBW, S>), dim3(grid), dim3(64 * S), 0, a);
+    return DM_OK;
+}
+template <typename TR>
+static int launch_p2pfm_direct(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
+                               int ld1, const TR* Phi2, int ld2, const double* mass2, double* C, int ldc, long long strideC) {
+    const int nrb = dm_cdiv(k2, 16), ncb = dm_cdiv(k1, 16);
+    const bool small = nrb <= 7 && ncb <= 7;
+    const int RBW = small ? 1 : 2, S = small ? 8 : 4;
+    p2pfm_args<TR> a;
+    a.Phi1 = Phi1; a.s1 = (long long)N1 * ld1; a.ld1 = ld1; a.N1 = N1;
+    a.Phi2 = Phi2; a.s2 = (long long)N2 * ld2; a.ld2 = ld2; a.N2 = N2;
+    a.p21 = p21; a.mass2 = mass2; a.k1 = k1; a.k2 = k2; a.C = C; a.ldc = ldc; a.strideC = strideC; a.B = B;
+    a.TM = dm_cdiv(nrb, RBW);
+    a.TC = dm_cdiv(ncb, small ? 7 : 5);        // (2 x 6 and 2 x 7 blocks per wave do not fit 256 registers with the next step's operands in flight)
+    const int CBW = dm_cdiv(ncb, a.TC);
+    a.rps = dm_cdiv(dm_cdiv(N2, S), 4) * 4;
+    const int grid = a.TM * a.TC * dm_cdiv(B, 8) * 8;
+#define P2PFM_CASE(C_) case C_: return small ? p2pfm_launch<TR, 1, C_, 8>(ctx, a, grid) : p2pfm_launch<TR, 2, C_, 4>(ctx, a, grid);
+    switch (CBW) {
+        P2PFM_CASE(1) P2PFM_CASE(2) P2PFM_CASE(3) P2PFM_CASE(4) P2PFM_CASE(5)
+        case 6: return p2pfm_launch<TR, 1, 6, 8>(ctx, a, grid);
+        case 7: return p2pfm_launch<TR, 1, 7, 8>(ctx, a, grid);
+        default: return dm_fail(ctx, DM_EINVAL, "p2p_to_fm: bad tile width %d", CBW);
+    }
+#undef P2PFM_CASE
 }
 
 template <typename TR>
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
                         int ld1, const TR* Phi2, int ld2, const double* mass2, double* C, int ldc,
                         long long strideC) {
+    if (ctx->opt_p2pfm_direct)
+        return launch_p2pfm_direct<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, mass2, C, ldc, strideC);
     const int nsplit = fm_split(B, N2, k1, k2);
     const int kchunk = FM_KCHUNK;
     double* partial = nullptr;
@@ -101,6 +289,122 @@ extern "C" int dm_p2p_to_fm_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int 
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
+// ---- the fused iteration (dm_zoomfuse.hip): 4 launches per iteration, no memset, no K-major copies -------------------------
+// Eligible: both meshes have at least one 256-row tile and the final map fits the embedding kernel's accumulators (k <= 208);
+// anything else runs the six-launch loop below (also dm_set_option "zoomout_fused" = 0: the tests compare the two).
+static bool zoomout_fused_ok(const dm_ctx* ctx, int N1, int N2, int kf) {
+    return ctx->opt_zoomout_fused && ctx->opt_knn_split && ctx->opt_simnn_pipe && N1 >= 256 && N2 >= 256 && kf <= 208;
+}
+static inline int zo_depth(int k) { const int d = 32 * ((k + 15) / 16); return d < 160 ? 160 : d; }   // halves per split row (tile kernel: >= 5 stages)
+constexpr int ZO_NCH = 32;
+
+template <typename TR>
+static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step, const TR* Phi1, int ld1,
+                         const TR* Phi2, int ld2, const TR* mass2_in, const double* C0, double* Cout, int32_t* p21_out) {
+    const int kf = k0 + nit * step;
+    const int Kpad = pad_to(kf, 16), R1 = pad_to(N1, 256), R2 = pad_to(N2, 256), N1pad = pad_to(N1, 128);
+    const int ldT = zo_depth(kf), ldS = ldT;
+    const size_t bytes_C = (size_t)B * Kpad * Kpad * 8;
+    const size_t bytes_Fx = (size_t)B * R2 * ldT * 2, bytes_Fy = (size_t)B * R1 * ldS * 2;
+    const size_t ctl1 = dm_simnn_ctl_bytes(B), amax1 = dm_align_up((size_t)B * 8), bmax1 = dm_align_up((size_t)B * 4);
+    const size_t bytes_zero = (size_t)(nit + 3) * amax1 + (size_t)(nit + 2) * (bmax1 + dm_align_up(ctl1));
+    const size_t need = dm_align_up((size_t)B * N2 * 8) + dm_align_up(bytes_Fx) + dm_align_up(bytes_Fy) + 2 * dm_align_up(bytes_C) +
+                        dm_align_up((size_t)B * R1 * 4) + dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N1 * Kpad * 8) +
+                        dm_align_up((size_t)B * N2 * 4) + dm_align_up((size_t)B * ZO_NCH * 8) + dm_align_up(bytes_zero) +
+                        dm_simnn_ws_bytes(B, N2, N1, 0) + 65536;
+    int rc = dm_ws_reserve(ctx, need);
+    if (rc) return rc;
+    const double* mass2 = nullptr;
+    rc = dm_widen_mass(ctx, (long long)B * N2, mass2_in, (double*)dm_ws_take(ctx, (size_t)B * N2 * 8), &mass2);
+    if (rc) return rc;
+    _Float16* Fx = (_Float16*)dm_ws_take(ctx, bytes_Fx);
+    _Float16* Fy = (_Float16*)dm_ws_take(ctx, bytes_Fy);
+    double* Ca = (double*)dm_ws_take(ctx, bytes_C);
+    double* Cb = (double*)dm_ws_take(ctx, bytes_C);
+    float* bias = (float*)dm_ws_take(ctx, (size_t)B * R1 * 4);
+    double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
+    double* embr = (double*)dm_ws_take(ctx, (size_t)B * N1 * Kpad * 8);
+    int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    double* amaxT = (double*)dm_ws_take(ctx, (size_t)B * ZO_NCH * 8);
+    char* zero = (char*)dm_ws_take(ctx, bytes_zero);
+    if (!Fx || !Fy || !Ca || !Cb || !bias || !n1 || !embr || !p21 || !amaxT || !zero)
+        return dm_fail(ctx, DM_ENOMEM, "zoomout: workspace not reserved");
+    char* amax_slots = zero;                                             // (nit + 3) x B maxima of |emb1| (float64 bits)
+    char* bmax_slots = zero + (size_t)(nit + 3) * amax1;                 // (nit + 2) x B maxima of |bias| (fp32 bits)
+    char* ctl_slots = bmax_slots + (size_t)(nit + 2) * bmax1;            // (nit + 2) control blocks of the tile pass
+    // everything an iteration accumulates into with atomicMax, for all iterations: ONE memset per call
+    DM_CHECK_HIP(ctx, hipMemsetAsync(zero, 0, bytes_zero, ctx->stream));
+    DM_CHECK_HIP(ctx, hipMemsetAsync(Ca, 0, bytes_C, ctx->stream));      // maps grow inside zeroed Kpad x Kpad frames
+    DM_CHECK_HIP(ctx, hipMemsetAsync(Cb, 0, bytes_C, ctx->stream));
+    if (R2 != N2) DM_CHECK_HIP(ctx, hipMemsetAsync(Fx, 0, bytes_Fx, ctx->stream));
+    if (R1 != N1) {
+        DM_CHECK_HIP(ctx, hipMemsetAsync(Fy, 0, bytes_Fy, ctx->stream));
+        DM_CHECK_HIP(ctx, hipMemsetAsync(bias, 0, (size_t)B * R1 * 4, ctx->stream));
+    }
+    // target side, once: scale and split rows of Phi2 for the full depth (a search at depth k reads the first 32 ceil(k / 16)
+    // halves; the source rows are zero beyond k)
+    rc = dm_zo_absmax_rows<TR>(ctx, B, N2, kf, Phi2, ld2, ZO_NCH, amaxT);
+    if (rc) return rc;
+    rc = dm_fm_split_build_rows<TR>(ctx, B, N2, kf, Phi2, ld2, amaxT, ZO_NCH, ldT, Fx, R2);
+    if (rc) return rc;
+    rc = dm_zo_copy_mat(ctx, B, k0, k0, C0, k0, (long long)k0 * k0, Ca, Kpad, (long long)Kpad * Kpad);
+    if (rc) return rc;
+    const size_t ws_mark = ctx->ws_off;
+
+    double* cur = Ca;
+    double* nxt = Cb;
+    int k = k0;
+    for (int it = 0; it <= nit; ++it) {
+        const bool last = (it == nit);
+        if (last && !p21_out) break;
+        ctx->ws_off = ws_mark;
+        zo_embed_args<TR> ea;
+        ea.Phi1 = Phi1; ea.s1 = (long long)N1 * ld1; ea.ld1 = ld1; ea.N1 = N1;
+        ea.C = cur; ea.strideC = (long long)Kpad * Kpad; ea.ldc = Kpad;
+        ea.k = k; ea.nrb = dm_cdiv(k, 16); ea.D = zo_depth(k); ea.ldS = ldS; ea.R1 = R1;
+        ea.Fy = Fy; ea.bias = bias; ea.n1 = n1; ea.N1pad = N1pad; ea.embr = embr; ea.Kpad = Kpad;
+        ea.amaxT = amaxT; ea.nT = ZO_NCH; ea.dbg = dm_knob("DM_ZO_DEBUG", 0);
+        ea.bmax = (unsigned int*)(bmax_slots + (size_t)it * bmax1);
+        if (it == 0) {                                                 // the first scale: a pass that only takes the maximum
+            ea.amax_prev = (const unsigned long long*)amax_slots;
+            ea.amax_cur = (unsigned long long*)amax_slots;
+            ea.only_max = 1;
+            rc = dm_zo_embed_split<TR>(ctx, B, ea);
+            if (rc) return rc;
+        }
+        ea.amax_prev = (const unsigned long long*)(amax_slots + (size_t)it * amax1);
+        ea.amax_cur = (unsigned long long*)(amax_slots + (size_t)(it + 1) * amax1);
+        ea.only_max = 0;
+        rc = dm_zo_embed_split<TR>(ctx, B, ea);
+        if (rc) return rc;
+        // the search: one biased key on split rows; dropped <xl, yl> and the two residuals 3 * 2^-22, the fp16 subnormal
+        // floor 2 sqrt(k) 2^-25 budgeted four times (the scale may be up to 4x below the ideal one), 25 % slack
+        const float rel_extra = 1.25f * (3.0f * 2.3841858e-7f + 4.0f * 2.0f * sqrtf((float)k) * 2.9802322e-8f);
+        dm_simnn_dual dual{};
+        dual.bias = bias; dual.tau_add = (const float*)ea.bmax; dual.padded = true; dual.single = true;
+        dm_simnn_ext ext;
+        ext.ctl = ctl_slots + (size_t)it * dm_align_up(ctl1); ext.skip_merge = true;
+        dm_simnn_queue qd;
+        rc = dm_simnn_core(ctx, B, N2, N1, ea.D, Fx, ldT, Fy, ldS, rel_extra, nullptr, nullptr, nullptr, nullptr, &qd, &dual, &ext);
+        if (rc) return rc;
+        zo_mx_args<TR> ma;
+        ma.q = dm_simnn_queue{ext.pb, ext.pj, ext.ps, ext.nparts, ext.pw, ext.N2pad, nullptr, nullptr, nullptr};
+        ma.tnorm2 = ext.tnorm2; ma.smax2 = ext.smax2; ma.bmax = ea.bmax; ma.tau_scale = ext.tau_scale;
+        ma.amax_prev = ea.amax_prev; ma.amax_cur = ea.amax_cur;
+        ma.Phi2 = Phi2; ma.ld2 = ld2; ma.embr = embr; ma.Kpad = Kpad; ma.n1 = n1; ma.N1pad = N1pad;
+        ma.K = k; ma.N2 = N2; ma.N1 = N1; ma.nn = last ? p21_out : p21; ma.dbg = (ea.dbg & 16) ? 1 : 0;
+        rc = dm_zo_merge_exact<TR>(ctx, B, ma);
+        if (rc) return rc;
+        if (last) break;
+        const int kn = k + step;
+        rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, kn, kn, p21, Phi1, ld1, Phi2, ld2, mass2, nxt, Kpad, (long long)Kpad * Kpad);
+        if (rc) return rc;
+        double* tmp = cur; cur = nxt; nxt = tmp;
+        k = kn;
+    }
+    return dm_zo_copy_mat(ctx, B, kf, kf, cur, Kpad, (long long)Kpad * Kpad, Cout, kf, (long long)kf * kf);
+}
+
 template <typename TR>
 static int zoomout_impl(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int step, const TR* Phi1, int ld1,
                         const TR* Phi2, int ld2, const TR* mass2_in, const double* C0, double* Cout,
@@ -111,6 +415,8 @@ static int zoomout_impl(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, int
     const int kf = k0 + nit * step;
     DM_REQUIRE(ctx, ld1 >= kf && ld2 >= kf, "not enough eigenvectors for k0 + nit*step (zoomout.py:87-92)");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (zoomout_fused_ok(ctx, N1, N2, kf))
+        return zoomout_fused<TR>(ctx, B, N1, N2, k0, nit, step, Phi1, ld1, Phi2, ld2, mass2_in, C0, Cout, p21_out);
 
     const int N1pad = pad_to(N1, 128), N2pad = pad_to(N2, 128), Kpad = pad_to(kf, 16);
     const size_t bytes_AT = (size_t)B * Kpad * N2pad * 8, bytes_BT = (size_t)B * Kpad * N1pad * 8;

@@ -82,7 +82,8 @@ class MatchEngine:
     def synchronize(self):
         self.stream.synchronize()
 
-    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0, "solve_reg": 1, "simnn_band": 4, "lsa_reg": 2, "simnn_big": 0, "energy_keep_gram": 0}
+    OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0, "solve_reg": 1, "simnn_band": 4, "lsa_reg": 2, "simnn_big": 0, "energy_keep_gram": 0,
+                       "p2pfm_direct": 1, "zoomout_fused": 1}
 
     def set_option(self, name, value):
         """Choose between equivalent code paths of the library (include/densematch.h: dm_set_option); every setting
@@ -410,9 +411,11 @@ class MatchEngine:
         # (the C ABI carries lumped masses as fp32, like every other entry point: the problem solved is the one with the
         #  rounded masses, so that Phi^T A Phi = I holds for the A the matching kernels will see)
         # Meshes of DIFFERENT vertex counts share a call too (`mass` a list of 1-D arrays): the smaller ones are padded with
-        # decoupled vertices whose only entry is a diagonal one inside the upper spectrum (the largest diagonal entry of the
-        # mesh's own operator), so the filter damps them like every unwanted eigenvector; their rows of Phi come back ~0 and
-        # the caller slices them off.
+        # decoupled vertices whose only entry is a diagonal one AT the Gershgorin bound of the mesh's own operator
+        # (max_i sum_q |L_iq| >= lambda_max: the upper end of the interval the Chebyshev filter damps, dm_eigen.hip
+        # gershgorin_kernel), so the spurious eigenvalue can never fall inside the wanted part of the spectrum -- the largest
+        # diagonal entry, used before, ranks near the MIDDLE of the spectrum on a near-uniform mesh.  Their rows of Phi come
+        # back ~0 and the caller slices them off.
         masses = [np.ascontiguousarray(a, dtype=np.float32).astype(np.float64).ravel() for a in mass]
         B, N = len(masses), max(a.shape[0] for a in masses)
         if any(np.any(a <= 0) for a in masses):
@@ -434,7 +437,7 @@ class MatchEngine:
             vals[b, rows, pos] = Lm.data
             mass[b, :nb] = masses[b]
             if nb < N:
-                vals[b, nb:, 0] = float(Lm.diagonal().max())
+                vals[b, nb:, 0] = float(abs(Lm).sum(axis=1).max())
         m = min(k + guard, N)
         g = torch.Generator(device=self.device).manual_seed(seed)
         X = torch.randn((B, N, m), dtype=torch.float64, device=self.device, generator=g)

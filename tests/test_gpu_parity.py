@@ -798,6 +798,30 @@ def test_eigenbasis_against_dense_eigh(eng, nu, nv, k):
         assert np.abs(P.T @ P - np.eye(cut)).max() <= 1e-7
 
 
+@pytest.mark.parametrize("small", [(16, 12), (28, 25)])
+def test_eigenbasis_small_mesh_beside_a_large_one(eng, small):
+    """TriMesh.process_many on meshes of different vertex counts.  N = 700 beside 1200, k = 128: one batched call, the
+    small mesh padded with decoupled vertices at the Gershgorin bound of its own operator (the top of the damped interval; the
+    largest diagonal entry used before ranks near the middle of the spectrum).  N = 192 beside 1200, k = 128 > N / 2: the wanted
+    range reaches into the upper half of the small mesh's spectrum, process_many solves the meshes one by one."""
+    import scipy.linalg
+    from densematcher_amd import synth
+    from densematcher_amd.pyFM.mesh import TriMesh
+    k = 128
+    meshes = [TriMesh(*synth.torus_mesh(*small)), TriMesh(*synth.torus_mesh(40, 30, perturb=0.05, seed=2))]
+    TriMesh.process_many(meshes, [k, k])
+    for m in meshes:
+        n = m.n_vertices
+        a = m.A.diagonal()
+        w = scipy.linalg.eigh(m.W.toarray(), np.diag(a), eigvals_only=True)
+        assert m.eigenvectors.shape == (n, k)
+        assert np.abs(m.eigenvalues - w[:k]).max() <= 1e-6 * w[k - 1], n
+        G = m.eigenvectors.T @ (a[:, None] * m.eigenvectors)
+        assert np.abs(G - np.eye(k)).max() <= 1e-6, n
+        R = m.W @ m.eigenvectors - (a[:, None] * m.eigenvectors) * m.eigenvalues[None, :]
+        assert np.abs(R).max() <= 1e-5 * w[k - 1], n
+
+
 def test_maps_on_gpu_eigenbasis_match_maps_on_host_eigenbasis(eng):
     """end to end: a pair matched on the GPU-made bases gives the same vertex maps as on SciPy's dense bases (the functional
     map itself is basis dependent inside clusters of equal eigenvalues, the maps are not)"""
