@@ -26,6 +26,7 @@ SIGNATURES = {
     "dm_version": (C.c_char_p, []),
     "dm_workspace_bytes": (C.c_size_t, [_p]),
     "dm_set_option": (_i, [_p, C.c_char_p, _i]),
+    "dm_last_requeued_rows": (_i, [_p, C.POINTER(_i)]),
     "dm_profile_kernel": (_i, [_p, C.c_char_p]),
     "dm_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(_d)]),
     "dm_profile_report": (_i, [_p, C.c_char_p, C.c_size_t]),

@@ -315,7 +315,7 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
     const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + 4 * dm_align_up(bG) + dm_align_up(bImg) +
                         2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 4 * dm_align_up((size_t)B * N2 * 4) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, k2) + dm_knn_split_ws_bytes(B, N2, N1, k2) +
-                        dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + 65536;
+                        dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + dm_p2pfm_xs_bytes(B, N2, k2) + 65536;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* AT = (double*)dm_ws_take(ctx, bAT);
@@ -349,8 +349,17 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
     dm_knn_split_state knn;                    // fp16 split of Phi2 for the nearest-neighbour searches, once
     rc = dm_knn_split_prepare(ctx, B, N2, N2pad, Kpad, k2, AT, &knn);
     if (rc) return rc;
+    // the left operand of every p2p_to_FM of the call (Phi2, unit masses), once (dm_p2pfm_prescale)
+    double* Xs = nullptr;
+    const int ldx = (k2 + 15) / 16 * 16;
+    if (ctx->opt_p2pfm_direct) {
+        Xs = (double*)dm_ws_take(ctx, dm_p2pfm_xs_bytes(B, N2, k2));
+        if (!Xs) return dm_fail(ctx, DM_ENOMEM, "icp: workspace not reserved");
+        rc = dm_p2pfm_prescale<TR>(ctx, B, N2, k2, Phi2, ld2, ones, Xs);
+        if (rc) return rc;
+    }
     const size_t ws_mark = ctx->ws_off;
-    rc = dm_launch_p2p_to_fm<TR>(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2);
+    rc = dm_launch_p2p_to_fm<TR>(ctx, B, N2, N2, k2, k2, iota, Phi2, ld2, Phi2, ld2, ones, G, k2, (long long)k2 * k2, Xs, ldx);
     if (rc) return rc;
     DM_CHECK_HIP(ctx, hipMemsetAsync(BT, 0, bBT, ctx->stream));
     // the Gram matrix does not change over the iterations: invert it once and apply the inverse by a GEMM per iteration
@@ -371,7 +380,7 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
         rc = dm_launch_knn21(ctx, a, knn, amaxS, dm_cdiv(N1pad, DM_EMB_COLS));
         if (rc) return rc;
         // R = Phi2^T Phi1[p21]   (k2 x k1);   Chat = (Phi2^T Phi2)^-1 R
-        rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1);
+        rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, ones, R, k1, (long long)k2 * k1, Xs, ldx);
         if (rc) return rc;
         {   // Chat = (Phi2^T Phi2)^-1 R with the inverse computed once before the loop
             KRowsF64 ga{Ginv, (long long)k2 * k2, k2, k2, k2, 0};

@@ -47,6 +47,7 @@ struct dm_ctx {
     int opt_p2p_split = 2;       // four maps: 0 the float64 G kernel, 1 two passes of the two-key fp16 tile kernel, 2 one pass reducing in both directions (3: 4-wave shape)
     int opt_simnn_persist = 1;   // 0: one workgroup per similarity tile instead of one persistent workgroup per CU
     int opt_p2pfm_direct = 1;    // 0: p2p_to_FM on the LDS-staged 64 x 64 tile kernel with split-K partials + a reduce launch
+    int opt_simnn1_wt = 4;       // the biased-key search of the fused ZoomOut iteration: 4 = 8 waves, 256 x 256 tiles, one workgroup per CU; 2 = 4 waves, 128 x 256, two per CU
     int opt_zoomout_fused = 1;   // 0: ZoomOut as six launches per iteration (embedding, row build, search, merge, exact, p2p_to_FM [+ reduce])
     int opt_energy_keep_gram = 0;  // 1: dm_fmap_energy_grad keeps P = A A^T, Q = B A^T of its FIRST call and reuses them while A, B
                                    // (pointers and sizes) stay the same: the caller promises not to change their contents (the L-BFGS
@@ -58,6 +59,8 @@ struct dm_ctx {
     bool gram_valid = false;
     bool gram_sums_valid = false;  // the basis sums p, s2 behind P, Q in the same block (written by the first evaluation that needs them)
     int n_cu = 0;                // multiProcessorCount of the device
+    const int32_t* last_flag_counts = nullptr;   // device: the four queue counters (64 ints apart) of the last tile pass with its own merge; null: none
+    int last_flag_sets = 0;
 };
 
 // Experiment knobs (ablation variants that may produce WRONG results) exist only in a -DDM_EXPERIMENTS build, where
@@ -246,8 +249,13 @@ int dm_fm_split_build_rows(dm_ctx* ctx, int B, int N, int K, const TR* Phi, int 
 template <typename TR>
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21,
                         const TR* Phi1, int ld1, const TR* Phi2, int ld2, const double* mass2,
-                        double* C, int ldc, long long strideC);
+                        double* C, int ldc, long long strideC,
+                        const double* Xs = nullptr, int ldx = 0);   // Xs: mass2 * Phi2 as dm_p2pfm_prescale builds it (a caller that
+                                                                    // converts many maps on the same target builds it once); null: built per call
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2);
+size_t dm_p2pfm_xs_bytes(int B, int N2, int k2);
+template <typename TR>
+int dm_p2pfm_prescale(dm_ctx* ctx, int B, int N2, int k2, const TR* Phi2, int ld2, const double* mass2, double* Xs);
 
 // dm_fmap_c00: sign(Phi1[0,0] Phi2[0,0]) sqrt(area2 / area1) per pair (pyFM/functional.py:654-658).  One workgroup of 256
 // threads per pair; also run as an extra workgroup of a projection's maxima pass (dm_fmap_fit), same arithmetic.

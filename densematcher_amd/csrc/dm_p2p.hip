@@ -837,6 +837,7 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
         a.mass1 = massbuf;
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
+    ctx->last_flag_counts = nullptr;
     if (split) { a.Ktrue = k2; return dm_launch_fm_split<TR>(ctx, a, amaxS, nS, amaxT, nT, zeroed, Phi2, ld2); }
     return dm_launch_gred(ctx, a);
 }

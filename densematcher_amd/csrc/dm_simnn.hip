@@ -55,6 +55,7 @@ struct simnn_params {
     float* snorm2; unsigned int* tmax2;
     int N1pad;
     int dbg;                                 // DM_EXPERIMENTS builds only (0 in the product): see simnn_pipe_kernel
+    unsigned long long* trace;               // DM_EXPERIMENTS builds only: stage timeline of workgroup 0 (XV bit 1024)
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -453,7 +454,8 @@ static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
     // ring | DUAL: two slots of (256 bias + 256 scale [+ TT target bias]) floats | DUAL 3, 8 waves: the eighth wave's transpose
     // buffer (the other seven use the ring slot that is free during an epilogue)
     size_t n = (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16);
-    if (dual) n += (size_t)2 * (dual == 3 ? 512 + TT : 512) * 4;
+    if (dual == -1) n += 8 * 256 * 8;                  // experiments: the stage timeline's log
+    if (dual > 0) n += (size_t)2 * (dual == 3 ? 512 + TT : 512) * 4;
     if (dual == 3 && WT == 4) n += 32 * 36 * 4;
     return n;
 }
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     constexpr int STAG = (XV >> 4) & 3;
     constexpr bool PINR = (XV & 64) != 0;
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
+    constexpr bool TRACE = (XV & 1024) != 0;     // experiments: s_memtime stamps of every stage of workgroup 0's third tile
     constexpr bool SPLIT = DUAL != 0;            // the key-set kernels read split rows [16 high | 16 low] per stage (dm_knnsplit.hip)
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | per-tile terms | transpose buffer
     // Behind the ring: DUAL: two slots of per-tile terms | DUAL 3, 8 waves: the eighth wave's transpose buffer (the transposes of
@@ -644,6 +647,22 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     if ((dbg & 15) != 5) __builtin_amdgcn_s_barrier();      /* (ablation 5: no stage barriers -- wrong results) */    \
     __builtin_amdgcn_sched_barrier(0);
 #define SIMNN_PIN() if (PINR) __builtin_amdgcn_sched_barrier(0);
+    // TRACE: seven s_memtime stamps per stage, taken without waiting for them (the scalar memory unit executes them in program
+    // order; the stage's own lgkmcnt(0) waits cover them) and written by lane 0 to this wave's part of an LDS log at the end of
+    // the stage; the log of workgroup 0's third tile is copied out when the tile is done
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0, tq5 = 0, tq6 = 0;
+    int tr_n = 0;
+    bool tr_on = false;
+    unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(smem + NBUF * PSTAGE) + wave * 256;
+#define SIMNN_STAMP(v_) if constexpr (TRACE) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(v_)); __builtin_amdgcn_sched_barrier(0); }
+#define SIMNN_TRACE_FLUSH()                                                                                            \
+    if constexpr (TRACE) {                                                                                             \
+        if (tr_on && tr_n + 8 <= 256 && lane == 0) {                                                                   \
+            tr_lds[tr_n] = tq0; tr_lds[tr_n + 1] = tq1; tr_lds[tr_n + 2] = tq2; tr_lds[tr_n + 3] = tq3;                \
+            tr_lds[tr_n + 4] = tq4; tr_lds[tr_n + 5] = tq5; tr_lds[tr_n + 6] = tq6; tr_lds[tr_n + 7] = 0;              \
+        }                                                                                                              \
+        if (tr_on) tr_n += 8;                                                                                          \
+    }
     // one stage: DMA_ = 1 in the steady state (stage g+PD exists), VM_ = loads allowed to stay in flight at the barrier,
     // NEXT_ = fetch the first fragments of the next stage (in the steady state also across a tile boundary: they wait
     // in registers while the epilogue runs)
@@ -651,17 +670,28 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     {                                                                                                                  \
         const int n_slot = (r_slot + 1 == NBUF) ? 0 : r_slot + 1;                                                      \
         if constexpr (!SPLIT) {                                                                                        \
+        SIMNN_STAMP(tq0)                                                                                               \
         if (!late) { SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } SIMNN_PIN() }                       \
+        SIMNN_STAMP(tq1)                                                                                               \
         SIMNN_MMA(fsa, fta, NORMS, ZERO_)                                                                              \
         if (late) { SIMNN_PIN() SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } }                        \
-        SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
+        SIMNN_STAMP(tq2)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if ((AFTER_EPI_) && n > 0 && !NOEPI) DM_WAIT_VM_LGKM0((VM_) + EPI_ST); else DM_WAIT_VM_LGKM0(VM_);             \
+        SIMNN_STAMP(tq3)                                                                                               \
+        if ((dbg & 15) != 5) __builtin_amdgcn_s_barrier();                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        SIMNN_STAMP(tq4)                                                                                               \
         if (!late) { if (NEXT_) { SIMNN_READ(fsa, fta, n_slot, foff0) } if (DMA_) { SIMNN_DMA1(1) } SIMNN_PIN() }        \
+        SIMNN_STAMP(tq5)                                                                                               \
         SIMNN_MMA(fsb, ftb, NORMS, false)                                                                              \
         if (late) { SIMNN_PIN() if (NEXT_) { SIMNN_READ(fsa, fta, n_slot, foff0) } if (DMA_) { SIMNN_DMA1(1) } }         \
+        SIMNN_STAMP(tq6)                                                                                               \
         /* the fragments of the next half-stage were requested eight MFMAs ago: make their arrival explicit here, or    \
            the compiler, merging the loop back-edge, waits lgkmcnt(0) in FRONT of the next MFMAs -- i.e. for the reads   \
            that were only just issued there */                                                                         \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        SIMNN_TRACE_FLUSH()                                                                                            \
         } else {                                                                                                       \
         /* split rows: a stage holds 16 contraction indices as [16 high halves | 16 low halves] of both operands and     \
            feeds THREE k-steps, hs.ht + hs.lt + ls.ht, from the same 12 fragment reads and the same 32 KiB of LDS-DMA    \
@@ -725,6 +755,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
         // the last stage die there and are read again here.
         if (DEFER_READ && n > 0) { SIMNN_READ(fsa, fta, r_slot, foff0) }
         const int i0 = tt_ * TT, j0 = ts_ * ST;
+        if constexpr (TRACE) tr_on = (blockIdx.x == 0 && n == 2);
         f32x16 acc[4][TB];
         // squared row norms for the exactness bound, accumulated from the MFMA fragments by the workgroups that own
         // the first tile of the other operand (every row of T / S is seen exactly once that way).  Those tiles run a
@@ -764,6 +795,15 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
             if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
         } else
 #endif
+        if constexpr (TRACE) {
+            if (tr_on) {
+                unsigned long long te;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(te));
+                if (lane == 0) { tr_lds[tr_n < 256 ? tr_n : 255] = te; }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                for (int q = lane; q < 256; q += 64) p.trace[wave * 256 + q] = (q <= tr_n) ? tr_lds[q] : 0ull;
+            }
+        }
         if (DUAL == 3) {
             // transposes go through the free slot (8 waves: seven of them, the eighth has its own buffer)
             float* tb = (NW == 8 && wave == 7) ? tb_extra : free_slot + wave * (32 * 36);
@@ -777,6 +817,8 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     __builtin_amdgcn_s_waitcnt(0x0070);                          // nothing of this workgroup may still be in flight
 #undef SIMNN_TILE_LOOP
 #undef SIMNN_STAGE
+#undef SIMNN_TRACE_FLUSH
+#undef SIMNN_STAMP
 #undef SIMNN_PIN
 #undef SIMNN_SYNC
 #undef SIMNN_MMA
@@ -785,6 +827,17 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
 #undef SIMNN_DMA1
 #undef SIMNN_DMA_TILE
 }
+
+#ifdef DM_EXPERIMENTS
+static unsigned long long* g_simnn_trace = nullptr;
+// experiments: the stage timeline of the last traced launch (8 waves x 256 stamps; tools/simnn_trace.py)
+extern "C" int dm_debug_simnn_trace(dm_ctx* ctx, unsigned long long* out) {
+    if (!ctx || !out || !g_simnn_trace) return DM_EINVAL;
+    DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DM_CHECK_HIP(ctx, hipMemcpy(out, g_simnn_trace, 8 * 256 * 8, hipMemcpyDeviceToHost));
+    return DM_OK;
+}
+#endif
 
 // one key set of a tile pass: its partials in, the arg-max and the queue of ambiguous rows out.  Up to four key sets (the four
 // maps of dm_fm_to_p2p: two per direction, with their own geometry) are merged by ONE launch: blockIdx.z selects the set.
@@ -1036,7 +1089,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     // the 4-wave / 8-wave shape
     const bool ops_in_l2 = ((size_t)N2 * ldT + (size_t)N1 * ldS) * 2 <= ((size_t)3 << 20);
     const int WT = cols ? ((ctx->opt_p2p_split == 3 || (ctx->opt_p2p_split == 2 && ops_in_l2 && !ctx->opt_simnn_big)) ? 2 : 4)
-                        : (dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT)));
+                        : (single ? (ctx->opt_simnn1_wt == 2 ? 2 : 4) : (dual ? 4 : ((p.dbg & 256) ? 4 : ((p.dbg & 512) ? 2 : SIMNN_PRODUCT_WT))));
     // (the stage loop peels its first and last stages: the contraction must be at least ring depth + 1 stages deep)
     const bool aligned = (N2 % ST == 0 && N1 % ST == 0);
     const int TB = (WT == 4 && ctx->opt_simnn_big && aligned) ? 4 : 2;       // 32-row target blocks per wave
@@ -1082,7 +1135,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             grid = want < p.total ? want : p.total;
             if (edge) {
                 if (cols) { if (WT == 4) SIMNN_LAUNCH_EDGE(4, 3, "simnn4_f16_mfma") else SIMNN_LAUNCH_EDGE(2, 3, "simnn4_f16_mfma") }
-                else if (single) SIMNN_LAUNCH_EDGE(4, 4, "simnn1_f16_mfma")
+                else if (single) { if (WT == 4) SIMNN_LAUNCH_EDGE(4, 4, "simnn1_f16_mfma") else SIMNN_LAUNCH_EDGE(2, 4, "simnn1_f16_mfma") }
                 else if (dual->scale) SIMNN_LAUNCH_EDGE(4, 1, "simnn2_f16_mfma")
                 else SIMNN_LAUNCH_EDGE(4, 2, "simnn2_f16_mfma")
                 continue;
@@ -1096,12 +1149,23 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             if (WT == 4) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 3, "simnn4_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 2, 3, "simnn4_f16_mfma")
         } else if (single) {
-            SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 4, "simnn1_f16_mfma")
+            if (WT == 4) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 4, "simnn1_f16_mfma")
+            else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 2, 4, "simnn1_f16_mfma")
         } else if (dual) {
             if (dual->scale) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 1, "simnn2_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 2, "simnn2_f16_mfma")
         } else {
 #ifdef DM_EXPERIMENTS
+        if (p.dbg == 0x10000) {         // stage timeline (tools/simnn_trace.py): the product variant + stamps, 8 waves
+            static unsigned long long* trace_dev = nullptr;
+            if (!trace_dev) DM_CHECK_HIP(ctx, hipMalloc((void**)&trace_dev, 8 * 256 * 8));
+            p.trace = trace_dev;
+            g_simnn_trace = trace_dev;
+            const size_t lds_tr = simnn_pipe_lds(4, -1);
+            rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<SIMNN_PRODUCT_XV + 1024, 4, 0>, lds_tr);
+            if (rc) return rc;
+            DM_LAUNCH(ctx, "simnn_f16_mfma", (simnn_pipe_kernel<SIMNN_PRODUCT_XV + 1024, 4, 0>), dim3(grid), dim3(512), lds_tr, p);
+        } else
         switch (p.dbg) {
 #define SIMNN_CASE(XV_) case 512 + XV_: SIMNN_LAUNCH_XV(XV_, 2, 0, "simnn_f16_mfma") break; case 256 + XV_: SIMNN_LAUNCH_XV(XV_, 4, 0, "simnn_f16_mfma") break;
             SIMNN_CASE(0) SIMNN_CASE(1) SIMNN_CASE(7) SIMNN_CASE(9)
@@ -1160,6 +1224,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         maxN = N1 > N2 ? N1 : N2;
     }
     DM_LAUNCH(ctx, "simnn_merge", simnn_merge_kernel, dim3(dm_cdiv(maxN, 256), B, nsets), dim3(256), 0, sets, tau_scale, force_flag);
+    ctx->last_flag_counts = flag_count; ctx->last_flag_sets = nsets;
     *q = dm_simnn_queue{p.pb, p.pj, p.ps, nparts, 128, p.N2pad, flag_count, flag_list, flag_thr};
     if (dual && !single) *dual->q_b = dm_simnn_queue{p.pb_2, p.pj_2, p.ps_2, nparts, 128, p.N2pad, flag_count2, flag_list2, flag_thr2};
     if (cols) {
@@ -1190,5 +1255,17 @@ extern "C" int dm_simnn_f16(dm_ctx* ctx, int B, int N2, int N1, int D, const voi
     }
     DM_LAUNCH(ctx, "simnn_fixup_f64", simnn_fixup_kernel, dim3(2048), dim3(256), lds, (const _Float16*)Ftgt,
               (const _Float16*)Fsrc, N2, N1, D, q.pb, q.pj, q.ps, q.nparts, q.pw, q.Npad, q.flag_count, q.flag_list, q.flag_thr, nn21);
+    return DM_OK;
+}
+
+extern "C" int dm_last_requeued_rows(dm_ctx* ctx, int out[4]) {
+    if (!ctx || !out) return DM_EINVAL;
+    for (int q = 0; q < 4; ++q) out[q] = -1;
+    if (!ctx->last_flag_counts) return DM_OK;
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int32_t host[4 * 64];
+    DM_CHECK_HIP(ctx, hipMemcpyAsync(host, ctx->last_flag_counts, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < ctx->last_flag_sets && q < 4; ++q) out[q] = host[64 * q];
     return DM_OK;
 }

@@ -19,7 +19,6 @@
 // kernel checks the ratio: inside [1/4, 8) the error bound below holds (the fp16 subnormal term is budgeted four times over);
 // outside, every row of the pair takes the exact path for that iteration -- slower, never wrong.
 #include "dm_device.h"
-#include "dm_exact.h"
 #include "dm_internal.h"
 #include "dm_split.h"
 #include "dm_zoomfuse.h"
@@ -59,21 +58,23 @@ template int dm_zo_absmax_rows<double>(dm_ctx*, int, int, int, const double*, in
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. embedding + split rows
-// Workgroup = 8 waves = 128 source vertices; wave w owns vertices 16 w .. 16 w + 15 and ALL of their (<= 16 NRB) embedding
+// Workgroup = ZE_NW waves = 16 ZE_NW source vertices; wave w owns vertices 16 w .. 16 w + 15 and ALL of their (<= 16 NRB) embedding
 // entries: NRB accumulator tiles of v_mfma_f64_16x16x4_f64 (A = the wave's rows of Phi1, read straight from global memory one
-// stage ahead -- a lane needs four entries per stage of 16 contraction indices --, B = rows of C, shared by the eight waves
+// stage ahead -- a lane needs four entries per stage of 16 contraction indices --, B = rows of C, shared by the waves
 // through two LDS stages, one barrier per stage).  A row is complete inside one wave: norm, maximum, split and all three
 // stores need no exchange beyond the wave.
 constexpr int ZE_LD = 18;                               // LDS row stride of the C stage (f64): conflict-free fragment reads
-static inline size_t zo_embed_lds(int NRB) { return (size_t)2 * NRB * 16 * ZE_LD * 8 + 8 * 1024; }
+constexpr int ZE_NW = 8;                                // waves per workgroup (16 vertices each); 4 (two or three workgroups per CU) measured 3 % slower
+static inline size_t zo_embed_lds(int NRB) { return (size_t)2 * NRB * 16 * ZE_LD * 8 + ZE_NW * 1024; }
 
 template <typename TR, int NRB>
-__global__ __launch_bounds__(512, NRB <= 6 ? 4 : 2) void zo_embed_split_kernel(zo_embed_args<TR> a) {
+__global__ __launch_bounds__(64 * ZE_NW, NRB <= 6 ? 4 : 2) void zo_embed_split_kernel(zo_embed_args<TR> a) {
     extern __shared__ __attribute__((aligned(16))) double ze_sm[];
     double* Cs = ze_sm;                                               // [2][16 NRB][ZE_LD]
-    unsigned int* scr = reinterpret_cast<unsigned int*>(ze_sm + 2 * NRB * 16 * ZE_LD);   // [8 waves][256 dwords]
-    constexpr int NQ = (NRB * 16 + 63) / 64;
-    const int b = blockIdx.y, v0 = blockIdx.x * 128;
+    unsigned int* scr = reinterpret_cast<unsigned int*>(ze_sm + 2 * NRB * 16 * ZE_LD);   // [ZE_NW waves][256 dwords]
+    constexpr int RPP = 8 * ZE_NW;                                    // rows of C staged per pass of the workgroup
+    constexpr int NQ = (NRB * 16 + RPP - 1) / RPP;
+    const int b = blockIdx.y, v0 = blockIdx.x * (16 * ZE_NW);
     const int t = threadIdx.x, lane = t & 63, l15 = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr int nrb = NRB;                                          // exact: no guard between the matrix instructions
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512, NRB <= 6 ? 4 : 2) void zo_embed_split_kernel(z
     typedef __attribute__((address_space(1))) const f64x2 gf64x2;
     typedef __attribute__((address_space(1))) const TR gTR;
     const double* Cb = a.C + (long long)b * a.strideC;
-    const int tr = t >> 3, mc = (t & 7) * 2;                          // C staging: rows tr + 64 q, contraction entries mc, mc + 1
+    const int tr = t >> 3, mc = (t & 7) * 2;                          // C staging: rows tr + RPP q, contraction entries mc, mc + 1
     gTR* arow = (gTR*)(a.Phi1 + (long long)b * a.s1 + (long long)min(v0 + wave * 16 + l15, a.N1 - 1) * a.ld1);
 
     f64x2 rc[NQ];
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(512, NRB <= 6 ? 4 : 2) void zo_embed_split_kernel(z
 #define ZE_FETCH(s_)                                                                           \
     {                                                                                          \
         _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                       \
-            const int row_ = tr + 64 * q;                                                      \
+            const int row_ = tr + RPP * q;                                                     \
             rc[q] = (row_ < 16 * nrb) ? *(gf64x2*)(Cb + (long long)row_ * a.ldc + 16 * (s_) + mc) : f64x2{0.0, 0.0}; \
         }                                                                                      \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(512, NRB <= 6 ? 4 : 2) void zo_embed_split_kernel(z
         double* Cw = Cs + (s & 1) * (NRB * 16 * ZE_LD);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int row = tr + 64 * q;
+            const int row = tr + RPP * q;
             if (row < 16 * NRB) *reinterpret_cast<f64x2*>(Cw + row * ZE_LD + mc) = rc[q];
         }
 #pragma unroll
@@ -140,14 +141,14 @@ __global__ __launch_bounds__(512, NRB <= 6 ? 4 : 2) void zo_embed_split_kernel(z
     // (vertices beyond N1 repeat the last one: they change no maximum)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off));
-    // one atomic per workgroup (the eight waves meet in the scratch area, which nothing has used yet)
+    // one atomic per workgroup (the waves meet in the scratch area, which nothing has used yet)
     double* wmax = reinterpret_cast<double*>(scr);
     if (lane == 0) wmax[wave] = amax;
     __syncthreads();
     if (t == 0) {
         double m = wmax[0];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) m = fmax(m, wmax[w]);
+        for (int w = 1; w < ZE_NW; ++w) m = fmax(m, wmax[w]);
         atomicMax(a.amax_cur + b, (unsigned long long)__double_as_longlong(m));
     }
     if (a.only_max || (a.dbg & 8)) return;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(512, NRB <= 6 ? 4 : 2) void zo_embed_split_kernel(z
     if (t == 0) {
         float m = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) m = fmaxf(m, reinterpret_cast<float*>(scr)[w]);
+        for (int w = 0; w < ZE_NW; ++w) m = fmaxf(m, reinterpret_cast<float*>(scr)[w]);
         atomicMax(a.bmax + b, __float_as_uint(m));
     }
     __syncthreads();
@@ -236,7 +237,7 @@ static int zo_embed_launch(dm_ctx* ctx, int B, const zo_embed_args<TR>& a) {
     const size_t lds = zo_embed_lds(NRB);
     int rc = dm_grant_lds(ctx, (const void*)zo_embed_split_kernel<TR, NRB>, lds);
     if (rc) return rc;
-    DM_LAUNCH(ctx, "zo_embed_split", (zo_embed_split_kernel<TR, NRB>), dim3(dm_cdiv(a.N1, 128), B), dim3(512), lds, a);
+    DM_LAUNCH(ctx, "zo_embed_split", (zo_embed_split_kernel<TR, NRB>), dim3(dm_cdiv(a.N1, 16 * ZE_NW), B), dim3(64 * ZE_NW), lds, a);
     return DM_OK;
 }
 template <typename TR>
@@ -267,10 +268,81 @@ template int dm_zo_embed_split<double>(dm_ctx*, int, const zo_embed_args<double>
 // inside the bound go on a list in LDS.  Phase 2: the whole workgroup re-evaluates the listed rows one by one in float64
 // (ks_exact_row: only the 32-candidate blocks the partials cannot rule out).
 constexpr int ZM_ROWS = 16;                        // target rows per workgroup: 16 lanes per row in the merge phase
+constexpr int ZM_KMAX = 208;                       // largest map of the fused path
+
+// Exact float64 re-evaluation of ONE queued row by ONE wave (no workgroup barrier: the four waves of a workgroup work on four
+// rows at once).  Same arithmetic and summation schedule as ks_exact_row<0> (dm_exact.h): per candidate eight partial sums over
+// the contraction indices r = p (mod 8), ascending fma chains, added in the order p = 0 .. 7; value |y_j|^2 - 2 g; blocks and
+// candidates ascend and comparisons are strict, so the lowest index wins ties.  Two lanes per candidate: lane (c, hh) carries
+// the parts 4 hh .. 4 hh + 3 (two 16-byte loads per eight indices), the odd lane hands its four sums to the even one.
+//   xw: this wave's K8 = 8 ceil(K / 8) doubles of LDS
+template <typename TR>
+__device__ __forceinline__ void zo_exact_row_wave(const zo_mx_args<TR>& a, int o, float thr, double* xw) {
+    const int lane = threadIdx.x & 63, c = lane >> 1, hh = lane & 1;
+    const int K = a.K, K8 = (K + 7) & ~7;
+    const int b = o / a.N2, i = o - b * a.N2;
+    const TR* __restrict__ trow = a.Phi2 + ((long long)b * a.N2 + i) * a.ld2;
+    for (int r = lane; r < K8; r += 64) xw[r] = (r < K) ? (double)trow[r] : 0.0;       // (zero beyond K: the padded products are exact zeros)
+    __builtin_amdgcn_wave_barrier();
+    const int nparts = a.q.nparts, pw = a.q.pw, nsub = nparts * (pw / 32);
+    const double* __restrict__ E = a.embr + (long long)b * a.N1 * a.Kpad;
+    const double* __restrict__ n1 = a.n1 + (long long)b * a.N1pad;
+    double bv = DM_INF_F64;
+    int bj = DM_IDX_NONE;
+    for (int sb0 = 0; sb0 < nsub; sb0 += 64) {
+        const int sbt = sb0 + lane;
+        const bool keep = sbt < nsub && dm_simnn_keep(a.q.pb, a.q.pj, a.q.ps, nparts, pw, a.q.Npad, b, i, sbt, thr);
+        unsigned long long mm = __ballot(keep);                   // uniform
+        while (mm) {
+            const int sb = sb0 + __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const int j = sb * 32 + c;
+            const int jc = min(j, a.N1 - 1);
+            const double* Cr = E + (long long)jc * a.Kpad + 4 * hh;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int r = 0;
+            // (loads of four steps ahead of their ordered fma chains: one L2 round trip per 32 indices instead of per 8)
+            for (; r + 32 <= K8; r += 32) {
+                f64x2 y[8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    y[2 * u] = *reinterpret_cast<const f64x2*>(Cr + r + 8 * u);
+                    y[2 * u + 1] = *reinterpret_cast<const f64x2*>(Cr + r + 8 * u + 2);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const f64x2 x0 = *reinterpret_cast<const f64x2*>(xw + r + 8 * u + 4 * hh), x1 = *reinterpret_cast<const f64x2*>(xw + r + 8 * u + 4 * hh + 2);
+                    s0 = fma(x0[0], y[2 * u][0], s0); s1 = fma(x0[1], y[2 * u][1], s1);
+                    s2 = fma(x1[0], y[2 * u + 1][0], s2); s3 = fma(x1[1], y[2 * u + 1][1], s3);
+                }
+            }
+            for (; r < K8; r += 8) {
+                const f64x2 y0 = *reinterpret_cast<const f64x2*>(Cr + r), y1 = *reinterpret_cast<const f64x2*>(Cr + r + 2);
+                const f64x2 x0 = *reinterpret_cast<const f64x2*>(xw + r + 4 * hh), x1 = *reinterpret_cast<const f64x2*>(xw + r + 4 * hh + 2);
+                s0 = fma(x0[0], y0[0], s0); s1 = fma(x0[1], y0[1], s1); s2 = fma(x1[0], y1[0], s2); s3 = fma(x1[1], y1[1], s3);
+            }
+            // parts 4 .. 7 from the odd lane (lane ^ 1), then the fixed order 0 .. 7
+            const double t0 = dpp_f64<0xB1>(s0), t1 = dpp_f64<0xB1>(s1), t2 = dpp_f64<0xB1>(s2), t3 = dpp_f64<0xB1>(s3);
+            const double g = ((((((s0 + s1) + s2) + s3) + t0) + t1) + t2) + t3;
+            if (hh == 0 && j < a.N1) {
+                const double v = n1[j] - 2.0 * g;                 // |y|^2 - 2 <x, y>
+                if (v < bv) { bv = v; bj = j; }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 2; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(bv, off);
+        const int oj = __shfl_xor(bj, off);
+        argmin_merge(bv, bj, ov, oj);
+    }
+    if (lane == 0 && bj != DM_IDX_NONE) a.nn[o] = bj;
+    __builtin_amdgcn_wave_barrier();                              // (xw is rewritten by this wave's next row)
+}
+
 template <typename TR>
 __global__ __launch_bounds__(256) void zo_merge_exact_kernel(zo_mx_args<TR> a) {
-    extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums
-    __shared__ unsigned long long cmask[4];
+    __shared__ __attribute__((aligned(16))) double xrow[4][ZM_KMAX];
     __shared__ int flist[ZM_ROWS];
     __shared__ float fthr[ZM_ROWS];
     __shared__ int fcount;
@@ -309,14 +381,14 @@ __global__ __launch_bounds__(256) void zo_merge_exact_kernel(zo_mx_args<TR> a) {
     __syncthreads();
     const int cnt = fcount;
     if (cnt == 0 || a.dbg) return;
-    ks_exact_args ea{nullptr, nullptr, a.n1, nullptr, nullptr, a.K, a.N2, 0, a.N1, a.N1pad, a.Kpad, a.q, a.nn, a.Phi2, a.embr, a.ld2, a.Kpad};
-    for (int e = 0; e < cnt; ++e) ks_exact_row<0, TR, double>(ea, flist[e], fthr[e], xrow, cmask);
+    const int wave = t >> 6;
+    for (int e = wave; e < cnt; e += 4) zo_exact_row_wave<TR>(a, flist[e], fthr[e], xrow[wave]);
 }
 
 template <typename TR>
 int dm_zo_merge_exact(dm_ctx* ctx, int B, const zo_mx_args<TR>& a) {
-    const size_t lds = ((size_t)a.K + 8 * 32 + 32) * sizeof(double);
-    DM_LAUNCH(ctx, "zo_merge_exact", zo_merge_exact_kernel<TR>, dim3(dm_cdiv(a.N2, ZM_ROWS), B), dim3(256), lds, a);
+    if (a.K > ZM_KMAX) return dm_fail(ctx, DM_EINVAL, "zo_merge_exact: map size %d beyond %d", a.K, ZM_KMAX);
+    DM_LAUNCH(ctx, "zo_merge_exact", zo_merge_exact_kernel<TR>, dim3(dm_cdiv(a.N2, ZM_ROWS), B), dim3(256), 0, a);
     return DM_OK;
 }
 template int dm_zo_merge_exact<float>(dm_ctx*, int, const zo_mx_args<float>&);

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_fm_kernel(const double* __r
     C[b * strideC + (long long)m * ldc + c] = s;
 }
 
+static inline int pad_to16(int x) { return (x + 15) / 16 * 16; }
 // split-K by a fixed chunk of vertices: the summation order of a pair must not depend on the batch it is in
 constexpr int FM_KCHUNK = 256;
 static int fm_split(int B, int N2, int k1, int k2) {
@@ -55,24 +56,68 @@ static int fm_split(int B, int N2, int k1, int k2) {
 // tiles up through LDS in a FIXED order at the end (no split-K partials in HBM, no reduce launch, no atomics: the sum of
 // a pair is the same in every batch and every run).  All workgroups of a pair run on one XCD (block b -> XCD b % 8) and
 // walk the vertices in step, so every row of Phi1 / Phi2 is fetched into that XCD's L2 once per slice position.
-//   tiles: RBW = 1 row block x up to 7 column blocks and S = 8 slices while the map has at most 7 x 7 blocks (k <= 112: more,
-//   lighter waves), else RBW = 2 x up to 5 column blocks, S = 4.
+//   tiles: 1 row block x up to 7 column blocks and S = 8 slices while the map has at most 7 x 7 blocks (k <= 112: more,
+//   lighter waves), else 2 row blocks x up to 5 column blocks, S = 4.
 template <typename TR>
 struct p2pfm_args {
     const TR* Phi1; long long s1; int ld1; int N1;
-    const TR* Phi2; long long s2; int ld2; int N2;
-    const int32_t* p21; const double* mass2;
+    const double* Xs; long long sx; int ldx; int N2;        // mass2 * Phi2, float64, (B, N2 + 1, ldx): row N2 is zero, ldx % 16 == 0
+    const int32_t* p21;
     int k1, k2;                       // columns (Phi1) / rows (Phi2) of the map
     double* C; int ldc; long long strideC;
     int B, TM, TC, rps;               // tiles = TM x TC per pair, vertices per slice (multiple of 4)
+    int dbg;                          // DM_EXPERIMENTS builds only (0 in the product): 32 no reduction / stores, 64 three k-steps only, 128 every step reads the slice's first vertices
 };
+
+// Xs[b][n][m] = mass2[b][n] * Phi2[b][n][m] (one rounding, like the reference's A2 @ ... products), zero for m >= k2 and for the
+// extra row n = N2 -- what the steps beyond a slice read.  Built once per ZoomOut call (the target basis does not change).
+template <typename TR>
+__global__ __launch_bounds__(256) void p2pfm_prescale_kernel(const TR* __restrict__ Phi2, int N2, int ld2, int k2, const double* __restrict__ mass2,
+                                                            double* __restrict__ Xs, int ldx) {
+    const int b = blockIdx.y;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)(N2 + 1) * ldx) return;
+    const int n = (int)(e / ldx), m = (int)(e - (long long)n * ldx);
+    double v = 0.0;
+    if (n < N2 && m < k2) v = mass2[(long long)b * N2 + n] * (double)Phi2[((long long)b * N2 + n) * ld2 + m];
+    Xs[(long long)b * (N2 + 1) * ldx + e] = v;
+}
+size_t dm_p2pfm_xs_bytes(int B, int N2, int k2) { return dm_align_up((size_t)B * (N2 + 1) * pad_to16(k2) * 8); }
+template <typename TR>
+int dm_p2pfm_prescale(dm_ctx* ctx, int B, int N2, int k2, const TR* Phi2, int ld2, const double* mass2, double* Xs) {
+    const int ldx = pad_to16(k2);
+    const long long n = (long long)(N2 + 1) * ldx;
+    DM_LAUNCH(ctx, "p2pfm_prescale", p2pfm_prescale_kernel<TR>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, ld2, k2, mass2, Xs, ldx);
+    return DM_OK;
+}
+template int dm_p2pfm_prescale<float>(dm_ctx*, int, int, int, const float*, int, const double*, double*);
+template int dm_p2pfm_prescale<double>(dm_ctx*, int, int, int, const double*, int, const double*, double*);
+
+// raw buffer descriptor over `bytes` bytes at p: loads beyond the range return 0 (no clamping arithmetic), addresses are
+// 32-bit offsets from a scalar base (one v_add per fragment instead of a 64-bit multiply-add: float64 matrix instructions do
+// not overlap with vector ALU work on this part, every address instruction in the loop is paid in full)
+typedef __amdgpu_buffer_rsrc_t p2pfm_rsrc_t;
+__device__ __forceinline__ p2pfm_rsrc_t p2pfm_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ T p2pfm_bload(p2pfm_rsrc_t rsrc, int voff);
+template <> __device__ __forceinline__ double p2pfm_bload<double>(p2pfm_rsrc_t rsrc, int voff) {
+    typedef int i32x2_t __attribute__((ext_vector_type(2)));
+    const i32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
+    return __hiloint2double(v[1], v[0]);
+}
+template <> __device__ __forceinline__ float p2pfm_bload<float>(p2pfm_rsrc_t rsrc, int voff) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+}
 
 // RBW x CBW blocks per wave, exactly (no guard between the matrix instructions).  Where the blocks do not divide evenly the LAST
 // group of row / column blocks starts early and overlaps its neighbour: the shared blocks are computed twice, by the same
 // arithmetic in the same order, and stored twice with identical bits (a 16 x 16 block per 13 costs less than a branch per MFMA).
 template <typename TR, int RBW, int CBW, int S>
 __global__ __launch_bounds__(64 * S, 2) void p2pfm_direct_kernel(p2pfm_args<TR> a) {
-    __shared__ double red[2][S][64 * 4];                      // one 16 x 16 block of every wave, double-buffered
+    // dynamic LDS: first every wave's slice of the gather indices (S x rps ints), then, for the reduction, one 16 x 16 block of
+    // every wave, double-buffered (2 x S x 256 doubles)
+    extern __shared__ __attribute__((aligned(16))) double p2pfm_sm[];
     const int T = a.TM * a.TC;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int b = xcd + 8 * (slot / T);
@@ -84,17 +129,17 @@ __global__ __launch_bounds__(64 * S, 2) void p2pfm_direct_kernel(p2pfm_args<TR> 
     const int nrb = dm_cdiv(a.k2, 16), ncb = dm_cdiv(a.k1, 16);
     const int mb0 = max(0, min(tm * RBW, nrb - RBW)), cb0 = max(0, min(tc * CBW, ncb - CBW));
 
-    const TR* __restrict__ X = a.Phi2 + (long long)b * a.s2;
-    const TR* __restrict__ Y = a.Phi1 + (long long)b * a.s1;
+    const p2pfm_rsrc_t rx = p2pfm_rsrc(a.Xs + (long long)b * a.sx, (unsigned)((long long)(a.N2 + 1) * a.ldx * 8));
+    const p2pfm_rsrc_t ry = p2pfm_rsrc(a.Phi1 + (long long)b * a.s1, (unsigned)((long long)a.N1 * a.ld1 * sizeof(TR)));
     const int32_t* __restrict__ idx = a.p21 + (long long)b * a.N2;
-    const double* __restrict__ msc = a.mass2 + (long long)b * a.N2;
-    // element offsets of this lane's column inside a row, clamped into the row (columns beyond the map only feed result
-    // entries that are not stored; they must not read past the array)
-    int colA[RBW], colB[CBW];
-#pragma unroll
-    for (int r = 0; r < RBW; ++r) colA[r] = min((mb0 + r) * 16 + l15, a.ld2 - 1);
-#pragma unroll
-    for (int c = 0; c < CBW; ++c) colB[c] = min((cb0 + c) * 16 + l15, a.ld1 - 1);
+    int* ip = reinterpret_cast<int*>(p2pfm_sm) + wave * a.rps;      // this wave's gather indices, clamped (an index load inside the
+                                                                    // loop shares the counter of the operand loads: the compiler drained
+                                                                    // the whole queue for it at the top of every iteration)
+    // byte offsets of this lane's first column inside a row; the other blocks sit at compile-time distances (16 columns).
+    // Rows of Xs are ldx >= 16 nrb wide; a column of Phi1 beyond its row feeds only result entries that are not stored, a read
+    // beyond the array returns 0.
+    const int cax = (mb0 * 16 + l15) * 8, cby = (cb0 * 16 + l15) * (int)sizeof(TR);
+    const int xstep = a.ldx * 8, ystep = a.ld1 * (int)sizeof(TR);
 
     f64x4 acc[RBW][CBW];
 #pragma unroll
@@ -103,81 +148,79 @@ __global__ __launch_bounds__(64 * S, 2) void p2pfm_direct_kernel(p2pfm_args<TR> 
         for (int c = 0; c < CBW; ++c) acc[r][c] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     const int nb = wave * a.rps, ne = min(a.N2, nb + a.rps);
-    const int nks = ne > nb ? (ne - nb + 3) >> 2 : 0;
-    // k-step t covers vertices nb + 4 t + g.  Per step and lane: the gather index and the mass of its vertex (fetched two
-    // steps ahead), one entry of each A block and of each B block (one step ahead).  A vertex beyond the slice gets mass 0
-    // and the addresses of the last valid vertex.
-    TR fa0[RBW], fb0[CBW], fa1[RBW], fb1[CBW], fa2[RBW], fb2[CBW];
-    int pr0 = 0, pr1 = 0, pr2 = 0;                // gather indices as loaded (steps = 0 / 1 / 2 mod 3), clamped where they are used
-    double ma0 = 0.0, ma1 = 0.0, ma2 = 0.0;       // masses of the steps whose operands are in set 0 / 1 / 2
-#define PF_IDX(t_, p_) { p_ = idx[min(nb + 4 * (t_) + g, a.N2 - 1)]; }
-#define PF_LOAD(t_, p_, fa_, fb_, ma_)                                             \
+    int nks = ne > nb ? (ne - nb + 3) >> 2 : 0;
+    if (a.dbg & 64) nks = min(nks, 3);
+    const int tstep = (a.dbg & 128) ? 0 : 4;
+    // k-step t covers vertices n = nb + 4 t + g.  Per step and lane: the gather index of its vertex (requested three steps
+    // ahead), one entry of each A block and of each B block (two steps ahead).  A vertex beyond the slice reads the zero row
+    // of Xs and the gather index of the last vertex: it adds exact zeros.
+    double fa0[RBW], fa1[RBW], fa2[RBW];
+    TR fb0[CBW], fb1[CBW], fb2[CBW];
+    for (int q = lane; q < a.rps; q += 64) ip[q] = min(max(idx[min(nb + q, a.N2 - 1)], 0), a.N1 - 1);
+    __builtin_amdgcn_wave_barrier();
+    int pr0 = 0, pr1 = 0, pr2 = 0;                // gather indices of the steps = 0 / 1 / 2 mod 3
+#define PF_IDX(t_, p_) { p_ = ip[min(tstep * (t_) + g, a.rps - 1)]; }
+#define PF_LOAD(t_, p_, fa_, fb_)                                                  \
     {                                                                              \
-        const int n_ = min(nb + 4 * (t_) + g, a.N2 - 1);                           \
-        const TR* xr_ = X + (long long)n_ * a.ld2;                                 \
-        const TR* yr_ = Y + (long long)min(max(p_, 0), a.N1 - 1) * a.ld1;          \
-        _Pragma("unroll") for (int r = 0; r < RBW; ++r) fa_[r] = xr_[colA[r]];     \
-        _Pragma("unroll") for (int c = 0; c < CBW; ++c) fb_[c] = yr_[colB[c]];     \
-        ma_ = msc[n_];                                                             \
+        const int n_ = nb + tstep * (t_) + g;                                      \
+        const int xo_ = ((n_ < ne) ? n_ : a.N2) * xstep + cax;                     \
+        const int yo_ = p_ * ystep + cby;                                          \
+        _Pragma("unroll") for (int r = 0; r < RBW; ++r) fa_[r] = p2pfm_bload<double>(rx, xo_ + r * 128); \
+        _Pragma("unroll") for (int c = 0; c < CBW; ++c) fb_[c] = p2pfm_bload<TR>(ry, yo_ + c * 16 * (int)sizeof(TR)); \
     }
-#define PF_MASS(t_, m_) ((nb + 4 * (t_) + g < ne) ? (m_) : 0.0)
-#define PF_MMA(fa_, fb_, m_)                                                       \
+#define PF_MMA(fa_, fb_)                                                           \
     {                                                                              \
-        _Pragma("unroll") for (int c = 0; c < CBW; ++c) {                          \
-            const double y_ = (m_) * (double)fb_[c];                               \
+        _Pragma("unroll") for (int c = 0; c < CBW; ++c)                            \
             _Pragma("unroll") for (int r = 0; r < RBW; ++r)                        \
-                acc[r][c] = mfma_f64_16x16x4((double)fa_[r], y_, acc[r][c]);       \
-        }                                                                          \
+                acc[r][c] = mfma_f64_16x16x4(fa_[r], (double)fb_[c], acc[r][c]);   \
     }
-    // The loop body has no branch: steps beyond the slice load the (clamped) last vertex with mass 0 and add exact zeros, so the
-    // compiler can count the loads in flight (with a conditional fetch it waited vmcnt(0) -- for the operands it had only
-    // just requested -- in front of every group of matrix instructions).  Per half iteration: fetch the operands of the NEXT
-    // step (their gather index was requested two steps ago), request the index three steps ahead, then the matrix instructions
-    // of the current step.  A compiler-level memory barrier (an empty asm that clobbers memory) + a scheduling barrier follow
-    // every fetch: without the first the loads of read-only memory were sunk across the loop's back edge to their use (every
-    // group of matrix instructions then waited for operands requested just before it), without the second the matrix
-    // instructions were hoisted in front of the fetch.
+    // The loop body has no branch, so the compiler can count the loads in flight (with a conditional fetch it waited vmcnt(0)
+    // -- for the operands it had only just requested -- in front of every group of matrix instructions).  Per third of an
+    // iteration: fetch the operands two steps ahead (their gather index was requested three steps before them), then the matrix
+    // instructions of the current step.  A compiler-level memory barrier (an empty asm that clobbers memory) + a scheduling
+    // barrier follow every fetch: without the first the loads of read-only memory were sunk across the loop's back edge to their
+    // use, without the second the matrix instructions were hoisted in front of the fetch.
 #define PF_FENCE() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-    // THREE operand sets: the fetch of step t + 2 is issued before the matrix instructions of step t (one set ahead left
-    // 640 cycles between a request and its use: less than an L2 round trip under load).
     if (nks > 0) {
         PF_IDX(0, pr0)
         PF_IDX(1, pr1)
         PF_IDX(2, pr2)
-        PF_LOAD(0, pr0, fa0, fb0, ma0)
+        PF_LOAD(0, pr0, fa0, fb0)
         PF_IDX(3, pr0)
-        PF_LOAD(1, pr1, fa1, fb1, ma1)
+        PF_FENCE()                                // (the order of the loads in flight at the loop's entry = the order inside the loop:
+        PF_LOAD(1, pr1, fa1, fb1)                 //  the counted waits of the loop then allow two sets in flight)
         PF_IDX(4, pr1)
+        PF_FENCE()
         const int nks3 = (nks + 2) / 3 * 3;
         for (int t = 0; t < nks3; t += 3) {
-            PF_LOAD(t + 2, pr2, fa2, fb2, ma2)
+            PF_LOAD(t + 2, pr2, fa2, fb2)
             PF_IDX(t + 5, pr2)
             PF_FENCE()
-            PF_MMA(fa0, fb0, PF_MASS(t, ma0))
-            PF_LOAD(t + 3, pr0, fa0, fb0, ma0)
+            PF_MMA(fa0, fb0)
+            PF_LOAD(t + 3, pr0, fa0, fb0)
             PF_IDX(t + 6, pr0)
             PF_FENCE()
-            PF_MMA(fa1, fb1, PF_MASS(t + 1, ma1))
-            PF_LOAD(t + 4, pr1, fa1, fb1, ma1)
+            PF_MMA(fa1, fb1)
+            PF_LOAD(t + 4, pr1, fa1, fb1)
             PF_IDX(t + 7, pr1)
             PF_FENCE()
-            PF_MMA(fa2, fb2, PF_MASS(t + 2, ma2))
+            PF_MMA(fa2, fb2)
         }
     }
-#undef PF_MASS
 #undef PF_FENCE
 #undef PF_MMA
 #undef PF_LOAD
 #undef PF_IDX
+    if (a.dbg & 32) { double z = 0.0; _Pragma("unroll") for (int r = 0; r < RBW; ++r) _Pragma("unroll") for (int c = 0; c < CBW; ++c) z += acc[r][c][0] + acc[r][c][3]; if (z == 1.2345) a.C[0] = z; return; }
     // the S slices of every block, added in ascending slice order by wave (block number % S)
+    __syncthreads();                                          // (the reduction buffers overlay the index slices)
     double* Cb = a.C + (long long)b * a.strideC;
 #pragma unroll
     for (int r = 0; r < RBW; ++r)
 #pragma unroll
         for (int c = 0; c < CBW; ++c) {
-            constexpr int dummy = 0; (void)dummy;
             const int blk = r * CBW + c;
-            double* buf = &red[blk & 1][0][0];
+            double* buf = p2pfm_sm + (blk & 1) * (S * 256);
             *reinterpret_cast<f64x4*>(buf + (wave * 64 + lane) * 4) = acc[r][c];
             __syncthreads();
             if (wave == blk % S) {
@@ -199,34 +242,54 @@ __global__ __launch_bounds__(64 * S, 2) void p2pfm_direct_kernel(p2pfm_args<TR> 
 
 size_t dm_p2pfm_ws_bytes(int B, int N2, int k1, int k2) {
     const int nsplit = fm_split(B, N2, k1, k2);
-    return nsplit > 1 ? dm_align_up((size_t)nsplit * B * k2 * k1 * 8) + 4096 : 4096;
+    return (nsplit > 1 ? dm_align_up((size_t)nsplit * B * k2 * k1 * 8) + 4096 : 4096) + dm_p2pfm_xs_bytes(B, N2, k2) + 4096;
 }
 
 template <typename TR, int RBW, int CBW, int S>
 static int p2pfm_launch(dm_ctx* ctx, const p2pfm_args<TR>& a, int grid) {
-    DM_LAUNCH(ctx, "p2pfm_tn_f64", (p2pfm_direct_kernel<TR, RBW, CBW, S>), dim3(grid), dim3(64 * S), 0, a);
+    const size_t red = (size_t)2 * S * 256 * 8, ind = (size_t)S * a.rps * 4;
+    DM_LAUNCH(ctx, "p2pfm_tn_f64", (p2pfm_direct_kernel<TR, RBW, CBW, S>), dim3(grid), dim3(64 * S), red > ind ? red : ind, a);
     return DM_OK;
 }
+// Xs: mass2 * Phi2 as dm_p2pfm_prescale builds it for ldx / 16 blocks of columns (>= ceil(k2 / 16)); null: built here
 template <typename TR>
 static int launch_p2pfm_direct(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
-                               int ld1, const TR* Phi2, int ld2, const double* mass2, double* C, int ldc, long long strideC) {
+                               int ld1, const TR* Phi2, int ld2, const double* mass2, double* C, int ldc, long long strideC,
+                               const double* Xs, int ldx) {
+    if (!Xs) {
+        double* buf = (double*)dm_ws_take(ctx, dm_p2pfm_xs_bytes(B, N2, k2));
+        if (!buf) return dm_fail(ctx, DM_ENOMEM, "p2p_to_fm: workspace not reserved");
+        int rc = dm_p2pfm_prescale<TR>(ctx, B, N2, k2, Phi2, ld2, mass2, buf);
+        if (rc) return rc;
+        Xs = buf; ldx = pad_to16(k2);
+    }
     const int nrb = dm_cdiv(k2, 16), ncb = dm_cdiv(k1, 16);
+    // The K-slicing fixes the summation order of every entry: it depends on the sizes only, never on the batch.
+    // Small maps (at most 7 x 7 blocks, k <= 112): 1 row block x all column blocks per wave, 8 slices (more, lighter waves);
+    // else 2 row blocks x up to 5 column blocks, 4 slices.
     const bool small = nrb <= 7 && ncb <= 7;
-    const int RBW = small ? 1 : 2, S = small ? 8 : 4;
+    const int knob = dm_knob("DM_P2PFM_SHAPE", 0);         // experiments: 1 = 8 slices for every size, 2 = one row block per wave for every size, 4 = at most 5 column blocks with two row blocks
+    const bool two = !small && !(knob & 2);
+    const bool s8 = small || (knob & 1);
+    const int S = s8 ? 8 : 4;
     p2pfm_args<TR> a;
     a.Phi1 = Phi1; a.s1 = (long long)N1 * ld1; a.ld1 = ld1; a.N1 = N1;
-    a.Phi2 = Phi2; a.s2 = (long long)N2 * ld2; a.ld2 = ld2; a.N2 = N2;
-    a.p21 = p21; a.mass2 = mass2; a.k1 = k1; a.k2 = k2; a.C = C; a.ldc = ldc; a.strideC = strideC; a.B = B;
-    a.TM = dm_cdiv(nrb, RBW);
-    a.TC = dm_cdiv(ncb, small ? 7 : 5);        // (2 x 6 and 2 x 7 blocks per wave do not fit 256 registers with the next step's operands in flight)
+    a.Xs = Xs; a.sx = (long long)(N2 + 1) * ldx; a.ldx = ldx; a.N2 = N2;
+    a.p21 = p21; a.k1 = k1; a.k2 = k2; a.C = C; a.ldc = ldc; a.strideC = strideC; a.B = B;
+    a.dbg = dm_knob("DM_ZO_DEBUG", 0);
+    a.TM = dm_cdiv(nrb, two ? 2 : 1);
+    a.TC = dm_cdiv(ncb, (two && (knob & 4)) ? 5 : 7);
     const int CBW = dm_cdiv(ncb, a.TC);
     a.rps = dm_cdiv(dm_cdiv(N2, S), 4) * 4;
     const int grid = a.TM * a.TC * dm_cdiv(B, 8) * 8;
-#define P2PFM_CASE(C_) case C_: return small ? p2pfm_launch<TR, 1, C_, 8>(ctx, a, grid) : p2pfm_launch<TR, 2, C_, 4>(ctx, a, grid);
+#ifdef DM_EXPERIMENTS
+#define P2PFM_CASE(C_) case C_: return two ? (s8 ? p2pfm_launch<TR, 2, C_, 8>(ctx, a, grid) : p2pfm_launch<TR, 2, C_, 4>(ctx, a, grid)) \
+                                            : (s8 ? p2pfm_launch<TR, 1, C_, 8>(ctx, a, grid) : p2pfm_launch<TR, 1, C_, 4>(ctx, a, grid));
+#else
+#define P2PFM_CASE(C_) case C_: return two ? p2pfm_launch<TR, 2, C_, 4>(ctx, a, grid) : p2pfm_launch<TR, 1, C_, 8>(ctx, a, grid);
+#endif
     switch (CBW) {
-        P2PFM_CASE(1) P2PFM_CASE(2) P2PFM_CASE(3) P2PFM_CASE(4) P2PFM_CASE(5)
-        case 6: return p2pfm_launch<TR, 1, 6, 8>(ctx, a, grid);
-        case 7: return p2pfm_launch<TR, 1, 7, 8>(ctx, a, grid);
+        P2PFM_CASE(1) P2PFM_CASE(2) P2PFM_CASE(3) P2PFM_CASE(4) P2PFM_CASE(5) P2PFM_CASE(6) P2PFM_CASE(7)
         default: return dm_fail(ctx, DM_EINVAL, "p2p_to_fm: bad tile width %d", CBW);
     }
 #undef P2PFM_CASE
@@ -235,9 +298,10 @@ static int launch_p2pfm_direct(dm_ctx* ctx, int B, int N1, int N2, int k1, int k
 template <typename TR>
 int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
                         int ld1, const TR* Phi2, int ld2, const double* mass2, double* C, int ldc,
-                        long long strideC) {
-    if (ctx->opt_p2pfm_direct)
-        return launch_p2pfm_direct<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, mass2, C, ldc, strideC);
+                        long long strideC, const double* Xs, int ldx) {
+    // (arrays of 4 GiB or more per pair would not fit the 32-bit offsets of the direct kernel)
+    if (ctx->opt_p2pfm_direct && (long long)N1 * ld1 * 8 < (1LL << 31) && (long long)(N2 + 1) * pad_to16(k2) * 8 < (1LL << 31) && N2 <= 15000)
+        return launch_p2pfm_direct<TR>(ctx, B, N1, N2, k1, k2, p21, Phi1, ld1, Phi2, ld2, mass2, C, ldc, strideC, Xs, ldx);
     const int nsplit = fm_split(B, N2, k1, k2);
     const int kchunk = FM_KCHUNK;
     double* partial = nullptr;
@@ -259,9 +323,9 @@ int dm_launch_p2p_to_fm(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, cons
     return DM_OK;
 }
 template int dm_launch_p2p_to_fm<float>(dm_ctx*, int, int, int, int, int, const int32_t*, const float*, int, const float*, int,
-                                        const double*, double*, int, long long);
+                                        const double*, double*, int, long long, const double*, int);
 template int dm_launch_p2p_to_fm<double>(dm_ctx*, int, int, int, int, int, const int32_t*, const double*, int, const double*, int,
-                                         const double*, double*, int, long long);
+                                         const double*, double*, int, long long, const double*, int);
 
 template <typename TR>
 static int p2p_to_fm_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const int32_t* p21, const TR* Phi1,
@@ -311,7 +375,7 @@ static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, in
     const size_t need = dm_align_up((size_t)B * N2 * 8) + dm_align_up(bytes_Fx) + dm_align_up(bytes_Fy) + 2 * dm_align_up(bytes_C) +
                         dm_align_up((size_t)B * R1 * 4) + dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N1 * Kpad * 8) +
                         dm_align_up((size_t)B * N2 * 4) + dm_align_up((size_t)B * ZO_NCH * 8) + dm_align_up(bytes_zero) +
-                        dm_simnn_ws_bytes(B, N2, N1, 0) + 65536;
+                        dm_simnn_ws_bytes(B, N2, N1, 0) + dm_p2pfm_xs_bytes(B, N2, kf) + 65536;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     const double* mass2 = nullptr;
@@ -348,6 +412,11 @@ static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, in
     rc = dm_fm_split_build_rows<TR>(ctx, B, N2, kf, Phi2, ld2, amaxT, ZO_NCH, ldT, Fx, R2);
     if (rc) return rc;
     rc = dm_zo_copy_mat(ctx, B, k0, k0, C0, k0, (long long)k0 * k0, Ca, Kpad, (long long)Kpad * Kpad);
+    if (rc) return rc;
+    // mass2 * Phi2 for p2p_to_FM, once for the full width (a smaller map reads its first blocks of columns)
+    double* Xs = (double*)dm_ws_take(ctx, dm_p2pfm_xs_bytes(B, N2, kf));
+    if (!Xs) return dm_fail(ctx, DM_ENOMEM, "zoomout: workspace not reserved");
+    rc = dm_p2pfm_prescale<TR>(ctx, B, N2, kf, Phi2, ld2, mass2, Xs);
     if (rc) return rc;
     const size_t ws_mark = ctx->ws_off;
 
@@ -397,7 +466,7 @@ static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, in
         if (rc) return rc;
         if (last) break;
         const int kn = k + step;
-        rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, kn, kn, p21, Phi1, ld1, Phi2, ld2, mass2, nxt, Kpad, (long long)Kpad * Kpad);
+        rc = dm_launch_p2p_to_fm<TR>(ctx, B, N1, N2, kn, kn, p21, Phi1, ld1, Phi2, ld2, mass2, nxt, Kpad, (long long)Kpad * Kpad, Xs, Kpad);
         if (rc) return rc;
         double* tmp = cur; cur = nxt; nxt = tmp;
         k = kn;

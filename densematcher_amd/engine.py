@@ -105,6 +105,13 @@ class MatchEngine:
         pass in both directions (bench.py names its dominant kernel accordingly)."""
         return int(self.lib.dm_fm_to_p2p_uses_split(self.ctx, int(N2), int(N1), int(k)))
 
+    def last_requeued_rows(self):
+        """rows of the last fm_to_p2p / simnn call that took the exact float64 path, per reduction (knn21, ind21, knn12, ind12;
+        -1: not applicable) -- include/densematch.h: dm_last_requeued_rows"""
+        out = (C.c_int * 4)()
+        self._chk(self.lib.dm_last_requeued_rows(self.ctx, out))
+        return [int(x) for x in out]
+
     def workspace_bytes(self):
         return int(self.lib.dm_workspace_bytes(self.ctx))
 
@@ -438,6 +445,12 @@ class MatchEngine:
             mass[b, :nb] = masses[b]
             if nb < N:
                 vals[b, nb:, 0] = float(abs(Lm).sum(axis=1).max())
+        nmin = min(a.shape[0] for a in masses)
+        if 2 * (k + guard) > nmin:
+            # (measured: with the wanted range reaching into the upper half of a spectrum the filtered block loses rank and the
+            #  Ritz step returns spurious zero pairs whose residual looks converged -- refuse instead of returning them)
+            raise ValueError(f"eigenbasis: k + guard = {k + guard} vectors need a mesh of at least {2 * (k + guard)} vertices "
+                             f"(the smallest has {nmin}): the subspace iteration resolves the lower half of a spectrum")
         m = min(k + guard, N)
         g = torch.Generator(device=self.device).manual_seed(seed)
         X = torch.randn((B, N, m), dtype=torch.float64, device=self.device, generator=g)

@@ -164,8 +164,9 @@ class TriMesh:
                 mesh.process(k, robust=robust, verbose=verbose)
             else:
                 todo.append((mesh, k))
-        # one batched call pads the smaller meshes with decoupled vertices at the top of their spectrum; that needs the wanted
-        # range (plus the solver's guard vectors) to stay in the lower half of every mesh's spectrum, else: one by one
+        # one batched call pads the smaller meshes with decoupled vertices at the top of their spectrum and solves all meshes
+        # for the largest k; when that k (plus the solver's guard vectors) would leave the lower half of the smallest mesh's
+        # spectrum the meshes are solved one by one, each with its own k
         if len(todo) == 1 or (todo and 2 * (max(m._n_eigs(k) for m, k in todo) + 32) > min(m.n_vertices for m, k in todo)):
             for mesh, k in todo:
                 mesh.process(k, robust=robust, verbose=verbose)

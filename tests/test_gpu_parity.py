@@ -798,17 +798,16 @@ def test_eigenbasis_against_dense_eigh(eng, nu, nv, k):
         assert np.abs(P.T @ P - np.eye(cut)).max() <= 1e-7
 
 
-@pytest.mark.parametrize("small", [(16, 12), (28, 25)])
-def test_eigenbasis_small_mesh_beside_a_large_one(eng, small):
+def test_eigenbasis_small_mesh_beside_a_large_one(eng):
     """TriMesh.process_many on meshes of different vertex counts.  N = 700 beside 1200, k = 128: one batched call, the
     small mesh padded with decoupled vertices at the Gershgorin bound of its own operator (the top of the damped interval; the
-    largest diagonal entry used before ranks near the middle of the spectrum).  N = 192 beside 1200, k = 128 > N / 2: the wanted
-    range reaches into the upper half of the small mesh's spectrum, process_many solves the meshes one by one."""
+    largest diagonal entry used before ranks near the middle of the spectrum).  N = 192, k = 128 > N / 2: the subspace iteration
+    cannot resolve the upper half of a spectrum -- it must say so instead of returning spurious pairs."""
     import scipy.linalg
     from densematcher_amd import synth
     from densematcher_amd.pyFM.mesh import TriMesh
     k = 128
-    meshes = [TriMesh(*synth.torus_mesh(*small)), TriMesh(*synth.torus_mesh(40, 30, perturb=0.05, seed=2))]
+    meshes = [TriMesh(*synth.torus_mesh(28, 25)), TriMesh(*synth.torus_mesh(40, 30, perturb=0.05, seed=2))]
     TriMesh.process_many(meshes, [k, k])
     for m in meshes:
         n = m.n_vertices
@@ -820,6 +819,8 @@ def test_eigenbasis_small_mesh_beside_a_large_one(eng, small):
         assert np.abs(G - np.eye(k)).max() <= 1e-6, n
         R = m.W @ m.eigenvectors - (a[:, None] * m.eigenvectors) * m.eigenvalues[None, :]
         assert np.abs(R).max() <= 1e-5 * w[k - 1], n
+    with pytest.raises(ValueError, match="lower half"):
+        TriMesh.process_many([TriMesh(*synth.torus_mesh(16, 12)), TriMesh(*synth.torus_mesh(40, 30, perturb=0.05, seed=2))], [k, k])
 
 
 def test_maps_on_gpu_eigenbasis_match_maps_on_host_eigenbasis(eng):

@@ -26,7 +26,11 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     cmd = " ".join(sys.argv[4:]) or "python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     lines = [f"# rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separate pass, --pmc WRITE_SIZE) -- {cmd}",
+             f"# csrc_sha16: {bench.csrc_sha16()}",
              "# raw counters are KB per dispatch; on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream "
              "(MI355X_MICROARCH.md, HBM) -> fetch_MB_corrected = 2 x raw",
              "kernel,dispatches,FETCH_SIZE_KB_avg,fetch_MB_corrected,WRITE_SIZE_KB_avg,write_MB"]
