@@ -106,6 +106,52 @@ __device__ __forceinline__ int fresh_lane() {
     return l;
 }
 
+// Squared row norms for the exactness bound, written right behind the tile loop that accumulated them (the tiles of source
+// tile column 0 / target tile row 0): |t_i|^2 per target row and max_j |s_j|^2 per pair (row direction), and, for a pass in both
+// directions (COLS), |s_j|^2 per source row and max_i |t_i|^2.  Kept out of the key epilogues: six more live registers there
+// were spilled to scratch, and every scratch reload waits vmcnt(0) -- for the whole LDS-DMA queue of the next tile.
+// maximum over the 16 lanes of a DPP row, on the vector ALU (a __shfl needs the lane id: the compiler kept the kernel's own copy of
+// it alive across the whole tile loop for that, in scratch).  The four row leaders of a wave then issue one atomic each.
+__device__ __forceinline__ float row16_max(float m) {
+    m = fmaxf(m, __int_as_float(dpp_i32<0xB1>(__float_as_int(m))));
+    m = fmaxf(m, __int_as_float(dpp_i32<0x4E>(__float_as_int(m))));
+    m = fmaxf(m, __int_as_float(dpp_i32<0x141>(__float_as_int(m))));
+    m = fmaxf(m, __int_as_float(dpp_i32<0x140>(__float_as_int(m))));
+    return m;
+}
+template <bool COLS, int TB>
+__device__ __forceinline__ void simnn_norms(const simnn_params& p, float (&nrm_t)[TB], float (&nrm_s)[4], bool do_tn, bool do_sn,
+                                            int b, int i0, int j0, int wsrc, int wtgt) {
+    const int lane = fresh_lane();
+    const int hi = lane >> 5;
+    if (do_tn) {
+        float m = 0.f;
+#pragma unroll
+        for (int x = 0; x < TB; ++x) {
+            const float v = nrm_t[x] + xhalf(nrm_t[x], hi != 0);
+            const int gi = i0 + wtgt * (32 * TB) + x * 32 + (lane & 31);
+            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
+            m = fmaxf(m, v);                             // (rows beyond N2 are zero rows of padded operands)
+        }
+        if (COLS) {
+            m = row16_max(m);
+            if ((lane & 15) == 0) atomicMax(p.tmax2 + b, __float_as_uint(m));
+        }
+    }
+    if (do_sn) {
+        float m = 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = nrm_s[x] + xhalf(nrm_s[x], hi != 0);
+            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
+            if (gj < p.N1) m = fmaxf(m, v);
+            if (COLS && lane < 32 && gj < p.N1) p.snorm2[(long long)b * p.N1 + gj] = v;
+        }
+        m = row16_max(m);
+        if ((lane & 15) == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
+    }
+}
+
 // Shared epilogue: row norms and, per wave, the top-2 of every target row over the wave's 128 source rows.  Each wave writes
 // its own partial (no exchange between the two source halves of a tile: no LDS scratch, no barrier in the epilogue); the
 // merge kernel reduces the 2 tilesS partials of a row.
@@ -126,26 +172,7 @@ __device__ __forceinline__ void simnn_tail(const simnn_params& p, f32x16 (&acc)[
     (void)lane_;
     const int lane = fresh_lane();
     const int hi = lane >> 5;
-    if (do_tn) {
-#pragma unroll
-        for (int x = 0; x < TB; ++x) {
-            const float v = nrm_t[x] + xhalf(nrm_t[x], hi != 0);
-            const int gi = i0 + wtgt * (32 * TB) + x * 32 + (lane & 31);
-            if (lane < 32 && gi < p.N2) p.tnorm2[(long long)b * p.N2 + gi] = v;
-        }
-    }
-    if (do_sn) {
-        float m = 0.f;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float v = nrm_s[x] + xhalf(nrm_s[x], hi != 0);
-            const int gj = j0 + wsrc * 128 + x * 32 + (lane & 31);
-            if (gj < p.N1) m = fmaxf(m, v);
-        }
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if (lane == 0) atomicMax(p.smax2 + b, __float_as_uint(m));
-    }
+    (void)nrm_t; (void)nrm_s; (void)do_tn; (void)do_sn;      // (the row norms leave the kernel in simnn_norms, right behind the tile loop)
 
     constexpr int NKIND = (DUAL && DUAL != 4) ? 2 : 1;       // DUAL 4: key A alone (score + bias[j])
 #pragma unroll
@@ -224,22 +251,7 @@ __device__ __forceinline__ void simnn_tail_cols(const simnn_params& p, f32x16 (&
                                                 const float* bT, int lane_, int wsrc, int wtgt) {
     const int lane = fresh_lane();
     const int hi = lane >> 5, l31 = lane & 31;
-    if (do_sn) {                                          // |s_j|^2 of the tile's source rows (tiles of target tile row 0)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const float v = nrm_s[x] + xhalf(nrm_s[x], hi != 0);
-            if (lane < 32 && (FULL || j0 + wsrc * 128 + x * 32 + lane < p.N1))
-                p.snorm2[(long long)b * p.N1 + j0 + wsrc * 128 + x * 32 + lane] = v;
-        }
-    }
-    if (do_tn) {                                          // max_i |t_i|^2 (tiles of source tile column 0)
-        float m = 0.f;
-#pragma unroll
-        for (int x = 0; x < TB; ++x) m = fmaxf(m, nrm_t[x] + xhalf(nrm_t[x], hi != 0));
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if (lane == 0) atomicMax(p.tmax2 + b, __float_as_uint(m));
-    }
+    (void)nrm_t; (void)nrm_s; (void)do_tn; (void)do_sn;
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const int gj = j0 + wsrc * 128 + st * 32 + l31;  // this lane's source row
@@ -406,6 +418,7 @@ __global__ __launch_bounds__(512, 2) void simnn_edge_kernel(simnn_params p) {
     }
 #undef SIMNN_FETCH
 #undef SIMNN_STASH
+    simnn_norms<false, 2>(p, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, wsrc, wtgt);
     simnn_tail<false, ST>(p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, lane, wsrc, wtgt);
 }
 
@@ -450,7 +463,7 @@ constexpr int SIMNN_PRODUCT_XV = 64;
 constexpr int SIMNN_PRODUCT_WT = 4;
 #define DM_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | ((((n) >> 4) & 3) << 14))    /* vmcnt(n) lgkmcnt(0) */
 static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
-    const int TT = 64 * WT, NBUF = WT == 4 ? 4 : 3;
+    const int TT = 64 * WT, NBUF = dual == -2 ? 5 : (WT == 4 ? 4 : 3);     // (-2: the five-slot ring of the one-key kernel)
     // ring | DUAL: two slots of (256 bias + 256 scale [+ TT target bias]) floats | DUAL 3, 8 waves: the eighth wave's transpose
     // buffer (the other seven use the ring slot that is free during an epilogue)
     size_t n = (size_t)NBUF * (TT + ST) * PBK * sizeof(_Float16);
@@ -493,12 +506,14 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     constexpr int TT = 64 * WT;                  // target rows per tile
     constexpr int NWT = TT / (32 * TB);          // waves along the target rows
     constexpr int NW = 2 * NWT;                  // waves
-    constexpr int NBUF = WT == 4 ? 4 : 3;        // ring depth
+    constexpr bool EARLY = (XV & 2048) != 0;     // five-slot ring, barrier at the END of a stage (see SIMNN_STAGE)
+    static_assert(!EARLY || (DUAL == 0 && WT == 4 && TB == 2), "the five-slot ring fills the LDS: one-key kernel, 8 waves");
+    constexpr int NBUF = EARLY ? 5 : (WT == 4 ? 4 : 3);   // ring depth
     constexpr int PD = NBUF - 1;                 // stages the DMA runs ahead
     constexpr int PSTAGE = (TT + ST) * PBK;      // halves per ring slot: T image then S image
     constexpr int NSI = 16 / NW;                 // DMA instructions per wave and stage for S ...
     constexpr int NTI = TT / 16 / NW;            // ... and for T
-    constexpr int VM_STEADY = (PD - 2) * (NTI + NSI) + (NTI + NSI) / 2;   // loads that may stay in flight at the barrier
+    constexpr int VM_STEADY = EARLY ? 2 * (NTI + NSI) : (PD - 2) * (NTI + NSI) + (NTI + NSI) / 2;   // loads that may stay in flight at the barrier
     constexpr int dbg = XV & 15;
     constexpr int STAG = (XV >> 4) & 3;
     constexpr bool PINR = (XV & 64) != 0;
@@ -600,7 +615,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
 #pragma unroll
     for (int q = 0; q < PD; ++q) { SIMNN_DMA1(0) SIMNN_DMA1(1) SIMNN_DMA_NEXT() }
     {                                                                // vmcnt: stage 0 has landed; the others in flight
-        constexpr int n0 = (PD - 1) * (NTI + NSI);
+        constexpr int n0 = (EARLY ? PD - 2 : PD - 1) * (NTI + NSI);      // (EARLY: stages 0 and 1 have landed)
         __builtin_amdgcn_s_waitcnt(0x0F70 | (n0 & 15) | (((n0 >> 4) & 3) << 14));
     }
     __builtin_amdgcn_s_barrier();
@@ -669,7 +684,23 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
 #define SIMNN_STAGE(NORMS, DMA_, VM_, NEXT_, ZERO_, AFTER_EPI_)                                                        \
     {                                                                                                                  \
         const int n_slot = (r_slot + 1 == NBUF) ? 0 : r_slot + 1;                                                      \
-        if constexpr (!SPLIT) {                                                                                        \
+        if constexpr (EARLY) {                                                                                         \
+        /* Five slots, the DMA four stages ahead, ONE barrier at the END of the stage: it publishes stage g + 2, so the     \
+           first fragments of stage g + 1 are requested BEFORE it, under this stage's second k-step, and the first matrix   \
+           instructions behind the barrier have their operands in registers.  (Four slots: the barrier sat between the two  \
+           k-steps, every wave requested its next fragments in one burst right behind it and waited 350-470 cycles for      \
+           them at the end of the stage: profiles/r04_simnn_stage_timeline.txt.)  Slot of stage g + 4 = slot of g - 1: its   \
+           last readers finished (lgkmcnt(0)) before the barrier of stage g - 1. */                                        \
+        SIMNN_READ(fsb, ftb, r_slot, foff1)                                                                            \
+        if (DMA_) { SIMNN_DMA1(0) }                                                                                    \
+        SIMNN_PIN()                                                                                                    \
+        SIMNN_MMA(fsa, fta, NORMS, ZERO_)                                                                              \
+        if (NEXT_) { SIMNN_READ(fsa, fta, n_slot, foff0) }                                                             \
+        if (DMA_) { SIMNN_DMA1(1) }                                                                                    \
+        SIMNN_PIN()                                                                                                    \
+        SIMNN_MMA(fsb, ftb, NORMS, false)                                                                              \
+        SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
+        } else if constexpr (!SPLIT) {                                                                                 \
         SIMNN_STAMP(tq0)                                                                                               \
         if (!late) { SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } SIMNN_PIN() }                       \
         SIMNN_STAMP(tq1)                                                                                               \
@@ -736,10 +767,11 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     {                                                                                                                  \
         const int nsteady = (n + 1 < ntile) ? ns : ns - PD;          /* >= 2 (host: ns >= NBUF + 1) */                 \
         SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, true, true)                                                                \
-        if (PD == 3) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, true)                                                  \
-        for (int s = PD - 1; s < nsteady; ++s) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, false)                       \
+        if (PD >= 3) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, true)                                                  \
+        for (int s = (PD >= 3 ? 2 : 1); s < nsteady; ++s) SIMNN_STAGE(NORMS, 1, VM_STEADY, 1, false, false)            \
         if (n + 1 == ntile) {                                                                                          \
-            if (PD == 3) SIMNN_STAGE(NORMS, 0, NTI + NSI, 1, false, false)                                             \
+            if (EARLY) SIMNN_STAGE(NORMS, 0, NTI + NSI, 1, false, false)    /* (the barrier of stage g needs g + 2) */  \
+            if (PD >= 3) SIMNN_STAGE(NORMS, 0, EARLY ? 0 : NTI + NSI, 1, false, false)                                 \
             SIMNN_STAGE(NORMS, 0, 0, 1, false, false)                                                                  \
             SIMNN_STAGE(NORMS, 0, 0, 0, false, false)                                                                  \
         }                                                                                                              \
@@ -767,7 +799,12 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
 #pragma unroll
         for (int x = 0; x < TB; ++x) nrm_t[x] = 0.f;
 
-        if ((ts_ == 0 || tt_ == 0) && want_n) { SIMNN_TILE_LOOP(true) } else { SIMNN_TILE_LOOP(false) }
+        if ((ts_ == 0 || tt_ == 0) && want_n) {
+            SIMNN_TILE_LOOP(true)
+            simnn_norms<DUAL == 3, TB>(p, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, wsrc, wtgt);
+        } else {
+            SIMNN_TILE_LOOP(false)
+        }
 
         if ((dbg & 7) == 1 || (dbg & 7) == 7) {
             float sacc = 0.f;
@@ -1156,6 +1193,12 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 2, "simnn2_f16_mfma")
         } else {
 #ifdef DM_EXPERIMENTS
+        if (p.dbg == 0x20000) {         // five-slot ring, barrier at the end of the stage
+            const size_t lds5 = simnn_pipe_lds(4, -2);
+            rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<SIMNN_PRODUCT_XV + 2048, 4, 0>, lds5);
+            if (rc) return rc;
+            DM_LAUNCH(ctx, "simnn_f16_mfma", (simnn_pipe_kernel<SIMNN_PRODUCT_XV + 2048, 4, 0>), dim3(grid), dim3(512), lds5, p);
+        } else
         if (p.dbg == 0x10000) {         // stage timeline (tools/simnn_trace.py): the product variant + stamps, 8 waves
             static unsigned long long* trace_dev = nullptr;
             if (!trace_dev) DM_CHECK_HIP(ctx, hipMalloc((void**)&trace_dev, 8 * 256 * 8));
