@@ -74,6 +74,9 @@ def parse_args():
                     help="code path of the four maps (dm_set_option p2p_split): 0 float64 kernel, 1 two fp16 passes, 2 one pass in both "
                          "directions (3: its 4-wave shape); default: the library's")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (RCCL) and run the barrier / max-over-ranks through it even with ONE rank: "
+                         "the N > 1 branch of the timing code on a 1-GPU box (tests/test_gpu_shard.py)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal of the N > 1 path on a 1-GPU box: every rank uses cuda:0, gloo carries the barrier")
     return ap.parse_args()
@@ -377,7 +380,11 @@ def main():
         local_rank, backend = 0, "gloo"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -458,7 +465,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": w["cfg"], "pairs_per_gpu": B, "N": N, "D": D, "k": k,
                    "basis_dtype": str(host["Phi1"].dtype) if "Phi1" in host else None,
-                   "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective"},
+                   "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective",
+                   "process_group": (backend if dist is not None else None)},
         "roofline": roofline_block(dominant, models.get(dominant), launches, avg_ms, wl_tag, table, kernel_ms_per_step, launches_per_step, eng),
     }
 
@@ -598,10 +606,74 @@ def secondary_surface_map():
         with contextlib.redirect_stdout(buf):
             surface_map_workload(a)
         r = json.loads(buf.getvalue().strip().splitlines()[-1])
-        return {"value": r["value"], "unit": "calls/s (one pair at a time)", "ms_per_call": r["ms_per_step"], "stages_ms": r["stages_ms"], "fit": r["fit"],
-                "config": r["config"]}
+        out = {"value": r["value"], "unit": "calls/s (one pair at a time)", "ms_per_call": r["ms_per_step"], "stages_ms": r["stages_ms"], "fit": r["fit"],
+               "config": r["config"]}
     except Exception as e:       # informational block
         return {"error": repr(e)}
+    try:
+        out["batched"] = surface_map_batch_rate(64)
+    except Exception as e:
+        out["batched"] = {"error": repr(e)}
+    return out
+
+
+def surface_map_batch_rate(B):
+    """throughput of the documented call through compute_surface_map_batch: B raw pairs (N = 2048, D = 512, notebook parameters,
+    compute_extra=True) per call, every pair its own meshes and descriptors; one warm-up call, one timed call, stage times of the
+    timed one.  Host work inside the call (Laplacian assembly of 2 B meshes, as in the reference) is part of the figure."""
+    import warnings
+    import torch
+    from densematcher_amd import functional_map as fmod, synth
+    from densematcher_amd.engine import MatchEngine
+    from densematcher_amd.pyFM.mesh import TriMesh
+    w = WORKLOADS["surface_map"]
+    nu, nv, D, k = w["nu"], w["nv"], w["D"], w["k"]
+    m1, m2, F1s, F2s = [], [], [], []
+    for i in range(B):
+        v1, f1 = synth.torus_mesh(nu, nv, perturb=0.03, seed=3 + 2 * i)
+        v2, f2 = synth.torus_mesh(nu, nv, perturb=0.08, seed=4 + 2 * i)
+        F1, F2, _ = synth.feature_pair(nu * nv, nu * nv, D, 1000 + i, 2000 + i, sigma=0.5, perm="identity")
+        m1.append(_Duck(v1, f1)); m2.append(_Duck(v2, f2)); F1s.append(F1); F2s.append(F2)
+    stages = {}
+
+    def timed(name, fn):
+        def wrapper(*a, **kw):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = fn(*a, **kw)
+            torch.cuda.synchronize()
+            stages[name] = stages.get(name, 0.0) + time.perf_counter() - t0
+            return res
+        return wrapper
+    patched = [(TriMesh, "process_many", "eigenbases (2 B meshes: assembly on the host, one batched eigensolve)", True),
+               (MatchEngine, "fit_general", "fit (device L-BFGS over B maps)", False), (MatchEngine, "fm_to_p2p", "vertex maps (2 x 4 maps x B)", False),
+               (MatchEngine, "precise_map", "precise maps", False), (MatchEngine, "icp", "ICP (10 iterations)", False),
+               (MatchEngine, "mapped_indicator", "indicator matrices (2 B)", False),
+               (MatchEngine, "linear_sum_assignment", "linear assignment (3 B matrices, one launch)", False)]
+    saved = [(o, n, o.__dict__[n]) for o, n, _, _ in patched]
+    for o, n, label, static in patched:
+        fn = getattr(o, n)
+        setattr(o, n, staticmethod(timed(label, fn)) if static else timed(label, fn))
+    try:
+        times = []
+        for rep in range(2):
+            stages.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res = fmod.compute_surface_map_batch(m1, m2, F1s, F2s, n_ev=k, compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(NOTEBOOK_FIT))
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    finally:
+        for o, n, fn in saved:
+            setattr(o, n, fn)
+    fr = res[0][7].fit_result
+    return {"value": round(B / times[-1], 2), "unit": "mesh-pairs/s", "pairs_per_call": B, "s_per_call": round(times[-1], 3),
+            "stages_ms": {n: round(1e3 * v, 1) for n, v in stages.items()},
+            "fit_evaluations_of_the_batch": int(getattr(fr, "nfev", [0])[0]),
+            "note": "compute_surface_map_batch: the documented call (example.ipynb cell 11) for B raw pairs at once; every pair's 14-tuple equals the "
+                    "single call's (tests/test_gpu_api.py::test_compute_surface_map_batch_equals_single_calls)"}
 
 
 def roofline_block(kernel, model, launches, avg_ms, workload, table, kernel_ms_per_step, launches_per_step, eng):

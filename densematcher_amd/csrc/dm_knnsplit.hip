@@ -12,6 +12,8 @@
 //  2. every row whose (best - second) is inside twice the error bound is re-evaluated exactly: float64 products of
 //     the original operands, only over the 32-source blocks that the partials cannot rule out (dm_simnn_keep), lowest
 //     index on ties.
+//     (the split runs on hardware conversions, f64 -> f32 -> f16, dm_split.h: split2_hw -- a direct f64 -> f16 conversion is a
+//      ~30-instruction software routine and was most of the row builders' time; the residual stays inside the budget below)
 //     Bound, relative to |t_i| max_j |s_j| (>= |x~_i| |y~_j|): fp32 accumulation D (1 + 1/16) 2^-23 (dm_simnn_core)
 //     + for the split: dropped <xl, yl> <= 2^-22, two residuals <= 2^-22 each, fp16 subnormal floor <= 2 sqrt(K) 2^-25
 //     (computed from the depth K of the search, 25 % slack; about 2^-19 at K = 200), bias pieces 2^-32.
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     _Float16 h, l;
-                    split2(col[(long long)q * Npad] * sc, h, l);
+                    split2_hw(col[(long long)q * Npad] * sc, h, l);
                     o[q >> 3][q & 7] = h;
                     o[2 + (q >> 3)][q & 7] = l;
                 }
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     _Float16 h = (_Float16)0.0f, l = (_Float16)0.0f;
-                    if (r0 + q < K) split2(col[(long long)q * Npad] * sc, h, l);
+                    if (r0 + q < K) split2_hw(col[(long long)q * Npad] * sc, h, l);
                     o[q >> 3][q & 7] = h;
                     o[2 + (q >> 3)][q & 7] = l;
                 }
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     _Float16 h, l;
-                    split2(col[(long long)q * Npad] * sc, h, l);
+                    split2_hw(col[(long long)q * Npad] * sc, h, l);
                     const int e = 3 * q;                                  // target: (h, h, l)   source: (h, l, h)
                     o[e >> 3][e & 7] = h;
                     o[(e + 1) >> 3][(e + 1) & 7] = SRC ? l : h;
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
             } else {
                 for (int q = 0; r0 + q < K; ++q) {
                     _Float16 h, l;
-                    split2(col[(long long)q * Npad] * sc, h, l);
+                    split2_hw(col[(long long)q * Npad] * sc, h, l);
                     dst[3 * q] = h; dst[3 * q + 1] = SRC ? l : h; dst[3 * q + 2] = SRC ? h : l;
                 }
             }
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
             const float x = (float)((double)xin[u] * sx);             // exact (sx is a power of two); 0 beyond K
             h = (_Float16)x; l = (_Float16)(x - (float)h);
         } else {
-            split2((double)xin[u] * sx, h, l);
+            split2_hw((double)xin[u] * sx, h, l);
         }
         hv[u] = h; lv[u] = l;
     }

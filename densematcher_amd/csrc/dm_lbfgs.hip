@@ -238,12 +238,13 @@ __global__ __launch_bounds__(256) void lbfgs_advance_kernel(int n, lbfgs_opts o,
         const double ge = gt[e];
         xb[e] = xtb[e];
         gb[e] = ge;
-        gmax = fmax(gmax, fabs(ge));
+        gmax = (ge != ge) ? DM_INF_F64 : fmax(gmax, fabs(ge));    // (fmax drops a NaN: a NaN gradient must not read as "converged")
     }
     gmax = lb_block_max(gmax, sh);
     __syncthreads();
     int status = LB_RUN;
-    if (gmax <= o.pgtol) status = LB_GTOL;
+    if (!isfinite(ft) || !isfinite(gmax)) status = LB_LSFAIL;       // energy or gradient not finite at an accepted point: abnormal end
+    else if (gmax <= o.pgtol) status = LB_GTOL;
     else if (phase != PH_FIRST && (fold - ft) <= o.ftol * fmax(fmax(fabs(fold), fabs(ft)), 1.0)) status = LB_FTOL;
     else if (iter >= o.maxiter) status = LB_MAXITER;
     else if (nfev >= o.maxfun) status = LB_MAXFUN;

@@ -296,7 +296,7 @@ class MatchEngine:
     LBFGS_REFERENCE = {"maxcor": 10, "ftol": 2.220446049250313e-09, "gtol": 1e-5, "maxfun": 15000, "maxls": 20}
     LBFGS_STATUS = {0: "running", 1: "CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL", 2: "CONVERGENCE: REL_REDUCTION_OF_F <= FACTR*EPSMCH",
                     3: "STOP: TOTAL NO. of ITERATIONS REACHED LIMIT", 4: "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT",
-                    5: "ABNORMAL_TERMINATION_IN_LNSRCH"}
+                    5: "ABNORMAL_TERMINATION_IN_LNSRCH (or a non-finite energy / gradient)"}
 
     def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4):
         """FunctionalMapping.fit for any of the implemented energy terms, a whole batch at once (reference: L-BFGS-B through
@@ -372,6 +372,7 @@ class MatchEngine:
         info = torch.empty((B, 4), dtype=torch.int32, device=self.device)
         self._chk(self.lib.dm_lbfgs_result(self.ctx, B, n, m, _ptr(state), _ptr(xo), _ptr(fo), _ptr(info)))
         info = info.cpu().numpy()
+        info[:, 0] = np.where(info[:, 0] == 0, 4, info[:, 0])      # (the host loop ended at the evaluation limit: report it as such)
         res = types.SimpleNamespace(x=xo.cpu().numpy(), fun=fo.cpu().numpy(), status=info[:, 0].copy(), nit=info[:, 1].copy(),
                                     nfev=info[:, 2].copy(), message=[self.LBFGS_STATUS.get(int(q), "?") for q in info[:, 0]],
                                     success=bool(np.all((info[:, 0] == 1) | (info[:, 0] == 2))), evaluations=nev)

@@ -102,3 +102,124 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
         print("Hungarian for vanilla, precise and icp took", time.time() - start_s, "seconds")
     return (p2p_21, p2p_12, hungarian, hungarian_precise, p2p_21_icp, p2p_12_icp, hungarian_icp, model, model.mesh1, model.mesh2,
             p2p_21_adjoint, p2p_12_adjoint, p2p_21_icp_adjoint, p2p_12_icp_adjoint)
+
+
+def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_extra=False, optimizer="fmin_l_bfgs_b", descr_type="neural",
+                              maxiter=100000, optimize_p2p=False, fit_params=None):
+    """compute_surface_map for a list of mesh pairs: returns the list of the 14-tuples compute_surface_map returns, each equal to the
+    single call's (same kernels, and every kernel's result for a pair is independent of the batch it is in).  No counterpart in
+    the reference (it matches one pair per call, functional_map.py:9-81): this is its documented call with the batch dimension the
+    GPU path has everywhere -- one batched eigensolve for all 2 B meshes, one device L-BFGS over B maps, the 2 x 4 vertex maps,
+    precise maps and ICP of all pairs in one library call each, and all 3 B linear assignments side by side (one workgroup per
+    matrix; a single call leaves 253 of 256 CUs idle there).  Pairs are grouped by (vertex counts, face count of mesh 1): the
+    batched kernels take one size per call; a group of one runs the single call."""
+    import torch
+    from .engine import default_engine
+    from .pyFM.spectral.convert import MappedIndicator, _real_dtype
+    assert descr_type == "neural", "the batched call takes network descriptors (descr_type='neural')"
+    B = len(meshes1_t)
+    assert len(meshes2_t) == B and len(c1s) == B and len(c2s) == B
+    fit_params = dict(fit_params or {})
+    fit_params.pop("verbose", None)
+    timing = os.environ.get("TIMEIT", False)
+    if timing:
+        compute_extra = True
+    eng = default_engine()
+    models = []
+    for i in range(B):
+        m1 = TriMesh(_np(meshes1_t[i].verts_list()[0]), _np(meshes1_t[i].faces_list()[0]))
+        m2 = TriMesh(_np(meshes2_t[i].verts_list()[0]), _np(meshes2_t[i].faces_list()[0]))
+        model = FunctionalMapping(m1, m2, partial=False, optimizer=optimizer)
+        model.k1, model.k2 = n_ev, n_ev
+        model.descr1, model.descr2 = _np(c1s[i]), _np(c2s[i])
+        models.append(model)
+    # ---- eigenbases: every mesh of every pair in one batched solve (FunctionalMapping.preprocess: functional.py:300-301)
+    all_meshes = [m for model in models for m in (model.mesh1, model.mesh2)]
+    type(all_meshes[0]).process_many(all_meshes, [n_ev] * len(all_meshes), robust=True)
+    out = [None] * B
+    groups = {}
+    for i, model in enumerate(models):
+        key = (model.mesh1.n_vertices, model.mesh2.n_vertices, model.mesh1.facelist.shape[0], model.descr1.shape[1],
+               str(model.descr1.dtype), str(model.descr2.dtype))
+        groups.setdefault(key, []).append(i)
+    for key, idx in groups.items():
+        g = [models[i] for i in idx]
+        nb = len(g)
+        rdt = _real_dtype(g[0].mesh1.eigenvectors, g[0].mesh2.eigenvectors)
+        st = lambda f, dt: np.ascontiguousarray(np.stack([f(m) for m in g]), dtype=dt)
+        Phi1, Phi2 = st(lambda m: m.mesh1.eigenvectors[:, :n_ev], rdt), st(lambda m: m.mesh2.eigenvectors[:, :n_ev], rdt)
+        a1, a2 = st(lambda m: m.mesh1.A.diagonal(), rdt), st(lambda m: m.mesh2.A.diagonal(), rdt)
+        lam1, lam2 = st(lambda m: m.mesh1.eigenvalues[:n_ev], np.float64), st(lambda m: m.mesh2.eigenvalues[:n_ev], np.float64)
+        fdt = np.float16 if (g[0].descr1.dtype == np.float16 and g[0].descr2.dtype == np.float16) else np.float32
+        F1, F2 = st(lambda m: m.descr1, fdt), st(lambda m: m.descr2, fdt)
+        tdt = {np.float16: torch.float16, np.float32: torch.float32, np.float64: torch.float64}
+        # ---- fit (FunctionalMapping.fit: the fp32 view of the bases like the reference's fit, functional.py:412-413)
+        dev = {"Phi1": eng._dev(Phi1.astype(np.float32), torch.float32, "Phi1"), "Phi2": eng._dev(Phi2.astype(np.float32), torch.float32, "Phi2"),
+               "a1": eng._dev(a1.astype(np.float32), torch.float32, "a1"), "a2": eng._dev(a2.astype(np.float32), torch.float32, "a2"),
+               "lam1": eng._dev(lam1, torch.float64, "lam1"), "lam2": eng._dev(lam2, torch.float64, "lam2"),
+               "F1": eng._dev(F1, tdt[fdt], "F1"), "F2": eng._dev(F2, tdt[fdt], "F2")}
+        fp = dict(w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_p2p=0, w_stochastic=0, w_ent=0, w_range01=0, w_sumto1=0, optinit="zeros",
+                  maxiter=1000000, stopping="tight")
+        unknown = set(fit_params) - set(fp) - {"w_orient", "w_area", "w_conformal", "w_area_difference", "w_mumford_shah", "mumford_shah_var",
+                                               "w_eta_entropy", "orient_reversing", "device", "driver"}
+        if unknown:
+            raise TypeError(f"fit() got unexpected keyword arguments {sorted(unknown)}")
+        fp.update({k_: v for k_, v in fit_params.items() if k_ in fp})
+        if any(fit_params.get(n, 0) > 0 for n in ("w_orient", "w_area", "w_conformal", "w_area_difference", "w_mumford_shah", "w_eta_entropy")):
+            raise NotImplementedError("orientation / area / conformal / Mumford-Shah terms are not on the accelerated path; pass 0")
+        general = {n: fp[n] for n in ("w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1")}
+        if any(v > 0 for v in general.values()):
+            from .pyFM.functional import LBFGS_OPTIONS
+            x0 = np.stack([m.get_x0(optinit=fp["optinit"]) for m in g])
+            C0, res = eng.fit_general(dev, dict(w_descr=fp["w_descr"], w_lap=fp["w_lap"], **general), x0, maxiter=fp["maxiter"],
+                                      lbfgs_options=LBFGS_OPTIONS if fp["stopping"] == "tight" else None)
+            C0 = np.asarray(C0, dtype=np.float64)
+        else:
+            res = None
+            A = eng.project(dev["Phi1"], dev["a1"], dev["F1"])
+            Bm = eng.project(dev["Phi2"], dev["a2"], dev["F2"])
+            c00 = eng.c00(Phi1, Phi2, a1, a2)
+            C0 = eng.fmap_solve(A, Bm, dev["lam1"], dev["lam2"], c00, fp["w_descr"], fp["w_lap"], check=True).cpu().numpy()
+        # ---- vertex maps of the fitted map, precise map, ICP, vertex maps of the ICP map: one call each for the group
+        _, P1, P2, A1d = eng._reals(Phi1, Phi2, a1)
+        C0d = eng._dev(C0, torch.float64, "C")
+        maps0 = eng.fm_to_p2p(P1, P2, A1d, C0d)
+        M0 = eng.mapped_indicator(P1, P2, A1d, C0d) if compute_extra else None
+        prec = None
+        if compute_extra:
+            faces = np.ascontiguousarray(np.stack([m.mesh1.facelist for m in g]), dtype=np.int32)
+            prec = eng.precise_map(P1, P2, C0d, faces, dense=True)[2]
+        Ci, resid, info = eng.icp(P1, P2, C0d, nit=10, return_resid=True)
+        if int(info.max()) != 0:
+            raise np.linalg.LinAlgError("ICP: Phi2^T Phi2 is not positive definite")
+        if float(resid.max()) > 1e-8:
+            raise np.linalg.LinAlgError(f"ICP: polar iteration did not converge (|C^T C - I| = {float(resid.max()):.2e})")
+        mapsi = eng.fm_to_p2p(P1, P2, A1d, Ci)
+        Mi = eng.mapped_indicator(P1, P2, A1d, Ci)
+        # ---- every assignment of the group in one launch
+        mats = ([M0, prec] if compute_extra else []) + [Mi]
+        cols = eng.linear_sum_assignment(torch.cat(mats, dim=0), maximize=True).cpu().numpy().astype(np.int64)
+
+        def assignment(c):
+            rows = np.nonzero(c >= 0)[0]
+            return rows, c[rows]
+        h = {n: v.cpu().numpy().astype(np.int64) for n, v in maps0.items()}
+        hi = {n: v.cpu().numpy().astype(np.int64) for n, v in mapsi.items()}
+        Ci_h = Ci.cpu().numpy()
+        for q, i in enumerate(idx):
+            model = g[q]
+            model.FM = C0[q]
+            model._FM_icp = Ci_h[q]
+            model.FM_type = "icp"
+            model.eta = np.ones(model.mesh2.n_vertices)
+            if res is not None:
+                import types
+                model.fit_result = types.SimpleNamespace(nit=res.nit[q:q + 1], nfev=res.nfev[q:q + 1], fun=res.fun[q:q + 1],
+                                                         status=res.status[q:q + 1], message=res.message[q:q + 1])
+            model.mapped_indicator = MappedIndicator(eng, P1[q:q + 1], P2[q:q + 1], A1d[q:q + 1], Ci[q:q + 1], hi["ind21"][q], hi["ind12"][q])
+            hung = assignment(cols[q]) if compute_extra else None
+            hung_p = assignment(cols[nb + q]) if compute_extra else None
+            hung_i = assignment(cols[(2 * nb if compute_extra else 0) + q])
+            out[i] = (h["ind21"][q], h["ind12"][q], hung, hung_p, hi["ind21"][q], hi["ind12"][q], hung_i, model, model.mesh1, model.mesh2,
+                      h["knn21"][q], h["knn12"][q], hi["knn21"][q], hi["knn12"][q])
+    return out

@@ -356,6 +356,18 @@ def test_compute_surface_map_notebook_call(fx_cfg1, fx_cfg1_notebook_call, monke
     h0 = scipy.optimize.linear_sum_assignment(M0, maximize=True)
     assert np.array_equal(res[2][0], h0[0])
     assert abs(M0[res[2]].sum() - M0[h0].sum()) <= 1e-9 * abs(M0[h0].sum())    # (same objective; the GPU indicator differs in the last bits)
+    # the matrix the GPU assignment ran on: every entry within the summation-order bound of the oracle's (2 k + 2 roundings on the
+    # sum of absolute terms), the assignment IS SciPy's on that matrix, and it is counted against SciPy's on the oracle's matrix
+    from densematcher_amd.engine import default_engine
+    Mg = default_engine().mapped_indicator(fx["Phi1"][None, :, :k], fx["Phi2"][None, :, :k], fx["a1"][None], C0[None])[0].cpu().numpy()
+    S = ((np.abs(e2) @ np.abs(C0)) @ np.abs(e1).T) * fx["a1"].astype(np.float64)[None, :]
+    ulp_bound = (2 * k + 2) * np.finfo(np.float64).eps * S
+    assert (np.abs(Mg - M0) <= ulp_bound).all(), float((np.abs(Mg - M0) / S).max() / np.finfo(np.float64).eps)
+    hg = scipy.optimize.linear_sum_assignment(Mg, maximize=True)
+    assert np.array_equal(res[2][1], hg[1])                                    # identical to SciPy on the GPU's own matrix
+    same_as_oracle_matrix = float((res[2][1] == h0[1]).mean())
+    print("hungarian on the GPU indicator vs on the oracle's indicator: %.4f of the rows equal" % same_as_oracle_matrix)
+    assert same_as_oracle_matrix >= 0.99
     P0, _, _ = orc.precise_map_dense(C0, e1, e2, fx["faces1"])
     hp = scipy.optimize.linear_sum_assignment(P0, maximize=True)
     assert abs(P0[res[3]].sum() - P0[hp].sum()) <= 1e-9 * abs(P0[hp].sum())
@@ -372,6 +384,54 @@ def test_compute_surface_map_notebook_call(fx_cfg1, fx_cfg1_notebook_call, monke
                   p2p_12_icp=res[5], hungarian_icp_cols=res[6][1], p2p_21_adjoint=res[10], p2p_12_adjoint=res[11]).items()}
     print("notebook call, agreement with the reference's tuple:", agree)
     assert min(agree[n] for n in ("p2p_21", "p2p_12", "p2p_21_adjoint", "p2p_12_adjoint", "hungarian_cols")) >= 0.95
+    # the same call with the reference's own stopping rule (SciPy's defaults, the fit ends ~5e-4 from the minimiser like the
+    # reference's does): how close to the reference's tuple the drop-in gets when it stops where the reference stops
+    res_r = compute_surface_map(_Duck(fx["verts1"], fx["faces1"]), _Duck(fx["verts2"], fx["faces2"]), fx["F1"], fx["F2"], n_ev=k,
+                                compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(NOTEBOOK, stopping="reference"))
+    agree_r = {n: round(float((np.asarray(a) == ref[n]).mean()), 4) for n, a in
+               dict(p2p_21=res_r[0], p2p_12=res_r[1], hungarian_cols=res_r[2][1], hungarian_precise_cols=res_r[3][1], p2p_21_icp=res_r[4],
+                    p2p_12_icp=res_r[5], hungarian_icp_cols=res_r[6][1], p2p_21_adjoint=res_r[10], p2p_12_adjoint=res_r[11]).items()}
+    print("notebook call with stopping='reference', agreement with the reference's tuple:", agree_r,
+          "max |C - C_ref| = %.2e (tight: %.2e)" % (np.abs(res_r[7]._FM_base - ref["FM_base"]).max(), np.abs(C0 - ref["FM_base"]).max()))
+    assert min(agree_r[n] for n in ("p2p_21", "p2p_12", "p2p_21_adjoint", "p2p_12_adjoint")) >= 0.90
+
+
+def test_compute_surface_map_batch_equals_single_calls(fx_cfg1, monkeypatch):
+    """compute_surface_map_batch (no reference counterpart: the documented call with a batch dimension) returns, pair by pair, what
+    compute_surface_map returns: three pairs -- two of one size (batched kernels: device L-BFGS over both maps, 2 x 4 vertex maps,
+    precise maps, ICP, six assignments in one launch), one with mesh 2 subsampled (its own group) -- on injected spectra, so
+    that both paths see the same eigenbases bit for bit."""
+    from densematcher_amd.functional_map import compute_surface_map, compute_surface_map_batch
+    from densematcher_amd.pyFM.mesh import TriMesh
+    fx = fx_cfg1
+    k = int(fx["k"])
+    by_verts = [(fx["verts1"], 1), (fx["verts2"], 2)]
+
+    def process(self, k=200, **kw):
+        for vv, which in by_verts:
+            if np.array_equal(self.vertlist, vv):
+                src = _mesh(fx, which, k)
+                self.W, self.A, self.eigenvalues, self.eigenvectors = src.W, src.A, src.eigenvalues, src.eigenvectors
+                return self
+        raise RuntimeError("unknown mesh")
+
+    monkeypatch.setattr(TriMesh, "process", process)
+    rng = np.random.default_rng(0)
+    F1b = (fx["F1"].astype(np.float32) + 0.05 * rng.standard_normal(fx["F1"].shape)).astype(np.float16)
+    pairs = [(_Duck(fx["verts1"], fx["faces1"]), _Duck(fx["verts2"], fx["faces2"]), fx["F1"], fx["F2"]),
+             (_Duck(fx["verts1"], fx["faces1"]), _Duck(fx["verts2"], fx["faces2"]), F1b, fx["F2"]),
+             (_Duck(fx["verts2"], fx["faces2"]), _Duck(fx["verts1"], fx["faces1"]), fx["F2"], fx["F1"])]
+    kw = dict(n_ev=k, compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(NOTEBOOK))
+    got = compute_surface_map_batch([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], **kw)
+    assert len(got) == 3
+    for q, p in enumerate(pairs):
+        want = compute_surface_map(*p, **kw)
+        assert np.array_equal(got[q][7]._FM_base, want[7]._FM_base), q        # a pair's fit does not depend on its batch
+        assert np.array_equal(got[q][7].FM, want[7].FM), q                    # (the ICP map)
+        for slot in (0, 1, 4, 5, 10, 11, 12, 13):
+            assert np.array_equal(got[q][slot], want[slot]), (q, slot)
+        for slot in (2, 3, 6):
+            assert np.array_equal(got[q][slot][0], want[slot][0]) and np.array_equal(got[q][slot][1], want[slot][1]), (q, slot)
 
 
 def test_compute_surface_map_from_raw_meshes():

@@ -76,3 +76,18 @@ def test_bench_self_launches_its_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["pairs_per_gpu"] == 4 and out["value"] > 0
+
+
+def test_bench_rccl_branch_on_one_device():
+    """The `nccl` (= RCCL) branch of bench.py's timing code -- init_process_group with a device id, the barrier, the
+    max-over-ranks all-reduce on a device tensor -- as far as ONE device allows: a process group of one rank (two ranks on one
+    device are refused by RCCL; the 2-rank rehearsal above therefore carries its barrier over gloo)."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = str(_free_port())
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["process_group"] == "nccl" and out["value"] > 0
