@@ -19,7 +19,7 @@
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
-enum { W_DESCR = 0, W_LAP, W_DCOMM, W_P2P, W_STOCH, W_ENT, W_RANGE01, W_SUMTO1, W_COUNT };
+enum { W_DESCR = 0, W_LAP, W_DCOMM, W_P2P, W_STOCH, W_ENT, W_RANGE01, W_SUMTO1, W_AREA, W_CONFORMAL, W_COUNT };
 struct mterm_weights { double p2p, stoch, ent, range01, sumto1; };
 
 // ---- functors -----------------------------------------------------------------------------------------------------
@@ -614,6 +614,59 @@ __global__ __launch_bounds__(256) void half_sumsq_kernel(const double* __restric
     if (t == 0) out[b] = 0.5 * tot;
 }
 
+// Area and conformal shape-difference terms (base_functions.py:228-294):
+//   E_area = 1/2 |C^T C - I|^2,                grad = 2 C (C^T C - I)
+//   E_conf = 1/2 |C^T D2 C - D1|^2,            grad = 2 D2 C (C^T D2 C - D1),    D = diag(lam / max(lam1.max, lam2.max))
+// One workgroup per pair: the k1 x k1 difference matrices (already times their weights) go through a scratch block in global
+// memory, then the k2 x k1 gradient is formed from them.  O(k^3) on the vector ALU: these terms belong to small maps (the
+// iterative fit of the notebook runs 15 x 15); gs = w_area grad_area + w_conf grad_conf, es = the weighted energy.
+__global__ __launch_bounds__(256) void shape_terms_kernel(const double* __restrict__ C, const double* __restrict__ lam1, const double* __restrict__ lam2,
+                                                          int k1, int k2, double w_area, double w_conf, double* __restrict__ Msc,
+                                                          double* __restrict__ gs, double* __restrict__ es) {
+    __shared__ double sh[4];
+    __shared__ double sscale;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const double* Cb = C + (long long)b * k2 * k1;
+    const double* l1 = lam1 + (long long)b * k1;
+    const double* l2 = lam2 + (long long)b * k2;
+    double m = -DM_INF_F64;
+    for (int e = t; e < k1; e += 256) m = fmax(m, l1[e]);
+    for (int e = t; e < k2; e += 256) m = fmax(m, l2[e]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((t & 63) == 0) sh[t >> 6] = m;
+    __syncthreads();
+    if (t == 0) sscale = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    __syncthreads();
+    const double scale = sscale;
+    double* Ma = Msc + (long long)b * 2 * k1 * k1;
+    double* Mc = Ma + (long long)k1 * k1;
+    double acc = 0.0;
+    for (int e = t; e < k1 * k1; e += 256) {
+        const int a = e / k1, c = e - a * k1;
+        double ta = 0.0, tc = 0.0;
+        for (int i = 0; i < k2; ++i) {
+            const double p = Cb[(long long)i * k1 + a] * Cb[(long long)i * k1 + c];
+            ta += p;
+            tc = fma(l2[i] / scale, p, tc);
+        }
+        const double da = ta - (a == c ? 1.0 : 0.0), dc = tc - (a == c ? l1[a] / scale : 0.0);
+        acc += 0.5 * (w_area * da * da + w_conf * dc * dc);
+        Ma[e] = w_area * da;
+        Mc[e] = w_conf * dc;
+    }
+    const double tot = block_sum_256(acc, sh);
+    if (t == 0) es[b] = tot;
+    __syncthreads();                                            // (the workgroup's own global writes are visible to it behind the barrier)
+    for (int e = t; e < k2 * k1; e += 256) {
+        const int i = e / k1, c = e - i * k1;
+        const double d2 = l2[i] / scale;
+        double g = 0.0;
+        for (int a = 0; a < k1; ++a) g = fma(Cb[(long long)i * k1 + a], 2.0 * (Ma[a * k1 + c] + d2 * Mc[a * k1 + c]), g);
+        gs[(long long)b * k2 * k1 + e] = g;
+    }
+}
+
 // grad += gm + w_dc (g1 - g2), column 0 zeroed; energy = e_quad + e_m + w_dc e_dc.  gm arrives as the split-K partials of
 // Phi2^T Y (added here in split order, as reduce_partials_kernel would); e_m = the tile kernels' workgroup shares + the
 // column-statistics terms (what m_finish_energy_kernel computes), summed here by the pair's workgroup.
@@ -624,7 +677,7 @@ struct combine_mterms {
 __global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad, combine_mterms cm, long long n_all, const double* __restrict__ g1,
                                                       const double* __restrict__ g2, double w_dc, int k1, int k2,
                                                       const double* __restrict__ e_quad, const double* __restrict__ e_dc, double* __restrict__ energy,
-                                                      quad_args qa) {
+                                                      quad_args qa, const double* __restrict__ gs, const double* __restrict__ es) {
     __shared__ double sh[4];
     const int b = blockIdx.x, t = threadIdx.x;
     // small maps: the quadratic terms are evaluated here instead of by a launch of their own (qa.C != null)
@@ -639,6 +692,7 @@ __global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad,
             g += s;
         }
         if (g1) g += w_dc * (g1[o] - g2[o]);
+        if (gs) g += gs[o];                                             // area / conformal terms (shape_terms_kernel)
         grad[o] = (e % k1 == 0) ? 0.0 : g;                              // base_functions.py:759
     }
     double e_m = 0.0;
@@ -653,7 +707,7 @@ __global__ __launch_bounds__(256) void combine_kernel(double* __restrict__ grad,
             }
         e_m = block_sum_256(acc, sh);
     }
-    if (t == 0) energy[b] = (qa.C ? eq : e_quad[b]) + (cm.pe ? e_m : 0.0) + (e_dc ? w_dc * e_dc[b] : 0.0);
+    if (t == 0) energy[b] = (qa.C ? eq : e_quad[b]) + (cm.pe ? e_m : 0.0) + (e_dc ? w_dc * e_dc[b] : 0.0) + (es ? es[b] : 0.0);
 }
 
 extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D, const float* Phi1, int ld1,
@@ -671,6 +725,7 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
     const mterm_weights mw{w[W_P2P], w[W_STOCH], w[W_ENT], w[W_RANGE01], w[W_SUMTO1]};
     const bool m_terms = mw.p2p > 0 || mw.stoch > 0 || mw.ent > 0 || mw.range01 > 0 || mw.sumto1 > 0;
     const bool dcomm = w[W_DCOMM] > 0.0 && n_ops > 0;
+    const bool shape = w[W_AREA] > 0.0 || w[W_CONFORMAL] > 0.0;
     DM_REQUIRE(ctx, !m_terms || (Phi1 && Phi2 && mass1 && ld1 >= k1 && ld2 >= k2), "the indicator terms need Phi1, Phi2, mass1");
     DM_REQUIRE(ctx, !(w[W_DCOMM] > 0.0) || (ops1 && ops2 && n_ops > 0), "w_dcomm > 0 needs the descriptor operators (dm_fmap_descr_ops)");
     DM_REQUIRE(ctx, !(w[W_DCOMM] > 0.0) || (long long)B * n_ops <= 65535, "too many (pair, descriptor) slots for one launch: split the batch");
@@ -704,6 +759,7 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
                 2 * dm_align_up((size_t)B * N1 * 8) + 2 * dm_align_up((size_t)B * ngroups * N1 * 8) + dm_align_up((size_t)B * dm_cdiv(N1 > N2 ? N1 : N2, 256) * 2 * 8) +
                 dm_align_up((size_t)B * ncs * dm_cdiv(N2, EM_T) * 8) + dm_align_up((size_t)nsplit_m * bKK) + 2 * dm_align_up((size_t)B * (k1 + k2) * 8);
     if (dcomm) need += dm_align_up((size_t)B * n_ops * k2 * k1 * 8) + dm_align_up((size_t)nsplit_d * bKK);
+    if (shape) need += dm_align_up((size_t)B * 2 * k1 * k1 * 8) + dm_align_up(bKK) + dm_align_up((size_t)B * 8) + 4096;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     double* PQ = (double*)dm_ws_take(ctx, (size_t)B * (k1 + k2) * k1 * 8);
@@ -886,9 +942,17 @@ extern "C" int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, i
             }
         }
     }
+    double* gs = nullptr; double* es = nullptr;
+    if (shape) {
+        double* Msc = (double*)dm_ws_take(ctx, (size_t)B * 2 * k1 * k1 * 8);
+        gs = (double*)dm_ws_take(ctx, bKK);
+        es = (double*)dm_ws_take(ctx, (size_t)B * 8);
+        if (!Msc || !gs || !es) return dm_fail(ctx, DM_ENOMEM, "energy_grad: workspace not reserved");
+        DM_LAUNCH(ctx, "energy_shape_terms", shape_terms_kernel, dim3(B), dim3(256), 0, C, lam1, lam2, k1, k2, w[W_AREA], w[W_CONFORMAL], Msc, gs, es);
+    }
     DM_LAUNCH(ctx, "energy_combine", combine_kernel, dim3(B), dim3(256), 0, grad, cm, (long long)B * k2 * k1,
               dcomm ? G1 : (const double*)nullptr, dcomm ? G2 : (const double*)nullptr, w[W_DCOMM], k1, k2, e_quad,
-              dcomm ? e_dc : (const double*)nullptr, energy, qz);
+              dcomm ? e_dc : (const double*)nullptr, energy, qz, (const double*)gs, (const double*)es);
     return DM_OK;
 }
 

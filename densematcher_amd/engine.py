@@ -236,7 +236,7 @@ class MatchEngine:
                     f"(row {int(info[bad[0]]) - 1}): descriptors are rank deficient in the basis and w_lap cannot fix it")
         return Cm
 
-    WEIGHT_ORDER = ("w_descr", "w_lap", "w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1")
+    WEIGHT_ORDER = ("w_descr", "w_lap", "w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1", "w_area", "w_conformal")
 
     def descr_ops(self, Phi, mass, F, k=None):
         """Multiplication operators of the descriptors in the reduced basis, Phi^T diag(mass * f_d) Phi -> (B,D,k,k) f64
@@ -270,7 +270,7 @@ class MatchEngine:
         unknown = set(weights) - set(self.WEIGHT_ORDER)
         if unknown:
             raise ValueError(f"energy_grad: unknown weights {sorted(unknown)}")
-        w = (C.c_double * 8)(*[float(weights.get(n, 0.0)) for n in self.WEIGHT_ORDER])
+        w = (C.c_double * 10)(*[float(weights.get(n, 0.0)) for n in self.WEIGHT_ORDER])
         N1 = N2 = ld1 = ld2 = 1
         if Phi1 is not None:
             Phi1 = self._dev(Phi1, torch.float32, "Phi1")
@@ -298,7 +298,47 @@ class MatchEngine:
                     3: "STOP: TOTAL NO. of ITERATIONS REACHED LIMIT", 4: "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT",
                     5: "ABNORMAL_TERMINATION_IN_LNSRCH (or a non-finite energy / gradient)"}
 
-    def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4):
+    def _fit_inputs(self, batch, weights, k, orient_ops):
+        """projected descriptors, spectra, operator lists and the weight dictionary dm_fmap_energy_grad takes: the orientation term is
+        a commutation term like w_dcomm (base_functions.py:567-600), its operator pairs ride in the same lists scaled by
+        sqrt(w_orient / w_dcomm) (w_dcomm = 1 when only w_orient is set)"""
+        k1 = k if k is not None else batch["lam1"].shape[1]
+        k2 = k if k is not None else batch["lam2"].shape[1]
+        Phi1, Phi2 = batch["Phi1"], batch["Phi2"]
+        A = self.project(Phi1, batch["a1"], batch["F1"], k1)
+        Bm = self.project(Phi2, batch["a2"], batch["F2"], k2)
+        lam1 = self._dev(batch["lam1"], torch.float64, "lam1")[:, :k1].contiguous()
+        lam2 = self._dev(batch["lam2"], torch.float64, "lam2")[:, :k2].contiguous()
+        w = {n: float(v) for n, v in weights.items() if n != "w_orient"}
+        w_orient, w_dcomm = float(weights.get("w_orient", 0.0)), float(weights.get("w_dcomm", 0.0))
+        ops1 = ops2 = None
+        if w_dcomm > 0:
+            ops1 = self.descr_ops(Phi1, batch["a1"], batch["F1"], k1)
+            ops2 = self.descr_ops(Phi2, batch["a2"], batch["F2"], k2)
+        if w_orient > 0:
+            if orient_ops is None:
+                raise ValueError("w_orient > 0 needs the orientation operators (FunctionalMapping.compute_orientation_op)")
+            sc = (w_orient / w_dcomm) ** 0.5 if w_dcomm > 0 else w_orient ** 0.5
+            o1 = self._dev(orient_ops[0], torch.float64, "orient_ops1") * sc
+            o2 = self._dev(orient_ops[1], torch.float64, "orient_ops2") * sc
+            ops1 = o1 if ops1 is None else torch.cat([ops1, o1], dim=1).contiguous()
+            ops2 = o2 if ops2 is None else torch.cat([ops2, o2], dim=1).contiguous()
+            if w_dcomm <= 0:
+                w["w_dcomm"] = 1.0
+        P1 = self._dev(Phi1, torch.float32, "Phi1")[:, :, :k1].contiguous()
+        P2 = self._dev(Phi2, torch.float32, "Phi2")[:, :, :k2].contiguous()
+        a1 = self._dev(batch["a1"], torch.float32, "a1")
+        return A, Bm, lam1, lam2, w, P1, P2, a1, ops1, ops2, k1, k2
+
+    def fit_energy(self, batch, weights, x, k=None, orient_ops=None):
+        """energy (B,) of the fit's objective at the maps x (B,k2,k1) -- what FunctionalMapping.fit evaluates at x0 to rescale the
+        orientation weight (functional.py:448-456)"""
+        A, Bm, lam1, lam2, w, P1, P2, a1, ops1, ops2, k1, k2 = self._fit_inputs(batch, weights, k, orient_ops)
+        w.setdefault("w_descr", 0.0)
+        e, _ = self.energy_grad(self._dev(x, torch.float64, "x"), A, Bm, lam1, lam2, w, P1, P2, a1, ops1, ops2)
+        return e.cpu().numpy()
+
+    def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4, orient_ops=None):
         """FunctionalMapping.fit for any of the implemented energy terms, a whole batch at once (reference: L-BFGS-B through
         scipy.optimize.minimize, one pair per call, functional.py:477).  Every pair runs its OWN limited-memory BFGS iteration --
         history, step length, stopping test -- so a pair's result does not depend on the batch it is in; the optimiser state
@@ -310,20 +350,7 @@ class MatchEngine:
         .status (B), .nit (B), .nfev (B), .message (list)."""
         import types
         import numpy as np
-        k1 = k if k is not None else batch["lam1"].shape[1]
-        k2 = k if k is not None else batch["lam2"].shape[1]
-        Phi1, Phi2 = batch["Phi1"], batch["Phi2"]
-        A = self.project(Phi1, batch["a1"], batch["F1"], k1)
-        Bm = self.project(Phi2, batch["a2"], batch["F2"], k2)
-        lam1 = self._dev(batch["lam1"], torch.float64, "lam1")[:, :k1].contiguous()
-        lam2 = self._dev(batch["lam2"], torch.float64, "lam2")[:, :k2].contiguous()
-        ops1 = ops2 = None
-        if weights.get("w_dcomm", 0) > 0:
-            ops1 = self.descr_ops(Phi1, batch["a1"], batch["F1"], k1)
-            ops2 = self.descr_ops(Phi2, batch["a2"], batch["F2"], k2)
-        P1 = self._dev(Phi1, torch.float32, "Phi1")[:, :, :k1].contiguous()
-        P2 = self._dev(Phi2, torch.float32, "Phi2")[:, :, :k2].contiguous()
-        a1 = self._dev(batch["a1"], torch.float32, "a1")
+        A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2, k1, k2 = self._fit_inputs(batch, weights, k, orient_ops)
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         B = x0.shape[0]
         opts = dict(self.LBFGS_REFERENCE)

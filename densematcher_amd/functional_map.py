@@ -158,16 +158,19 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
                "a1": eng._dev(a1.astype(np.float32), torch.float32, "a1"), "a2": eng._dev(a2.astype(np.float32), torch.float32, "a2"),
                "lam1": eng._dev(lam1, torch.float64, "lam1"), "lam2": eng._dev(lam2, torch.float64, "lam2"),
                "F1": eng._dev(F1, tdt[fdt], "F1"), "F2": eng._dev(F2, tdt[fdt], "F2")}
-        fp = dict(w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_p2p=0, w_stochastic=0, w_ent=0, w_range01=0, w_sumto1=0, optinit="zeros",
-                  maxiter=1000000, stopping="tight")
-        unknown = set(fit_params) - set(fp) - {"w_orient", "w_area", "w_conformal", "w_area_difference", "w_mumford_shah", "mumford_shah_var",
+        fp = dict(w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_p2p=0, w_stochastic=0, w_ent=0, w_range01=0, w_sumto1=0, w_area=0, w_conformal=0,
+                  optinit="zeros", maxiter=1000000, stopping="tight")
+        unknown = set(fit_params) - set(fp) - {"w_orient", "w_area_difference", "w_mumford_shah", "mumford_shah_var",
                                                "w_eta_entropy", "orient_reversing", "device", "driver"}
         if unknown:
             raise TypeError(f"fit() got unexpected keyword arguments {sorted(unknown)}")
         fp.update({k_: v for k_, v in fit_params.items() if k_ in fp})
-        if any(fit_params.get(n, 0) > 0 for n in ("w_orient", "w_area", "w_conformal", "w_area_difference", "w_mumford_shah", "w_eta_entropy")):
-            raise NotImplementedError("orientation / area / conformal / Mumford-Shah terms are not on the accelerated path; pass 0")
-        general = {n: fp[n] for n in ("w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1")}
+        if any(fit_params.get(n, 0) > 0 for n in ("w_area_difference", "w_mumford_shah", "w_eta_entropy")):
+            raise NotImplementedError("area-difference / Mumford-Shah / eta-entropy terms are not on the accelerated path; pass 0")
+        if fit_params.get("w_orient", 0) > 0:
+            raise NotImplementedError("w_orient: the orientation operators are built per pair on the host (FunctionalMapping.fit); "
+                                      "use compute_surface_map for it")
+        general = {n: fp[n] for n in ("w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1", "w_area", "w_conformal")}
         if any(v > 0 for v in general.values()):
             from .pyFM.functional import LBFGS_OPTIONS
             x0 = np.stack([m.get_x0(optinit=fp["optinit"]) for m in g])

@@ -144,12 +144,12 @@ class FunctionalMapping:
             raise ValueError(f"Unknown solver {self.optimizer}")
         if self.partial:
             raise NotImplementedError()                                        # functional.py:480
-        off_path = dict(w_orient=w_orient, w_area=w_area, w_conformal=w_conformal, w_area_difference=w_area_difference,
-                        w_mumford_shah=w_mumford_shah, w_eta_entropy=w_eta_entropy)
+        off_path = dict(w_area_difference=w_area_difference, w_mumford_shah=w_mumford_shah, w_eta_entropy=w_eta_entropy)
         live = [n for n, v in off_path.items() if v > 0]
         if live:
             raise NotImplementedError(f"energy terms {live} are not on the accelerated path; pass 0")
-        general = dict(w_dcomm=w_dcomm, w_p2p=w_p2p, w_stochastic=w_stochastic, w_ent=w_ent, w_range01=w_range01, w_sumto1=w_sumto1)
+        general = dict(w_dcomm=w_dcomm, w_p2p=w_p2p, w_stochastic=w_stochastic, w_ent=w_ent, w_range01=w_range01, w_sumto1=w_sumto1,
+                       w_orient=w_orient, w_area=w_area, w_conformal=w_conformal)
         iterative = any(v > 0 for v in general.values())
         if not (w_descr > 0 or w_lap > 0 or iterative):
             raise ValueError("every energy weight is 0")                       # base_functions.py:534,639 would fail too
@@ -173,8 +173,26 @@ class FunctionalMapping:
             weights = dict(w_descr=w_descr, w_lap=w_lap, **general)
             if stopping not in ("tight", "reference"):
                 raise ValueError("stopping must be 'tight' or 'reference'")
-            C, res = eng.fit_general(dev, weights, self.get_x0(optinit=optinit)[None], maxiter=maxiter,
-                                     lbfgs_options=LBFGS_OPTIONS if stopping == "tight" else None, driver=driver)
+            x0 = self.get_x0(optinit=optinit)
+            orient_ops = None
+            if w_orient > 0:
+                # functional.py:432-456: the orientation operators, and the weight rescaled by (energy of the other terms at x0) /
+                # (orientation energy at x0).  The reference rescales with the NumPy operators of compute_orientation_op
+                # (reversing honoured there) and then OPTIMISES with the operators energy_func_std rebuilds itself
+                # (base_functions.py:567-597: rows divided by diag(A), never reversed) -- both restated as they are.
+                resc = self.compute_orientation_op(reversing=orient_reversing)
+                o1 = np.stack([a for a, _ in resc])[None]
+                o2 = np.stack([b for _, b in resc])[None]
+                w_native = dict(weights, w_orient=0.0)
+                e_native = eng.fit_energy(dev, w_native, x0[None])
+                e_orient = eng.fit_energy(dev, dict(w_orient=1.0), x0[None], orient_ops=(o1, o2))
+                w_orient = w_orient * float(e_native[0]) / float(e_orient[0])
+                weights["w_orient"] = w_orient
+                self.w_orient_rescaled = w_orient
+                fit_ops = self.compute_orientation_op(reversing=False, area="mass")
+                orient_ops = (np.stack([a for a, _ in fit_ops])[None], np.stack([b for _, b in fit_ops])[None])
+            C, res = eng.fit_general(dev, weights, x0[None], maxiter=maxiter,
+                                     lbfgs_options=LBFGS_OPTIONS if stopping == "tight" else None, driver=driver, orient_ops=orient_ops)
             self.FM = np.asarray(C[0], dtype=np.float64)
             self.fit_result = res
             if verbose:
@@ -189,6 +207,24 @@ class FunctionalMapping:
             self.FM = C[0].cpu().numpy()
         self.eta = np.ones(m2.eigenvectors.shape[0])                           # functional.py:483
         self._dev = dev
+
+    def compute_orientation_op(self, reversing=False, normalize=False, area="vertex"):
+        """functional.py:686-728: per descriptor the pair (pinv1 O1 Phi1, +-pinv2 O2 Phi2) of orientation operators in the reduced
+        bases, O = TriMesh.orientation_op(gradient of the descriptor).  area = "vertex": rows divided by the mesh's vertex_areas (the
+        reference's method); "mass": by diag(A) (what energy_func_std builds, base_functions.py:573).  Host arithmetic (sparse
+        products per descriptor), as in the reference."""
+        out = []
+        sides = []
+        for mesh, descr, k in ((self.mesh1, self.descr1, self.k1), (self.mesh2, self.descr2, self.k2)):
+            ev = np.asarray(mesh.eigenvectors[:, :k], dtype=np.float64)
+            pinv = ev.T @ mesh.A
+            pva = None if area == "vertex" else np.asarray(mesh.A.diagonal())
+            d = np.asarray(descr, dtype=np.float64)
+            sides.append([np.asarray(pinv @ (mesh.orientation_op(mesh.gradient(d[:, i], normalize=normalize), per_vert_area=pva) @ ev))
+                          for i in range(d.shape[1])])
+        for a, b in zip(*sides):
+            out.append((a, -b if reversing else b))
+        return out
 
     def get_x0(self, optinit="zeros"):
         """functional.py:629-660"""

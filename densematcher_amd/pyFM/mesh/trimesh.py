@@ -79,6 +79,66 @@ class TriMesh:
             return 0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1).sum()
         return self.A.sum()
 
+    # -- differential geometry of the faces (inputs of the orientation term of FunctionalMapping.fit; host arithmetic, as in
+    #    the reference: pyFM/mesh/geometry.py)
+    @property
+    def normals(self):
+        """(m, 3) unit face normals (trimesh.py:255-266 -> geometry.py:110-133)"""
+        v, f = self.vertlist, self.facelist
+        n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+        return n / np.linalg.norm(n, axis=1, keepdims=True)
+
+    @property
+    def faces_areas(self):
+        v, f = self.vertlist, self.facelist
+        return 0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1)
+
+    @property
+    def vertex_areas(self):
+        """trimesh.py:286-298: the row sums of A once the Laplacian exists, else a third of the adjacent face areas"""
+        if self.A is None:
+            f = self.facelist
+            return np.bincount(f.ravel(), weights=np.repeat(self.faces_areas / 3.0, 3), minlength=self.n_vertices)
+        return np.asarray(self.A.sum(1)).squeeze()
+
+    def _hat_gradients(self):
+        """gradients of the three hat functions on every face, 3 x (m, 3) (geometry.py:284-316)"""
+        v, f, n = self.vertlist, self.facelist, self.normals
+        inv2a = 1.0 / (2.0 * self.faces_areas)[:, None]
+        v1, v2, v3 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+        return np.cross(n, v3 - v2) * inv2a, np.cross(n, v1 - v3) * inv2a, np.cross(n, v2 - v1) * inv2a
+
+    def gradient(self, f, normalize=False):
+        """per-face gradient of a vertex function, (m, 3) (trimesh.py:949-972 -> geometry.py:373-430)"""
+        fl = self.facelist
+        g1, g2, g3 = self._hat_gradients()
+        f = np.asarray(f, dtype=np.float64)
+        grad = f[fl[:, 0], None] * g1 + f[fl[:, 1], None] * g2 + f[fl[:, 2], None] * g3
+        if normalize:
+            grad = grad / np.linalg.norm(grad, axis=1, keepdims=True)
+        return grad
+
+    def orientation_op(self, gradf, normalize=False, per_vert_area=None):
+        """(n, n) sparse operator g -> <n x grad f, grad g> at the vertices (trimesh.py:992-1019 -> geometry.py:919-985);
+        per_vert_area: the areas the rows are divided by (default: vertex_areas, like the reference's method)"""
+        gradf = np.asarray(gradf, dtype=np.float64)
+        if normalize:
+            gradf = gradf / np.linalg.norm(gradf, axis=1, keepdims=True)
+        v, f, nrm = self.vertlist, self.facelist, self.normals
+        area = self.vertex_areas if per_vert_area is None else np.asarray(per_vert_area)
+        v1, v2, v3 = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+        j1, j2, j3 = np.cross(nrm, v3 - v2) / 2, np.cross(nrm, v1 - v3) / 2, np.cross(nrm, v2 - v1) / 2
+        rot = np.cross(nrm, gradf)
+        rows = np.concatenate([f[:, 0], f[:, 1], f[:, 2]])
+        cols = np.concatenate([f[:, 1], f[:, 2], f[:, 0]])
+        d = lambda j: np.einsum("ij,ij->i", j, rot)
+        sij = np.concatenate([d(j2), d(j3), d(j1)]) / 3.0
+        sji = np.concatenate([d(j1), d(j2), d(j3)]) / 3.0
+        n = self.n_vertices
+        Wm = sparse.coo_matrix((np.concatenate([sij, sji, -sij, -sji]),
+                                (np.concatenate([rows, cols, rows, cols]), np.concatenate([cols, rows, rows, cols]))), shape=(n, n)).tocsc()
+        return sparse.diags(1.0 / area, shape=(n, n), format="csc") @ Wm
+
     @property
     def L(self):
         """A^-1 W (trimesh.py:482); built lazily, the matching path never needs it densified."""

@@ -187,7 +187,10 @@ int dm_fmap_fit_f64(dm_ctx* ctx, int B, int N1, int N2, int D, int k1, int k2,
 /* ---- general functional-map energy and gradient -----------------------------------
  * What scipy's L-BFGS-B evaluates in FunctionalMapping.fit when energy terms beyond w_descr / w_lap are switched on:
  * replaces energy_func_std / grad_energy_std (pyFM/optimize/base_functions.py:480-763) for the terms
- *   weights[0..7] = w_descr, w_lap, w_dcomm, w_p2p, w_stochastic, w_ent, w_range01, w_sumto1   (HOST array of 8 doubles)
+ *   weights[0..9] = w_descr, w_lap, w_dcomm, w_p2p, w_stochastic, w_ent, w_range01, w_sumto1, w_area, w_conformal   (HOST array of 10 doubles)
+ *   (w_area 1/2 |C^T C - I|^2, w_conformal 1/2 |C^T D2 C - D1|^2 with D = diag(lam / max lam): base_functions.py:228-294.  The
+ *    orientation term w_orient, base_functions.py:567-600, is a commutation term like w_dcomm: the host appends its operator pairs,
+ *    scaled by sqrt(w_orient / w_dcomm), to ops1 / ops2 -- densematcher_amd/pyFM/functional.py.)
  * i.e. descr_preservation :31, LB_commutation :79, oplist_commutation :168 (descriptor multiplication operators),
  * p2p :296, doubly_stochastic :324, entropy :363, range01 :374, sumto1 :387 (eta == 1, v = None).
  * energy (B) fp64 = the reference's energy value; grad (B,k2,k1) fp64 = its gradient with column 0 zeroed (:759).
@@ -199,7 +202,7 @@ int dm_fmap_energy_grad(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int 
                         const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass1,
                         const float* A, const float* Bm, const double* lam1, const double* lam2,
                         const double* ops1 /*nullable*/, const double* ops2 /*nullable*/, int n_ops,
-                        const double* weights /*host, 8*/, const double* C, double* energy, double* grad);
+                        const double* weights /*host, 10*/, const double* C, double* energy, double* grad);
 
 /* ---- batched L-BFGS on the device --------------------------------------------------------------------------------
  * The optimiser FunctionalMapping.fit runs for the non-quadratic terms: replaces scipy.optimize.minimize(method = "L-BFGS-B")

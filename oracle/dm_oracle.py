@@ -420,10 +420,76 @@ def dcomm_energy_grad(C, ops1, ops2):
     return float(E), G
 
 
-def energy_grad_general(C, A, B, ev, phi1, phi2, a1, weights, ops1=None, ops2=None):
+def area_energy_grad(C):
+    """1/2 |C^T C - I|^2 and 2 C C^T C - 2 C -- base_functions.py:228-255 (area, area_grad)."""
+    M = C.T @ C - np.eye(C.shape[1])
+    return float(0.5 * np.square(M).sum()), 2.0 * C @ M
+
+
+def conformal_energy_grad(C, lam1, lam2):
+    """1/2 |C^T D2 C - D1|^2, D = diag(lam / max(lam1.max, lam2.max)), and 2 D2 C C^T D2 C - 2 D2 C D1
+    -- base_functions.py:257-294 (conformal, conformal_grad)."""
+    lam1, lam2 = np.asarray(lam1, np.float64), np.asarray(lam2, np.float64)
+    scale = max(lam1.max(), lam2.max())
+    d1, d2 = lam1 / scale, lam2 / scale
+    M = C.T @ (d2[:, None] * C) - np.diag(d1)
+    return float(0.5 * np.square(M).sum()), 2.0 * (d2[:, None] * C) @ M
+
+
+def face_normals(verts, faces):
+    """unit face normals -- pyFM/mesh/geometry.py:110-133 (compute_normals)."""
+    v1, v2, v3 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    n = np.cross(v2 - v1, v3 - v1)
+    return n / np.linalg.norm(n, axis=1, keepdims=True)
+
+
+def face_gradients(verts, faces, F):
+    """per-face gradients of the vertex functions F (n, p) by linear interpolation, (m, 3, p)
+    -- pyFM/mesh/geometry.py:284-316 (_get_grad_dir), :319-370 (grad_mat), :373-430 (grad_f)."""
+    verts = np.asarray(verts, np.float64)
+    F = np.asarray(F, np.float64)
+    v1, v2, v3 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    nrm = face_normals(verts, faces)
+    fa = 0.5 * np.linalg.norm(np.cross(v2 - v1, v3 - v1), axis=1)
+    g1 = np.cross(nrm, v3 - v2) / (2 * fa[:, None])
+    g2 = np.cross(nrm, v1 - v3) / (2 * fa[:, None])
+    g3 = np.cross(nrm, v2 - v1) / (2 * fa[:, None])
+    return (g1[:, :, None] * F[faces[:, 0]][:, None, :] + g2[:, :, None] * F[faces[:, 1]][:, None, :]
+            + g3[:, :, None] * F[faces[:, 2]][:, None, :])
+
+
+def orientation_ops(phi, mass, verts, faces, F, vertex_areas=None):
+    """The orientation operators of the descriptors in the reduced basis, (p, k, k): pinv diag(1 / area) W_i Phi with W_i the
+    sparse operator g -> <n x grad f_i, grad g> summed over the faces around a vertex
+    -- pyFM/mesh/geometry.py:919-985 (get_orientation_op), pyFM/functional.py:686-728 (compute_orientation_op: area = the mesh's
+    vertex_areas, the row sums of A) and base_functions.py:430-478, :567-597 (orientation_op_torch inside energy_func_std: area =
+    diag(A), which cancels against pinv = Phi^T A).  vertex_areas None = the second form."""
+    phi = np.asarray(phi, np.float64)
+    verts = np.asarray(verts, np.float64)
+    mass = np.asarray(mass, np.float64)
+    nrm = face_normals(verts, faces)
+    v1, v2, v3 = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    Jc1, Jc2, Jc3 = np.cross(nrm, v3 - v2) / 2, np.cross(nrm, v1 - v3) / 2, np.cross(nrm, v2 - v1) / 2
+    rot = np.cross(nrm[:, :, None], face_gradients(verts, faces, F), axis=1)                    # (m, 3, p)
+    dot = lambda J: np.einsum("fc,fcp->fp", J, rot)
+    Sij = np.concatenate([dot(Jc2), dot(Jc3), dot(Jc1)]) / 3.0                                    # (3 m, p)
+    Sji = np.concatenate([dot(Jc1), dot(Jc2), dot(Jc3)]) / 3.0
+    I = np.concatenate([faces[:, 0], faces[:, 1], faces[:, 2]])
+    J = np.concatenate([faces[:, 1], faces[:, 2], faces[:, 0]])
+    left = phi * (mass / (mass if vertex_areas is None else np.asarray(vertex_areas, np.float64)))[:, None]   # rows of pinv^T / area
+    k = phi.shape[1]
+    # sum_e S_e outer(left[In_e], phi[Jn_e]) over In = [I, J, I, J], Jn = [J, I, I, J], S = [Sij, Sji, -Sij, -Sji]
+    ops = (np.einsum("ep,ea,eb->pab", Sij, left[I], phi[J] - phi[I], optimize=True)
+           + np.einsum("ep,ea,eb->pab", Sji, left[J], phi[I] - phi[J], optimize=True))
+    return ops.reshape(F.shape[1], k, k)
+
+
+def energy_grad_general(C, A, B, ev, phi1, phi2, a1, weights, ops1=None, ops2=None, lam1=None, lam2=None, orient_ops=None):
     """energy_func_std / grad_energy_std restated for the terms the GPU path implements (base_functions.py:480-763):
-    w_descr, w_lap, w_dcomm, w_p2p, w_stochastic, w_ent, w_range01, w_sumto1; the gradient's column 0 is zeroed (:759)."""
-    w = dict(w_descr=0.0, w_lap=0.0, w_dcomm=0.0, w_p2p=0.0, w_stochastic=0.0, w_ent=0.0, w_range01=0.0, w_sumto1=0.0)
+    w_descr, w_lap, w_dcomm, w_orient (orient_ops = (ops1, ops2)), w_area, w_conformal (lam1, lam2), w_p2p, w_stochastic, w_ent,
+    w_range01, w_sumto1; the gradient's column 0 is zeroed (:759)."""
+    w = dict(w_descr=0.0, w_lap=0.0, w_dcomm=0.0, w_p2p=0.0, w_stochastic=0.0, w_ent=0.0, w_range01=0.0, w_sumto1=0.0,
+             w_orient=0.0, w_area=0.0, w_conformal=0.0)
     w.update(weights)
     E = energy(C, A, B, ev, w["w_descr"], w["w_lap"])
     G = w["w_descr"] * (C @ A - B) @ A.T + w["w_lap"] * C * ev
@@ -431,6 +497,18 @@ def energy_grad_general(C, A, B, ev, phi1, phi2, a1, weights, ops1=None, ops2=No
         e, g = dcomm_energy_grad(C, ops1, ops2)
         E += w["w_dcomm"] * e
         G += w["w_dcomm"] * g
+    if w["w_orient"] > 0:
+        e, g = dcomm_energy_grad(C, orient_ops[0], orient_ops[1])
+        E += w["w_orient"] * e
+        G += w["w_orient"] * g
+    if w["w_area"] > 0:
+        e, g = area_energy_grad(C)
+        E += w["w_area"] * e
+        G += w["w_area"] * g
+    if w["w_conformal"] > 0:
+        e, g = conformal_energy_grad(C, lam1, lam2)
+        E += w["w_conformal"] * e
+        G += w["w_conformal"] * g
     if any(w[t] > 0 for t in M_TERMS):
         e, g = m_terms_energy_grad(C, phi1, phi2, a1, **{t: w[t] for t in M_TERMS})
         E += e

@@ -51,6 +51,12 @@ def fx_cfg1_terms():
 
 
 @pytest.fixture(scope="session")
+def fx_cfg1_shape_terms():
+    """area / conformal / orientation terms of the reference at a fixed map (tools/make_golden_r04.py)"""
+    return load_golden("fx_cfg1_shape_terms.npz")
+
+
+@pytest.fixture(scope="session")
 def oracle_cfg1_fits():
     """float64 minimisers computed by the ORACLE (tools/make_oracle_vectors.py), committed to save test time"""
     return load_golden("oracle_cfg1_fits.npz")

@@ -140,7 +140,7 @@ def test_functional_mapping_and_surface_map(fx_cfg1, monkeypatch):
     model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
     model.preprocess(n_ev=(k, k), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
     with pytest.raises(NotImplementedError):
-        model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_area=1.0)    # area / conformal / orientation terms are off the path
+        model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_mumford_shah=1.0)    # Mumford-Shah / area-difference / eta-entropy are off the path
     model.fit(**fit_params)
     assert model.FM.shape == (k, k) and model.FM.dtype == np.float64
     assert np.abs(model.FM - fx["C_f64"]).max() < 1e-4
@@ -316,8 +316,47 @@ def test_fit_with_descriptor_commutativity(fx_cfg1, fx_cfg1_terms):
     print("w_dcomm fit: |C - C_oracle| =", np.abs(model.FM - Co).max(), " |C - C_fit(reference)| =", np.abs(model.FM - fx_cfg1_terms["C_fit_dcomm"]).max())
     assert np.abs(model.FM - Co).max() <= 1e-4
     assert np.abs(model.FM - fx_cfg1_terms["C_fit_dcomm"]).max() <= 2e-3
-    with pytest.raises(NotImplementedError):
-        model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_orient=1.0)
+
+
+def test_fit_with_orientation_area_conformal_terms(fx_cfg1, fx_cfg1_shape_terms):
+    """The last part of fit()'s surface (VERDICT r03 missing #1): w_area, w_conformal (dm_fmap_energy_grad weights 8, 9) and w_orient
+    (orientation operators on the host like the reference, the commutation energy on the GPU through the operator lists).
+    Energy and gradient of each term against the oracle (pinned to the reference's autograd in fx_cfg1_shape_terms.npz); the
+    orientation operators of the mirror against the reference's; the rescaled orientation weight and the fitted map against the
+    reference's own fit (its float32 L-BFGS-B noise floor)."""
+    from densematcher_amd.engine import default_engine
+    from densematcher_amd.pyFM.functional import FunctionalMapping
+    fx, ft = fx_cfg1, fx_cfg1_shape_terms
+    k, nd = int(fx["k"]), int(ft["ndesc"])
+    eng = default_engine()
+    model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
+    model.preprocess(n_ev=(k, k), n_descr=nd, descr1=fx["F1"][:, :nd].astype(np.float64), descr2=fx["F2"][:, :nd].astype(np.float64), subsample_step=1)
+    ops = model.compute_orientation_op()
+    o1, o2 = np.stack([a for a, _ in ops]), np.stack([b for _, b in ops])
+    assert np.abs(o1 - ft["orient_np_op1"]).max() <= 1e-10 * np.abs(o1).max() and np.abs(o2 - ft["orient_np_op2"]).max() <= 1e-10 * np.abs(o2).max()
+    opsr = model.compute_orientation_op(reversing=True)
+    assert np.array_equal(opsr[0][0], ops[0][0]) and np.array_equal(opsr[0][1], -ops[0][1])
+    # energy + gradient of the three terms on the GPU at the fixture's map
+    e1, e2 = fx["Phi1"][:, :k].astype(np.float32), fx["Phi2"][:, :k].astype(np.float32)
+    batch = {"Phi1": e1[None], "Phi2": e2[None], "a1": fx["a1"][None], "a2": fx["a2"][None], "lam1": fx["lam1"][None, :k], "lam2": fx["lam2"][None, :k],
+             "F1": fx["F1"][None, :, :nd].astype(np.float32), "F2": fx["F2"][None, :, :nd].astype(np.float32)}
+    C = ft["C"]
+    A, Bm, lam1, lam2, w, P1, P2, a1, ops1, ops2, _, _ = eng._fit_inputs(batch, dict(w_orient=0.7, w_area=2.0, w_conformal=3.0), None,
+                                                                        (ft["orient_t_op1"][None], ft["orient_t_op2"][None]))
+    w.setdefault("w_descr", 0.0)
+    e, g = eng.energy_grad(C[None], A, Bm, lam1, lam2, w, P1, P2, a1, ops1, ops2)
+    ea, ga = orc.area_energy_grad(C)
+    ec, gc = orc.conformal_energy_grad(C, fx["lam1"][:k], fx["lam2"][:k])
+    eo, go = orc.dcomm_energy_grad(C, ft["orient_t_op1"], ft["orient_t_op2"])
+    Eo, Go = 2.0 * ea + 3.0 * ec + 0.7 * eo, 2.0 * ga + 3.0 * gc + 0.7 * go
+    Go[:, 0] = 0
+    assert abs(float(e[0]) - Eo) <= 1e-11 * abs(Eo)
+    assert np.abs(g[0].cpu().numpy() - Go).max() <= 1e-11 * np.abs(Go).max()
+    # the reference's fit with the three terms switched on
+    model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_orient=1, w_area=1e2, w_conformal=1e2, optinit="zeros")
+    d = np.abs(model.FM - ft["fit_orient_C"]).max()
+    print("fit with w_orient / w_area / w_conformal: |C - C_reference| = %.2e, rescaled w_orient = %.4e" % (d, model.w_orient_rescaled))
+    assert d <= 5e-3
 
 
 def test_compute_surface_map_notebook_call(fx_cfg1, fx_cfg1_notebook_call, monkeypatch):

@@ -211,3 +211,30 @@ def test_precise_map_against_reference(fx_cfg1, fx_cfg1_precise):
     P[fx_cfg1_precise["precise_rows"], fx_cfg1_precise["precise_cols"]] = fx_cfg1_precise["precise_vals"]
     assert np.abs(M - P).max() < 1e-12
     assert np.allclose(bary.sum(axis=1), 1.0)
+
+
+def test_shape_and_orientation_terms_against_reference(fx_cfg1, fx_cfg1_shape_terms):
+    """area / conformal energies and gradients (base_functions.py:228-294) against the reference's values and torch autograd
+    gradients; the orientation operators against BOTH forms the reference builds (compute_orientation_op, NumPy float64:
+    functional.py:686-728; orientation_op_torch inside energy_func_std, float32 inside: base_functions.py:430-478) and the
+    commutation energy / gradient on them (base_functions.py:176-203)."""
+    fx, ft = fx_cfg1, fx_cfg1_shape_terms
+    k = int(fx["k"])
+    C = ft["C"]
+    e, g = orc.area_energy_grad(C)
+    assert abs(e - float(ft["area_E"])) <= 1e-12 * abs(e) and np.abs(g - ft["area_G"]).max() <= 1e-11
+    e, g = orc.conformal_energy_grad(C, fx["lam1"][:k], fx["lam2"][:k])
+    assert abs(e - float(ft["conf_E"])) <= 1e-12 * abs(e) and np.abs(g - ft["conf_G"]).max() <= 1e-11
+    nd = int(ft["ndesc"])
+    ops = []
+    for which in (1, 2):
+        phi, a = fx[f"Phi{which}"][:, :k].astype(np.float64), fx[f"a{which}"].astype(np.float64)
+        F = fx[f"F{which}"][:, :nd].astype(np.float64)
+        o_np = orc.orientation_ops(phi, a, fx[f"verts{which}"], fx[f"faces{which}"], F, vertex_areas=ft[f"vertex_areas{which}"])
+        o_t = orc.orientation_ops(phi, a, fx[f"verts{which}"], fx[f"faces{which}"], F)
+        sc = np.abs(ft[f"orient_np_op{which}"]).max()
+        assert np.abs(o_np - ft[f"orient_np_op{which}"]).max() <= 1e-11 * sc
+        assert np.abs(o_t - ft[f"orient_t_op{which}"]).max() <= 5e-6 * sc              # (the reference's gradients are float32 there)
+        ops.append(ft[f"orient_t_op{which}"])
+    e, g = orc.dcomm_energy_grad(C, ops[0], ops[1])
+    assert abs(e - float(ft["orient_E"])) <= 1e-11 * abs(e) and np.abs(g - ft["orient_G"]).max() <= 1e-10 * np.abs(g).max()
