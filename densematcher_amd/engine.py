@@ -443,8 +443,10 @@ class MatchEngine:
         Returns (lam (B,k) f64, Phi (B,N,k) f64, resid (B,), rounds)."""
         import numpy as np
         import scipy.sparse as sp
-        # (the C ABI carries lumped masses as fp32, like every other entry point: the problem solved is the one with the
-        #  rounded masses, so that Phi^T A Phi = I holds for the A the matching kernels will see)
+        # (dm_eigenbasis takes the lumped masses as fp32: the problem solved is the one with the ROUNDED masses, and Phi^T A Phi = I
+        #  holds for those.  The float64 entry points downstream receive the caller's unrounded mesh.A: the basis is orthonormal
+        #  for a mass vector that differs from theirs by <= 6e-8 relative -- far inside the 1e-4 bar on C, and the reason the
+        #  eigenbasis tests compare with SciPy on the rounded masses.)
         # Meshes of DIFFERENT vertex counts share a call too (`mass` a list of 1-D arrays): the smaller ones are padded with
         # decoupled vertices whose only entry is a diagonal one AT the Gershgorin bound of the mesh's own operator
         # (max_i sum_q |L_iq| >= lambda_max: the upper end of the interval the Chebyshev filter damps, dm_eigen.hip
