@@ -82,6 +82,7 @@ extern "C" int dm_set_option(dm_ctx* ctx, const char* name, int value) {
     else if (n == "p2pfm_direct") ctx->opt_p2pfm_direct = value;
     else if (n == "zoomout_fused") ctx->opt_zoomout_fused = value;
     else if (n == "simnn1_wt") ctx->opt_simnn1_wt = value;
+    else if (n == "proj_onepass") ctx->opt_proj_onepass = value;
     else if (n == "energy_keep_gram") { ctx->opt_energy_keep_gram = value; ctx->gram_valid = false; }
     else return dm_fail(ctx, DM_EINVAL, "dm_set_option: unknown option '%s'", name);
     return DM_OK;

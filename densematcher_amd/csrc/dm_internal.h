@@ -38,6 +38,7 @@ struct dm_ctx {
     int opt_simnn_pipe = 1;      // 0: every similarity tile goes through the bounds-checked register-staged kernel
     int opt_knn_split = 1;       // 0: knn21 (ZoomOut, ICP, knn_query) on the float64 G kernel instead of the fp16 split
     int opt_solve_packed = 0;    // 1: the packed-storage solver for every system size it supports
+    int opt_proj_onepass = 1;    // 1: the fp16-split projection reads the basis once (running scale per workgroup); 0: maxima pass + fp32 copy + r03 tile kernel
     int opt_simnn_big = 0;       // 1: the tile kernels run four waves of 128 x 128 (accumulators in AGPRs) instead of eight of 128 x 64
     int opt_simnn_band = 4;      // tile rows per band of the similarity kernels' tile order (0: row-major); 4 measured best at
                                  // N = 8192 (tools/simnn_band_sweep.py: 8.93 / 8.62 / 8.44 / 8.57 / 8.82 ms for 0 / 2 / 4 / 8 / 16), neutral at N = 2048
@@ -266,15 +267,15 @@ struct dm_c00_args {
 #ifdef __HIPCC__
 template <typename TR>
 __device__ __forceinline__ void dm_c00_body(const dm_c00_args<TR>& z, int b, int t, double (&red)[2][4]) {
-    double a1 = 0.0, a2 = 0.0;
-    for (int i = t; i < z.N1; i += 256) a1 += (double)z.mass1[(long long)b * z.N1 + i];
-    for (int i = t; i < z.N2; i += 256) a2 += (double)z.mass2[(long long)b * z.N2 + i];
+    double a1 = 0.0, a2 = 0.0;               // (threads beyond 256 of a larger workgroup only take part in the barrier)
+    for (int i = t; i < z.N1 && t < 256; i += 256) a1 += (double)z.mass1[(long long)b * z.N1 + i];
+    for (int i = t; i < z.N2 && t < 256; i += 256) a2 += (double)z.mass2[(long long)b * z.N2 + i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         a1 += __shfl_xor(a1, off);
         a2 += __shfl_xor(a2, off);
     }
-    if ((t & 63) == 0) { red[0][t >> 6] = a1; red[1][t >> 6] = a2; }
+    if ((t & 63) == 0 && t < 256) { red[0][t >> 6] = a1; red[1][t >> 6] = a2; }
     __syncthreads();
     if (t == 0) {
         const double area1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);

@@ -287,6 +287,284 @@ __global__ __launch_bounds__(256, 2) void proj_f16split_kernel(proj_params<TR> p
             }
 }
 
+// ---- one pass over the basis (r04) ---------------------------------------------------------------------------------------
+// The kernel above needs max |mass Phi| of the pair before it can split a value: a pass of its own over the basis (project_absmax:
+// 2 x 48 us and 410 MB of the config-2 step for a maximum), plus the fp32 copy that pass leaves behind because four d-tiles
+// re-reading a float64 slab from L2 bound the tile kernel.  This kernel reads the basis ONCE, as it is:
+//  * the scale is a RUNNING one per workgroup: the split-K partial of a workgroup is written back unscaled, so nothing outside
+//    the workgroup ever sees its scale.  Every stage (32 vertices x 128 basis columns) publishes its max |mass Phi| through an
+//    LDS max one stage before it is split; when a stage raises the running maximum past the current power of two, the
+//    accumulators are multiplied by the (exact) ratio of the two scales and the loop goes on.  The scale only ever shrinks:
+//    no value can overflow, and a value far below the running maximum loses low bits of its low half only (fp16 subnormals
+//    degrade gradually: the absolute error stays below 2^-25 of the scaled maximum).
+//  * 8 waves per workgroup, tile 128 basis columns x 384 descriptor channels: two d-tiles (not four) re-read a slab, which from
+//    float64 is the L2 traffic the fp32 copy had; half the split arithmetic per output.
+//  * a wave whose 32-column blocks lie beyond k skips their matrix instructions (k = 200: one block in eight).
+constexpr int P2TD = 384;                 // descriptor channels per tile
+constexpr int P2NT = 3;                   // 32-channel blocks per wave (4 waves along d)
+constexpr int P2LDF = 416;                // LDS row stride of the descriptor rows in halves (832 B = 208 dwords = 16 mod 64)
+constexpr int P2STAGE = 2 * PBK * PLD + PBK * P2LDF;   // halves per stage buffer: Xhi | Xlo | F
+constexpr size_t P2_LDS = (size_t)2 * P2STAGE * sizeof(_Float16) + 16;   // two buffers + three max slots
+
+template <typename TR>
+struct proj2_params {
+    const TR* Phi; const TR* mass; const _Float16* F;
+    float* partial;          // (nsplit, B, k, D) fp32
+    int B, N, D, k, ld, nsplit, kchunk, tiles_m, tiles_d, ntiles;
+    dm_c00_args<TR> cz; int with_c00;
+    int flip;                // 1: the two waves of a SIMD run the halves of an iteration in opposite order (0: experiments)
+};
+
+template <typename TR, int NMT>
+__device__ __forceinline__ void proj2_body(const proj2_params<TR>& p, _Float16* smem, unsigned* slot, int b, int split, int m0, int d0) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nbeg = split * p.kchunk, nend = min(p.N, nbeg + p.kchunk);
+    const TR* Phi = p.Phi + (long long)b * p.N * p.ld;
+    const TR* mass = p.mass + (long long)b * p.N;
+    const _Float16* F = p.F + (long long)b * p.N * p.D;
+
+    f32x16 acc[NMT > 0 ? NMT : 1][P2NT];
+#pragma unroll
+    for (int a = 0; a < (NMT > 0 ? NMT : 1); ++a)
+#pragma unroll
+        for (int c = 0; c < P2NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    const int srow = t >> 4, scol = (t & 15) * 8;            // staging: row of the stage, 8 consecutive basis columns
+    const int fcol = (t & 15) * (P2TD / 16);                 //          and 24 consecutive descriptor channels
+    // Loads run a full iteration ahead of their first use (one workgroup per CU: nothing else covers their latency): the basis
+    // slab of stage s + 3 and the descriptor rows of stage s + 2 are requested at the top of iteration s; register sets A / B
+    // alternate by stage parity.  Every load is an UNCONDITIONAL buffer load (rows past the pair read as 0; rows past the chunk
+    // and columns past k are zeroed where the value is used): with loads under conditions the compiler cannot count the ones in
+    // flight and waits for all of them -- also the ones it issued a moment ago.
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int NQ = (int)sizeof(TR) / 2;                  // 16-byte loads per thread and stage: 8 values
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<TR*>(Phi), (short)0, (int)((unsigned)p.N * p.ld * sizeof(TR)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<TR*>(mass), (short)0, (int)((unsigned)p.N * sizeof(TR)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(F), (short)0, (int)((unsigned)p.N * p.D * 2), 0x00020000);
+    unsigned colmask = 0;                                    // bit q: basis column m0 + scol + q exists
+#pragma unroll
+    for (int q = 0; q < 8; ++q) colmask |= (m0 + scol + q < p.k) ? (1u << q) : 0u;
+    i32x4_t xrA[NQ], xrB[NQ], anA, anB;                      // stages s + 2 / s + 3 as loaded (an: [0 .. 1] hold the mass)
+    float xf[8];                                             // stage s + 1: fl(fl32(Phi) * fl32(mass)), not yet scaled
+    i32x4_t frA[3], frB[3];
+#define P2_FENCE() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define P2_FETCH_X(s_, xr, an_raw)                                                                            \
+    {                                                                                                         \
+        const int n_ = nbeg + (s_) * PBK + srow;                                                              \
+        const int vo = colmask ? (n_ * p.ld + m0 + scol) * (int)sizeof(TR) : 0x7fffff00;   /* no column: reads 0 */ \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rX, vo + 16 * q, 0, 0);   \
+        if constexpr (sizeof(TR) == 8) {                                                                      \
+            const auto m2 = __builtin_amdgcn_raw_buffer_load_b64(rM, n_ * 8, 0, 0);                           \
+            an_raw[0] = m2[0]; an_raw[1] = m2[1];                                                             \
+        } else {                                                                                              \
+            an_raw[0] = __builtin_amdgcn_raw_buffer_load_b32(rM, n_ * 4, 0, 0);                               \
+        }                                                                                                     \
+        P2_FENCE()                                                                                            \
+    }
+#define P2_FETCH_F(s_, fr)                                                                                    \
+    {                                                                                                         \
+        const int n_ = nbeg + (s_) * PBK + srow;                                                              \
+        const int vo = (n_ * p.D + d0 + fcol) * 2;                                                            \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) fr[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, vo + 16 * q, 0, 0);   \
+        P2_FENCE()                                                                                            \
+    }
+    // the loaded stage becomes fp32 products (the rounding the reference's fit applies: basis and mass rounded to fp32, one
+    // rounded product); their maximum goes to the stage's slot.  Non-negative floats order like their bit patterns.
+#define P2_PUBLISH(s_, xr, an_raw)                                                                            \
+    {                                                                                                         \
+        const bool rv = nbeg + (s_) * PBK + srow < nend;                                                      \
+        float an;                                                                                             \
+        if constexpr (sizeof(TR) == 8) an = (float)__hiloint2double(an_raw[1], an_raw[0]);                    \
+        else an = __int_as_float(an_raw[0]);                                                                  \
+        an = rv ? an : 0.f;              /* a row of the next chunk: finite data times 0 */                   \
+        float mx = 0.f;                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                       \
+            float x_;                                                                                         \
+            if constexpr (sizeof(TR) == 8) x_ = (float)__hiloint2double(xr[q >> 1][2 * (q & 1) + 1], xr[q >> 1][2 * (q & 1)]);   \
+            else x_ = __int_as_float(xr[q >> 2][q & 3]);                                                      \
+            float v_ = x_ * an;                                                                               \
+            asm volatile("" : "+v"(v_));                                                                      \
+            xf[q] = v_;                                                                                       \
+        }                                                                                                     \
+        if (colmask != 0xffu && colmask != 0u) {     /* the one thread per row whose columns straddle k: whatever lies */ \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) xf[q] = ((colmask >> q) & 1u) ? xf[q] : 0.f;   /* behind k must not reach the scale */ \
+        }                                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) mx = fmaxf(mx, fabsf(xf[q]));                           \
+        /* wave maximum: four DPP steps inside the rows of 16, the four row results through scalar registers, ONE LDS   \
+           atomic per wave (left to the compiler, same-address atomics become a scalar loop over the active lanes) */     \
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0xB1, 0xF, 0xF, true)));   \
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x4E, 0xF, 0xF, true)));   \
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x141, 0xF, 0xF, true)));  \
+        mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), 0x140, 0xF, 0xF, true)));  \
+        const unsigned mu = __builtin_bit_cast(unsigned, mx);                                                 \
+        const unsigned m01 = max((unsigned)__builtin_amdgcn_readlane((int)mu, 0), (unsigned)__builtin_amdgcn_readlane((int)mu, 16));   \
+        const unsigned m23 = max((unsigned)__builtin_amdgcn_readlane((int)mu, 32), (unsigned)__builtin_amdgcn_readlane((int)mu, 48));  \
+        const unsigned mw = max(m01, m23);                                                                    \
+        if (lane == 0 && mw != 0u) __hip_atomic_fetch_max(&slot[(s_) % 3], mw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        \
+    }
+    // split stage s_ with the running scale (max |X| * scale in [2^13, 2^14) at the moment the scale was set)
+#define P2_STASH(s_, buf_, fr)                                                                                   \
+    {                                                                                                         \
+        const float smx = __builtin_bit_cast(float, slot[(s_) % 3]);                                          \
+        if (smx > run_max) {                                                                                  \
+            run_max = smx;                                                                                    \
+            int ex = 0;                                                                                       \
+            (void)frexpf(smx, &ex);                                                                           \
+            const int e2 = min(14 - ex, 100);                                                                 \
+            if (e2 < cur_e) {           /* the accumulators follow once the current stage's products are in (P2_RESCALE) */ \
+                ratio = ldexpf(1.0f, e2 - cur_e);                                                             \
+                cur_e = e2;                                                                                   \
+                scale = ldexpf(1.0f, e2);                                                                     \
+            }                                                                                                 \
+        }                                                                                                     \
+        _Float16* Xh = smem + (buf_) * P2STAGE + srow * PLD + scol;                                           \
+        _Float16* Xl = Xh + PBK * PLD;                                                                        \
+        _Float16* Fs = smem + (buf_) * P2STAGE + 2 * PBK * PLD + srow * P2LDF + fcol;                         \
+        f16x8 h, l;                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                       \
+            const float xs_ = xf[q] * scale;                                                                  \
+            const _Float16 hi = (_Float16)xs_;                                                                \
+            h[q] = hi;                                                                                        \
+            l[q] = (_Float16)(xs_ - (float)hi);                                                               \
+        }                                                                                                     \
+        *reinterpret_cast<f16x8*>(Xh) = h;                                                                    \
+        *reinterpret_cast<f16x8*>(Xl) = l;                                                                    \
+        const bool rvf = nbeg + (s_) * PBK + srow < nend;                                                     \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                         \
+            *reinterpret_cast<i32x4_t*>(Fs + 8 * q) = rvf ? fr[q] : i32x4_t{0, 0, 0, 0};                      \
+    }
+
+#define P2_RESCALE()                                                                                          \
+    if (ratio != 1.0f) {                                                                                      \
+        _Pragma("unroll") for (int a = 0; a < (NMT > 0 ? NMT : 1); ++a)                                       \
+            _Pragma("unroll") for (int c = 0; c < P2NT; ++c)                                                  \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][c][r] *= ratio;                         \
+        ratio = 1.0f;                                                                                         \
+    }
+    float run_max = 0.f, scale = ldexpf(1.0f, 100), ratio = 1.0f;
+    int cur_e = 100;
+    const int ns = (nend - nbeg + PBK - 1) / PBK;
+    if (t < 3) slot[t] = 0u;
+    __syncthreads();
+    if (ns > 0) {
+        P2_FETCH_X(0, xrA, anA)
+        P2_FETCH_F(0, frA)
+        P2_FETCH_X(1, xrB, anB)
+        P2_FETCH_F(1, frB)
+        P2_PUBLISH(0, xrA, anA)
+        P2_FETCH_X(2, xrA, anA)
+    }
+    __syncthreads();
+    if (ns > 0) {
+        P2_STASH(0, 0, frA)
+        ratio = 1.0f;                                        // (nothing accumulated yet)
+        if (ns > 1) P2_PUBLISH(1, xrB, anB)
+    }
+    __syncthreads();
+    // iteration s: XL / ANL receive stage s + 3, XU / ANU hold stage s + 2; FL receives stage s + 2, FU holds stage s + 1
+#define P2_MMA(buf_)                                                                                          \
+        if constexpr (NMT > 0) {                                                                              \
+            const _Float16* Xh = smem + (buf_) * P2STAGE;                                                     \
+            const _Float16* Xl = Xh + PBK * PLD;                                                              \
+            const _Float16* Fs = Xl + PBK * PLD;                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < PBK / 16; ++ks) {                                         \
+                const int row0 = ks * 16 + 8 * (lane >> 5);                                                   \
+                const int sub = 16 * ((lane >> 4) & 1);          /* 16-column half of the 32-wide tile */      \
+                f16x8 ah[NMT > 0 ? NMT : 1], al[NMT > 0 ? NMT : 1], bf[P2NT];                                 \
+                _Pragma("unroll") for (int x = 0; x < NMT; ++x) {                                             \
+                    ah[x] = tr_frag<PLD>(Xh, row0, wm * 64 + x * 32 + sub, lane);                             \
+                    al[x] = tr_frag<PLD>(Xl, row0, wm * 64 + x * 32 + sub, lane);                             \
+                }                                                                                             \
+                _Pragma("unroll") for (int x = 0; x < P2NT; ++x)                                              \
+                    bf[x] = tr_frag<P2LDF>(Fs, row0, wn * (P2TD / 4) + x * 32 + sub, lane);                   \
+                _Pragma("unroll") for (int mt = 0; mt < NMT; ++mt)                                            \
+                    _Pragma("unroll") for (int nt = 0; nt < P2NT; ++nt) {                                     \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bf[nt], acc[mt][nt], 0, 0, 0);   \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bf[nt], acc[mt][nt], 0, 0, 0);   \
+                    }                                                                                         \
+            }                                                                                                 \
+        }
+    // The two waves of a SIMD (w and w + 4) run the halves of an iteration in opposite order: one splits and publishes (VALU,
+    // LDS writes) while the other multiplies (matrix pipe).  In lockstep -- all eight waves in the same phase, which is what one
+    // barrier per stage gives -- the two pipes take turns idling.
+#define P2_ITER(s_, XL, ANL, XU, ANU, FL, FU)                                                                 \
+    {                                                                                                         \
+        const int buf = (s_) & 1;                                                                             \
+        P2_FETCH_X((s_) + 3, XL, ANL)                        /* (past the chunk: zeroed at use) */                 \
+        P2_FETCH_F((s_) + 2, FL)                                                                              \
+        if (p.flip && wave >= 4) {                                                                            \
+            if ((s_) + 1 < ns) { P2_STASH((s_) + 1, buf ^ 1, FU) }                                            \
+            if ((s_) + 2 < ns) { P2_PUBLISH((s_) + 2, XU, ANU) }                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            P2_MMA(buf)                                                                                       \
+        } else {                                                                                              \
+            P2_MMA(buf)                                                                                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            if ((s_) + 1 < ns) { P2_STASH((s_) + 1, buf ^ 1, FU) }                                            \
+            if ((s_) + 2 < ns) { P2_PUBLISH((s_) + 2, XU, ANU) }                                              \
+        }                                                                                                     \
+        P2_RESCALE()                                                                                          \
+        if (t == 0) slot[(s_) % 3] = 0u;                     /* the slot of stage s + 3 (read for stage s one barrier ago) */ \
+        __syncthreads();                                                                                      \
+    }
+    for (int s = 0; s < ns; s += 2) {
+        P2_ITER(s, xrB, anB, xrA, anA, frA, frB)
+        if (s + 1 < ns) P2_ITER(s + 1, xrA, anA, xrB, anB, frB, frA)
+    }
+#undef P2_ITER
+#undef P2_FENCE
+#undef P2_MMA
+#undef P2_RESCALE
+#undef P2_FETCH_X
+#undef P2_FETCH_F
+#undef P2_PUBLISH
+#undef P2_STASH
+
+    if constexpr (NMT > 0) {
+        const float inv_scale = 1.0f / scale;
+        float* out = p.partial + ((long long)split * p.B + b) * p.k * p.D;
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < P2NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int d = d0 + wn * (P2TD / 4) + nt * 32 + (lane & 31);
+                    if (m < p.k && d < p.D) out[(long long)m * p.D + d] = acc[mt][nt][r] * inv_scale;
+                }
+    }
+}
+
+template <typename TR>
+__global__ __launch_bounds__(512, 2) void proj_onepass_kernel(proj2_params<TR> p) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];               // [2 buffers][Xhi | Xlo | F] | max slots
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x >= p.ntiles) {                        // (uniform) the extra workgroups of dm_fmap_fit: the pairs' c00
+        __shared__ double red[2][4];
+        dm_c00_body<TR>(p.cz, (int)blockIdx.x - p.ntiles, t, red);
+        return;
+    }
+    unsigned* slot = reinterpret_cast<unsigned*>(smem + 2 * P2STAGE);
+    // XCD-aware: the tiles that share one (pair, vertex chunk) slab of the basis / of the descriptors are neighbours in the
+    // logical order and meet in the same XCD's L2
+    const int ntile = p.tiles_m * p.tiles_d;
+    const int id = xcd_remap(blockIdx.x, p.ntiles);
+    const int tile = id % ntile;
+    const int split = (id / ntile) % p.nsplit;
+    const int b = id / (ntile * p.nsplit);
+    const int tm = tile / p.tiles_d, td = tile - tm * p.tiles_d;
+    const int m0 = tm * PT, d0 = td * P2TD;
+    const int wm = __builtin_amdgcn_readfirstlane(t >> 8);
+    const int left = p.k - (m0 + wm * 64);                    // basis columns this wave's two blocks still cover
+    if (left > 32) proj2_body<TR, 2>(p, smem, slot, b, split, m0, d0);
+    else if (left > 0) proj2_body<TR, 1>(p, smem, slot, b, split, m0, d0);
+    else proj2_body<TR, 0>(p, smem, slot, b, split, m0, d0);
+}
+
 __global__ __launch_bounds__(256) void proj_reduce_kernel(const float* __restrict__ partial, int nsplit, long long n,
                                                           float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -326,6 +604,24 @@ int dm_project_f16split_launch(dm_ctx* ctx, int B, int N, int D, int k, const TR
     if (!p.partial || !amax_part) return dm_fail(ctx, DM_ENOMEM, "dm_project: workspace not reserved");
     p.amax_part = amax_part; p.n_part = n_part;
     const size_t lds = (size_t)2 * PSTAGE * sizeof(_Float16);
+    // (its buffer loads take 32-bit byte offsets into a pair's arrays and dword-aligned descriptor rows)
+    const bool onepass_ok = (long long)N * ld * (long long)sizeof(TR) < (1ll << 31) - 4096 && (long long)N * D * 2 < (1ll << 31) && (D & 1) == 0;
+    if (ctx->opt_proj_onepass && onepass_ok) {
+        // one pass over the basis as it is (running scale per workgroup): no maxima pass, no fp32 copy
+        proj2_params<TR> q;
+        q.Phi = Phi; q.mass = mass; q.F = p.F; q.partial = p.partial;
+        q.B = B; q.N = N; q.D = D; q.k = k; q.ld = ld; q.nsplit = nsplit; q.kchunk = p.kchunk;
+        q.tiles_m = p.tiles_m; q.tiles_d = dm_cdiv(D, P2TD); q.ntiles = q.tiles_m * q.tiles_d * nsplit * B;
+        q.with_c00 = cz ? 1 : 0;
+        q.flip = 1;
+#ifdef DM_EXPERIMENTS
+        q.flip = dm_knob("DM_PROJ_FLIP", 1);
+#endif
+        q.cz = cz ? *cz : dm_c00_args<TR>{};
+        rc = dm_grant_lds(ctx, (const void*)proj_onepass_kernel<TR>, P2_LDS);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "project_f16split_mfma", proj_onepass_kernel<TR>, dim3(q.ntiles + (cz ? B : 0)), dim3(512), P2_LDS, q);
+    } else
     if constexpr (sizeof(TR) == 8) {
         // float64 basis: the scale pass also leaves an fp32 copy (the rounding the reference's fit applies), the tile kernel runs on it
         float* phi32 = (float*)dm_ws_take(ctx, (size_t)B * N * ld * 4);

@@ -460,6 +460,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // the epilogue (21 instead of 57 us) and loses more to its 1.5x DMA traffic.
 constexpr int PBK = 32;                    // halves per stage
 constexpr int SIMNN_PRODUCT_XV = 64;
+// the one-key kernel (config 3) issues its fragment reads and DMA between the matrix instructions of a k-step (bit 4096): -1.3 %
+// on features, -3 % on zero operands (tools/simnn_power_test.py); the key-set kernels keep them in front (+2 % with it, simnn1)
+constexpr int SIMNN_PRODUCT_ILV0 = 4096;
 constexpr int SIMNN_PRODUCT_WT = 4;
 #define DM_WAIT_VM_LGKM0(n) __builtin_amdgcn_s_waitcnt(0x0070 | ((n) & 15) | ((((n) >> 4) & 3) << 14))    /* vmcnt(n) lgkmcnt(0) */
 static inline size_t simnn_pipe_lds(int WT, int dual = 0) {
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     constexpr bool PINR = (XV & 64) != 0;
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
     constexpr bool TRACE = (XV & 1024) != 0;     // experiments: s_memtime stamps of every stage of workgroup 0's third tile
+    constexpr bool ILV = (XV & 4096) != 0;       // fragment reads and DMA issued BETWEEN the matrix instructions of a k-step
     constexpr bool SPLIT = DUAL != 0;            // the key-set kernels read split rows [16 high | 16 low] per stage (dm_knnsplit.hip)
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | per-tile terms | transpose buffer
     // Behind the ring: DUAL: two slots of per-tile terms | DUAL 3, 8 waves: the eighth wave's transpose buffer (the transposes of
@@ -655,6 +659,25 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
             _Pragma("unroll") for (int tt = 0; tt < TB; ++tt)                                                          \
                 acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], (ZERO_) ? zero16 : acc[st][tt], 0, 0, 0); \
     }
+    // a k-step whose fragment reads (next k-step's operands: rs_ / rt_ from ring slot rslot_ at rfo_) and DMA half H_ are issued in
+    // the shadow of its own matrix instructions -- two reads behind each of the first MFMAs, then the DMA -- instead of in
+    // front of them: the matrix pipe starts right behind the barrier
+#define SIMNN_MMA_ILV(fs_, ft_, ZERO_, RDS_, rs_, RDT_, rt_, rslot_, rfo_, DODMA_, H_)                                 \
+    if ((dbg & 7) != 7) {                                                                                              \
+        const _Float16* Br = smem + (rslot_) * PSTAGE;                                                                 \
+        _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
+            _Pragma("unroll") for (int tt = 0; tt < TB; ++tt) {                                                        \
+                acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], (ZERO_) ? zero16 : acc[st][tt], 0, 0, 0); \
+                const int mi = st * TB + tt;                                                                           \
+                const int ns_ = (RDS_) ? 4 : 0, nt_ = (RDT_) ? TB : 0;                                                 \
+                _Pragma("unroll") for (int r = 2 * mi; r < 2 * mi + 2; ++r) {                                          \
+                    if (r < ns_) rs_[r < 4 ? r : 0] = *reinterpret_cast<const f16x8*>(Br + sbase + r * 32 * PBK + (rfo_));  \
+                    else if (r < ns_ + nt_) rt_[(r - ns_) < TB ? (r - ns_) : 0] = *reinterpret_cast<const f16x8*>(Br + tbase + (r - ns_) * 32 * PBK + (rfo_)); \
+                }                                                                                                      \
+                if ((DODMA_) && mi == (ns_ + nt_ + 1) / 2) { SIMNN_DMA1(H_) }                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+    }
 #define SIMNN_SYNC(n_, AFTER_EPI_)                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
     if ((AFTER_EPI_) && n > 0 && !NOEPI) DM_WAIT_VM_LGKM0((n_) + EPI_ST);                                              \
@@ -700,6 +723,38 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
         SIMNN_PIN()                                                                                                    \
         SIMNN_MMA(fsb, ftb, NORMS, false)                                                                              \
         SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
+        } else if constexpr (ILV && !SPLIT) {                                                                          \
+        if (NORMS) {                                                                                                   \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(fta[x], nrm_t[x]); }         \
+            if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsa[x], nrm_s[x]); }          \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        SIMNN_MMA_ILV(fsa, fta, ZERO_, true, fsb, true, ftb, r_slot, foff1, DMA_, 0)                                   \
+        SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
+        if (NORMS) {                                                                                                   \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(ftb[x], nrm_t[x]); }         \
+            if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsb[x], nrm_s[x]); }          \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        SIMNN_MMA_ILV(fsb, ftb, false, NEXT_, fsa, NEXT_, fta, n_slot, foff0, DMA_, 1)                                 \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        } else if constexpr (ILV) {                                                                                    \
+        if (NORMS) {                                                                                                   \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(fta[x], sumsq8(fta[x], nrm_t[x])); } \
+            if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsa[x], sumsq8(fsa[x], nrm_s[x])); } \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        SIMNN_MMA_ILV(fsa, fta, ZERO_, true, fsb, true, ftb, r_slot, foff1, DMA_, 0)                                   \
+        SIMNN_SYNC(VM_, AFTER_EPI_)                                                                                    \
+        if (NORMS) {                                                                                                   \
+            if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(ftb[x], nrm_t[x]); }         \
+            if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fsb[x], nrm_s[x]); }          \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        SIMNN_MMA_ILV(fsa, ftb, false, false, fsa, NEXT_, ftn, n_slot, foff0, DMA_, 1)                                 \
+        SIMNN_MMA_ILV(fsb, fta, false, NEXT_, fsa, false, ftn, n_slot, foff0, false, 1)                                \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                                            \
+        if (NEXT_) { _Pragma("unroll") for (int x = 0; x < TB; ++x) fta[x] = ftn[x]; }                                 \
         } else if constexpr (!SPLIT) {                                                                                 \
         SIMNN_STAMP(tq0)                                                                                               \
         if (!late) { SIMNN_READ(fsb, ftb, r_slot, foff1) if (DMA_) { SIMNN_DMA1(0) } SIMNN_PIN() }                       \
@@ -1182,7 +1237,14 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             else if (dual && dual->scale) SIMNN_LAUNCH_BIG(1, "simnn2_f16_mfma")
             else if (dual) SIMNN_LAUNCH_BIG(2, "simnn2_f16_mfma")
             else SIMNN_LAUNCH_BIG(0, "simnn_f16_mfma")
-        } else if (cols) {
+        }
+#ifdef DM_EXPERIMENTS
+        else if (dm_knob("DM_SIMNN_ILV", 0) && WT == 4 && (cols || single)) {    // the key-set kernels with interleaved issue
+            if (cols) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV + 4096, 4, 3, "simnn4_f16_mfma")
+            else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV + 4096, 4, 4, "simnn1_f16_mfma")
+        }
+#endif
+        else if (cols) {
             if (WT == 4) SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 4, 3, "simnn4_f16_mfma")
             else SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, 2, 3, "simnn4_f16_mfma")
         } else if (single) {
@@ -1219,10 +1281,10 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
             SIMNN_CASE(64 + 2) SIMNN_CASE(64 + 4) SIMNN_CASE(64 + 6)
             SIMNN_CASE(64 + 128) SIMNN_CASE(64 + 128 + 1) SIMNN_CASE(64 + 128 + 9)
 #undef SIMNN_CASE
-            default: SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma") break;
+            default: SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV + SIMNN_PRODUCT_ILV0, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma") break;
         }
 #else
-        SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma")
+        SIMNN_LAUNCH_XV(SIMNN_PRODUCT_XV + SIMNN_PRODUCT_ILV0, SIMNN_PRODUCT_WT, 0, "simnn_f16_mfma")
 #endif
         }
         }
