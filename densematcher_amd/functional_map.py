@@ -27,6 +27,9 @@ def _assign(matrix):
     return rows, col[rows]
 
 
+_ASSIGN_STACK_LIMIT = 2 << 30
+
+
 def _assign_many(matrices):
     """the assignments of several (n2, n1) matrices in ONE batched call: one workgroup per matrix, so three assignments take
     the time of the longest instead of their sum"""
@@ -35,7 +38,12 @@ def _assign_many(matrices):
     eng = default_engine()
     devs = [m.device_tensor() if hasattr(m, "device_tensor") else m for m in matrices]
     devs = [d if d.dim() == 2 else d[0] for d in devs]
-    col = eng.linear_sum_assignment(torch.stack(devs), maximize=True).cpu().numpy().astype(np.int64)
+    # torch.stack copies every matrix next to its original (which the caller's MappedIndicator keeps alive): beyond 2 GiB of copies
+    # (n around 9 k for three float64 matrices) the matrices are assigned one after the other, as the reference does
+    if len(devs) > 1 and sum(d.numel() * d.element_size() for d in devs) > _ASSIGN_STACK_LIMIT:
+        col = np.stack([eng.linear_sum_assignment(d[None], maximize=True)[0].cpu().numpy() for d in devs]).astype(np.int64)
+    else:
+        col = eng.linear_sum_assignment(torch.stack(devs), maximize=True).cpu().numpy().astype(np.int64)
     out = []
     for c in col:
         rows = np.nonzero(c >= 0)[0]

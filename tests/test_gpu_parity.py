@@ -743,6 +743,19 @@ def test_hungarian_of_mapped_indicator(eng, fx_cfg1):
     assert agree >= 0.999
 
 
+def test_assign_many_sequential_equals_batched(eng, monkeypatch):
+    """functional_map._assign_many: above its memory threshold the matrices are assigned one after the other (no stacked copy)
+    -- same assignments as the batched call"""
+    from densematcher_amd import functional_map as fmod
+    rng = np.random.default_rng(11)
+    mats = [torch.as_tensor(rng.random((90, 90))).to(eng.device) for _ in range(3)]
+    batched = fmod._assign_many(mats)
+    monkeypatch.setattr(fmod, "_ASSIGN_STACK_LIMIT", 0)
+    seq = fmod._assign_many(mats)
+    for (r0, c0), (r1, c1) in zip(batched, seq):
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+
+
 def test_precise_map_and_its_assignment(eng, fx_cfg1, fx_cfg1_precise):
     """dm_precise_map against the reference's get_precise_map (tests/golden/fx_cfg1_precise.npz) and the oracle; the
     assignment of the dense precise map (hungarian_precise, functional_map.py:62-66) against the reference's"""
