@@ -28,7 +28,9 @@ struct zo_mx_args {
     const double* embr; int Kpad; const double* n1; int N1pad;
     int K, N2, N1;
     int32_t* nn;
-    int dbg;                                         // DM_EXPERIMENTS builds only: 1 = no exact phase (WRONG results)
+    int* qrow; float* qthr;                          // (B N2) the iteration's queue: rows whose margin is inside the bound + their thresholds
+    unsigned int* qcount; int qcap;                  // its length (zeroed by the caller), its capacity B N2
+    int dbg;                                         // DM_EXPERIMENTS builds only (WRONG results): 1 no exact launch work, 2 first two kept blocks of a row only, 4 every block reads the pair's first rows
 };
 template <typename TR>
 int dm_zo_merge_exact(dm_ctx* ctx, int B, const zo_mx_args<TR>& a);

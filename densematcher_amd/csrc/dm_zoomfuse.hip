@@ -1,13 +1,14 @@
-// The fused ZoomOut iteration (dm_zoomout.hip: zoomout_impl): four launches per iteration
+// The fused ZoomOut iteration (dm_zoomout.hip: zoomout_impl): five launches per iteration
 //
 //   1. zo_embed_split   emb1 = Phi1[:, :k] C^T on the float64 matrix cores; the rows leave the kernel three ways at once:
 //                       as SPLIT fp16 rows of the search ([16 high | 16 low] halves per 16 contraction indices), as float64
 //                       rows for the exact re-evaluation, and as |emb1_j|^2 (float64) / the fp32 bias -|emb1_j|^2 sx sy / 2.
 //                       (before: embedding kernel -> K-major float64 copy -> row-build kernel re-reading it)
 //   2. simnn1_f16_mfma  the search: dm_simnn_core with one biased key on split rows (dm_simnn.hip)
-//   3. zo_merge_exact   top-2 of every target row over the tile pass's partials, and the exact float64 re-evaluation of the
-//                       rows whose margin is inside the error bound, in the same workgroup (before: merge launch -> queue in
-//                       HBM -> exact launch)
+//   3. zo_merge         top-2 of every target row over the tile pass's partials (a thread per row), queue of the rows whose
+//      zo_exact         margin is inside the error bound; their exact float64 re-evaluation, a workgroup per row with all of a
+//                       block's loads in flight (two lean launches: as one kernel of 4096 small workgroups it was bound by
+//                       their dispatch, 36 us; as these two 8 + 12)
 //   4. p2pfm_tn_f64     C' = Phi2^T (a2 * Phi1[p21]) (dm_zoomout.hip: p2pfm_direct_kernel, no split-K partials)
 //
 // Reference arithmetic: pyFM/refine/zoomout.py:7-44 (one iteration), pyFM/spectral/convert.py:96-147 (FM_to_p2p),
@@ -263,132 +264,211 @@ template int dm_zo_embed_split<float>(dm_ctx*, int, const zo_embed_args<float>&)
 template int dm_zo_embed_split<double>(dm_ctx*, int, const zo_embed_args<double>&);
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 3. merge + exact.  One workgroup = 16 target rows of a pair.  Phase 1: sixteen lanes per row merge the row's partials of the tile
-// pass (top-2 with the lowest-index rule, like simnn_merge_kernel), the arg-max is written, and the rows whose margin is
-// inside the bound go on a list in LDS.  Phase 2: the whole workgroup re-evaluates the listed rows one by one in float64
-// (ks_exact_row: only the 32-candidate blocks the partials cannot rule out).
-constexpr int ZM_ROWS = 16;                        // target rows per workgroup: 16 lanes per row in the merge phase
-constexpr int ZM_KMAX = 208;                       // largest map of the fused path
+// 3. merge, exact.  zo_merge: top-2 of every target row over the tile pass's partials (lowest-index rule, like simnn_merge_kernel),
+// the arg-max is written, the rows whose margin is inside the bound are queued.  zo_exact: a workgroup per queued row
+// re-evaluates it in float64 (only the 32-candidate blocks the partials cannot rule out, like ks_exact_row).
+constexpr int ZM_KMAX = 208;                       // largest map of the fused path (<= 256: four chunks of 64 indices)
 
-// Exact float64 re-evaluation of ONE queued row by ONE wave (no workgroup barrier: the four waves of a workgroup work on four
-// rows at once).  Same arithmetic and summation schedule as ks_exact_row<0> (dm_exact.h): per candidate eight partial sums over
-// the contraction indices r = p (mod 8), ascending fma chains, added in the order p = 0 .. 7; value |y_j|^2 - 2 g; blocks and
-// candidates ascend and comparisons are strict, so the lowest index wins ties.  Two lanes per candidate: lane (c, hh) carries
-// the parts 4 hh .. 4 hh + 3 (two 16-byte loads per eight indices), the odd lane hands its four sums to the even one.
-//   xw: this wave's K8 = 8 ceil(K / 8) doubles of LDS
+// Exact float64 re-evaluation of ONE queued row by the WHOLE workgroup (r04 second half; before: one wave per row, two lanes per
+// candidate, the row's loads in seven dependent rounds -- a flagged row took 10 - 20 us, and the kernel ended with the last one).
+// Same arithmetic and summation schedule as ks_exact_row<0> (dm_exact.h): per candidate eight partial sums over the contraction
+// indices r = p (mod 8), ascending fma chains, added in the order p = 0 .. 7; value |y_j|^2 - 2 g; blocks and candidates ascend
+// and comparisons are strict, so the lowest index wins ties.  Eight lanes per candidate (lane p carries part p: the eight lanes
+// read one 64-byte run per eight indices), a wave = 8 candidates, the workgroup = one block of 32; ALL loads of a block are in
+// flight at once up to k = 128 (sixteen per lane and round: one L2 / fabric round trip per 128 indices instead of one per 32).
+//   xw: 256 doubles of LDS (zero beyond K: the padded products are exact zeros), redv / redj: one slot per wave
 template <typename TR>
-__device__ __forceinline__ void zo_exact_row_wave(const zo_mx_args<TR>& a, int o, float thr, double* xw) {
-    const int lane = threadIdx.x & 63, c = lane >> 1, hh = lane & 1;
+__device__ __forceinline__ void zo_exact_row_wg(const zo_mx_args<TR>& a, int o, float thr, double* xw, double* redv, int* redj) {
+    const int t = threadIdx.x, lane = t & 63, p = lane & 7, c8 = lane >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int K = a.K, K8 = (K + 7) & ~7;
     const int b = o / a.N2, i = o - b * a.N2;
     const TR* __restrict__ trow = a.Phi2 + ((long long)b * a.N2 + i) * a.ld2;
-    for (int r = lane; r < K8; r += 64) xw[r] = (r < K) ? (double)trow[r] : 0.0;       // (zero beyond K: the padded products are exact zeros)
-    __builtin_amdgcn_wave_barrier();
+    // Dependent round trips of a flagged row: the target row x, the row's partials (just read by the merge phase: cache hits),
+    // the candidates and their norms.  x is requested first and only written to LDS when the first block's candidates are in
+    // flight, the norm before the products it is combined with: two round trips instead of four.
+    const int nh = (K8 + 127) >> 7;                                // rounds of 128 contraction indices
+    const double xr = (t < K) ? (double)trow[t] : 0.0;             // (K <= 256)
+    bool x_in_lds = false;                                        // uniform
     const int nparts = a.q.nparts, pw = a.q.pw, nsub = nparts * (pw / 32);
     const double* __restrict__ E = a.embr + (long long)b * a.N1 * a.Kpad;
     const double* __restrict__ n1 = a.n1 + (long long)b * a.N1pad;
     double bv = DM_INF_F64;
     int bj = DM_IDX_NONE;
     for (int sb0 = 0; sb0 < nsub; sb0 += 64) {
-        const int sbt = sb0 + lane;
-        const bool keep = sbt < nsub && dm_simnn_keep(a.q.pb, a.q.pj, a.q.ps, nparts, pw, a.q.Npad, b, i, sbt, thr);
+        const int sbt = sb0 + lane;                               // (every wave takes the same ballot: no exchange)
+        bool keep = false;
+        {   // dm_simnn_keep with its three loads side by side (short-circuit evaluation made them three dependent round trips)
+            const int q = min((sbt * 32) / pw, nparts - 1);
+            const long long oq = ((long long)b * nparts + q) * a.q.Npad + i;
+            const float qs = a.q.ps[oq], qb = a.q.pb[oq];
+            const int qj = a.q.pj[oq];
+            keep = sbt < nsub && (qs >= thr || (qb >= thr && (qj >> 5) == sbt));
+        }
         unsigned long long mm = __ballot(keep);                   // uniform
+        // four kept blocks per pass, their loads in flight together (a flagged row typically keeps one whole partial = four
+        // blocks: one round trip instead of four; the launch has at most two workgroups per CU, registers are free)
         while (mm) {
-            const int sb = sb0 + __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            const int j = sb * 32 + c;
-            const int jc = min(j, a.N1 - 1);
-            const double* Cr = E + (long long)jc * a.Kpad + 4 * hh;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int r = 0;
-            // (loads of four steps ahead of their ordered fma chains: one L2 round trip per 32 indices instead of per 8)
-            for (; r + 32 <= K8; r += 32) {
-                f64x2 y[8];
+            constexpr int NB = 4, NU = 16;
+            int sb[NB];
+            bool on[NB];                                          // uniform
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    y[2 * u] = *reinterpret_cast<const f64x2*>(Cr + r + 8 * u);
-                    y[2 * u + 1] = *reinterpret_cast<const f64x2*>(Cr + r + 8 * u + 2);
+            for (int c = 0; c < NB; ++c) {
+                on[c] = mm != 0;
+                sb[c] = on[c] ? sb0 + __ffsll((long long)mm) - 1 : sb[0];
+                mm &= mm - 1;
+            }
+#ifdef DM_EXPERIMENTS
+            if (a.dbg & 2) mm = 0;                                // (the first pass only)
+#endif
+            int j[NB], jc[NB];
+            const double* Cr[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                j[c] = sb[c] * 32 + wave * 8 + c8;
+                jc[c] = (a.dbg & 4) ? wave * 8 + c8 : min(j[c], a.N1 - 1);   // (experiments: every block reads the pair's first rows)
+                Cr[c] = E + (long long)jc[c] * a.Kpad;
+            }
+            // sixteen loads per block and round (one round up to k = 128, two beyond)
+            double sacc[NB], nj[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) { sacc[c] = 0.0; nj[c] = 0.0; }
+            for (int h = 0; h < nh; ++h) {
+                double y[NB][NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int r = 8 * (NU * h + u) + p;
+                    const int rr = r < K8 ? r : p;                // (beyond the row: any finite entry, its x is zero)
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) y[c][u] = Cr[c][rr];
+                }
+                if (h == 0) {
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) nj[c] = n1[jc[c]];
+                    if (!x_in_lds) {
+                        __syncthreads();                          // (the previous row's readers of xw / red are done)
+                        xw[t] = xr;
+                        __syncthreads();
+                        x_in_lds = true;
+                    }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const f64x2 x0 = *reinterpret_cast<const f64x2*>(xw + r + 8 * u + 4 * hh), x1 = *reinterpret_cast<const f64x2*>(xw + r + 8 * u + 4 * hh + 2);
-                    s0 = fma(x0[0], y[2 * u][0], s0); s1 = fma(x0[1], y[2 * u][1], s1);
-                    s2 = fma(x1[0], y[2 * u + 1][0], s2); s3 = fma(x1[1], y[2 * u + 1][1], s3);
+                for (int u = 0; u < NU; ++u) {
+                    const double xv = xw[8 * (NU * h + u) + p];
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) sacc[c] = fma(xv, y[c][u], sacc[c]);
                 }
             }
-            for (; r < K8; r += 8) {
-                const f64x2 y0 = *reinterpret_cast<const f64x2*>(Cr + r), y1 = *reinterpret_cast<const f64x2*>(Cr + r + 2);
-                const f64x2 x0 = *reinterpret_cast<const f64x2*>(xw + r + 4 * hh), x1 = *reinterpret_cast<const f64x2*>(xw + r + 4 * hh + 2);
-                s0 = fma(x0[0], y0[0], s0); s1 = fma(x0[1], y0[1], s1); s2 = fma(x1[0], y1[0], s2); s3 = fma(x1[1], y1[1], s3);
-            }
-            // parts 4 .. 7 from the odd lane (lane ^ 1), then the fixed order 0 .. 7
-            const double t0 = dpp_f64<0xB1>(s0), t1 = dpp_f64<0xB1>(s1), t2 = dpp_f64<0xB1>(s2), t3 = dpp_f64<0xB1>(s3);
-            const double g = ((((((s0 + s1) + s2) + s3) + t0) + t1) + t2) + t3;
-            if (hh == 0 && j < a.N1) {
-                const double v = n1[j] - 2.0 * g;                 // |y|^2 - 2 <x, y>
-                if (v < bv) { bv = v; bj = j; }
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                // parts 1 .. 7 from the lanes p + 1 .. p + 7 of the row (row_shl), added in the fixed order: valid in the lanes p == 0
+                double g = sacc[c];
+                g += dpp_f64<0x101>(sacc[c]); g += dpp_f64<0x102>(sacc[c]); g += dpp_f64<0x103>(sacc[c]); g += dpp_f64<0x104>(sacc[c]);
+                g += dpp_f64<0x105>(sacc[c]); g += dpp_f64<0x106>(sacc[c]); g += dpp_f64<0x107>(sacc[c]);
+                if (p == 0 && on[c] && j[c] < a.N1) {             // (blocks ascend: strict comparisons keep the lowest index)
+                    const double v = nj[c] - 2.0 * g;             // |y|^2 - 2 <x, y>
+                    if (v < bv) { bv = v; bj = j[c]; }
+                }
             }
         }
     }
 #pragma unroll
-    for (int off = 2; off < 64; off <<= 1) {
+    for (int off = 8; off < 64; off <<= 1) {
         const double ov = __shfl_xor(bv, off);
         const int oj = __shfl_xor(bj, off);
         argmin_merge(bv, bj, ov, oj);
     }
-    if (lane == 0 && bj != DM_IDX_NONE) a.nn[o] = bj;
-    __builtin_amdgcn_wave_barrier();                              // (xw is rewritten by this wave's next row)
+    if (!x_in_lds) __syncthreads();                               // (no block kept: still behind the previous row's readers of red)
+    if (lane == 0) { redv[wave] = bv; redj[wave] = bj; }
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) argmin_merge(bv, bj, redv[w], redj[w]);
+        if (bj != DM_IDX_NONE) a.nn[o] = bj;
+    }
 }
 
+// Merge: ONE THREAD per target row reads the row's partials of the tile pass (consecutive rows = consecutive lanes: every load
+// instruction reads 256 contiguous bytes), keeps the top-2 with the lowest-index rule, writes the arg-max and appends the rows
+// whose margin is inside the error bound to the iteration's queue (one atomic per wave that holds any).  256 workgroups
+// instead of 4096: the r04 kernel (16 rows per workgroup, its flagged rows re-evaluated in the same workgroup) spent 20 - 39 us
+// on getting its 4096 workgroups dispatched while the flagged ones held their slots (per-workgroup stamps, tools/zo_experiment.py).
 template <typename TR>
-__global__ __launch_bounds__(256) void zo_merge_exact_kernel(zo_mx_args<TR> a) {
-    __shared__ __attribute__((aligned(16))) double xrow[4][ZM_KMAX];
-    __shared__ int flist[ZM_ROWS];
-    __shared__ float fthr[ZM_ROWS];
-    __shared__ int fcount;
-    const int b = blockIdx.y, t = threadIdx.x;
-    const int i = blockIdx.x * ZM_ROWS + (t >> 4), sub = t & 15;
-    if (t == 0) fcount = 0;
-    __syncthreads();
+__global__ __launch_bounds__(256) void zo_merge_kernel(zo_mx_args<TR> a) {
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int i = blockIdx.x * 256 + t, ic = min(i, a.N2 - 1);
+    const long long orow = (long long)b * a.N2 + ic;
+    const float tn2 = a.tnorm2[orow];
+    const float sm2 = __uint_as_float(a.smax2[b]), bmx = __uint_as_float(a.bmax[b]);
+    const double mp = __longlong_as_double((long long)a.amax_prev[b]), mcur = __longlong_as_double((long long)a.amax_cur[b]);
     float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
     int bj = DM_IDX_NONE;
-    if (i < a.N2) {
-        for (int q = sub; q < a.q.nparts; q += 16) {
-            const long long o = ((long long)b * a.q.nparts + q) * a.q.Npad + i;
-            top2_merge(bv, bj, sv, a.q.pb[o], a.q.pj[o], a.q.ps[o]);
-        }
-    }
+    const long long o0 = (long long)b * a.q.nparts * a.q.Npad + ic;
+    // eight partials (24 loads) in flight per round; a round past the end re-reads the last partial and merges nothing
+    const float* __restrict__ pb = a.q.pb; const int32_t* __restrict__ pj = a.q.pj; const float* __restrict__ ps = a.q.ps;
+    for (int q0 = 0; q0 < a.q.nparts; q0 += 8) {
+        float vb[8], vs[8];
+        int vj[8];
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) {
-        const float ob = __shfl_xor(bv, off), os = __shfl_xor(sv, off);
-        const int oj = __shfl_xor(bj, off);
-        top2_merge(bv, bj, sv, ob, oj, os);
+        for (int u = 0; u < 8; ++u) {
+            const long long o = o0 + (long long)min(q0 + u, a.q.nparts - 1) * a.q.Npad;
+            vb[u] = pb[o]; vj[u] = pj[o]; vs[u] = ps[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q0 + u < a.q.nparts) top2_merge(bv, bj, sv, vb[u], vj[u], vs[u]);
     }
     // the scale of the source rows was derived from the previous iteration's maximum: the bound holds while the true one is near it
-    const double mp = __longlong_as_double((long long)a.amax_prev[b]), mcur = __longlong_as_double((long long)a.amax_cur[b]);
     const double ratio = mcur * ks_scale(&mp, 1);
     const bool forced = !(ratio >= 0.25 && ratio < 8.0);
-    if (i < a.N2 && sub == 0) {
-        const long long o = (long long)b * a.N2 + i;
-        a.nn[o] = (bj == DM_IDX_NONE) ? 0 : bj;
-        const float tau = a.tau_scale * (sqrtf(a.tnorm2[o] * __uint_as_float(a.smax2[b])) + __uint_as_float(a.bmax[b]));
-        if (forced || !(bv - sv > tau)) {
-            const int pos = atomicAdd(&fcount, 1);
-            flist[pos] = (int)o;
-            fthr[pos] = forced ? DM_NEG_INF_F32 : bv - tau;
+    const float tau = a.tau_scale * (sqrtf(tn2 * sm2) + bmx);
+    const bool flag = i < a.N2 && (forced || !(bv - sv > tau));
+    if (i < a.N2) a.nn[orow] = (bj == DM_IDX_NONE) ? 0 : bj;
+    const unsigned long long fm = __ballot(flag);
+    if (fm) {                                                     // uniform per wave
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(a.qcount, (unsigned int)__popcll(fm));
+        base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+        if (flag) {
+            const unsigned int pos = base + (unsigned int)__popcll(fm & ((1ull << lane) - 1ull));
+            a.qrow[pos] = (int)orow;
+            a.qthr[pos] = forced ? DM_NEG_INF_F32 : bv - tau;
         }
     }
-    __syncthreads();
-    const int cnt = fcount;
-    if (cnt == 0 || a.dbg) return;
-    const int wave = t >> 6;
-    for (int e = wave; e < cnt; e += 4) zo_exact_row_wave<TR>(a, flist[e], fthr[e], xrow[wave]);
 }
 
+// Exact: the queue's rows, one per workgroup at a time (a fixed grid strides over the queue: its length is only known on the
+// device).
+template <typename TR>
+__global__ __launch_bounds__(256, 2) void zo_exact_kernel(zo_mx_args<TR> a) {
+    __shared__ __attribute__((aligned(16))) double xrow[256];
+    __shared__ double redv[4];
+    __shared__ int redj[4];
+    // (the first entry is requested together with the queue's length: beyond the length it is stale, never out of bounds)
+    unsigned int e = blockIdx.x;
+    const unsigned int ec = min(e, (unsigned int)a.qcap - 1u);
+    int o = a.qrow[ec];
+    float thr = a.qthr[ec];
+    const unsigned int cnt = *a.qcount;
+    if (a.dbg & 1) return;
+    if (e >= cnt) return;
+    while (true) {
+        const unsigned int en = e + gridDim.x;                    // (the next entry is requested before this row's work)
+        const bool more = en < cnt;
+        const int on = more ? a.qrow[en] : 0;
+        const float thrn = more ? a.qthr[en] : 0.f;
+        zo_exact_row_wg<TR>(a, o, thr, xrow, redv, redj);
+        if (!more) break;
+        e = en; o = on; thr = thrn;
+    }
+}
+
+constexpr int ZX_GRID = 512;                                      // workgroups of the exact launch
 template <typename TR>
 int dm_zo_merge_exact(dm_ctx* ctx, int B, const zo_mx_args<TR>& a) {
     if (a.K > ZM_KMAX) return dm_fail(ctx, DM_EINVAL, "zo_merge_exact: map size %d beyond %d", a.K, ZM_KMAX);
-    DM_LAUNCH(ctx, "zo_merge_exact", zo_merge_exact_kernel<TR>, dim3(dm_cdiv(a.N2, ZM_ROWS), B), dim3(256), 0, a);
+    DM_LAUNCH(ctx, "zo_merge", zo_merge_kernel<TR>, dim3(dm_cdiv(a.N2, 256), B), dim3(256), 0, a);
+    DM_LAUNCH(ctx, "zo_exact", zo_exact_kernel<TR>, dim3(ZX_GRID), dim3(256), 0, a);
     return DM_OK;
 }
 template int dm_zo_merge_exact<float>(dm_ctx*, int, const zo_mx_args<float>&);

@@ -265,34 +265,59 @@ static int launch_p2pfm_direct(dm_ctx* ctx, int B, int N1, int N2, int k1, int k
     }
     const int nrb = dm_cdiv(k2, 16), ncb = dm_cdiv(k1, 16);
     // The K-slicing fixes the summation order of every entry: it depends on the sizes only, never on the batch.
-    // Small maps (at most 7 x 7 blocks, k <= 112): 1 row block x all column blocks per wave, 8 slices (more, lighter waves);
-    // else 2 row blocks x up to 5 column blocks, 4 slices.
+    // Small maps (at most 7 x 7 blocks, k <= 112): 8 slices (more, lighter waves), else 4.
     const bool small = nrb <= 7 && ncb <= 7;
-    const int knob = dm_knob("DM_P2PFM_SHAPE", 0);         // experiments: 1 = 8 slices for every size, 2 = one row block per wave for every size, 4 = at most 5 column blocks with two row blocks
-    const bool two = !small && !(knob & 2);
-    const bool s8 = small || (knob & 1);
-    const int S = s8 ? 8 : 4;
+    const int knob = dm_knob("DM_P2PFM_SHAPE", 0);         // experiments: 1 = 8 slices for every size, 8 = 4 slices for every size, 16 = the r04 tile choice
+    const int S = ((small && !(knob & 8)) || (knob & 1)) ? 8 : 4;
+    // The tile of a workgroup (R x C blocks per wave) only decides who computes an entry, not how: it is chosen for the batch.
+    // A workgroup is one quantum of N R C / 16 matrix instructions per SIMD, the pairs of an XCD (b % 8) share its 32 CUs, a CU
+    // that holds two workgroups takes twice as long: cost = ceil(tiles x pairs on the XCD / 32) (R C + 0.3 (R + C) + 0.75).  (r04 took 2 x 7-wide tiles for every large map: 10 / 12 / 14 tiles per pair,
+    // i.e. 1.25 - 1.75 workgroups per CU at B = 32 -- two rounds where 3 x 5, 5 x 3 or 6 x 3 tiles need one.)
+    static const int shapes4[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 7}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7},
+                                     {3, 3}, {3, 4}, {3, 5}, {4, 3}, {4, 4}, {5, 3}, {6, 3}};
+    static const int shapes8[][2] = {{1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 7}};
+    const int (*shapes)[2] = S == 8 ? shapes8 : shapes4;
+    const int nshapes = S == 8 ? (int)(sizeof(shapes8) / sizeof(shapes8[0])) : (int)(sizeof(shapes4) / sizeof(shapes4[0]));
+    int R = 0, Cw = 0;
+    if (knob >> 8) {                                       // experiments: forced shape, (R << 4 | C) << 8
+        R = (knob >> 12) & 15; Cw = (knob >> 8) & 15;
+        if (R > nrb) R = nrb;
+        if (Cw > ncb) Cw = ncb;
+    } else if (knob & 16) {
+        const bool two = !small;
+        R = two ? 2 : 1;
+        Cw = dm_cdiv(ncb, dm_cdiv(ncb, 7));
+        if (S == 8) R = 1;
+    } else {
+        long long best = -1;
+        const int ppx = dm_cdiv(B, 8);                     // pairs on the fullest XCD
+        for (int q = 0; q < nshapes; ++q) {
+            const int r = shapes[q][0], c = shapes[q][1];
+            if (r > nrb || c > ncb) continue;
+            const int T = dm_cdiv(nrb, r) * dm_cdiv(ncb, c);
+            // per round and workgroup: R C matrix instructions per k-step, R + C operand loads (0.3 of a matrix instruction
+            // each, measured on the 1 x 7 shape), a fixed part (index slices, reduction)
+            const long long cost = (long long)dm_cdiv(T * ppx, 32) * (100 * r * c + 30 * (r + c) + 75);
+            const long long key = (cost << 12) + T;
+            if (best < 0 || key < best) { best = key; R = r; Cw = c; }
+        }
+    }
     p2pfm_args<TR> a;
     a.Phi1 = Phi1; a.s1 = (long long)N1 * ld1; a.ld1 = ld1; a.N1 = N1;
     a.Xs = Xs; a.sx = (long long)(N2 + 1) * ldx; a.ldx = ldx; a.N2 = N2;
     a.p21 = p21; a.k1 = k1; a.k2 = k2; a.C = C; a.ldc = ldc; a.strideC = strideC; a.B = B;
     a.dbg = dm_knob("DM_ZO_DEBUG", 0);
-    a.TM = dm_cdiv(nrb, two ? 2 : 1);
-    a.TC = dm_cdiv(ncb, (two && (knob & 4)) ? 5 : 7);
-    const int CBW = dm_cdiv(ncb, a.TC);
+    a.TM = dm_cdiv(nrb, R);
+    a.TC = dm_cdiv(ncb, Cw);
     a.rps = dm_cdiv(dm_cdiv(N2, S), 4) * 4;
     const int grid = a.TM * a.TC * dm_cdiv(B, 8) * 8;
-#ifdef DM_EXPERIMENTS
-#define P2PFM_CASE(C_) case C_: return two ? (s8 ? p2pfm_launch<TR, 2, C_, 8>(ctx, a, grid) : p2pfm_launch<TR, 2, C_, 4>(ctx, a, grid)) \
-                                            : (s8 ? p2pfm_launch<TR, 1, C_, 8>(ctx, a, grid) : p2pfm_launch<TR, 1, C_, 4>(ctx, a, grid));
-#else
-#define P2PFM_CASE(C_) case C_: return two ? p2pfm_launch<TR, 2, C_, 4>(ctx, a, grid) : p2pfm_launch<TR, 1, C_, 8>(ctx, a, grid);
-#endif
-    switch (CBW) {
-        P2PFM_CASE(1) P2PFM_CASE(2) P2PFM_CASE(3) P2PFM_CASE(4) P2PFM_CASE(5) P2PFM_CASE(6) P2PFM_CASE(7)
-        default: return dm_fail(ctx, DM_EINVAL, "p2p_to_fm: bad tile width %d", CBW);
-    }
+#define P2PFM_CASE(R_, C_, S_) if (R == R_ && Cw == C_ && S == S_) return p2pfm_launch<TR, R_, C_, S_>(ctx, a, grid);
+    P2PFM_CASE(1, 1, 4) P2PFM_CASE(1, 2, 4) P2PFM_CASE(1, 3, 4) P2PFM_CASE(1, 4, 4) P2PFM_CASE(1, 5, 4) P2PFM_CASE(1, 6, 4) P2PFM_CASE(1, 7, 4)
+    P2PFM_CASE(2, 1, 4) P2PFM_CASE(2, 2, 4) P2PFM_CASE(2, 3, 4) P2PFM_CASE(2, 4, 4) P2PFM_CASE(2, 5, 4) P2PFM_CASE(2, 6, 4) P2PFM_CASE(2, 7, 4)
+    P2PFM_CASE(3, 3, 4) P2PFM_CASE(3, 4, 4) P2PFM_CASE(3, 5, 4) P2PFM_CASE(4, 3, 4) P2PFM_CASE(4, 4, 4) P2PFM_CASE(5, 3, 4) P2PFM_CASE(6, 3, 4)
+    P2PFM_CASE(1, 1, 8) P2PFM_CASE(1, 2, 8) P2PFM_CASE(1, 3, 8) P2PFM_CASE(1, 4, 8) P2PFM_CASE(1, 5, 8) P2PFM_CASE(1, 6, 8) P2PFM_CASE(1, 7, 8)
 #undef P2PFM_CASE
+    return dm_fail(ctx, DM_EINVAL, "p2p_to_fm: no tile shape %d x %d x %d", R, Cw, S);
 }
 
 template <typename TR>
@@ -353,7 +378,7 @@ extern "C" int dm_p2p_to_fm_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int 
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
-// ---- the fused iteration (dm_zoomfuse.hip): 4 launches per iteration, no memset, no K-major copies -------------------------
+// ---- the fused iteration (dm_zoomfuse.hip): 5 launches per iteration, no memset, no K-major copies -------------------------
 // Eligible: both meshes have at least one 256-row tile and the final map fits the embedding kernel's accumulators (k <= 208);
 // anything else runs the six-launch loop below (also dm_set_option "zoomout_fused" = 0: the tests compare the two).
 static bool zoomout_fused_ok(const dm_ctx* ctx, int N1, int N2, int kf) {
@@ -371,10 +396,10 @@ static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, in
     const size_t bytes_C = (size_t)B * Kpad * Kpad * 8;
     const size_t bytes_Fx = (size_t)B * R2 * ldT * 2, bytes_Fy = (size_t)B * R1 * ldS * 2;
     const size_t ctl1 = dm_simnn_ctl_bytes(B), amax1 = dm_align_up((size_t)B * 8), bmax1 = dm_align_up((size_t)B * 4);
-    const size_t bytes_zero = (size_t)(nit + 3) * amax1 + (size_t)(nit + 2) * (bmax1 + dm_align_up(ctl1));
+    const size_t bytes_zero = (size_t)(nit + 3) * amax1 + (size_t)(nit + 2) * (bmax1 + dm_align_up(ctl1)) + dm_align_up((size_t)(nit + 2) * 4);
     const size_t need = dm_align_up((size_t)B * N2 * 8) + dm_align_up(bytes_Fx) + dm_align_up(bytes_Fy) + 2 * dm_align_up(bytes_C) +
                         dm_align_up((size_t)B * R1 * 4) + dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N1 * Kpad * 8) +
-                        dm_align_up((size_t)B * N2 * 4) + dm_align_up((size_t)B * ZO_NCH * 8) + dm_align_up(bytes_zero) +
+                        3 * dm_align_up((size_t)B * N2 * 4) + dm_align_up((size_t)B * ZO_NCH * 8) + dm_align_up(bytes_zero) +
                         dm_simnn_ws_bytes(B, N2, N1, 0) + dm_p2pfm_xs_bytes(B, N2, kf) + 65536;
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
@@ -389,13 +414,16 @@ static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, in
     double* n1 = (double*)dm_ws_take(ctx, (size_t)B * N1pad * 8);
     double* embr = (double*)dm_ws_take(ctx, (size_t)B * N1 * Kpad * 8);
     int32_t* p21 = (int32_t*)dm_ws_take(ctx, (size_t)B * N2 * 4);
+    int* qrow = (int*)dm_ws_take(ctx, (size_t)B * N2 * 4);                // queue of the rows an iteration re-evaluates exactly
+    float* qthr = (float*)dm_ws_take(ctx, (size_t)B * N2 * 4);
     double* amaxT = (double*)dm_ws_take(ctx, (size_t)B * ZO_NCH * 8);
     char* zero = (char*)dm_ws_take(ctx, bytes_zero);
-    if (!Fx || !Fy || !Ca || !Cb || !bias || !n1 || !embr || !p21 || !amaxT || !zero)
+    if (!Fx || !Fy || !Ca || !Cb || !bias || !n1 || !embr || !p21 || !qrow || !qthr || !amaxT || !zero)
         return dm_fail(ctx, DM_ENOMEM, "zoomout: workspace not reserved");
     char* amax_slots = zero;                                             // (nit + 3) x B maxima of |emb1| (float64 bits)
     char* bmax_slots = zero + (size_t)(nit + 3) * amax1;                 // (nit + 2) x B maxima of |bias| (fp32 bits)
     char* ctl_slots = bmax_slots + (size_t)(nit + 2) * bmax1;            // (nit + 2) control blocks of the tile pass
+    unsigned int* qcount_slots = (unsigned int*)(ctl_slots + (size_t)(nit + 2) * dm_align_up(ctl1));   // (nit + 2) queue lengths
     // everything an iteration accumulates into with atomicMax, for all iterations: ONE memset per call
     DM_CHECK_HIP(ctx, hipMemsetAsync(zero, 0, bytes_zero, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemsetAsync(Ca, 0, bytes_C, ctx->stream));      // maps grow inside zeroed Kpad x Kpad frames
@@ -461,7 +489,9 @@ static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, in
         ma.tnorm2 = ext.tnorm2; ma.smax2 = ext.smax2; ma.bmax = ea.bmax; ma.tau_scale = ext.tau_scale;
         ma.amax_prev = ea.amax_prev; ma.amax_cur = ea.amax_cur;
         ma.Phi2 = Phi2; ma.ld2 = ld2; ma.embr = embr; ma.Kpad = Kpad; ma.n1 = n1; ma.N1pad = N1pad;
-        ma.K = k; ma.N2 = N2; ma.N1 = N1; ma.nn = last ? p21_out : p21; ma.dbg = (ea.dbg & 16) ? 1 : 0;
+        ma.K = k; ma.N2 = N2; ma.N1 = N1; ma.nn = last ? p21_out : p21;
+        ma.qrow = qrow; ma.qthr = qthr; ma.qcount = qcount_slots + it; ma.qcap = B * N2;
+        ma.dbg = ((ea.dbg & 16) ? 1 : 0) | ((ea.dbg & 256) ? 2 : 0) | ((ea.dbg & 512) ? 4 : 0);
         rc = dm_zo_merge_exact<TR>(ctx, B, ma);
         if (rc) return rc;
         if (last) break;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Ablations of the fused ZoomOut kernels (libdensematch_exp.so, -DDM_EXPERIMENTS: WRONG results on purpose).
 DM_ZO_DEBUG bits: zo_embed_split: 1 no split-row stores, 2 no float64 row stores, 4 one contraction stage only, 8 no epilogue;
-zo_merge_exact: 16 no exact phase; p2pfm: 32 no reduction / stores, 64 three k-steps only, 128 every step re-reads the same vertices.
+zo_exact: 16 no work, 256 first two kept blocks of a row only, 512 every block reads the pair's first rows; p2pfm: 32 no reduction / stores, 64 three k-steps only, 128 every step re-reads the same vertices.
 DM_P2PFM_SHAPE: 1 = 8 slices for every size, 2 = one row block per wave for every size.
 usage: python tools/zo_experiment.py  (runs itself once per setting)"""
 import os
@@ -30,6 +30,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("DBG", os.environ.get("DM_ZO_DEBUG", "0"), "SHAPE", os.environ.get("DM_P2PFM_SHAPE", "0"),
           " ".join(f"{n}={1e3 * ms / c:.1f}us" for n, (c, ms) in rep.items() if c > 10), flush=True)
 else:
-    for dbg, shape in (("0", "0"), ("0", "4"), ("0", "5")):
+    # settings on the command line as dbg:shape tokens, e.g. 0:0 16:0 3:0
+    sets = [tuple(a.split(":")) for a in sys.argv[1:]] or (("0", "0"), ("0", "4"), ("0", "5"))
+    for dbg, shape in sets:
         env = dict(os.environ, DM_ZO_DEBUG=dbg, DM_P2PFM_SHAPE=shape)
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, check=False)
