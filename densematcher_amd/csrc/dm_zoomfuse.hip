@@ -102,6 +102,14 @@ __global__ __launch_bounds__(64 * ZE_NW, NRB <= 6 ? 4 : 2) void zo_embed_split_k
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) acc[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
     ZE_FETCH(0)
+    // the scales of the rows (known before the call: the previous iteration's maximum, the target operand's maxima) are fetched
+    // here, under the main loop, not in front of the epilogue that needs them
+    double sy = 1.0, sxy = 1.0;
+    if (!a.only_max) {
+        double mp = __longlong_as_double((long long)a.amax_prev[b]);
+        sy = ks_scale(&mp, 1);
+        sxy = ks_scale(a.amaxT + b * a.nT, a.nT) * sy;
+    }
     for (int s = 0; s < ((a.dbg & 4) ? 1 : ns); ++s) {
         double* Cw = Cs + (s & 1) * (NRB * 16 * ZE_LD);
 #pragma unroll
@@ -155,9 +163,6 @@ __global__ __launch_bounds__(64 * ZE_NW, NRB <= 6 ? 4 : 2) void zo_embed_split_k
     if (a.only_max || (a.dbg & 8)) return;
     __syncthreads();                                  // (the scratch area is reused below)
 
-    double mp = __longlong_as_double((long long)a.amax_prev[b]);
-    const double sy = ks_scale(&mp, 1);
-    const double sxy = ks_scale(a.amaxT + b * a.nT, a.nT) * sy;
     float bm = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
