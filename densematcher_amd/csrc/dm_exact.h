@@ -45,6 +45,16 @@ __device__ __forceinline__ void ks_exact_row(const ks_exact_args& a, int o, floa
         const int b = o / N2, i = o - b * N2;
         const double* A = AT ? AT + (long long)b * Kpad * N2pad + i : nullptr;
         const double* Bm = BT ? BT + (long long)b * Kpad * N1pad : nullptr;
+        // the block filter of the first 256 blocks (dm_simnn_keep with its three loads side by side: short-circuit evaluation made
+        // them three dependent round trips), requested before the target row: one round trip for both
+        auto keep_of = [&](int sbt) -> bool {
+            const int q = min((sbt * 32) / pw, nparts - 1);
+            const long long oq = ((long long)b * nparts + q) * Npad_s + i;
+            const float vs = qps[oq], vb = qpb[oq];
+            const int vj = qpj[oq];
+            return sbt < nsub && (vs >= thr || (vb >= thr && (vj >> 5) == sbt));
+        };
+        bool keep = keep_of(t);
         __syncthreads();
         if (Trow) { for (int r = t; r < K; r += 256) xrow[r] = (double)Trow[((long long)b * N2 + i) * ldrow + r]; }
         else { for (int r = t; r < K; r += 256) xrow[r] = A[(long long)r * N2pad]; }
@@ -55,8 +65,7 @@ __device__ __forceinline__ void ks_exact_row(const ks_exact_args& a, int o, floa
         // candidate blocks: one gather of the row's partials (256 blocks at a time), then only the blocks that can still
         // hold the optimum are visited, in ascending order (dm_simnn_keep)
         for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
-            const int sbt = sb0 + t;
-            const bool keep = sbt < nsub && dm_simnn_keep(qpb, qpj, qps, nparts, pw, Npad_s, b, i, sbt, thr);
+            if (sb0) keep = keep_of(sb0 + t);
             const unsigned long long km = __ballot(keep);
             if ((t & 63) == 0) cmask[t >> 6] = km;
             __syncthreads();

@@ -947,8 +947,9 @@ struct simnn_merge_sets { simnn_merge_set s[4]; };
 __global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_sets sets, float tau_scale, const int32_t* __restrict__ force_flag) {
     const simnn_merge_set& s = sets.s[blockIdx.z];
     const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= s.N) return;
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i0 < s.N;
+    const int i = valid ? i0 : s.N - 1;              // (lanes past the end repeat the last row and store nothing: the queue append below is per wave)
     float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
     int bj = DM_IDX_NONE;
     // (loads of eight partials ahead of their merges: the loop is a chain of L2 round trips otherwise)
@@ -969,17 +970,29 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_sets sets,
         top2_merge(bv, bj, sv, s.pb[o], s.pj[o], s.ps[o]);
     }
     const long long o = (long long)b * s.N + i;
-    if (s.zero_if && s.zero_if[o] == 0.0) { s.nn[o] = 0; return; }
-    s.nn[o] = (bj == DM_IDX_NONE) ? 0 : bj;
+    const bool zero = s.zero_if && s.zero_if[o] == 0.0;
     const float m = bv - sv;
-    if (s.best) s.best[o] = bv;
-    if (s.margin) s.margin[o] = m;
     const float tau = tau_scale * (sqrtf(s.norm2[o] * __uint_as_float(s.max2[b])) * (s.tau_mul ? s.tau_mul[b] : 1.0f) + (s.tau_add ? s.tau_add[b] : 0.0f));
     const bool forced = force_flag && force_flag[b] != 0;   // the caller could not bound the error for this pair: re-score everything
-    if (forced || !(m > tau)) {
-        const int pos = atomicAdd(s.flag_count, 1);
-        s.flag_list[pos] = (int32_t)o;
-        s.flag_thr[pos] = forced ? DM_NEG_INF_F32 : bv - tau;   // candidates scoring below this (in fp32) cannot be the float64 argmax
+    if (valid) {
+        s.nn[o] = (zero || bj == DM_IDX_NONE) ? 0 : bj;
+        if (!zero && s.best) s.best[o] = bv;
+        if (!zero && s.margin) s.margin[o] = m;
+    }
+    // queue of the rows to re-score: one atomic per wave that holds any (r04: one per flagged row -- thousands of returning atomics
+    // on one address per launch, served one after the other)
+    const bool flag = valid && !zero && (forced || !(m > tau));
+    const unsigned long long fm = __ballot(flag);
+    if (fm) {                                                     // uniform per wave
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(s.flag_count, __popcll(fm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (flag) {
+            const int pos = base + __popcll(fm & ((1ull << lane) - 1ull));
+            s.flag_list[pos] = (int32_t)o;
+            s.flag_thr[pos] = forced ? DM_NEG_INF_F32 : bv - tau;   // candidates scoring below this (in fp32) cannot be the float64 argmax
+        }
     }
 }
 
