@@ -191,10 +191,12 @@ class FunctionalMapping:
                 self.w_orient_rescaled = w_orient
                 fit_ops = self.compute_orientation_op(reversing=False, area="mass")
                 orient_ops = (np.stack([a for a, _ in fit_ops])[None], np.stack([b for _, b in fit_ops])[None])
+            self._verbose_terms(eng, dev, weights, x0, orient_ops, "x0")
             C, res = eng.fit_general(dev, weights, x0[None], maxiter=maxiter,
                                      lbfgs_options=LBFGS_OPTIONS if stopping == "tight" else None, driver=driver, orient_ops=orient_ops)
             self.FM = np.asarray(C[0], dtype=np.float64)
             self.fit_result = res
+            self._verbose_terms(eng, dev, weights, self.FM, orient_ops, "solution")
             if verbose:
                 print(f"\tTask funcall : {res.nfev}, nit : {res.nit}, warnflag : {res.message}")
         else:
@@ -207,6 +209,25 @@ class FunctionalMapping:
             self.FM = C[0].cpu().numpy()
         self.eta = np.ones(m2.eigenvectors.shape[0])                           # functional.py:483
         self._dev = dev
+
+    # the reference's per-term printout (base_functions.py:27-29, 538-636: `VERBOSE` in the environment prints every live term's
+    # weighted loss at every energy evaluation).  The optimiser runs on the device here, so the same lines are printed where the
+    # host sees the map: at the start point and at the solution.
+    _VERBOSE_LABELS = (("w_descr", "descr loss:"), ("w_lap", "lap loss:"), ("w_dcomm", "descr comm loss:"), ("w_orient", "orient loss:"),
+                       ("w_area", "area loss:"), ("w_conformal", "conformal loss:"), ("w_p2p", "p2p loss:"),
+                       ("w_stochastic", "stochastic loss:"), ("w_ent", "entropy loss:"), ("w_range01", "range01 loss:"),
+                       ("w_sumto1", "sumto1 loss:"))
+
+    def _verbose_terms(self, eng, dev, weights, x, orient_ops, where):
+        import os
+        if not os.environ.get("VERBOSE", False):
+            return
+        print(f"energy terms at the {where}:")
+        for name, label in self._VERBOSE_LABELS:
+            w = weights.get(name, 0)
+            if w > 0:
+                e = eng.fit_energy(dev, {name: w}, np.asarray(x)[None], orient_ops=orient_ops if name == "w_orient" else None)
+                print(label, float(e[0]))
 
     def compute_orientation_op(self, reversing=False, normalize=False, area="vertex"):
         """functional.py:686-728: per descriptor the pair (pinv1 O1 Phi1, +-pinv2 O2 Phi2) of orientation operators in the reduced

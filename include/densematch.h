@@ -81,8 +81,8 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *   "energy_keep_gram" 0 | 1   dm_fmap_energy_grad: 1 = keep what does not depend on C (A A^T, B A^T, the mass-weighted column sums
  *                           of the bases) from the next call and reuse it while the same A, B, Phi1, Phi2, mass1 pointers and sizes are
  *                           passed; the caller promises not to change their CONTENTS meanwhile (an optimiser's evaluations of one fit).  Setting the option (to any value) drops what is kept.
- *   "zoomout_fused" 1 | 0   dm_zoomout on meshes of at least 256 vertices, maps up to 208: four launches per iteration (embedding + split
- *                           rows, biased-key search, merge + exact, p2p_to_FM) | six (seven with the reduce) through K-major copies
+ *   "zoomout_fused" 1 | 0   dm_zoomout on meshes of at least 256 vertices, maps up to 208: five launches per iteration (embedding + split
+ *                           rows, biased-key search, merge, exact, p2p_to_FM) | six (seven with the reduce) through K-major copies
  *   "p2pfm_direct"  1 | 0   dm_p2p_to_fm (and the p2p_to_FM steps of dm_zoomout / dm_icp): register-resident tiles, operands straight
  *                           from global memory, fixed-order in-workgroup reduction | LDS-staged 64 x 64 tiles + split-K partials + reduce
  *   "simnn1_wt"     4 | 2   tile shape of the fused ZoomOut search: 8 waves, 256 x 256 | 4 waves, 128 x 256 (two workgroups per CU)

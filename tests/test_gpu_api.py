@@ -303,6 +303,33 @@ def test_fit_with_notebook_params(fx_cfg1, fx_cfg1_terms, oracle_cfg1_fits):
     assert Eg <= Er and np.abs(Gg).max() <= 1e-4 * max(1.0, abs(Eg))
 
 
+def test_fit_verbose_prints_the_reference_terms(fx_cfg1, monkeypatch, capsys):
+    """VERBOSE in the environment (reference base_functions.py:27-29, 538-636): every live term's weighted loss under the
+    reference's labels, at the start point and at the solution; the printed terms add up to the objective"""
+    from densematcher_amd.pyFM import FunctionalMapping
+    from densematcher_amd.engine import default_engine
+    fx = fx_cfg1
+    k = int(fx["k"])
+    monkeypatch.setenv("VERBOSE", "1")
+    model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
+    model.preprocess(n_ev=(k, k), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
+    model.fit(**NOTEBOOK)
+    out = capsys.readouterr().out
+    live = {n: v for n, v in NOTEBOOK.items() if n.startswith("w_") and v > 0}
+    labels = dict(model._VERBOSE_LABELS)
+    sol = out.split("energy terms at the solution:")[1]
+    vals = {}
+    for n in live:
+        assert out.count(labels[n]) == 2, (n, out)
+        vals[n] = float(sol.split(labels[n])[1].split()[0])
+    total = float(default_engine().fit_energy(model._dev, live, model.FM[None])[0])
+    print("VERBOSE terms at the solution:", vals, "sum", sum(vals.values()), "objective", total)
+    assert abs(sum(vals.values()) - total) <= 1e-9 * abs(total)
+    monkeypatch.delenv("VERBOSE")
+    model.fit(**NOTEBOOK)
+    assert "loss:" not in capsys.readouterr().out
+
+
 def test_fit_with_descriptor_commutativity(fx_cfg1, fx_cfg1_terms):
     """the pyFM default w_dcomm = 1 (all 128 descriptor operators): the bare model.fit(w_descr, w_lap) call of the reference"""
     from densematcher_amd.pyFM import FunctionalMapping

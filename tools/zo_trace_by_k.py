@@ -10,7 +10,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 per = defaultdict(list)
 for r in rows:
     n = r["Kernel_Name"]
-    for key in ("simnn_pipe_kernel", "zo_embed_split", "p2pfm_direct", "zo_merge_exact"):
+    for key in ("simnn_pipe_kernel", "zo_embed_split", "p2pfm_direct", "zo_merge", "zo_exact"):
         if key in n:
             per[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("# us per launch by iteration (last 150 launches of each kernel = the timed step; k = 50 + iteration)")
