@@ -368,7 +368,10 @@ struct KRowsStackedF32 {
 // stride to the second chunk is 0 when there is only one (its entries are then the stored values themselves).
 struct PartPair {
     float p0, p1;
-    __device__ __forceinline__ operator double() const { return (double)(float)((double)p0 + (double)p1); }
+    // (the fp32 sum IS float(double(p0) + double(p1)): the double sum of two floats is exact or rounds innocuously, 53 >= 2 * 24 + 2;
+    //  one fp32 add + one conversion instead of four float64-rate operations per staged element -- vector ALU work that float64
+    //  matrix instructions do not overlap with)
+    __device__ __forceinline__ operator double() const { return (double)(p0 + p1); }
 };
 struct KRowsStackedPart {
     typedef PartPair elem_t;

@@ -190,22 +190,23 @@ __global__ __launch_bounds__(256) void ks_build_kernel(const double* __restrict_
     }
 }
 
-// exact re-evaluation: one workgroup per queued row (dm_exact.h: ks_exact_row), grid-stride over the queue
-template <int KIND, typename TR>
-__device__ __forceinline__ void ks_exact_body(const ks_exact_args& a, int wg, int nwg) {
-    extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums + 32 scores
-    __shared__ unsigned long long cmask[4];
-    const int count = *a.q.flag_count;
-    for (int e = wg; e < count; e += nwg) ks_exact_row<KIND, TR, TR>(a, a.q.flag_list[e], a.q.flag_thr[e], xrow, cmask);
-}
-
-// one launch for up to four reductions of a pass: blockIdx.y selects the queue (and the value kind)
+// exact re-evaluation: one workgroup per queued row (dm_exact.h: ks_exact_row).  One launch serves up to four reductions of a pass
+// (gridDim.y = their number, each with its value kind); the workgroups stride over the CONCATENATION of the queues -- their
+// lengths differ by an order of magnitude (config 2: 0.07 - 0.9 % of the rows), and with one slice of the grid per queue the
+// longest one ran three rows per workgroup one after the other while the other slices idled.
 template <int K0, int K1, int K2 = 0, int K3 = 0, typename TR = double>
 __global__ __launch_bounds__(256) void ks_exact_kernel(ks_exact_args a0, ks_exact_args a1, ks_exact_args a2, ks_exact_args a3) {
-    if (blockIdx.y == 0) ks_exact_body<K0, TR>(a0, blockIdx.x, gridDim.x);
-    else if (blockIdx.y == 1) ks_exact_body<K1, TR>(a1, blockIdx.x, gridDim.x);
-    else if (blockIdx.y == 2) ks_exact_body<K2, TR>(a2, blockIdx.x, gridDim.x);
-    else ks_exact_body<K3, TR>(a3, blockIdx.x, gridDim.x);
+    extern __shared__ double xrow[];                 // K doubles + 8 x 32 partial sums + 32 scores
+    __shared__ unsigned long long cmask[4];
+    const int nq = gridDim.y;
+    const int c0 = *a0.q.flag_count, c1 = nq > 1 ? *a1.q.flag_count : 0, c2 = nq > 2 ? *a2.q.flag_count : 0, c3 = nq > 3 ? *a3.q.flag_count : 0;
+    const int total = c0 + c1 + c2 + c3, nwg = gridDim.x * gridDim.y;
+    for (int g = blockIdx.x + gridDim.x * blockIdx.y; g < total; g += nwg) {       // (uniform per workgroup)
+        if (g < c0) ks_exact_row<K0, TR, TR>(a0, a0.q.flag_list[g], a0.q.flag_thr[g], xrow, cmask);
+        else if (g < c0 + c1) ks_exact_row<K1, TR, TR>(a1, a1.q.flag_list[g - c0], a1.q.flag_thr[g - c0], xrow, cmask);
+        else if (g < c0 + c1 + c2) ks_exact_row<K2, TR, TR>(a2, a2.q.flag_list[g - c0 - c1], a2.q.flag_thr[g - c0 - c1], xrow, cmask);
+        else ks_exact_row<K3, TR, TR>(a3, a3.q.flag_list[g - c0 - c1 - c2], a3.q.flag_thr[g - c0 - c1 - c2], xrow, cmask);
+    }
 }
 
 static inline size_t ks_build_lds(int fill) { return (size_t)64 * (fill + 8) * sizeof(_Float16); }

@@ -952,6 +952,12 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_sets sets,
     const int i = valid ? i0 : s.N - 1;              // (lanes past the end repeat the last row and store nothing: the queue append below is per wave)
     float bv = DM_NEG_INF_F32, sv = DM_NEG_INF_F32;
     int bj = DM_IDX_NONE;
+    // (what the row's bound needs is requested before the partials, not behind them: one round trip less)
+    const long long o = (long long)b * s.N + i;
+    const bool zero = s.zero_if && s.zero_if[o] == 0.0;
+    const float rn2 = s.norm2[o], mx2 = __uint_as_float(s.max2[b]);
+    const float tmul = s.tau_mul ? s.tau_mul[b] : 1.0f, tadd = s.tau_add ? s.tau_add[b] : 0.0f;
+    const bool forced = force_flag && force_flag[b] != 0;   // the caller could not bound the error for this pair: re-score everything
     // (loads of eight partials ahead of their merges: the loop is a chain of L2 round trips otherwise)
     int q = 0;
     for (; q + 8 <= s.nparts; q += 8) {
@@ -959,21 +965,18 @@ __global__ __launch_bounds__(256) void simnn_merge_kernel(simnn_merge_sets sets,
         int vj[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const long long o = ((long long)b * s.nparts + q + u) * s.Npad + i;
-            vb[u] = s.pb[o]; vj[u] = s.pj[o]; vs[u] = s.ps[o];
+            const long long op = ((long long)b * s.nparts + q + u) * s.Npad + i;
+            vb[u] = s.pb[op]; vj[u] = s.pj[op]; vs[u] = s.ps[op];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) top2_merge(bv, bj, sv, vb[u], vj[u], vs[u]);
     }
     for (; q < s.nparts; ++q) {
-        const long long o = ((long long)b * s.nparts + q) * s.Npad + i;
-        top2_merge(bv, bj, sv, s.pb[o], s.pj[o], s.ps[o]);
+        const long long op = ((long long)b * s.nparts + q) * s.Npad + i;
+        top2_merge(bv, bj, sv, s.pb[op], s.pj[op], s.ps[op]);
     }
-    const long long o = (long long)b * s.N + i;
-    const bool zero = s.zero_if && s.zero_if[o] == 0.0;
     const float m = bv - sv;
-    const float tau = tau_scale * (sqrtf(s.norm2[o] * __uint_as_float(s.max2[b])) * (s.tau_mul ? s.tau_mul[b] : 1.0f) + (s.tau_add ? s.tau_add[b] : 0.0f));
-    const bool forced = force_flag && force_flag[b] != 0;   // the caller could not bound the error for this pair: re-score everything
+    const float tau = tau_scale * (sqrtf(rn2 * mx2) * tmul + tadd);
     if (valid) {
         s.nn[o] = (zero || bj == DM_IDX_NONE) ? 0 : bj;
         if (!zero && s.best) s.best[o] = bv;
@@ -1020,43 +1023,54 @@ __global__ __launch_bounds__(256) void simnn_fixup_kernel(const _Float16* __rest
         const float thr = flag_thr[e];
         const int b = o / N2, i = o - b * N2;
         const _Float16* tr = Ftgt + ((long long)b * N2 + i) * D;
+        // A flagged row is a chain of dependent round trips, not arithmetic: the block filter of the first 256 blocks (dm_simnn_keep
+        // with its three loads side by side) is requested together with the target row, and a kept block's loads are all in flight
+        // at once (up to twelve 16-byte pieces per lane: D <= 768 in one round; r04: three dependent loads for the filter, four
+        // pieces per round).
+        const int nsub = nparts * (pw / 32);
+        auto keep_of = [&](int sbt) -> bool {
+            const int q = min((sbt * 32) / pw, nparts - 1);
+            const long long oq = ((long long)b * nparts + q) * N2pad + i;
+            const float vs = qps[oq], vb = qpb[oq];
+            const int vj = qpj[oq];
+            return sbt < nsub && (vs >= thr || (vb >= thr && (vj >> 5) == sbt));
+        };
+        bool keep = keep_of((int)threadIdx.x);
         __syncthreads();
         for (int k = threadIdx.x; k < D; k += 256) trow[k] = (double)tr[k];
-        __syncthreads();
         double bv = -DM_INF_F64;
         int bj = DM_IDX_NONE;
-        // candidate blocks: one gather of the row's partials (256 blocks at a time), then only the blocks that can still
-        // hold the arg-max are visited, in ascending order
-        const int nsub = nparts * (pw / 32);
+        // candidate blocks: only the blocks that can still hold the arg-max are visited, in ascending order
         for (int sb0 = 0; sb0 < nsub; sb0 += 256) {
-            const int sbt = sb0 + (int)threadIdx.x;
-            const bool keep = sbt < nsub && dm_simnn_keep(qpb, qpj, qps, nparts, pw, N2pad, b, i, sbt, thr);
+            if (sb0) keep = keep_of(sb0 + (int)threadIdx.x);
             const unsigned long long km = __ballot(keep);
             if (lane == 0) cmask[wave] = km;
-            __syncthreads();
+            __syncthreads();                                      // (also: trow is complete)
             for (int w = 0; w < 4; ++w) {
                 unsigned long long mm = cmask[w];                 // uniform
                 while (mm) {
                     const int sb = sb0 + w * 64 + __ffsll((long long)mm) - 1;
                     mm &= mm - 1;
                     const int j = sb * 32 + cand;
+                    const _Float16* sr = Fsrc + ((long long)b * N1 + min(j, N1 - 1)) * D;
                     double sacc = 0.0;
-                    if (j < N1) {
-                        const _Float16* sr = Fsrc + ((long long)b * N1 + j) * D;
-                        int k = part * 8;                              // D % 8 == 0 is guaranteed by the caller
-                        for (; k + 192 < D; k += 256) {                // four loads ahead of their (ordered) fma chains
-                            f16x8 v[4];
+                    // pieces k = 8 part, + 64, ... of the candidate's row, NV at a time (D % 8 == 0 is guaranteed by the caller; a
+                    // piece past the row re-reads the lane's first piece and is not added)
+                    constexpr int NV = 12;
+                    for (int k0 = part * 8; k0 < D; k0 += 64 * NV) {
+                        f16x8 v[NV];
 #pragma unroll
-                            for (int w4 = 0; w4 < 4; ++w4) v[w4] = *reinterpret_cast<const f16x8*>(sr + k + 64 * w4);
-#pragma unroll
-                            for (int w4 = 0; w4 < 4; ++w4)
-#pragma unroll
-                                for (int u = 0; u < 8; ++u) sacc = fma((double)v[w4][u], trow[k + 64 * w4 + u], sacc);
+                        for (int w4 = 0; w4 < NV; ++w4) {
+                            const int k = k0 + 64 * w4;
+                            v[w4] = *reinterpret_cast<const f16x8*>(sr + (k < D ? k : part * 8));
                         }
-                        for (; k < D; k += 64) {
-                            const f16x8 v = *reinterpret_cast<const f16x8*>(sr + k);
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) sacc = fma((double)v[u], trow[k + u], sacc);
+                        for (int w4 = 0; w4 < NV; ++w4) {
+                            const int k = k0 + 64 * w4;
+                            if (k < D) {
+#pragma unroll
+                                for (int u = 0; u < 8; ++u) sacc = fma((double)v[w4][u], trow[k + u], sacc);
+                            }
                         }
                     }
                     sacc += __shfl_xor(sacc, 1);
