@@ -65,7 +65,10 @@ template int dm_zo_absmax_rows<double>(dm_ctx*, int, int, int, const double*, in
 // through two LDS stages, one barrier per stage).  A row is complete inside one wave: norm, maximum, split and all three
 // stores need no exchange beyond the wave.
 constexpr int ZE_LD = 18;                               // LDS row stride of the C stage (f64): conflict-free fragment reads
-constexpr int ZE_NW = 8;                                // waves per workgroup (16 vertices each); 4 (two or three workgroups per CU) measured 3 % slower
+#ifndef ZE_NW_DEF
+#define ZE_NW_DEF 8
+#endif
+constexpr int ZE_NW = ZE_NW_DEF;                        // waves per workgroup (16 vertices each); 4 (two or three workgroups per CU) measured 3 % slower
 static inline size_t zo_embed_lds(int NRB) { return (size_t)2 * NRB * 16 * ZE_LD * 8 + ZE_NW * 1024; }
 
 template <typename TR, int NRB>

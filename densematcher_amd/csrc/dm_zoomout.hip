@@ -56,8 +56,9 @@ static int fm_split(int B, int N2, int k1, int k2) {
 // tiles up through LDS in a FIXED order at the end (no split-K partials in HBM, no reduce launch, no atomics: the sum of
 // a pair is the same in every batch and every run).  All workgroups of a pair run on one XCD (block b -> XCD b % 8) and
 // walk the vertices in step, so every row of Phi1 / Phi2 is fetched into that XCD's L2 once per slice position.
-//   tiles: 1 row block x up to 7 column blocks and S = 8 slices while the map has at most 7 x 7 blocks (k <= 112: more,
-//   lighter waves), else 2 row blocks x up to 5 column blocks, S = 4.
+//   S = 8 slices while the map has at most 7 x 7 blocks (k <= 112: more, lighter waves), else 4; the tile of a wave (1 x c, 2 x c,
+//   3 x 5, 5 x 3, 6 x 3 ... blocks) is chosen per launch by a cost model of the batch (launch_p2pfm_direct): it decides who
+//   computes an entry, not in which order its terms are added.
 template <typename TR>
 struct p2pfm_args {
     const TR* Phi1; long long s1; int ld1; int N1;

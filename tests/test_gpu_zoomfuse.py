@@ -1,5 +1,5 @@
 """
-GPU (-m gpu): the fused ZoomOut iteration (csrc/dm_zoomfuse.hip: embedding + split rows, biased-key search, merge + exact) and the
+GPU (-m gpu): the fused ZoomOut iteration (csrc/dm_zoomfuse.hip: embedding + split rows, biased-key search, merge, exact) and the
 direct p2p_to_FM kernel (csrc/dm_zoomout.hip: p2pfm_direct_kernel) against the six-launch loop they replace (dm_set_option
 "zoomout_fused" / "p2pfm_direct" = 0) and against the oracle (oracle/dm_oracle.py: zoomout_refine, p2p_to_fm; reference
 pyFM/refine/zoomout.py:7-44, pyFM/spectral/convert.py:14-51).  Vertex maps bit-exact, C within 1e-11.
@@ -62,11 +62,34 @@ def test_p2p_to_fm_direct_kernel(eng, N1, N2, k1, k2, dt):
     assert np.array_equal(Cc, Cr)
 
 
+@pytest.mark.parametrize("k", [64, 100, 144, 160, 176, 192, 200])
+def test_p2p_to_fm_tile_shape_follows_the_batch_result_does_not(eng, k):
+    """the direct kernel picks its tile (R x C blocks per wave: 1 x c, 2 x c, 3 x 5, 5 x 3, 6 x 3 ...) from a cost model of the batch:
+    the same pair inside batches of 1, 2, 9, 16, 33 and 64 pairs (different shapes, different numbers of workgroups per CU) gives the
+    same bits, equal to the oracle's to rounding"""
+    rng = np.random.default_rng(k)
+    N1, N2, Bmax = 384, 512, 64
+    Phi1 = (rng.standard_normal((Bmax, N1, k)) * 0.1)
+    Phi2 = (rng.standard_normal((Bmax, N2, k + 2)) * 0.1)
+    a2 = rng.uniform(0.5, 1.5, (Bmax, N2))
+    p = rng.integers(0, N1, (Bmax, N2)).astype(np.int32)
+    Co = orc.p2p_to_fm(p[0], Phi1[0][:, :k], Phi2[0][:, :k], a2[0])
+    ref = None
+    for B in (1, 2, 9, 16, 33, 64):
+        C = _np(eng.p2p_to_fm(p[:B], Phi1[:B], Phi2[:B], a2[:B], k, k))
+        assert np.abs(C[0] - Co).max() <= 1e-12 * max(1.0, np.abs(Co).max())
+        if ref is None:
+            ref = C[0]
+        assert np.array_equal(C[0], ref), B
+        if B > 1:
+            assert np.abs(C[B - 1] - orc.p2p_to_fm(p[B - 1], Phi1[B - 1][:, :k], Phi2[B - 1][:, :k], a2[B - 1])).max() <= 1e-12
+
+
 @pytest.mark.parametrize("nu,nv,k0,nit,step,dt,B", [(32, 16, 10, 8, 3, np.float32, 3), (32, 16, 60, 6, 5, np.float64, 2),
                                                    (40, 25, 20, 12, 4, np.float64, 2), (64, 32, 50, 30, 5, np.float64, 2),
                                                    (64, 32, 190, 4, 4, np.float32, 2), (24, 11, 3, 5, 1, np.float64, 2)])
 def test_zoomout_fused_equals_unfused_and_oracle(eng, nu, nv, k0, nit, step, dt, B):
-    """the four-launch iteration against the six-launch one (same vertex maps; C to rounding: the embedding and p2p_to_FM sum in
+    """the fused (five-launch) iteration against the six-launch one (same vertex maps; C to rounding: the embedding and p2p_to_FM sum in
     other orders) and the oracle, on aligned (N = 512, 2048) and padded (N = 1000, 264) sizes, depths below the tile kernel's
     minimum (k < 65: zero-padded rows) and up to 206, fp32 and float64 bases"""
     kmax = k0 + nit * step
