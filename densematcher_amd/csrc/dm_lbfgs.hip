@@ -402,3 +402,21 @@ extern "C" int dm_lbfgs_result(dm_ctx* ctx, int B, int n, int m, const void* sta
     DM_LAUNCH(ctx, "lbfgs_result", lbfgs_result_kernel, dim3(B), dim3(256), 0, n, B, L.x, L.sc, L.ic, x, f, info);
     return DM_OK;
 }
+
+// nsteps x (energy + gradient at the trial points -> advance): the evaluation loop of a fit on the library side of the ABI
+extern "C" int dm_fmap_fit_steps(dm_ctx* ctx, int nsteps, int B, int N1, int N2, int k1, int k2, int D, const float* Phi1, int ld1,
+                                 const float* Phi2, int ld2, const float* mass1, const float* A, const float* Bm, const double* lam1,
+                                 const double* lam2, const double* ops1, const double* ops2, int n_ops, const double* weights, int m,
+                                 void* state, double* x_trial, double* energy, double* grad, double ftol, double pgtol, int maxiter,
+                                 int maxfun, int maxls) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, nsteps > 0 && state && x_trial && energy && grad, "fit_steps: null pointer or no steps");
+    for (int s = 0; s < nsteps; ++s) {
+        int rc = dm_fmap_energy_grad(ctx, B, N1, N2, k1, k2, D, Phi1, ld1, Phi2, ld2, mass1, A, Bm, lam1, lam2, ops1, ops2, n_ops, weights,
+                                     x_trial, energy, grad);
+        if (rc) return rc;
+        rc = dm_lbfgs_advance(ctx, B, k2 * k1, m, state, energy, grad, x_trial, ftol, pgtol, maxiter, maxfun, maxls);
+        if (rc) return rc;
+    }
+    return DM_OK;
+}

@@ -26,6 +26,10 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class _KeepAlive(tuple):
+    """an argument tuple that also holds the tensors its raw pointers refer to"""
+
+
 class MatchEngine:
     def __init__(self, device=None, lib_path=None):
         if not torch.cuda.is_available():
@@ -258,6 +262,17 @@ class MatchEngine:
     def energy_grad(self, Cm, A, Bm, lam1, lam2, weights, Phi1=None, Phi2=None, a1=None, ops1=None, ops2=None):
         """Energy (B,) and gradient (B,k2,k1) of the functional-map objective for the weights in `weights` (dict with keys
         of WEIGHT_ORDER; reference energy_func_std / grad_energy_std, base_functions.py:480-763)."""
+        ev = self._energy_grad_args(Cm, A, Bm, lam1, lam2, weights, Phi1, Phi2, a1, ops1, ops2)
+        Cm = ev[-1]
+        B, k2, k1 = Cm.shape
+        energy = torch.empty((B,), dtype=torch.float64, device=self.device)
+        grad = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_fmap_energy_grad(self.ctx, *ev[:-1], _ptr(Cm), _ptr(energy), _ptr(grad)))
+        return energy, grad
+
+    def _energy_grad_args(self, Cm, A, Bm, lam1, lam2, weights, Phi1=None, Phi2=None, a1=None, ops1=None, ops2=None):
+        """the argument list dm_fmap_energy_grad and dm_fmap_fit_steps share (B ... weights), followed by the map tensor; the tensors
+        behind the pointers are kept alive by the tuple"""
         Cm = self._dev(Cm, torch.float64, "C")
         A = self._dev(A, torch.float32, "A")
         Bm = self._dev(Bm, torch.float32, "Bm")
@@ -285,12 +300,11 @@ class MatchEngine:
             n_ops = ops1.shape[1]
             if ops1.shape != (B, n_ops, k1, k1) or ops2.shape != (B, n_ops, k2, k2):
                 raise ValueError("energy_grad: descriptor operators must be (B,D,k1,k1) and (B,D,k2,k2)")
-        energy = torch.empty((B,), dtype=torch.float64, device=self.device)
-        grad = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
-        self._chk(self.lib.dm_fmap_energy_grad(self.ctx, B, N1, N2, k1, k2, D, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(A),
-                                               _ptr(Bm), _ptr(lam1), _ptr(lam2), _ptr(ops1), _ptr(ops2), n_ops,
-                                               C.cast(w, C.c_void_p), _ptr(Cm), _ptr(energy), _ptr(grad)))
-        return energy, grad
+        keep = (Phi1, Phi2, a1, A, Bm, lam1, lam2, ops1, ops2, w)
+        args = _KeepAlive((B, N1, N2, k1, k2, D, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1), _ptr(lam2),
+                           _ptr(ops1), _ptr(ops2), n_ops, C.cast(w, C.c_void_p), Cm))
+        args.keep = keep
+        return args
 
     # SciPy's L-BFGS-B defaults, i.e. what the reference's `minimize(..., options={'maxiter': maxiter})` runs with (functional.py:477)
     LBFGS_REFERENCE = {"maxcor": 10, "ftol": 2.220446049250313e-09, "gtol": 1e-5, "maxfun": 15000, "maxls": 20}
@@ -383,15 +397,18 @@ class MatchEngine:
         nev, maxfun = 0, int(opts["maxfun"])
         # the projected descriptors A, Bm are fixed during the fit: their Gram blocks are computed by the first evaluation only
         self.set_option("energy_keep_gram", 1)
+        # the evaluation loop itself runs behind the ABI, `check_every` evaluations per call (dm_fmap_fit_steps): a Python round per
+        # evaluation cost more host time than the evaluation takes on the device for one small pair
+        ev = self._energy_grad_args(xt, A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
+        energy = torch.empty((B,), dtype=torch.float64, device=self.device)
+        grad = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
         try:
             while True:
-                e, g = self.energy_grad(xt, A, Bm, lam1, lam2, weights, P1, P2, a1, ops1, ops2)
-                self._chk(self.lib.dm_lbfgs_advance(self.ctx, B, n, m, _ptr(state), _ptr(e), _ptr(g), _ptr(xt), float(opts["ftol"]),
-                                                    float(opts["gtol"]), int(maxiter), maxfun, int(opts["maxls"])))
-                nev += 1
-                if nev % check_every == 0 or nev > maxfun + 2:
-                    if bool((ints[:, 0] != 0).all()) or nev > maxfun + 2:    # (one host synchronisation per check_every evaluations)
-                        break
+                self._chk(self.lib.dm_fmap_fit_steps(self.ctx, int(check_every), *ev[:-1], m, _ptr(state), _ptr(xt), _ptr(energy), _ptr(grad),
+                                                     float(opts["ftol"]), float(opts["gtol"]), int(maxiter), maxfun, int(opts["maxls"])))
+                nev += int(check_every)
+                if bool((ints[:, 0] != 0).all()) or nev > maxfun + 2:        # (one host synchronisation per check_every evaluations)
+                    break
         finally:
             self.set_option("energy_keep_gram", 0)
         xo = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)

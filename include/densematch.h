@@ -221,6 +221,17 @@ int dm_lbfgs_init(dm_ctx* ctx, int B, int n, int m, const double* x0, void* stat
 int dm_lbfgs_advance(dm_ctx* ctx, int B, int n, int m, void* state, const double* energy, const double* grad, double* x_trial,
                      double ftol, double pgtol, int maxiter, int maxfun, int maxls);
 int dm_lbfgs_result(dm_ctx* ctx, int B, int n, int m, const void* state, double* x, double* f, int32_t* info);
+/* `nsteps` rounds of (dm_fmap_energy_grad at x_trial -> dm_lbfgs_advance) without returning to the caller in between: the loop
+ * of one scipy.optimize.minimize call (pyFM/functional.py:477), nsteps evaluations at a time.  `energy` (B) and `grad` (B,k2,k1)
+ * are scratch the caller owns; x_trial (B,k2,k1) is the trial point dm_lbfgs_init / the last advance left.  Pairs that have
+ * stopped are not moved by further steps.  (A Python loop around the two calls costs more host time per evaluation than the
+ * evaluation takes on the device for one small pair.) */
+int dm_fmap_fit_steps(dm_ctx* ctx, int nsteps, int B, int N1, int N2, int k1, int k2, int D,
+                      const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass1,
+                      const float* A, const float* Bm, const double* lam1, const double* lam2,
+                      const double* ops1 /*nullable*/, const double* ops2 /*nullable*/, int n_ops,
+                      const double* weights /*host, 10*/, int m, void* state, double* x_trial, double* energy, double* grad,
+                      double ftol, double pgtol, int maxiter, int maxfun, int maxls);
 
 /* ops[b][d] = Phi[b][:, :k]^T diag(mass[b] * F[b][:, d]) Phi[b][:, :k]   (B, D, k, k) fp64: the multiplication operator
  * of descriptor d in the reduced basis.  Replaces commute_left / commute_right of base_functions.py:550-555

@@ -714,6 +714,11 @@ def test_fit_general_batched_device_lbfgs(fx_cfg1, oracle_cfg1_fits):
     assert np.abs(Cr[0] - C3[0]).max() <= 2e-3 and rr.nfev[0] < r3.nfev[0]
     with pytest.raises(ValueError):
         eng.fit_general(batch, w, np.stack([x0] * 3), driver="scipy")
+    # the evaluation loop behind the ABI (dm_fmap_fit_steps): one evaluation per call, four, or seven -- the same iterates, the same
+    # counters (rounds past a pair's stop do not move it)
+    for ce in (1, 7):
+        Cc, rc_ = eng.fit_general(batch, w, np.stack([x0] * 3), lbfgs_options=tight, check_every=ce)
+        assert np.array_equal(Cc, C3) and np.array_equal(rc_.nit, r3.nit) and np.array_equal(rc_.nfev, r3.nfev), ce
 
 
 def test_zoomout_with_farthest_point_subsample_from_the_model(fx_cfg1):
