@@ -877,7 +877,12 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
 
     OutScaled out{PQ, (long long)(k1 + k2) * k1, k1, w_descr, Timg, (long long)(NB * (NB + 1) / 2) * 256, k1};
     dim3 grid(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
-    DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D);
+    switch (dm_knob("DM_GRAM_NPRE", 2)) {           // experiments: stages of operand loads in flight (96 -> 71 us with the uniform fast path of the operand functors; 1 / 2 / 3 / 4 stages: 73.5 / 71.4 / 73.6 / 75.1)
+        case 1: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 1>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
+        case 4: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 4>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
+        case 3: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 3>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
+        default: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 2>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
+    }
 
     if (two_phase) {
         const int NBr = NB - NA;

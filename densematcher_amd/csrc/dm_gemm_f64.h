@@ -15,6 +15,14 @@
 // Operand functors stage their data in the type it has in memory (`elem_t`, default double): the conversion to float64
 // happens when the staged registers are written to LDS one stage later.  Converting inside load8 would make every fetch
 // wait for its own data (s_waitcnt right behind the load) instead of overlapping the matrix instructions of the stage.
+// Optional FAST form of an NT operand functor: `bool fast_ok(int K, int rows_used) const` (uniform: every 8-wide piece of the
+// product's K range is a whole, aligned vector inside the operand, and the product does not read rows past the operand as zeros),
+// `load8_fast` (no branch, no select: rows past the operand repeat the last one -- their result entries are not stored) and
+// `cvt(const elem_t&, int row)` (what depends on the row is applied when the staged element is written to LDS, not behind the
+// load).  Why: load8's "vector or element-wise" decision depends on the thread's k0, so the compiler emits both paths under exec
+// masks and waits vmcnt(0) where they join -- every prefetch was waited for on the spot (r04, found in the Gram kernel's ISA).
+template <class T, class = void> struct dm_has_fast { static constexpr bool value = false; };
+template <class T> struct dm_has_fast<T, std::void_t<decltype(&T::fast_ok)>> { static constexpr bool value = true; };
 template <class T, class = void> struct dm_elem { typedef double type; };
 template <class T> struct dm_elem<T, std::void_t<typename T::elem_t>> { typedef typename T::elem_t type; };
 typedef __attribute__((address_space(1))) const f32x4 dm_gf32x4;      // global address space: global_load, not flat_load
@@ -69,7 +77,73 @@ constexpr int NT_T = 64;     // tile
 constexpr int NT_BK = 32;    // k per stage
 constexpr int NT_LD = 34;    // padded LDS row stride (f64): 2*34 = 68 = 4 (mod 64) dwords -> conflict-free b64 reads
 
-template <class OpA, class OpB, class Out>
+// NPRE: stages of operand loads in flight (register sets).  1 = the next stage is requested while the current one is multiplied:
+// a stage is 32 matrix instructions per wave (~1 us), a global round trip ~2 us, so short products (K = 128: four stages) and
+// staged conversions wait for their operands every stage; NPRE = 3 - 4 keeps that many stages in flight (the loads past the last
+// stage re-read it: unconditional, so the compiler counts them instead of waiting for all).  Same sums in the same order.
+template <bool FAST, class Op>
+__device__ __forceinline__ void nt_load8(const Op& op, int b, int row, int k0, typename dm_elem<Op>::type (&v)[8]) {
+    if constexpr (FAST) op.load8_fast(b, row, k0, v); else op.load8(b, row, k0, v);
+}
+template <bool FAST, class Op>
+__device__ __forceinline__ double nt_cvt(const Op& op, const typename dm_elem<Op>::type& x, int row) {
+    if constexpr (FAST) return op.cvt(x, row); else return (double)x;
+}
+template <bool FAST, int NPRE, class OpA, class OpB>
+__device__ __forceinline__ void gemm_nt_body(const OpA& opa, const OpB& opb, int b, int i0, int j0, int K, double* As, double* Bs,
+                                             f64x4 (&acc)[2][2]) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = t >> 2, lk = (t & 3) * 8;
+    typename dm_elem<OpA>::type ra[NPRE][8];
+    typename dm_elem<OpB>::type rb[NPRE][8];
+    const int ns = (K + NT_BK - 1) / NT_BK;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+        const int sl = (NPRE == 1 || u < ns) ? u : ns - 1;
+        nt_load8<FAST>(opa, b, i0 + lrow, sl * NT_BK + lk, ra[u]);
+        nt_load8<FAST>(opb, b, j0 + lrow, sl * NT_BK + lk, rb[u]);
+    }
+    for (int s0 = 0; s0 < ns; s0 += NPRE) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) {
+            const int s = s0 + u;
+            if (s < ns) {                                          // (uniform)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    As[lrow * NT_LD + lk + e] = nt_cvt<FAST>(opa, ra[u][e], i0 + lrow);
+                    Bs[lrow * NT_LD + lk + e] = nt_cvt<FAST>(opb, rb[u][e], j0 + lrow);
+                }
+                __syncthreads();
+                if (NPRE > 1 || s + 1 < ns) {
+                    const int sl = s + NPRE < ns ? s + NPRE : ns - 1;
+                    nt_load8<FAST>(opa, b, i0 + lrow, sl * NT_BK + lk, ra[u]);
+                    nt_load8<FAST>(opb, b, j0 + lrow, sl * NT_BK + lk, rb[u]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < NT_BK / 4; ++ks) {
+                    const int kk = ks * 4 + (lane >> 4);
+                    double a[2], bb[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) a[mt] = As[(wm * 32 + mt * 16 + (lane & 15)) * NT_LD + kk];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) bb[nt] = Bs[(wn * 32 + nt * 16 + (lane & 15)) * NT_LD + kk];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// NPRE: stages of operand loads in flight (register sets).  1 = the next stage is requested while the current one is multiplied:
+// a stage is 32 matrix instructions per wave (~1 us), a global round trip ~2 us, so short products (K = 128: four stages) wait
+// for their operands every stage; NPRE = 2 - 4 keeps that many stages in flight (the loads past the last stage re-read it:
+// unconditional, so the compiler counts them instead of waiting for all).  Same sums in the same order.
+template <class OpA, class OpB, class Out, int NPRE = 1>
 __global__ __launch_bounds__(256) void gemm_nt_f64(OpA opa, OpB opb, Out out, int M, int N, int K) {
     __shared__ double As[NT_T * NT_LD];
     __shared__ double Bs[NT_T * NT_LD];
@@ -79,7 +153,6 @@ __global__ __launch_bounds__(256) void gemm_nt_f64(OpA opa, OpB opb, Out out, in
     const int i0 = ti * NT_T, j0 = tj * NT_T;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int lrow = t >> 2, lk = (t & 3) * 8;
 
     f64x4 acc[2][2];
 #pragma unroll
@@ -87,36 +160,11 @@ __global__ __launch_bounds__(256) void gemm_nt_f64(OpA opa, OpB opb, Out out, in
 #pragma unroll
         for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    typename dm_elem<OpA>::type ra[8];
-    typename dm_elem<OpB>::type rb[8];
-    const int ns = (K + NT_BK - 1) / NT_BK;
-    opa.load8(b, i0 + lrow, lk, ra);
-    opb.load8(b, j0 + lrow, lk, rb);
-    for (int s = 0; s < ns; ++s) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            As[lrow * NT_LD + lk + e] = (double)ra[e];
-            Bs[lrow * NT_LD + lk + e] = (double)rb[e];
-        }
-        __syncthreads();
-        if (s + 1 < ns) {
-            opa.load8(b, i0 + lrow, (s + 1) * NT_BK + lk, ra);
-            opb.load8(b, j0 + lrow, (s + 1) * NT_BK + lk, rb);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NT_BK / 4; ++ks) {
-            const int kk = ks * 4 + (lane >> 4);
-            double a[2], bb[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[mt] = As[(wm * 32 + mt * 16 + (lane & 15)) * NT_LD + kk];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bb[nt] = Bs[(wn * 32 + nt * 16 + (lane & 15)) * NT_LD + kk];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_f64_16x16x4(a[mt], bb[nt], acc[mt][nt]);
-        }
-        __syncthreads();
+    if constexpr (dm_has_fast<OpA>::value && dm_has_fast<OpB>::value) {
+        if (opa.fast_ok(K, M) && opb.fast_ok(K, N)) gemm_nt_body<true, NPRE>(opa, opb, b, i0, j0, K, As, Bs, acc);   // (uniform)
+        else gemm_nt_body<false, NPRE>(opa, opb, b, i0, j0, K, As, Bs, acc);
+    } else {
+        gemm_nt_body<false, NPRE>(opa, opb, b, i0, j0, K, As, Bs, acc);
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -372,11 +420,27 @@ struct PartPair {
     //  one fp32 add + one conversion instead of four float64-rate operations per staged element -- vector ALU work that float64
     //  matrix instructions do not overlap with)
     __device__ __forceinline__ operator double() const { return (double)(p0 + p1); }
+    __device__ __forceinline__ double sum(bool two) const { return (double)(two ? p0 + p1 : p0); }
 };
 struct KRowsStackedPart {
     typedef PartPair elem_t;
     const float* A; const float* Bm; long long nA, nB;     // second chunk of A at A + nA (= B k1 D; 0: none), of Bm at Bm + nB
     int k1, k2, D;
+    __device__ __forceinline__ bool fast_ok(int K, int rows_used) const {
+        return ((K + NT_BK - 1) / NT_BK) * NT_BK <= D && (D & 3) == 0 && (((((uintptr_t)A) | ((uintptr_t)Bm)) & 15) == 0) && ((nA | nB) & 3) == 0 &&
+               rows_used <= k1 + k2;
+    }
+    __device__ __forceinline__ void load8_fast(int b, int row, int k0, PartPair (&v)[8]) const {
+        const int rc = min(row, k1 + k2 - 1);
+        const bool isA = rc < k1;
+        const float* r = isA ? A + ((long long)b * k1 + rc) * D : Bm + ((long long)b * k2 + (rc - k1)) * D;
+        const long long nq = isA ? nA : nB;                // (0: the second load re-reads the first chunk; cvt ignores it)
+        const f32x4 a0 = *(dm_gf32x4*)(r + k0), a1 = *(dm_gf32x4*)(r + k0 + 4);
+        const f32x4 b0 = *(dm_gf32x4*)(r + nq + k0), b1 = *(dm_gf32x4*)(r + nq + k0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = PartPair{a0[e], b0[e]}; v[4 + e] = PartPair{a1[e], b1[e]}; }
+    }
+    __device__ __forceinline__ double cvt(const PartPair& x, int row) const { return x.sum((min(row, k1 + k2 - 1) < k1 ? nA : nB) != 0); }
     __device__ __forceinline__ void load8(int b, int row, int k0, PartPair (&v)[8]) const {
         const bool in = row < k1 + k2;
         const int rc = in ? row : 0;
@@ -404,6 +468,17 @@ struct KRowsStackedPart {
 struct KRowsPart {                                         // the rows of A alone (the second operand of the Gram product)
     typedef PartPair elem_t;
     const float* A; long long nA; int k1, D;               // nA: stride to the second chunk, 0: none
+    __device__ __forceinline__ bool fast_ok(int K, int rows_used) const {
+        return ((K + NT_BK - 1) / NT_BK) * NT_BK <= D && (D & 3) == 0 && ((((uintptr_t)A) & 15) == 0) && (nA & 3) == 0 && rows_used <= k1;
+    }
+    __device__ __forceinline__ void load8_fast(int b, int row, int k0, PartPair (&v)[8]) const {
+        const float* r = A + ((long long)b * k1 + min(row, k1 - 1)) * D;
+        const f32x4 a0 = *(dm_gf32x4*)(r + k0), a1 = *(dm_gf32x4*)(r + k0 + 4);
+        const f32x4 b0 = *(dm_gf32x4*)(r + nA + k0), b1 = *(dm_gf32x4*)(r + nA + k0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = PartPair{a0[e], b0[e]}; v[4 + e] = PartPair{a1[e], b1[e]}; }
+    }
+    __device__ __forceinline__ double cvt(const PartPair& x, int) const { return x.sum(nA != 0); }
     __device__ __forceinline__ void load8(int b, int row, int k0, PartPair (&v)[8]) const {
         const bool in = row < k1;
         const float* r = A + ((long long)b * k1 + min(row, k1 - 1)) * D;
@@ -430,6 +505,16 @@ struct KRowsPart {                                         // the rows of A alon
 // K-contiguous rows of a float64 matrix (B, nrows, ld); `trans` reads element (row,k) at p[k*ld + row]
 struct KRowsF64 {
     const double* p; long long stride_b; int ld; int nrows; int ncols; int trans;
+    __device__ __forceinline__ bool fast_ok(int K, int rows_used) const {
+        return !trans && ((K + NT_BK - 1) / NT_BK) * NT_BK <= ncols && ((ld & 1) == 0) && ((stride_b & 1) == 0) && ((((uintptr_t)p) & 15) == 0) &&
+               rows_used <= nrows;
+    }
+    __device__ __forceinline__ void load8_fast(int b, int row, int k0, double (&v)[8]) const {
+        const f64x2* q = reinterpret_cast<const f64x2*>(p + b * stride_b + (long long)min(row, nrows - 1) * ld + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const f64x2 x = q[e]; v[2 * e] = x[0]; v[2 * e + 1] = x[1]; }
+    }
+    __device__ __forceinline__ double cvt(const double& x, int) const { return x; }
     __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const {
         const double* base = p + b * stride_b;
         if (!trans && row < nrows && k0 + 7 < ncols && ((ld & 1) == 0) && ((stride_b & 1) == 0) && ((((uintptr_t)p) & 15) == 0)) {
