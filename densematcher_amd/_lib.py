@@ -43,6 +43,8 @@ SIGNATURES = {
     "dm_lbfgs_result": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "dm_fmap_fit_steps": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p, _p, _p, _p,
                                _d, _d, _i, _i, _i]),
+    "dm_fmap_fit_fused_ok": (_i, [_i, _i, _p, _i]),
+    "dm_fmap_fit_fused": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _d, _d, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dm_fmap_descr_ops": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
     "dm_fm_to_p2p": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_fm_to_p2p_uses_split": (_i, [_p, _i, _i, _i]),

@@ -1,0 +1,593 @@
+// The iterative fit of small functional maps (k1, k2 <= 32) with ONE launch per energy evaluation (dm_fmap_fit_fused).
+//
+// Reference computation replaced: the loop of scipy.optimize.minimize(method = "L-BFGS-B") around energy_func_std / grad_energy_std
+// in FunctionalMapping.fit (pyFM/functional.py:352-487, 477; pyFM/optimize/base_functions.py:480-763) for the terms
+//   w_descr, w_lap (:31-121), w_p2p (:296), w_ent (:363), w_range01 (:374), w_sumto1 (:387; eta == 1, v = None)
+// -- the notebook's call (example.ipynb cell 11: n_ev = 15, w_descr, w_lap, w_ent, w_sumto1).  The multi-launch path
+// (dm_fmap_energy_grad + dm_lbfgs_advance, six launches per evaluation) stays for every other combination of terms and sizes.
+//
+// Why a different formulation for small maps.  With k1 = 15 the two products around the element-wise terms of the mapped
+// indicator M = (Phi2 C) (a1 Phi1)^T are 15 fused multiply-adds each per entry; the float64 matrix cores have the vector ALU's
+// float64 rate on this part and do not overlap with it, so staging tiles for them only adds LDS traffic and barriers.  Here a
+// LANE owns a row i of M (E2_i = Phi2_i C in registers), the rows Psi_j = a1_j Phi1_j of the other factor arrive through the
+// SCALAR cache (wave-uniform address: s_load, no vector memory instruction and no LDS in the loop), and per entry the lane runs
+//   m = E2_i . Psi_j  ->  energy e(m), derivative d = e'(m)  ->  Y_i += d Psi_j
+// on the vector ALU.  log and the reciprocal are short in-line sequences valid on the clamped range [1e-10, 1 + 1e-10] of the
+// entropy term's argument (no special cases).  The sum-to-one term is linear in M before it is squared, so it is a quadratic form
+// in C with two centred k x k Gram matrices computed once per fit (below): no N2 x N1 work at all.
+//
+// Decomposition (by the sizes only, never by the batch: a pair's bits do not depend on the batch it is in).  A UNIT is 64 rows x
+// 128 columns of M (a workgroup of four waves, 32 columns each); its result is a partial (k2 x k1) gradient Phi2_R^T Y_R (the four
+// waves' Y summed in wave order, then contracted on the float64 matrix cores) and a partial energy.  Eight consecutive units are
+// a CHUNK (summed in unit order), the chunks of a pair are summed in chunk order.  Small batches run one unit per workgroup, large
+// ones several whole chunks per workgroup -- the tree of additions is the same.  The last workgroup to deliver (a counter per
+// chunk and per pair, release / acquire at agent scope) adds up, evaluates the O(k^3) terms and advances that pair's L-BFGS
+// (lb_advance_pair): nobody waits for anybody, so a launch cannot hang, and finished pairs cost nothing (their workgroups leave
+// at once).  The host enqueues a few launches back to back and reads the status words in between.
+#include "dm_gemm_f64.h"
+#include "dm_internal.h"
+#include "dm_energy_dev.h"
+#include "dm_lbfgs_dev.h"
+
+constexpr int FF_ROWS = 64;        // rows of a unit (one per lane)
+constexpr int FF_WCOLS = 32;       // columns per wave
+constexpr int FF_COLS = 128;       // columns of a unit
+constexpr int FF_CHUNK = 8;        // units per chunk
+constexpr int FF_LDT = 65;         // LDS row stride (doubles) of the transposed 64-row panels: b64 reads of 16 rows x 4 columns conflict-free
+constexpr int FF_KMAX = 32;
+constexpr int FF_SUMS = 2 * FF_KMAX + 2 * FF_KMAX * FF_KMAX;     // per pair: p | s2 | G1c | G2c
+
+struct ff_params {
+    int B, N1, N2, k1, k2, n;
+    int N1pad, ncc, nrb, nU, nchunks;
+    int unit_mode, W, wg_per_pair;
+    const float* Phi2; int ld2;
+    double* xt;                                 // (B, k2, k1) trial maps: read by everyone at the start, advanced by the pair's last workgroup
+    double* unit_part; double* chunk_part;      // (B, nU, n + 1) [unit mode], (B, nchunks, n + 1): gradient entries, then the energy
+    int* chunk_cnt; int* pair_cnt;
+    double w_ent, w_p2p, w_r01, w_sum;
+    quad_args qa;
+    const double* sums;
+    double* energy; double* grad;
+    int advance; lbfgs_opts lo; lb_layout L;
+};
+
+// log(y) for y in [1e-10, 1 + 1e-10] (normal, positive: no special cases): y = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1),
+// log m = 2 s (1 + s^2 / 3 + s^4 / 5 + ...); |s| <= 0.1716, the series is cut behind s^18 / 19 (next term: 8e-18 absolute)
+__device__ __forceinline__ double ff_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double ff_log(double y) {
+    int e = __builtin_amdgcn_frexp_exp(y);
+    double m = __builtin_amdgcn_frexp_mant(y);                    // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0, den = 2.0 + f;
+    const double r = ff_rcp(den);
+    double s = f * r;
+    s = fma(fma(-den, s, f), r, s);
+    const double z = s * s;
+    double p = 2.0 / 19.0;
+    p = fma(p, z, 2.0 / 17.0); p = fma(p, z, 2.0 / 15.0); p = fma(p, z, 2.0 / 13.0); p = fma(p, z, 2.0 / 11.0);
+    p = fma(p, z, 2.0 / 9.0); p = fma(p, z, 2.0 / 7.0); p = fma(p, z, 2.0 / 5.0); p = fma(p, z, 2.0 / 3.0);
+    const double lm = fma(s * z, p, s + s);
+    return fma((double)e, 0.693147180559945309417, lm);
+}
+
+// energy and derivative of the element-wise indicator terms at the entry m (base_functions.py:296-428)
+template <bool GENERAL>
+__device__ __forceinline__ double ff_element(double m, double w_ent, double w_p2p, double w_r01, double& eacc) {
+    double d = 0.0;
+    if (!GENERAL || w_ent > 0.0) {
+        const double c = fmin(fmax(m, 0.0), 1.0);
+        const double y = c + 1e-10;
+        const double lg = ff_log(y);
+        eacc = fma(w_ent, -c * lg, eacc);
+        const double inv = ff_rcp(y);
+        const double dd = w_ent * (-lg - c * inv);
+        d = (m >= 0.0 && m <= 1.0) ? dd : 0.0;                    // torch.clamp passes the gradient on [0, 1]
+    }
+    if (GENERAL) {
+        if (w_p2p > 0.0) { const double q = m * m - m; eacc = fma(w_p2p * q, q, eacc); d = fma(w_p2p * 2.0 * q, 2.0 * m - 1.0, d); }
+        if (w_r01 > 0.0) {
+            const double lo = fmax(-m, 0.0), hi = fmax(m - 1.0, 0.0);
+            eacc = fma(w_r01, lo * lo + hi * hi, eacc);
+            d = fma(w_r01, 2.0 * hi - 2.0 * lo, d);
+        }
+    }
+    return d;
+}
+
+// wave sum in a fixed order (butterfly over lane distances 32 ... 1): every lane gets the total
+__device__ __forceinline__ double ff_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int KL1, int K2P, bool GENERAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ? 4 : 2, KL1 <= 16 ? 4 : 2))) void ff_eval_kernel(const ff_params p, const double* __restrict__ Psi) {
+    constexpr int KT1 = (KL1 + 15) / 16 * 16, T1 = KT1 / 16, T2 = K2P / 16;
+    extern __shared__ __attribute__((aligned(16))) double ff_sm[];
+    double* Cs = ff_sm;                              // [K2P][KL1]      the trial map, zero padded
+    double* P2s = Cs + K2P * KL1;                    // [K2P][FF_LDT]   Phi2 rows of the row block, (a, i)
+    double* Ysum = P2s + K2P * FF_LDT;               // [KT1][FF_LDT]   the four waves' Y added up, (c, i)
+    double* Ysh = Ysum + KT1 * FF_LDT;               // [2][KT1][64]    two waves' Y, (c, i);  later  Dsh [4][T2 * T1][256]
+    double* Dsh = Ysh;
+    __shared__ double esh[4];
+    __shared__ double sh4[4];
+    __shared__ int s_flag;
+    __shared__ double s_u[FF_KMAX], s_q[FF_KMAX], s_gu[FF_KMAX], s_gq[FF_KMAX];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vid / p.wg_per_pair, w = vid - b * p.wg_per_pair;
+    if (p.advance && p.L.ic[(long long)b * LI_NINT + LI_STATUS] != LB_RUN) return;
+    const int k1 = p.k1, k2 = p.k2, n = p.n, np1 = p.n + 1;
+    {
+        const double* xb = p.xt + (long long)b * n;
+        for (int e = t; e < K2P * KL1; e += 256) {
+            const int a = e / KL1, c = e - a * KL1;
+            Cs[e] = (a < k2 && c < k1) ? xb[a * k1 + c] : 0.0;
+        }
+        for (int e = t; e < KT1 * FF_LDT; e += 256) Ysum[e] = 0.0;          // (the padding columns c >= KL1 of Ysum stay zero)
+    }
+    __syncthreads();
+    int u_begin, u_end, ch_begin, ch_end;
+    if (p.unit_mode) { u_begin = w; u_end = w + 1; ch_begin = w / FF_CHUNK; ch_end = ch_begin + 1; }
+    else { ch_begin = w * p.W; ch_end = min(ch_begin + p.W, p.nchunks); u_begin = ch_begin * FF_CHUNK; u_end = min(ch_end * FF_CHUNK, p.nU); }
+    double acc[T2][T1];
+#pragma unroll
+    for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+        for (int tc = 0; tc < T1; ++tc) acc[ta][tc] = 0.0;
+    double eacc_chunk = 0.0;                           // (thread 0)
+    double E2[KL1];
+    int rb_prev = -1;
+    for (int u = u_begin; u < u_end; ++u) {
+        const int rb = u / p.ncc, cc = u - rb * p.ncc;
+        if (rb != rb_prev) {
+            // this lane's row of Phi2 and of E2 = Phi2 C; the row block's Phi2 panel for the contraction (each wave a quarter of it)
+            const int i = rb * FF_ROWS + lane;
+            const float* row = p.Phi2 + ((long long)b * p.N2 + (i < p.N2 ? i : 0)) * p.ld2;
+            float x[K2P];
+#pragma unroll
+            for (int a = 0; a < K2P; ++a) x[a] = (a < k2 && i < p.N2) ? row[a] : 0.f;
+#pragma unroll
+            for (int a = 0; a < K2P; ++a)
+                if (a / (K2P / 4) == wave) P2s[a * FF_LDT + lane] = (double)x[a];
+#pragma unroll
+            for (int c = 0; c < KL1; ++c) E2[c] = 0.0;
+#pragma unroll
+            for (int a = 0; a < K2P; ++a) {
+                const double xa = (double)x[a];
+#pragma unroll
+                for (int c = 0; c < KL1; ++c) E2[c] = fma(xa, Cs[a * KL1 + c], E2[c]);
+            }
+            rb_prev = rb;
+        }
+        // ---- the unit's entries: 32 columns per wave, Psi rows through the scalar cache
+        double Y[KL1];
+#pragma unroll
+        for (int c = 0; c < KL1; ++c) Y[c] = 0.0;
+        double eacc = 0.0;
+        const double* psi = Psi + ((long long)b * p.N1pad + cc * FF_COLS + wave * FF_WCOLS) * KL1;
+#pragma unroll 2
+        for (int jj = 0; jj < FF_WCOLS; ++jj) {
+            double ps[KL1];
+#pragma unroll
+            for (int c = 0; c < KL1; ++c) ps[c] = psi[jj * KL1 + c];
+            double m = 0.0;
+#pragma unroll
+            for (int c = 0; c < KL1; ++c) m = fma(E2[c], ps[c], m);
+            const double d = ff_element<GENERAL>(m, p.w_ent, p.w_p2p, p.w_r01, eacc);
+#pragma unroll
+            for (int c = 0; c < KL1; ++c) Y[c] = fma(d, ps[c], Y[c]);
+        }
+        // ---- unit epilogue: (Y0 + Y1) + (Y2 + Y3) through two LDS panels -> Ysum -> Phi2_R^T Ysum on the matrix cores (each wave 16 of
+        //      the 64 rows) -> the unit's partial
+        {
+            const double es = ff_wave_sum(eacc);
+            if (lane == 0) esh[wave] = es;
+        }
+        if (wave & 1) {
+#pragma unroll
+            for (int c = 0; c < KL1; ++c) Ysh[((wave >> 1) * KT1 + c) * 64 + lane] = Y[c];
+        }
+        __syncthreads();
+        if (!(wave & 1)) {
+#pragma unroll
+            for (int c = 0; c < KL1; ++c) Y[c] += Ysh[((wave >> 1) * KT1 + c) * 64 + lane];
+            if (wave == 2) {                        // (its own panel: the reads above are this wave's, in order)
+#pragma unroll
+                for (int c = 0; c < KL1; ++c) Ysh[(1 * KT1 + c) * 64 + lane] = Y[c];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int c = 0; c < KL1; ++c) Ysum[c * FF_LDT + lane] = Y[c] + Ysh[(1 * KT1 + c) * 64 + lane];
+        }
+        __syncthreads();
+        f64x4 Dm[T2][T1];
+#pragma unroll
+        for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+            for (int tc = 0; tc < T1; ++tc) Dm[ta][tc] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i = 16 * wave + 4 * s + (lane >> 4);
+            double ao[T2], bo[T1];
+#pragma unroll
+            for (int ta = 0; ta < T2; ++ta) ao[ta] = P2s[(ta * 16 + (lane & 15)) * FF_LDT + i];
+#pragma unroll
+            for (int tc = 0; tc < T1; ++tc) bo[tc] = Ysum[(tc * 16 + (lane & 15)) * FF_LDT + i];
+#pragma unroll
+            for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+                for (int tc = 0; tc < T1; ++tc) Dm[ta][tc] = mfma_f64_16x16x4(ao[ta], bo[tc], Dm[ta][tc]);
+        }
+#pragma unroll
+        for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+            for (int tc = 0; tc < T1; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Dsh[((wave * T2 + ta) * T1 + tc) * 256 + r * 64 + lane] = Dm[ta][tc][r];
+        __syncthreads();
+        // thread t owns entry (a, c) = (ta 16 + (lane >> 4) + 4 (t >> 6), tc 16 + (lane & 15)) of every 16 x 16 tile
+        double uv[T2][T1];
+#pragma unroll
+        for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+            for (int tc = 0; tc < T1; ++tc)
+                uv[ta][tc] = ((Dsh[((0 * T2 + ta) * T1 + tc) * 256 + t] + Dsh[((1 * T2 + ta) * T1 + tc) * 256 + t]) + Dsh[((2 * T2 + ta) * T1 + tc) * 256 + t]) +
+                             Dsh[((3 * T2 + ta) * T1 + tc) * 256 + t];
+        const double eu = (t == 0) ? ((esh[0] + esh[1]) + esh[2]) + esh[3] : 0.0;
+        __syncthreads();                               // (Dsh aliases Ysh: the next unit writes it)
+        if (p.unit_mode) {
+            double* up = p.unit_part + ((long long)b * p.nU + u) * np1;
+#pragma unroll
+            for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+                for (int tc = 0; tc < T1; ++tc) {
+                    const int a = ta * 16 + (lane >> 4) + 4 * (t >> 6), c = tc * 16 + (lane & 15);
+                    if (a < k2 && c < k1) up[a * k1 + c] = uv[ta][tc];
+                }
+            if (t == 0) up[n] = eu;
+        } else {
+#pragma unroll
+            for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+                for (int tc = 0; tc < T1; ++tc) acc[ta][tc] += uv[ta][tc];
+            eacc_chunk += eu;
+            if (((u + 1) % FF_CHUNK) == 0 || u + 1 == u_end) {
+                double* cp = p.chunk_part + ((long long)b * p.nchunks + u / FF_CHUNK) * np1;
+#pragma unroll
+                for (int ta = 0; ta < T2; ++ta)
+#pragma unroll
+                    for (int tc = 0; tc < T1; ++tc) {
+                        const int a = ta * 16 + (lane >> 4) + 4 * (t >> 6), c = tc * 16 + (lane & 15);
+                        if (a < k2 && c < k1) cp[a * k1 + c] = acc[ta][tc];
+                        acc[ta][tc] = 0.0;
+                    }
+                if (t == 0) cp[n] = eacc_chunk;
+                eacc_chunk = 0.0;
+            }
+        }
+    }
+    // ---- hand in.  Unit mode: the chunk's last unit adds the chunk up (unit order, from zero: the additions of the other mode)
+    int done = ch_end - ch_begin;
+    if (p.unit_mode) {
+        const int ch = ch_begin, u0 = ch * FF_CHUNK, nu = min(FF_CHUNK, p.nU - u0);
+        __threadfence();
+        __syncthreads();
+        if (t == 0) s_flag = (atomicAdd(p.chunk_cnt + (long long)b * p.nchunks + ch, 1) + 1 == nu) ? 1 : 0;
+        __syncthreads();
+        if (!s_flag) return;
+        __threadfence();
+        const double* up = p.unit_part + ((long long)b * p.nU + u0) * np1;
+        double* cp = p.chunk_part + ((long long)b * p.nchunks + ch) * np1;
+        for (int e = t; e < np1; e += 256) {
+            double v[FF_CHUNK];
+#pragma unroll
+            for (int q = 0; q < FF_CHUNK; ++q) v[q] = q < nu ? up[(long long)q * np1 + e] : 0.0;
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < FF_CHUNK; ++q) if (q < nu) s += v[q];
+            cp[e] = s;
+        }
+        if (t == 0) p.chunk_cnt[(long long)b * p.nchunks + ch] = 0;
+        done = 1;
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_flag = (atomicAdd(p.pair_cnt + b, done) + done == p.nchunks) ? 1 : 0;
+    __syncthreads();
+    if (!s_flag) return;
+    __threadfence();
+    if (t == 0) p.pair_cnt[b] = 0;
+    // ---- the pair's last workgroup: chunk partials in chunk order, the O(k^3) terms, the optimiser
+    double gm[4] = {0.0, 0.0, 0.0, 0.0};
+    double em = 0.0;
+    {
+        const double* cp = p.chunk_part + (long long)b * p.nchunks * np1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q;
+            if (e < n) {
+                double s = 0.0;
+                int ch = 0;
+                for (; ch + 8 <= p.nchunks; ch += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) v[z] = cp[(long long)(ch + z) * np1 + e];
+#pragma unroll
+                    for (int z = 0; z < 8; ++z) s += v[z];
+                }
+                for (; ch < p.nchunks; ++ch) s += cp[(long long)ch * np1 + e];
+                gm[q] = s;
+            }
+        }
+        if (t == 0) for (int ch = 0; ch < p.nchunks; ++ch) em += cp[(long long)ch * np1 + n];
+    }
+    double* gradb = p.grad + (long long)b * n;
+    const double eq = quad_pair(p.qa, b, t, k1, k2, p.grad, sh4);
+    // sum-to-one term: w [ (C p)^T G2c (C p) + (C^T s2)^T G1c (C^T s2) ]   (rs = Phi2 C p, cs = Psi C^T s2; centred Gram matrices)
+    double es = 0.0;
+    const double* sm = p.sums + (long long)b * FF_SUMS;
+    if (p.w_sum > 0.0) {                               // (uniform)
+        const double* pv = sm; const double* s2 = sm + FF_KMAX;
+        const double* G1 = sm + 2 * FF_KMAX; const double* G2 = G1 + FF_KMAX * FF_KMAX;
+        if (t < k2) { double s = 0.0; for (int c = 0; c < k1; ++c) s = fma(Cs[t * KL1 + c], pv[c], s); s_u[t] = s; }
+        if (t >= 64 && t < 64 + k1) { const int c = t - 64; double s = 0.0; for (int a = 0; a < k2; ++a) s = fma(Cs[a * KL1 + c], s2[a], s); s_q[c] = s; }
+        __syncthreads();
+        if (t < k2) { double s = 0.0; for (int a = 0; a < k2; ++a) s = fma(G2[t * FF_KMAX + a], s_u[a], s); s_gu[t] = s; }
+        if (t >= 64 && t < 64 + k1) { const int c = t - 64; double s = 0.0; for (int a = 0; a < k1; ++a) s = fma(G1[c * FF_KMAX + a], s_q[a], s); s_gq[c] = s; }
+        __syncthreads();
+        if (t == 0) {
+            double s = 0.0;
+            for (int a = 0; a < k2; ++a) s = fma(s_u[a], s_gu[a], s);
+            for (int c = 0; c < k1; ++c) s = fma(s_q[c], s_gq[c], s);
+            es = p.w_sum * s;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q;
+            if (e < n) { const int a = e / k1, c = e - a * k1; gm[q] += 2.0 * p.w_sum * (s_gu[a] * pv[c] + s2[a] * s_gq[c]); }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = t + 256 * q;
+        if (e < n) gradb[e] = (e % k1 == 0) ? 0.0 : gradb[e] + gm[q];                // base_functions.py:759
+    }
+    if (t == 0) p.energy[b] = eq + em + es;
+    if (!p.advance) return;
+    __syncthreads();
+    lb_advance_pair<LB_FAST_M_FUSED>(b, n, p.lo, p.energy, p.grad, p.xt, p.L.x, p.L.g, p.L.d, p.L.S, p.L.Y, p.L.rho, p.L.sc, p.L.ic, p.L.al);
+}
+
+// Psi[b][j][c] = a1_j Phi1[j][c]  (float64; zero for j >= N1 and c >= k1)
+__global__ __launch_bounds__(256) void ff_psi_kernel(const float* __restrict__ Phi1, int ld1, const float* __restrict__ mass1, int N1, int N1pad,
+                                                     int k1, int KL1, long long total, double* __restrict__ Psi) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % KL1);
+    const long long r = e / KL1;
+    const int j = (int)(r % N1pad);
+    const long long b = r / N1pad;
+    Psi[e] = (j < N1 && c < k1) ? (double)mass1[b * N1 + j] * (double)Phi1[(b * N1 + j) * ld1 + c] : 0.0;
+}
+
+// Column sums and centred Gram matrix of the rows X_i (i < N) of one factor: blockIdx.y = 0: X = Psi (-> p, G1c), 1: X = Phi2 (-> s2, G2c).
+//   sums[c] = sum_i X[i][c] (eight interleaved partial sums, added in order);   G[a][c] = sum_i (X[i][a] - sums[a] / N)(X[i][c] - sums[c] / N)
+__global__ __launch_bounds__(256) void ff_sums_kernel(const double* __restrict__ Psi, int N1pad, int KL1, int N1, int k1,
+                                                      const float* __restrict__ Phi2, int ld2, int N2, int k2, double* __restrict__ sums) {
+    __shared__ double part[8][FF_KMAX];
+    __shared__ double mean[FF_KMAX];
+    __shared__ double Xs[64][FF_KMAX + 1];
+    const int b = blockIdx.x, which = blockIdx.y, t = threadIdx.x;
+    const int N = which ? N2 : N1, k = which ? k2 : k1;
+    double* out = sums + (long long)b * FF_SUMS;
+    double* osum = out + (which ? FF_KMAX : 0);
+    double* G = out + 2 * FF_KMAX + (which ? FF_KMAX * FF_KMAX : 0);
+    auto X = [&](int i, int c) -> double {
+        return which ? (double)Phi2[((long long)b * N2 + i) * ld2 + c] : Psi[((long long)b * N1pad + i) * KL1 + c];
+    };
+    {
+        const int c = t & 31, rl = t >> 5;
+        double s = 0.0;
+        if (c < k) for (int i = rl; i < N; i += 8) s += X(i, c);
+        part[rl][c] = s;
+        __syncthreads();
+        if (t < FF_KMAX) {
+            double a = 0.0;
+            for (int r = 0; r < 8; ++r) a += part[r][t];
+            osum[t] = t < k ? a : 0.0;
+            mean[t] = t < k ? a / (double)N : 0.0;
+        }
+        __syncthreads();
+    }
+    const int a = t >> 3, c0 = (t & 7) * 4;
+    double g[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        for (int e = t; e < 64 * FF_KMAX; e += 256) {
+            const int r = e >> 5, c = e & 31;
+            Xs[r][c] = (i0 + r < N && c < k) ? X(i0 + r, c) - mean[c] : 0.0;
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; ++r) {
+            const double xa = Xs[r][a];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = fma(xa, Xs[r][c0 + q], g[q]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) G[a * FF_KMAX + c0 + q] = g[q];
+}
+
+__global__ __launch_bounds__(256) void ff_result_kernel(int n, const double* __restrict__ x, const double* __restrict__ sc, const int* __restrict__ ic,
+                                                        double* __restrict__ xo, double* __restrict__ fo, int32_t* __restrict__ info) {
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < n; e += 256) xo[(long long)b * n + e] = x[(long long)b * n + e];
+    if (threadIdx.x == 0) {
+        fo[b] = sc[(long long)b * LS_NSCAL + LS_F];
+        const int* icb = ic + (long long)b * LI_NINT;
+        info[4 * b] = icb[LI_STATUS]; info[4 * b + 1] = icb[LI_ITER]; info[4 * b + 2] = icb[LI_NFEV]; info[4 * b + 3] = icb[LI_NHIST];
+    }
+}
+
+template <int KL1, int K2P>
+static size_t ff_lds_bytes() {
+    constexpr int KT1 = (KL1 + 15) / 16 * 16;
+    constexpr size_t panels = (size_t)2 * KT1 * 64, dsh = (size_t)4 * (K2P / 16) * (KT1 / 16) * 256;
+    return ((size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8;
+}
+
+template <int KL1, int K2P>
+static int ff_launch(dm_ctx* ctx, const ff_params& p, const double* Psi, bool general) {
+    const size_t lds = ff_lds_bytes<KL1, K2P>();
+    const dim3 grid(p.B * p.wg_per_pair);
+    if (general) {
+        int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, true>, lds);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "fit_fused_eval", (ff_eval_kernel<KL1, K2P, true>), grid, dim3(256), lds, p, Psi);
+    } else {
+        int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, false>, lds);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "fit_fused_eval", (ff_eval_kernel<KL1, K2P, false>), grid, dim3(256), lds, p, Psi);
+    }
+    return DM_OK;
+}
+static int ff_dispatch(dm_ctx* ctx, const ff_params& p, const double* Psi, int KL1, int K2P, bool general) {
+#define FF_CASE(A_, B_) if (KL1 == A_ && K2P == B_) return ff_launch<A_, B_>(ctx, p, Psi, general);
+    FF_CASE(16, 16) FF_CASE(24, 16) FF_CASE(32, 16) FF_CASE(16, 32) FF_CASE(24, 32) FF_CASE(32, 32)
+#undef FF_CASE
+    return dm_fail(ctx, DM_EINVAL, "fit_fused: no instantiation for KL1 = %d, K2P = %d", KL1, K2P);
+}
+
+extern "C" int dm_fmap_fit_fused_ok(int k1, int k2, const double* weights /*host, 10*/, int n_ops) {
+    if (!weights || k1 < 1 || k2 < 1 || k1 > FF_KMAX || k2 > FF_KMAX) return 0;
+    // weights: w_descr, w_lap, w_dcomm, w_p2p, w_stochastic, w_ent, w_range01, w_sumto1, w_area, w_conformal
+    if ((weights[2] > 0.0 && n_ops > 0) || weights[4] > 0.0 || weights[8] > 0.0 || weights[9] > 0.0) return 0;
+    return (weights[3] > 0.0 || weights[5] > 0.0 || weights[6] > 0.0 || weights[7] > 0.0) ? 1 : 0;
+}
+
+extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D, const float* Phi1, int ld1, const float* Phi2,
+                                 int ld2, const float* mass1, const float* A, const float* Bm, const double* lam1, const double* lam2,
+                                 const double* weights, int m, const double* x0, double ftol, double pgtol, int maxiter, int maxfun,
+                                 int maxls, double* x_out, double* f_out, int32_t* info_out, double* grad_out, int* evaluations_out) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && N1 > 0 && N2 > 0 && k1 > 0 && k2 > 0 && D > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && A && Bm && lam1 && lam2 && weights && x0 && f_out, "null pointer");
+    DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than k");
+    DM_REQUIRE(ctx, dm_fmap_fit_fused_ok(k1, k2, weights, 0), "fit_fused: maps up to 32 x 32 with w_p2p / w_ent / w_range01 / w_sumto1 (and w_descr, w_lap) only");
+    const bool eval_only = maxfun <= 0;
+    DM_REQUIRE(ctx, eval_only ? (grad_out != nullptr) : (x_out && info_out && m > 0 && m <= 64), "fit_fused: outputs");
+    for (int q = 0; q < 10; ++q) DM_REQUIRE(ctx, weights[q] >= 0.0, "weights must be >= 0");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const int n = k2 * k1, np1 = n + 1;
+    const int KL1 = k1 <= 16 ? 16 : (k1 <= 24 ? 24 : 32), K2P = k2 <= 16 ? 16 : 32;
+    ff_params p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.N1 = N1; p.N2 = N2; p.k1 = k1; p.k2 = k2; p.n = n;
+    p.ncc = dm_cdiv(N1, FF_COLS); p.nrb = dm_cdiv(N2, FF_ROWS); p.N1pad = p.ncc * FF_COLS;
+    p.nU = p.nrb * p.ncc; p.nchunks = dm_cdiv(p.nU, FF_CHUNK);
+    // one unit per workgroup while that keeps the launch small; else W whole chunks per workgroup, W chosen for the fewest rounds of
+    // resident workgroups x chunks per workgroup (the element loop holds ~140 registers and the LDS panels of a unit: four
+    // workgroups per CU for maps up to 16 x 16), the largest such W (fewer recomputed rows of Phi2 C, fewer hand-ins)
+    if ((long long)B * p.nU <= 4096) { p.unit_mode = 1; p.W = 0; p.wg_per_pair = p.nU; }
+    else {
+        const int KT1 = (KL1 + 15) / 16 * 16;
+        const size_t panels = (size_t)2 * KT1 * 64, dsh = (size_t)4 * (K2P / 16) * (KT1 / 16) * 256;
+        const size_t lds = ((size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8 + 2048;
+        int per_cu = (int)((160 * 1024) / lds);
+        const int by_regs = KL1 <= 16 ? 4 : 2;                        // (maps up to 16 columns: 128 registers, four waves per SIMD)
+        per_cu = per_cu < 1 ? 1 : (per_cu > by_regs ? by_regs : per_cu);
+        const long long slots = (long long)(ctx->n_cu > 0 ? ctx->n_cu : 256) * per_cu;
+        long long best = -1;
+        p.unit_mode = 0; p.W = 1;
+        for (int W = 1; W <= p.nchunks; ++W) {
+            const long long grid = (long long)B * dm_cdiv(p.nchunks, W);
+            const long long cost = ((grid + slots - 1) / slots) * W;
+            if (best < 0 || cost <= best) { best = cost; p.W = W; }
+        }
+        p.wg_per_pair = dm_cdiv(p.nchunks, p.W);
+    }
+    DM_REQUIRE(ctx, (long long)B * p.wg_per_pair < (1ll << 31), "batch too large for one launch");
+    const size_t bPsi = (size_t)B * p.N1pad * KL1 * 8, bSums = (size_t)B * FF_SUMS * 8, bPQ = (size_t)B * (k1 + k2) * k1 * 8;
+    const size_t bUnit = p.unit_mode ? (size_t)B * p.nU * np1 * 8 : 0, bChunk = (size_t)B * p.nchunks * np1 * 8;
+    const size_t bCnt = (size_t)B * (p.nchunks + 1) * 4, bState = eval_only ? 0 : lb_state_bytes(B, n, m);
+    int rc = dm_ws_reserve(ctx, dm_align_up(bPsi) + dm_align_up(bSums) + dm_align_up(bPQ) + dm_align_up(bUnit) + dm_align_up(bChunk) + dm_align_up(bCnt) +
+                                    dm_align_up(bState) + 3 * dm_align_up((size_t)B * n * 8) + 2 * dm_align_up((size_t)B * 8) + 65536);
+    if (rc) return rc;
+    double* Psi = (double*)dm_ws_take(ctx, bPsi);
+    double* sums = (double*)dm_ws_take(ctx, bSums);
+    double* PQ = (double*)dm_ws_take(ctx, bPQ);
+    double* unit_part = p.unit_mode ? (double*)dm_ws_take(ctx, bUnit) : nullptr;
+    double* chunk_part = (double*)dm_ws_take(ctx, bChunk);
+    int* cnt = (int*)dm_ws_take(ctx, bCnt);
+    void* state = eval_only ? nullptr : dm_ws_take(ctx, bState);
+    double* xt = (double*)dm_ws_take(ctx, (size_t)B * n * 8);
+    double* grad = (double*)dm_ws_take(ctx, (size_t)B * n * 8);
+    double* energy = (double*)dm_ws_take(ctx, (size_t)B * 8);
+    if (!Psi || !sums || !PQ || (p.unit_mode && !unit_part) || !chunk_part || !cnt || (!eval_only && !state) || !xt || !grad || !energy)
+        return dm_fail(ctx, DM_ENOMEM, "fit_fused: workspace not reserved");
+    // ---- once per fit: Psi, the basis sums and centred Gram matrices, P = A A^T, Q = Bm A^T
+    {
+        const long long total = (long long)B * p.N1pad * KL1;
+        DM_LAUNCH(ctx, "fit_fused_psi", ff_psi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, Phi1, ld1, mass1, N1, p.N1pad, k1, KL1, total, Psi);
+        DM_LAUNCH(ctx, "fit_fused_sums", ff_sums_kernel, dim3(B, 2), dim3(256), 0, (const double*)Psi, p.N1pad, KL1, N1, k1, Phi2, ld2, N2, k2, sums);
+        KRowsStackedF32 opa{A, Bm, k1, k2, D};
+        KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
+        OutNT out{PQ, (long long)(k1 + k2) * k1, k1};
+        DM_LAUNCH(ctx, "energy_gram_nt_f64", (gemm_nt_f64<KRowsStackedF32, KRowsF32, OutNT>), dim3(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B),
+                  dim3(256), 0, opa, opb, out, k1 + k2, k1, D);
+    }
+    DM_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, bCnt, ctx->stream));
+    DM_CHECK_HIP(ctx, hipMemcpyAsync(xt, x0, (size_t)B * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    p.Phi2 = Phi2; p.ld2 = ld2; p.xt = xt; p.unit_part = unit_part; p.chunk_part = chunk_part;
+    p.chunk_cnt = cnt; p.pair_cnt = cnt + (size_t)B * p.nchunks;
+    p.w_p2p = weights[3]; p.w_ent = weights[5]; p.w_r01 = weights[6]; p.w_sum = weights[7];
+    p.qa = quad_args{xt, nullptr, PQ, Bm, lam1, lam2, D, weights[0], weights[1]};
+    p.sums = sums; p.energy = energy; p.grad = grad;
+    const bool general = p.w_p2p > 0.0 || p.w_r01 > 0.0 || !(p.w_ent > 0.0);
+    if (eval_only) {
+        p.advance = 0;
+        rc = ff_dispatch(ctx, p, Psi, KL1, K2P, general);
+        if (rc) return rc;
+        DM_CHECK_HIP(ctx, hipMemcpyAsync(f_out, energy, (size_t)B * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        DM_CHECK_HIP(ctx, hipMemcpyAsync(grad_out, grad, (size_t)B * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        if (evaluations_out) *evaluations_out = 1;
+        return DM_OK;
+    }
+    p.advance = 1;
+    p.lo = lbfgs_opts{ftol, pgtol, m, maxiter, maxfun, maxls > 0 ? maxls : 20};
+    p.L = lb_carve(state, B, n, m);
+    DM_CHECK_HIP(ctx, hipMemsetAsync(state, 0, bState, ctx->stream));
+    DM_CHECK_HIP(ctx, hipMemcpyAsync(p.L.x, x0, (size_t)B * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    // the evaluations: `chk` launches back to back, then the status words (a finished pair's workgroups leave at once, so the
+    // launches behind the last stop cost a few microseconds each)
+    const int chk = 16;
+    std::vector<int> host_ic((size_t)B * LI_NINT);
+    int evals = 0;
+    for (;;) {
+        for (int s = 0; s < chk; ++s) {
+            rc = ff_dispatch(ctx, p, Psi, KL1, K2P, general);
+            if (rc) return rc;
+        }
+        evals += chk;
+        DM_CHECK_HIP(ctx, hipMemcpyAsync(host_ic.data(), p.L.ic, (size_t)B * LI_NINT * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool running = false;
+        for (int b = 0; b < B; ++b) running = running || host_ic[(size_t)b * LI_NINT + LI_STATUS] == LB_RUN;
+        if (!running || evals > maxfun + chk) break;
+    }
+    DM_LAUNCH(ctx, "lbfgs_result", ff_result_kernel, dim3(B), dim3(256), 0, n, (const double*)p.L.x, (const double*)p.L.sc, (const int*)p.L.ic, x_out, f_out, info_out);
+    if (evaluations_out) *evaluations_out = evals;
+    return DM_OK;
+}

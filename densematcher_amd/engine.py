@@ -352,7 +352,63 @@ class MatchEngine:
         e, _ = self.energy_grad(self._dev(x, torch.float64, "x"), A, Bm, lam1, lam2, w, P1, P2, a1, ops1, ops2)
         return e.cpu().numpy()
 
-    def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4, orient_ops=None):
+    def _weight_array(self, weights):
+        return (C.c_double * 10)(*[float(weights.get(n, 0.0)) for n in self.WEIGHT_ORDER])
+
+    def fit_fused_ok(self, k1, k2, weights, ops1=None):
+        """does dm_fmap_fit_fused take this fit (maps up to 32 x 32; w_descr, w_lap, w_p2p, w_ent, w_range01, w_sumto1 only)?"""
+        w = self._weight_array(weights)
+        return bool(self.lib.dm_fmap_fit_fused_ok(int(k1), int(k2), C.cast(w, C.c_void_p), 0 if ops1 is None else int(ops1.shape[1])))
+
+    def _fit_fused(self, A, Bm, lam1, lam2, weights, P1, P2, a1, x0, opts, maxiter):
+        """the whole fit in one library call (dm_fmap_fit_fused: one launch per evaluation, the optimiser inside the kernel)"""
+        import types
+        import numpy as np
+        B, k1, D = A.shape
+        k2 = Bm.shape[1]
+        _, N1, ld1 = P1.shape
+        _, N2, ld2 = P2.shape
+        w = self._weight_array(weights)
+        x0d = self._dev(x0, torch.float64, "x0")
+        xo = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        fo = torch.empty((B,), dtype=torch.float64, device=self.device)
+        info = torch.empty((B, 4), dtype=torch.int32, device=self.device)
+        nev = C.c_int(0)
+        self._chk(self.lib.dm_fmap_fit_fused(self.ctx, B, N1, N2, k1, k2, D, _ptr(P1), ld1, _ptr(P2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1),
+                                             _ptr(lam2), C.cast(w, C.c_void_p), int(opts["maxcor"]), _ptr(x0d), float(opts["ftol"]), float(opts["gtol"]),
+                                             int(maxiter), int(opts["maxfun"]), int(opts["maxls"]), _ptr(xo), _ptr(fo), _ptr(info), C.c_void_p(0),
+                                             C.byref(nev)))
+        info = info.cpu().numpy()
+        info[:, 0] = np.where(info[:, 0] == 0, 4, info[:, 0])
+        res = types.SimpleNamespace(x=xo.cpu().numpy(), fun=fo.cpu().numpy(), status=info[:, 0].copy(), nit=info[:, 1].copy(),
+                                    nfev=info[:, 2].copy(), message=[self.LBFGS_STATUS.get(int(q), "?") for q in info[:, 0]],
+                                    success=bool(np.all((info[:, 0] == 1) | (info[:, 0] == 2))), evaluations=int(nev.value), path="fused")
+        return res.x, res
+
+    def energy_grad_fused(self, Cm, A, Bm, lam1, lam2, weights, Phi1, Phi2, a1):
+        """energy (B,) and gradient (B,k2,k1) at the maps Cm through the arithmetic of dm_fmap_fit_fused (its single-evaluation mode):
+        what the fused fit minimises, for tests and diagnostics"""
+        Cm = self._dev(Cm, torch.float64, "C")
+        A = self._dev(A, torch.float32, "A")
+        Bm = self._dev(Bm, torch.float32, "Bm")
+        lam1 = self._dev(lam1, torch.float64, "lam1")
+        lam2 = self._dev(lam2, torch.float64, "lam2")
+        P1 = self._dev(Phi1, torch.float32, "Phi1")
+        P2 = self._dev(Phi2, torch.float32, "Phi2")
+        a1 = self._dev(a1, torch.float32, "a1")
+        B, k2, k1 = Cm.shape
+        D = A.shape[2]
+        _, N1, ld1 = P1.shape
+        _, N2, ld2 = P2.shape
+        w = self._weight_array(weights)
+        energy = torch.empty((B,), dtype=torch.float64, device=self.device)
+        grad = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_fmap_fit_fused(self.ctx, B, N1, N2, k1, k2, D, _ptr(P1), ld1, _ptr(P2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1),
+                                             _ptr(lam2), C.cast(w, C.c_void_p), 0, _ptr(Cm), 0.0, 0.0, 0, 0, 0, C.c_void_p(0), _ptr(energy), C.c_void_p(0),
+                                             _ptr(grad), None))
+        return energy, grad
+
+    def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4, orient_ops=None, fused=True):
         """FunctionalMapping.fit for any of the implemented energy terms, a whole batch at once (reference: L-BFGS-B through
         scipy.optimize.minimize, one pair per call, functional.py:477).  Every pair runs its OWN limited-memory BFGS iteration --
         history, step length, stopping test -- so a pair's result does not depend on the batch it is in; the optimiser state
@@ -386,6 +442,8 @@ class MatchEngine:
                                           options={"maxiter": maxiter, **opts})
             return res.x.reshape(B, k2, k1), res
         n, m = k2 * k1, int(opts["maxcor"])
+        if self.fit_fused_ok(k1, k2, weights, ops1) and fused:
+            return self._fit_fused(A, Bm, lam1, lam2, weights, P1, P2, a1, x0, opts, maxiter)
         nbytes = int(self.lib.dm_lbfgs_state_bytes(B, n, m))
         state = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
         xt = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)

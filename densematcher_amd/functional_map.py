@@ -167,7 +167,7 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
                "lam1": eng._dev(lam1, torch.float64, "lam1"), "lam2": eng._dev(lam2, torch.float64, "lam2"),
                "F1": eng._dev(F1, tdt[fdt], "F1"), "F2": eng._dev(F2, tdt[fdt], "F2")}
         fp = dict(w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_p2p=0, w_stochastic=0, w_ent=0, w_range01=0, w_sumto1=0, w_area=0, w_conformal=0,
-                  optinit="zeros", maxiter=1000000, stopping="tight")
+                  optinit="zeros", maxiter=1000000, stopping="reference")
         unknown = set(fit_params) - set(fp) - {"w_orient", "w_area_difference", "w_mumford_shah", "mumford_shah_var",
                                                "w_eta_entropy", "orient_reversing", "device", "driver"}
         if unknown:

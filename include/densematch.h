@@ -233,6 +233,25 @@ int dm_fmap_fit_steps(dm_ctx* ctx, int nsteps, int B, int N1, int N2, int k1, in
                       const double* weights /*host, 10*/, int m, void* state, double* x_trial, double* energy, double* grad,
                       double ftol, double pgtol, int maxiter, int maxfun, int maxls);
 
+/* The WHOLE iterative fit of small maps in one call: FunctionalMapping.fit (pyFM/functional.py:352-487) for maps up to 32 x 32 whose
+ * energy has, besides w_descr / w_lap, only element-wise indicator terms and the sum-to-one term (w_p2p, w_ent, w_range01, w_sumto1:
+ * base_functions.py:296, 363, 374, 387) -- the notebook's call (example.ipynb cell 11).  One launch per energy evaluation: the
+ * workgroup that delivers a pair's last partial sum also adds up, evaluates the O(k^3) terms and advances that pair's L-BFGS
+ * (same optimiser, constants and stopping rules as dm_lbfgs_advance); the status words are read every 16 launches.  A pair's
+ * result does not depend on the batch it is in (the additions follow a tree fixed by N1, N2 alone).
+ *   dm_fmap_fit_fused_ok  1 when the sizes / weights (host array of 10, order of dm_fmap_energy_grad) are taken, else 0 (the caller
+ *                         then runs dm_fmap_fit_steps)
+ *   x0 (B,k2,k1) start (first column = the pinned one); x_out (B,k2,k1), f_out (B), info_out (B,4) as dm_lbfgs_result;
+ *   evaluations_out (host, nullable): launches issued.
+ *   maxfun <= 0: ONE evaluation at x0, no optimiser: f_out (B) energy, grad_out (B,k2,k1) gradient (x_out / info_out unused). */
+int dm_fmap_fit_fused_ok(int k1, int k2, const double* weights /*host, 10*/, int n_ops);
+int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D,
+                      const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass1,
+                      const float* A, const float* Bm, const double* lam1, const double* lam2,
+                      const double* weights /*host, 10*/, int m, const double* x0,
+                      double ftol, double pgtol, int maxiter, int maxfun, int maxls,
+                      double* x_out, double* f_out, int32_t* info_out, double* grad_out /*nullable*/, int* evaluations_out /*host, nullable*/);
+
 /* ops[b][d] = Phi[b][:, :k]^T diag(mass[b] * F[b][:, d]) Phi[b][:, :k]   (B, D, k, k) fp64: the multiplication operator
  * of descriptor d in the reduced basis.  Replaces commute_left / commute_right of base_functions.py:550-555
  * (pinv @ (descr[:, i, None] * evects), pinv = evects^T A, pyFM/functional.py:416-417).  B * D <= 65535 per call. */

@@ -286,7 +286,7 @@ def test_fit_with_notebook_params(fx_cfg1, fx_cfg1_terms, oracle_cfg1_fits):
     k = int(fx["k"])
     model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
     model.preprocess(n_ev=(k, k), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
-    model.fit(**NOTEBOOK)
+    model.fit(**NOTEBOOK, stopping="tight")
     C = model.FM
     print("notebook fit:", model.fit_result.nit, "iterations,", model.fit_result.nfev, "evaluations;",
           "|C - C_oracle| =", np.abs(C - oracle_cfg1_fits["C_nb"]).max(), " |C - C_fit(reference)| =", np.abs(C - fx_cfg1_terms["C_fit_nb"]).max())
@@ -337,7 +337,7 @@ def test_fit_with_descriptor_commutativity(fx_cfg1, fx_cfg1_terms):
     k = int(fx["k"])
     model = FunctionalMapping(_mesh(fx, 1, k), _mesh(fx, 2, k), partial=False, optimizer="L-BFGS-B")
     model.preprocess(n_ev=(k, k), n_descr=128, descr1=fx["F1"], descr2=fx["F2"], subsample_step=1)
-    model.fit(w_descr=1e4, w_lap=1e3)                           # w_dcomm defaults to 1
+    model.fit(w_descr=1e4, w_lap=1e3, stopping="tight")         # w_dcomm defaults to 1
     Co, _ = orc.fit_general(fx["Phi1"][:, :k], fx["Phi2"][:, :k], fx["lam1"][:k], fx["lam2"][:k], fx["a1"], fx["a2"], fx["F1"], fx["F2"],
                             dict(w_descr=1e4, w_lap=1e3, w_dcomm=1.0))
     print("w_dcomm fit: |C - C_oracle| =", np.abs(model.FM - Co).max(), " |C - C_fit(reference)| =", np.abs(model.FM - fx_cfg1_terms["C_fit_dcomm"]).max())
@@ -380,7 +380,7 @@ def test_fit_with_orientation_area_conformal_terms(fx_cfg1, fx_cfg1_shape_terms)
     assert abs(float(e[0]) - Eo) <= 1e-11 * abs(Eo)
     assert np.abs(g[0].cpu().numpy() - Go).max() <= 1e-11 * np.abs(Go).max()
     # the reference's fit with the three terms switched on
-    model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_orient=1, w_area=1e2, w_conformal=1e2, optinit="zeros")
+    model.fit(w_descr=1e4, w_lap=1e3, w_dcomm=0, w_orient=1, w_area=1e2, w_conformal=1e2, optinit="zeros", stopping="tight")
     d = np.abs(model.FM - ft["fit_orient_C"]).max()
     print("fit with w_orient / w_area / w_conformal: |C - C_reference| = %.2e, rescaled w_orient = %.4e" % (d, model.w_orient_rescaled))
     assert d <= 5e-3
@@ -450,16 +450,18 @@ def test_compute_surface_map_notebook_call(fx_cfg1, fx_cfg1_notebook_call, monke
                   p2p_12_icp=res[5], hungarian_icp_cols=res[6][1], p2p_21_adjoint=res[10], p2p_12_adjoint=res[11]).items()}
     print("notebook call, agreement with the reference's tuple:", agree)
     assert min(agree[n] for n in ("p2p_21", "p2p_12", "p2p_21_adjoint", "p2p_12_adjoint", "hungarian_cols")) >= 0.95
-    # the same call with the reference's own stopping rule (SciPy's defaults, the fit ends ~5e-4 from the minimiser like the
-    # reference's does): how close to the reference's tuple the drop-in gets when it stops where the reference stops
-    res_r = compute_surface_map(_Duck(fx["verts1"], fx["faces1"]), _Duck(fx["verts2"], fx["faces2"]), fx["F1"], fx["F2"], n_ev=k,
-                                compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(NOTEBOOK, stopping="reference"))
-    agree_r = {n: round(float((np.asarray(a) == ref[n]).mean()), 4) for n, a in
-               dict(p2p_21=res_r[0], p2p_12=res_r[1], hungarian_cols=res_r[2][1], hungarian_precise_cols=res_r[3][1], p2p_21_icp=res_r[4],
-                    p2p_12_icp=res_r[5], hungarian_icp_cols=res_r[6][1], p2p_21_adjoint=res_r[10], p2p_12_adjoint=res_r[11]).items()}
-    print("notebook call with stopping='reference', agreement with the reference's tuple:", agree_r,
-          "max |C - C_ref| = %.2e (tight: %.2e)" % (np.abs(res_r[7]._FM_base - ref["FM_base"]).max(), np.abs(C0 - ref["FM_base"]).max()))
-    assert min(agree_r[n] for n in ("p2p_21", "p2p_12", "p2p_21_adjoint", "p2p_12_adjoint")) >= 0.90
+    # the same call with the package's tight stopping rule (ftol 1e-12: the float64 minimiser; the reference's own fit stops ~5e-4 short
+    # of it, so the tuple moves AWAY from the reference's -- the reason the default is SciPy's rule)
+    res_t = compute_surface_map(_Duck(fx["verts1"], fx["faces1"]), _Duck(fx["verts2"], fx["faces2"]), fx["F1"], fx["F2"], n_ev=k,
+                                compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(NOTEBOOK, stopping="tight"))
+    agree_t = {n: round(float((np.asarray(a) == ref[n]).mean()), 4) for n, a in
+               dict(p2p_21=res_t[0], p2p_12=res_t[1], hungarian_cols=res_t[2][1], hungarian_precise_cols=res_t[3][1], p2p_21_icp=res_t[4],
+                    p2p_12_icp=res_t[5], hungarian_icp_cols=res_t[6][1], p2p_21_adjoint=res_t[10], p2p_12_adjoint=res_t[11]).items()}
+    print("notebook call with stopping='tight', agreement with the reference's tuple:", agree_t,
+          "max |C - C_ref| = %.2e (default rule: %.2e)" % (np.abs(res_t[7]._FM_base - ref["FM_base"]).max(), np.abs(C0 - ref["FM_base"]).max()))
+    assert min(agree_t[n] for n in ("p2p_21", "p2p_12", "p2p_21_adjoint", "p2p_12_adjoint")) >= 0.90
+    # the default must not be the worse of the two on the slots the fit's stopping point moves most (the ICP maps)
+    assert agree["p2p_21_icp"] + agree["p2p_12_icp"] >= agree_t["p2p_21_icp"] + agree_t["p2p_12_icp"] - 0.02
 
 
 def test_compute_surface_map_batch_equals_single_calls(fx_cfg1, monkeypatch):

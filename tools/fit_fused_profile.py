@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""The notebook's iterative fit (N = 2048, k = 15, D = 512; w_descr, w_lap, w_ent, w_sumto1) through dm_fmap_fit_fused and through the
+multi-launch path, one pair and a batch of 64: wall time, evaluations, per-kernel times.
+    python tools/fit_fused_profile.py [B ...]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from densematcher_amd import synth  # noqa: E402
+from densematcher_amd.engine import default_engine  # noqa: E402
+from densematcher_amd.pyFM.functional import LBFGS_OPTIONS  # noqa: E402
+
+W = dict(w_descr=1e4, w_lap=1e3, w_ent=1e-1, w_sumto1=1e1)
+eng = default_engine()
+sizes = [int(a) for a in sys.argv[1:]] or [1, 64]
+k = 15
+for B in sizes:
+    host = synth.make_pair_batch(B, 64, 32, 512, k, sigma=0.5, n_distinct_meshes=min(B, 2))
+    dev = {n: torch.as_tensor(v).to(eng.device) for n, v in host.items()}
+    x0 = np.zeros((B, k, k))
+    for b in range(B):
+        x0[b, 0, 0] = np.sign(host["Phi1"][b, 0, 0] * host["Phi2"][b, 0, 0]) * np.sqrt(host["a2"][b].astype(np.float64).sum() / host["a1"][b].astype(np.float64).sum())
+    for stopping, opts in (("tight", dict(LBFGS_OPTIONS)), ("reference", None)):
+        for fused in (True, False):
+            for rep in range(2):
+                if rep == 1:
+                    eng.profile_kernel("*")
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                C, res = eng.fit_general(dev, W, x0, lbfgs_options=opts, fused=fused)
+                torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            rep_ = eng.profile_report(); eng.profile_kernel("")
+            tot = sum(ms for _, ms in rep_.values())
+            print(f"B = {B:3d} stopping = {stopping:9s} {'fused' if fused else 'multi':5s}: {1e3 * dt:8.2f} ms wall, {tot:8.2f} ms of kernels, evaluations max {int(res.nfev.max())} "
+                  f"mean {float(res.nfev.mean()):.0f}, launched {res.evaluations}, energy[0] {float(res.fun[0]):.10e}")
+            for name, (n, ms) in sorted(rep_.items(), key=lambda kv: -kv[1][1])[:6]:
+                print(f"      {name:28s} {n:6d} x {1e3 * ms / n:9.2f} us = {ms:8.2f} ms")
+            if fused:
+                Cf = C
+            else:
+                print(f"      max |C_fused - C_multi| = {np.abs(Cf - C).max():.2e}")
