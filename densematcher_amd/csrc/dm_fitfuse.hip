@@ -28,6 +28,7 @@
 #include "dm_internal.h"
 #include "dm_energy_dev.h"
 #include "dm_lbfgs_dev.h"
+#include "dm_logtab.h"
 
 constexpr int FF_ROWS = 64;        // rows of a unit (one per lane)
 constexpr int FF_WCOLS = 32;       // columns per wave
@@ -35,7 +36,8 @@ constexpr int FF_COLS = 128;       // columns of a unit
 constexpr int FF_CHUNK = 8;        // units per chunk
 constexpr int FF_LDT = 65;         // LDS row stride (doubles) of the transposed 64-row panels: b64 reads of 16 rows x 4 columns conflict-free
 constexpr int FF_KMAX = 32;
-constexpr int FF_SUMS = 2 * FF_KMAX + 2 * FF_KMAX * FF_KMAX;     // per pair: p | s2 | G1c | G2c
+constexpr int FF_SUMS = 2 * FF_KMAX + 2 * FF_KMAX * FF_KMAX + 8;     // per pair: p | s2 | G1c | G2c | max eigenvalue, |Bm|^2 (+ padding)
+constexpr int FF_SUMS_SCALE = 2 * FF_KMAX + 2 * FF_KMAX * FF_KMAX, FF_SUMS_BN = FF_SUMS_SCALE + 1;
 
 struct ff_params {
     int B, N1, N2, k1, k2, n;
@@ -50,42 +52,45 @@ struct ff_params {
     const double* sums;
     double* energy; double* grad;
     int advance; lbfgs_opts lo; lb_layout L;
+    int dbg_mode;                               // experiments build (WRONG results): 1 no unit epilogue, 2 every column reads Psi row 0, 4 no element-wise terms
+    long long* dbg;                             // experiments build: 16 time stamps (100 MHz counter) of the pair-0 chain of the last launch; else null
 };
+#define FF_STAMP(i_) do { if (p.dbg && b == 0 && t == 0) p.dbg[i_] = (long long)wall_clock64(); } while (0)
 
-// log(y) for y in [1e-10, 1 + 1e-10] (normal, positive: no special cases): y = 2^e m, m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1),
-// log m = 2 s (1 + s^2 / 3 + s^4 / 5 + ...); |s| <= 0.1716, the series is cut behind s^18 / 19 (next term: 8e-18 absolute)
+// v_rcp_f64 is good to 2^-24.4 (measured over 1e6 arguments on the part); one Newton step leaves 2.2e-15, two 1.1e-16.  One is what
+// both uses need: the quotient of ff_log gets its own correction step, and c / y <= 1 enters a derivative of magnitude 1 .. 23.
 __device__ __forceinline__ double ff_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
-__device__ __forceinline__ double ff_log(double y) {
-    int e = __builtin_amdgcn_frexp_exp(y);
-    double m = __builtin_amdgcn_frexp_mant(y);                    // [0.5, 1)
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;
-    e = lo ? e - 1 : e;
-    const double f = m - 1.0, den = 2.0 + f;
-    const double r = ff_rcp(den);
-    double s = f * r;
-    s = fma(fma(-den, s, f), r, s);
-    const double z = s * s;
-    double p = 2.0 / 19.0;
-    p = fma(p, z, 2.0 / 17.0); p = fma(p, z, 2.0 / 15.0); p = fma(p, z, 2.0 / 13.0); p = fma(p, z, 2.0 / 11.0);
-    p = fma(p, z, 2.0 / 9.0); p = fma(p, z, 2.0 / 7.0); p = fma(p, z, 2.0 / 5.0); p = fma(p, z, 2.0 / 3.0);
-    const double lm = fma(s * z, p, s + s);
-    return fma((double)e, 0.693147180559945309417, lm);
+// log(y) for y in [1e-10, 1 + 1e-10] (positive, normal: no special cases).  y = 2^e m, m in [1, 2); the seven leading mantissa bits
+// select (u_i, -log u_i) from a 2 KiB table in the LDS (dm_logtab.h; lanes that share an argument -- every clamped entry -- share
+// the address), r = m u_i - 1 comes out of one fma with |r| < 2^-8, and log(1 + r) = r - r^2/2 + ... - r^6/6 (next term 2e-18).
+// Absolute error <= 4e-15 at |log| = 23, i.e. 1.5e-16 relative to the largest values; near y = 1 the two table terms cancel to
+// an absolute error of 3e-17.  (The division-based form it replaces -- frexp, s = (m - 1) / (m + 1), nine-term series -- took 145
+// issue clocks per entry against 60: 21 % of the element loop.)
+__device__ __forceinline__ double ff_log(double y, const double* __restrict__ tab) {
+    const unsigned hi = (unsigned)__double2hiint(y), lo = (unsigned)__double2loint(y);
+    const int e = (int)(hi >> 20) - 1023;
+    const unsigned idx = (hi >> 13) & 0x7fu;
+    const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), (int)lo);
+    const f64x2 tv = *reinterpret_cast<const f64x2*>(tab + 2 * idx);
+    const double r = fma(m, tv[0], -1.0);
+    double q = fma(r, -1.0 / 6.0, 0.2);
+    q = fma(q, r, -0.25); q = fma(q, r, 1.0 / 3.0); q = fma(q, r, -0.5);
+    const double lp = fma(q * r, r, r);
+    return fma((double)e, 0.693147180559945309417, tv[1] + lp);
 }
 
 // energy and derivative of the element-wise indicator terms at the entry m (base_functions.py:296-428)
 template <bool GENERAL>
-__device__ __forceinline__ double ff_element(double m, double w_ent, double w_p2p, double w_r01, double& eacc) {
+__device__ __forceinline__ double ff_element(double m, double w_ent, double w_p2p, double w_r01, double& eacc, const double* __restrict__ tab) {
     double d = 0.0;
     if (!GENERAL || w_ent > 0.0) {
         const double c = fmin(fmax(m, 0.0), 1.0);
         const double y = c + 1e-10;
-        const double lg = ff_log(y);
+        const double lg = ff_log(y, tab);
         eacc = fma(w_ent, -c * lg, eacc);
         const double inv = ff_rcp(y);
         const double dd = w_ent * (-lg - c * inv);
@@ -102,6 +107,15 @@ __device__ __forceinline__ double ff_element(double m, double w_ent, double w_p2
     return d;
 }
 
+// Partial sums cross workgroups (other CUs, other XCDs) inside a launch.  They are written and read with agent-scope relaxed atomic
+// accesses (global_store / global_load ... sc1: through to / from the level the XCDs share), and a workgroup waits for its stores
+// (s_waitcnt vmcnt(0)) before its thread 0 bumps the counter: no cache maintenance.  (The generic release / acquire fences of
+// __threadfence() write back and invalidate the XCD's whole L2: 10 us each with 512 workgroups doing it, measured with the stamps
+// of the experiments build -- 35 of the 96 us a single pair's evaluation took.)
+__device__ __forceinline__ void ff_put(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ff_get(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ff_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // wave sum in a fixed order (butterfly over lane distances 32 ... 1): every lane gets the total
 __device__ __forceinline__ double ff_wave_sum(double v) {
 #pragma unroll
@@ -113,7 +127,8 @@ template <int KL1, int K2P, bool GENERAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ? 4 : 2, KL1 <= 16 ? 4 : 2))) void ff_eval_kernel(const ff_params p, const double* __restrict__ Psi) {
     constexpr int KT1 = (KL1 + 15) / 16 * 16, T1 = KT1 / 16, T2 = K2P / 16;
     extern __shared__ __attribute__((aligned(16))) double ff_sm[];
-    double* Cs = ff_sm;                              // [K2P][KL1]      the trial map, zero padded
+    double* Ltab = ff_sm;                            // [128][2]        (u_i, -log u_i) of the in-line logarithm
+    double* Cs = Ltab + 256;                         // [K2P][KL1]      the trial map, zero padded
     double* P2s = Cs + K2P * KL1;                    // [K2P][FF_LDT]   Phi2 rows of the row block, (a, i)
     double* Ysum = P2s + K2P * FF_LDT;               // [KT1][FF_LDT]   the four waves' Y added up, (c, i)
     double* Ysh = Ysum + KT1 * FF_LDT;               // [2][KT1][64]    two waves' Y, (c, i);  later  Dsh [4][T2 * T1][256]
@@ -121,12 +136,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
     __shared__ double esh[4];
     __shared__ double sh4[4];
     __shared__ int s_flag;
+    __shared__ double s_em;
     __shared__ double s_u[FF_KMAX], s_q[FF_KMAX], s_gu[FF_KMAX], s_gq[FF_KMAX];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int b = vid / p.wg_per_pair, w = vid - b * p.wg_per_pair;
     if (p.advance && p.L.ic[(long long)b * LI_NINT + LI_STATUS] != LB_RUN) return;
     const int k1 = p.k1, k2 = p.k2, n = p.n, np1 = p.n + 1;
+    if (p.dbg && b == 0 && t == 0) atomicMin((unsigned long long*)p.dbg, (unsigned long long)wall_clock64());      // earliest start of a pair-0 workgroup
     {
         const double* xb = p.xt + (long long)b * n;
         for (int e = t; e < K2P * KL1; e += 256) {
@@ -134,6 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
             Cs[e] = (a < k2 && c < k1) ? xb[a * k1 + c] : 0.0;
         }
         for (int e = t; e < KT1 * FF_LDT; e += 256) Ysum[e] = 0.0;          // (the padding columns c >= KL1 of Ysum stay zero)
+        Ltab[t] = dm_logtab[t];
     }
     __syncthreads();
     int u_begin, u_end, ch_begin, ch_end;
@@ -149,6 +167,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
     int rb_prev = -1;
     for (int u = u_begin; u < u_end; ++u) {
         const int rb = u / p.ncc, cc = u - rb * p.ncc;
+        const double* psi = Psi + ((long long)b * p.N1pad + cc * FF_COLS + wave * FF_WCOLS) * KL1;
+        // One unit per workgroup (small batches): every launch starts with cold caches, and the element loop's scalar loads are
+        // dependent round trips (16 of them, 1.5 us each from the memory side: 24 of the 28 us a unit took).  One vector load per
+        // lane pulls the wave's 32 x KL1 doubles into the XCD's L2 first -- a single round trip -- and is waited for behind the
+        // Phi2 C rows below.  (Whole chunks per workgroup: four waves per SIMD cover the scalar latency, nothing to do.)
+        int touch0 = 0, touch1 = 0;
+        if (p.unit_mode) {
+            const int* tp = reinterpret_cast<const int*>(psi) + lane * 16;          // one 64-byte line per lane
+            touch0 = __builtin_nontemporal_load(tp);
+            if (KL1 > 16 && lane * 16 + 1024 < FF_WCOLS * KL1 * 2) touch1 = __builtin_nontemporal_load(tp + 1024);
+        }
         if (rb != rb_prev) {
             // this lane's row of Phi2 and of E2 = Phi2 C; the row block's Phi2 panel for the contraction (each wave a quarter of it)
             const int i = rb * FF_ROWS + lane;
@@ -174,19 +203,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #pragma unroll
         for (int c = 0; c < KL1; ++c) Y[c] = 0.0;
         double eacc = 0.0;
-        const double* psi = Psi + ((long long)b * p.N1pad + cc * FF_COLS + wave * FF_WCOLS) * KL1;
+        asm volatile("" :: "v"(touch0), "v"(touch1));
+#ifdef DM_EXPERIMENTS
+        const int jmul = (p.dbg_mode & 2) ? 0 : KL1;
+#else
+        constexpr int jmul = KL1;
+#endif
 #pragma unroll 2
         for (int jj = 0; jj < FF_WCOLS; ++jj) {
             double ps[KL1];
 #pragma unroll
-            for (int c = 0; c < KL1; ++c) ps[c] = psi[jj * KL1 + c];
+            for (int c = 0; c < KL1; ++c) ps[c] = psi[jj * jmul + c];
             double m = 0.0;
 #pragma unroll
             for (int c = 0; c < KL1; ++c) m = fma(E2[c], ps[c], m);
-            const double d = ff_element<GENERAL>(m, p.w_ent, p.w_p2p, p.w_r01, eacc);
+#ifdef DM_EXPERIMENTS
+            const double d = (p.dbg_mode & 4) ? m : ff_element<GENERAL>(m, p.w_ent, p.w_p2p, p.w_r01, eacc, Ltab);
+#else
+            const double d = ff_element<GENERAL>(m, p.w_ent, p.w_p2p, p.w_r01, eacc, Ltab);
+#endif
 #pragma unroll
             for (int c = 0; c < KL1; ++c) Y[c] = fma(d, ps[c], Y[c]);
         }
+#ifdef DM_EXPERIMENTS
+        if (p.dbg_mode & 1) { asm volatile("" :: "v"(Y[0]), "v"(Y[KL1 - 1]), "v"(eacc)); continue; }
+#endif
         // ---- unit epilogue: (Y0 + Y1) + (Y2 + Y3) through two LDS panels -> Ysum -> Phi2_R^T Ysum on the matrix cores (each wave 16 of
         //      the 64 rows) -> the unit's partial
         {
@@ -254,9 +295,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #pragma unroll
                 for (int tc = 0; tc < T1; ++tc) {
                     const int a = ta * 16 + (lane >> 4) + 4 * (t >> 6), c = tc * 16 + (lane & 15);
-                    if (a < k2 && c < k1) up[a * k1 + c] = uv[ta][tc];
+                    if (a < k2 && c < k1) ff_put(up + a * k1 + c, uv[ta][tc]);
                 }
-            if (t == 0) up[n] = eu;
+            if (t == 0) ff_put(up + n, eu);
         } else {
 #pragma unroll
             for (int ta = 0; ta < T2; ++ta)
@@ -270,45 +311,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #pragma unroll
                     for (int tc = 0; tc < T1; ++tc) {
                         const int a = ta * 16 + (lane >> 4) + 4 * (t >> 6), c = tc * 16 + (lane & 15);
-                        if (a < k2 && c < k1) cp[a * k1 + c] = acc[ta][tc];
+                        if (a < k2 && c < k1) ff_put(cp + a * k1 + c, acc[ta][tc]);
                         acc[ta][tc] = 0.0;
                     }
-                if (t == 0) cp[n] = eacc_chunk;
+                if (t == 0) ff_put(cp + n, eacc_chunk);
                 eacc_chunk = 0.0;
             }
         }
     }
+    if (w == p.wg_per_pair - 1) FF_STAMP(1);        // (the pair's last workgroup by index: its units are done)
     // ---- hand in.  Unit mode: the chunk's last unit adds the chunk up (unit order, from zero: the additions of the other mode)
     int done = ch_end - ch_begin;
     if (p.unit_mode) {
         const int ch = ch_begin, u0 = ch * FF_CHUNK, nu = min(FF_CHUNK, p.nU - u0);
-        __threadfence();
+        ff_stores_done();
         __syncthreads();
         if (t == 0) s_flag = (atomicAdd(p.chunk_cnt + (long long)b * p.nchunks + ch, 1) + 1 == nu) ? 1 : 0;
         __syncthreads();
         if (!s_flag) return;
-        __threadfence();
+        if (ch_begin == p.nchunks - 1) FF_STAMP(2);
         const double* up = p.unit_part + ((long long)b * p.nU + u0) * np1;
         double* cp = p.chunk_part + ((long long)b * p.nchunks + ch) * np1;
         for (int e = t; e < np1; e += 256) {
             double v[FF_CHUNK];
 #pragma unroll
-            for (int q = 0; q < FF_CHUNK; ++q) v[q] = q < nu ? up[(long long)q * np1 + e] : 0.0;
+            for (int q = 0; q < FF_CHUNK; ++q) v[q] = q < nu ? ff_get(up + (long long)q * np1 + e) : 0.0;
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < FF_CHUNK; ++q) if (q < nu) s += v[q];
-            cp[e] = s;
+            ff_put(cp + e, s);
         }
         if (t == 0) p.chunk_cnt[(long long)b * p.nchunks + ch] = 0;
         done = 1;
     }
-    __threadfence();
+    ff_stores_done();
     __syncthreads();
     if (t == 0) s_flag = (atomicAdd(p.pair_cnt + b, done) + done == p.nchunks) ? 1 : 0;
     __syncthreads();
     if (!s_flag) return;
-    __threadfence();
     if (t == 0) p.pair_cnt[b] = 0;
+    FF_STAMP(3);
     // ---- the pair's last workgroup: chunk partials in chunk order, the O(k^3) terms, the optimiser
     double gm[4] = {0.0, 0.0, 0.0, 0.0};
     double em = 0.0;
@@ -320,24 +362,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
             if (e < n) {
                 double s = 0.0;
                 int ch = 0;
+                for (; ch + 32 <= p.nchunks; ch += 32) {           // (32 loads in flight, added in chunk order)
+                    double v[32];
+#pragma unroll
+                    for (int z = 0; z < 32; ++z) v[z] = ff_get(cp + (long long)(ch + z) * np1 + e);
+#pragma unroll
+                    for (int z = 0; z < 32; ++z) s += v[z];
+                }
                 for (; ch + 8 <= p.nchunks; ch += 8) {
                     double v[8];
 #pragma unroll
-                    for (int z = 0; z < 8; ++z) v[z] = cp[(long long)(ch + z) * np1 + e];
+                    for (int z = 0; z < 8; ++z) v[z] = ff_get(cp + (long long)(ch + z) * np1 + e);
 #pragma unroll
                     for (int z = 0; z < 8; ++z) s += v[z];
                 }
-                for (; ch < p.nchunks; ++ch) s += cp[(long long)ch * np1 + e];
+                for (; ch < p.nchunks; ++ch) s += ff_get(cp + (long long)ch * np1 + e);
                 gm[q] = s;
             }
         }
-        if (t == 0) for (int ch = 0; ch < p.nchunks; ++ch) em += cp[(long long)ch * np1 + n];
+        if (t == 255) {                                    // (the energies: a thread with no gradient entry of its own when n <= 255)
+            int ch = 0;
+            for (; ch + 8 <= p.nchunks; ch += 8) {
+                double v[8];
+#pragma unroll
+                for (int z = 0; z < 8; ++z) v[z] = ff_get(cp + (long long)(ch + z) * np1 + n);
+#pragma unroll
+                for (int z = 0; z < 8; ++z) em += v[z];
+            }
+            for (; ch < p.nchunks; ++ch) em += ff_get(cp + (long long)ch * np1 + n);
+            s_em = em;                                     // (thread 0 reads it behind the barriers of quad_pair)
+        }
     }
     double* gradb = p.grad + (long long)b * n;
-    const double eq = quad_pair(p.qa, b, t, k1, k2, p.grad, sh4);
-    // sum-to-one term: w [ (C p)^T G2c (C p) + (C^T s2)^T G1c (C^T s2) ]   (rs = Phi2 C p, cs = Psi C^T s2; centred Gram matrices)
-    double es = 0.0;
+    FF_STAMP(4);
+    // quadratic terms (quad_pair's arithmetic: grad = w_d (C P - Q) + w_l C ev, e = 1/2 w_d (sum C (CP - 2Q) + |B|^2) + 1/2 w_l sum C^2 ev) with
+    // the map read from the LDS, a column of P fetched whole (independent loads), the eigenvalue scale and |B|^2 from the once-per-fit block
     const double* sm = p.sums + (long long)b * FF_SUMS;
+    double eq;
+    {
+        const double scale = sm[FF_SUMS_SCALE], bn = sm[FF_SUMS_BN];
+        const double* Pm = p.qa.PQ + (long long)b * (k1 + k2) * k1;
+        const double* Qm = Pm + (long long)k1 * k1;
+        const double w_d = p.qa.w_d, w_l = p.qa.w_l;
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = t + 256 * q;
+            if (e < n) {
+                const int i = e / k1, j = e - i * k1;
+                double pc[KL1];
+#pragma unroll
+                for (int k = 0; k < KL1; ++k) pc[k] = k < k1 ? Pm[k * k1 + j] : 0.0;
+                const double qv = Qm[e], l1 = p.qa.lam1[(long long)b * k1 + j], l2 = p.qa.lam2[(long long)b * k2 + i];
+                double cp = 0.0;
+#pragma unroll
+                for (int k = 0; k < KL1; ++k) cp = fma(Cs[i * KL1 + k], pc[k], cp);
+                const double c = Cs[i * KL1 + j];
+                const double dl = l1 / scale - l2 / scale;                       // functional.py:404-405
+                const double ev = dl * dl;
+                gm[q] += w_d * (cp - qv) + w_l * c * ev;
+                acc += 0.5 * w_d * c * (cp - 2.0 * qv) + 0.5 * w_l * c * c * ev;
+            }
+        }
+        eq = block_sum_256(acc, sh4) + 0.5 * w_d * bn;
+    }
+    FF_STAMP(5);
+    double es = 0.0;
+    // sum-to-one term: w [ (C p)^T G2c (C p) + (C^T s2)^T G1c (C^T s2) ]   (rs = Phi2 C p, cs = Psi C^T s2; centred Gram matrices)
     if (p.w_sum > 0.0) {                               // (uniform)
         const double* pv = sm; const double* s2 = sm + FF_KMAX;
         const double* G1 = sm + 2 * FF_KMAX; const double* G2 = G1 + FF_KMAX * FF_KMAX;
@@ -362,12 +453,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = t + 256 * q;
-        if (e < n) gradb[e] = (e % k1 == 0) ? 0.0 : gradb[e] + gm[q];                // base_functions.py:759
+        if (e < n) gradb[e] = (e % k1 == 0) ? 0.0 : gm[q];                            // base_functions.py:759
     }
-    if (t == 0) p.energy[b] = eq + em + es;
+    if (t == 0) p.energy[b] = eq + s_em + es;
+    FF_STAMP(6);
     if (!p.advance) return;
     __syncthreads();
     lb_advance_pair<LB_FAST_M_FUSED>(b, n, p.lo, p.energy, p.grad, p.xt, p.L.x, p.L.g, p.L.d, p.L.S, p.L.Y, p.L.rho, p.L.sc, p.L.ic, p.L.al);
+    FF_STAMP(7);
 }
 
 // Psi[b][j][c] = a1_j Phi1[j][c]  (float64; zero for j >= N1 and c >= k1)
@@ -384,8 +477,10 @@ __global__ __launch_bounds__(256) void ff_psi_kernel(const float* __restrict__ P
 
 // Column sums and centred Gram matrix of the rows X_i (i < N) of one factor: blockIdx.y = 0: X = Psi (-> p, G1c), 1: X = Phi2 (-> s2, G2c).
 //   sums[c] = sum_i X[i][c] (eight interleaved partial sums, added in order);   G[a][c] = sum_i (X[i][a] - sums[a] / N)(X[i][c] - sums[c] / N)
+//   blockIdx.y = 0 also leaves max(lam1, lam2) (functional.py:404) and |Bm|^2 = sum of the squared projected target descriptors
 __global__ __launch_bounds__(256) void ff_sums_kernel(const double* __restrict__ Psi, int N1pad, int KL1, int N1, int k1,
-                                                      const float* __restrict__ Phi2, int ld2, int N2, int k2, double* __restrict__ sums) {
+                                                      const float* __restrict__ Phi2, int ld2, int N2, int k2, double* __restrict__ sums,
+                                                      const double* __restrict__ lam1, const double* __restrict__ lam2, const float* __restrict__ Bm, int D) {
     __shared__ double part[8][FF_KMAX];
     __shared__ double mean[FF_KMAX];
     __shared__ double Xs[64][FF_KMAX + 1];
@@ -409,6 +504,22 @@ __global__ __launch_bounds__(256) void ff_sums_kernel(const double* __restrict__
             osum[t] = t < k ? a : 0.0;
             mean[t] = t < k ? a / (double)N : 0.0;
         }
+        __syncthreads();
+    }
+    if (which == 0) {
+        __shared__ double red[4];
+        double mx = 0.0;
+        for (int j = t; j < k1; j += 256) mx = fmax(mx, lam1[(long long)b * k1 + j]);
+        for (int i = t; i < k2; i += 256) mx = fmax(mx, lam2[(long long)b * k2 + i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+        if ((t & 63) == 0) red[t >> 6] = mx;
+        __syncthreads();
+        if (t == 0) out[FF_SUMS_SCALE] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        double bn = 0.0;
+        for (int e = t; e < k2 * D; e += 256) { const double x = (double)Bm[(long long)b * k2 * D + e]; bn += x * x; }
+        const double tot = block_sum_256(bn, red);
+        if (t == 0) out[FF_SUMS_BN] = tot;
         __syncthreads();
     }
     const int a = t >> 3, c0 = (t & 7) * 4;
@@ -445,13 +556,18 @@ template <int KL1, int K2P>
 static size_t ff_lds_bytes() {
     constexpr int KT1 = (KL1 + 15) / 16 * 16;
     constexpr size_t panels = (size_t)2 * KT1 * 64, dsh = (size_t)4 * (K2P / 16) * (KT1 / 16) * 256;
-    return ((size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8;
+    return (256 + (size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8;
 }
 
 template <int KL1, int K2P>
 static int ff_launch(dm_ctx* ctx, const ff_params& p, const double* Psi, bool general) {
     const size_t lds = ff_lds_bytes<KL1, K2P>();
     const dim3 grid(p.B * p.wg_per_pair);
+    if (p.dbg && dm_knob("DM_FF_DEBUG", 0) > 1) {
+        int nb = -1;
+        hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ff_eval_kernel<KL1, K2P, false>, 256, lds);
+        fprintf(stderr, "fit_fused: occupancy %d workgroups per CU (%s), dynamic LDS %zu bytes, grid %u, W = %d\n", nb, hipGetErrorString(e_), lds, grid.x, p.W);
+    }
     if (general) {
         int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, true>, lds);
         if (rc) return rc;
@@ -504,7 +620,7 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     else {
         const int KT1 = (KL1 + 15) / 16 * 16;
         const size_t panels = (size_t)2 * KT1 * 64, dsh = (size_t)4 * (K2P / 16) * (KT1 / 16) * 256;
-        const size_t lds = ((size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8 + 2048;
+        const size_t lds = (256 + (size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8 + 2048;
         int per_cu = (int)((160 * 1024) / lds);
         const int by_regs = KL1 <= 16 ? 4 : 2;                        // (maps up to 16 columns: 128 registers, four waves per SIMD)
         per_cu = per_cu < 1 ? 1 : (per_cu > by_regs ? by_regs : per_cu);
@@ -541,7 +657,7 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     {
         const long long total = (long long)B * p.N1pad * KL1;
         DM_LAUNCH(ctx, "fit_fused_psi", ff_psi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, Phi1, ld1, mass1, N1, p.N1pad, k1, KL1, total, Psi);
-        DM_LAUNCH(ctx, "fit_fused_sums", ff_sums_kernel, dim3(B, 2), dim3(256), 0, (const double*)Psi, p.N1pad, KL1, N1, k1, Phi2, ld2, N2, k2, sums);
+        DM_LAUNCH(ctx, "fit_fused_sums", ff_sums_kernel, dim3(B, 2), dim3(256), 0, (const double*)Psi, p.N1pad, KL1, N1, k1, Phi2, ld2, N2, k2, sums, lam1, lam2, Bm, D);
         KRowsStackedF32 opa{A, Bm, k1, k2, D};
         KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
         OutNT out{PQ, (long long)(k1 + k2) * k1, k1};
@@ -574,11 +690,24 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     // launches behind the last stop cost a few microseconds each)
     const int chk = 16;
     std::vector<int> host_ic((size_t)B * LI_NINT);
+    long long* dbg = nullptr;
+    if (dm_knob("DM_FF_DEBUG", 0)) { DM_CHECK_HIP(ctx, hipMalloc((void**)&dbg, 16 * 8)); p.dbg = dbg; }
+    p.dbg_mode = dm_knob("DM_FF_MODE", 0);
+    double dbg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int dbg_n = 0;
     int evals = 0;
     for (;;) {
         for (int s = 0; s < chk; ++s) {
+            if (dbg) DM_CHECK_HIP(ctx, hipMemsetAsync(dbg, 0xff, 8, ctx->stream));
             rc = ff_dispatch(ctx, p, Psi, KL1, K2P, general);
             if (rc) return rc;
+            if (dbg && evals + s >= 16 && evals + s < 80) {      // (launches 16 .. 79: every pair is still running)
+                long long h[8];
+                DM_CHECK_HIP(ctx, hipMemcpyAsync(h, dbg, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+                DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                for (int q = 1; q < 8; ++q) dbg_sum[q] += (double)(h[q] - h[0]) * 0.01;
+                ++dbg_n;
+            }
         }
         evals += chk;
         DM_CHECK_HIP(ctx, hipMemcpyAsync(host_ic.data(), p.L.ic, (size_t)B * LI_NINT * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -586,6 +715,12 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
         bool running = false;
         for (int b = 0; b < B; ++b) running = running || host_ic[(size_t)b * LI_NINT + LI_STATUS] == LB_RUN;
         if (!running || evals > maxfun + chk) break;
+    }
+    if (dbg) {
+        fprintf(stderr, "fit_fused stamps (us after the first pair-0 workgroup started; B = %d, %d launches): units done %.1f, last chunk leader %.1f, pair leader %.1f, "
+                "partials added %.1f, quadratic terms %.1f, gradient written %.1f, optimiser advanced %.1f\n", B, dbg_n, dbg_sum[1] / dbg_n, dbg_sum[2] / dbg_n,
+                dbg_sum[3] / dbg_n, dbg_sum[4] / dbg_n, dbg_sum[5] / dbg_n, dbg_sum[6] / dbg_n, dbg_sum[7] / dbg_n);
+        (void)hipFree(dbg);
     }
     DM_LAUNCH(ctx, "lbfgs_result", ff_result_kernel, dim3(B), dim3(256), 0, n, (const double*)p.L.x, (const double*)p.L.sc, (const int*)p.L.ic, x_out, f_out, info_out);
     if (evaluations_out) *evaluations_out = evals;

@@ -42,3 +42,10 @@ for B in sizes:
                 Cf = C
             else:
                 print(f"      max |C_fused - C_multi| = {np.abs(Cf - C).max():.2e}")
+    # every pair still running in every launch: stop after 12 iterations
+    for rep in range(2):
+        if rep == 1:
+            eng.profile_kernel("fit_fused_eval")
+        C, res = eng.fit_general(dev, W, x0, maxiter=12)
+    nl, ms = eng.profile_read(); eng.profile_kernel("")
+    print(f"B = {B:3d} full load (12 iterations, status {set(res.status.tolist())}): {nl} launches, {1e3 * ms / max(nl, 1):.1f} us each")
