@@ -263,6 +263,8 @@ def surface_map_workload(args):
     import torch
     from densematcher_amd import functional_map as fmod, synth
     from densematcher_amd.pyFM.functional import FunctionalMapping
+    from densematcher_amd.pyFM.mesh import laplacian as _lap
+    _lap.set_robust_backend("restated")       # (no robust_laplacian wheel on the box: the call opts into the package's restatement)
     w = WORKLOADS["surface_map"]
     nu, nv, D, k = w["nu"], w["nv"], w["D"], w["k"]
     (v1, f1), (v2, f2) = synth.torus_mesh(nu, nv, perturb=0.03, seed=3), synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
@@ -628,7 +630,8 @@ def surface_map_batch_rate(B):
     import torch
     from densematcher_amd import functional_map as fmod, synth
     from densematcher_amd.engine import MatchEngine
-    from densematcher_amd.pyFM.mesh import TriMesh
+    from densematcher_amd.pyFM.mesh import TriMesh, laplacian as _lap
+    _lap.set_robust_backend("restated")
     w = WORKLOADS["surface_map"]
     nu, nv, D, k = w["nu"], w["nv"], w["D"], w["k"]
     m1, m2, F1s, F2s = [], [], [], []

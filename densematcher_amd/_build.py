@@ -17,7 +17,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libdensematch.so")
-SOURCES = ["dm_ctx.hip", "dm_p2p.hip", "dm_fmap.hip", "dm_project.hip", "dm_zoomout.hip", "dm_zoomfuse.hip", "dm_icp.hip", "dm_simnn.hip", "dm_knnsplit.hip", "dm_energy.hip", "dm_assign.hip", "dm_precise.hip", "dm_eigen.hip", "dm_peaks.hip", "dm_lbfgs.hip", "dm_fitfuse.hip"]
+SOURCES = ["dm_ctx.hip", "dm_p2p.hip", "dm_fmap.hip", "dm_project.hip", "dm_zoomout.hip", "dm_zoomfuse.hip", "dm_icp.hip", "dm_simnn.hip", "dm_knnsplit.hip", "dm_energy.hip", "dm_assign.hip", "dm_precise.hip", "dm_eigen.hip", "dm_peaks.hip", "dm_lbfgs.hip", "dm_fitfuse.hip", "dm_laplacian.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 

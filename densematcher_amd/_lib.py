@@ -53,6 +53,11 @@ SIGNATURES = {
     "dm_mapped_indicator": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_p2p_to_fm": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "dm_eigenbasis": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "dm_tufted_cover": (_i, [_i, _i, _p, _p, _d, _p, _p, _p, _p]),
+    "dm_tufted_cover_batch": (_i, [_i, _p, _p, _p, _p, _d, _p, _p, _p, _p, _i]),
+    "dm_laplacian_rows_bytes": (C.c_size_t, [_i, _i, _i]),
+    "dm_laplacian_rows": (_i, [_p, _i, _i, _i, _p, _p, _p, _d, _p, _p, C.POINTER(_i)]),
+    "dm_laplacian_ell": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_precise_map": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_linear_sum_assignment": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "dm_p2p_to_fm_lstsq": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),

@@ -411,7 +411,12 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
                              int k, int guard, int n_iter, int degree, int warm_start, double* X /* B*N*(k+guard), in/out */,
                              double* lam /* B*k */, double* Phi /* B*N*k */, double* resid /* B */) {
     if (!ctx) return DM_EINVAL;
-    DM_REQUIRE(ctx, B > 0 && N > 0 && nnz > 0 && k > 0 && guard >= 0 && n_iter > 0, "sizes must be positive");
+    // warm_start == 2: the DENSE route for meshes too small for the filtered iteration -- X holds an orthonormal basis of the whole
+    // space (the identity: k + guard = N <= 512), no filter, ONE Rayleigh-Ritz step = the eigendecomposition of L itself
+    const bool dense = warm_start == 2;
+    if (dense) n_iter = 0;
+    DM_REQUIRE(ctx, B > 0 && N > 0 && nnz > 0 && k > 0 && guard >= 0 && (n_iter > 0 || dense), "sizes must be positive");
+    DM_REQUIRE(ctx, !dense || k + guard == N, "the dense route takes the whole space: k + guard = N");
     DM_REQUIRE(ctx, ell_cols && ell_vals && mass && X && lam && Phi && resid, "null pointer");
     const int m = k + guard;
     DM_REQUIRE(ctx, m <= N && m <= 512, "k + guard must be <= min(N, 512)");

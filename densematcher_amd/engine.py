@@ -509,12 +509,81 @@ class MatchEngine:
         self._chk(getattr(self.lib, "dm_p2p_to_fm" + sfx)(self.ctx, B, N1, N2, k1, k2, _ptr(p21), _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a2), _ptr(Cm)))
         return Cm
 
-    def eigenbasis(self, W_list, mass, k, guard=32, degree=30, tol=1e-9, max_rounds=12, seed=0):
+    def tufted_covers(self, meshes, mollify_factor=1e-5, n_threads=0):
+        """The tufted intrinsic-Delaunay cover of every (verts, faces) in `meshes` (dm_tufted_cover_batch: host C++ on a thread pool,
+        like the reference's robust_laplacian wheel).  Returns [(T (2 nf, 3) int32, L (2 nf, 3) f64, flips, converged, eps)]."""
+        import numpy as np
+        cnt = len(meshes)
+        V = [np.ascontiguousarray(v, dtype=np.float64) for v, _ in meshes]
+        F = [np.ascontiguousarray(f, dtype=np.int32) for _, f in meshes]
+        for v, f in zip(V, F):
+            if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3 or f.shape[0] == 0:
+                raise ValueError("tufted_covers: meshes are (verts (n, 3), faces (m, 3)) with at least one face")
+        T = [np.empty((2 * f.shape[0], 3), np.int32) for f in F]
+        L = [np.empty((2 * f.shape[0], 3), np.float64) for f in F]
+        info = np.zeros((cnt, 2), np.int32)
+        eps = np.zeros(cnt, np.float64)
+        n = np.array([v.shape[0] for v in V], np.int32)
+        nf = np.array([f.shape[0] for f in F], np.int32)
+        ptrs = lambda arrs: C.cast((C.c_void_p * cnt)(*[a.ctypes.data for a in arrs]), C.c_void_p)
+        rc = self.lib.dm_tufted_cover_batch(cnt, n.ctypes.data, nf.ctypes.data, ptrs(V), ptrs(F), float(mollify_factor), ptrs(T), ptrs(L),
+                                            info.ctypes.data, eps.ctypes.data, int(n_threads))
+        if rc != 0:
+            raise ValueError("tufted cover: face indices must lie in [0, n)")
+        return [(T[i], L[i], int(info[i, 0]), bool(info[i, 1]), float(eps[i])) for i in range(cnt)]
+
+    def laplacian_ell(self, tris, lens=None, verts=None, scale=1.0, want_w=True):
+        """Cotangent Laplacians of a batch of meshes assembled on the device (dm_laplacian_rows + dm_laplacian_ell).
+        tris: list of (nt_b, 3) int arrays; lens: list of (nt_b, 3) intrinsic side lengths, or None with verts: list of (n_b, 3)
+        coordinates (the reference's cotangent_weights / dia_area_mat arithmetic); meshes of different sizes are padded to the
+        largest (padding vertices become decoupled rows at the top of the spectrum).  n_verts of a mesh = len(verts[b]) or, with
+        lens, max index + 1 unless `verts` gives it.
+        Returns dict(cols (B,N,nnz) int32, vals (B,N,nnz) f64 [A^-1/2 W A^-1/2], mass32 (B,N), w (B,N,nnz) f64 [W] or None,
+        mass64 (B,N), nnz, n_verts (list))."""
+        import numpy as np
+        Bn = len(tris)
+        if lens is None and verts is None:
+            raise ValueError("laplacian_ell: pass intrinsic lengths or vertex coordinates")
+        n_verts = [int(np.asarray(v).shape[0]) for v in verts] if verts is not None else [int(np.max(t)) + 1 for t in tris]
+        N, nt = max(n_verts), max(int(np.asarray(t).shape[0]) for t in tris)
+        tri_h = np.full((Bn, nt, 3), -1, np.int32)
+        for b, t in enumerate(tris):
+            tri_h[b, :len(t)] = t
+        tri_d = torch.as_tensor(tri_h).to(self.device)
+        len_d = vert_d = None
+        if lens is not None:
+            len_h = np.ones((Bn, nt, 3), np.float64)
+            for b, l in enumerate(lens):
+                len_h[b, :len(l)] = l
+            len_d = torch.as_tensor(len_h).to(self.device)
+        else:
+            vert_h = np.zeros((Bn, N, 3), np.float64)
+            for b, v in enumerate(verts):
+                vert_h[b, :len(v)] = v
+            vert_d = torch.as_tensor(vert_h).to(self.device)
+        ragged = min(n_verts) < N
+        nv_d = torch.as_tensor(np.asarray(n_verts, np.int32)).to(self.device) if ragged else None
+        rows = torch.empty(int(self.lib.dm_laplacian_rows_bytes(Bn, N, nt)), dtype=torch.uint8, device=self.device)
+        mx = C.c_int(0)
+        self._chk(self.lib.dm_laplacian_rows(self.ctx, Bn, N, nt, _ptr(tri_d), _ptr(len_d), _ptr(vert_d), float(scale), _ptr(nv_d), _ptr(rows), C.byref(mx)))
+        nnz = int(mx.value)
+        cols = torch.empty((Bn, N, nnz), dtype=torch.int32, device=self.device)
+        vals = torch.empty((Bn, N, nnz), dtype=torch.float64, device=self.device)
+        mass32 = torch.empty((Bn, N), dtype=torch.float32, device=self.device)
+        w = torch.empty((Bn, N, nnz), dtype=torch.float64, device=self.device) if want_w else None
+        mass64 = torch.empty((Bn, N), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.dm_laplacian_ell(self.ctx, Bn, N, nt, _ptr(rows), nnz, _ptr(nv_d), _ptr(cols), _ptr(vals), _ptr(mass32), _ptr(w), _ptr(mass64)))
+        return {"cols": cols, "vals": vals, "mass32": mass32, "w": w, "mass64": mass64, "nnz": nnz, "n_verts": n_verts}
+
+    def eigenbasis(self, W_list, mass, k, guard=32, degree=30, tol=1e-9, max_rounds=12, seed=0, ell=None):
         """k smallest eigenpairs of W phi = lambda A phi for a batch of meshes (reference TriMesh.process ->
-        laplacian_spectrum: ARPACK on the host, one mesh at a time).  W_list: sparse stiffness matrices (host, SciPy);
-        mass (B,N) lumped masses, or a list of 1-D arrays when the vertex counts differ (Phi is then padded to the largest).
-        The sparsity bookkeeping (ELL layout of A^-1/2 W A^-1/2) is host work, as assembling W is in the reference; the
-        iteration runs on the GPU (dm_eigenbasis) until max_j |L x_j - lam_j x_j| <= tol * lam_k.
+        laplacian_spectrum: ARPACK on the host, one mesh at a time).
+        ell = the dict laplacian_ell returns (operands already on the device; W_list / mass are ignored), or
+        W_list: sparse stiffness matrices (host, SciPy) with mass (B,N) lumped masses, or a list of 1-D arrays when the vertex
+        counts differ (Phi is then padded to the largest) -- the ELL layout of A^-1/2 W A^-1/2 is then built on the host.
+        The iteration runs on the GPU (dm_eigenbasis) until max_j |L x_j - lam_j x_j| <= tol * lam_k.  Meshes too small for the
+        filtered subspace iteration (2 (k + guard) > N) take the dense route: the whole space as the subspace, one Rayleigh-Ritz
+        step (a Jacobi eigensolve of the N x N operator, N <= 512).
         Returns (lam (B,k) f64, Phi (B,N,k) f64, resid (B,), rounds)."""
         import numpy as np
         import scipy.sparse as sp
@@ -522,49 +591,60 @@ class MatchEngine:
         #  holds for those.  The float64 entry points downstream receive the caller's unrounded mesh.A: the basis is orthonormal
         #  for a mass vector that differs from theirs by <= 6e-8 relative -- far inside the 1e-4 bar on C, and the reason the
         #  eigenbasis tests compare with SciPy on the rounded masses.)
-        # Meshes of DIFFERENT vertex counts share a call too (`mass` a list of 1-D arrays): the smaller ones are padded with
-        # decoupled vertices whose only entry is a diagonal one AT the Gershgorin bound of the mesh's own operator
-        # (max_i sum_q |L_iq| >= lambda_max: the upper end of the interval the Chebyshev filter damps, dm_eigen.hip
-        # gershgorin_kernel), so the spurious eigenvalue can never fall inside the wanted part of the spectrum -- the largest
-        # diagonal entry, used before, ranks near the MIDDLE of the spectrum on a near-uniform mesh.  Their rows of Phi come
-        # back ~0 and the caller slices them off.
-        masses = [np.ascontiguousarray(a, dtype=np.float32).astype(np.float64).ravel() for a in mass]
-        B, N = len(masses), max(a.shape[0] for a in masses)
-        if any(np.any(a <= 0) for a in masses):
-            raise ValueError("eigenbasis: every vertex needs a positive lumped mass (isolated or degenerate vertices?)")
-        mats = []
-        for b in range(B):
-            d = sp.diags(1.0 / np.sqrt(masses[b]))
-            mats.append((d @ sp.csr_matrix(W_list[b]) @ d).tocsr())
-        nnz = max(int(np.diff(Lm.indptr).max()) for Lm in mats)
-        cols = np.tile(np.arange(N, dtype=np.int32)[None, :, None], (B, 1, nnz))
-        vals = np.zeros((B, N, nnz))
-        mass = np.ones((B, N))
-        for b, Lm in enumerate(mats):
-            nb = Lm.shape[0]
-            cnt = np.diff(Lm.indptr)
-            pos = np.arange(Lm.nnz) - np.repeat(Lm.indptr[:-1], cnt)
-            rows = np.repeat(np.arange(nb), cnt)
-            cols[b, rows, pos] = Lm.indices
-            vals[b, rows, pos] = Lm.data
-            mass[b, :nb] = masses[b]
-            if nb < N:
-                vals[b, nb:, 0] = float(abs(Lm).sum(axis=1).max())
-        nmin = min(a.shape[0] for a in masses)
-        if 2 * (k + guard) > nmin:
-            # (measured: with the wanted range reaching into the upper half of a spectrum the filtered block loses rank and the
-            #  Ritz step returns spurious zero pairs whose residual looks converged -- refuse instead of returning them)
-            raise ValueError(f"eigenbasis: k + guard = {k + guard} vectors need a mesh of at least {2 * (k + guard)} vertices "
-                             f"(the smallest has {nmin}): the subspace iteration resolves the lower half of a spectrum")
-        m = min(k + guard, N)
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        X = torch.randn((B, N, m), dtype=torch.float64, device=self.device, generator=g)
-        cols_d = torch.as_tensor(cols).to(self.device)
-        vals_d = torch.as_tensor(vals).to(self.device)
-        mass_d = torch.as_tensor(mass.astype(np.float32)).to(self.device)
+        # Meshes of DIFFERENT vertex counts share a call too: the smaller ones are padded with decoupled vertices whose only entry
+        # is a diagonal one AT the Gershgorin bound of the mesh's own operator (max_i sum_q |L_iq| >= lambda_max: the upper end of
+        # the interval the Chebyshev filter damps), so the spurious eigenvalue can never fall inside the wanted part of the
+        # spectrum.  Their rows of Phi come back ~0 and the caller slices them off.
+        if ell is not None:
+            cols_d, vals_d, mass_d, nnz = ell["cols"], ell["vals"], ell["mass32"], int(ell["nnz"])
+            B, N = mass_d.shape
+            nmin = min(ell["n_verts"])
+        else:
+            masses = [np.ascontiguousarray(a, dtype=np.float32).astype(np.float64).ravel() for a in mass]
+            B, N = len(masses), max(a.shape[0] for a in masses)
+            if any(np.any(a <= 0) for a in masses):
+                raise ValueError("eigenbasis: every vertex needs a positive lumped mass (isolated or degenerate vertices?)")
+            mats = []
+            for b in range(B):
+                d = sp.diags(1.0 / np.sqrt(masses[b]))
+                mats.append((d @ sp.csr_matrix(W_list[b]) @ d).tocsr())
+            nnz = max(int(np.diff(Lm.indptr).max()) for Lm in mats)
+            cols = np.tile(np.arange(N, dtype=np.int32)[None, :, None], (B, 1, nnz))
+            vals = np.zeros((B, N, nnz))
+            mass_h = np.ones((B, N))
+            for b, Lm in enumerate(mats):
+                nb = Lm.shape[0]
+                cnt = np.diff(Lm.indptr)
+                pos = np.arange(Lm.nnz) - np.repeat(Lm.indptr[:-1], cnt)
+                rows = np.repeat(np.arange(nb), cnt)
+                cols[b, rows, pos] = Lm.indices
+                vals[b, rows, pos] = Lm.data
+                mass_h[b, :nb] = masses[b]
+                if nb < N:
+                    vals[b, nb:, 0] = float(abs(Lm).sum(axis=1).max())
+            nmin = min(a.shape[0] for a in masses)
+            cols_d = torch.as_tensor(cols).to(self.device)
+            vals_d = torch.as_tensor(vals).to(self.device)
+            mass_d = torch.as_tensor(mass_h.astype(np.float32)).to(self.device)
         lam = torch.empty((B, k), dtype=torch.float64, device=self.device)
         Phi = torch.empty((B, N, k), dtype=torch.float64, device=self.device)
         resid = torch.empty((B,), dtype=torch.float64, device=self.device)
+        if k > nmin:
+            raise ValueError(f"eigenbasis: {k} eigenpairs asked of a mesh with {nmin} vertices")
+        if 2 * (k + guard) > nmin:
+            # (measured: with the wanted range reaching into the upper half of a spectrum the filtered block loses rank and the Ritz step
+            #  returns spurious zero pairs whose residual looks converged.)  Dense route: X = I, no filter -- the Rayleigh-Ritz step IS the
+            # eigendecomposition of L; the padding rows of a ragged batch sit at their Gershgorin bound, above every wanted pair.
+            if N > 512:
+                raise ValueError(f"eigenbasis: k + guard = {k + guard} vectors need a mesh of at least {2 * (k + guard)} vertices "
+                                 f"(the smallest has {nmin}); the dense route takes meshes up to 512 vertices, this batch has {N}")
+            X = torch.eye(N, dtype=torch.float64, device=self.device).repeat(B, 1, 1).contiguous()
+            self._chk(self.lib.dm_eigenbasis(self.ctx, B, N, nnz, _ptr(cols_d), _ptr(vals_d), _ptr(mass_d), k, N - k, 1, 2, 2,
+                                             _ptr(X), _ptr(lam), _ptr(Phi), _ptr(resid)))
+            return lam, Phi, resid, 0
+        m = min(k + guard, N)
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        X = torch.randn((B, N, m), dtype=torch.float64, device=self.device, generator=g)
         rounds = 0
         for rounds in range(1, max_rounds + 1):
             n_iter = 5 if rounds == 1 else 2

@@ -20,8 +20,26 @@ What is tested instead (tests/test_laplacian_cpu.py): on a Delaunay mesh the res
 of a planar triangulation (same geometry, worse triangles) gives the SAME matrix (the intrinsic Delaunay triangulation is
 unique); all edge weights are non-negative, rows sum to zero, masses sum to the area.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sparse
+
+# What `process(robust=True)` may run when the reference's `robust_laplacian` wheel cannot be imported:
+#   "wheel"     (default) nothing: ImportError -- a drop-in must not silently compute on an operator that is not pinned to the reference's
+#   "restated"  this package's own construction (dm_tufted_cover + device assembly in the product; robust_mesh_laplacian below is
+#               the NumPy restatement the CPU tests pin it to)
+_ROBUST_BACKEND = [os.environ.get("DENSEMATCHER_AMD_ROBUST_LAPLACIAN", "wheel")]
+
+
+def set_robust_backend(name):
+    if name not in ("wheel", "restated"):
+        raise ValueError("robust backend must be 'wheel' or 'restated'")
+    _ROBUST_BACKEND[0] = name
+
+
+def robust_backend():
+    return _ROBUST_BACKEND[0]
 
 
 def cotangent_laplacian(verts, faces):

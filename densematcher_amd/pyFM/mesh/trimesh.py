@@ -3,13 +3,17 @@ TriMesh: the data carrier of the matching path (reference: densematcher/pyFM/mes
 
 Only what the hot path consumes is kept: vertices / faces, the cotangent stiffness matrix W, the lumped
 (diagonal) mass matrix A, L = A^-1 W, the Laplace-Beltrami spectrum, `area`, `process`, `project`, `decode`.
-Producing the spectrum: the stiffness / mass matrices are assembled on the host like in the
-reference (trimesh.py:440-531 -> laplacian.py:143-182); the eigensolve -- ARPACK shift-invert there -- runs on the GPU
-(dm_eigenbasis: Chebyshev-filtered subspace iteration).
-The reference's `robust=True` uses the external `robust_laplacian` wheel (tufted intrinsic-Delaunay Laplacian with
-mollification); it is used here too when it can be imported.  When it cannot, this package's own implementation of the same
-construction runs (pyFM/mesh/laplacian.py: mollified lengths, tufted cover, intrinsic Delaunay flips) and a warning says that
-its parity with the wheel is unpinned.  `robust=False` is the classical cotangent Laplacian with lumped masses.
+Producing the spectrum (reference trimesh.py:440-531 -> laplacian.py:143-182): the stiffness rows,
+the lumped masses and A^-1/2 W A^-1/2 in ELL are assembled ON THE DEVICE for all meshes of a call (dm_laplacian_rows / dm_laplacian_ell),
+the eigensolve -- ARPACK shift-invert there -- runs on the GPU (dm_eigenbasis: Chebyshev-filtered subspace iteration; meshes too
+small for it take a dense Jacobi eigensolve).  `robust=False` is the classical cotangent Laplacian with lumped masses
+(laplacian.cotangent_weights / dia_area_mat of the reference, same arithmetic).
+The reference's `robust=True` uses the external `robust_laplacian` wheel (tufted intrinsic-Delaunay Laplacian with mollification);
+it is used here too when it can be imported.  When it cannot, `robust=True` FAILS unless the caller has opted into this package's
+own implementation of the same construction (laplacian.set_robust_backend("restated") or DENSEMATCHER_AMD_ROBUST_LAPLACIAN=restated
+in the environment): its parity with the wheel is unpinned (the wheel is not installable here, no network), and a drop-in must
+not silently compute on a different operator.  The restatement: dm_tufted_cover (host C++ like the wheel: mollified lengths,
+tufted cover, intrinsic Delaunay flips) + the device assembly on the cover's intrinsic lengths.
 """
 import warnings
 
@@ -24,7 +28,8 @@ class TriMesh:
         assert 0 < len(args) < 3, "Provide vertices / faces"
         if isinstance(args[0], str):
             raise NotImplementedError("mesh file loading is outside the matching path: pass (vertices, faces)")
-        self.W = None
+        self._W = None
+        self._W_dev = None               # (cols (N, nnz), w (N, nnz)) device tensors of the last device assembly: W is built from them on demand
         self.A = None
         self._L = None
         self.eigenvalues = None
@@ -45,7 +50,7 @@ class TriMesh:
         elif vertlist.shape[1] != 3:
             raise ValueError('Vertex list requires 3D coordinates')
         self._vertlist = vertlist.copy()
-        self.W = self.A = self._L = self.eigenvalues = self.eigenvectors = None
+        self._W = self._W_dev = self.A = self._L = self.eigenvalues = self.eigenvectors = None
 
     @property
     def facelist(self):
@@ -62,6 +67,24 @@ class TriMesh:
             self._facelist = facelist.astype(np.int64).copy()
         else:
             self._facelist = None
+
+    @property
+    def W(self):
+        """cotangent stiffness matrix (CSR).  After a device assembly it is materialised on first use (the matching path itself
+        never reads it)."""
+        if self._W is None and self._W_dev is not None:
+            cols, w = (t.cpu().numpy() for t in self._W_dev)
+            n = self.n_vertices
+            rows = np.repeat(np.arange(n), cols.shape[1])
+            Wm = sparse.coo_matrix((w.ravel(), (rows, cols.ravel().astype(np.int64))), shape=(n, n)).tocsr()   # (padding: zeros on the diagonal)
+            Wm.eliminate_zeros()
+            self._W = Wm
+        return self._W
+
+    @W.setter
+    def W(self, value):
+        self._W = value
+        self._W_dev = None
 
     vertices = property(lambda self: self._vertlist)
     faces = property(lambda self: self._facelist)
@@ -150,31 +173,61 @@ class TriMesh:
     def L(self, value):
         self._L = value
 
-    # ------------------------------------------------------------- spectrum (host side input of the path)
+    # ------------------------------------------------------------- spectrum
     def _assemble_laplacian(self, robust=False):
-        """W, A on the host (trimesh.py:440-482 -> laplacian.py:143-160); returns the lumped masses."""
-        if self.facelist is None:
-            raise NotImplementedError("point-cloud Laplacians are outside the matching path")
-        mass = None
+        """W, A of this mesh (trimesh.py:440-482 -> laplacian.py:143-160); returns the lumped masses."""
+        TriMesh._assemble_many([self], robust)
+        return np.asarray(self.A.diagonal())
+
+    @staticmethod
+    def _assemble_many(meshes, robust=False):
+        """Stiffness rows and lumped masses of several meshes.  Returns the dict MatchEngine.laplacian_ell produced (the operands of
+        dm_eigenbasis, on the device, meshes padded to the largest) -- or None when the robust_laplacian wheel assembled the
+        matrices on the host (the caller then hands W, A to the eigensolver as SciPy matrices)."""
+        from ...engine import default_engine
+        from . import laplacian as _lap
+        for mesh in meshes:
+            if mesh.facelist is None:
+                raise NotImplementedError("point-cloud Laplacians are outside the matching path")
         if robust:
             try:
                 import robust_laplacian                                       # trimesh.py:465-470
-                self.W, Am = robust_laplacian.mesh_laplacian(self.vertlist, self.facelist, mollify_factor=1e-5)
-                self.W = sparse.csr_matrix(self.W)
-                mass = np.asarray(Am.diagonal())
+                for mesh in meshes:
+                    Wm, Am = robust_laplacian.mesh_laplacian(mesh.vertlist, mesh.facelist, mollify_factor=1e-5)
+                    mesh.W = sparse.csr_matrix(Wm)
+                    mass = np.asarray(Am.diagonal())
+                    if np.any(mass <= 0):
+                        raise ValueError("vertices with zero lumped mass (isolated vertices or degenerate faces): clean the mesh first")
+                    mesh.A = sparse.diags(mass).tocsr()
+                    mesh._L = None
+                return None
             except ImportError:
-                from . import laplacian as _lap
+                if _lap.robust_backend() != "restated":
+                    raise ImportError(
+                        "process(robust=True) needs the `robust_laplacian` package (what the reference calls, pyFM/mesh/trimesh.py:465-470), "
+                        "which is not installed.  This package carries its own implementation of the same construction (tufted cover, "
+                        "intrinsic Delaunay flips, mollification), NOT pinned against the wheel: opt in with "
+                        "densematcher_amd.pyFM.mesh.laplacian.set_robust_backend('restated') or DENSEMATCHER_AMD_ROBUST_LAPLACIAN=restated, "
+                        "or pass robust=False for the plain cotangent Laplacian")
                 warnings.warn("robust=True: the robust_laplacian package is not installed; using this package's own tufted "
                               "intrinsic-Delaunay Laplacian (same construction, parity with the wheel unpinned)")
-                self.W, Am = _lap.robust_mesh_laplacian(self.vertlist, self.facelist, mollify_factor=1e-5)
-                mass = np.asarray(Am.diagonal())
-        if mass is None:
-            self.W, mass = synth.cotan_laplacian(self.vertlist, self.facelist)
-        if np.any(mass <= 0):
-            raise ValueError("vertices with zero lumped mass (isolated vertices or degenerate faces): clean the mesh first")
-        self.A = sparse.diags(mass).tocsr()
-        self._L = None
-        return mass
+        eng = default_engine()
+        if robust:
+            covers = eng.tufted_covers([(m.vertlist, m.facelist) for m in meshes], mollify_factor=1e-5)
+            bad = [i for i, c in enumerate(covers) if not c[3]]
+            if bad:
+                raise RuntimeError(f"intrinsic Delaunay flips did not converge for meshes {bad[:8]}")
+            ell = eng.laplacian_ell([c[0] for c in covers], lens=[c[1] for c in covers], verts=[m.vertlist for m in meshes], scale=0.5)
+        else:
+            ell = eng.laplacian_ell([m.facelist for m in meshes], verts=[m.vertlist for m in meshes], scale=1.0)
+        mass = ell["mass64"].cpu().numpy()
+        for b, mesh in enumerate(meshes):
+            n = mesh.n_vertices
+            mesh._W = None
+            mesh._W_dev = (ell["cols"][b, :n], ell["w"][b, :n])
+            mesh.A = sparse.diags(mass[b, :n]).tocsr()
+            mesh._L = None
+        return ell
 
     def _n_eigs(self, k):
         return min(max(20, k), self.n_vertices - 1)                           # laplacian.py:165 computes at least 20 pairs
@@ -192,12 +245,15 @@ class TriMesh:
 
     # ------------------------------------------------------------- spectrum (host side input of the path)
     def laplacian_spectrum(self, k, intrinsic=False, return_spectrum=True, robust=False, verbose=False):
-        """trimesh.py:440-496 -> laplacian.py:143-182.  W, A on the host; the k smallest eigenpairs on the GPU."""
-        mass = self._assemble_laplacian(robust)
+        """trimesh.py:440-496 -> laplacian.py:143-182.  W, A assembled on the device; the k smallest eigenpairs on the GPU."""
+        ell = TriMesh._assemble_many([self], robust)
         if k > 0:
             kk = self._n_eigs(k)
             from ...engine import default_engine
-            lam, phi, resid, _ = default_engine().eigenbasis([self.W], mass[None], kk, tol=1e-10)
+            if ell is None:
+                lam, phi, resid, _ = default_engine().eigenbasis([self.W], np.asarray(self.A.diagonal())[None], kk, tol=1e-10)
+            else:
+                lam, phi, resid, _ = default_engine().eigenbasis(None, None, kk, tol=1e-10, ell=ell)
             self._store_spectrum(lam[0], phi[0], resid[0], k)
             if return_spectrum:
                 return self.eigenvalues, self.eigenvectors
@@ -214,9 +270,9 @@ class TriMesh:
     @staticmethod
     def process_many(meshes, ks, robust=False, verbose=False):
         """mesh.process(k) for several meshes (FunctionalMapping.preprocess: functional.py:300-301 processes its two meshes one
-        after the other).  The eigensolver is a chain of small launches whose duration does not depend on how many meshes
-        ride along, so the meshes that still need a spectrum are solved in ONE batched call (engine.eigenbasis pads the
-        smaller ones); each keeps its own k pairs."""
+        after the other).  One device assembly and ONE batched eigensolve for the meshes that still need a spectrum (the
+        eigensolver is a chain of small launches whose duration does not depend on how many meshes ride along; the smaller meshes
+        are padded); each keeps its own k pairs."""
         todo = []
         for mesh, k in zip(meshes, ks):
             # (a subclass or a patched `process` -- a caller that supplies its own spectra -- keeps the say)
@@ -224,19 +280,26 @@ class TriMesh:
                 mesh.process(k, robust=robust, verbose=verbose)
             else:
                 todo.append((mesh, k))
-        # one batched call pads the smaller meshes with decoupled vertices at the top of their spectrum and solves all meshes
-        # for the largest k; when that k (plus the solver's guard vectors) would leave the lower half of the smallest mesh's
-        # spectrum the meshes are solved one by one, each with its own k
-        if len(todo) == 1 or (todo and 2 * (max(m._n_eigs(k) for m, k in todo) + 32) > min(m.n_vertices for m, k in todo)):
+        if not todo:
+            return meshes
+        from ...engine import default_engine
+        eng = default_engine()
+        kk = max(mesh._n_eigs(k) for mesh, k in todo)
+        nmin, nmax = min(m.n_vertices for m, _ in todo), max(m.n_vertices for m, _ in todo)
+        # one batched call pads the smaller meshes with decoupled vertices at the top of their spectrum and solves all meshes for the
+        # largest k; when that k (plus the solver's guard vectors) would leave the lower half of the smallest mesh's spectrum -- or
+        # exceed it -- the meshes are solved one by one, each with its own k (small ones by the dense route)
+        if len(todo) > 1 and (2 * (kk + 32) > nmin or kk > nmin - 1):
             for mesh, k in todo:
                 mesh.process(k, robust=robust, verbose=verbose)
-        elif todo:
-            masses = [mesh._assemble_laplacian(robust) for mesh, _ in todo]
-            kk = max(mesh._n_eigs(k) for mesh, k in todo)
-            from ...engine import default_engine
-            lam, phi, resid, _ = default_engine().eigenbasis([mesh.W for mesh, _ in todo], masses, kk, tol=1e-10)
-            for q, (mesh, k) in enumerate(todo):
-                mesh._store_spectrum(lam[q], phi[q], resid[q], k)
+            return meshes
+        ell = TriMesh._assemble_many([mesh for mesh, _ in todo], robust)
+        if ell is None:
+            lam, phi, resid, _ = eng.eigenbasis([mesh.W for mesh, _ in todo], [np.asarray(mesh.A.diagonal()) for mesh, _ in todo], kk, tol=1e-10)
+        else:
+            lam, phi, resid, _ = eng.eigenbasis(None, None, kk, tol=1e-10, ell=ell)
+        for q, (mesh, k) in enumerate(todo):
+            mesh._store_spectrum(lam[q], phi[q], resid[q], k)
         return meshes
 
     # ------------------------------------------------------------- vertex sampling (input of the subsampled ZoomOut)

@@ -334,10 +334,41 @@ int dm_p2p_to_fm_f64(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2,
  * Output: lam (B,k) fp64 ascending, Phi (B,N,k) fp64 (sign: largest entry of a column positive), resid (B) fp64 =
  * max_j |L x_j - lam_j x_j| over the k wanted pairs -- the caller iterates (warm_start = 1) until it is small enough.
  * ARPACK's output is not reproducible either (random start vector, arbitrary basis of multiple eigenvalues): parity is
- * stated on eigenvalues and invariant subspaces, never on bits.  k + guard <= min(N, 512). */
+ * stated on eigenvalues and invariant subspaces, never on bits.  k + guard <= min(N, 512).
+ * warm_start = 2: the dense route for small meshes (where ARPACK, laplacian.py:165, works for any k < N): X = the identity (k + guard =
+ * N <= 512), no filter, one Rayleigh-Ritz step = the Jacobi eigendecomposition of L; n_iter / degree are ignored. */
 int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* ell_cols, const double* ell_vals, const float* mass,
                   int k, int guard, int n_iter, int degree, int warm_start,
                   double* X, double* lam, double* Phi, double* resid);
+
+/* ---- Laplace-Beltrami operators ---------------------------------------------------------------------------------------
+ * What TriMesh.process assembles before its eigensolve (pyFM/mesh/trimesh.py:440-482).
+ *   dm_tufted_cover   HOST function (no device, no context, thread safe): the tufted intrinsic-Delaunay cover of one mesh -- the
+ *                     construction behind robust_laplacian.mesh_laplacian(V, F, mollify_factor) (external C++ wheel of the reference,
+ *                     trimesh.py:465-470): mollified edge lengths, front / back copy of every face glued around every edge,
+ *                     intrinsic edge flips until every cover edge is Delaunay.  T (2 nf, 3) int32 corner vertices and L (2 nf, 3)
+ *                     fp64 side lengths (side s runs from corner s to corner s + 1) of the cover's triangles; info = [flips,
+ *                     converged]; mollify_eps (nullable) = what was added to every length.  Its Laplacian = dm_laplacian_* of
+ *                     (T, L) with scale 1/2.
+ *   dm_laplacian_rows cotangent stiffness rows and lumped masses of B meshes of N vertices and nt triangles each, on the device, in a
+ *                     fixed order of additions.  tri (B,nt,3) int32; len (B,nt,3) fp64 intrinsic side lengths (Heron) or null: from
+ *                     verts (B,N,3) fp64 with the reference's arithmetic (laplacian.py:88-140, 5-40).  n_verts (B, nullable): meshes
+ *                     with fewer vertices / triangles ride along padded (triangles (-1,-1,-1); vertices >= n_verts[b] become decoupled
+ *                     rows at the top of the spectrum).  rows: dm_laplacian_rows_bytes of device memory; max_row (host): longest row.
+ *   dm_laplacian_ell  the operands of dm_eigenbasis from those rows: L = A^-1/2 W A^-1/2 in ELL (ell_cols, ell_vals (B,N,nnz), nnz >=
+ *                     max_row, padded with (col = row, val = 0)) and mass32 (B,N) = fp32(diag A); optional w_vals (B,N,nnz) = the
+ *                     entries of W itself and mass64 (B,N) fp64 (what TriMesh.W / TriMesh.A hold). */
+int dm_tufted_cover(int n, int nf, const double* verts /*host*/, const int32_t* faces /*host*/, double mollify_factor,
+                    int32_t* T /*host, 2 nf x 3*/, double* L /*host, 2 nf x 3*/, int32_t* info /*host, 2, nullable*/, double* mollify_eps /*host, nullable*/);
+/* dm_tufted_cover for `count` meshes on n_threads host threads (<= 0: one per hardware thread); arrays of per-mesh sizes and pointers */
+int dm_tufted_cover_batch(int count, const int32_t* n, const int32_t* nf, const double* const* verts, const int32_t* const* faces,
+                          double mollify_factor, int32_t* const* T, double* const* L, int32_t* info /*count x 2*/,
+                          double* mollify_eps /*count, nullable*/, int n_threads);
+size_t dm_laplacian_rows_bytes(int B, int N, int nt);
+int dm_laplacian_rows(dm_ctx* ctx, int B, int N, int nt, const int32_t* tri, const double* len /*nullable*/, const double* verts /*nullable*/,
+                      double scale, const int32_t* n_verts /*nullable*/, void* rows, int* max_row /*host*/);
+int dm_laplacian_ell(dm_ctx* ctx, int B, int N, int nt, const void* rows, int nnz, const int32_t* n_verts /*nullable*/,
+                     int32_t* ell_cols, double* ell_vals, float* mass32, double* w_vals /*nullable*/, double* mass64 /*nullable*/);
 
 /* ---- precise (barycentric) map ----------------------------------------------------
  * For every vertex i of mesh 2 the face of mesh 1 its spectral embedding projects onto and the barycentric coordinates

@@ -12,6 +12,10 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # process(robust=True) -- what FunctionalMapping.preprocess always asks for, like the reference -- needs the robust_laplacian wheel or
+    # an explicit opt-in to this package's restatement of it (it fails closed otherwise: tests/test_gpu_laplacian.py); the tests opt in
+    from densematcher_amd.pyFM.mesh import laplacian
+    laplacian.set_robust_backend("restated")
 
 
 def load_golden(name):

@@ -1,0 +1,179 @@
+"""
+GPU (-m gpu): the Laplace-Beltrami operators assembled on the device (dm_laplacian_rows / dm_laplacian_ell; reference
+pyFM/mesh/laplacian.py:5-40, 88-140 and the robust_laplacian wheel behind pyFM/mesh/trimesh.py:465-470) and the eigenbases built on
+them, against the host restatements, the reference's own spectra (fixtures) and SciPy's dense eigensolver.
+"""
+import numpy as np
+import pytest
+import scipy.linalg
+import scipy.sparse as sp
+
+from densematcher_amd import synth
+from densematcher_amd.pyFM.mesh import laplacian as lap
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_cotangent(V, F):
+    """laplacian.cotangent_weights + dia_area_mat of the reference, restated (pyFM/mesh/laplacian.py:88-140, 5-40)"""
+    v1, v2, v3 = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
+    u1, u2, u3 = v3 - v2, v1 - v3, v2 - v1
+    L1, L2, L3 = (np.linalg.norm(u, axis=1) for u in (u1, u2, u3))
+    A1 = np.einsum('ij,ij->i', -u2, u3) / (L2 * L3)
+    A2 = np.einsum('ij,ij->i', u1, -u3) / (L1 * L3)
+    A3 = np.einsum('ij,ij->i', -u1, u2) / (L1 * L2)
+    I = np.concatenate([F[:, 0], F[:, 1], F[:, 2]])
+    J = np.concatenate([F[:, 1], F[:, 2], F[:, 0]])
+    S = np.concatenate([A3, A1, A2])
+    S = 0.5 * S / np.sqrt(1 - S ** 2)
+    n = V.shape[0]
+    W = sp.coo_matrix((np.concatenate([-S, -S, S, S]), (np.concatenate([I, J, I, J]), np.concatenate([J, I, I, J]))), shape=(n, n)).tocsr()
+    fa = 0.5 * np.linalg.norm(np.cross(v2 - v1, v3 - v1), axis=1)
+    mass = np.bincount(F.ravel(), weights=np.repeat(fa / 3.0, 3), minlength=n)
+    return W, mass
+
+
+def _dense(ell, b, n):
+    cols, w = ell["cols"][b, :n].cpu().numpy(), ell["w"][b, :n].cpu().numpy()
+    rows = np.repeat(np.arange(n), cols.shape[1])
+    return sp.coo_matrix((w.ravel(), (rows, cols.ravel())), shape=(n, n)).toarray()
+
+
+def _meshes():
+    V1, F1 = synth.torus_mesh(40, 24, perturb=0.05, seed=3)
+    V2, F2 = synth.torus_mesh(32, 20, perturb=0.02, seed=1)
+    Vn = np.array([[0, 0, 0], [1, 0, 0], [0.5, 0.8, 0], [0.5, -0.7, 0.3], [0.5, 0.1, 0.9], [1.5, 0.9, 0.2]], float)
+    Fn = np.array([[0, 1, 2], [1, 0, 3], [0, 1, 4], [1, 5, 2]])
+    return [(V1, F1), (V2, F2), (Vn, Fn)]
+
+
+def test_plain_cotangent_assembly_equals_the_reference_arithmetic():
+    """robust = False: W, the lumped masses and the scaled ELL operand of a ragged batch (three meshes of 960, 640 and 6 vertices
+    in one call) against the reference's cotangent_weights / dia_area_mat; padding vertices sit at the Gershgorin bound"""
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    meshes = _meshes()
+    ell = eng.laplacian_ell([f for _, f in meshes], verts=[v for v, _ in meshes], scale=1.0)
+    N = ell["mass32"].shape[1]
+    assert N == 960 and ell["n_verts"] == [960, 640, 6]
+    for b, (V, F) in enumerate(meshes):
+        n = V.shape[0]
+        W, mass = _reference_cotangent(V, F)
+        Wd = _dense(ell, b, n)
+        assert np.abs(Wd - W.toarray()).max() <= 1e-11 * abs(W).max(), b
+        m64 = ell["mass64"][b, :n].cpu().numpy()
+        assert np.abs(m64 - mass).max() <= 1e-13 * mass.max()
+        assert np.array_equal(ell["mass32"][b, :n].cpu().numpy(), m64.astype(np.float32))
+        # the scaled operand: A^-1/2 W A^-1/2 with the fp32-rounded masses, entry by entry
+        cols, vals = ell["cols"][b].cpu().numpy(), ell["vals"][b].cpu().numpy()
+        mr = m64.astype(np.float32).astype(np.float64)
+        Ld = sp.coo_matrix((vals[:n].ravel(), (np.repeat(np.arange(n), cols.shape[1]), cols[:n].ravel())), shape=(n, n)).toarray()
+        want = W.toarray() / np.sqrt(np.outer(mr, mr))
+        assert np.abs(Ld - want).max() <= 1e-11 * np.abs(want).max()
+        if n < N:      # padding: decoupled rows whose single entry is the Gershgorin bound of the mesh's own operator, unit mass
+            g = np.abs(want).sum(axis=1).max()
+            assert np.all(cols[n:, 0] == np.arange(n, N)) and np.all(vals[n:, 1:] == 0)
+            assert np.abs(vals[n:, 0] - g).max() <= 1e-12 * g
+            assert np.all(ell["mass32"][b, n:].cpu().numpy() == 1.0)
+    # same input, same bits
+    ell2 = eng.laplacian_ell([f for _, f in meshes], verts=[v for v, _ in meshes], scale=1.0)
+    assert np.array_equal(ell2["vals"].cpu().numpy(), ell["vals"].cpu().numpy()) and np.array_equal(ell2["cols"].cpu().numpy(), ell["cols"].cpu().numpy())
+
+
+def test_robust_assembly_equals_the_numpy_restatement():
+    """robust = True, opted into the restatement: host cover (dm_tufted_cover_batch) + device assembly on the intrinsic lengths
+    against pyFM/mesh/laplacian.py:robust_mesh_laplacian (the NumPy restatement tests/test_laplacian_cpu.py pins)"""
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    meshes = _meshes()
+    covers = eng.tufted_covers(meshes)
+    assert all(c[3] for c in covers) and covers[0][2] > 200
+    ell = eng.laplacian_ell([c[0] for c in covers], lens=[c[1] for c in covers], verts=[v for v, _ in meshes], scale=0.5)
+    for b, (V, F) in enumerate(meshes):
+        n = V.shape[0]
+        W, M = lap.robust_mesh_laplacian(V, F)
+        assert np.abs(_dense(ell, b, n) - W.toarray()).max() <= 1e-9 * abs(W).max(), b
+        assert np.abs(ell["mass64"][b, :n].cpu().numpy() - M.diagonal()).max() <= 1e-12 * M.diagonal().max()
+
+
+def test_robust_fails_closed_without_the_wheel_or_the_opt_in():
+    from densematcher_amd.pyFM.mesh import TriMesh
+    V, F = synth.torus_mesh(16, 12, perturb=0.02, seed=1)
+    old = lap.robust_backend()
+    try:
+        lap.set_robust_backend("wheel")
+        try:
+            import robust_laplacian  # noqa: F401
+            pytest.skip("the wheel is installed here")
+        except ImportError:
+            pass
+        with pytest.raises(ImportError, match="robust_laplacian"):
+            TriMesh(V, F).process(k=20, robust=True)
+        TriMesh(V, F).process(k=20, robust=False)            # the plain Laplacian needs no wheel
+    finally:
+        lap.set_robust_backend(old)
+
+
+def test_spectra_against_the_reference_fixture(fx_cfg1):
+    """The fixture's spectra were produced by the REFERENCE (tools/make_golden.py: its own cotangent_weights / dia_area_mat + ARPACK).
+    Plain assembly + dm_eigenbasis reproduces both meshes' eigenvalues; mesh 1 is Delaunay (no flip, no mollification), so the
+    restated robust Laplacian must give the same spectrum there -- and a different one on mesh 2 (478 flips), by how much is printed"""
+    from densematcher_amd.pyFM.mesh import TriMesh
+    fx = fx_cfg1
+    k = int(fx["k"])
+    for which, delaunay in ((1, True), (2, False)):
+        V, F = fx[f"verts{which}"], fx[f"faces{which}"]
+        lam_ref = fx[f"lam{which}"][:k]
+        plain = TriMesh(V, F).process(k=k, robust=False)
+        assert np.abs(plain.eigenvalues - lam_ref).max() <= 1e-7 * lam_ref[-1], which
+        # the eigenvectors span the reference's eigenspaces (clusters apart by more than 1e-6 relative)
+        P = fx[f"Phi{which}"][:, :k].astype(np.float64)
+        a = fx[f"a{which}"].astype(np.float64)
+        G = plain.eigenvectors.T @ (a[:, None] * P)
+        sv = np.linalg.svd(G, compute_uv=False)
+        gap = (fx[f"lam{which}"][k] - lam_ref[-1]) / lam_ref[-1] if len(fx[f"lam{which}"]) > k else 1.0
+        if gap > 1e-3:
+            assert sv.min() >= 1 - 1e-4, (which, sv.min())
+        robust = TriMesh(V, F).process(k=k, robust=True)
+        d = np.abs(robust.eigenvalues - lam_ref).max() / lam_ref[-1]
+        print(f"mesh {which}: |lam_robust(restated) - lam_reference(cotangent)| / lam_k = {d:.2e}")
+        if delaunay:
+            assert d <= 1e-7
+            assert np.abs(robust.A.diagonal() - plain.A.diagonal()).max() <= 1e-12 * plain.A.diagonal().max()
+            assert abs(robust.W - plain.W).max() <= 1e-9 * abs(plain.W).max()
+        else:
+            assert d > 1e-6
+
+
+@pytest.mark.parametrize("n_u,n_v,k", [(16, 12, 60), (10, 8, 50), (24, 18, 200), (8, 5, 20)])
+def test_small_meshes_take_the_dense_route(n_u, n_v, k):
+    """2 (k + guard) > N: ARPACK (laplacian.py:165) works for any k < N; here the whole space is the subspace and the Rayleigh-Ritz
+    step is a Jacobi eigensolve -- eigenvalues against SciPy's dense generalised eigensolver, mass-orthonormal eigenvectors"""
+    from densematcher_amd.pyFM.mesh import TriMesh
+    V, F = synth.torus_mesh(n_u, n_v, perturb=0.03, seed=2)
+    n = V.shape[0]
+    mesh = TriMesh(V, F).process(k=k, robust=False)
+    W, mass = _reference_cotangent(V, F)
+    mr = mass.astype(np.float32).astype(np.float64)
+    kk = min(max(20, k), n - 1)
+    lam = scipy.linalg.eigh(W.toarray(), np.diag(mr), eigvals_only=True)[:min(k, kk)]
+    assert mesh.eigenvalues.shape[0] == min(k, kk)
+    assert np.abs(mesh.eigenvalues - lam).max() <= 1e-9 * max(lam[-1], 1.0)
+    G = mesh.eigenvectors.T @ (mr[:, None] * mesh.eigenvectors)
+    assert np.abs(G - np.eye(G.shape[0])).max() <= 1e-9
+    R = W @ mesh.eigenvectors - (mr[:, None] * mesh.eigenvectors) * mesh.eigenvalues[None, :]
+    assert np.abs(R).max() <= 1e-8 * max(lam[-1], 1.0)
+
+
+def test_process_many_pairs_a_small_and_a_large_mesh():
+    """FunctionalMapping.preprocess hands both meshes to one call: a 2048-vertex and a 60-vertex mesh with k = 25 cannot share the
+    filtered iteration (the small one takes the dense route on its own)"""
+    from densematcher_amd.pyFM.mesh import TriMesh
+    big = TriMesh(*synth.torus_mesh(64, 32, perturb=0.03, seed=3))
+    small = TriMesh(*synth.torus_mesh(10, 6, perturb=0.03, seed=4))
+    TriMesh.process_many([big, small], [25, 25], robust=True)
+    for m in (big, small):
+        assert m.eigenvalues.shape == (25,) and m.eigenvectors.shape == (m.n_vertices, 25)
+        mr = m.A.diagonal().astype(np.float32).astype(np.float64)
+        R = m.W @ m.eigenvectors - (mr[:, None] * m.eigenvectors) * m.eigenvalues[None, :]
+        assert np.abs(R).max() <= 1e-7 * max(m.eigenvalues[-1], 1.0)

@@ -815,7 +815,8 @@ def test_eigenbasis_small_mesh_beside_a_large_one(eng):
     """TriMesh.process_many on meshes of different vertex counts.  N = 700 beside 1200, k = 128: one batched call, the
     small mesh padded with decoupled vertices at the Gershgorin bound of its own operator (the top of the damped interval; the
     largest diagonal entry used before ranks near the middle of the spectrum).  N = 192, k = 128 > N / 2: the subspace iteration
-    cannot resolve the upper half of a spectrum -- it must say so instead of returning spurious pairs."""
+    cannot resolve the upper half of a spectrum (r04 refused such meshes) -- the meshes are then solved one by one and the small
+    one takes the dense route (r05: ARPACK in the reference handles any k < N, laplacian.py:165)."""
     import scipy.linalg
     from densematcher_amd import synth
     from densematcher_amd.pyFM.mesh import TriMesh
@@ -832,8 +833,16 @@ def test_eigenbasis_small_mesh_beside_a_large_one(eng):
         assert np.abs(G - np.eye(k)).max() <= 1e-6, n
         R = m.W @ m.eigenvectors - (a[:, None] * m.eigenvectors) * m.eigenvalues[None, :]
         assert np.abs(R).max() <= 1e-5 * w[k - 1], n
-    with pytest.raises(ValueError, match="lower half"):
-        TriMesh.process_many([TriMesh(*synth.torus_mesh(16, 12)), TriMesh(*synth.torus_mesh(40, 30, perturb=0.05, seed=2))], [k, k])
+    pair = [TriMesh(*synth.torus_mesh(16, 12)), TriMesh(*synth.torus_mesh(40, 30, perturb=0.05, seed=2))]
+    TriMesh.process_many(pair, [k, k])
+    for m in pair:
+        a = m.A.diagonal().astype(np.float32).astype(np.float64)
+        w = scipy.linalg.eigh(m.W.toarray(), np.diag(a), eigvals_only=True)
+        assert m.eigenvectors.shape == (m.n_vertices, k)
+        assert np.abs(m.eigenvalues - w[:k]).max() <= 1e-6 * w[k - 1], m.n_vertices
+    # beyond the dense route's size the refusal stays (k + guard vectors cannot sit in the lower half of 600 eigenvalues)
+    with pytest.raises(ValueError, match="dense route"):
+        TriMesh(*synth.torus_mesh(30, 20)).process(k=290)
 
 
 def test_maps_on_gpu_eigenbasis_match_maps_on_host_eigenbasis(eng):

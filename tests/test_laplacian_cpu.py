@@ -108,3 +108,59 @@ def test_mollification_rescues_a_degenerate_face():
     W, M = lap.robust_mesh_laplacian(V, F, mollify_factor=1e-5)
     assert lap.robust_mesh_laplacian.last_info["mollify_eps"] > 0
     assert np.isfinite(W.toarray()).all() and M.diagonal().min() > 0
+
+
+def _cover_laplacian(V, F):
+    """W, mass from the HOST C++ cover (dm_tufted_cover: cover + gluing + intrinsic Delaunay flips) with the assembly step of the
+    NumPy restatement (lap.robust_mesh_laplacian section 4) -- the arithmetic dm_laplacian_rows runs on the device"""
+    import ctypes as C
+    import scipy.sparse as sparse
+    from densematcher_amd import _lib
+    lib = _lib.load()
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    Fi = np.ascontiguousarray(F, dtype=np.int32)
+    n, nf = V.shape[0], Fi.shape[0]
+    T = np.empty((2 * nf, 3), np.int32)
+    L = np.empty((2 * nf, 3), np.float64)
+    info = np.zeros(2, np.int32)
+    eps = C.c_double(0.0)
+    rc = lib.dm_tufted_cover(n, nf, V.ctypes.data, Fi.ctypes.data, 1e-5, T.ctypes.data, L.ctypes.data, info.ctypes.data, C.cast(C.byref(eps), C.c_void_p))
+    assert rc == 0
+    area, cot = lap._areas_and_cots(L)
+    a_id, b_id = T.astype(np.int64), T[:, [1, 2, 0]].astype(np.int64)
+    w = 0.25 * cot
+    rows = np.concatenate([a_id.ravel(), b_id.ravel(), a_id.ravel(), b_id.ravel()])
+    cols = np.concatenate([b_id.ravel(), a_id.ravel(), a_id.ravel(), b_id.ravel()])
+    vals = np.concatenate([-w.ravel(), -w.ravel(), w.ravel(), w.ravel()])
+    W = sparse.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    mass = np.zeros(n)
+    np.add.at(mass, T.ravel(), np.repeat(0.5 * area / 3.0, 3))
+    return W, mass, info, eps.value
+
+
+def test_host_cover_equals_the_numpy_restatement():
+    """dm_tufted_cover (C++: what the product runs) against robust_mesh_laplacian (NumPy: the restatement the property tests above
+    pin) on meshes that need thousands of flips, on boundaries, on non-manifold edges and on a needle triangle that takes the
+    mollification: the intrinsic Delaunay triangulation is unique, so the two flip orders end at the same operator"""
+    cases = []
+    cases.append(synth.torus_mesh(40, 24, perturb=0.05, seed=3))                        # closed, ~ half of the quads flip
+    V, F = _planar(300, 5)
+    cases.append((V, _flip_some_edges(V, F, 60, 1)))                                    # boundary + bad interior edges
+    Vn = np.array([[0, 0, 0], [1, 0, 0], [0.5, 0.8, 0], [0.5, -0.7, 0.3], [0.5, 0.1, 0.9], [1.5, 0.9, 0.2]], float)
+    Fn = np.array([[0, 1, 2], [1, 0, 3], [0, 1, 4], [1, 5, 2]])                          # three faces around edge (0, 1), a fin, boundaries
+    cases.append((Vn, Fn))
+    Vd = np.array([[0, 0, 0], [1, 0, 0], [0.5, 1e-9, 0], [0.5, 1, 0], [0.5, -1, 0]], float)
+    Fd = np.array([[0, 1, 2], [0, 2, 3], [2, 1, 3], [1, 0, 4]])                          # a needle: mollified
+    cases.append((Vd, Fd))
+    for V, F in cases:
+        Wn, Mn = lap.robust_mesh_laplacian(V, F)
+        infn = dict(lap.robust_mesh_laplacian.last_info)
+        Wc, mc, info, eps = _cover_laplacian(V, F)
+        assert info[1] == 1 and infn["converged"]
+        assert abs(eps - infn["mollify_eps"]) <= 1e-15 * max(1.0, abs(eps))
+        scale = abs(Wn).max()
+        assert abs(Wc - Wn).max() <= 1e-9 * scale, (abs(Wc - Wn).max(), scale, info, infn)
+        assert np.abs(mc - Mn.diagonal()).max() <= 1e-12 * Mn.diagonal().max()
+    # the first case did flip
+    _, _, info, _ = _cover_laplacian(*cases[0])
+    assert info[0] > 200
