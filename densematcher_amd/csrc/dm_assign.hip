@@ -622,7 +622,7 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
         {                                                                                                              \
             rc = dm_grant_lds(ctx, (const void*)lsa_reg_kernel<CPT_, WARM_, NT_>, lds_reg);                            \
             if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", (lsa_reg_kernel<CPT_, WARM_, NT_>), dim3(B), dim3(NT_), lds_reg, Cm, R, Cn, \
+            DM_LAUNCH(ctx, (WARM_ ? "lsa_shortest_augmenting_path" : (RUNIF_ ? "lsa_rerun_in_order" : "lsa_in_order")), (lsa_reg_kernel<CPT_, WARM_, NT_>), dim3(B), dim3(NT_), lds_reg, Cm, R, Cn, \
                       maximize ? 1 : 0, gu, gv, outp, info, RUNIF_, WARM_ ? tie : (int32_t*)nullptr);                                                   \
         }
 #define LSA_REG_NT(WARM_, RUNIF_, NT_)                                                                                 \

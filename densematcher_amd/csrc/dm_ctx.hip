@@ -94,6 +94,10 @@ extern "C" size_t dm_workspace_bytes(const dm_ctx* ctx) { return ctx ? ctx->ws_b
 
 int dm_ws_reserve(dm_ctx* ctx, size_t total_bytes) {
     ctx->ws_off = 0;
+    // (the queue counters dm_last_requeued_rows reads live in the arena of the call that wrote them: a new call recycles -- or, growing,
+    //  frees -- that memory, so the pointer dies here; only the call that sets it again at its end makes the diagnostic valid.  ADVICE r04)
+    ctx->last_flag_counts = nullptr;
+    ctx->last_flag_sets = 0;
     total_bytes = dm_align_up(total_bytes + 4096, 1 << 20);
     if (total_bytes <= ctx->ws_bytes) return DM_OK;
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));

@@ -81,12 +81,16 @@ __global__ __launch_bounds__(256) void eig_reduce_partials_kernel(const double* 
 
 // ---- sparse product with the fused three-term recurrence ------------------------------------------------------------------
 // Ynew[i][c] = alpha (sum_nz L[i][n] Y[n][c] - cc Y[i][c]) - beta Yprev[i][c];  (alpha, cc, beta) = coef[b][step] or (1, 0, 0)
+// A workgroup covers 256 / cw rows x cw columns (cw = the block width rounded up to a power of two, <= 256): with one row per
+// workgroup a block of 52 vectors kept 52 of 256 lanes busy and 128 meshes took 324 us per product (r05: 72 ms of a 64-pair
+// compute_surface_map_batch call); same sums in the same order.
 __global__ __launch_bounds__(256) void spmm_ell_kernel(const double* __restrict__ vals, const int32_t* __restrict__ cols, int N, int nnz,
                                                        const double* __restrict__ Y, const double* __restrict__ Yprev,
-                                                       double* __restrict__ Ynew, int m, const double* __restrict__ coef, int step) {
-    const int b = blockIdx.z, i = blockIdx.x;              // (the row index rides on grid x: meshes above 65535 vertices)
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= m) return;
+                                                       double* __restrict__ Ynew, int m, const double* __restrict__ coef, int step, int cw) {
+    const int b = blockIdx.z, rpb = 256 / cw;
+    const int i = blockIdx.x * rpb + threadIdx.x / cw;      // (the row index rides on grid x: meshes above 65535 vertices)
+    const int c = blockIdx.y * cw + (threadIdx.x & (cw - 1));
+    if (c >= m || i >= N) return;
     const double* Yb = Y + (long long)b * N * m;
     const double* vr = vals + ((long long)b * N + i) * nnz;
     const int32_t* cr = cols + ((long long)b * N + i) * nnz;
@@ -358,9 +362,72 @@ __global__ __launch_bounds__(256) void eig_finish_kernel(const double* __restric
     if (t == 0) lam[(long long)b * k + c] = theta[(long long)b * m + c];
 }
 
+// Cholesky-QR building block: G = X^T X (m x m, symmetric positive definite) -> M = L^-T with G = L L^T, so that X M has
+// orthonormal columns.  One workgroup per mesh, G in the LDS (m <= 128: 129 KiB); right-looking factorisation, then column c of
+// L^-1 by forward substitution in thread c.  `shift` (relative to the mean diagonal entry) is added to the diagonal first: the
+// first of the two passes runs with 1e-13 so that a block at the edge of the factorisation's reach (condition 1e7) still factors;
+// the second pass sees a block orthonormal to ~1e-10 and runs unshifted.  A non-positive pivot sets fail[b] (the residual the
+// call returns for that mesh is then +inf: the caller's convergence test can never pass on a broken basis).
+constexpr int EIG_CHOLQR_MAX = 128;
+__global__ __launch_bounds__(256) void eig_chol_inv_kernel(const double* __restrict__ Gs, double* __restrict__ Ms, int m, double shift, int* __restrict__ fail) {
+    extern __shared__ __attribute__((aligned(16))) double chol_sm[];
+    __shared__ double s_piv;
+    __shared__ double red[4];
+    const int b = blockIdx.x, t = threadIdx.x, ld = m + 1;
+    double* A = chol_sm;                                   // [m][m + 1]
+    const double* G = Gs + (long long)b * m * m;
+    double tr = 0.0;
+    for (int e = t; e < m * m; e += 256) { const int i = e / m, j = e - i * m; const double x = G[e]; A[i * ld + j] = x; if (i == j) tr += x; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tr += __shfl_xor(tr, off);
+    if ((t & 63) == 0) red[t >> 6] = tr;
+    __syncthreads();
+    const double add = shift * ((red[0] + red[1]) + (red[2] + red[3])) / (double)m;
+    for (int j = t; j < m; j += 256) A[j * ld + j] += add;
+    __syncthreads();
+    bool bad = false;
+    for (int j = 0; j < m; ++j) {
+        if (t == 0) {
+            const double d = A[j * ld + j];
+            s_piv = (d > 0.0 && isfinite(d)) ? sqrt(d) : -1.0;
+        }
+        __syncthreads();
+        double piv = s_piv;
+        if (!(piv > 0.0)) { bad = true; piv = 1.0; }
+        const double inv = 1.0 / piv;
+        for (int i = j + t; i < m; i += 256) A[i * ld + j] = (i == j) ? piv : A[i * ld + j] * inv;      // column j of L
+        __syncthreads();
+        // trailing update: A[i][c] -= L[i][j] L[c][j] for j < c <= i
+        const int nrem = m - j - 1;
+        for (int e = t; e < nrem * nrem; e += 256) {
+            const int i = j + 1 + e / nrem, c = j + 1 + e % nrem;
+            if (c <= i) A[i * ld + c] -= A[i * ld + j] * A[c * ld + j];
+        }
+        __syncthreads();
+    }
+    if (bad && t == 0) atomicOr(fail + b, 1);
+    // M = L^-T: thread c solves L y = e_c (y_i = 0 for i < c); y_i, i > c, waits in the unused upper triangle A[c][i], then row c of M
+    double* M = Ms + (long long)b * m * m;
+    for (int c = t; c < m; c += 256) {
+        const double yc = 1.0 / A[c * ld + c];
+        for (int i = c + 1; i < m; ++i) {
+            double sacc = -A[i * ld + c] * yc;
+            for (int k = c + 1; k < i; ++k) sacc = fma(-A[i * ld + k], A[c * ld + k], sacc);
+            A[c * ld + i] = sacc / A[i * ld + i];
+        }
+        for (int i = 0; i < m; ++i) M[(long long)c * m + i] = i < c ? 0.0 : (i == c ? yc : A[c * ld + i]);
+    }
+}
+// resid[b] = +inf for the meshes whose orthonormalisation failed
+__global__ void eig_fail_kernel(const int* __restrict__ fail, int B, double* __restrict__ resid) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && fail[b]) resid[b] = DM_INF_F64;
+}
+
 // ---- building blocks on the host side ------------------------------------------------------------------------------------------
 struct eig_ws {
     int B, N, m;
+    int* fail;                      // (B) set when a Cholesky-QR pass met a non-positive pivot
     double *T, *W, *part;           // m x m scratch (x2) and split-K partials
     int nsplit, kchunk;             // split-K of the Gram products: rows per chunk by the block size only (never by the batch)
 };
@@ -407,6 +474,28 @@ static int eig_polar(dm_ctx* ctx, const eig_ws& w, double* Xa, double* Xb, doubl
     return DM_OK;
 }
 
+// orthonormal basis of span(X) (columns of unit length on entry): two Cholesky-QR passes for blocks up to 128 vectors -- two Gram
+// products, two small factorisations and two block products, 8 launches -- else the matrix-polynomial polar iteration (60 launches:
+// round 4 used it for every size; at 128 meshes its products were 39 of the eigensolver's 107 ms, and a third of its launches)
+static int eig_orthonormalize(dm_ctx* ctx, const eig_ws& w, double* Xa, double* Xb, double** result) {
+    if (w.m > EIG_CHOLQR_MAX) return eig_polar(ctx, w, Xa, Xb, result);
+    const size_t lds = (size_t)w.m * (w.m + 1) * 8;
+    int rc = dm_grant_lds(ctx, (const void*)eig_chol_inv_kernel, lds);
+    if (rc) return rc;
+    double* xo = Xa;
+    double* xn = Xb;
+    for (int pass = 0; pass < 2; ++pass) {
+        rc = eig_gram(ctx, w, xo, xo, w.T, 1);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "eig_chol_inv", eig_chol_inv_kernel, dim3(w.B), dim3(256), lds, (const double*)w.T, w.W, w.m, pass == 0 ? 1e-13 : 0.0, w.fail);
+        rc = eig_apply(ctx, w, xo, w.W, 1, 0.0, 1.0, xn);
+        if (rc) return rc;
+        double* tmp = xo; xo = xn; xn = tmp;
+    }
+    *result = xo;
+    return DM_OK;
+}
+
 extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* ell_cols, const double* ell_vals, const float* mass,
                              int k, int guard, int n_iter, int degree, int warm_start, double* X /* B*N*(k+guard), in/out */,
                              double* lam /* B*k */, double* Phi /* B*N*k */, double* resid /* B */) {
@@ -429,7 +518,7 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
     w.kchunk = m <= TN_T ? 128 : 512;
     w.nsplit = dm_cdiv(N, w.kchunk);
     int rc = dm_ws_reserve(ctx, 3 * dm_align_up(bX) + 5 * dm_align_up(bM) + dm_align_up((size_t)w.nsplit * bM) + dm_align_up((size_t)B * m * 8) +
-                                    dm_align_up((size_t)B * EIG_MAX_DEG * 3 * 8) + 2 * dm_align_up((size_t)B * 8) + 4096);
+                                    dm_align_up((size_t)B * EIG_MAX_DEG * 3 * 8) + 3 * dm_align_up((size_t)B * 8) + 4096);
     if (rc) return rc;
     double* Ya = (double*)dm_ws_take(ctx, bX);
     double* Yb = (double*)dm_ws_take(ctx, bX);
@@ -444,24 +533,29 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
     double* coef = (double*)dm_ws_take(ctx, (size_t)B * EIG_MAX_DEG * 3 * 8);
     double* lmax = (double*)dm_ws_take(ctx, (size_t)B * 8);
     unsigned long long* rbits = (unsigned long long*)dm_ws_take(ctx, (size_t)B * 8);
+    w.fail = (int*)dm_ws_take(ctx, (size_t)B * 4);
+    if (!w.fail) return dm_fail(ctx, DM_ENOMEM, "eigenbasis: workspace not reserved");
+    DM_CHECK_HIP(ctx, hipMemsetAsync(w.fail, 0, (size_t)B * 4, ctx->stream));
     if (!Ya || !Yb || !Yc || !H || !V || !Q || !w.T || !w.W || !w.part || !theta || !coef || !lmax || !rbits)
         return dm_fail(ctx, DM_ENOMEM, "eigenbasis: workspace not reserved");
     DM_LAUNCH(ctx, "eig_gershgorin", gershgorin_kernel, dim3(B), dim3(256), 0, ell_vals, N, nnz, lmax);
-    const dim3 gsp(N, dm_cdiv(m, 256), B);
+    int spmm_cw = 16;
+    while (spmm_cw < m && spmm_cw < 256) spmm_cw <<= 1;
+    const dim3 gsp(dm_cdiv(N, 256 / spmm_cw), dm_cdiv(m, spmm_cw), B);
     const double* Xcur = X;
 
     if (!warm_start) {      // the caller's X holds a random block: orthonormalise it (unit columns / sqrt(m): singular values <= 1)
         DM_LAUNCH(ctx, "eig_unit_columns", unit_columns_kernel, dim3(m, B), dim3(256), 0, X, N, m, 1.0 / sqrt((double)m));
         double* r = nullptr;
         DM_CHECK_HIP(ctx, hipMemcpyAsync(Ya, X, bX, hipMemcpyDeviceToDevice, ctx->stream));
-        rc = eig_polar(ctx, w, Ya, Yb, &r);
+        rc = eig_orthonormalize(ctx, w, Ya, Yb, &r);
         if (rc) return rc;
         DM_CHECK_HIP(ctx, hipMemcpyAsync(X, r, bX, hipMemcpyDeviceToDevice, ctx->stream));
     }
     for (int it = 0; it <= n_iter; ++it) {
         // Rayleigh-Ritz on span(Xcur): H = X^T L X, eigen-decomposition, X <- X Q
         DM_LAUNCH(ctx, "eig_spmm", spmm_ell_kernel, gsp, dim3(256), 0, ell_vals, ell_cols, N, nnz, Xcur, (const double*)nullptr,
-                  Ya, m, (const double*)nullptr, 0);
+                  Ya, m, (const double*)nullptr, 0, spmm_cw);
         rc = eig_gram(ctx, w, Xcur, Ya, H, 1);
         if (rc) return rc;
         const size_t jac_lds = (size_t)2 * m * m * 8;
@@ -488,7 +582,7 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
         const double* ycur = y0;
         for (int j = 1; j <= deg; ++j) {
             double* ynew = bufs[j % 3];
-            DM_LAUNCH(ctx, "eig_spmm", spmm_ell_kernel, gsp, dim3(256), 0, ell_vals, ell_cols, N, nnz, ycur, yprev, ynew, m, (const double*)coef, j - 1);
+            DM_LAUNCH(ctx, "eig_spmm", spmm_ell_kernel, gsp, dim3(256), 0, ell_vals, ell_cols, N, nnz, ycur, yprev, ynew, m, (const double*)coef, j - 1, spmm_cw);
             yprev = ycur; ycur = ynew;
         }
         // orthonormalise the filtered block
@@ -496,16 +590,17 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
         DM_LAUNCH(ctx, "eig_unit_columns", unit_columns_kernel, dim3(m, B), dim3(256), 0, Yf, N, m, 1.0 / sqrt((double)m));
         double* other = (Yf == Ya) ? Yb : Ya;
         double* r = nullptr;
-        rc = eig_polar(ctx, w, Yf, other, &r);
+        rc = eig_orthonormalize(ctx, w, Yf, other, &r);
         if (rc) return rc;
         DM_CHECK_HIP(ctx, hipMemcpyAsync(X, r, bX, hipMemcpyDeviceToDevice, ctx->stream));   // (the three Y buffers are scratch again)
     }
     // residual of the k wanted pairs, outputs
     DM_LAUNCH(ctx, "eig_spmm", spmm_ell_kernel, gsp, dim3(256), 0, ell_vals, ell_cols, N, nnz, (const double*)X, (const double*)nullptr, Ya, m,
-              (const double*)nullptr, 0);
+              (const double*)nullptr, 0, spmm_cw);
     DM_CHECK_HIP(ctx, hipMemsetAsync(rbits, 0, (size_t)B * 8, ctx->stream));
     DM_LAUNCH(ctx, "eig_residual", ritz_residual_kernel, dim3(k, B), dim3(256), 0, (const double*)X, (const double*)Ya, N, m, (const double*)theta, rbits);
     DM_CHECK_HIP(ctx, hipMemcpyAsync(resid, rbits, (size_t)B * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    DM_LAUNCH(ctx, "eig_fail", eig_fail_kernel, dim3(dm_cdiv(B, 256)), dim3(256), 0, (const int*)w.fail, B, resid);
     DM_LAUNCH(ctx, "eig_finish", eig_finish_kernel, dim3(k, B), dim3(256), 0, (const double*)X, N, m, k, mass, (const double*)theta, Phi, lam);
     return DM_OK;
 }

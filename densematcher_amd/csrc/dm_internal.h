@@ -13,7 +13,9 @@
 
 #include "densematch.h"
 
-#define DM_VERSION_STRING "densematch 0.1.0 (gfx950)"
+// (abi N: bumped whenever an existing entry point changes what it reads or writes -- abi 5: dm_fmap_energy_grad / dm_fmap_fit_steps read TEN
+//  weights (w_area, w_conformal appended in round 4); dm_eigenbasis warm_start = 2; dm_laplacian_*, dm_fmap_fit_fused added)
+#define DM_VERSION_STRING "densematch 0.5.0 (gfx950, abi 5)"
 
 struct dm_ctx {
     int device = 0;

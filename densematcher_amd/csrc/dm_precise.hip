@@ -204,34 +204,51 @@ __global__ __launch_bounds__(256) void precise_project_kernel(const double* __re
     const bool listed = ncand <= PM_MAXCAND;          // else: every face is visited and the candidate test repeated (uniform per wave)
     if (!listed && t == 0) overflow[b] = 1;           // informational: the slow route was taken for some point of this pair
     const bool multi = ncand > 1;
-    // project on every candidate: one candidate per wave at a time (the result is the lexicographic minimum of (distance,
-    // face index): independent of the order the list was filled in)
+    // project on the candidates: G lanes per candidate (16 for maps up to 16 columns, 32 up to 32, else the whole wave), 64 / G
+    // candidates per wave at a time -- every candidate is a chain of dependent gathers (face -> three embedding rows), and with k = 15
+    // a wave per candidate left 49 lanes idle through it: 46 ms for 64 pairs (r05).  The sums are the same additions as before: a lane
+    // holds the same elements, the butterfly over G lanes is the tail of the one over 64 (whose upper levels added zeros).
+    // (The result is the lexicographic minimum of (distance, face index): independent of the order the list was filled in.)
+    const int G = k <= 16 ? 16 : (k <= 32 ? 32 : 64), per_wave = 64 / G, sl = lane & (G - 1), grp = lane / G;
     double bd = DM_INF_F64, bs = 0.0, bt = 0.0;
     int bf = DM_IDX_NONE;
     const int nloop = listed ? ncand : nf;
-    for (int q = wave; q < nloop; q += 4) {
-        const int f = listed ? cand[q] : q;
-        if (!listed) {
-            const int32_t* fw = faces + ((long long)b * nf + f) * 3;
-            const double dmin = fmin(fmin(drow[fw[0]], drow[fw[1]]), drow[fw[2]]);
-            if (!(dmin - fc[((long long)b * nf + f) * 4 + 3] < Deltamin)) continue;
+    for (int q0 = wave * per_wave; q0 < nloop; q0 += 4 * per_wave) {
+        const int q = q0 + grp;
+        bool live = q < nloop;
+        int f = 0;
+        if (live) {
+            f = listed ? cand[q] : q;
+            if (!listed) {
+                const int32_t* fw = faces + ((long long)b * nf + f) * 3;
+                const double dmin = fmin(fmin(drow[fw[0]], drow[fw[1]]), drow[fw[2]]);
+                if (!(dmin - fc[((long long)b * nf + f) * 4 + 3] < Deltamin)) live = false;
+            }
         }
-        const int32_t* fv = faces + ((long long)b * nf + f) * 3;
-        const double* p0 = E1 + ((long long)b * N1 + fv[0]) * k;
-        const double* p1 = E1 + ((long long)b * N1 + fv[1]) * k;
-        const double* p2 = E1 + ((long long)b * N1 + fv[2]) * k;
         double d = 0.0, e = 0.0, ff = 0.0;
-        for (int c = lane; c < k; c += 64) {
-            const double base = p0[c], diff = base - pt[c];
-            d += (p1[c] - base) * diff; e += (p2[c] - base) * diff; ff += diff * diff;
+        if (live) {
+            const int32_t* fv = faces + ((long long)b * nf + f) * 3;
+            const double* p0 = E1 + ((long long)b * N1 + fv[0]) * k;
+            const double* p1 = E1 + ((long long)b * N1 + fv[1]) * k;
+            const double* p2 = E1 + ((long long)b * N1 + fv[2]) * k;
+            for (int c = sl; c < k; c += G) {
+                const double base = p0[c], diff = base - pt[c];
+                d += (p1[c] - base) * diff; e += (p2[c] - base) * diff; ff += diff * diff;
+            }
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { d += __shfl_xor(d, off); e += __shfl_xor(e, off); ff += __shfl_xor(ff, off); }
-        const double* cst = fc + ((long long)b * nf + f) * 4;
-        double s_, t_, sq;
-        point_triangle(cst[0], cst[1], cst[2], d, e, ff, multi, s_, t_, sq);
-        const double dd = sqrt(fmax(sq, 0.0));
-        if (dd < bd || (dd == bd && f < bf)) { bd = dd; bf = f; bs = s_; bt = t_; }
+        for (int off = G >> 1; off > 0; off >>= 1) { d += __shfl_xor(d, off); e += __shfl_xor(e, off); ff += __shfl_xor(ff, off); }
+        if (live) {
+            const double* cst = fc + ((long long)b * nf + f) * 4;
+            double s_, t_, sq;
+            point_triangle(cst[0], cst[1], cst[2], d, e, ff, multi, s_, t_, sq);
+            const double dd = sqrt(fmax(sq, 0.0));
+            if (dd < bd || (dd == bd && f < bf)) { bd = dd; bf = f; bs = s_; bt = t_; }
+        }
+    }
+    for (int off = G; off < 64; off <<= 1) {                  // the wave's groups: lexicographic minimum
+        const double od = __shfl_xor(bd, off), os = __shfl_xor(bs, off), ot = __shfl_xor(bt, off);
+        const int of = __shfl_xor(bf, off);
+        if (od < bd || (od == bd && of < bf)) { bd = od; bf = of; bs = os; bt = ot; }
     }
     if (lane == 0) { w_dist[wave] = bd; w_face[wave] = bf; w_s[wave] = bs; w_t[wave] = bt; }
     __syncthreads();

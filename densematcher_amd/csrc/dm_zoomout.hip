@@ -401,7 +401,9 @@ static int zoomout_fused(dm_ctx* ctx, int B, int N1, int N2, int k0, int nit, in
     const size_t need = dm_align_up((size_t)B * N2 * 8) + dm_align_up(bytes_Fx) + dm_align_up(bytes_Fy) + 2 * dm_align_up(bytes_C) +
                         dm_align_up((size_t)B * R1 * 4) + dm_align_up((size_t)B * N1pad * 8) + dm_align_up((size_t)B * N1 * Kpad * 8) +
                         3 * dm_align_up((size_t)B * N2 * 4) + dm_align_up((size_t)B * ZO_NCH * 8) + dm_align_up(bytes_zero) +
-                        dm_simnn_ws_bytes(B, N2, N1, 0) + dm_p2pfm_xs_bytes(B, N2, kf) + 65536;
+                        dm_simnn_ws_bytes(B, N2, N1, 0) + dm_p2pfm_ws_bytes(B, N2, kf, kf) + 65536;
+    // (dm_p2pfm_ws_bytes = the prescaled basis Xs AND the split-K partials of the staged p2p_to_FM, which dm_launch_p2p_to_fm falls back
+    //  to beyond 15000 target vertices or with p2pfm_direct = 0: ADVICE r04 -- with the Xs share alone that fallback ran out of workspace)
     int rc = dm_ws_reserve(ctx, need);
     if (rc) return rc;
     const double* mass2 = nullptr;

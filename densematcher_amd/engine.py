@@ -643,15 +643,34 @@ class MatchEngine:
                                              _ptr(X), _ptr(lam), _ptr(Phi), _ptr(resid)))
             return lam, Phi, resid, 0
         m = min(k + guard, N)
-        g = torch.Generator(device=self.device).manual_seed(seed)
-        X = torch.randn((B, N, m), dtype=torch.float64, device=self.device, generator=g)
+        # A mesh's result must not depend on the batch it is solved in: its start block is drawn for ITS vertex count (one draw per
+        # distinct count, the same seed; padding rows start at zero), and its outputs are latched the first time its own residual
+        # passes -- the batch iterates on until the last mesh has, but a mesh that was done keeps what it had.
+        nvs = ell["n_verts"] if ell is not None else [a.shape[0] for a in masses]
+        X = torch.zeros((B, N, m), dtype=torch.float64, device=self.device)
+        draws = {}
+        for b, nb in enumerate(nvs):
+            if nb not in draws:
+                g = torch.Generator(device=self.device).manual_seed(seed)
+                draws[nb] = torch.randn((nb, m), dtype=torch.float64, device=self.device, generator=g)
+            X[b, :nb] = draws[nb]
+        lam_w, Phi_w, resid_w = torch.empty_like(lam), torch.empty_like(Phi), torch.empty_like(resid)
+        done = torch.zeros((B,), dtype=torch.bool, device=self.device)
         rounds = 0
         for rounds in range(1, max_rounds + 1):
             n_iter = 5 if rounds == 1 else 2
             self._chk(self.lib.dm_eigenbasis(self.ctx, B, N, nnz, _ptr(cols_d), _ptr(vals_d), _ptr(mass_d), k, m - k, n_iter, degree,
-                                             0 if rounds == 1 else 1, _ptr(X), _ptr(lam), _ptr(Phi), _ptr(resid)))
-            scale = torch.clamp(lam[:, -1].abs(), min=1e-300)
-            if bool((resid <= tol * scale).all()):
+                                             0 if rounds == 1 else 1, _ptr(X), _ptr(lam_w), _ptr(Phi_w), _ptr(resid_w)))
+            scale = torch.clamp(lam_w[:, -1].abs(), min=1e-300)
+            ok = resid_w <= tol * scale
+            take = ~done if rounds == max_rounds else (ok & ~done)        # (the last round: whatever is there, the caller judges the residual)
+            if B == 1:
+                if bool(take[0]):
+                    lam, Phi, resid = lam_w, Phi_w, resid_w
+            else:
+                lam[take], Phi[take], resid[take] = lam_w[take], Phi_w[take], resid_w[take]
+            done |= ok
+            if bool(done.all()):
                 break
         return lam, Phi, resid, rounds
 

@@ -27,7 +27,7 @@ def _assign(matrix):
     return rows, col[rows]
 
 
-_ASSIGN_STACK_LIMIT = 2 << 30
+_ASSIGN_STACK_LIMIT = 16 << 30     # bytes of dense matrices copied side by side for one assignment launch (288 GB of HBM on the part)
 
 
 def _assign_many(matrices):
@@ -112,46 +112,26 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
             p2p_21_adjoint, p2p_12_adjoint, p2p_21_icp_adjoint, p2p_12_icp_adjoint)
 
 
-def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_extra=False, optimizer="fmin_l_bfgs_b", descr_type="neural",
-                              maxiter=100000, optimize_p2p=False, fit_params=None):
-    """compute_surface_map for a list of mesh pairs: returns the list of the 14-tuples compute_surface_map returns, each equal to the
-    single call's (same kernels, and every kernel's result for a pair is independent of the batch it is in).  No counterpart in
-    the reference (it matches one pair per call, functional_map.py:9-81): this is its documented call with the batch dimension the
-    GPU path has everywhere -- one batched eigensolve for all 2 B meshes, one device L-BFGS over B maps, the 2 x 4 vertex maps,
-    precise maps and ICP of all pairs in one library call each, and all 3 B linear assignments side by side (one workgroup per
-    matrix; a single call leaves 253 of 256 CUs idle there).  Pairs are grouped by (vertex counts, face count of mesh 1): the
-    batched kernels take one size per call; a group of one runs the single call."""
+def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenbases=None):
+    """the pairs `idx` of a batch on the CURRENT stream's engine: eigenbases of their 2 len(idx) meshes in one batched solve, then per group
+    of equal sizes one device L-BFGS, one call per map stage, all assignments of the group side by side"""
     import torch
     from .engine import default_engine
     from .pyFM.spectral.convert import MappedIndicator, _real_dtype
-    assert descr_type == "neural", "the batched call takes network descriptors (descr_type='neural')"
-    B = len(meshes1_t)
-    assert len(meshes2_t) == B and len(c1s) == B and len(c2s) == B
-    fit_params = dict(fit_params or {})
-    fit_params.pop("verbose", None)
-    timing = os.environ.get("TIMEIT", False)
-    if timing:
-        compute_extra = True
     eng = default_engine()
-    models = []
-    for i in range(B):
-        m1 = TriMesh(_np(meshes1_t[i].verts_list()[0]), _np(meshes1_t[i].faces_list()[0]))
-        m2 = TriMesh(_np(meshes2_t[i].verts_list()[0]), _np(meshes2_t[i].faces_list()[0]))
-        model = FunctionalMapping(m1, m2, partial=False, optimizer=optimizer)
-        model.k1, model.k2 = n_ev, n_ev
-        model.descr1, model.descr2 = _np(c1s[i]), _np(c2s[i])
-        models.append(model)
-    # ---- eigenbases: every mesh of every pair in one batched solve (FunctionalMapping.preprocess: functional.py:300-301)
-    all_meshes = [m for model in models for m in (model.mesh1, model.mesh2)]
+    # ---- eigenbases: every mesh of the chunk in one batched solve (FunctionalMapping.preprocess: functional.py:300-301)
+    all_meshes = [m for i in idx for m in (models[i].mesh1, models[i].mesh2)]
     type(all_meshes[0]).process_many(all_meshes, [n_ev] * len(all_meshes), robust=True)
-    out = [None] * B
+    if after_eigenbases is not None:
+        after_eigenbases()
     groups = {}
-    for i, model in enumerate(models):
+    for i in idx:
+        model = models[i]
         key = (model.mesh1.n_vertices, model.mesh2.n_vertices, model.mesh1.facelist.shape[0], model.descr1.shape[1],
                str(model.descr1.dtype), str(model.descr2.dtype))
         groups.setdefault(key, []).append(i)
-    for key, idx in groups.items():
-        g = [models[i] for i in idx]
+    for key, gidx in groups.items():
+        g = [models[i] for i in gidx]
         nb = len(g)
         rdt = _real_dtype(g[0].mesh1.eigenvectors, g[0].mesh2.eigenvectors)
         st = lambda f, dt: np.ascontiguousarray(np.stack([f(m) for m in g]), dtype=dt)
@@ -168,16 +148,7 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
                "F1": eng._dev(F1, tdt[fdt], "F1"), "F2": eng._dev(F2, tdt[fdt], "F2")}
         fp = dict(w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_p2p=0, w_stochastic=0, w_ent=0, w_range01=0, w_sumto1=0, w_area=0, w_conformal=0,
                   optinit="zeros", maxiter=1000000, stopping="reference")
-        unknown = set(fit_params) - set(fp) - {"w_orient", "w_area_difference", "w_mumford_shah", "mumford_shah_var",
-                                               "w_eta_entropy", "orient_reversing", "device", "driver"}
-        if unknown:
-            raise TypeError(f"fit() got unexpected keyword arguments {sorted(unknown)}")
         fp.update({k_: v for k_, v in fit_params.items() if k_ in fp})
-        if any(fit_params.get(n, 0) > 0 for n in ("w_area_difference", "w_mumford_shah", "w_eta_entropy")):
-            raise NotImplementedError("area-difference / Mumford-Shah / eta-entropy terms are not on the accelerated path; pass 0")
-        if fit_params.get("w_orient", 0) > 0:
-            raise NotImplementedError("w_orient: the orientation operators are built per pair on the host (FunctionalMapping.fit); "
-                                      "use compute_surface_map for it")
         general = {n: fp[n] for n in ("w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1", "w_area", "w_conformal")}
         if any(v > 0 for v in general.values()):
             from .pyFM.functional import LBFGS_OPTIONS
@@ -209,7 +180,12 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
         Mi = eng.mapped_indicator(P1, P2, A1d, Ci)
         # ---- every assignment of the group in one launch
         mats = ([M0, prec] if compute_extra else []) + [Mi]
-        cols = eng.linear_sum_assignment(torch.cat(mats, dim=0), maximize=True).cpu().numpy().astype(np.int64)
+        # (one launch for all of them -- a matrix is one workgroup -- unless the concatenation, a COPY next to the originals, would pass
+        #  the same limit _assign_many has: then kind by kind)
+        if sum(m_.numel() * m_.element_size() for m_ in mats) > _ASSIGN_STACK_LIMIT and len(mats) > 1:
+            cols = np.concatenate([eng.linear_sum_assignment(m_, maximize=True).cpu().numpy() for m_ in mats]).astype(np.int64)
+        else:
+            cols = eng.linear_sum_assignment(torch.cat(mats, dim=0) if len(mats) > 1 else mats[0], maximize=True).cpu().numpy().astype(np.int64)
 
         def assignment(c):
             rows = np.nonzero(c >= 0)[0]
@@ -217,7 +193,7 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
         h = {n: v.cpu().numpy().astype(np.int64) for n, v in maps0.items()}
         hi = {n: v.cpu().numpy().astype(np.int64) for n, v in mapsi.items()}
         Ci_h = Ci.cpu().numpy()
-        for q, i in enumerate(idx):
+        for q, i in enumerate(gidx):
             model = g[q]
             model.FM = C0[q]
             model._FM_icp = Ci_h[q]
@@ -233,4 +209,99 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
             hung_i = assignment(cols[(2 * nb if compute_extra else 0) + q])
             out[i] = (h["ind21"][q], h["ind12"][q], hung, hung_p, hi["ind21"][q], hi["ind12"][q], hung_i, model, model.mesh1, model.mesh2,
                       h["knn21"][q], h["knn12"][q], hi["knn21"][q], hi["knn12"][q])
+
+
+def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_extra=False, optimizer="fmin_l_bfgs_b", descr_type="neural",
+                              maxiter=100000, optimize_p2p=False, fit_params=None, streams=None):
+    """compute_surface_map for a list of mesh pairs: returns the list of the 14-tuples compute_surface_map returns, each equal to the
+    single call's (same kernels, and every kernel's result for a pair is independent of the batch it is in).  No counterpart in
+    the reference (it matches one pair per call, functional_map.py:9-81): this is its documented call with the batch dimension the
+    GPU path has everywhere -- one batched eigensolve for the meshes, one device L-BFGS over the maps, the 2 x 4 vertex maps,
+    precise maps and ICP of all pairs in one library call each, and all linear assignments side by side (one workgroup per
+    matrix; a single call leaves 253 of 256 CUs idle there).  Pairs are grouped by (vertex counts, face count of mesh 1): the
+    batched kernels take one size per call; a group of one runs the same path with a batch of one.
+    streams: the batch is cut into that many contiguous chunks, each run by its own host thread on its own HIP stream (its own
+    MatchEngine: context, workspace).  The stages of a chunk depend on each other, the chunks do not: while one chunk's iterative fit
+    fills the vector ALUs, another's eigensolver (a chain of a thousand small launches), linear assignments (a workgroup per matrix,
+    latency bound) and host-side bookkeeping run beside it.  Default: 2 chunks from 16 pairs (measured at 64 pairs: 500 ms on one stream, 455 on two, 495 on three, 580 on four -- a
+    chunk's thousand small launches wait for register space behind the other chunks' fit kernels).  A pair's results do
+    not depend on the chunking."""
+    import torch
+    assert descr_type == "neural", "the batched call takes network descriptors (descr_type='neural')"
+    B = len(meshes1_t)
+    assert len(meshes2_t) == B and len(c1s) == B and len(c2s) == B
+    fit_params = dict(fit_params or {})
+    fit_params.pop("verbose", None)
+    known = {"w_descr", "w_lap", "w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1", "w_area", "w_conformal", "optinit",
+             "maxiter", "stopping", "w_orient", "w_area_difference", "w_mumford_shah", "mumford_shah_var", "w_eta_entropy", "orient_reversing",
+             "device", "driver"}
+    unknown = set(fit_params) - known
+    if unknown:
+        raise TypeError(f"fit() got unexpected keyword arguments {sorted(unknown)}")
+    if any(fit_params.get(n, 0) > 0 for n in ("w_area_difference", "w_mumford_shah", "w_eta_entropy")):
+        raise NotImplementedError("area-difference / Mumford-Shah / eta-entropy terms are not on the accelerated path; pass 0")
+    if fit_params.get("w_orient", 0) > 0:
+        raise NotImplementedError("w_orient: the orientation operators are built per pair on the host (FunctionalMapping.fit); "
+                                  "use compute_surface_map for it")
+    if fit_params.get("stopping", "reference") not in ("tight", "reference"):
+        raise ValueError("stopping must be 'tight' or 'reference'")
+    timing = os.environ.get("TIMEIT", False)
+    if timing:
+        compute_extra = True
+    models = []
+    for i in range(B):
+        m1 = TriMesh(_np(meshes1_t[i].verts_list()[0]), _np(meshes1_t[i].faces_list()[0]))
+        m2 = TriMesh(_np(meshes2_t[i].verts_list()[0]), _np(meshes2_t[i].faces_list()[0]))
+        model = FunctionalMapping(m1, m2, partial=False, optimizer=optimizer)
+        model.k1, model.k2 = n_ev, n_ev
+        model.descr1, model.descr2 = _np(c1s[i]), _np(c2s[i])
+        models.append(model)
+    out = [None] * B
+    if streams is None:
+        streams = 2 if B >= 16 else 1
+    streams = max(1, min(int(streams), B))
+    if streams == 1:
+        _batch_chunk(models, list(range(B)), out, n_ev, compute_extra, fit_params)
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    from .shard import block_range
+    dev_index = torch.cuda.current_device()
+    caller = torch.cuda.current_stream(dev_index)
+    side = _side_streams(dev_index, streams)
+
+    # The chunks run STAGGERED by one stage: chunk c starts its eigensolve when chunk c - 1 has finished its own.  Started together they
+    # would move in lockstep -- every stream in the same stage, competing for the same resource -- and gain little (measured, 64 pairs:
+    # 500 ms on one stream, 462 on two, 565 on four); staggered, one chunk's eigensolver (launch-latency bound) runs beside the previous
+    # chunk's fit (vector-ALU bound), whose linear assignments (one workgroup per matrix) run beside the next chunk's fit.
+    import threading
+    eig_done = [threading.Event() for _ in range(streams)]
+
+    def run(c):
+        try:
+            lo, hi = block_range(B, c, streams)
+            torch.cuda.set_device(dev_index)
+            if c > 0:
+                eig_done[c - 1].wait()
+            side[c].wait_stream(caller)
+            with torch.cuda.stream(side[c]):
+                _batch_chunk(models, list(range(lo, hi)), out, n_ev, compute_extra, fit_params, after_eigenbases=eig_done[c].set)
+            side[c].synchronize()
+        finally:
+            eig_done[c].set()                                             # (a chunk that failed must not leave the next one waiting)
+    with ThreadPoolExecutor(max_workers=streams) as ex:
+        for f in [ex.submit(run, c) for c in range(streams)]:
+            f.result()                                                    # (re-raises a chunk's exception here)
     return out
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev_index, n):
+    """the chunk streams of compute_surface_map_batch, created once per device (every stream brings a MatchEngine with its own workspace
+    arena: default_engine() keys on the stream)"""
+    import torch
+    have = _SIDE_STREAMS.setdefault(dev_index, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=dev_index))
+    return have[:n]

@@ -51,7 +51,10 @@ class MappedIndicator:
     def device_tensor(self):
         """the (n2, n1) matrix on the GPU (formed once by dm_mapped_indicator): input of the assignment kernel"""
         if getattr(self, "_dev", None) is None:
-            self._dev = self._eng.mapped_indicator(*self._args)[0]
+            # (the engine of the CALLER's stream: the indicator may have been set up by a chunk thread of compute_surface_map_batch on
+            #  its own stream, whose work is complete by the time anybody holds this object)
+            from ...engine import default_engine
+            self._dev = default_engine().mapped_indicator(*self._args)[0]
         return self._dev
 
     def __array__(self, dtype=None, copy=None):

@@ -580,7 +580,13 @@ def test_fm_to_p2p_split_equals_f64_kernel(eng, kind):
                     assert _ulp_tie(C[b], Phi1[b], Phi2[b], a1[b], name, int(idx), int(got[idx]), int(w[idx])), \
                         (kind, name, b, int(idx), int(got[idx]), int(w[idx]))
                     ties += 1
-        print(f"{kind} {(B, N1, N2, k1, k2)}: equal to the oracle except {ties} few-ulp ties")
+        rows = 2 * B * (N1 + N2)
+        print(f"{kind} {(B, N1, N2, k1, k2)}: equal to the oracle except {ties} few-ulp ties of {rows} map entries")
+        # a ceiling on what the tie rule may forgive: a handful per case is two summation orders meeting a near-tie; a
+        # regression that decides rows wrongly by a few ulps en masse must not pass as "ties"
+        # ("duplicates" plants exactly equal rows: every planted pair is a candidate tie whose winner is a matter of summation order --
+        #  39 of 7680 entries measured; elsewhere a tie is an accident)
+        assert ties <= (rows // 50 if kind == "duplicates" else max(4, rows // 500)), (kind, ties, rows)
 
 
 def test_fuzz_knn_query(eng):

@@ -163,3 +163,28 @@ def test_requeued_rows_diagnostic(eng, fx_cfg2):
     eng.set_option("p2p_split", 0)
     eng.fm_to_p2p(b(fx["Phi1"]), b(fx["Phi2"]), b(fx["a1"]), b(fx["C_f64"]))
     assert eng.last_requeued_rows() == [-1, -1, -1, -1]
+
+
+@pytest.mark.parametrize("N2,direct", [(768, 0), (15360, 1)])
+def test_zoomout_fused_with_the_staged_p2p_to_fm_on_a_fresh_context(N2, direct):
+    """the fused loop reserved the prescaled basis but not the split-K partials of the staged p2p_to_FM, which
+    dm_launch_p2p_to_fm falls back to with p2pfm_direct = 0 and beyond 15000 target vertices -- DM_ENOMEM on a context whose arena had
+    not been grown by an earlier call.  A fresh engine per case; result against the six-launch loop."""
+    from densematcher_amd.engine import MatchEngine
+    rng = np.random.default_rng(N2)
+    N1, k0, nit, step = 512, 12, 3, 4
+    kmax = k0 + nit * step
+    Phi1 = (rng.standard_normal((1, N1, kmax)) / np.sqrt(N1)).astype(np.float64)
+    Phi2 = (rng.standard_normal((1, N2, kmax)) / np.sqrt(N2)).astype(np.float64)
+    a2 = (rng.uniform(0.5, 1.5, (1, N2)) / N2)
+    C0 = (np.eye(k0) + 0.05 * rng.standard_normal((k0, k0)))[None]
+    eng = MatchEngine()
+    try:
+        eng.set_option("p2pfm_direct", direct)
+        C, p = eng.zoomout(Phi1, Phi2, a2, C0, nit=nit, step=step, return_p2p=True)          # (raised MemoryError before the fix)
+        eng.set_option("zoomout_fused", 0)
+        Cu, pu = eng.zoomout(Phi1, Phi2, a2, C0, nit=nit, step=step, return_p2p=True)
+        assert np.array_equal(_np(p), _np(pu))
+        assert np.abs(_np(C) - _np(Cu)).max() <= 1e-11
+    finally:
+        eng.close()

@@ -71,3 +71,22 @@ def test_match_sharded_two_ranks(B):
     assert set(got) == {"knn21", "C"}
     assert np.array_equal(got["knn21"], ref["knn21"].numpy())
     assert np.array_equal(got["C"], ref["C"].numpy())
+
+
+def test_match_sharded_keeps_one_engine_per_process_and_returns_local_tensors():
+    """gather=False: the rank's block comes back as the engine's own tensors (no gather, no host copy); the engine is built once per
+    process however many batches go through"""
+    built = []
+
+    class Counting(_FakeEngine):
+        def __init__(self):
+            built.append(1)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        batch = {"F1": torch.as_tensor(rng.standard_normal((5, 6, 4)).astype(np.float32)), "F2": torch.as_tensor(rng.standard_normal((5, 5, 4)).astype(np.float32))}
+        res = shard.match_sharded(batch, Counting, rank=1, world=2, gather=False)
+        lo, hi = shard.block_range(5, 1, 2)
+        assert res["knn21"].shape[0] == hi - lo and isinstance(res["C"], torch.Tensor)
+        want = _FakeEngine().match({k: v[lo:hi] for k, v in batch.items()})
+        assert torch.equal(res["knn21"], want["knn21"])
+    assert len(built) == 1

@@ -15,6 +15,8 @@ import bench  # noqa: E402
 from densematcher_amd import functional_map as fmod, synth  # noqa: E402
 from densematcher_amd.engine import default_engine  # noqa: E402
 
+from densematcher_amd.pyFM.mesh import laplacian as _lap
+_lap.set_robust_backend("restated")
 w = bench.WORKLOADS["surface_map"]
 nu, nv, D, k = w["nu"], w["nv"], w["D"], w["k"]
 (v1, f1), (v2, f2) = synth.torus_mesh(nu, nv, perturb=0.03, seed=3), synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
