@@ -60,13 +60,15 @@ SIGNATURES = {
     "dm_laplacian_ell": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_precise_map": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "dm_linear_sum_assignment": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
+    "dm_lsa_indicator_ok": (_i, [_p, _i, _i, _i, _i]),
+    "dm_lsa_indicator": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p]),
     "dm_p2p_to_fm_lstsq": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p]),
     "dm_icp": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p]),
     "dm_zoomout": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
 }
 
 # the float64-basis forms (const double* Phi / mass): same argument lists
-for _n in ("dm_project", "dm_fmap_fit", "dm_fmap_c00", "dm_fm_to_p2p", "dm_mapped_indicator", "dm_p2p_to_fm", "dm_precise_map", "dm_p2p_to_fm_lstsq", "dm_icp",
+for _n in ("dm_project", "dm_fmap_fit", "dm_fmap_c00", "dm_fm_to_p2p", "dm_mapped_indicator", "dm_p2p_to_fm", "dm_precise_map", "dm_p2p_to_fm_lstsq", "dm_icp", "dm_lsa_indicator",
            "dm_zoomout"):
     SIGNATURES[_n + "_f64"] = SIGNATURES[_n]
 

@@ -17,6 +17,7 @@
 // scratch.
 #include "dm_device.h"
 #include "dm_internal.h"
+#include "dm_indicator_dev.h"
 
 constexpr int LSA_NT = 1024;
 constexpr int LSA_LDS_MAX_COLS = 4608;      // 28 bytes per column + reduction scratch within 160 KiB
@@ -189,6 +190,12 @@ __device__ __forceinline__ int lsa_wave_max(int k) {                // uniform r
     return __builtin_amdgcn_readlane(k, 63);
 }
 
+// Where a matrix's entries come from.  Matrices 0 .. n_lr-1 of a launch are mapped indicators given by their FACTORS (dm_indicator_dev.h:
+// E2p (n_lr, nr, KP), P1p (n_lr, nc, KP), a1p (n_lr, nc)): a thread keeps the factor rows of its columns in registers and a cost row is
+// KP fused multiply-adds per column from one broadcast row of E2p -- no N x N matrix is read (or needs to exist).  The others are
+// dense (nr x nc float64 each, from `dense`).  KP = 0 instantiations know dense matrices only.
+struct lsa_src { const double* dense; const double* E2p; const double* P1p; const double* a1p; int n_lr; };
+
 // ---- the same search with the column state in registers ---------------------------------------------------------------------
 // Thread t owns the columns t, t + NT, ... (CPT of them, nc <= NT CPT): their dual v, tentative cost, "scanned" flag and
 // POSITION IN SCIPY'S `remaining` LIST live in registers, the cost row is read coalesced, and a step needs ONE barrier:
@@ -201,8 +208,8 @@ __device__ __forceinline__ int lsa_wave_max(int k) {                // uniform r
 //   there to an optimum).  Fewer and shorter searches, but not SciPy's order: the caller accepts the result only when
 //   lsa_unique_kernel finds the optimum unique (no slack-free edge outside the assignment), else it reruns with WARM = 0.
 // returns true when the warm start stepped aside (nothing written): the caller runs the search in SciPy's order instead
-template <int CPT, int WARM, int NT>
-__device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const double* __restrict__ costs, int nr, int nc, int negate,
+template <int CPT, int WARM, int NT, int KP>
+__device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const lsa_src& src, int nr, int nc, int negate,
                                              double* __restrict__ g_u, double* __restrict__ g_v, int32_t* __restrict__ out_col4row,
                                              int32_t* __restrict__ info) {
     // LDS: u (nr) doubles | row4col (nc), path (nc), col4row (nr) ints | slots
@@ -214,7 +221,29 @@ __device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const doub
     __shared__ int2 sl_it[2][16];                         // (the candidates' tie keys, lsa_key, and the rows their columns are assigned to)
     __shared__ int s_count[2];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const double* cost = costs + (long long)b * nr * nc;
+    const bool lr = KP > 0 && b < src.n_lr;               // (uniform) entries from the factors
+    const double* cost = lr ? nullptr : src.dense + (long long)(b - src.n_lr) * nr * nc;
+    const double* E2b = lr ? src.E2p + (long long)b * nr * (KP > 0 ? KP : 1) : nullptr;
+    double psi[CPT][KP > 0 ? KP : 1], a1c[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int j = t + NT * q;
+        a1c[q] = (lr && j < nc) ? src.a1p[(long long)b * nc + j] : 0.0;
+#pragma unroll
+        for (int k = 0; k < (KP > 0 ? KP : 1); ++k) psi[q][k] = (lr && j < nc) ? src.P1p[((long long)b * nc + j) * (KP > 0 ? KP : 1) + k] : 0.0;
+    }
+    // row i of the matrix, this thread's columns
+    auto load_row = [&](int i, double (&cv_)[CPT]) {
+        if (KP > 0 && lr) {
+            const double* e = E2b + (long long)i * (KP > 0 ? KP : 1);
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) cv_[q] = ind_value<(KP > 0 ? KP : 1)>(e, psi[q], a1c[q]);
+        } else {
+            const double* crow = cost + (long long)i * nc;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) { const int j = t + NT * q; cv_[q] = crow[j < nc ? j : nc - 1]; }
+        }
+    };
     const double sgn = negate ? -1.0 : 1.0;
     double v[CPT], spc[CPT];
     int pos[CPT];
@@ -231,11 +260,11 @@ __device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const doub
 #pragma unroll
         for (int q = 0; q < CPT; ++q) { v[q] = DM_INF_F64; arg[q] = -1; cnt[q] = 0; }
         for (int i = 0; i < nr; ++i) {
-            const double* crow = cost + (long long)i * nc;
+            double crow_[CPT];
+            load_row(i, crow_);
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
-                const int j = t + NT * q;
-                const double c = sgn * crow[j < nc ? j : nc - 1];
+                const double c = sgn * crow_[q];
                 const bool lt = c < v[q];
                 cnt[q] = lt ? 1 : cnt[q] + (c == v[q] ? 1 : 0);
                 arg[q] = lt ? i : arg[q];
@@ -298,11 +327,7 @@ __device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const doub
         }
         double ui = u[i];
         double cv[CPT];
-        {
-            const double* crow = cost + (long long)i * nc;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) { const int j = t + NT * q; cv[q] = crow[j < nc ? j : nc - 1]; }
-        }
+        load_row(i, cv);
         while (true) {
             // relax the open columns (no branch: a select per column; the predecessor stays in a register until the search ends)
             double cand[CPT];
@@ -390,9 +415,7 @@ __device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const doub
             min_val = wv;
             if (!wsk) {                                    // the next row's loads go out before the list is updated
                 i = inext;
-                const double* crow = cost + (long long)i * nc;
-#pragma unroll
-                for (int q = 0; q < CPT; ++q) { const int j = t + NT * q; cv[q] = crow[j < nc ? j : nc - 1]; }
+                load_row(i, cv);
                 ui = u[i];
             }
             // remove the chosen column from the list: the column at the last position takes its place
@@ -455,17 +478,17 @@ __device__ __forceinline__ bool lsa_reg_body(unsigned char* lsa_smem, const doub
 // skip_warm (the warm-start launch): a matrix the warm start steps aside from is searched in SciPy's order right here, by the
 // same workgroup (other matrices of the batch are still in their warm searches: no reason to wait for the rerun launch), and
 // flagged 2 = "done in order": the uniqueness check cannot lower that and the rerun passes it by.
-template <int CPT, int WARM, int NT>
-__global__ __launch_bounds__(NT) void lsa_reg_kernel(const double* __restrict__ costs, int nr, int nc, int negate,
+template <int CPT, int WARM, int NT, int KP>
+__global__ __launch_bounds__(NT) void lsa_reg_kernel(const lsa_src src, int nr, int nc, int negate,
                                                          double* __restrict__ g_u, double* __restrict__ g_v,
                                                          int32_t* __restrict__ out_col4row, int32_t* __restrict__ info,
                                                          const int32_t* __restrict__ run_if, int32_t* __restrict__ skip_warm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
     if (run_if && run_if[blockIdx.x] != 1) return;
-    const bool aside = lsa_reg_body<CPT, WARM, NT>(lsa_smem, costs, nr, nc, negate, g_u, g_v, out_col4row, info);
+    const bool aside = lsa_reg_body<CPT, WARM, NT, KP>(lsa_smem, src, nr, nc, negate, g_u, g_v, out_col4row, info);
     if (WARM && aside) {                                  // (uniform)
         __syncthreads();
-        lsa_reg_body<CPT, 0, NT>(lsa_smem, costs, nr, nc, negate, g_u, g_v, out_col4row, info);
+        lsa_reg_body<CPT, 0, NT, KP>(lsa_smem, src, nr, nc, negate, g_u, g_v, out_col4row, info);
         if (threadIdx.x == 0 && skip_warm) skip_warm[blockIdx.x] = 2;
     }
 }
@@ -503,6 +526,34 @@ __global__ __launch_bounds__(256) void lsa_tight_kernel(const double* __restrict
             const int r = row4col[(long long)b * nc + j];
             if (r < 0) freecol = true;
             else atomicOr(&adj[((long long)b * nr + i) * nw + (r >> 5)], 1u << (r & 31));
+        }
+    }
+    if (__any(freecol) && (threadIdx.x & 63) == 0) atomicMax(&tie[b], 1);
+}
+// the same for matrices given by their factors: a thread owns a column (its factor row in registers) and sweeps 64 rows
+template <int KP>
+__global__ __launch_bounds__(256) void lsa_tight_lr_kernel(const double* __restrict__ E2p, const double* __restrict__ P1p, const double* __restrict__ a1p,
+                                                           int nr, int nc, int negate, const double* __restrict__ g_u, const double* __restrict__ g_v,
+                                                           const int32_t* __restrict__ col4row, const int32_t* __restrict__ row4col,
+                                                           unsigned int* __restrict__ adj, int nw, int32_t* __restrict__ tie) {
+    const int b = blockIdx.z, j = blockIdx.x * 256 + threadIdx.x, i0 = blockIdx.y * 64;
+    const double sgn = negate ? -1.0 : 1.0;
+    bool freecol = false;
+    if (j < nc) {
+        double p[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) p[k] = P1p[((long long)b * nc + j) * KP + k];
+        const double a1 = a1p[(long long)b * nc + j], vj = g_v[(long long)b * nc + j];
+        const int r = row4col[(long long)b * nc + j];
+        const int i1 = min(nr, i0 + 64);
+        for (int i = i0; i < i1; ++i) {
+            if (col4row[(long long)b * nr + i] == j) continue;
+            const double c = sgn * ind_value<KP>(E2p + ((long long)b * nr + i) * KP, p, a1), ui = g_u[(long long)b * nr + i];
+            const double slack = (c - ui) - vj;
+            if (!(slack > 1e-13 * (fabs(c) + fabs(ui) + fabs(vj)))) {
+                if (r < 0) freecol = true;
+                else atomicOr(&adj[((long long)b * nr + i) * nw + (r >> 5)], 1u << (r & 31));
+            }
         }
     }
     if (__any(freecol) && (threadIdx.x & 63) == 0) atomicMax(&tie[b], 1);
@@ -577,37 +628,43 @@ __global__ __launch_bounds__(256) void lsa_invert_kernel(const int32_t* __restri
     if (r >= 0 && r < nr) col_of_row[(long long)b * nr + r] = c;
 }
 
-extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, const double* cost, int maximize, int32_t* col_of_row,
-                                        int32_t* info) {
-    if (!ctx) return DM_EINVAL;
-    DM_REQUIRE(ctx, B > 0 && nr > 0 && nc > 0, "sizes must be positive");
-    DM_REQUIRE(ctx, cost && col_of_row && info, "null pointer");
-    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
-    const bool transposed = nr > nc;                   // SciPy solves the transposed problem when there are more rows than columns
+static size_t lsa_ws_bytes(int B, int nr, int nc) {
+    const bool transposed = nr > nc;
     const int R = transposed ? nc : nr, Cn = transposed ? nr : nc;
     const size_t bT = transposed ? (size_t)B * nr * nc * 8 : 0;
     const size_t bF = (size_t)B * (R + 2 * (size_t)Cn) * 8, bI = (size_t)B * (2 * (size_t)R + 4 * (size_t)Cn) * 4;
     const size_t bO = transposed ? (size_t)B * R * 4 : 0;
-    int rc = dm_ws_reserve(ctx, dm_align_up(bT) + dm_align_up(bF) + dm_align_up(bI) + dm_align_up(bO) + dm_align_up((size_t)B * 4) +
-                                    dm_align_up((size_t)B * R * dm_cdiv(R, 32) * 4) + dm_align_up((size_t)B * Cn * 4) + dm_align_up((size_t)B * 2 * R * 4) + 8192);
-    if (rc) return rc;
+    return dm_align_up(bT) + dm_align_up(bF) + dm_align_up(bI) + dm_align_up(bO) + dm_align_up((size_t)B * 4) +
+           dm_align_up((size_t)B * R * dm_cdiv(R, 32) * 4) + dm_align_up((size_t)B * Cn * 4) + dm_align_up((size_t)B * 2 * R * 4) + 8192;
+}
+
+// B matrices: the first n_lr from factors (KP = 16 | 32), the others dense.  The workspace is reserved by the caller (lsa_ws_bytes).
+static int lsa_run(dm_ctx* ctx, int B, int nr, int nc, const double* dense, int n_lr, int KP, const double* E2p, const double* P1p,
+                   const double* a1p, int maximize, int32_t* col_of_row, int32_t* info) {
+    const int n_dense = B - n_lr;
+    const bool transposed = nr > nc;                   // SciPy solves the transposed problem when there are more rows than columns
+    if (n_lr > 0 && transposed) return dm_fail(ctx, DM_EINVAL, "assignment from factors: needs nr <= nc");
+    const int R = transposed ? nc : nr, Cn = transposed ? nr : nc;
+    const size_t bT = transposed ? (size_t)B * nr * nc * 8 : 0;
+    const size_t bF = (size_t)B * (R + 2 * (size_t)Cn) * 8, bI = (size_t)B * (2 * (size_t)R + 4 * (size_t)Cn) * 4;
+    const size_t bO = transposed ? (size_t)B * R * 4 : 0;
+    int rc;
     double* Ct = transposed ? (double*)dm_ws_take(ctx, bT) : nullptr;
     double* gf = (double*)dm_ws_take(ctx, bF);
     int* gi = (int*)dm_ws_take(ctx, bI);
     int32_t* tmp = transposed ? (int32_t*)dm_ws_take(ctx, bO) : nullptr;
     if ((transposed && (!Ct || !tmp)) || !gf || !gi) return dm_fail(ctx, DM_ENOMEM, "assignment: workspace not reserved");
-    DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
-    {
+    if (n_dense > 0) {
         const long long nel = (long long)nr * nc;
         const int gx = (int)((nel + 256 * 16 - 1) / (256 * 16)) < 1024 ? (int)((nel + 256 * 16 - 1) / (256 * 16)) : 1024;
-        DM_LAUNCH(ctx, "lsa_validate", lsa_validate_kernel, dim3(gx, B), dim3(256), 0, cost, nel, maximize ? 1 : 0, info);
+        DM_LAUNCH(ctx, "lsa_validate", lsa_validate_kernel, dim3(gx, n_dense), dim3(256), 0, dense, nel, maximize ? 1 : 0, info + n_lr);
     }
     if (transposed)
-        DM_LAUNCH(ctx, "lsa_transpose", lsa_transpose_kernel, dim3(dm_cdiv(nc, 32), dm_cdiv(nr, 32), B), dim3(256), 0, cost, nr, nc, Ct);
+        DM_LAUNCH(ctx, "lsa_transpose", lsa_transpose_kernel, dim3(dm_cdiv(nc, 32), dm_cdiv(nr, 32), B), dim3(256), 0, dense, nr, nc, Ct);
     // register-resident search (columns owned by threads) when the columns fit 8 per thread and the row state fits the LDS
     const size_t lds_reg = (size_t)R * 8 + ((size_t)2 * Cn + R) * 4 + 64;
     if (ctx->opt_lsa_reg && Cn <= 8 * LSA_NT && lds_reg <= 150 * 1024) {
-        const double* Cm = transposed ? Ct : cost;
+        const lsa_src src{transposed ? Ct : dense, E2p, P1p, a1p, n_lr};
         int32_t* outp = transposed ? tmp : col_of_row;
         int32_t* tie = (int32_t*)dm_ws_take(ctx, (size_t)B * 4);
         if (!tie) return dm_fail(ctx, DM_ENOMEM, "assignment: workspace not reserved");
@@ -618,18 +675,23 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
         const int nt = Cn <= 8 * 512 ? 512 : LSA_NT;
         const int per = dm_cdiv(Cn, nt);
         const int cpt = per <= 1 ? 1 : (per <= 2 ? 2 : (per <= 4 ? 4 : 8));
-#define LSA_REG(CPT_, WARM_, RUNIF_, NT_)                                                                              \
+        if (n_lr > 0 && (cpt > 4 || nt != 512)) return dm_fail(ctx, DM_EINVAL, "assignment from factors: at most 2048 columns");
+#define LSA_REG(CPT_, WARM_, RUNIF_, NT_, KP_)                                                                         \
         {                                                                                                              \
-            rc = dm_grant_lds(ctx, (const void*)lsa_reg_kernel<CPT_, WARM_, NT_>, lds_reg);                            \
+            rc = dm_grant_lds(ctx, (const void*)lsa_reg_kernel<CPT_, WARM_, NT_, KP_>, lds_reg);                       \
             if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, (WARM_ ? "lsa_shortest_augmenting_path" : (RUNIF_ ? "lsa_rerun_in_order" : "lsa_in_order")), (lsa_reg_kernel<CPT_, WARM_, NT_>), dim3(B), dim3(NT_), lds_reg, Cm, R, Cn, \
+            DM_LAUNCH(ctx, (WARM_ ? "lsa_shortest_augmenting_path" : (RUNIF_ ? "lsa_rerun_in_order" : "lsa_in_order")), (lsa_reg_kernel<CPT_, WARM_, NT_, KP_>), dim3(B), dim3(NT_), lds_reg, src, R, Cn, \
                       maximize ? 1 : 0, gu, gv, outp, info, RUNIF_, WARM_ ? tie : (int32_t*)nullptr);                                                   \
         }
 #define LSA_REG_NT(WARM_, RUNIF_, NT_)                                                                                 \
-        if (cpt == 1) LSA_REG(1, WARM_, RUNIF_, NT_) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_, NT_)                 \
-        else if (cpt == 4) LSA_REG(4, WARM_, RUNIF_, NT_) else LSA_REG(8, WARM_, RUNIF_, NT_)
+        if (cpt == 1) LSA_REG(1, WARM_, RUNIF_, NT_, 0) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_, NT_, 0)           \
+        else if (cpt == 4) LSA_REG(4, WARM_, RUNIF_, NT_, 0) else LSA_REG(8, WARM_, RUNIF_, NT_, 0)
+#define LSA_REG_LR(WARM_, RUNIF_)                                                                                      \
+        if (KP == 16) { if (cpt == 1) LSA_REG(1, WARM_, RUNIF_, 512, 16) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_, 512, 16) else LSA_REG(4, WARM_, RUNIF_, 512, 16) } \
+        else { if (cpt == 1) LSA_REG(1, WARM_, RUNIF_, 512, 32) else if (cpt == 2) LSA_REG(2, WARM_, RUNIF_, 512, 32) else LSA_REG(4, WARM_, RUNIF_, 512, 32) }
 #define LSA_REG_CPT(WARM_, RUNIF_)                                                                                     \
-        if (nt == 512) { LSA_REG_NT(WARM_, RUNIF_, 512) } else { LSA_REG_NT(WARM_, RUNIF_, 1024) }
+        if (n_lr > 0) { LSA_REG_LR(WARM_, RUNIF_) }                                                                    \
+        else if (nt == 512) { LSA_REG_NT(WARM_, RUNIF_, 512) } else { LSA_REG_NT(WARM_, RUNIF_, 1024) }
         if (ctx->opt_lsa_reg >= 2 && R == Cn) {
             // column-reduction start (not SciPy's order; square problems only: the duals of columns that stay unassigned would have
             // to be zero), accepted per matrix when its optimum is provably unique, else redone exactly.  Measured and dropped:
@@ -647,14 +709,24 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
             DM_CHECK_HIP(ctx, hipMemsetAsync(adj, 0, (size_t)B * R * nw * 4, ctx->stream));
             DM_CHECK_HIP(ctx, hipMemsetAsync(r4c, 0xFF, (size_t)B * Cn * 4, ctx->stream));
             DM_LAUNCH(ctx, "lsa_unique", lsa_rowofcol_kernel, dim3(dm_cdiv(R, 256), B), dim3(256), 0, (const int32_t*)outp, R, Cn, r4c);
-            DM_LAUNCH(ctx, "lsa_unique", lsa_tight_kernel, dim3(gx, B), dim3(256), 0, Cm, R, Cn, maximize ? 1 : 0, (const double*)gu,
-                      (const double*)gv, (const int32_t*)outp, (const int32_t*)r4c, adj, nw, tie);
+            if (n_lr > 0) {
+                const dim3 gl(dm_cdiv(Cn, 256), dm_cdiv(R, 64), n_lr);
+                if (KP == 16) DM_LAUNCH(ctx, "lsa_unique", lsa_tight_lr_kernel<16>, gl, dim3(256), 0, E2p, P1p, a1p, R, Cn, maximize ? 1 : 0, (const double*)gu,
+                                        (const double*)gv, (const int32_t*)outp, (const int32_t*)r4c, adj, nw, tie);
+                else DM_LAUNCH(ctx, "lsa_unique", lsa_tight_lr_kernel<32>, gl, dim3(256), 0, E2p, P1p, a1p, R, Cn, maximize ? 1 : 0, (const double*)gu,
+                               (const double*)gv, (const int32_t*)outp, (const int32_t*)r4c, adj, nw, tie);
+            }
+            if (n_dense > 0)
+                DM_LAUNCH(ctx, "lsa_unique", lsa_tight_kernel, dim3(gx, n_dense), dim3(256), 0, src.dense, R, Cn, maximize ? 1 : 0, (const double*)(gu + (size_t)n_lr * R),
+                          (const double*)(gv + (size_t)n_lr * Cn), (const int32_t*)(outp + (size_t)n_lr * R), (const int32_t*)(r4c + (size_t)n_lr * Cn),
+                          adj + (size_t)n_lr * R * nw, nw, tie + n_lr);
             DM_LAUNCH(ctx, "lsa_unique", lsa_acyclic_kernel, dim3(B), dim3(1024), 0, (const unsigned int*)adj, R, nw, indeg, tie);
             LSA_REG_CPT(0, (const int32_t*)tie)
         } else {
             LSA_REG_CPT(0, (const int32_t*)nullptr)
         }
 #undef LSA_REG_CPT
+#undef LSA_REG_LR
 #undef LSA_REG_NT
 #undef LSA_REG
         if (transposed) {
@@ -663,15 +735,67 @@ extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, cons
         }
         return DM_OK;
     }
+    if (n_lr > 0) return dm_fail(ctx, DM_EINVAL, "assignment from factors: sizes outside the register-resident search");
     const int use_lds = Cn <= LSA_LDS_MAX_COLS;
     const size_t lds = use_lds ? (size_t)Cn * 28 + 64 : 0;
     rc = dm_grant_lds(ctx, (const void*)lsa_kernel, lds);
     if (rc) return rc;
-    DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", lsa_kernel, dim3(B), dim3(LSA_NT), lds, transposed ? Ct : cost, R, Cn, maximize ? 1 : 0,
+    DM_LAUNCH(ctx, "lsa_shortest_augmenting_path", lsa_kernel, dim3(B), dim3(LSA_NT), lds, transposed ? Ct : dense, R, Cn, maximize ? 1 : 0,
               use_lds, gf, gi, transposed ? tmp : col_of_row, info);
     if (transposed) {
         DM_CHECK_HIP(ctx, hipMemsetAsync(col_of_row, 0xFF, (size_t)B * nr * 4, ctx->stream));
         DM_LAUNCH(ctx, "lsa_invert", lsa_invert_kernel, dim3(dm_cdiv(nc, 256), B), dim3(256), 0, tmp, nr, nc, col_of_row);
     }
     return DM_OK;
+}
+
+extern "C" int dm_linear_sum_assignment(dm_ctx* ctx, int B, int nr, int nc, const double* cost, int maximize, int32_t* col_of_row,
+                                        int32_t* info) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, B > 0 && nr > 0 && nc > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, cost && col_of_row && info, "null pointer");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = dm_ws_reserve(ctx, lsa_ws_bytes(B, nr, nc));
+    if (rc) return rc;
+    DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
+    return lsa_run(ctx, B, nr, nc, cost, 0, 0, nullptr, nullptr, nullptr, maximize, col_of_row, info);
+}
+
+// 1 when dm_lsa_indicator takes these sizes (else the caller forms the dense indicators and calls dm_linear_sum_assignment)
+extern "C" int dm_lsa_indicator_ok(dm_ctx* ctx, int N1, int N2, int k1, int k2) {
+    if (!ctx || !ctx->opt_lsa_reg) return 0;
+    return (k1 >= 1 && k2 >= 1 && k1 <= 32 && k2 <= 32 && N2 <= N1 && N1 <= 2048 && N2 >= 1) ? 1 : 0;
+}
+
+// The assignments of n_ind mapped indicators (Phi2 C Phi1^T diag(a1), N2 x N1 each, given by their factors) and of n_dense dense
+// N2 x N1 matrices in ONE launch (a workgroup per matrix): col_of_row / info hold the indicators' results first, then the dense ones'.
+template <typename TR>
+static int lsa_indicator_impl(dm_ctx* ctx, int n_ind, int N1, int N2, int k1, int k2, const TR* Phi1, int ld1, const TR* Phi2, int ld2,
+                              const TR* mass1, const double* C, int n_dense, const double* dense, int maximize, int32_t* col_of_row, int32_t* info) {
+    if (!ctx) return DM_EINVAL;
+    DM_REQUIRE(ctx, n_ind > 0 && n_dense >= 0 && N1 > 0 && N2 > 0, "sizes must be positive");
+    DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && C && col_of_row && info && (n_dense == 0 || dense), "null pointer");
+    DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
+    DM_REQUIRE(ctx, dm_lsa_indicator_ok(ctx, N1, N2, k1, k2), "lsa_indicator: maps up to 32 x 32, N2 <= N1 <= 2048");
+    DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    const int B = n_ind + n_dense, KP = k1 <= 16 ? 16 : 32;
+    const size_t bE2 = (size_t)n_ind * N2 * KP * 8, bP1 = (size_t)n_ind * N1 * KP * 8, bA = (size_t)n_ind * N1 * 8;
+    int rc = dm_ws_reserve(ctx, dm_align_up(bE2) + dm_align_up(bP1) + dm_align_up(bA) + lsa_ws_bytes(B, N2, N1) + 4096);
+    if (rc) return rc;
+    double* E2p = (double*)dm_ws_take(ctx, bE2);
+    double* P1p = (double*)dm_ws_take(ctx, bP1);
+    double* a1p = (double*)dm_ws_take(ctx, bA);
+    if (!E2p || !P1p || !a1p) return dm_fail(ctx, DM_ENOMEM, "lsa_indicator: workspace not reserved");
+    DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
+    DM_LAUNCH(ctx, "indicator_e2", ind_e2_kernel<TR>, dim3(dm_cdiv(N2, 256), n_ind), dim3(256), 0, Phi2, ld2, N2, k1, k2, C, KP, E2p, info);
+    DM_LAUNCH(ctx, "indicator_p1", ind_p1_kernel<TR>, dim3(dm_cdiv(N1, 256), n_ind), dim3(256), 0, Phi1, ld1, mass1, N1, k1, KP, P1p, a1p, info);
+    return lsa_run(ctx, B, N2, N1, dense, n_ind, KP, E2p, P1p, a1p, maximize, col_of_row, info);
+}
+extern "C" int dm_lsa_indicator(dm_ctx* ctx, int n_ind, int N1, int N2, int k1, int k2, const float* Phi1, int ld1, const float* Phi2, int ld2,
+                                const float* mass1, const double* C, int n_dense, const double* dense, int maximize, int32_t* col_of_row, int32_t* info) {
+    return lsa_indicator_impl<float>(ctx, n_ind, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, mass1, C, n_dense, dense, maximize, col_of_row, info);
+}
+extern "C" int dm_lsa_indicator_f64(dm_ctx* ctx, int n_ind, int N1, int N2, int k1, int k2, const double* Phi1, int ld1, const double* Phi2, int ld2,
+                                    const double* mass1, const double* C, int n_dense, const double* dense, int maximize, int32_t* col_of_row, int32_t* info) {
+    return lsa_indicator_impl<double>(ctx, n_ind, N1, N2, k1, k2, Phi1, ld1, Phi2, ld2, mass1, C, n_dense, dense, maximize, col_of_row, info);
 }

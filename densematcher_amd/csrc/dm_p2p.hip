@@ -16,6 +16,7 @@
 
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
+#include "dm_indicator_dev.h"
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -912,6 +913,23 @@ static int mapped_indicator_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && C && M, "null pointer");
     DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than the map size");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    if (k1 <= 32 && k2 <= 32) {
+        // small maps: the shared arithmetic of dm_indicator_dev.h (what the linear assignment evaluates from the factors, bit for bit)
+        const int KP = k1 <= 16 ? 16 : 32;
+        const size_t bE2 = (size_t)B * N2 * KP * 8, bP1 = (size_t)B * N1 * KP * 8, bA = (size_t)B * N1 * 8;
+        int rc = dm_ws_reserve(ctx, dm_align_up(bE2) + dm_align_up(bP1) + dm_align_up(bA) + 4096);
+        if (rc) return rc;
+        double* E2p = (double*)dm_ws_take(ctx, bE2);
+        double* P1p = (double*)dm_ws_take(ctx, bP1);
+        double* a1p = (double*)dm_ws_take(ctx, bA);
+        if (!E2p || !P1p || !a1p) return dm_fail(ctx, DM_ENOMEM, "mapped_indicator: workspace not reserved");
+        DM_LAUNCH(ctx, "indicator_e2", ind_e2_kernel<TR>, dim3(dm_cdiv(N2, 256), B), dim3(256), 0, Phi2, ld2, N2, k1, k2, C, KP, E2p, (int32_t*)nullptr);
+        DM_LAUNCH(ctx, "indicator_p1", ind_p1_kernel<TR>, dim3(dm_cdiv(N1, 256), B), dim3(256), 0, Phi1, ld1, mass1, N1, k1, KP, P1p, a1p, (int32_t*)nullptr);
+        const dim3 grid(dm_cdiv(N1, 256), dm_cdiv(N2, 64), B);
+        if (KP == 16) DM_LAUNCH(ctx, "indicator_dense", ind_dense_kernel<16>, grid, dim3(256), 0, (const double*)E2p, (const double*)P1p, (const double*)a1p, N1, N2, M);
+        else DM_LAUNCH(ctx, "indicator_dense", ind_dense_kernel<32>, grid, dim3(256), 0, (const double*)E2p, (const double*)P1p, (const double*)a1p, N1, N2, M);
+        return DM_OK;
+    }
     const size_t bE = (size_t)B * N2 * k1 * 8;
     int rc = dm_ws_reserve(ctx, bE);
     if (rc) return rc;

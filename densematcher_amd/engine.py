@@ -713,6 +713,36 @@ class MatchEngine:
             raise ValueError("cost matrix is infeasible")
         return out
 
+    def lsa_indicator_ok(self, N1, N2, k1, k2):
+        return bool(self.lib.dm_lsa_indicator_ok(self.ctx, int(N1), int(N2), int(k1), int(k2)))
+
+    def lsa_indicator(self, Phi1, Phi2, a1, Cm, dense=None, maximize=True):
+        """Optimal assignments of the mapped indicators Phi2 C Phi1^T diag(a1) given by their factors (no N2 x N1 matrix is formed: the
+        kernel evaluates cost rows from the factors with dm_mapped_indicator's arithmetic, bit for bit) and of the dense (n, N2, N1)
+        matrices `dense` in the same launch.  Returns col_of_row (n_ind + n_dense, N2) int32, the indicators first.
+        (reference functional_map.py:57, 66, 78: scipy.optimize.linear_sum_assignment(..., maximize=True))"""
+        sfx, Phi1, Phi2, a1 = self._reals(Phi1, Phi2, a1)
+        Cm = self._dev(Cm, torch.float64, "C")
+        B, N1, ld1 = Phi1.shape
+        _, N2, ld2 = Phi2.shape
+        k2, k1 = Cm.shape[1], Cm.shape[2]
+        nd = 0
+        if dense is not None:
+            dense = self._dev(dense, torch.float64, "dense")
+            if dense.dim() != 3 or dense.shape[1:] != (N2, N1):
+                raise ValueError("lsa_indicator: dense matrices must be (n, N2, N1)")
+            nd = dense.shape[0]
+        out = torch.empty((B + nd, N2), dtype=torch.int32, device=self.device)
+        info = torch.empty((B + nd,), dtype=torch.int32, device=self.device)
+        self._chk(getattr(self.lib, "dm_lsa_indicator" + sfx)(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(Cm), nd, _ptr(dense),
+                                                             1 if maximize else 0, _ptr(out), _ptr(info)))
+        worst = int(info.max())
+        if worst == 2:
+            raise ValueError("matrix contains invalid numeric entries")
+        if worst == 1:
+            raise ValueError("cost matrix is infeasible")
+        return out
+
     def p2p_to_fm_lstsq(self, p21, Phi1, Phi2, k1, k2):
         """argmin_X |Phi2[:, :k2] X - Phi1[p21, :k1]|_F (reference convert.py:51, no mass matrix) -> (B,k2,k1) f64."""
         sfx, Phi1, Phi2 = self._reals(Phi1, Phi2)

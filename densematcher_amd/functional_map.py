@@ -32,18 +32,40 @@ _ASSIGN_STACK_LIMIT = 16 << 30     # bytes of dense matrices copied side by side
 
 def _assign_many(matrices):
     """the assignments of several (n2, n1) matrices in ONE batched call: one workgroup per matrix, so three assignments take
-    the time of the longest instead of their sum"""
+    the time of the longest instead of their sum.  Mapped indicators of small maps (k <= 32) go in by their FACTORS
+    (dm_lsa_indicator: the kernel evaluates their rows itself, the dense matrices are not formed); everything else dense."""
     import torch
     from .engine import default_engine
     eng = default_engine()
-    devs = [m.device_tensor() if hasattr(m, "device_tensor") else m for m in matrices]
-    devs = [d if d.dim() == 2 else d[0] for d in devs]
-    # torch.stack copies every matrix next to its original (which the caller's MappedIndicator keeps alive): beyond 2 GiB of copies
-    # (n around 9 k for three float64 matrices) the matrices are assigned one after the other, as the reference does
-    if len(devs) > 1 and sum(d.numel() * d.element_size() for d in devs) > _ASSIGN_STACK_LIMIT:
-        col = np.stack([eng.linear_sum_assignment(d[None], maximize=True)[0].cpu().numpy() for d in devs]).astype(np.int64)
+    # From the factors a search step costs 15 fused multiply-adds per column where the dense row costs one load: measured on one pair,
+    # 24 ms against 15.5 ms for the fitted map's indicator (tools/lsa_batch_spread.py) -- so a few matrices go in dense, and the factor
+    # form serves where the dense copies would not fit (and compute_surface_map_batch, whose launch lasts as long as its slowest
+    # matrix either way: 91 ms against 93 for 192 matrices, without 4 GB of indicators).
+    devs_bytes = sum(int(np.prod(m.shape)) * 8 for m in matrices)
+    ind = [q for q, m in enumerate(matrices) if hasattr(m, "_args") and getattr(m, "_dev", None) is None] if devs_bytes > _ASSIGN_STACK_LIMIT else []
+    if ind:
+        shapes = {(tuple(matrices[q]._args[0].shape[1:]), tuple(matrices[q]._args[1].shape[1:]), tuple(matrices[q]._args[3].shape[1:]),
+                   str(matrices[q]._args[0].dtype), str(getattr(matrices[q]._args[2], "dtype", None))) for q in ind}
+        P1, P2, _, C0 = matrices[ind[0]]._args
+        if len(shapes) != 1 or not eng.lsa_indicator_ok(P1.shape[1], P2.shape[1], C0.shape[2], C0.shape[1]):
+            ind = []
+    if ind:
+        rest = [q for q in range(len(matrices)) if q not in ind]
+        dev = [matrices[q].device_tensor() if hasattr(matrices[q], "device_tensor") else matrices[q] for q in rest]
+        dev = [d if d.dim() == 2 else d[0] for d in dev]
+        cat = lambda z: torch.cat([torch.as_tensor(matrices[q]._args[z]).to(eng.device) for q in ind], dim=0)      # (masses may arrive as NumPy arrays)
+        col = eng.lsa_indicator(cat(0), cat(1), cat(2), cat(3), dense=torch.stack(dev) if dev else None, maximize=True).cpu().numpy().astype(np.int64)
+        order = ind + rest
+        col = col[np.argsort(order)]
     else:
-        col = eng.linear_sum_assignment(torch.stack(devs), maximize=True).cpu().numpy().astype(np.int64)
+        devs = [m.device_tensor() if hasattr(m, "device_tensor") else m for m in matrices]
+        devs = [d if d.dim() == 2 else d[0] for d in devs]
+        # torch.stack copies every matrix next to its original (which the caller's MappedIndicator keeps alive): beyond the limit
+        # the matrices are assigned one after the other, as the reference does
+        if len(devs) > 1 and sum(d.numel() * d.element_size() for d in devs) > _ASSIGN_STACK_LIMIT:
+            col = np.stack([eng.linear_sum_assignment(d[None], maximize=True)[0].cpu().numpy() for d in devs]).astype(np.int64)
+        else:
+            col = eng.linear_sum_assignment(torch.stack(devs), maximize=True).cpu().numpy().astype(np.int64)
     out = []
     for c in col:
         rows = np.nonzero(c >= 0)[0]
@@ -166,7 +188,8 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
         _, P1, P2, A1d = eng._reals(Phi1, Phi2, a1)
         C0d = eng._dev(C0, torch.float64, "C")
         maps0 = eng.fm_to_p2p(P1, P2, A1d, C0d)
-        M0 = eng.mapped_indicator(P1, P2, A1d, C0d) if compute_extra else None
+        lr = eng.lsa_indicator_ok(P1.shape[1], P2.shape[1], C0d.shape[2], C0d.shape[1])     # assignments from the indicators' factors
+        M0 = eng.mapped_indicator(P1, P2, A1d, C0d) if (compute_extra and not lr) else None
         prec = None
         if compute_extra:
             faces = np.ascontiguousarray(np.stack([m.mesh1.facelist for m in g]), dtype=np.int32)
@@ -177,15 +200,23 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
         if float(resid.max()) > 1e-8:
             raise np.linalg.LinAlgError(f"ICP: polar iteration did not converge (|C^T C - I| = {float(resid.max()):.2e})")
         mapsi = eng.fm_to_p2p(P1, P2, A1d, Ci)
-        Mi = eng.mapped_indicator(P1, P2, A1d, Ci)
-        # ---- every assignment of the group in one launch
-        mats = ([M0, prec] if compute_extra else []) + [Mi]
-        # (one launch for all of them -- a matrix is one workgroup -- unless the concatenation, a COPY next to the originals, would pass
-        #  the same limit _assign_many has: then kind by kind)
-        if sum(m_.numel() * m_.element_size() for m_ in mats) > _ASSIGN_STACK_LIMIT and len(mats) > 1:
-            cols = np.concatenate([eng.linear_sum_assignment(m_, maximize=True).cpu().numpy() for m_ in mats]).astype(np.int64)
+        # ---- every assignment of the group in one launch (a matrix is one workgroup): rows [plain | precise | ICP] when compute_extra
+        if lr:
+            # the indicators by their factors (no N2 x N1 matrices: dm_lsa_indicator), the precise maps dense, in the same launch
+            if compute_extra:
+                c_ = eng.lsa_indicator(torch.cat([P1, P1]), torch.cat([P2, P2]), torch.cat([A1d, A1d]), torch.cat([C0d, Ci]), dense=prec,
+                                       maximize=True).cpu().numpy().astype(np.int64)
+                cols = np.concatenate([c_[:nb], c_[2 * nb:], c_[nb:2 * nb]])
+            else:
+                cols = eng.lsa_indicator(P1, P2, A1d, Ci, maximize=True).cpu().numpy().astype(np.int64)
         else:
-            cols = eng.linear_sum_assignment(torch.cat(mats, dim=0) if len(mats) > 1 else mats[0], maximize=True).cpu().numpy().astype(np.int64)
+            Mi = eng.mapped_indicator(P1, P2, A1d, Ci)
+            mats = ([M0, prec] if compute_extra else []) + [Mi]
+            # (unless the concatenation, a COPY next to the originals, would pass the same limit _assign_many has: then kind by kind)
+            if sum(m_.numel() * m_.element_size() for m_ in mats) > _ASSIGN_STACK_LIMIT and len(mats) > 1:
+                cols = np.concatenate([eng.linear_sum_assignment(m_, maximize=True).cpu().numpy() for m_ in mats]).astype(np.int64)
+            else:
+                cols = eng.linear_sum_assignment(torch.cat(mats, dim=0) if len(mats) > 1 else mats[0], maximize=True).cpu().numpy().astype(np.int64)
 
         def assignment(c):
             rows = np.nonzero(c >= 0)[0]

@@ -341,6 +341,21 @@ int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* ell_cols, c
                   int k, int guard, int n_iter, int degree, int warm_start,
                   double* X, double* lam, double* Phi, double* resid);
 
+/* The linear assignments of mapped indicators WITHOUT the dense matrices (functional_map.py:57, 78 call
+ * scipy.optimize.linear_sum_assignment(mapped_indicator, maximize=True) on the N2 x N1 matrix of pyFM/spectral/convert.py:144).  For maps
+ * up to 32 x 32 the kernel evaluates a cost row from the factors E2 = Phi2 C and Phi1, a1 -- the same arithmetic, bit for bit, as
+ * dm_mapped_indicator's entries (csrc/dm_indicator_dev.h), so the result is the assignment of that matrix -- and n_dense dense N2 x N1
+ * matrices (the precise map, functional_map.py:66) ride in the same launch.  Phi1 (n_ind,N1,ld1), Phi2 (n_ind,N2,ld2), mass1 (n_ind,N1),
+ * C (n_ind,k2,k1) fp64; col_of_row (n_ind + n_dense, N2), info (n_ind + n_dense): the indicators first.  dm_lsa_indicator_ok: 1 when
+ * the sizes are taken (k1, k2 <= 32, N2 <= N1 <= 2048). */
+int dm_lsa_indicator_ok(dm_ctx* ctx, int N1, int N2, int k1, int k2);
+int dm_lsa_indicator(dm_ctx* ctx, int n_ind, int N1, int N2, int k1, int k2, const float* Phi1, int ld1, const float* Phi2, int ld2,
+                     const float* mass1, const double* C, int n_dense, const double* dense /*nullable*/, int maximize,
+                     int32_t* col_of_row, int32_t* info);
+int dm_lsa_indicator_f64(dm_ctx* ctx, int n_ind, int N1, int N2, int k1, int k2, const double* Phi1, int ld1, const double* Phi2, int ld2,
+                         const double* mass1, const double* C, int n_dense, const double* dense /*nullable*/, int maximize,
+                         int32_t* col_of_row, int32_t* info);
+
 /* ---- Laplace-Beltrami operators ---------------------------------------------------------------------------------------
  * What TriMesh.process assembles before its eigensolve (pyFM/mesh/trimesh.py:440-482).
  *   dm_tufted_cover   HOST function (no device, no context, thread safe): the tufted intrinsic-Delaunay cover of one mesh -- the

@@ -843,3 +843,40 @@ def test_energy_keep_gram_option():
                                          e1[b].cpu().numpy(), e2[b].cpu().numpy(), a1[b].cpu().numpy(), wm)
         assert abs(float(plain[0][0][b]) - Eo) <= 1e-11 * abs(Eo)
         assert np.abs(plain[0][1][b].cpu().numpy() - Go).max() <= 1e-11 * np.abs(Go).max()
+
+
+def test_assignment_from_the_indicator_factors(fx_cfg1, monkeypatch):
+    """dm_lsa_indicator: the linear assignments of mapped indicators evaluated from their factors (no N2 x N1 matrix) are the assignments
+    of the dense matrices dm_mapped_indicator forms (same arithmetic, bit for bit), for 15 x 15 and 30 x 30 maps (the 16- and 32-wide
+    register tiles), float64 and fp32 bases, with a dense matrix riding in the same launch; and _assign_many takes that route when
+    the dense copies would pass its limit"""
+    import scipy.optimize
+    from densematcher_amd import functional_map as fmod
+    from densematcher_amd.engine import default_engine
+    from densematcher_amd.pyFM.spectral.convert import MappedIndicator
+    eng = default_engine()
+    fx = fx_cfg1
+    rng = np.random.default_rng(4)
+    for k, dt in ((15, np.float64), (30, np.float64), (15, np.float32)):
+        P1, P2 = fx["Phi1"][None, :, :k].astype(dt), fx["Phi2"][None, :, :k].astype(dt)
+        a1 = fx["a1"][None].astype(dt)
+        Cs = np.stack([fx["C_f64"][:k, :k], fx["C_f64"][:k, :k] + 0.05 * rng.standard_normal((k, k))])
+        rep = lambda x: np.concatenate([x, x])
+        assert eng.lsa_indicator_ok(P1.shape[1], P2.shape[1], k, k)
+        dense = eng.mapped_indicator(rep(P1), rep(P2), rep(a1), Cs)
+        extra = torch_rand = rng.standard_normal((1, P2.shape[1], P1.shape[1]))
+        got = eng.lsa_indicator(rep(P1), rep(P2), rep(a1), Cs, dense=extra).cpu().numpy()
+        want = eng.linear_sum_assignment(dense, maximize=True).cpu().numpy()
+        assert np.array_equal(got[:2], want), (k, dt)
+        assert np.array_equal(got[2], scipy.optimize.linear_sum_assignment(extra[0], maximize=True)[1])
+        assert np.array_equal(got[0], scipy.optimize.linear_sum_assignment(dense[0].cpu().numpy(), maximize=True)[1])
+    # the route _assign_many takes beyond its stacking limit
+    k = 15
+    P1, P2, a1 = (eng._dev(x, __import__("torch").float64, "x") for x in (fx["Phi1"][None, :, :k], fx["Phi2"][None, :, :k], fx["a1"][None]))
+    C = eng._dev(fx["C_f64"][None, :k, :k], __import__("torch").float64, "C")
+    mi = MappedIndicator(eng, P1, P2, a1, C, None, None)
+    ref = fmod._assign_many([MappedIndicator(eng, P1, P2, a1, C, None, None)])[0]
+    monkeypatch.setattr(fmod, "_ASSIGN_STACK_LIMIT", 1)
+    viaf = fmod._assign_many([mi])[0]
+    assert getattr(mi, "_dev", None) is None                       # (no dense matrix was formed)
+    assert np.array_equal(viaf[0], ref[0]) and np.array_equal(viaf[1], ref[1])
