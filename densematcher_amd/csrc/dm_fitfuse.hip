@@ -43,6 +43,8 @@ struct ff_params {
     int B, N1, N2, k1, k2, n;
     int N1pad, ncc, nrb, nU, nchunks;
     int unit_mode, W, wg_per_pair;
+    int n_active;
+    const int* active;                          // (n_active) the pairs of this launch: workgroups vid / wg_per_pair -> pair active[...]
     const float* Phi2; int ld2;
     double* xt;                                 // (B, k2, k1) trial maps: read by everyone at the start, advanced by the pair's last workgroup
     double* unit_part; double* chunk_part;      // (B, nU, n + 1) [unit mode], (B, nchunks, n + 1): gradient entries, then the energy
@@ -140,7 +142,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
     __shared__ double s_u[FF_KMAX], s_q[FF_KMAX], s_gu[FF_KMAX], s_gq[FF_KMAX];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int b = vid / p.wg_per_pair, w = vid - b * p.wg_per_pair;
+    const int slot = vid / p.wg_per_pair, w = vid - slot * p.wg_per_pair;
+    const int b = p.active[slot];
     if (p.advance && p.L.ic[(long long)b * LI_NINT + LI_STATUS] != LB_RUN) return;
     const int k1 = p.k1, k2 = p.k2, n = p.n, np1 = p.n + 1;
     if (p.dbg && b == 0 && t == 0) atomicMin((unsigned long long*)p.dbg, (unsigned long long)wall_clock64());      // earliest start of a pair-0 workgroup
@@ -562,7 +565,7 @@ static size_t ff_lds_bytes() {
 template <int KL1, int K2P>
 static int ff_launch(dm_ctx* ctx, const ff_params& p, const double* Psi, bool general) {
     const size_t lds = ff_lds_bytes<KL1, K2P>();
-    const dim3 grid(p.B * p.wg_per_pair);
+    const dim3 grid(p.n_active * p.wg_per_pair);
     if (p.dbg && dm_knob("DM_FF_DEBUG", 0) > 1) {
         int nb = -1;
         hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ff_eval_kernel<KL1, K2P, false>, 256, lds);
@@ -613,11 +616,13 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     p.B = B; p.N1 = N1; p.N2 = N2; p.k1 = k1; p.k2 = k2; p.n = n;
     p.ncc = dm_cdiv(N1, FF_COLS); p.nrb = dm_cdiv(N2, FF_ROWS); p.N1pad = p.ncc * FF_COLS;
     p.nU = p.nrb * p.ncc; p.nchunks = dm_cdiv(p.nU, FF_CHUNK);
-    // one unit per workgroup while that keeps the launch small; else W whole chunks per workgroup, W chosen for the fewest rounds of
-    // resident workgroups x chunks per workgroup (the element loop holds ~140 registers and the LDS panels of a unit: four
-    // workgroups per CU for maps up to 16 x 16), the largest such W (fewer recomputed rows of Phi2 C, fewer hand-ins)
-    if ((long long)B * p.nU <= 4096) { p.unit_mode = 1; p.W = 0; p.wg_per_pair = p.nU; }
-    else {
+    // The decomposition of a launch, for the pairs still running (na): one unit per workgroup while that keeps the launch small; else W
+    // whole chunks per workgroup, W chosen for the fewest rounds of resident workgroups x chunks per workgroup (the element loop holds
+    // 127 registers and 35 KiB of LDS panels: four workgroups per CU for maps up to 16 x 16), the largest such W (fewer recomputed
+    // rows of Phi2 C, fewer hand-ins).  Re-chosen whenever the status words are read: as pairs finish, the others get their CUs (the
+    // tree of additions does not depend on it).
+    auto choose = [&](int na) {
+        if ((long long)na * p.nU <= 4096) { p.unit_mode = 1; p.W = 0; p.wg_per_pair = p.nU; return; }
         const int KT1 = (KL1 + 15) / 16 * 16;
         const size_t panels = (size_t)2 * KT1 * 64, dsh = (size_t)4 * (K2P / 16) * (KT1 / 16) * 256;
         const size_t lds = (256 + (size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8 + 2048;
@@ -628,30 +633,33 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
         long long best = -1;
         p.unit_mode = 0; p.W = 1;
         for (int W = 1; W <= p.nchunks; ++W) {
-            const long long grid = (long long)B * dm_cdiv(p.nchunks, W);
+            const long long grid = (long long)na * dm_cdiv(p.nchunks, W);
             const long long cost = ((grid + slots - 1) / slots) * W;
             if (best < 0 || cost <= best) { best = cost; p.W = W; }
         }
         p.wg_per_pair = dm_cdiv(p.nchunks, p.W);
-    }
-    DM_REQUIRE(ctx, (long long)B * p.wg_per_pair < (1ll << 31), "batch too large for one launch");
+    };
+    choose(B);
+    p.n_active = B;
+    DM_REQUIRE(ctx, (long long)B * p.nU < (1ll << 31), "batch too large for one launch");
     const size_t bPsi = (size_t)B * p.N1pad * KL1 * 8, bSums = (size_t)B * FF_SUMS * 8, bPQ = (size_t)B * (k1 + k2) * k1 * 8;
-    const size_t bUnit = p.unit_mode ? (size_t)B * p.nU * np1 * 8 : 0, bChunk = (size_t)B * p.nchunks * np1 * 8;
+    const size_t bUnit = (size_t)B * p.nU * np1 * 8, bChunk = (size_t)B * p.nchunks * np1 * 8;
     const size_t bCnt = (size_t)B * (p.nchunks + 1) * 4, bState = eval_only ? 0 : lb_state_bytes(B, n, m);
     int rc = dm_ws_reserve(ctx, dm_align_up(bPsi) + dm_align_up(bSums) + dm_align_up(bPQ) + dm_align_up(bUnit) + dm_align_up(bChunk) + dm_align_up(bCnt) +
-                                    dm_align_up(bState) + 3 * dm_align_up((size_t)B * n * 8) + 2 * dm_align_up((size_t)B * 8) + 65536);
+                                    dm_align_up(bState) + 3 * dm_align_up((size_t)B * n * 8) + 3 * dm_align_up((size_t)B * 8) + 65536);
     if (rc) return rc;
     double* Psi = (double*)dm_ws_take(ctx, bPsi);
     double* sums = (double*)dm_ws_take(ctx, bSums);
     double* PQ = (double*)dm_ws_take(ctx, bPQ);
-    double* unit_part = p.unit_mode ? (double*)dm_ws_take(ctx, bUnit) : nullptr;
+    double* unit_part = (double*)dm_ws_take(ctx, bUnit);       // (unit mode may come later, when few pairs are left)
+    int* active = (int*)dm_ws_take(ctx, (size_t)B * 4);
     double* chunk_part = (double*)dm_ws_take(ctx, bChunk);
     int* cnt = (int*)dm_ws_take(ctx, bCnt);
     void* state = eval_only ? nullptr : dm_ws_take(ctx, bState);
     double* xt = (double*)dm_ws_take(ctx, (size_t)B * n * 8);
     double* grad = (double*)dm_ws_take(ctx, (size_t)B * n * 8);
     double* energy = (double*)dm_ws_take(ctx, (size_t)B * 8);
-    if (!Psi || !sums || !PQ || (p.unit_mode && !unit_part) || !chunk_part || !cnt || (!eval_only && !state) || !xt || !grad || !energy)
+    if (!Psi || !sums || !PQ || !unit_part || !active || !chunk_part || !cnt || (!eval_only && !state) || !xt || !grad || !energy)
         return dm_fail(ctx, DM_ENOMEM, "fit_fused: workspace not reserved");
     // ---- once per fit: Psi, the basis sums and centred Gram matrices, P = A A^T, Q = Bm A^T
     {
@@ -666,6 +674,11 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     }
     DM_CHECK_HIP(ctx, hipMemsetAsync(cnt, 0, bCnt, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemcpyAsync(xt, x0, (size_t)B * n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    std::vector<int> host_active((size_t)B);
+    for (int b = 0; b < B; ++b) host_active[b] = b;
+    DM_CHECK_HIP(ctx, hipMemcpyAsync(active, host_active.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));         // (the host vector is rewritten below)
+    p.active = active;
     p.Phi2 = Phi2; p.ld2 = ld2; p.xt = xt; p.unit_part = unit_part; p.chunk_part = chunk_part;
     p.chunk_cnt = cnt; p.pair_cnt = cnt + (size_t)B * p.nchunks;
     p.w_p2p = weights[3]; p.w_ent = weights[5]; p.w_r01 = weights[6]; p.w_sum = weights[7];
@@ -712,9 +725,16 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
         evals += chk;
         DM_CHECK_HIP(ctx, hipMemcpyAsync(host_ic.data(), p.L.ic, (size_t)B * LI_NINT * 4, hipMemcpyDeviceToHost, ctx->stream));
         DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        bool running = false;
-        for (int b = 0; b < B; ++b) running = running || host_ic[(size_t)b * LI_NINT + LI_STATUS] == LB_RUN;
-        if (!running || evals > maxfun + chk) break;
+        int na = 0;
+        for (int b = 0; b < B; ++b)
+            if (host_ic[(size_t)b * LI_NINT + LI_STATUS] == LB_RUN) host_active[na++] = b;
+        if (na == 0 || evals > maxfun + chk) break;
+        if (na != p.n_active) {                                   // the pairs that stopped leave the launches; the others spread out
+            DM_CHECK_HIP(ctx, hipMemcpyAsync(active, host_active.data(), (size_t)na * 4, hipMemcpyHostToDevice, ctx->stream));
+            DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            p.n_active = na;
+            choose(na);
+        }
     }
     if (dbg) {
         fprintf(stderr, "fit_fused stamps (us after the first pair-0 workgroup started; B = %d, %d launches): units done %.1f, last chunk leader %.1f, pair leader %.1f, "

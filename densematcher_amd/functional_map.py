@@ -158,7 +158,7 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
         rdt = _real_dtype(g[0].mesh1.eigenvectors, g[0].mesh2.eigenvectors)
         st = lambda f, dt: np.ascontiguousarray(np.stack([f(m) for m in g]), dtype=dt)
         Phi1, Phi2 = st(lambda m: m.mesh1.eigenvectors[:, :n_ev], rdt), st(lambda m: m.mesh2.eigenvectors[:, :n_ev], rdt)
-        a1, a2 = st(lambda m: m.mesh1.A.diagonal(), rdt), st(lambda m: m.mesh2.A.diagonal(), rdt)
+        a1, a2 = st(lambda m: m.mesh1.vertex_masses, rdt), st(lambda m: m.mesh2.vertex_masses, rdt)
         lam1, lam2 = st(lambda m: m.mesh1.eigenvalues[:n_ev], np.float64), st(lambda m: m.mesh2.eigenvalues[:n_ev], np.float64)
         fdt = np.float16 if (g[0].descr1.dtype == np.float16 and g[0].descr2.dtype == np.float16) else np.float32
         F1, F2 = st(lambda m: m.descr1, fdt), st(lambda m: m.descr2, fdt)

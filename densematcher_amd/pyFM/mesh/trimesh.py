@@ -30,7 +30,8 @@ class TriMesh:
             raise NotImplementedError("mesh file loading is outside the matching path: pass (vertices, faces)")
         self._W = None
         self._W_dev = None               # (cols (N, nnz), w (N, nnz)) device tensors of the last device assembly: W is built from them on demand
-        self.A = None
+        self._A = None
+        self._mass = None                # lumped masses of the last device assembly: A (CSR) is built from them on demand
         self._L = None
         self.eigenvalues = None
         self.eigenvectors = None
@@ -50,7 +51,7 @@ class TriMesh:
         elif vertlist.shape[1] != 3:
             raise ValueError('Vertex list requires 3D coordinates')
         self._vertlist = vertlist.copy()
-        self._W = self._W_dev = self.A = self._L = self.eigenvalues = self.eigenvectors = None
+        self._W = self._W_dev = self._A = self._mass = self._L = self.eigenvalues = self.eigenvectors = None
 
     @property
     def facelist(self):
@@ -86,6 +87,24 @@ class TriMesh:
         self._W = value
         self._W_dev = None
 
+    @property
+    def A(self):
+        """lumped (diagonal) mass matrix (CSR), built on first use after a device assembly (a batch of 128 meshes spent 14 ms in
+        scipy.sparse constructors nobody read: the batched path takes `vertex_masses`)"""
+        if self._A is None and self._mass is not None:
+            self._A = sparse.diags(self._mass).tocsr()
+        return self._A
+
+    @A.setter
+    def A(self, value):
+        self._A = value
+        self._mass = None if value is None else np.asarray(value.diagonal())
+
+    @property
+    def vertex_masses(self):
+        """diag(A) as an array (None before the Laplacian exists)"""
+        return self._mass
+
     vertices = property(lambda self: self._vertlist)
     faces = property(lambda self: self._facelist)
     n_vertices = property(lambda self: self._vertlist.shape[0])
@@ -94,13 +113,13 @@ class TriMesh:
     @property
     def area(self):
         """trimesh.py:206-221: A.sum() once the Laplacian exists, else the sum of the face areas."""
-        if self.A is None:
+        if self._mass is None and self.A is None:
             if self.facelist is None:
                 return None
             v = self.vertlist
             f = self.facelist
             return 0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1).sum()
-        return self.A.sum()
+        return self._mass.sum() if self._mass is not None else self.A.sum()
 
     # -- differential geometry of the faces (inputs of the orientation term of FunctionalMapping.fit; host arithmetic, as in
     #    the reference: pyFM/mesh/geometry.py)
@@ -225,7 +244,8 @@ class TriMesh:
             n = mesh.n_vertices
             mesh._W = None
             mesh._W_dev = (ell["cols"][b, :n], ell["w"][b, :n])
-            mesh.A = sparse.diags(mass[b, :n]).tocsr()
+            mesh._A = None
+            mesh._mass = mass[b, :n].copy()
             mesh._L = None
         return ell
 
@@ -236,7 +256,8 @@ class TriMesh:
         """lam (>= k,), phi (N, >= k): device tensors of the solver; keeps the first k pairs (laplacian.py:165-167)"""
         if float(resid) > 1e-6 * max(1.0, float(lam[-1])):
             raise RuntimeError(f"eigensolver did not converge (residual {float(resid):.2e})")
-        self.eigenvalues, self.eigenvectors = lam[:k].cpu().numpy(), phi[:self.n_vertices, :k].cpu().numpy()
+        self.eigenvalues = np.array(lam[:k].cpu().numpy())
+        self.eigenvectors = np.ascontiguousarray(phi[:self.n_vertices, :k].cpu().numpy())
         if abs(self.eigenvalues[0]) < 1e-9 * max(1.0, self.eigenvalues[-1]):
             self.eigenvalues[0] = max(self.eigenvalues[0], 0.0)
 
@@ -298,6 +319,7 @@ class TriMesh:
             lam, phi, resid, _ = eng.eigenbasis([mesh.W for mesh, _ in todo], [np.asarray(mesh.A.diagonal()) for mesh, _ in todo], kk, tol=1e-10)
         else:
             lam, phi, resid, _ = eng.eigenbasis(None, None, kk, tol=1e-10, ell=ell)
+        lam, phi, resid = lam.cpu(), phi.cpu(), resid.cpu()                      # (one copy each for the batch, not three per mesh)
         for q, (mesh, k) in enumerate(todo):
             mesh._store_spectrum(lam[q], phi[q], resid[q], k)
         return meshes
