@@ -575,7 +575,7 @@ class MatchEngine:
         self._chk(self.lib.dm_laplacian_ell(self.ctx, Bn, N, nt, _ptr(rows), nnz, _ptr(nv_d), _ptr(cols), _ptr(vals), _ptr(mass32), _ptr(w), _ptr(mass64)))
         return {"cols": cols, "vals": vals, "mass32": mass32, "w": w, "mass64": mass64, "nnz": nnz, "n_verts": n_verts}
 
-    def eigenbasis(self, W_list, mass, k, guard=32, degree=30, tol=1e-9, max_rounds=12, seed=0, ell=None):
+    def eigenbasis(self, W_list, mass, k, guard=None, degree=30, tol=1e-9, max_rounds=12, seed=0, ell=None):
         """k smallest eigenpairs of W phi = lambda A phi for a batch of meshes (reference TriMesh.process ->
         laplacian_spectrum: ARPACK on the host, one mesh at a time).
         ell = the dict laplacian_ell returns (operands already on the device; W_list / mass are ignored), or
@@ -595,6 +595,12 @@ class MatchEngine:
         # is a diagonal one AT the Gershgorin bound of the mesh's own operator (max_i sum_q |L_iq| >= lambda_max: the upper end of
         # the interval the Chebyshev filter damps), so the spurious eigenvalue can never fall inside the wanted part of the
         # spectrum.  Their rows of Phi come back ~0 and the caller slices them off.
+        if guard is None:
+            # guard vectors: 12 .. 32, so that the block k + guard is a multiple of 32 columns where that is possible -- the sparse
+            # product gathers whole rows of the block, and 32 doubles are two aligned 128-byte lines (measured, 128 meshes of 2048
+            # vertices, k = 20: 79 ms with 32 guard vectors = 52 columns, 46 ms with 12 = 32 columns, one more round, same eigenpairs
+            # to 1e-15: tools/eig_sweep.py)
+            guard = next((g for g in range(12, 33) if (k + g) % 32 == 0), 32)
         if ell is not None:
             cols_d, vals_d, mass_d, nnz = ell["cols"], ell["vals"], ell["mass32"], int(ell["nnz"])
             B, N = mass_d.shape
