@@ -52,3 +52,7 @@ print("all indicators by factors + precise maps dense, one launch: %.1f ms" %
       timed(lambda: eng.lsa_indicator(np.concatenate([P1, P1]), np.concatenate([P2, P2]), np.concatenate([a1, a1]), np.concatenate([C0, Ci]), dense=prec)))
 print("indicators only, one launch: %.1f ms" % timed(lambda: eng.lsa_indicator(np.concatenate([P1, P1]), np.concatenate([P2, P2]), np.concatenate([a1, a1]), np.concatenate([C0, Ci]))))
 print("precise maps only, one launch: %.1f ms" % timed(lambda: eng.linear_sum_assignment(prec, maximize=True)))
+if os.environ.get("LSA_DUMP"):
+    nb = min(B, 8)
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.savez_compressed("gpurun_out/lsa_factors.npz", P1=P1[:nb], P2=P2[:nb], a1=a1[:nb], C0=C0[:nb], Ci=Ci[:nb])
