@@ -45,6 +45,19 @@ def fx_cfg2():
 
 
 @pytest.fixture(scope="session")
+def fx_cfg5():
+    """BASELINE config-5 size (N = 8192, D = 384, k = 200), one pair, run through the reference (tools/make_golden_r05.py)"""
+    fx = load_golden("fx_cfg5.npz")
+    from densematcher_amd import synth
+    n = fx["Phi1"].shape[0]
+    s1, s2 = (int(x) for x in fx["feat_seeds"])
+    F1, F2, _ = synth.feature_pair(n, n, int(fx["D"]), s1, s2, sigma=float(fx["feat_sigma"]), perm="identity")
+    assert synth.sha256_of(F1, F2) == str(fx["feat_sha256"]), "regenerated descriptors differ from the fixture's"
+    fx["F1"], fx["F2"] = F1, F2
+    return fx
+
+
+@pytest.fixture(scope="session")
 def fx_cfg2_icp():
     return load_golden("fx_cfg2_icp.npz")
 

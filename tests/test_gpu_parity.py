@@ -36,7 +36,7 @@ def _b(x):
 
 
 # --------------------------------------------------------------------------- #
-@pytest.mark.parametrize("fxname", ["fx_cfg1", "fx_cfg2"])
+@pytest.mark.parametrize("fxname", ["fx_cfg1", "fx_cfg2", "fx_cfg5"])
 def test_project_and_solve(eng, fxname, request):
     fx = request.getfixturevalue(fxname)
     k = int(fx["k"])
@@ -74,7 +74,8 @@ def test_project_and_solve(eng, fxname, request):
 
 
 @pytest.mark.parametrize("fxname,pre,cname", [("fx_cfg1", "", "C_fit"), ("fx_cfg2", "", "C_fit"),
-                                              ("fx_cfg2", "f64_", "C_f64"), ("fx_cfg1", "icp_", "C_icp")])
+                                              ("fx_cfg2", "f64_", "C_f64"), ("fx_cfg1", "icp_", "C_icp"),
+                                              ("fx_cfg5", "", "C_fit"), ("fx_cfg5", "f64_", "C_f64")])
 def test_fm_to_p2p_bit_exact(eng, fxname, pre, cname, request):
     fx = request.getfixturevalue(fxname)
     k = int(fx["k"])
@@ -116,6 +117,13 @@ def test_ties_lowest_index(eng, fx_ties):
                                 with_indicator=False)
     assert np.array_equal(_np(out["knn21"])[0], p21)
     assert np.array_equal(_np(out["knn12"])[0], p12)
+
+
+def test_p2p_to_fm_config5_size_against_reference(eng, fx_cfg5):
+    """N = 8192, k = 200: p2p_to_FM of the reference's own knn21 (convert.py:39-51) against the reference's result"""
+    fx, k = fx_cfg5, int(fx_cfg5["k"])
+    C = _np(eng.p2p_to_fm(_b(fx["knn21"].astype(np.int32)), _b(fx["Phi1"]), _b(fx["Phi2"]), _b(fx["a2"]), k, k))[0]
+    assert np.abs(C - fx["C_from_p2p"]).max() <= 1e-12 * max(1.0, np.abs(fx["C_from_p2p"]).max())
 
 
 def test_p2p_to_fm(eng, fx_cfg1, fx_cfg2):

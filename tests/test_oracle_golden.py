@@ -12,7 +12,7 @@ def _f64(fx, *names):
     return [np.asarray(fx[n], dtype=np.float64) for n in names]
 
 
-@pytest.mark.parametrize("fxname", ["fx_cfg1", "fx_cfg2"])
+@pytest.mark.parametrize("fxname", ["fx_cfg1", "fx_cfg2", "fx_cfg5"])
 def test_fit_matches_reference(fxname, request):
     fx = request.getfixturevalue(fxname)
     phi1, phi2, a1, a2 = _f64(fx, "Phi1", "Phi2", "a1", "a2")
@@ -49,7 +49,7 @@ def test_pieces_cfg1(fx_cfg1):
     assert np.abs(Cl - fx["C_f64"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("fxname,pre", [("fx_cfg1", ""), ("fx_cfg2", ""), ("fx_cfg2", "f64_")])
+@pytest.mark.parametrize("fxname,pre", [("fx_cfg1", ""), ("fx_cfg2", ""), ("fx_cfg2", "f64_"), ("fx_cfg5", ""), ("fx_cfg5", "f64_")])
 def test_maps_bit_exact(fxname, pre, request):
     fx = request.getfixturevalue(fxname)
     k = int(fx["k"])

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""
+Round-5 golden fixture, produced by IMPORTING THE REFERENCE (/root/reference) in the build container (recipe and stubs:
+tools/make_golden.py, which this script re-uses).  VERDICT r04 "missing" #4 / "do this" #3: a reference-generated fixture at
+BASELINE config-5 size.
+
+    fx_cfg5.npz   configs[4] shape, ONE pair: N = 8192 (128 x 64 torus), D = 384, k = 200
+        Phi1 / Phi2, lam1 / lam2, a1 / a2   the reference's spectrum (TriMesh.process(200, robust=True), trimesh.py:498-531), eigenvectors
+                                            and masses rounded to float32 (what the file stores is what the reference then consumed)
+        C_fit                               FunctionalMapping.fit with the notebook weights (functional.py:352-487)
+        C_f64                               the same energy minimised in float64 with the reference's analytic gradients (make_golden.ref_C_f64)
+        knn21 .. ind12 (and f64_*)          FM_to_p2p + the indicator arg-maxes on C_fit (on C_f64)  (convert.py:134-144, functional_map.py:49-50)
+        C_from_p2p                          p2p_to_FM(knn21) with A2 (convert.py:39-51)
+    Descriptors are regenerated from seeds by the tests (sha256 pinned in the file).
+Run time here: about ten minutes, 9 GB.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as mg  # noqa: E402
+
+OUT = mg.OUT
+
+
+def main():
+    nu, nv, D, k = 128, 64, 384, 200
+    t0 = time.time()
+    v1, f1 = mg.synth.torus_mesh(nu, nv)
+    v2, f2 = mg.synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
+    m1, (phi1, lam1, a1) = mg.processed_mesh(v1, f1, k)
+    m2, (phi2, lam2, a2) = mg.processed_mesh(v2, f2, k)
+    print("spectra", time.time() - t0, flush=True)
+    F1, F2, perm = mg.synth.feature_pair(nu * nv, nu * nv, D, 5000, 6000, sigma=1.0, perm="identity")
+    model, A32, B32 = mg.ref_fit(m1, m2, F1, F2, k)
+    C_fit = model.FM.copy()
+    print("fit", time.time() - t0, flush=True)
+    C_f64, x0, A64, B64, ev = mg.ref_C_f64(model, F1, F2)
+    print("f64 fit", time.time() - t0, "|C_fit - C_f64| =", np.abs(C_fit - C_f64).max(), flush=True)
+    k21, k12, i21, i12, _ = mg.ref_maps(C_fit, model.mesh1, model.mesh2)
+    f21, f12, fi21, fi12, _ = mg.ref_maps(C_f64, model.mesh1, model.mesh2)
+    print("maps", time.time() - t0, flush=True)
+    C_from_p2p = mg.ref_spectral.p2p_to_FM(k21, model.mesh1.eigenvectors, model.mesh2.eigenvectors, A2=model.mesh2.A)
+    np.savez_compressed(
+        os.path.join(OUT, "fx_cfg5.npz"),
+        Phi1=phi1, Phi2=phi2, lam1=lam1, lam2=lam2, a1=a1, a2=a2, nu=nu, nv=nv,
+        feat_seeds=np.array([5000, 6000]), feat_sigma=1.0, feat_sha256=mg.synth.sha256_of(F1, F2), D=D, k=k,
+        w_descr=mg.W_DESCR, w_lap=mg.W_LAP, x0_col0=x0[:, 0],
+        C_fit=C_fit, C_f64=C_f64,
+        knn21=k21.astype(np.int32), knn12=k12.astype(np.int32), ind21=i21.astype(np.int32), ind12=i12.astype(np.int32),
+        f64_knn21=f21.astype(np.int32), f64_knn12=f12.astype(np.int32), f64_ind21=fi21.astype(np.int32), f64_ind12=fi12.astype(np.int32),
+        C_from_p2p=C_from_p2p,
+    )
+    print("cfg5 written in", time.time() - t0, "s: map agreement fit-vs-f64:", (k21 == f21).mean(), (i21 == fi21).mean(),
+          " ind21==perm:", (i21 == perm).mean())
+
+
+if __name__ == "__main__":
+    main()
