@@ -55,7 +55,16 @@ extern "C" int dm_destroy(dm_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gram_keep) (void)hipFree(ctx->gram_keep);
+    if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
+    if (ctx->pinned_event) (void)hipEventDestroy(ctx->pinned_event);
     delete ctx;
+    return DM_OK;
+}
+
+int dm_pinned_words(dm_ctx* ctx, int32_t** words, hipEvent_t* ev) {
+    if (!ctx->pinned_words) DM_CHECK_HIP(ctx, hipHostMalloc((void**)&ctx->pinned_words, 64 * sizeof(int32_t), hipHostMallocDefault));
+    if (!ctx->pinned_event) DM_CHECK_HIP(ctx, hipEventCreateWithFlags(&ctx->pinned_event, hipEventDisableTiming));
+    *words = ctx->pinned_words; *ev = ctx->pinned_event;
     return DM_OK;
 }
 

@@ -23,6 +23,10 @@
 // masks and waits vmcnt(0) where they join -- every prefetch was waited for on the spot (r04, found in the Gram kernel's ISA).
 template <class T, class = void> struct dm_has_fast { static constexpr bool value = false; };
 template <class T> struct dm_has_fast<T, std::void_t<decltype(&T::fast_ok)>> { static constexpr bool value = true; };
+// Out::skip(b) (optional): a wave-uniform "this batch entry has nothing to compute" -- gemm_nt_f64 then hands every output of the tile to
+// Out::store_skipped(b, i, j) instead of running the product (the ICP's polar iteration: pairs that have converged), gemm_tn_f64 writes nothing
+template <class T, class = void> struct dm_has_skip { static constexpr bool value = false; };
+template <class T> struct dm_has_skip<T, std::void_t<decltype(&T::skip)>> { static constexpr bool value = true; };
 template <class T, class = void> struct dm_elem { typedef double type; };
 template <class T> struct dm_elem<T, std::void_t<typename T::elem_t>> { typedef typename T::elem_t type; };
 typedef __attribute__((address_space(1))) const f32x4 dm_gf32x4;      // global address space: global_load, not flat_load
@@ -153,6 +157,21 @@ __global__ __launch_bounds__(256) void gemm_nt_f64(OpA opa, OpB opb, Out out, in
     const int i0 = ti * NT_T, j0 = tj * NT_T;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    if constexpr (dm_has_skip<Out>::value) {
+        if (out.skip(b)) {                                    // (uniform)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + wm * 32 + mt * 16 + (lane >> 4) + 4 * r;
+                        const int j = j0 + wn * 32 + nt * 16 + (lane & 15);
+                        if (i < M && j < N) out.store_skipped(b, i, j);
+                    }
+            return;
+        }
+    }
 
     f64x4 acc[2][2];
 #pragma unroll
@@ -195,6 +214,7 @@ __global__ __launch_bounds__(256) void gemm_tn_f64(OpX opx, OpY opy, Out out, in
     const int tiles_c = (N + TN_T - 1) / TN_T;
     const int tm = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
     const int split = blockIdx.y, b = blockIdx.z;
+    if constexpr (dm_has_skip<Out>::value) { if (out.skip(b)) return; }            // (uniform)
     const int m0 = tm * TN_T, c0 = tc * TN_T;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;

@@ -15,6 +15,19 @@
 // 12 + 6 steps reach |X^T X - I| ~ 1e-16 for sigma_min / sigma_max down to ~4e-7 (plain Newton-Schulz gains only a
 // factor 1.5 per step: 22 steps stalled at 8e-4 on a Chat with sigma_min / sigma_max = 6e-4,
 // tests/test_gpu_parity.py::test_refine_ragged).  The final |X^T X - I| is reported.
+// r05: the schedule is per pair and follows what the iteration measures on the T = X^T X every step computes anyway (polar_decide:
+// one workgroup per pair, T in the LDS):
+//   * first step: s^2 = |T|_inf >= sigma_max^2 is the scaling, folded into the step's coefficients (the row-sum norm of T is far
+//     tighter than sqrt(|X|_1 |X|_inf), which overestimates sigma_max of a 128 x 128 orthogonal matrix nine times);
+//   * LIFT while rho = |T - I|_2 > 0.62, estimated from below by a few power iterations per step whose vector is kept from step to
+//     step (T's eigenvectors are X's right singular vectors: the same at every step; a singular value still far below 1 is an
+//     eigenvalue ~1 of I - T next to others below 0.54: it dominates after a handful of iterations);
+//   * then Newton-Schulz until r = |T - I|_inf (>= rho: a safe bound) is below 3e-8: that step is the last (its error
+//     1.5 (r / 2)^2 = 3e-16); nothing runs for the pair after it.  An optimistic rho costs Newton-Schulz steps (x 1.5 per step,
+//     always convergent below sqrt 3), never the result; NS_MAX_STEPS caps the schedule.
+//   The host stops launching once no pair is left, and launches the lifts' T^2 product only while some pair lifts (lagged reads of
+//   two words through page-locked memory: the queue never drains).  A well-conditioned Chat takes 0-1 lifts + 5-6 polish steps
+//   (20 launches) instead of 12 + 6 (49); an ill-conditioned one as many lifts as it needs (481 of 570 launches).
 #include "dm_chol.h"
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
@@ -22,6 +35,9 @@
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 
 constexpr int NS_LIFT = 12, NS_POLISH = 6;
+constexpr int NS_POWER0 = 6, NS_POWER = 3;                 // power iterations of the first / of a later lifting step
+constexpr double NS_RHO = 0.62;                            // lift while |T - I|_2 is (estimated) above
+constexpr int NS_MAX_STEPS = NS_LIFT + 28;                 // cap of the schedule
 // (the k x k products of the polar iteration with all four stages of operand loads in flight from the start, dm_gemm_f64.h NPRE = 4:
 //  16.2 -> 19.1 us per launch; they stay at one stage ahead)
 constexpr double NS_A = 3.4445, NS_B = -4.7750, NS_C = 2.0315;
@@ -95,25 +111,6 @@ __global__ __launch_bounds__(256) void spd_multi_rhs_kernel(const double* __rest
     for (int r = t; r < n; r += 256) X[((long long)b * n + r) * nrhs + c] = xv[r];
 }
 
-// alpha_b = sqrt(|X|_1 |X|_inf) >= sigma_max;  X <- X / alpha      (one workgroup per pair)
-__global__ __launch_bounds__(256) void polar_scale_kernel(double* __restrict__ X, int k2, int k1) {
-    __shared__ double rs[256], cs[256];
-    const int b = blockIdx.x, t = threadIdx.x;
-    double* M = X + (long long)b * k2 * k1;
-    double r = 0.0, c = 0.0;
-    if (t < k2) for (int j = 0; j < k1; ++j) r += fabs(M[(long long)t * k1 + j]);
-    if (t < k1) for (int i = 0; i < k2; ++i) c += fabs(M[(long long)i * k1 + t]);
-    rs[t] = r; cs[t] = c;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (t < off) { rs[t] = fmax(rs[t], rs[t + off]); cs[t] = fmax(cs[t], cs[t + off]); }
-        __syncthreads();
-    }
-    const double alpha = sqrt(rs[0] * cs[0]);
-    const double inv = alpha > 0.0 ? 1.0 / alpha : 0.0;
-    for (int e = t; e < k2 * k1; e += 256) M[e] *= inv;
-}
-
 struct RowsF64 {                       // K-major f64 operand for gemm_tn_f64
     const double* p; long long stride_b; int ld; int ncols;
     __device__ __forceinline__ void load4(int b, int n, int col0, double (&v)[4]) const {
@@ -129,6 +126,173 @@ struct OutPlainTN {
 struct OutPlainNT {
     double* p; long long stride_b; int ld;
     __device__ __forceinline__ void store(int b, int i, int j, double v) const { p[b * stride_b + (long long)i * ld + j] = v; }
+};
+// ---- the polar iteration's per-pair schedule --------------------------------------------------------------------
+// a step is  X <- a X + b X M,  M = T = X^T X (Newton-Schulz) or M = W = wb T + wc T^2 (lift)
+struct polar_state { double a, b, wb, wc; int mode, lift, lifting, count; };   // mode 0: step, 1: step and stop, 2: done; lift: M = W this step
+// One workgroup per pair, after the T of the step: the step's coefficients.  T (k x k, k <= 256) is copied to the LDS when it fits
+// (lds_T != 0; else it is read where it is); vecs: (B, 256) the pair's power-iteration vector.  counts[0] += pairs that step,
+// counts[1] += pairs that lift at this step.
+__global__ __launch_bounds__(256) void polar_decide_kernel(const double* __restrict__ Tm, int k, polar_state* __restrict__ st,
+                                                           double* __restrict__ vecs, int32_t* __restrict__ counts, int lds_T) {
+    extern __shared__ __attribute__((aligned(16))) double pd_smem[];
+    __shared__ double red[8], vec[2][256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    // Everything the kernel reads from memory is requested at once, before the first use: T (into registers, on its way to the LDS), the
+    // pair's vector and its state -- one round trip instead of three dependent ones (each ~2 us on this part; the kernel's work is ~5).
+    const double* Tg = Tm + (long long)b * k * k;
+    const int n = k * k, n2 = n >> 1;
+    const bool packed = lds_T && (n & 1) == 0;                 // (uniform)
+    constexpr int PRE = 36;                                    // 36 x 256 x 16 bytes = 144 KiB: every T that fits the LDS
+    f64x2 tx[PRE];
+    if (packed) {
+        const f64x2* src = reinterpret_cast<const f64x2*>(Tg);
+#pragma unroll
+        for (int u = 0; u < PRE; ++u) { const int e = 256 * u + t; tx[u] = src[e < n2 ? e : n2 - 1]; }
+    }
+    const double gv_t = vecs[(long long)b * 256 + t];
+    const polar_state old = st[b];                             // (uniform)
+    if (old.mode >= 1) {                                       // its last step ran in the previous round (or it was done already)
+        if (t == 0 && old.mode == 1) st[b] = polar_state{1.0, 0.0, 0.0, 0.0, 2, 0, 0, old.count};
+        return;
+    }
+    const double* T = Tg;
+    if (lds_T) {                                               // (uniform)
+        if (packed) {
+            f64x2* dst = reinterpret_cast<f64x2*>(pd_smem);
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) { const int e = 256 * u + t; if (e < n2) dst[e] = tx[u]; }
+        } else {
+            for (int e = t; e < n; e += 256) pd_smem[e] = Tg[e];
+        }
+        __syncthreads();
+        T = pd_smem;
+    }
+    const bool first = old.count == 0;
+    // column sums (T is symmetric) of |T| (first step) or |T - I|: thread (j, half of the rows); consecutive threads read consecutive words
+    const int j = t & 127, half = t >> 7;
+    const int ibeg = half * ((k + 1) / 2), iend = half ? k : (k + 1) / 2;
+    // (columns past k read column k - 1 and are dropped at the end: no branch in the loops, eight independent reads per pass)
+    const int ja = min(j, k - 1), jb = min(j + 128, k - 1);
+    const double dsub = first ? 0.0 : 1.0;
+    double c0 = 0.0, c1 = 0.0;
+    {
+        int i = ibeg;
+        for (; i + 8 <= iend; i += 8) {
+            double xa[8], xb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xa[u] = T[(i + u) * k + ja]; xb[u] = T[(i + u) * k + jb]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c0 += fabs(xa[u] - ((i + u == ja) ? dsub : 0.0)); c1 += fabs(xb[u] - ((i + u == jb) ? dsub : 0.0)); }
+        }
+        for (; i < iend; ++i) { c0 += fabs(T[i * k + ja] - ((i == ja) ? dsub : 0.0)); c1 += fabs(T[i * k + jb] - ((i == jb) ? dsub : 0.0)); }
+        if (j >= k) c0 = 0.0;
+        if (j + 128 >= k) c1 = 0.0;
+    }
+    if (half == 1) { vec[0][j] = c0; vec[1][j] = c1; }
+    __syncthreads();
+    double m = 0.0;
+    if (half == 0) { m = fmax(c0 + vec[0][j], c1 + vec[1][j]); }
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    const double rinf = fmax(red[0], red[1]);                  // |T|_inf (first step) or |T - I|_inf
+    __syncthreads();
+    if (first && !(rinf > 0.0)) {                              // X = 0 stays 0 (the residual reports it); (uniform)
+        if (t == 0) st[b] = polar_state{1.0, 0.0, 0.0, 0.0, 2, 0, 0, 1};
+        return;
+    }
+    const double inv_s2 = first ? 1.0 / rinf : 1.0;            // E = I - T / s^2
+    bool lifting = first || old.lifting;                       // (uniform)
+    double rho = 0.0;
+    if (lifting) {
+        // power iteration on E, from the pair's vector of the previous step
+        double* gv = vecs + (long long)b * 256;
+        vec[0][t] = first ? ((t < k) ? 1.0 + 0.37 * ((t * 7) % 5) : 0.0) : gv_t;
+        __syncthreads();
+        const int nit = first ? NS_POWER0 : NS_POWER;
+        for (int it = 0; it < nit; ++it) {
+            const int cur = it & 1;
+            double y0 = 0.0, y1 = 0.0;
+            {
+                int i = ibeg;
+                for (; i + 8 <= iend; i += 8) {
+                    double xa[8], xb[8], vi[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { xa[u] = T[(i + u) * k + ja]; xb[u] = T[(i + u) * k + jb]; vi[u] = vec[cur][i + u]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { y0 = fma(xa[u], vi[u], y0); y1 = fma(xb[u], vi[u], y1); }
+                }
+                for (; i < iend; ++i) { const double vi = vec[cur][i]; y0 = fma(T[i * k + ja], vi, y0); y1 = fma(T[i * k + jb], vi, y1); }
+                if (j >= k) y0 = 0.0;
+                if (j + 128 >= k) y1 = 0.0;
+            }
+            if (half == 1) { vec[cur ^ 1][j] = y0; if (j + 128 < 256) vec[cur ^ 1][j + 128] = y1; }
+            __syncthreads();
+            if (half == 0) { vec[cur ^ 1][j] += y0; if (j + 128 < 256) vec[cur ^ 1][j + 128] += y1; }
+            __syncthreads();
+            const double v_t = t < k ? vec[cur][t] : 0.0;
+            const double w_t = t < k ? v_t - inv_s2 * vec[cur ^ 1][t] : 0.0;       // (E v)_t
+            double p1 = v_t * v_t, p2 = w_t * w_t;
+            for (int off = 32; off > 0; off >>= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+            __syncthreads();
+            if ((t & 63) == 0) { red[t >> 6] = p1; red[4 + (t >> 6)] = p2; }
+            __syncthreads();
+            const double vn = (red[0] + red[1]) + (red[2] + red[3]), wn = (red[4] + red[5]) + (red[6] + red[7]);
+            rho = vn > 0.0 ? sqrt(wn / vn) : 0.0;                                  // |E v| / |v| <= |E|_2
+            vec[cur ^ 1][t] = wn > 0.0 ? w_t / sqrt(wn) : v_t;
+            __syncthreads();
+        }
+        gv[t] = vec[nit & 1][t];
+        lifting = rho > NS_RHO;
+    }
+    if (t == 0) {
+        const double is = first ? sqrt(inv_s2) : 1.0, is2 = is * is;             // 1 / s
+        polar_state s;
+        if (lifting) s = polar_state{NS_A * is, 1.0, NS_B * is * is2, NS_C * is * is2 * is2, 0, 1, 1, old.count + 1};
+        else {
+            s = polar_state{1.5 * is, -0.5 * is * is2, 0.0, 0.0, 0, 0, 0, old.count + 1};
+            if (!first && rinf < 1e-14) s = polar_state{1.0, 0.0, 0.0, 0.0, 2, 0, 0, old.count};
+            else if (!first && rinf < 3e-8) s.mode = 1;
+        }
+        st[b] = s;
+        if (s.mode != 2) atomicAdd(&counts[0], 1);
+        if (s.lift) atomicAdd(&counts[1], 1);
+    }
+}
+struct OutPolarT {                     // T = X^T X; nothing to do for a pair that has taken its last step
+    double* p; long long stride_b; int ld; const polar_state* st;
+    __device__ __forceinline__ bool skip(int b) const { return st[b].mode >= 1; }
+    __device__ __forceinline__ void store(int b, int, int m, int c, double v) const { p[b * stride_b + (long long)m * ld + c] = v; }
+};
+struct OutPolarW {                     // W = wb T + wc T T for the pairs that lift
+    const double* tm; double* wm; long long stride_b; int ld; const polar_state* st;
+    __device__ __forceinline__ bool skip(int b) const { return st[b].lift == 0; }
+    __device__ __forceinline__ void store_skipped(int, int, int) const {}
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const {
+        const long long o = b * stride_b + (long long)i * ld + j;
+        wm[o] = st[b].wb * tm[o] + st[b].wc * v;
+    }
+};
+struct OutPolarX {                     // Xnew = a Xold + b Xold M; a finished pair's X is carried over to the other buffer
+    const double* xo; double* xn; long long stride_b; int ld; const polar_state* st;
+    __device__ __forceinline__ bool skip(int b) const { return st[b].mode == 2; }
+    __device__ __forceinline__ void store_skipped(int b, int i, int j) const {
+        const long long o = b * stride_b + (long long)i * ld + j;
+        xn[o] = xo[o];
+    }
+    __device__ __forceinline__ void store(int b, int i, int j, double v) const {
+        const long long o = b * stride_b + (long long)i * ld + j;
+        xn[o] = st[b].a * xo[o] + st[b].b * v;
+    }
+};
+struct KRowsPolarM {                   // the step's M: W for a pair that lifts, T otherwise (same interface as KRowsF64)
+    KRowsF64 t, w; const polar_state* st;
+    __device__ __forceinline__ const KRowsF64& of(int b) const { return st[b].lift ? w : t; }
+    __device__ __forceinline__ bool fast_ok(int K, int rows_used) const { return t.fast_ok(K, rows_used) && w.fast_ok(K, rows_used); }
+    __device__ __forceinline__ void load8_fast(int b, int row, int k0, double (&v)[8]) const { of(b).load8_fast(b, row, k0, v); }
+    __device__ __forceinline__ double cvt(const double& x, int) const { return x; }
+    __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const { of(b).load8(b, row, k0, v); }
 };
 struct OutAxpby {                      // Xnew = alpha Xold + beta (product)
     const double* xo; double* xn; long long stride_b; int ld; double alpha, beta;
@@ -315,8 +479,10 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
     const size_t bAT = (size_t)B * Kpad * N2pad * 8, bBT = (size_t)B * Kpad * N1pad * 8;
     const size_t bC = (size_t)B * k2 * k1 * 8, bG = (size_t)B * k2 * k2 * 8, bImg = (size_t)B * nblk * 256 * 8;
     const size_t bT = (size_t)B * k1 * k1 * 8;
+    const size_t bState = (size_t)B * sizeof(polar_state), bCnt = (size_t)(nit > 0 ? nit : 1) * NS_MAX_STEPS * 8;
     const size_t need = dm_align_up(bAT) + dm_align_up(bBT) + 4 * dm_align_up(bC) + 4 * dm_align_up(bG) + dm_align_up(bImg) +
                         2 * dm_align_up(bT) + dm_align_up((size_t)B * N1pad * 8) + 4 * dm_align_up((size_t)B * N2 * 4) +
+                        dm_align_up(bState) + dm_align_up(bCnt) + dm_align_up((size_t)B * 256 * 8) +
                         dm_gred_ws_bytes(B, N2, N1) + dm_knn_split_prep_bytes(B, N2, k2) + dm_knn_split_ws_bytes(B, N2, N1, k2) +
                         dm_align_up((size_t)B * (N1pad / DM_EMB_COLS + 1) * 8) + dm_p2pfm_ws_bytes(B, N2, max(k1, k2), k2) + dm_p2pfm_xs_bytes(B, N2, k2) + 65536;
     int rc = dm_ws_reserve(ctx, need);
@@ -339,11 +505,22 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
     double* amaxS = (double*)dm_ws_take(ctx, (size_t)B * (N1pad / DM_EMB_COLS + 1) * 8);
     double* Gx = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
     double* Gt = chol ? nullptr : (double*)dm_ws_take(ctx, bG);
+    polar_state* pst = (polar_state*)dm_ws_take(ctx, bState);
+    int32_t* pcnt = (int32_t*)dm_ws_take(ctx, bCnt);
+    double* pvec = (double*)dm_ws_take(ctx, (size_t)B * 256 * 8);
+    const size_t lds_decide = (size_t)k1 * k1 * 8 <= 140 * 1024 ? (size_t)k1 * k1 * 8 : 0;          // T of the step in the LDS when it fits
+    if (lds_decide) { rc = dm_grant_lds(ctx, (const void*)polar_decide_kernel, lds_decide); if (rc) return rc; }
+    int32_t* host_words = nullptr;
+    hipEvent_t host_ev = nullptr;
+    rc = dm_pinned_words(ctx, &host_words, &host_ev);
+    if (rc) return rc;
+    if (!pst || !pcnt || !pvec) return dm_fail(ctx, DM_ENOMEM, "icp: workspace not reserved");
     if (!AT || !BT || !Ccur || !R || !Xa || !Xb || !G || !Ginv || !img || !Tm || !Wm || !n1 || !p21 || !iota || !ones || !amaxS ||
         (!chol && (!Gx || !Gt)))
         return dm_fail(ctx, DM_ENOMEM, "icp: workspace not reserved");
 
     DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * 4, ctx->stream));
+    DM_CHECK_HIP(ctx, hipMemsetAsync(pcnt, 0, bCnt, ctx->stream));
     DM_CHECK_HIP(ctx, hipMemcpyAsync(Ccur, C0, bC, hipMemcpyDeviceToDevice, ctx->stream));
     DM_LAUNCH(ctx, "iota_ones", iota_ones_kernel, dim3((unsigned)(((long long)B * N2 + 255) / 256)), dim3(256), 0, iota, ones, N2, B);
     // iteration independent: Phi2^T (K-major f64) and the Gram matrix Phi2^T Phi2 with its blocked image
@@ -392,29 +569,78 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
             DM_LAUNCH(ctx, "icp_apply_inverse_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutPlainNT>),
                       dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ga, rb, oc, k2, k1, k2);
         }
-        // polar factor of Chat by Newton-Schulz
-        DM_LAUNCH(ctx, "polar_scale", polar_scale_kernel, dim3(B), dim3(256), 0, Xa, k2, k1);
+        // polar factor of Chat: every pair steps by its own schedule (polar_decide), the host stops launching when none is left
+        DM_CHECK_HIP(ctx, hipMemsetAsync(pst, 0, bState, ctx->stream));                      // mode 0, no step taken
         double* xo = Xa;
         double* xn = Xb;
-        for (int q = 0; q < NS_LIFT + NS_POLISH; ++q) {
-            const bool lift = q < NS_LIFT;
+        const dim3 grid_t(dm_cdiv(k1, TN_T) * dm_cdiv(k1, TN_T), 1, B), grid_w(dm_cdiv(k1, NT_T) * dm_cdiv(k1, NT_T), 1, B),
+                   grid_x(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
+        auto launch_xtx = [&]() -> int {
             RowsF64 opx{xo, (long long)k2 * k1, k1, k1};
-            OutPlainTN ot{Tm, (long long)k1 * k1, k1};
-            DM_LAUNCH(ctx, "polar_xtx_tn_f64", (gemm_tn_f64<RowsF64, RowsF64, OutPlainTN>), dim3(dm_cdiv(k1, TN_T) * dm_cdiv(k1, TN_T), 1, B),
-                      dim3(256), 0, opx, opx, ot, k1, k1, k2, pad_to(k2, TN_BK));
-            if (lift) {
-                // W = b T + c T T^T   (T is symmetric)
-                KRowsF64 ta{Tm, (long long)k1 * k1, k1, k1, k1, 0};
-                OutAxpby ow{Tm, Wm, (long long)k1 * k1, k1, NS_B, NS_C};
-                DM_LAUNCH(ctx, "polar_poly_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutAxpby>),
-                          dim3(dm_cdiv(k1, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ta, ta, ow, k1, k1, k1);
+            OutPolarT ot{Tm, (long long)k1 * k1, k1, pst};
+            DM_LAUNCH(ctx, "polar_xtx_tn_f64", (gemm_tn_f64<RowsF64, RowsF64, OutPolarT>), grid_t, dim3(256), 0, opx, opx, ot, k1, k1, k2,
+                      pad_to(k2, TN_BK));
+            return DM_OK;
+        };
+        rc = launch_xtx();
+        if (rc) return rc;
+        // The host learns how many pairs lift one step late (the lagged read): a pair decides to stop lifting on its own, so the T^2
+        // launch follows "some pair lifted at the last step that has been read" and runs one step longer than needed, never shorter
+        // (a pair only ever goes from lifting to not lifting).
+        // A decision costs a launch (8 us for a small map, 19 us at k = 128: a third of a step there): a batch whose pairs keep lifting
+        // pays more for its decisions than the lifts it saves (measured at k = 128, the bench's call from a poor start: 15.0 ms
+        // against 14.1 on the fixed schedule; with L lifts and P polish steps (L + P) decisions + 3 L + 2 P products against 48
+        // products break even near L = 6).  Such a batch continues on the r04 schedule -- lifts up to twelve in all, six
+        // Newton-Schulz steps, no decisions: large maps as soon as any pair lifts at all, small ones when a pair still lifts at its
+        // seventh step.  The others (a fit's result refined: the documented call) take the measured schedule.
+        const int adaptive_lifts = k1 >= 96 ? 0 : 6;
+        bool any_lift = true, fixed = false;
+        for (int q = 0; q < NS_MAX_STEPS; ++q) {
+            if (fixed) {
+                if (q >= NS_LIFT + NS_POLISH) break;
+                const bool lift = q < NS_LIFT;
+                if (lift) {
+                    KRowsF64 ta{Tm, (long long)k1 * k1, k1, k1, k1, 0};
+                    OutAxpby ow{Tm, Wm, (long long)k1 * k1, k1, NS_B, NS_C};
+                    DM_LAUNCH(ctx, "polar_poly_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutAxpby>), grid_w, dim3(256), 0, ta, ta, ow, k1, k1, k1);
+                }
+                KRowsF64 opa{xo, (long long)k2 * k1, k1, k2, k1, 0};
+                KRowsF64 opb{lift ? Wm : Tm, (long long)k1 * k1, k1, k1, k1, 0};
+                OutAxpby on{xo, xn, (long long)k2 * k1, k1, lift ? NS_A : 1.5, lift ? 1.0 : -0.5};
+                DM_LAUNCH(ctx, "polar_update_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutAxpby>), grid_x, dim3(256), 0, opa, opb, on, k2, k1, k1);
+                double* tmp = xo; xo = xn; xn = tmp;
+                if (q + 1 < NS_LIFT + NS_POLISH) {
+                    RowsF64 opx{xo, (long long)k2 * k1, k1, k1};
+                    OutPlainTN ot{Tm, (long long)k1 * k1, k1};
+                    DM_LAUNCH(ctx, "polar_xtx_tn_f64", (gemm_tn_f64<RowsF64, RowsF64, OutPlainTN>), grid_t, dim3(256), 0, opx, opx, ot, k1, k1, k2,
+                              pad_to(k2, TN_BK));
+                }
+                continue;
             }
-            KRowsF64 opa{xo, (long long)k2 * k1, k1, k2, k1, 0};
-            KRowsF64 opb{lift ? Wm : Tm, (long long)k1 * k1, k1, k1, k1, 0};
-            OutAxpby on{xo, xn, (long long)k2 * k1, k1, lift ? NS_A : 1.5, lift ? 1.0 : -0.5};
-            DM_LAUNCH(ctx, "polar_update_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutAxpby>),
-                      dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, opa, opb, on, k2, k1, k1);
+            int32_t* cnt_q = pcnt + ((size_t)it * NS_MAX_STEPS + q) * 2;                     // [pairs that step, pairs that lift]
+            DM_LAUNCH(ctx, "polar_decide", polar_decide_kernel, dim3(B), dim3(256), lds_decide, Tm, k1, pst, pvec, cnt_q, lds_decide ? 1 : 0);
+            DM_CHECK_HIP(ctx, hipMemcpyAsync(host_words, cnt_q, 8, hipMemcpyDeviceToHost, ctx->stream));
+            DM_CHECK_HIP(ctx, hipEventRecord(host_ev, ctx->stream));
+            if (any_lift) {                                   // W = wb T + wc T T^T   (T is symmetric) for the pairs that lift
+                KRowsF64 ta{Tm, (long long)k1 * k1, k1, k1, k1, 0};
+                OutPolarW ow{Tm, Wm, (long long)k1 * k1, k1, pst};
+                DM_LAUNCH(ctx, "polar_poly_nt_f64", (gemm_nt_f64<KRowsF64, KRowsF64, OutPolarW>), grid_w, dim3(256), 0, ta, ta, ow, k1, k1, k1);
+            }
+            {
+                KRowsF64 opa{xo, (long long)k2 * k1, k1, k2, k1, 0};
+                KRowsPolarM opb{KRowsF64{Tm, (long long)k1 * k1, k1, k1, k1, 0}, KRowsF64{Wm, (long long)k1 * k1, k1, k1, k1, 0}, pst};
+                OutPolarX on{xo, xn, (long long)k2 * k1, k1, pst};
+                DM_LAUNCH(ctx, "polar_update_nt_f64", (gemm_nt_f64<KRowsF64, KRowsPolarM, OutPolarX>), grid_x, dim3(256), 0, opa, opb, on, k2, k1, k1);
+            }
             double* tmp = xo; xo = xn; xn = tmp;
+            if (q + 1 < NS_MAX_STEPS) {
+                rc = launch_xtx();                                                           // (the next step's T: the queue stays full while the host waits)
+                if (rc) return rc;
+            }
+            DM_CHECK_HIP(ctx, hipEventSynchronize(host_ev));
+            any_lift = host_words[1] > 0;
+            if (host_words[0] == 0) break;                                                   // every pair was done before this step: X is where xo points
+            if (q == adaptive_lifts && any_lift) fixed = true;
         }
         DM_CHECK_HIP(ctx, hipMemcpyAsync(Ccur, xo, bC, hipMemcpyDeviceToDevice, ctx->stream));
         if (resid && it == nit - 1) {

@@ -62,6 +62,8 @@ struct dm_ctx {
     bool gram_valid = false;
     bool gram_sums_valid = false;  // the basis sums p, s2 behind P, Q in the same block (written by the first evaluation that needs them)
     int n_cu = 0;                // multiProcessorCount of the device
+    int32_t* pinned_words = nullptr;   // 64 ints of page-locked host memory + an event: small device -> host reads that must not stall the
+    hipEvent_t pinned_event = nullptr; // launch queue (dm_pinned_words; the ICP's "have all polar iterations converged?")
     const int32_t* last_flag_counts = nullptr;   // device: the four queue counters (64 ints apart) of the last tile pass with its own merge; null: none
     int last_flag_sets = 0;
 };
@@ -75,6 +77,8 @@ static inline int dm_knob(const char*, int dflt) { return dflt; }
 #endif
 
 int dm_fail(dm_ctx* ctx, int code, const char* fmt, ...);
+// the context's 64 page-locked words and their event, allocated at first use
+int dm_pinned_words(dm_ctx* ctx, int32_t** words, hipEvent_t* ev);
 // allow `func` to be launched with `bytes` of dynamic LDS (> 64 KiB needs an explicit opt-in); remembered per context
 int dm_grant_lds(dm_ctx* ctx, const void* func, size_t bytes);
 

@@ -635,6 +635,33 @@ def test_icp_config2_size_against_reference(eng, fx_cfg2, fx_cfg2_icp):
         assert np.array_equal(_np(maps[name])[0], fx_cfg2_icp["icp_" + name]), name
 
 
+def test_icp_polar_schedule_follows_the_conditioning(eng, fx_cfg2):
+    """r05: the polar iteration's schedule is per batch and per pair.  From a fitted map (the documented call) a pair needs at most a lift
+    or two and a handful of Newton-Schulz steps; from a poor start the batch takes the
+    twelve lifts.  Either way C^T C = I to rounding; from the fitted map C equals the oracle's SVD-based icp_refine."""
+    fx = fx_cfg2
+    k = 40
+    P1, P2 = fx["Phi1"][:, :k].astype(np.float64), fx["Phi2"][:, :k].astype(np.float64)
+    good = orc.p2p_to_fm(fx["knn21"], P1, P2, fx["a2"])                          # a map that already is close to a vertex map's
+    rng = np.random.default_rng(5)
+    poor = np.eye(k) + 0.5 * rng.standard_normal((k, k))
+    launches = {}
+    for name, C0 in (("good", good), ("poor", poor)):
+        eng.profile_kernel("*")
+        C, resid, info = eng.icp(_b(P1), _b(P2), _b(C0), nit=4, return_resid=True)
+        torch.cuda.synchronize()
+        rep = eng.profile_report()
+        eng.profile_kernel("")
+        launches[name] = {n: v[0] for n, v in rep.items() if n.startswith("polar_")}
+        assert int(_np(info)[0]) == 0 and float(_np(resid)[0]) < 1e-13
+        if name == "good":                                   # (from the poor start the iterates' vertex maps sit on near-ties: not a comparison)
+            Co = orc.icp_refine(C0, P1, P2, nit=4)
+            assert np.abs(_np(C)[0] - Co).max() < 1e-8
+    print("polar launches of 4 ICP iterations:", launches)
+    assert launches["good"]["polar_update_nt_f64"] <= 4 * 13                     # (r04: 18 steps per polar factor, always)
+    assert launches["good"]["polar_update_nt_f64"] < launches["poor"]["polar_update_nt_f64"]
+
+
 @pytest.mark.parametrize("k1,k2", [(200, 200), (180, 200), (177, 177), (40, 256)])
 def test_icp_large_k(eng, k1, k2):
     """k2 > 176: the Gram matrix is inverted by Newton-Schulz on the matrix cores instead of the in-LDS Cholesky
