@@ -702,9 +702,11 @@ class MatchEngine:
                                           _ptr(fm), _ptr(bary), _ptr(M), _ptr(info)))
         return (fm, bary, M) if dense else (fm, bary)
 
-    def linear_sum_assignment(self, cost, maximize=False):
+    def linear_sum_assignment(self, cost, maximize=False, defer=False):
         """Optimal assignment of every matrix of the batch `cost` (B,nr,nc) f64 -> col_of_row (B,nr) int32, -1 = unassigned
-        (identical to scipy.optimize.linear_sum_assignment, reference functional_map.py:57,66,78)."""
+        (identical to scipy.optimize.linear_sum_assignment, reference functional_map.py:57,66,78).
+        defer=True: the launches go out and a function is returned that waits for them, raises SciPy's errors and hands back the result
+        (a search is a single workgroup busy for milliseconds: a caller with other work for the GPU queues it on another stream meanwhile)."""
         cost = self._dev(cost, torch.float64, "cost")
         if cost.dim() != 3:
             raise ValueError("linear_sum_assignment expects (B,nr,nc)")
@@ -712,17 +714,20 @@ class MatchEngine:
         out = torch.empty((B, nr), dtype=torch.int32, device=self.device)
         info = torch.empty((B,), dtype=torch.int32, device=self.device)
         self._chk(self.lib.dm_linear_sum_assignment(self.ctx, B, nr, nc, _ptr(cost), 1 if maximize else 0, _ptr(out), _ptr(info)))
-        worst = int(info.max())                              # (the caller reads the result next: this synchronisation is not extra)
-        if worst == 2:
-            raise ValueError("matrix contains invalid numeric entries")          # SciPy's messages
-        if worst == 1:
-            raise ValueError("cost matrix is infeasible")
-        return out
+
+        def finish(keep=cost):                               # (`keep`: the matrix stays alive until the search has read it)
+            worst = int(info.max())                          # (the caller reads the result next: this synchronisation is not extra)
+            if worst == 2:
+                raise ValueError("matrix contains invalid numeric entries")      # SciPy's messages
+            if worst == 1:
+                raise ValueError("cost matrix is infeasible")
+            return out
+        return finish if defer else finish()
 
     def lsa_indicator_ok(self, N1, N2, k1, k2):
         return bool(self.lib.dm_lsa_indicator_ok(self.ctx, int(N1), int(N2), int(k1), int(k2)))
 
-    def lsa_indicator(self, Phi1, Phi2, a1, Cm, dense=None, maximize=True):
+    def lsa_indicator(self, Phi1, Phi2, a1, Cm, dense=None, maximize=True, defer=False):
         """Optimal assignments of the mapped indicators Phi2 C Phi1^T diag(a1) given by their factors (no N2 x N1 matrix is formed: the
         kernel evaluates cost rows from the factors with dm_mapped_indicator's arithmetic, bit for bit) and of the dense (n, N2, N1)
         matrices `dense` in the same launch.  Returns col_of_row (n_ind + n_dense, N2) int32, the indicators first.
@@ -742,12 +747,15 @@ class MatchEngine:
         info = torch.empty((B + nd,), dtype=torch.int32, device=self.device)
         self._chk(getattr(self.lib, "dm_lsa_indicator" + sfx)(self.ctx, B, N1, N2, k1, k2, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(a1), _ptr(Cm), nd, _ptr(dense),
                                                              1 if maximize else 0, _ptr(out), _ptr(info)))
-        worst = int(info.max())
-        if worst == 2:
-            raise ValueError("matrix contains invalid numeric entries")
-        if worst == 1:
-            raise ValueError("cost matrix is infeasible")
-        return out
+
+        def finish(keep=(Phi1, Phi2, a1, Cm, dense)):        # (defer=True: see linear_sum_assignment)
+            worst = int(info.max())
+            if worst == 2:
+                raise ValueError("matrix contains invalid numeric entries")
+            if worst == 1:
+                raise ValueError("cost matrix is infeasible")
+            return out
+        return finish if defer else finish()
 
     def p2p_to_fm_lstsq(self, p21, Phi1, Phi2, k1, k2):
         """argmin_X |Phi2[:, :k2] X - Phi1[p21, :k1]|_F (reference convert.py:51, no mass matrix) -> (B,k2,k1) f64."""

@@ -27,6 +27,32 @@ def _assign(matrix):
     return rows, col[rows]
 
 
+def _assign_early(matrix, slot):
+    """_assign started NOW on a side stream (its own MatchEngine), while the caller goes on with the main stream: returns the
+    function that waits for it and hands back (row_ind, col_ind).  compute_surface_map's three assignments do not depend on each
+    other (functional_map.py:57, 66, 78), and the longest -- the fitted map's indicator, 20 ms on one workgroup -- can start as soon
+    as the fit is done, beside the precise map, ICP and the vertex maps of the refined map."""
+    import torch
+    from .engine import default_engine
+    dev_index = torch.cuda.current_device()
+    main = torch.cuda.current_stream(dev_index)
+    side = _side_streams(dev_index, slot + 1)[slot]
+    dev = matrix.device_tensor() if hasattr(matrix, "device_tensor") else matrix       # (formed on the main stream)
+    if dev.dim() == 2:
+        dev = dev[None]
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dev.record_stream(side)
+        done = default_engine().linear_sum_assignment(dev, maximize=True, defer=True)
+
+    def finish():
+        with torch.cuda.stream(side):
+            col = done()[0].cpu().numpy().astype(np.int64)
+        rows = np.nonzero(col >= 0)[0]
+        return rows, col[rows]
+    return finish
+
+
 _ASSIGN_STACK_LIMIT = 16 << 30     # bytes of dense matrices copied side by side for one assignment launch (288 GB of HBM on the part)
 
 
@@ -105,13 +131,17 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
         compute_extra = True
 
     # The reference interleaves its three Hungarian calls with the precise map and ICP (functional_map.py:57-78).  None of the
-    # three depends on another one's result, so here the matrices are formed first and the assignments run as ONE batched
-    # call (a matrix's shortest-augmenting-path search is sequential: one workgroup each, side by side on the GPU).
+    # three depends on another one's result, and a matrix's shortest-augmenting-path search is sequential (one workgroup, tens of
+    # milliseconds): each starts on its own stream as soon as its matrix exists, beside whatever the main stream does next.
     start_s = time.time()
-    ind_plain = model.mapped_indicator if compute_extra else None               # functional_map.py:57
-    precise = None
+    early = None
     if compute_extra:
+        # (the two assignments that are ready now start on side streams; TIMEIT keeps the reference's printed stages whole)
+        hung_plain = _assign_early(model.mapped_indicator, 0) if not timing else None      # functional_map.py:57
         precise = model._precise_map_device()                                   # functional_map.py:62 (get_precise_map().toarray())
+        hung_prec = _assign_early(precise, 1) if not timing else None           # functional_map.py:66
+        early = (hung_plain, hung_prec) if not timing else None
+        ind_plain = model.mapped_indicator if timing else None
         if timing:
             print("getting precise map took", time.time() - start_s, "seconds")
 
@@ -123,7 +153,10 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
     p2p_21_icp_adjoint, p2p_12_icp_adjoint = model.get_p2p(n_jobs=1)
     p2p_21_icp = (model.mapped_indicator * model.eta[..., None]).argmax(axis=1)
     p2p_12_icp = (model.mapped_indicator * model.eta[..., None]).argmax(axis=0)
-    if compute_extra:
+    if compute_extra and early is not None:
+        hungarian_icp = _assign_many([model.mapped_indicator])[0]               # functional_map.py:78
+        hungarian, hungarian_precise = early[0](), early[1]()
+    elif compute_extra:
         hungarian, hungarian_precise, hungarian_icp = _assign_many([ind_plain, precise, model.mapped_indicator])   # :57, :66, :78
     else:
         hungarian, hungarian_precise = None, None
@@ -201,6 +234,9 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
             raise np.linalg.LinAlgError(f"ICP: polar iteration did not converge (|C^T C - I| = {float(resid.max()):.2e})")
         mapsi = eng.fm_to_p2p(P1, P2, A1d, Ci)
         # ---- every assignment of the group in one launch (a matrix is one workgroup): rows [plain | precise | ICP] when compute_extra
+        # (Measured and dropped, r05: the fitted maps' and the precise maps' assignments started early on streams of their own, as
+        #  compute_surface_map does for one pair -- with two chunks their searches then sit on the compute units the other chunk's
+        #  fit is balanced over, and the call got slower: 396-432 ms against 342.)
         if lr:
             # the indicators by their factors (no N2 x N1 matrices: dm_lsa_indicator), the precise maps dense, in the same launch
             if compute_extra:

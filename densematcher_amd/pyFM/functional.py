@@ -125,8 +125,9 @@ class FunctionalMapping:
                 self.descr2 = np.hstack([self.descr2, sig(self.mesh2, n_descr, landmarks=lmks2, k=self.k2)])
         else:
             raise ValueError(f'Descriptor type "{descr_type}" not implemented')
-        self.descr1 = self.descr1[:, np.arange(0, self.descr1.shape[1], subsample_step)]      # functional.py:333-334
-        self.descr2 = self.descr2[:, np.arange(0, self.descr2.shape[1], subsample_step)]
+        if subsample_step != 1:                                                  # (step 1 selects every column: the arrays as they are)
+            self.descr1 = self.descr1[:, np.arange(0, self.descr1.shape[1], subsample_step)]      # functional.py:333-334
+            self.descr2 = self.descr2[:, np.arange(0, self.descr2.shape[1], subsample_step)]
         return self                                                                          # no normalisation (:336-344)
 
     # ---------------------------------------------------------------- fit (functional.py:352-487)
