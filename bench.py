@@ -286,33 +286,46 @@ def surface_map_workload(args):
                (FunctionalMapping, "fit", "fit (L-BFGS, notebook energy terms)"), (FunctionalMapping, "get_p2p", "vertex maps (2 x 4 maps)"),
                (FunctionalMapping, "_precise_map_device", "precise map"), (FunctionalMapping, "icp_refine", "ICP (10 iterations)"),
                (fmod, "_assign_many", "linear assignment (3 matrices, one batched call)")]
+    import warnings
+
+    def one_call():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res_ = fmod.compute_surface_map(_Duck(v1, f1), _Duck(v2, f2), F1, F2, n_ev=k, compute_extra=True, optimizer="L-BFGS-B",
+                                            fit_params=dict(NOTEBOOK_FIT))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, res_
+    # the call as a user makes it (the assignments overlap the later stages on side streams): this is `value`
+    times = []
+    for rep in range(args.warmup + args.steps):
+        dt, res = one_call()
+        times.append(dt)
+    t = float(np.median(times[args.warmup:]))
+    # per-stage times from a separate instrumented call: every stage bracketed by device synchronisations, the three assignments as one
+    # batched call at the end (the stages add up to more than the clean call: nothing overlaps there)
     saved = [(o, n, getattr(o, n)) for o, n, _ in patched]
     for o, n, label in patched:
         setattr(o, n, timed(label, getattr(o, n)))
-    import warnings
+    fmod.EARLY_ASSIGNMENTS = False
     try:
-        times = []
-        for rep in range(args.warmup + args.steps):
-            stages.clear()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                res = fmod.compute_surface_map(_Duck(v1, f1), _Duck(v2, f2), F1, F2, n_ev=k, compute_extra=True, optimizer="L-BFGS-B",
-                                               fit_params=dict(NOTEBOOK_FIT))
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
+        stages.clear()
+        t_instr, _ = one_call()
         last_stages = dict(stages)
     finally:
+        fmod.EARLY_ASSIGNMENTS = True
         for o, n, fn in saved:
             setattr(o, n, fn)
-    t = float(np.median(times[args.warmup:]))
     model = res[7]
     out = {"metric": "compute_surface_map calls/sec (one pair at a time, notebook parameters)", "value": round(1.0 / t, 4), "unit": "mesh-pairs/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t, 2), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": w["cfg"], "pairs_per_gpu": 1, "N": nu * nv, "D": D, "k": k},
            "stages_ms": {n: round(1e3 * v, 2) for n, v in last_stages.items()},
+           "stages_note": "from a separate instrumented call (%.1f ms: every stage bracketed by device synchronisations, the three assignments as one "
+                          "batched call at the end); in the timed calls the fitted map's and the precise map's assignments run on side streams "
+                          "beside the later stages" % (1e3 * t_instr),
            "fit": {"iterations": int(model.fit_result.nit[0]), "evaluations": int(model.fit_result.nfev[0]), "status": model.fit_result.message[0]},
            "roofline": {"bound": "latency", "kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                         "note": "a single pair cannot fill the chip: this workload reports the latency of the API; the throughput kernels are in the default workload"}}
@@ -502,7 +515,7 @@ def main():
                 summary["config5_stress"] = {q: blk[q] for q in ("value", "unit", "ms_per_step", "launches_per_step", "workspace_bytes")}
                 sm = secondary_surface_map()
                 details["surface_map"] = sm
-                summary["surface_map"] = {"single_call_ms": sm.get("ms_per_call"), "single_stages_ms": sm.get("stages_ms"),
+                summary["surface_map"] = {"single_call_ms": sm.get("ms_per_call"), "single_stages_ms": sm.get("stages_ms"), "single_stages_note": sm.get("stages_note"),
                                           "batched_pairs_per_s": (sm.get("batched") or {}).get("value"),
                                           "batched_s_per_call": (sm.get("batched") or {}).get("s_per_call"),
                                           "batched_pairs_per_call": (sm.get("batched") or {}).get("pairs_per_call"),
@@ -743,7 +756,7 @@ def secondary_surface_map():
         with contextlib.redirect_stdout(buf):
             surface_map_workload(a)
         r = json.loads(buf.getvalue().strip().splitlines()[-1])
-        out = {"value": r["value"], "unit": "calls/s (one pair at a time)", "ms_per_call": r["ms_per_step"], "stages_ms": r["stages_ms"], "fit": r["fit"],
+        out = {"value": r["value"], "unit": "calls/s (one pair at a time)", "ms_per_call": r["ms_per_step"], "stages_ms": r["stages_ms"], "stages_note": r.get("stages_note"), "fit": r["fit"],
                "config": r["config"]}
     except Exception as e:       # informational block
         return {"error": repr(e)}
