@@ -171,7 +171,19 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
             p2p_21_adjoint, p2p_12_adjoint, p2p_21_icp_adjoint, p2p_12_icp_adjoint)
 
 
-def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenbases=None):
+def _on_side_stream(side, tensors, launch):
+    """`launch()` (a deferred MatchEngine call) on the stream `side`, which first waits for the current stream; `tensors` (made on the
+    current stream) are marked as in use there.  Returns what launch returned (the function that waits and hands back the result)."""
+    import torch
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for t_ in tensors:
+            if t_ is not None:
+                t_.record_stream(side)
+        return launch()
+
+
+def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenbases=None, lsa_streams=None):
     """the pairs `idx` of a batch on the CURRENT stream's engine: eigenbases of their 2 len(idx) meshes in one batched solve, then per group
     of equal sizes one device L-BFGS, one call per map stage, all assignments of the group side by side"""
     import torch
@@ -227,21 +239,47 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
         maps0 = eng.fm_to_p2p(P1, P2, A1d, C0d)
         lr = eng.lsa_indicator_ok(P1.shape[1], P2.shape[1], C0d.shape[2], C0d.shape[1])     # assignments from the indicators' factors
         M0 = eng.mapped_indicator(P1, P2, A1d, C0d) if (compute_extra and not lr) else None
+        # A call that runs as ONE chunk has nothing beside which its assignments could run.  Its searches go out as early as their
+        # matrices exist, the long ones first: the fitted maps' on a stream of their own as soon as the fit is done, the ICP maps'
+        # (an ICP that drifted gives the slowest matrix of a batch: 82 ms) on another right after ICP -- which runs BEFORE the precise
+        # map here; the precise maps' (18 ms) close the chunk on this stream (lsa_streams; compute_surface_map does the same for one pair).
+        early = EARLY_ASSIGNMENTS and lr and compute_extra and lsa_streams is not None
+        early_plain = early_icp = None
+        if early:
+            early_plain = _on_side_stream(lsa_streams[0], (P1, P2, A1d, C0d),
+                                          lambda: default_engine().lsa_indicator(P1, P2, A1d, C0d, maximize=True, defer=True))
+
+        def run_icp():
+            Ci_, resid, info = eng.icp(P1, P2, C0d, nit=10, return_resid=True)
+            if int(info.max()) != 0:
+                raise np.linalg.LinAlgError("ICP: Phi2^T Phi2 is not positive definite")
+            if float(resid.max()) > 1e-8:
+                raise np.linalg.LinAlgError(f"ICP: polar iteration did not converge (|C^T C - I| = {float(resid.max()):.2e})")
+            return Ci_
+        Ci = None
+        if early:
+            Ci = run_icp()
+            early_icp = _on_side_stream(lsa_streams[1], (P1, P2, A1d, Ci),
+                                        lambda: default_engine().lsa_indicator(P1, P2, A1d, Ci, maximize=True, defer=True))
         prec = None
         if compute_extra:
             faces = np.ascontiguousarray(np.stack([m.mesh1.facelist for m in g]), dtype=np.int32)
             prec = eng.precise_map(P1, P2, C0d, faces, dense=True)[2]
-        Ci, resid, info = eng.icp(P1, P2, C0d, nit=10, return_resid=True)
-        if int(info.max()) != 0:
-            raise np.linalg.LinAlgError("ICP: Phi2^T Phi2 is not positive definite")
-        if float(resid.max()) > 1e-8:
-            raise np.linalg.LinAlgError(f"ICP: polar iteration did not converge (|C^T C - I| = {float(resid.max()):.2e})")
+        if Ci is None:
+            Ci = run_icp()
         mapsi = eng.fm_to_p2p(P1, P2, A1d, Ci)
         # ---- every assignment of the group in one launch (a matrix is one workgroup): rows [plain | precise | ICP] when compute_extra
-        # (Measured and dropped, r05: the fitted maps' and the precise maps' assignments started early on streams of their own, as
-        #  compute_surface_map does for one pair -- with two chunks their searches then sit on the compute units the other chunk's
-        #  fit is balanced over, and the call got slower: 396-432 ms against 342.)
-        if lr:
+        # (Measured, r05, same box, alternating: with two chunks, every chunk's assignments started early 396-432 ms against 342 -- the
+        #  searches sit on the compute units the other chunk's fit is balanced over --, only the last chunk's 356-391 against 339-373;
+        #  one chunk: 380-383 against 399-404.  So: one chunk only.)
+        if early:
+            cp_ = eng.linear_sum_assignment(prec, maximize=True).cpu().numpy().astype(np.int64)
+            with torch.cuda.stream(lsa_streams[0]):
+                c0_ = early_plain().cpu().numpy().astype(np.int64)
+            with torch.cuda.stream(lsa_streams[1]):
+                ci_ = early_icp().cpu().numpy().astype(np.int64)
+            cols = np.concatenate([c0_, cp_, ci_])
+        elif lr:
             # the indicators by their factors (no N2 x N1 matrices: dm_lsa_indicator), the precise maps dense, in the same launch
             if compute_extra:
                 c_ = eng.lsa_indicator(torch.cat([P1, P1]), torch.cat([P2, P2]), torch.cat([A1d, A1d]), torch.cat([C0d, Ci]), dense=prec,
@@ -331,12 +369,13 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
     if streams is None:
         streams = 2 if B >= 16 else 1
     streams = max(1, min(int(streams), B))
+    dev_index = torch.cuda.current_device()
     if streams == 1:
-        _batch_chunk(models, list(range(B)), out, n_ev, compute_extra, fit_params)
+        lsa_side = _side_streams(dev_index, 2)                                  # the two assignment streams
+        _batch_chunk(models, list(range(B)), out, n_ev, compute_extra, fit_params, lsa_streams=lsa_side)
         return out
     from concurrent.futures import ThreadPoolExecutor
     from .shard import block_range
-    dev_index = torch.cuda.current_device()
     caller = torch.cuda.current_stream(dev_index)
     side = _side_streams(dev_index, streams)
 

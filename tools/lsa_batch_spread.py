@@ -56,3 +56,16 @@ if os.environ.get("LSA_DUMP"):
     nb = min(B, 8)
     os.makedirs("gpurun_out", exist_ok=True)
     np.savez_compressed("gpurun_out/lsa_factors.npz", P1=P1[:nb], P2=P2[:nb], a1=a1[:nb], C0=C0[:nb], Ci=Ci[:nb])
+if os.environ.get("LSA_OUTLIERS"):
+    # the slowest ICP indicators: time in the warm-start mode and in SciPy's order
+    order = np.argsort(t_icp)[::-1][:3]
+    for b in order:
+        line = f"pair {b}: ICP indicator {t_icp[b]:.1f} ms (fitted {t_plain[b]:.1f})"
+        for mode in (2, 1):
+            eng.set_option("lsa_reg", mode)
+            line += f"   lsa_reg={mode}: {timed(lambda: eng.lsa_indicator(P1[b:b + 1], P2[b:b + 1], a1[b:b + 1], Ci[b:b + 1])):.1f} ms"
+        eng.reset_options()
+        s = np.linalg.svd(Ci[b], compute_uv=False)
+        d = np.abs(Ci[b] - C0[b]).max()
+        line += f"   |Ci - C0|max {d:.2f}, sigma(Ci) in [{s.min():.3f}, {s.max():.3f}], |diag Ci| mean {np.abs(np.diag(Ci[b])).mean():.2f} (fitted {np.abs(np.diag(C0[b])).mean():.2f})"
+        print(line)

@@ -27,6 +27,20 @@ ref = None
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for ns in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+        if os.environ.get("AB_EARLY"):            # A/B on the same box: the last chunk's early assignments off / on, alternating
+            from densematcher_amd import functional_map as _f
+            for trial in range(3):
+                line = []
+                for flag in (False, True):
+                    _f.EARLY_ASSIGNMENTS = flag
+                    tt = []
+                    for rep in range(3):
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                        fmod.compute_surface_map_batch(m1, m2, F1s, F2s, n_ev=k, compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(bench.NOTEBOOK_FIT), streams=ns)
+                        torch.cuda.synchronize(); tt.append(time.perf_counter() - t0)
+                    line.append(f"early={flag}: {[round(1e3 * t) for t in tt]}")
+                print(f"streams = {ns} trial {trial}: " + "   ".join(line), flush=True)
+            _f.EARLY_ASSIGNMENTS = True
         ts = []
         for rep in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
