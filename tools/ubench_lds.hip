@@ -274,6 +274,81 @@ static int run_apart(const _Float16* g, float* out, int fill, int ncu) {
     return 0;
 }
 
+// (p), (q): VERDICT r04 #6 -- the TARGET fragments come straight from global memory into the registers the matrix instructions read (a
+// lane's 16 bytes are contiguous in a row-major fp16 row: global_load_dwordx4, requested four iterations ahead into a ring of register
+// sets), only the SOURCE operand travels through the LDS (half the LDS-DMA bytes of a stage).
+//   LAYOUT 0: eight waves x (32 targets x 256 sources): per k-step 8 source fragments (ds_read) x 1 target fragment (global): the target
+//             operand is read once per workgroup, the source fragments by all eight waves;
+//   LAYOUT 1: the product kernel's 2 x 4 arrangement (4 source x 2 target fragments per k-step): every target fragment is requested by
+//             four waves (32 KiB of global requests per stage for 16 KiB of data).
+// Per wave and iteration (two k-steps): 16 matrix instructions, NRD = 16 / 8 ds_read_b128, 2 LDS-DMA, NGL = 2 / 4 global_load_dwordx4.
+template <int LAYOUT, bool WITH_DMA, bool WITH_GL>
+__global__ __launch_bounds__(512, 2) void k_direct(const _Float16* __restrict__ g, float* out, int iters, int fill) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int i = t; i < 65536; i += blockDim.x) smem[i] = fill ? g[i] : (_Float16)0.f;
+    __syncthreads();
+    constexpr int NS = LAYOUT == 0 ? 8 : 4, NT = LAYOUT == 0 ? 1 : 2;      // source / target fragments per k-step
+    f32x16 acc[NS][NT];
+    for (int a = 0; a < NS; ++a) for (int c = 0; c < NT; ++c) for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    typedef __attribute__((address_space(1))) const f16x8 gf16x8;
+    const char* gb = reinterpret_cast<const char*>(g) + (size_t)blockIdx.x * 65536 + lane * 16;
+    f16x8 ring[4][2][NT];                                       // [iteration mod 4][k-step][target fragment]
+    for (int u = 0; u < 4; ++u) for (int h = 0; h < 2; ++h) for (int c = 0; c < NT; ++c)
+        ring[u][h][c] = *(gf16x8*)(gb + ((u * 4 + h * 2 + c) & 15) * 1024 + wave * 16384 % 49152);
+    f16x8 fs[NS];
+    for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const _Float16* B0 = smem + ((i + u) & 3) * 16384 + wave * 512 + lane * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int x = 0; x < NS; ++x) fs[x] = *reinterpret_cast<const f16x8*>(B0 + ((h * NS + x) & 15) * 1024);
+                if (WITH_DMA)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(gb + (((i + u) * 2 + h) & 15) * 1024 + wave * 16384 % 49152),
+                                                     (lptr_t)(smem + ((i + u + 2) & 3) * 16384 + wave * 1024 + h * 512), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < NS; ++st)
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs[st], ring[u][h][tt], acc[st][tt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (WITH_GL) {                                    // the same slot's fragments for four iterations from now
+#pragma unroll
+                    for (int c = 0; c < NT; ++c)
+                        ring[u][h][c] = *(gf16x8*)(gb + ((((i + u + 4) * 4) + h * 2 + c) & 15) * 1024 + wave * 16384 % 49152);
+                    asm volatile("" ::: "memory");
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    float s = 0.f;
+    for (int a = 0; a < NS; ++a) for (int c = 0; c < NT; ++c) s += acc[a][c][(a + c) & 15];
+    out[blockIdx.x * blockDim.x + t] = s + (float)fs[0][0] + (float)ring[0][0][0][0];
+}
+template <int LAYOUT, bool WITH_DMA, bool WITH_GL>
+static int run_direct(const char* name, const _Float16* g, float* out, int fill, int ncu) {
+    const int iters = 20000;
+    CK(hipFuncSetAttribute((const void*)k_direct<LAYOUT, WITH_DMA, WITH_GL>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    k_direct<LAYOUT, WITH_DMA, WITH_GL><<<ncu, 512, 131072>>>(g, out, 2000, fill);
+    CK(hipEventRecord(e0));
+    k_direct<LAYOUT, WITH_DMA, WITH_GL><<<ncu, 512, 131072>>>(g, out, iters, fill);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double ns = 1e6 * ms / iters;
+    const int nrd = LAYOUT == 0 ? 16 : 8, ngl = WITH_GL ? (LAYOUT == 0 ? 2 : 4) : 0, ndma = WITH_DMA ? 2 : 0;
+    printf("%-58s %-6s %8.1f ns/iter  = %7.1f clk @2.4GHz   LDS read %6.1f B/clk/CU  (LDS-DMA %5.1f, to registers %5.1f)   matrix pipe busy %5.1f %% (of 2.4 GHz)\n",
+           name, fill ? "random" : "zeros", ns, ns * 2.4, 8.0 * nrd * 1024 / (ns * 2.4), 8.0 * ndma * 1024 / (ns * 2.4), 8.0 * ngl * 1024 / (ns * 2.4),
+           100.0 * 1024.0 / (ns * 2.4));
+    return 0;
+}
+
 template <int MODE>
 static int run(const char* name, const _Float16* g, float* out, unsigned long long* clk, int waves, int fill, int ncu) {
     const int iters = 20000;
@@ -328,6 +403,14 @@ int main() {
     if (run<13>("(l) 16 MFMA + 4 ds_write_b128 (no memory instr.)", g, out, clk, 8, 0, ncu)) return 1;
     if (run<11>("(j) 12 ds_read_b128 + 4 LDS-DMA (no MFMA)", g, out, clk, 8, 0, ncu)) return 1;
     for (int fill : {0, 1}) for (int d : {0, 8, 12}) if (run_spec(g, out, clk, fill, ncu, d)) return 1;
+    for (int fill : {0, 1}) {
+        if (run_direct<0, false, false>("(p0) 8x1 waves: 16 MFMA + 16 ds_read (no delivery)", g, out, fill, ncu)) return 1;
+        if (run_direct<0, false, true>("(p1) 8x1: 16 MFMA + 16 ds_read + 2 global->VGPR fragments", g, out, fill, ncu)) return 1;
+        if (run_direct<0, true, false>("(p2) 8x1: 16 MFMA + 16 ds_read + 2 LDS-DMA", g, out, fill, ncu)) return 1;
+        if (run_direct<0, true, true>("(p)  8x1: 16 MFMA + 16 ds_read + 2 LDS-DMA + 2 global->VGPR", g, out, fill, ncu)) return 1;
+        if (run_direct<1, false, true>("(q1) 2x4: 16 MFMA + 8 ds_read + 4 global->VGPR fragments", g, out, fill, ncu)) return 1;
+        if (run_direct<1, true, true>("(q)  2x4: 16 MFMA + 8 ds_read + 2 LDS-DMA + 4 global->VGPR", g, out, fill, ncu)) return 1;
+    }
     if (run<4>("(e) 4 LDS-DMA per wave and iteration alone", g, out, clk, 8, 1, ncu)) return 1;
     if (run<4>("(e) 4 LDS-DMA per wave and iteration alone", g, out, clk, 4, 1, ncu)) return 1;
     if (run<6>("(f) 4 global_load_dwordx4 alone (to registers)", g, out, clk, 8, 1, ncu)) return 1;
