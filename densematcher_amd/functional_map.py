@@ -190,17 +190,47 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
     from .engine import default_engine
     from .pyFM.spectral.convert import MappedIndicator, _real_dtype
     eng = default_engine()
-    # ---- eigenbases: every mesh of the chunk in one batched solve (FunctionalMapping.preprocess: functional.py:300-301)
-    all_meshes = [m for i in idx for m in (models[i].mesh1, models[i].mesh2)]
-    type(all_meshes[0]).process_many(all_meshes, [n_ev] * len(all_meshes), robust=True)
-    if after_eigenbases is not None:
-        after_eigenbases()
     groups = {}
     for i in idx:
         model = models[i]
         key = (model.mesh1.n_vertices, model.mesh2.n_vertices, model.mesh1.facelist.shape[0], model.descr1.shape[1],
                str(model.descr1.dtype), str(model.descr2.dtype))
         groups.setdefault(key, []).append(i)
+    # The descriptors do not wait for the eigenbases: a helper thread stacks them (64 MiB per side for 32 pairs of 2048 x 512 fp16)
+    # and uploads them on a stream of its own while this thread drives the eigensolver -- 28 ms of a 64-pair call that the first
+    # chunk otherwise spends between its eigensolve and its fit with the GPU idle (rocprofv3 timeline, tools/batch_timeline.py).
+    import threading
+    tdt = {np.float16: torch.float16, np.float32: torch.float32, np.float64: torch.float64}
+    main_stream = torch.cuda.current_stream()
+    up_stream = _upload_stream(main_stream)
+    staged, stage_err = {}, []
+
+    def stage_descriptors():
+        try:
+            with torch.cuda.stream(up_stream):
+                for key_, gidx_ in groups.items():
+                    g_ = [models[i] for i in gidx_]
+                    fdt_ = np.float16 if (g_[0].descr1.dtype == np.float16 and g_[0].descr2.dtype == np.float16) else np.float32
+                    pair = []
+                    for side in ("descr1", "descr2"):
+                        host = np.ascontiguousarray(np.stack([getattr(m, side) for m in g_]), dtype=fdt_)
+                        pair.append(torch.as_tensor(host).to(eng.device))
+                    staged[key_] = (fdt_, pair[0], pair[1])
+                up_stream.synchronize()
+        except BaseException as e:                      # (re-raised by the chunk's thread)
+            stage_err.append(e)
+    helper = threading.Thread(target=stage_descriptors)
+    helper.start()
+    try:
+        # ---- eigenbases: every mesh of the chunk in one batched solve (FunctionalMapping.preprocess: functional.py:300-301)
+        all_meshes = [m for i in idx for m in (models[i].mesh1, models[i].mesh2)]
+        type(all_meshes[0]).process_many(all_meshes, [n_ev] * len(all_meshes), robust=True)
+    finally:
+        if after_eigenbases is not None:
+            after_eigenbases()
+        helper.join()
+    if stage_err:
+        raise stage_err[0]
     for key, gidx in groups.items():
         g = [models[i] for i in gidx]
         nb = len(g)
@@ -209,14 +239,13 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
         Phi1, Phi2 = st(lambda m: m.mesh1.eigenvectors[:, :n_ev], rdt), st(lambda m: m.mesh2.eigenvectors[:, :n_ev], rdt)
         a1, a2 = st(lambda m: m.mesh1.vertex_masses, rdt), st(lambda m: m.mesh2.vertex_masses, rdt)
         lam1, lam2 = st(lambda m: m.mesh1.eigenvalues[:n_ev], np.float64), st(lambda m: m.mesh2.eigenvalues[:n_ev], np.float64)
-        fdt = np.float16 if (g[0].descr1.dtype == np.float16 and g[0].descr2.dtype == np.float16) else np.float32
-        F1, F2 = st(lambda m: m.descr1, fdt), st(lambda m: m.descr2, fdt)
-        tdt = {np.float16: torch.float16, np.float32: torch.float32, np.float64: torch.float64}
+        fdt, F1d, F2d = staged[key]
+        F1d.record_stream(main_stream); F2d.record_stream(main_stream)
         # ---- fit (FunctionalMapping.fit: the fp32 view of the bases like the reference's fit, functional.py:412-413)
         dev = {"Phi1": eng._dev(Phi1.astype(np.float32), torch.float32, "Phi1"), "Phi2": eng._dev(Phi2.astype(np.float32), torch.float32, "Phi2"),
                "a1": eng._dev(a1.astype(np.float32), torch.float32, "a1"), "a2": eng._dev(a2.astype(np.float32), torch.float32, "a2"),
                "lam1": eng._dev(lam1, torch.float64, "lam1"), "lam2": eng._dev(lam2, torch.float64, "lam2"),
-               "F1": eng._dev(F1, tdt[fdt], "F1"), "F2": eng._dev(F2, tdt[fdt], "F2")}
+               "F1": eng._dev(F1d, tdt[fdt], "F1"), "F2": eng._dev(F2d, tdt[fdt], "F2")}
         fp = dict(w_descr=1e-1, w_lap=1e-3, w_dcomm=1, w_p2p=0, w_stochastic=0, w_ent=0, w_range01=0, w_sumto1=0, w_area=0, w_conformal=0,
                   optinit="zeros", maxiter=1000000, stopping="reference")
         fp.update({k_: v for k_, v in fit_params.items() if k_ in fp})
@@ -402,6 +431,18 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
         for f in [ex.submit(run, c) for c in range(streams)]:
             f.result()                                                    # (re-raises a chunk's exception here)
     return out
+
+
+_UPLOAD_STREAMS = {}
+
+
+def _upload_stream(main_stream):
+    """the stream a chunk's descriptors are uploaded on (one per chunk stream, created once)"""
+    import torch
+    key = (main_stream.device.index, main_stream.cuda_stream)
+    if key not in _UPLOAD_STREAMS:
+        _UPLOAD_STREAMS[key] = torch.cuda.Stream(device=main_stream.device)
+    return _UPLOAD_STREAMS[key]
 
 
 _SIDE_STREAMS = {}
