@@ -294,6 +294,106 @@ struct KRowsPolarM {                   // the step's M: W for a pair that lifts,
     __device__ __forceinline__ double cvt(const double& x, int) const { return x; }
     __device__ __forceinline__ void load8(int b, int row, int k0, double (&v)[8]) const { of(b).load8(b, row, k0, v); }
 };
+// Maps up to 32 x 32 (the documented call: n_ev = 15 ... 30): the WHOLE polar iteration of a pair in one workgroup -- X, T, W in the LDS,
+// the same schedule as polar_decide (scaling by |T|_inf at the first step, lifts while the estimated |T - I|_2 > NS_RHO, Newton-Schulz
+// until |T - I|_inf < 3e-8, then one last step), decisions free of launches: an ICP iteration's ~20 launches become one.  256 threads:
+// thread t owns the entries e = t, t + 256, ... of every 32 x 32 product (ascending sums over the contraction index).
+__global__ __launch_bounds__(256) void polar_small_kernel(const double* __restrict__ Xin, double* __restrict__ Xout, int k2, int k1) {
+    constexpr int LD = 33;
+    __shared__ double Xs[2][32 * LD], Ts[32 * LD], Ws[32 * LD], vec[32], bc[8];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63;
+    const double* Xg = Xin + (long long)b * k2 * k1;
+    for (int e = t; e < 32 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        Xs[0][r * LD + c] = (r < k2 && c < k1) ? Xg[r * k1 + c] : 0.0;
+    }
+    if (t < 32) vec[t] = (t < k1) ? 1.0 + 0.37 * ((t * 7) % 5) : 0.0;
+    __syncthreads();
+    int cur = 0, lifts = 0;
+    bool lifting = true;                                       // (uniform: decided from LDS broadcasts)
+    for (int step = 0; step < NS_MAX_STEPS; ++step) {
+        const double* X = Xs[cur];
+        // T = X^T X
+        for (int e = t; e < 32 * 32; e += 256) {
+            const int a = e >> 5, c = e & 31;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) acc = fma(X[r * LD + a], X[r * LD + c], acc);
+            Ts[a * LD + c] = acc;
+        }
+        __syncthreads();
+        const bool first = step == 0;
+        // wave 0: row sums, power iteration, the step's coefficients -> bc[0..5] = a, b, wb, wc, mode (0 step, 1 last, 2 done), lift
+        if (t < 64) {
+            double rs = 0.0;
+            if (lane < k1) for (int c = 0; c < k1; ++c) rs += fabs(Ts[lane * LD + c] - ((!first && c == lane) ? 1.0 : 0.0));
+            double rinf = rs;
+            for (int off = 32; off > 0; off >>= 1) rinf = fmax(rinf, __shfl_xor(rinf, off));
+            double a_ = 1.0, b_ = 0.0, wb = 0.0, wc = 0.0;
+            int mode = 0, lift = 0;
+            if (first && !(rinf > 0.0)) mode = 2;
+            else {
+                const double inv_s2 = first ? 1.0 / rinf : 1.0;
+                bool lf = lifting;
+                if (lf) {
+                    double v = lane < 32 ? vec[lane] : 0.0, rho = 0.0;
+                    const int nit = first ? NS_POWER0 : NS_POWER;
+                    for (int it = 0; it < nit; ++it) {
+                        double y = 0.0;
+                        if (lane < k1) for (int c = 0; c < k1; ++c) y = fma(Ts[lane * LD + c], __shfl(v, c), y);
+                        const double wv = lane < k1 ? v - inv_s2 * y : 0.0;
+                        double p1 = v * v, p2 = wv * wv;
+                        for (int off = 32; off > 0; off >>= 1) { p1 += __shfl_xor(p1, off); p2 += __shfl_xor(p2, off); }
+                        rho = p1 > 0.0 ? sqrt(p2 / p1) : 0.0;
+                        v = p2 > 0.0 ? wv / sqrt(p2) : v;
+                    }
+                    if (lane < 32) vec[lane] = v;
+                    lf = rho > NS_RHO && lifts < NS_LIFT;
+                }
+                const double is = first ? sqrt(inv_s2) : 1.0, is2 = is * is;
+                if (lf) { a_ = NS_A * is; b_ = 1.0; wb = NS_B * is * is2; wc = NS_C * is * is2 * is2; lift = 1; }
+                else {
+                    a_ = 1.5 * is; b_ = -0.5 * is * is2;
+                    if (!first && rinf < 1e-14) mode = 2;
+                    else if (!first && rinf < 3e-8) mode = 1;
+                }
+            }
+            if (lane == 0) { bc[0] = a_; bc[1] = b_; bc[2] = wb; bc[3] = wc; bc[4] = (double)mode; bc[5] = (double)lift; }
+        }
+        __syncthreads();
+        const double ca = bc[0], cb = bc[1], cwb = bc[2], cwc = bc[3];
+        const int mode = (int)bc[4];
+        const bool lift = bc[5] != 0.0;
+        lifting = lift;
+        lifts += lift ? 1 : 0;
+        if (mode == 2) break;                                  // (uniform)
+        const double* M = Ts;
+        if (lift) {                                            // W = wb T + wc T T
+            for (int e = t; e < 32 * 32; e += 256) {
+                const int a = e >> 5, c = e & 31;
+                double acc = 0.0;
+#pragma unroll 8
+                for (int j = 0; j < 32; ++j) acc = fma(Ts[a * LD + j], Ts[j * LD + c], acc);
+                Ws[a * LD + c] = cwb * Ts[a * LD + c] + cwc * acc;
+            }
+            __syncthreads();
+            M = Ws;
+        }
+        double* Xn = Xs[cur ^ 1];
+        for (int e = t; e < 32 * 32; e += 256) {
+            const int r = e >> 5, c = e & 31;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) acc = fma(X[r * LD + j], M[j * LD + c], acc);
+            Xn[r * LD + c] = ca * X[r * LD + c] + cb * acc;
+        }
+        cur ^= 1;
+        __syncthreads();
+        if (mode == 1) break;
+    }
+    double* Xo = Xout + (long long)b * k2 * k1;
+    for (int e = t; e < k2 * k1; e += 256) { const int r = e / k1, c = e - r * k1; Xo[e] = Xs[cur][r * LD + c]; }
+}
 struct OutAxpby {                      // Xnew = alpha Xold + beta (product)
     const double* xo; double* xn; long long stride_b; int ld; double alpha, beta;
     __device__ __forceinline__ void store(int b, int i, int j, double v) const {
@@ -570,9 +670,14 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
                       dim3(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B), dim3(256), 0, ga, rb, oc, k2, k1, k2);
         }
         // polar factor of Chat: every pair steps by its own schedule (polar_decide), the host stops launching when none is left
-        DM_CHECK_HIP(ctx, hipMemsetAsync(pst, 0, bState, ctx->stream));                      // mode 0, no step taken
         double* xo = Xa;
         double* xn = Xb;
+        const bool small_polar = k1 <= 32 && k2 <= 32;                                       // one launch for the whole iteration
+        if (small_polar) {
+            DM_LAUNCH(ctx, "polar_small", polar_small_kernel, dim3(B), dim3(256), 0, (const double*)Xa, Xb, k2, k1);
+            xo = Xb; xn = Xa;
+        } else {
+        DM_CHECK_HIP(ctx, hipMemsetAsync(pst, 0, bState, ctx->stream));                      // mode 0, no step taken
         const dim3 grid_t(dm_cdiv(k1, TN_T) * dm_cdiv(k1, TN_T), 1, B), grid_w(dm_cdiv(k1, NT_T) * dm_cdiv(k1, NT_T), 1, B),
                    grid_x(dm_cdiv(k2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
         auto launch_xtx = [&]() -> int {
@@ -642,6 +747,7 @@ static int icp_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const TR
             if (host_words[0] == 0) break;                                                   // every pair was done before this step: X is where xo points
             if (q == adaptive_lifts && any_lift) fixed = true;
         }
+        }   // (!small_polar)
         DM_CHECK_HIP(ctx, hipMemcpyAsync(Ccur, xo, bC, hipMemcpyDeviceToDevice, ctx->stream));
         if (resid && it == nit - 1) {
             RowsF64 opx{xo, (long long)k2 * k1, k1, k1};
