@@ -558,12 +558,17 @@ __global__ __launch_bounds__(256) void lsa_tight_lr_kernel(const double* __restr
     }
     if (__any(freecol) && (threadIdx.x & 63) == 0) atomicMax(&tie[b], 1);
 }
+// IN_LDS: the in-degrees and the front live in the LDS (2 nr ints of dynamic LDS): a round of the peel is two scans and three barriers,
+// and the equality graph of a fitted map's indicator is hundreds of rounds deep -- with the counters in global memory every round paid
+// device-memory atomics and round trips (192 matrices of 2048 rows: 5.7 ms, as long as its slowest matrix; r05).
+template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void lsa_acyclic_kernel(const unsigned int* __restrict__ adj, int nr, int nw, int* __restrict__ indeg_ws,
                                                            int32_t* __restrict__ tie) {
+    extern __shared__ int acy_sh[];
     __shared__ int s_removed, s_front;
     const int b = blockIdx.x, t = threadIdx.x;
     const unsigned int* A = adj + (long long)b * nr * nw;
-    int* indeg = indeg_ws + (long long)b * 2 * nr;       // in-degree, then -1 once removed
+    int* indeg = IN_LDS ? acy_sh : indeg_ws + (long long)b * 2 * nr;       // in-degree, then -1 once removed
     int* front = indeg + nr;                              // the rows removed in the current round
     for (int i = t; i < nr; i += 1024) indeg[i] = 0;
     if (t == 0) s_removed = 0;
@@ -708,19 +713,20 @@ static int lsa_run(dm_ctx* ctx, int B, int nr, int nc, const double* dense, int 
             if (!adj || !r4c || !indeg) return dm_fail(ctx, DM_ENOMEM, "assignment: workspace not reserved");
             DM_CHECK_HIP(ctx, hipMemsetAsync(adj, 0, (size_t)B * R * nw * 4, ctx->stream));
             DM_CHECK_HIP(ctx, hipMemsetAsync(r4c, 0xFF, (size_t)B * Cn * 4, ctx->stream));
-            DM_LAUNCH(ctx, "lsa_unique", lsa_rowofcol_kernel, dim3(dm_cdiv(R, 256), B), dim3(256), 0, (const int32_t*)outp, R, Cn, r4c);
+            DM_LAUNCH(ctx, "lsa_unique_rowofcol", lsa_rowofcol_kernel, dim3(dm_cdiv(R, 256), B), dim3(256), 0, (const int32_t*)outp, R, Cn, r4c);
             if (n_lr > 0) {
                 const dim3 gl(dm_cdiv(Cn, 256), dm_cdiv(R, 64), n_lr);
-                if (KP == 16) DM_LAUNCH(ctx, "lsa_unique", lsa_tight_lr_kernel<16>, gl, dim3(256), 0, E2p, P1p, a1p, R, Cn, maximize ? 1 : 0, (const double*)gu,
+                if (KP == 16) DM_LAUNCH(ctx, "lsa_unique_tight", lsa_tight_lr_kernel<16>, gl, dim3(256), 0, E2p, P1p, a1p, R, Cn, maximize ? 1 : 0, (const double*)gu,
                                         (const double*)gv, (const int32_t*)outp, (const int32_t*)r4c, adj, nw, tie);
-                else DM_LAUNCH(ctx, "lsa_unique", lsa_tight_lr_kernel<32>, gl, dim3(256), 0, E2p, P1p, a1p, R, Cn, maximize ? 1 : 0, (const double*)gu,
+                else DM_LAUNCH(ctx, "lsa_unique_tight", lsa_tight_lr_kernel<32>, gl, dim3(256), 0, E2p, P1p, a1p, R, Cn, maximize ? 1 : 0, (const double*)gu,
                                (const double*)gv, (const int32_t*)outp, (const int32_t*)r4c, adj, nw, tie);
             }
             if (n_dense > 0)
-                DM_LAUNCH(ctx, "lsa_unique", lsa_tight_kernel, dim3(gx, n_dense), dim3(256), 0, src.dense, R, Cn, maximize ? 1 : 0, (const double*)(gu + (size_t)n_lr * R),
+                DM_LAUNCH(ctx, "lsa_unique_tight", lsa_tight_kernel, dim3(gx, n_dense), dim3(256), 0, src.dense, R, Cn, maximize ? 1 : 0, (const double*)(gu + (size_t)n_lr * R),
                           (const double*)(gv + (size_t)n_lr * Cn), (const int32_t*)(outp + (size_t)n_lr * R), (const int32_t*)(r4c + (size_t)n_lr * Cn),
                           adj + (size_t)n_lr * R * nw, nw, tie + n_lr);
-            DM_LAUNCH(ctx, "lsa_unique", lsa_acyclic_kernel, dim3(B), dim3(1024), 0, (const unsigned int*)adj, R, nw, indeg, tie);
+            if ((size_t)R * 8 <= 60 * 1024) DM_LAUNCH(ctx, "lsa_unique_acyclic", lsa_acyclic_kernel<true>, dim3(B), dim3(1024), (size_t)R * 8, (const unsigned int*)adj, R, nw, indeg, tie);
+            else DM_LAUNCH(ctx, "lsa_unique_acyclic", lsa_acyclic_kernel<false>, dim3(B), dim3(1024), 0, (const unsigned int*)adj, R, nw, indeg, tie);
             LSA_REG_CPT(0, (const int32_t*)tie)
         } else {
             LSA_REG_CPT(0, (const int32_t*)nullptr)
