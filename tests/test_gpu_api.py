@@ -500,6 +500,19 @@ def test_compute_surface_map_batch_equals_single_calls(fx_cfg1, monkeypatch):
             assert np.array_equal(got[q][slot], want[slot]), (q, slot)
         for slot in (2, 3, 6):
             assert np.array_equal(got[q][slot][0], want[slot][0]) and np.array_equal(got[q][slot][1], want[slot][1]), (q, slot)
+    # r05: the same results whichever way the work is laid over streams -- two chunk streams (helper threads, upload streams), and the
+    # single call with its three assignments in one launch instead of on side streams as soon as their matrices exist
+    import densematcher_amd.functional_map as fmod
+    got2 = compute_surface_map_batch([p[0] for p in pairs], [p[1] for p in pairs], [p[2] for p in pairs], [p[3] for p in pairs], streams=2, **kw)
+    monkeypatch.setattr(fmod, "EARLY_ASSIGNMENTS", False)
+    want0 = compute_surface_map(*pairs[0], **kw)
+    got0 = compute_surface_map_batch([pairs[0][0]], [pairs[0][1]], [pairs[0][2]], [pairs[0][3]], **kw)[0]
+    for q in range(3):
+        for other, mine in ((got2[q], got[q]),) + (((want0, got[0]), (got0, got[0])) if q == 0 else ()):
+            for slot in (0, 1, 4, 5, 10, 11, 12, 13):
+                assert np.array_equal(other[slot], mine[slot]), (q, slot)
+            for slot in (2, 3, 6):
+                assert np.array_equal(other[slot][0], mine[slot][0]) and np.array_equal(other[slot][1], mine[slot][1]), (q, slot)
 
 
 def test_compute_surface_map_from_raw_meshes():
