@@ -58,6 +58,13 @@ def fx_cfg5():
 
 
 @pytest.fixture(scope="session")
+def fx_cfg4():
+    """BASELINE config 4 at full length (ZoomOut 50 -> 200, 150 iterations, N = 2048), one pair, run through the reference
+    (tools/make_golden_r05.py cfg4)"""
+    return load_golden("fx_cfg4.npz")
+
+
+@pytest.fixture(scope="session")
 def fx_cfg2_icp():
     return load_golden("fx_cfg2_icp.npz")
 

@@ -125,6 +125,15 @@ def test_config4_zoomout_full_length_against_oracle(eng):
     assert np.abs(Cz[0].cpu().numpy() - Co).max() < 1e-9
 
 
+def test_config4_zoomout_full_length_against_reference(eng, fx_cfg4):
+    """r05: config 4 at its full length against the REFERENCE's own run (tests/golden/fx_cfg4.npz: zoomout_refine 50 -> 200, 150
+    iterations, on the reference's spectra): the final vertex map bit-exact, C within 1e-9"""
+    fx = fx_cfg4
+    Cz, pz = eng.zoomout(fx["Phi1"][None], fx["Phi2"][None], fx["a2"][None], fx["C0"][None], nit=int(fx["nit"]), step=1, return_p2p=True)
+    assert np.array_equal(pz[0].cpu().numpy(), fx["p21_zo"])
+    assert np.abs(Cz[0].cpu().numpy() - fx["C_zo"]).max() < 1e-9
+
+
 def test_config4_zoomout_batch32(eng):
     """config 4 at its per-GPU batch (32 pairs): every pair's trajectory is independent of its batch"""
     B = 32

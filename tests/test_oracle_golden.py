@@ -238,3 +238,13 @@ def test_shape_and_orientation_terms_against_reference(fx_cfg1, fx_cfg1_shape_te
         ops.append(ft[f"orient_t_op{which}"])
     e, g = orc.dcomm_energy_grad(C, ops[0], ops[1])
     assert abs(e - float(ft["orient_E"])) <= 1e-11 * abs(e) and np.abs(g - ft["orient_G"]).max() <= 1e-10 * np.abs(g).max()
+
+
+def test_zoomout_config4_full_length_against_reference(fx_cfg4):
+    """r05: the reference's own zoomout_refine 50 -> 200 (150 iterations, N = 2048) -- the oracle follows it to the end: same final
+    vertex map, C to 1e-9"""
+    fx = fx_cfg4
+    phi1, phi2, a2 = _f64(fx, "Phi1", "Phi2", "a2")
+    C, p21 = orc.zoomout_refine(fx["C0"], phi1, phi2, nit=int(fx["nit"]), step=1, a2=a2, return_p2p=True)
+    assert np.array_equal(p21, fx["p21_zo"])
+    assert np.abs(C - fx["C_zo"]).max() < 1e-9

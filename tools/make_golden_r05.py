@@ -12,6 +12,7 @@ BASELINE config-5 size.
         knn21 .. ind12 (and f64_*)          FM_to_p2p + the indicator arg-maxes on C_fit (on C_f64)  (convert.py:134-144, functional_map.py:49-50)
         C_from_p2p                          p2p_to_FM(knn21) with A2 (convert.py:39-51)
     Descriptors are regenerated from seeds by the tests (sha256 pinned in the file).
+    fx_cfg4.npz   configs[3] at full length, ONE pair (python tools/make_golden_r05.py cfg4): see case_cfg4
 Run time here: about ten minutes, 9 GB.
 """
 import os
@@ -58,5 +59,26 @@ def main():
           " ind21==perm:", (i21 == perm).mean())
 
 
+def case_cfg4():
+    """fx_cfg4.npz: BASELINE config 4 at its full length for one pair, run through the reference: N = 2048 (64 x 32 torus and its perturbed
+    copy), the reference's spectra (k = 200, eigenvectors and masses rounded to float32 as stored), zoomout_refine 50 -> 200, step 1,
+    150 iterations from C0 = I + 0.02 N(0, 1) (refine/zoomout.py:47-115 through the harness repair of SURVEY.md 0.4): final C and p21."""
+    nu, nv, k0, k = 64, 32, 50, 200
+    t0 = time.time()
+    v1, f1 = mg.synth.torus_mesh(nu, nv)
+    v2, f2 = mg.synth.torus_mesh(nu, nv, perturb=0.08, seed=1)
+    m1, (phi1, lam1, a1) = mg.processed_mesh(v1, f1, k)
+    m2, (phi2, lam2, a2) = mg.processed_mesh(v2, f2, k)
+    rng = np.random.default_rng(4)
+    C0 = np.eye(k0) + 0.02 * rng.standard_normal((k0, k0))
+    C_zo, p21_zo = mg.ref_zoomout(C0, m1, m2, nit=k - k0, step=1)
+    np.savez_compressed(os.path.join(OUT, "fx_cfg4.npz"), Phi1=phi1, Phi2=phi2, a1=a1, a2=a2, C0=C0, C_zo=C_zo, p21_zo=p21_zo.astype(np.int32),
+                        k0=k0, k=k, nit=k - k0)
+    print("cfg4 written in", time.time() - t0, "s; C", C_zo.shape, "distinct targets", len(np.unique(p21_zo)))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg4":
+        case_cfg4()
+    else:
+        main()
