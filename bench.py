@@ -811,10 +811,10 @@ def surface_map_batch_rate(B):
         torch.cuda.synchronize()
         return r, time.perf_counter() - t0
     # the figure: the call as a user makes it (its default: two chunk streams), no instrumentation; two warm-ups (the first call of a
-    # process creates the chunk streams' engines and their workspaces), then the median of five
+    # process creates the chunk streams' engines and their workspaces), then the median of seven
     call(); call()
     times = []
-    for rep in range(5):
+    for rep in range(7):
         res, dt = call()
         times.append(dt)
     t_call = float(np.median(times))
