@@ -680,7 +680,18 @@ class MatchEngine:
                 break
         return lam, Phi, resid, rounds
 
-    def precise_map(self, Phi1, Phi2, Cm, faces1, dense=False):
+    def scratch(self, name, shape, dtype):
+        """a device tensor that belongs to this engine and is handed out again by the next call with the same name, shape and dtype: for
+        large intermediates of a call that never reach the user (a gigabyte of precise maps per chunk: allocated per call, the caching
+        allocator of a process with other tensors around kept going back to hipMalloc, which stalls every stream)"""
+        cache = self.__dict__.setdefault("_scratch", {})
+        t = cache.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+            cache[name] = t
+        return t
+
+    def precise_map(self, Phi1, Phi2, Cm, faces1, dense=False, scratch=False):
         """Barycentric projection of every vertex of mesh 2 onto the faces of mesh 1 in the spectral embedding (reference
         get_precise_map, functional.py:221-251).  Returns (face_match (B,N2) int32, bary (B,N2,3) f64[, dense (B,N2,N1) f64])."""
         sfx, Phi1, Phi2 = self._reals(Phi1, Phi2)
@@ -696,7 +707,9 @@ class MatchEngine:
             raise ValueError("precise_map: face indices must lie in [0, N1)")
         fm = torch.empty((B, N2), dtype=torch.int32, device=self.device)
         bary = torch.empty((B, N2, 3), dtype=torch.float64, device=self.device)
-        M = torch.empty((B, N2, N1), dtype=torch.float64, device=self.device) if dense else None
+        # (scratch=True: the dense matrices live in this engine's scratch and are overwritten by its next such call)
+        M = (self.scratch("precise_dense", (B, N2, N1), torch.float64) if scratch else
+             torch.empty((B, N2, N1), dtype=torch.float64, device=self.device)) if dense else None
         info = torch.empty((B,), dtype=torch.int32, device=self.device)
         self._chk(getattr(self.lib, "dm_precise_map" + sfx)(self.ctx, B, N1, N2, k1, k2, nf, _ptr(Phi1), ld1, _ptr(Phi2), ld2, _ptr(Cm), _ptr(faces1),
                                           _ptr(fm), _ptr(bary), _ptr(M), _ptr(info)))

@@ -208,7 +208,7 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
     def stage_descriptors():
         try:
             with torch.cuda.stream(up_stream):
-                for key_, gidx_ in groups.items():
+                for gno_, (key_, gidx_) in enumerate(groups.items()):
                     g_ = [models[i] for i in gidx_]
                     fdt_ = np.float16 if (g_[0].descr1.dtype == np.float16 and g_[0].descr2.dtype == np.float16) else np.float32
                     pair = []
@@ -220,7 +220,7 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
                         hv = host.numpy()
                         for q_, m in enumerate(g_):
                             hv[q_] = getattr(m, side)            # (converts to fdt_ where the caller's dtype differs)
-                        pair.append(host.to(eng.device, non_blocking=True))
+                        pair.append(eng.scratch("%s_%d" % (side, gno_), tuple(host.shape), tdt[fdt_]).copy_(host, non_blocking=True))
                     staged[key_] = (fdt_, pair[0], pair[1])
                 up_stream.synchronize()
         except BaseException as e:                      # (re-raised by the chunk's thread)
@@ -299,7 +299,7 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
         prec = None
         if compute_extra:
             faces = np.ascontiguousarray(np.stack([m.mesh1.facelist for m in g]), dtype=np.int32)
-            prec = eng.precise_map(P1, P2, C0d, faces, dense=True)[2]
+            prec = eng.precise_map(P1, P2, C0d, faces, dense=True, scratch=True)[2]       # (never leaves this function)
         if Ci is None:
             Ci = run_icp()
         mapsi = eng.fm_to_p2p(P1, P2, A1d, Ci)
