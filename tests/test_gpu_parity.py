@@ -662,6 +662,23 @@ def test_icp_polar_schedule_follows_the_conditioning(eng, fx_cfg2):
     assert launches["good"]["polar_update_nt_f64"] < launches["poor"]["polar_update_nt_f64"]
 
 
+@pytest.mark.parametrize("k1,k2", [(12, 20), (15, 15), (32, 32), (7, 31), (1, 5)])
+def test_icp_small_maps_one_launch_polar(eng, fx_cfg1, k1, k2):
+    """maps up to 32 x 32 (the documented call's sizes) take their polar factors in one workgroup launch (polar_small_kernel), square
+    and rectangular: C^T C = I to rounding and C equal to the oracle's SVD-based icp_refine; a batch of two gives each pair its own result"""
+    fx = fx_cfg1
+    P1, P2 = fx["Phi1"][:, :k1].astype(np.float64), fx["Phi2"][:, :k2].astype(np.float64)
+    rng = np.random.default_rng(k1 * 37 + k2)
+    C0 = np.eye(k2, k1) + 0.05 * rng.standard_normal((k2, k1))
+    C1 = np.eye(k2, k1) + 0.3 * rng.standard_normal((k2, k1))
+    C, resid, info = eng.icp(np.stack([P1, P1]), np.stack([P2, P2]), np.stack([C0, C1]), nit=3, return_resid=True)
+    assert int(_np(info).max()) == 0 and float(_np(resid).max()) < 1e-13
+    Co = orc.icp_refine(C0, P1, P2, nit=3)
+    assert np.abs(_np(C)[0] - Co).max() < 1e-8
+    Cs = eng.icp(_b(P1), _b(P2), _b(C1), nit=3)
+    assert np.array_equal(_np(Cs)[0], _np(C)[1])
+
+
 @pytest.mark.parametrize("k1,k2", [(200, 200), (180, 200), (177, 177), (40, 256)])
 def test_icp_large_k(eng, k1, k2):
     """k2 > 176: the Gram matrix is inverted by Newton-Schulz on the matrix cores instead of the in-LDS Cholesky
