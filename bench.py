@@ -421,31 +421,43 @@ def main():
     extra = {}
 
     models = kernel_models(N, max(D, 1), k, B, eng)
+    # Every workload goes through the library's sharded entry point (densematcher_amd/shard.py: run_sharded): this rank holds block
+    # [rank B, (rank + 1) B) of a world x B batch (weak scaling: no rank builds the whole batch), results stay on the rank's device
+    # (gather=False), no data-path collective.  With one rank this is the plain engine call.
+    from densematcher_amd import shard
+    blk = (rank * B, (rank + 1) * B, world * B)
+
+    def sharded(method, local, **kw):
+        return shard.run_sharded(method, local, lambda: eng, rank, world, gather=False, block=blk, **kw)
     if args.workload in ("fmap", "stress"):
         def step():
-            return eng.match(dev, k=k)
+            return sharded("match", dev, k=k)
         split = eng.p2p_split_active(N, N, k)
         maps_kernel = ("simnn4_f16_mfma" if split >= 2 else "simnn2_f16_mfma") if split else "gred_f64"
         dtype = "f16" if split else "f64"
     elif args.workload == "simnn":
+        sim_in = {"F2": dev["F2"], "F1": dev["F1"]}
+
         def step():
-            return eng.simnn(dev["F2"], dev["F1"])
+            return sharded("simnn", sim_in)["nn21"]
         dtype = "f16"
     elif args.workload == "icp":
         gen = torch.Generator(device=eng.device).manual_seed(1 + rank)
         C0 = torch.eye(k, dtype=torch.float64, device=eng.device).repeat(B, 1, 1) \
             + 0.01 * torch.randn(B, k, k, dtype=torch.float64, device=eng.device, generator=gen)
+        icp_in = {"Phi1": dev["Phi1"], "Phi2": dev["Phi2"], "C0": C0}
 
         def step():
-            return eng.icp(dev["Phi1"], dev["Phi2"], C0, nit=10)
+            return sharded("icp", icp_in, nit=10)["C"]
         dtype = "f16"
         models.update(refine_models("icp", N, k, B, eng))
     else:
         k0, nit = 50, 150
         C0 = torch.eye(k0, dtype=torch.float64, device=eng.device).repeat(B, 1, 1)
+        zo_in = {"Phi1": dev["Phi1"], "Phi2": dev["Phi2"], "a2": dev["a2"], "C0": C0}
 
         def step():
-            return eng.zoomout(dev["Phi1"], dev["Phi2"], dev["a2"], C0, nit=nit, step=1)
+            return sharded("zoomout", zo_in, nit=nit, step=1)["C"]
         dtype = "f16"
         models.update(refine_models("zoomout", N, k, B, eng))
 
@@ -495,7 +507,7 @@ def main():
         if not args.no_secondary:
             c3 = secondary_simnn(eng, rank, barrier, max_over_ranks, world)
             summary["config3_simnn"] = {q: c3[q] for q in ("value", "unit", "ms_per_step", "kernel", "avg_launch_ms", "achieved", "peak", "frac",
-                                                           "frac_of_measured_peak_random_operands")}
+                                                           "frac_of_step", "frac_of_measured_peak_random_operands")}
             details["config3_simnn"] = c3
             if world == 1:
                 hard = secondary_hard(eng, host, dev, k, barrier)
@@ -522,7 +534,8 @@ def main():
                                           "batched_streams": (sm.get("batched") or {}).get("streams"),
                                           "robust_laplacian": "restated (opt-in: the robust_laplacian wheel is not installed on the box)",
                                           "error": sm.get("error") or (sm.get("batched") or {}).get("error")}
-    # ---- the line: the contract's keys first, then the figures a truncated tail must not lose, the long tables last
+    # ---- the line.  The driver keeps the LAST 2 000 characters of it: the contract's keys come first, the long tables (`details`) in the
+    # middle, and `roofline`, `cpu_baseline` and a compact `summary` (every secondary figure, <= 1 500 characters) at the very end
     out = {
         "metric": "mesh-pairs/sec at N=2048 D=768 k=128" if args.workload == "fmap" else f"mesh-pairs/sec ({args.workload})",
         "value": round(value, 2), "unit": "mesh-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -534,22 +547,58 @@ def main():
                    "basis_dtype": str(host["Phi1"].dtype) if "Phi1" in host else None,
                    "parallelism": f"pairs sharded over {world} GPU(s), one process per GPU, no data-path collective",
                    "process_group": (backend if dist is not None else None), "process_group_size": group_size},
-        "roofline": roof,
-        "summary": summary,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.workload, host, k)
     out["timing"] = {"blocks": N_BLOCKS, "reported": "median block of exactly `steps` steps, each block bracketed by barrier + synchronize (max over ranks per block)",
-                     "blocks_ms_per_step": [round(1e3 * b_ / args.steps, 4) for b_ in blocks], "blocks_ms_per_step_by_rank": per_rank}
+                     "blocks_ms_per_step": [round(1e3 * b_ / args.steps, 4) for b_ in blocks], "blocks_ms_per_step_by_rank": per_rank,
+                     "kernel_ms_per_step_note": "kernel_ms_per_step in `roofline` is a sum of single-kernel HIP-event brackets taken after the timed "
+                                                "region: the brackets add about 2 %, so it can exceed ms_per_step"}
     if pcie:
         out["pcie_inclusive"] = pcie
     if args.workload == "fmap" and not args.batch and rank == 0:
         out["parity"] = parity_block(eng)
+    details["summary_long"] = summary
     out["details"] = details
+    out["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, host, k)
+    out["summary"] = compact_summary(summary, pcie)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def compact_summary(summary, pcie):
+    """The secondary figures in <= 1 500 characters, printed as the LAST key of the line (the driver keeps the end of it).  Short keys:
+    c3 = config 3 (feature NN), c4 = config 4 (ZoomOut 50 -> 200), c5 = config 5 (N = 8192 stress), sm = compute_surface_map."""
+    def rnd(x, n=4):
+        return round(x, n) if isinstance(x, float) else x
+    s = {}
+    c3 = summary.get("config3_simnn")
+    if c3:
+        s["c3"] = {"pairs_s": rnd(c3.get("value"), 1), "step_ms": rnd(c3.get("ms_per_step")), "kernel_ms": rnd(c3.get("avg_launch_ms")),
+                   "frac": rnd(c3.get("frac")), "frac_step": rnd(c3.get("frac_of_step")),
+                   "frac_meas_peak": rnd(c3.get("frac_of_measured_peak_random_operands"))}
+    for key, short in (("config4_zoomout", "c4"), ("config5_stress", "c5"), ("icp", "icp")):
+        blk = summary.get(key)
+        if blk:
+            s[short] = {"pairs_s": rnd(blk.get("value"), 1), "step_ms": rnd(blk.get("ms_per_step"), 3), "launches": blk.get("launches_per_step")}
+    sm = summary.get("surface_map")
+    if sm:
+        s["sm"] = {"single_ms": rnd(sm.get("single_call_ms"), 2), "batch_pairs_s": rnd(sm.get("batched_pairs_per_s"), 1),
+                   "batch_s_per_call": rnd(sm.get("batched_s_per_call")), "pairs_per_call": sm.get("batched_pairs_per_call"),
+                   "robust_laplacian": "restated"}
+        if sm.get("error"):
+            s["sm"]["error"] = str(sm["error"])[:120]
+    d64 = summary.get("config2_distinct64")
+    if d64:
+        s["c2_distinct64"] = {"pairs_s": rnd(d64.get("value"), 1), "step_ms": rnd(d64.get("ms_per_step"))}
+    hard = summary.get("config2_hard_pairs_per_s")
+    if hard:
+        s["c2_hard_pairs_s"] = {k_: rnd(v, 0) for k_, v in hard.items()}
+    if pcie:
+        s["pcie_inclusive_pairs_s"] = rnd(pcie.get("value"), 1)
+    return s
 
 
 def pcie_inclusive(eng, host, dev, k, barrier, steps=10):
@@ -898,6 +947,7 @@ def secondary_simnn(eng, rank, barrier, max_over_ranks, world):
             "kernel": "simnn_f16_mfma", "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops, "achieved": round(ach, 3),
             "peak": PEAK_TFLOPS["f16"], "unit_roofline": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS["f16"], 4),
             "frac_of_measured_peak_random_operands": round(ach / pk["mfma_f16_random_operands_tflops"], 4),
+            "frac_of_step": round(flops / (elapsed / steps) / 1e12 / PEAK_TFLOPS["f16"], 4),   # the same flops over the whole step (kernel + merge + exact repair)
             "traffic": traffic, "traffic_file": ("profiles/" + tfile) if tfile else None}
 
 

@@ -605,6 +605,9 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     DM_REQUIRE(ctx, Phi1 && Phi2 && mass1 && A && Bm && lam1 && lam2 && weights && x0 && f_out, "null pointer");
     DM_REQUIRE(ctx, ld1 >= k1 && ld2 >= k2, "eigenvector row stride smaller than k");
     DM_REQUIRE(ctx, dm_fmap_fit_fused_ok(k1, k2, weights, 0), "fit_fused: maps up to 32 x 32 with w_p2p / w_ent / w_range01 / w_sumto1 (and w_descr, w_lap) only");
+    // (this entry point takes no operator lists: a caller that wants the commutativity term -- w_dcomm with operators -- goes through
+    //  dm_fmap_fit_steps; accepting the weight here would drop the term silently)
+    DM_REQUIRE(ctx, weights[2] == 0.0, "fit_fused: w_dcomm (weights[2]) must be 0 -- the fused evaluation has no commutativity term");
     const bool eval_only = maxfun <= 0;
     DM_REQUIRE(ctx, eval_only ? (grad_out != nullptr) : (x_out && info_out && m > 0 && m <= 64), "fit_fused: outputs");
     for (int q = 0; q < 10; ++q) DM_REQUIRE(ctx, weights[q] >= 0.0, "weights must be >= 0");

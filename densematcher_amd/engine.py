@@ -368,7 +368,7 @@ class MatchEngine:
         k2 = Bm.shape[1]
         _, N1, ld1 = P1.shape
         _, N2, ld2 = P2.shape
-        w = self._weight_array(weights)
+        w = self._weight_array(dict(weights, w_dcomm=0.0))      # (reached only without operator lists: the commutativity term is off)
         x0d = self._dev(x0, torch.float64, "x0")
         xo = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
         fo = torch.empty((B,), dtype=torch.float64, device=self.device)
@@ -400,7 +400,7 @@ class MatchEngine:
         D = A.shape[2]
         _, N1, ld1 = P1.shape
         _, N2, ld2 = P2.shape
-        w = self._weight_array(weights)
+        w = self._weight_array(dict(weights, w_dcomm=0.0))
         energy = torch.empty((B,), dtype=torch.float64, device=self.device)
         grad = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
         self._chk(self.lib.dm_fmap_fit_fused(self.ctx, B, N1, N2, k1, k2, D, _ptr(P1), ld1, _ptr(P2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1),

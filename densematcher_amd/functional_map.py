@@ -102,9 +102,30 @@ def _assign_many(matrices):
     return out
 
 
+class _robust_backend_for_call:
+    """robust_backend='restated' | 'wheel' for the duration of one call (None: whatever laplacian.set_robust_backend / the environment say)"""
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        from .pyFM.mesh import laplacian
+        self.prev = laplacian.robust_backend()
+        if self.name is not None:
+            laplacian.set_robust_backend(self.name)
+
+    def __exit__(self, *exc):
+        from .pyFM.mesh import laplacian
+        laplacian.set_robust_backend(self.prev)
+        return False
+
+
 def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, optimizer="fmin_l_bfgs_b", descr_type="neural",
-                        maxiter=100000, optimize_p2p=False, fit_params=None):
+                        maxiter=100000, optimize_p2p=False, fit_params=None, robust_backend=None):
     '''
+    robust_backend (not in the reference): the Laplacians are built with robust=True like the reference's (functional.py:294-295), which
+        calls the `robust_laplacian` wheel.  Where that wheel is not installed the call raises ImportError -- unless
+        robust_backend="restated" (or laplacian.set_robust_backend / DENSEMATCHER_AMD_ROBUST_LAPLACIAN) opts into this package's own
+        implementation of the same construction, whose parity with the wheel is unpinned (DESIGN.md section 5).
     Returns (reference functional_map.py:81):
         p2p_21, p2p_12, hungarian, hungarian_precise, p2p_21_icp, p2p_12_icp, hungarian_icp, model, mesh1, mesh2,
         p2p_21_adjoint, p2p_12_adjoint, p2p_21_icp_adjoint, p2p_12_icp_adjoint
@@ -121,7 +142,8 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
         process_params = {'n_ev': (n_ev, n_ev), 'n_descr': 16 if descr_type == "HKS" else 2048, 'landmarks': None,
                           'descr_type': descr_type, 'subsample_step': 1}
     model = FunctionalMapping(mesh1, mesh2, partial=False, optimizer=optimizer)
-    model.preprocess(**process_params, verbose=False)
+    with _robust_backend_for_call(robust_backend):
+        model.preprocess(**process_params, verbose=False)
     fit_params = dict(fit_params or {})
     fit_params.pop("verbose", None)
     model.fit(**fit_params)
@@ -167,6 +189,7 @@ def compute_surface_map(mesh1_t, mesh2_t, c1, c2, n_ev=50, compute_extra=False, 
         hungarian_icp = _assign_many([model.mapped_indicator])[0]               # functional_map.py:78
     if timing:
         print("Hungarian for vanilla, precise and icp took", time.time() - start_s, "seconds")
+    model.mesh1.release_device_rows(); model.mesh2.release_device_rows()       # (views of the assembly's batch arrays: not kept alive by a result)
     return (p2p_21, p2p_12, hungarian, hungarian_precise, p2p_21_icp, p2p_12_icp, hungarian_icp, model, model.mesh1, model.mesh2,
             p2p_21_adjoint, p2p_12_adjoint, p2p_21_icp_adjoint, p2p_12_icp_adjoint)
 
@@ -356,7 +379,7 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
 
 
 def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_extra=False, optimizer="fmin_l_bfgs_b", descr_type="neural",
-                              maxiter=100000, optimize_p2p=False, fit_params=None, streams=None):
+                              maxiter=100000, optimize_p2p=False, fit_params=None, streams=None, robust_backend=None):
     """compute_surface_map for a list of mesh pairs: returns the list of the 14-tuples compute_surface_map returns, each equal to the
     single call's (same kernels, and every kernel's result for a pair is independent of the batch it is in).  No counterpart in
     the reference (it matches one pair per call, functional_map.py:9-81): this is its documented call with the batch dimension the
@@ -369,7 +392,18 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
     fills the vector ALUs, another's eigensolver (a chain of a thousand small launches), linear assignments (a workgroup per matrix,
     latency bound) and host-side bookkeeping run beside it.  Default: 2 chunks from 16 pairs (measured at 64 pairs: 500 ms on one stream, 455 on two, 495 on three, 580 on four -- a
     chunk's thousand small launches wait for register space behind the other chunks' fit kernels).  A pair's results do
-    not depend on the chunking."""
+    not depend on the chunking.
+    robust_backend: as for compute_surface_map.  Two host threads may call concurrently when each calls on its own HIP stream."""
+    with _robust_backend_for_call(robust_backend):
+        out = _compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev, compute_extra, optimizer, descr_type, maxiter, optimize_p2p,
+                                         fit_params, streams)
+    for t in out:
+        if t is not None:
+            t[8].release_device_rows(); t[9].release_device_rows()
+    return out
+
+
+def _compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev, compute_extra, optimizer, descr_type, maxiter, optimize_p2p, fit_params, streams):
     import torch
     assert descr_type == "neural", "the batched call takes network descriptors (descr_type='neural')"
     B = len(meshes1_t)
@@ -470,11 +504,16 @@ def _upload_stream(main_stream):
 _SIDE_STREAMS = {}
 
 
-def _side_streams(dev_index, n):
-    """the chunk streams of compute_surface_map_batch, created once per device (every stream brings a MatchEngine with its own workspace
-    arena: default_engine() keys on the stream)"""
+def _side_streams(dev_index, n, caller=None):
+    """the chunk / assignment streams of compute_surface_map[_batch], created once per (device, caller's stream) (every stream brings a
+    MatchEngine with its own workspace arena: default_engine() keys on the stream).  Keyed on the caller's stream as well (ADVICE
+    r05): two host threads that call on their own streams get their own side streams, upload streams (keyed on the chunk stream) and
+    page-locked buffers (ditto) -- one dm_ctx is never driven from two threads.  Two threads on the SAME stream are not supported (nor
+    are they by the one-engine-per-(device, stream) design anywhere else in the package)."""
     import torch
-    have = _SIDE_STREAMS.setdefault(dev_index, [])
+    if caller is None:
+        caller = torch.cuda.current_stream(dev_index)
+    have = _SIDE_STREAMS.setdefault((dev_index, caller.cuda_stream), [])
     while len(have) < n:
         have.append(torch.cuda.Stream(device=dev_index))
     return have[:n]

@@ -30,6 +30,7 @@ class TriMesh:
             raise NotImplementedError("mesh file loading is outside the matching path: pass (vertices, faces)")
         self._W = None
         self._W_dev = None               # (cols (N, nnz), w (N, nnz)) device tensors of the last device assembly: W is built from them on demand
+        self._W_recipe = None            # robust flag of a device assembly whose rows were released (release_device_rows): W is re-assembled on the host on demand
         self._A = None
         self._mass = None                # lumped masses of the last device assembly: A (CSR) is built from them on demand
         self._L = None
@@ -51,7 +52,7 @@ class TriMesh:
         elif vertlist.shape[1] != 3:
             raise ValueError('Vertex list requires 3D coordinates')
         self._vertlist = vertlist.copy()
-        self._W = self._W_dev = self._A = self._mass = self._L = self.eigenvalues = self.eigenvectors = None
+        self._W = self._W_dev = self._W_recipe = self._A = self._mass = self._L = self.eigenvalues = self.eigenvectors = None
 
     @property
     def facelist(self):
@@ -80,12 +81,27 @@ class TriMesh:
             Wm = sparse.coo_matrix((w.ravel(), (rows, cols.ravel().astype(np.int64))), shape=(n, n)).tocsr()   # (padding: zeros on the diagonal)
             Wm.eliminate_zeros()
             self._W = Wm
+            self._W_dev = None
+        elif self._W is None and self._W_recipe is not None and self._facelist is not None:
+            # the device rows were released when the mesh left compute_surface_map[_batch] (they are views of a whole chunk's arrays:
+            # one surviving mesh would pin them all): the same construction on the host, for the rare caller that reads W
+            from . import laplacian as _lap
+            self._W = (_lap.robust_mesh_laplacian(self.vertlist, self.facelist, mollify_factor=1e-5)[0] if self._W_recipe == "robust"
+                       else sparse.csr_matrix(_lap.cotangent_laplacian(self.vertlist, self.facelist)[0]))
         return self._W
+
+    def release_device_rows(self):
+        """forget the device copy of the stiffness rows (views of the batched assembly's (B, N, nnz) arrays, which they keep alive in
+        HBM); `W` is re-assembled on the host if somebody asks for it later.  compute_surface_map[_batch] call this on the meshes
+        they return."""
+        if self._W_dev is not None:
+            self._W_dev = None
 
     @W.setter
     def W(self, value):
         self._W = value
         self._W_dev = None
+        self._W_recipe = None
 
     @property
     def A(self):
@@ -211,6 +227,9 @@ class TriMesh:
         if robust:
             try:
                 import robust_laplacian                                       # trimesh.py:465-470
+            except ImportError:                                               # (only the import itself: an ImportError from inside the wheel is the wheel's)
+                robust_laplacian = None
+            if robust_laplacian is not None:
                 for mesh in meshes:
                     Wm, Am = robust_laplacian.mesh_laplacian(mesh.vertlist, mesh.facelist, mollify_factor=1e-5)
                     mesh.W = sparse.csr_matrix(Wm)
@@ -220,16 +239,16 @@ class TriMesh:
                     mesh.A = sparse.diags(mass).tocsr()
                     mesh._L = None
                 return None
-            except ImportError:
-                if _lap.robust_backend() != "restated":
-                    raise ImportError(
-                        "process(robust=True) needs the `robust_laplacian` package (what the reference calls, pyFM/mesh/trimesh.py:465-470), "
-                        "which is not installed.  This package carries its own implementation of the same construction (tufted cover, "
-                        "intrinsic Delaunay flips, mollification), NOT pinned against the wheel: opt in with "
-                        "densematcher_amd.pyFM.mesh.laplacian.set_robust_backend('restated') or DENSEMATCHER_AMD_ROBUST_LAPLACIAN=restated, "
-                        "or pass robust=False for the plain cotangent Laplacian")
-                warnings.warn("robust=True: the robust_laplacian package is not installed; using this package's own tufted "
-                              "intrinsic-Delaunay Laplacian (same construction, parity with the wheel unpinned)")
+            if _lap.robust_backend() != "restated":
+                raise ImportError(
+                    "process(robust=True) -- what FunctionalMapping.preprocess and compute_surface_map always ask for -- needs the "
+                    "`robust_laplacian` package (what the reference calls, pyFM/mesh/trimesh.py:465-470), which is not installed.  This "
+                    "package carries its own implementation of the same construction (tufted cover, intrinsic Delaunay flips, "
+                    "mollification), NOT pinned against the wheel: opt in with compute_surface_map(..., robust_backend='restated'), "
+                    "densematcher_amd.pyFM.mesh.laplacian.set_robust_backend('restated') or DENSEMATCHER_AMD_ROBUST_LAPLACIAN=restated, "
+                    "or pass robust=False for the plain cotangent Laplacian")
+            warnings.warn("robust=True: the robust_laplacian package is not installed; using this package's own tufted "
+                          "intrinsic-Delaunay Laplacian (same construction, parity with the wheel unpinned)")
         eng = default_engine()
         if robust:
             covers = eng.tufted_covers([(m.vertlist, m.facelist) for m in meshes], mollify_factor=1e-5)
@@ -244,6 +263,7 @@ class TriMesh:
             n = mesh.n_vertices
             mesh._W = None
             mesh._W_dev = (ell["cols"][b, :n], ell["w"][b, :n])
+            mesh._W_recipe = "robust" if robust else "cotangent"
             mesh._A = None
             mesh._mass = mass[b, :n].copy()
             mesh._L = None

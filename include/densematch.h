@@ -243,7 +243,9 @@ int dm_fmap_fit_steps(dm_ctx* ctx, int nsteps, int B, int N1, int N2, int k1, in
  *                         then runs dm_fmap_fit_steps)
  *   x0 (B,k2,k1) start (first column = the pinned one); x_out (B,k2,k1), f_out (B), info_out (B,4) as dm_lbfgs_result;
  *   evaluations_out (host, nullable): launches issued.
- *   maxfun <= 0: ONE evaluation at x0, no optimiser: f_out (B) energy, grad_out (B,k2,k1) gradient (x_out / info_out unused). */
+ *   maxfun <= 0: ONE evaluation at x0, no optimiser: f_out (B) energy, grad_out (B,k2,k1) gradient (x_out / info_out unused).
+ *   dm_fmap_fit_fused takes no operator lists, so it has no commutativity term: weights[2] (w_dcomm) must be 0, DM_EINVAL otherwise
+ *   (a fit with operators goes through dm_fmap_fit_steps; dm_fmap_fit_fused_ok(..., n_ops > 0) says so). */
 int dm_fmap_fit_fused_ok(int k1, int k2, const double* weights /*host, 10*/, int n_ops);
 int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, int D,
                       const float* Phi1, int ld1, const float* Phi2, int ld2, const float* mass1,

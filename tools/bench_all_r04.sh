@@ -6,6 +6,6 @@ for W in simnn zoomout stress icp surface_map; do python bench.py --workload $W 
 python bench.py --basis f32 --no-secondary --no-cpu-baseline > $O/r04_fmap_f32basis_bench.json 2> $O/f32.err
 python bench.py --gpus 2 --single-device --no-secondary --no-cpu-baseline > $O/r04_fmap_2rank_single_device_bench.json 2> $O/2rank.err
 for W in zoomout fmap icp stress; do python tools/step_profile.py $W > $O/r04_${W}_step_kernels.txt 2> /dev/null; done
-python tools/simnn_power_test.py > $O/r04_simnn_power_test.txt 2> /dev/null
-python tools/proj_test.py > $O/r04_proj_onepass_test.txt 2> /dev/null
+python tools/simnn_power_check.py > $O/r04_simnn_power_test.txt 2> /dev/null
+python tools/proj_check.py > $O/r04_proj_onepass_test.txt 2> /dev/null
 ls -la $O | tail -20

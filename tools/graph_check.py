@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Does replaying a captured HIP graph shorten the gaps between the dependent launches of a call?  ZoomOut (756 launches per
 step), ICP (610) and the config-2 step (11) as plain launches on a side stream against one graph launch per step.
-usage: python tools/graph_test.py"""
+usage: python tools/graph_check.py"""
 import os
 import sys
 import time

@@ -2,7 +2,7 @@
 """The one-pass projection kernel (running scale per workgroup, csrc/dm_project.hip: proj_onepass_kernel) against the r03 pair
 of launches it replaces (maxima pass + tile kernel on an fp32 copy; dm_set_option "proj_onepass" = 0) and against a float64
 product, on the config-2 shape and on inputs that move the running scale (magnitudes growing / shrinking along the vertices).
-usage: python tools/proj_test.py"""
+usage: python tools/proj_check.py"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The five-slot-ring variant of the config-3 kernel (DM_SIMNN_DEBUG=0x20000, libdensematch_exp.so) against the product kernel:
-same arg-max, kernel time.  usage: python tools/simnn_early_test.py"""
+same arg-max, kernel time.  usage: python tools/simnn_early_check.py"""
 import os
 import subprocess
 import sys

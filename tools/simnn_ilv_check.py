@@ -2,7 +2,7 @@
 """The interleaved-issue variant of the tile kernels (XV bit 4096: fragment reads and LDS-DMA issued between the matrix
 instructions of a k-step; DM_SIMNN_ILV=1, libdensematch_exp.so) against the product variant (reads pinned in front):
 same maps, kernel time of simnn_f16_mfma (config 3), simnn4_f16_mfma (config 2) and simnn1_f16_mfma (config 4).
-usage: python tools/simnn_ilv_test.py"""
+usage: python tools/simnn_ilv_check.py"""
 import os
 import subprocess
 import sys

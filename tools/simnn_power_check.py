@@ -3,7 +3,7 @@
 traffic) on operands that toggle fewer and fewer bits: random features (the bench's), a constant, zeros.  A schedule-bound
 kernel takes the same time on all three; a power-bound one speeds up as the data quiets down.
 The exp build's schedule variants run the same cases.
-usage: python tools/simnn_power_test.py"""
+usage: python tools/simnn_power_check.py"""
 import os
 import sys
 
