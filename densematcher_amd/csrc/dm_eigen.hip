@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void ritz_residual_kernel(const double* __rest
     if (t == 0) atomicMax(resid_bits + b, (unsigned long long)__double_as_longlong(sqrt(sh[0])));   // (non-negative doubles order like their bits)
 }
 
-// Cyclic two-sided Jacobi eigensolver of a symmetric m x m matrix (m <= 512), one workgroup of 1024 threads per matrix,
+// Cyclic two-sided Jacobi eigensolver of a symmetric m x m matrix (m <= 2048), one workgroup of 1024 threads per matrix,
 // round-robin ordering (m/2 disjoint rotations per round: the row updates of a round are independent, then the column
 // updates of H and of the accumulated eigenvectors V).  H is overwritten (diagonal = eigenvalues), V (m x m, columns).
 // IN_LDS: both matrices live in the LDS for the duration (2 m^2 doubles; m <= 90): a round is three barriers around two
@@ -280,8 +280,8 @@ __global__ __launch_bounds__(256) void ritz_residual_kernel(const double* __rest
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(double* __restrict__ Hs, double* __restrict__ Vs, int m, int max_sweeps) {
     extern __shared__ __attribute__((aligned(16))) double jac_sm[];
-    __shared__ double rc[256], rs[256];
-    __shared__ int rp[256], rq[256];
+    __shared__ double rc[1024], rs[1024];          // (a round's m / 2 rotations: m <= 2048)
+    __shared__ int rp[1024], rq[1024];
     __shared__ unsigned long long s_off, s_diag;
     const int b = blockIdx.x, t = threadIdx.x, nthr = blockDim.x;
     double* Hg = Hs + (long long)b * m * m;
@@ -615,14 +615,16 @@ extern "C" int dm_eigenbasis(dm_ctx* ctx, int B, int N, int nnz, const int32_t* 
                              double* lam /* B*k */, double* Phi /* B*N*k */, double* resid /* B */) {
     if (!ctx) return DM_EINVAL;
     // warm_start == 2: the DENSE route for meshes too small for the filtered iteration -- X holds an orthonormal basis of the whole
-    // space (the identity: k + guard = N <= 512), no filter, ONE Rayleigh-Ritz step = the eigendecomposition of L itself
+    // space (the identity: k + guard = N <= 2048), no filter, ONE Rayleigh-Ritz step = the eigendecomposition of L itself
     const bool dense = warm_start == 2;
     if (dense) n_iter = 0;
     DM_REQUIRE(ctx, B > 0 && N > 0 && nnz > 0 && k > 0 && guard >= 0 && (n_iter > 0 || dense), "sizes must be positive");
     DM_REQUIRE(ctx, !dense || k + guard == N, "the dense route takes the whole space: k + guard = N");
     DM_REQUIRE(ctx, ell_cols && ell_vals && mass && X && lam && Phi && resid, "null pointer");
     const int m = k + guard;
-    DM_REQUIRE(ctx, m <= N && m <= 512, "k + guard must be <= min(N, 512)");
+    // (the dense route's Jacobi eigensolve runs from global memory past 90 vectors, one workgroup per mesh: ~0.3 s at N = 1024, seconds
+    //  at N = 2048 -- slow, but a mesh whose wanted range passes the middle of its spectrum is solved like the reference's ARPACK solves it)
+    DM_REQUIRE(ctx, m <= N && m <= (dense ? 2048 : 512), "k + guard must be <= min(N, 512) (dense route: N <= 2048)");
     DM_REQUIRE(ctx, degree >= 2 && degree <= EIG_MAX_DEG, "filter degree must be in [2, 64]");
     DM_CHECK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bX = (size_t)B * N * m * 8, bM = (size_t)B * m * m * 8;

@@ -523,6 +523,8 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
     constexpr bool FLIP = (XV & 128) != 0;       // second wave of each SIMD: MFMAs first, then the reads / DMA of the half-stage
     constexpr bool TRACE = (XV & 1024) != 0;     // experiments: s_memtime stamps of every stage of workgroup 0's third tile
     constexpr bool ILV = (XV & 4096) != 0;       // fragment reads and DMA issued BETWEEN the matrix instructions of a k-step
+    constexpr bool PRIO = (XV & 8192) != 0;      // s_setprio(1) around every cluster of matrix instructions: the SIMD's arbiter prefers the wave
+                                                 // that is feeding the matrix pipe over the other wave's reads / DMA / reduction epilogue
     constexpr bool SPLIT = DUAL != 0;            // the key-set kernels read split rows [16 high | 16 low] per stage (dm_knnsplit.hip)
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];             // NBUF x (T | S) | per-tile terms | transpose buffer
     // Behind the ring: DUAL: two slots of per-tile terms | DUAL 3, 8 waves: the eighth wave's transpose buffer (the transposes of
@@ -655,9 +657,11 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
             if (do_tn) { _Pragma("unroll") for (int x = 0; x < TB; ++x) nrm_t[x] = sumsq8(ft_[x], nrm_t[x]); }         \
             if (do_sn) { _Pragma("unroll") for (int x = 0; x < 4; ++x) nrm_s[x] = sumsq8(fs_[x], nrm_s[x]); }          \
         }                                                                                                              \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
             _Pragma("unroll") for (int tt = 0; tt < TB; ++tt)                                                          \
                 acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], (ZERO_) ? zero16 : acc[st][tt], 0, 0, 0); \
+        if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                       \
     }
     // a k-step whose fragment reads (next k-step's operands: rs_ / rt_ from ring slot rslot_ at rfo_) and DMA half H_ are issued in
     // the shadow of its own matrix instructions -- two reads behind each of the first MFMAs, then the DMA -- instead of in
@@ -665,6 +669,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
 #define SIMNN_MMA_ILV(fs_, ft_, ZERO_, RDS_, rs_, RDT_, rt_, rslot_, rfo_, DODMA_, H_)                                 \
     if ((dbg & 7) != 7) {                                                                                              \
         const _Float16* Br = smem + (rslot_) * PSTAGE;                                                                 \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                       \
         _Pragma("unroll") for (int st = 0; st < 4; ++st)                                                               \
             _Pragma("unroll") for (int tt = 0; tt < TB; ++tt) {                                                        \
                 acc[st][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fs_[st], ft_[tt], (ZERO_) ? zero16 : acc[st][tt], 0, 0, 0); \
@@ -677,6 +682,7 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
                 if ((DODMA_) && mi == (ns_ + nt_ + 1) / 2) { SIMNN_DMA1(H_) }                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
+        if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                       \
     }
 #define SIMNN_SYNC(n_, AFTER_EPI_)                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                 \
@@ -1221,12 +1227,18 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
         const int ncu = ctx->n_cu > 0 ? ctx->n_cu : 256;
         const int resident = ncu * (WT == 4 ? 1 : 2);
         int rc = DM_OK, grid = 0;
-#define SIMNN_LAUNCH_XV(XV_, WT_, DUAL_, NAME_)                                                                        \
+#define SIMNN_LAUNCH_XV1(XV_, WT_, DUAL_, NAME_)                                                                       \
         {                                                                                                              \
             rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<XV_, WT_, DUAL_>, lds_pipe);                         \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, NAME_, (simnn_pipe_kernel<XV_, WT_, DUAL_>), dim3(grid), dim3(128 * WT_), lds_pipe, p);     \
         }
+#ifdef DM_EXPERIMENTS   /* dm_set_option("simnn_prio", 1): the s_setprio variant (measured r06: no change on any workload, profiles/r06_simnn_setprio_ab.txt) */
+#define SIMNN_LAUNCH_XV(XV_, WT_, DUAL_, NAME_)                                                                        \
+        { if (ctx->opt_simnn_prio) SIMNN_LAUNCH_XV1((XV_) | 8192, WT_, DUAL_, NAME_) else SIMNN_LAUNCH_XV1(XV_, WT_, DUAL_, NAME_) }
+#else
+#define SIMNN_LAUNCH_XV(XV_, WT_, DUAL_, NAME_) SIMNN_LAUNCH_XV1(XV_, WT_, DUAL_, NAME_)
+#endif
 #define SIMNN_LAUNCH_EDGE(WT_, DUAL_, NAME_)                                                                           \
         {                                                                                                              \
             rc = dm_grant_lds(ctx, (const void*)simnn_pipe_kernel<SIMNN_PRODUCT_XV, WT_, DUAL_, 2, true>, lds_pipe);   \
@@ -1318,6 +1330,7 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
 #undef SIMNN_LAUNCH_BIG
 #undef SIMNN_LAUNCH_EDGE
 #undef SIMNN_LAUNCH_XV
+#undef SIMNN_LAUNCH_XV1
     } else {
         int rc = dm_grant_lds(ctx, (const void*)simnn_edge_kernel, lds_edge);
         if (rc) return rc;
@@ -1331,6 +1344,9 @@ int dm_simnn_core(dm_ctx* ctx, int B, int N2, int N1, int D, const _Float16* Ftg
     // bounded relative to |t_i| max|s_j| + max|bias_j|, key B relative to |t_i| max|s_j| max scale_j.
     // (key-set passes read split rows: D halves per row stand for 3 D / 2 products, hx.hy + hx.ly + lx.hy per index)
     const float nprod = dual ? 1.5f * (float)D : (float)D;
+    // DM_EXPERIMENTS builds: DM_TAU_EXTRA_LOG2 = e adds 2^-e to the relative error bound (results stay exact, more rows take the exact
+    // path): what a first pass on the high halves alone (error 2^-10 |t||s|) would requeue -- tools/one_product_pass_experiment.py
+    if (const int e_ = dm_knob("DM_TAU_EXTRA_LOG2", 0)) rel_extra += ldexpf(1.0f, -e_);
     const float tau_scale = 2.0f * 1.01f * (nprod * (1.0f + 1.0f / 16.0f) * 1.1920929e-7f + 2.0f * 1.9073486e-6f + rel_extra +
                                             (dual ? 1.1920929e-7f : 0.0f));
     if (ext) {

@@ -279,11 +279,13 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
                   optinit="zeros", maxiter=1000000, stopping="reference")
         fp.update({k_: v for k_, v in fit_params.items() if k_ in fp})
         general = {n: fp[n] for n in ("w_dcomm", "w_p2p", "w_stochastic", "w_ent", "w_range01", "w_sumto1", "w_area", "w_conformal")}
-        if any(v > 0 for v in general.values()):
+        from .pyFM.functional import CLOSED_FORM_MAX_K1
+        wide = n_ev > CLOSED_FORM_MAX_K1              # (FunctionalMapping.fit: maps wider than the closed form's solvers take the iterative scheme, tight)
+        if any(v > 0 for v in general.values()) or wide:
             from .pyFM.functional import LBFGS_OPTIONS
             x0 = np.stack([m.get_x0(optinit=fp["optinit"]) for m in g])
             C0, res = eng.fit_general(dev, dict(w_descr=fp["w_descr"], w_lap=fp["w_lap"], **general), x0, maxiter=fp["maxiter"],
-                                      lbfgs_options=LBFGS_OPTIONS if fp["stopping"] == "tight" else None)
+                                      lbfgs_options=LBFGS_OPTIONS if (fp["stopping"] == "tight" or wide) else None)
             C0 = np.asarray(C0, dtype=np.float64)
         else:
             res = None
@@ -309,10 +311,16 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
 
         def run_icp():
             Ci_, resid, info = eng.icp(P1, P2, C0d, nit=10, return_resid=True)
-            if int(info.max()) != 0:
-                raise np.linalg.LinAlgError("ICP: Phi2^T Phi2 is not positive definite")
-            if float(resid.max()) > 1e-8:
-                raise np.linalg.LinAlgError(f"ICP: polar iteration did not converge (|C^T C - I| = {float(resid.max()):.2e})")
+            bad = np.nonzero((info.cpu().numpy() != 0) | ~(resid.cpu().numpy() <= 1e-8))[0]
+            if bad.size:
+                # rank-deficient least-squares maps: those pairs re-run with the reference's lstsq + SVD (pyFM/refine/icp.py: icp_host_svd)
+                import warnings
+                from .pyFM.refine.icp import icp_host_svd
+                warnings.warn(f"ICP: the polar iteration did not converge for pairs {bad.tolist()[:8]} of the group; they run the "
+                              "reference's lstsq + SVD on the host")
+                for q_ in bad:
+                    Ci_[q_] = torch.as_tensor(icp_host_svd(C0[q_], g[q_].mesh1.eigenvectors[:, :n_ev], g[q_].mesh2.eigenvectors[:, :n_ev], 10),
+                                              dtype=torch.float64).to(Ci_.device)
             return Ci_
         Ci = None
         if early:

@@ -19,6 +19,7 @@ _OPTIMIZERS = ("L-BFGS-B", "fmin_l_bfgs_b", "l-bfgs-b")
 # or 1690 at 1e-15) as summation orders inside the evaluation changed, for maps that agree to 2e-5.  Measured on that fit
 # (tools/fit_profile.py <ftol>; distance of C from the 1e-15 result): 1e-14 464 evaluations 8e-7, 1e-13 448 1e-6,
 # 1e-12 332 9e-6, 1e-11 261 4e-5, 1e-10 224 1.3e-4.  1e-12 keeps a factor ten under the 1e-4 bar on C.
+CLOSED_FORM_MAX_K1 = 200          # dm_fmap_solve / dm_fmap_fit: the in-LDS solvers take systems of order <= 199
 LBFGS_OPTIONS = {"ftol": 1e-12, "gtol": 1e-9, "maxcor": 30, "maxfun": 15000}
 
 
@@ -160,8 +161,12 @@ class FunctionalMapping:
         iterative = any(v > 0 for v in general.values())
         if not (w_descr > 0 or w_lap > 0 or iterative):
             raise ValueError("every energy weight is 0")                       # base_functions.py:534,639 would fail too
+        # The closed form solves k2 systems of order k1 - 1 in on-chip memory: maps up to 200 columns.  Wider maps (the reference has no
+        # cap, functional.py:352) take the reference's own scheme instead -- L-BFGS on the two quadratic terms, on the device, float64,
+        # run to ftol 1e-12 (the float64 minimiser to 1e-5) unless the caller asked for the reference's stopping rule explicitly.
         if not self.preprocessed:
             self.preprocess()
+        wide = (not iterative) and self.mesh1.eigenvectors.shape[1] > CLOSED_FORM_MAX_K1
         eng = default_engine()
         m1, m2 = self.mesh1, self.mesh2
         # like the reference (functional.py:412-413) fit uses every stored eigenvector column
@@ -176,8 +181,10 @@ class FunctionalMapping:
                  "F1": np.ascontiguousarray(d1, dtype=fdt)[None], "F2": np.ascontiguousarray(d2, dtype=fdt)[None]}
         dev = {n: eng._dev(v, {np.float16: __import__("torch").float16, np.float32: __import__("torch").float32,
                                np.float64: __import__("torch").float64}[v.dtype.type], n) for n, v in batch.items()}
-        if iterative:
+        if iterative or wide:
             weights = dict(w_descr=w_descr, w_lap=w_lap, **general)
+            if wide:
+                stopping = "tight"
             if stopping not in ("tight", "reference"):
                 raise ValueError("stopping must be 'tight' or 'reference'")
             x0 = self.get_x0(optinit=optinit)

@@ -893,3 +893,32 @@ def test_assignment_from_the_indicator_factors(fx_cfg1, monkeypatch):
     viaf = fmod._assign_many([mi])[0]
     assert getattr(mi, "_dev", None) is None                       # (no dense matrix was formed)
     assert np.array_equal(viaf[0], ref[0]) and np.array_equal(viaf[1], ref[1])
+
+
+@pytest.mark.gpu
+def test_fit_wider_than_the_closed_form_takes_the_iterative_scheme():
+    """n_ev > 200 (the reference has no cap, functional.py:352): the in-LDS solvers of the closed form stop at 200
+    columns, wider maps run the reference's own scheme -- L-BFGS on the two quadratic terms, on the device -- to the float64 minimiser:
+    within 1e-4 of the oracle's closed form, first column pinned"""
+    import types
+    import scipy.sparse as sp
+    from densematcher_amd import synth
+    from densematcher_amd.pyFM import FunctionalMapping
+    N, k, D = 1200, 208, 96
+    lam1, phi1, a1 = synth.random_basis(N, k, 31)
+    lam2, phi2, a2 = synth.random_basis(N, k, 32)
+    F1, F2, _ = synth.feature_pair(N, N, D, 5, 6, sigma=0.3, perm="identity")
+
+    def mesh(lam, phi, a):
+        m = types.SimpleNamespace(eigenvalues=lam[:k].copy(), eigenvectors=phi[:, :k].astype(np.float64), A=sp.diags(a.astype(np.float64)).tocsr())
+        m.process = lambda *a_, **kw: m
+        m.area = float(a.astype(np.float64).sum())
+        return m
+    model = FunctionalMapping(mesh(lam1, phi1, a1), mesh(lam2, phi2, a2), partial=False, optimizer="L-BFGS-B")
+    model.preprocess(n_ev=(k, k), n_descr=D, descr1=F1, descr2=F2, subsample_step=1)
+    model.fit(w_descr=1e-1, w_lap=1e-3, w_dcomm=0, optinit="zeros")
+    Co = orc.fit(phi1[:, :k], phi2[:, :k], lam1[:k], lam2[:k], a1, a2, F1, F2, 1e-1, 1e-3)
+    err = np.abs(model.FM - Co).max()
+    print("k = 208 fit:", model.fit_result.nit, "iterations; |C - C_oracle| =", err)
+    assert err <= 1e-4
+    assert np.array_equal(model.FM[:, 0], model.get_x0()[:, 0])

@@ -696,6 +696,33 @@ def test_icp_large_k(eng, k1, k2):
     assert np.abs(_np(C)[0] - Co).max() < 1e-8
 
 
+def test_icp_rank_deficient_map_takes_the_reference_svd(eng, fx_cfg1):
+    """A start whose vertex map has fewer distinct images than the map has columns gives a rank-deficient least-squares map: the
+    reference's scipy.linalg.svd returns U I V^T for any rank (icp.py:38-40); the polar iteration cannot, so that pair re-runs with
+    lstsq + SVD (pyFM/refine/icp.py: icp_host_svd) instead of raising.  The null-space completion is LAPACK's
+    choice, so the checks are the properties that define U I V^T: orthonormal columns, and trace(C^T X) = the sum of X's singular
+    values for the least-squares map X of the step; where the map has full rank the fallback equals the oracle."""
+    import scipy.linalg
+    from densematcher_amd.pyFM import refine
+    fx = fx_cfg1
+    k = 12
+    P1, P2 = fx["Phi1"][:, :k].astype(np.float64), fx["Phi2"][:, :k].astype(np.float64)
+    C0 = np.zeros((k, k))
+    C0[1, 1] = 1e-6                                      # a one-dimensional, tiny embedding: every target picks one of its two extreme sources
+    p21 = orc.knn_query(P1 @ C0.T, P2)
+    X = scipy.linalg.lstsq(P2, P1[p21])[0]
+    sv = scipy.linalg.svd(X, compute_uv=False)
+    assert (sv > 1e-9 * sv[0]).sum() < k                 # the case is what it claims to be
+    with pytest.warns(UserWarning, match="lstsq \\+ SVD"):
+        C = refine.icp_iteration(C0, P1, P2)
+    assert np.abs(C.T @ C - np.eye(k)).max() < 1e-10
+    assert abs(np.trace(C.T @ X) - sv.sum()) < 1e-9 * max(1.0, sv.sum())
+    # full rank: the host path is the oracle's arithmetic
+    rng = np.random.default_rng(2)
+    C1 = np.eye(k) + 0.05 * rng.standard_normal((k, k))
+    assert np.abs(refine.icp.icp_host_svd(C1, P1, P2, 3) - orc.icp_refine(C1, P1, P2, nit=3)).max() < 1e-9
+
+
 # --------------------------------------------------------------------------- #
 # linear assignment (the Hungarian outputs of compute_surface_map)
 def test_linear_sum_assignment_equals_scipy(eng):
