@@ -46,6 +46,7 @@ struct ff_params {
     int n_active;
     const int* active;                          // (n_active) the pairs of this launch: workgroups vid / wg_per_pair -> pair active[...]
     const float* Phi2; int ld2;
+    const float* Psi32;                         // (B, N1pad, KL1) fp32 rounding of Psi: the other factor's rows of the fp32 element loop (F32 kernels)
     double* xt;                                 // (B, k2, k1) trial maps: read by everyone at the start, advanced by the pair's last workgroup
     double* unit_part; double* chunk_part;      // (B, nU, n + 1) [unit mode], (B, nchunks, n + 1): gradient entries, then the energy
     int* chunk_cnt; int* pair_cnt;
@@ -109,6 +110,34 @@ __device__ __forceinline__ double ff_element(double m, double w_ent, double w_p2
     return d;
 }
 
+// The same terms in fp32 -- the precision the REFERENCE evaluates them in (pyFM/functional.py:379-383 moves everything to float32 tensors,
+// base_functions.py:363-428).  v_log_f32 / v_rcp_f32 are good to 1 ulp; the energy of the wave's 32 entries of a row is added up in fp32
+// by the caller and folded into float64 once per unit.
+typedef float ff_f32x2 __attribute__((ext_vector_type(2)));
+template <bool GENERAL>
+__device__ __forceinline__ float ff_element_f32(float m, float w_ent, float w_p2p, float w_r01, float& eacc) {
+    float d = 0.f;
+    if (!GENERAL || w_ent > 0.f) {
+        const float c = __builtin_amdgcn_fmed3f(m, 0.f, 1.f);
+        const float y = c + 1e-10f;
+        const float lg = __builtin_amdgcn_logf(y) * 0.693147180559945309417f;       // v_log_f32 = log2
+        const float cl = c * lg;
+        eacc = fmaf(w_ent, -cl, eacc);
+        const float inv = __builtin_amdgcn_rcpf(y);
+        const float dd = w_ent * (-lg - c * inv);
+        d = (m >= 0.f && m <= 1.f) ? dd : 0.f;
+    }
+    if (GENERAL) {
+        if (w_p2p > 0.f) { const float q = m * m - m; eacc = fmaf(w_p2p * q, q, eacc); d = fmaf(w_p2p * 2.f * q, 2.f * m - 1.f, d); }
+        if (w_r01 > 0.f) {
+            const float lo = fmaxf(-m, 0.f), hi = fmaxf(m - 1.f, 0.f);
+            eacc = fmaf(w_r01, lo * lo + hi * hi, eacc);
+            d = fmaf(w_r01, 2.f * hi - 2.f * lo, d);
+        }
+    }
+    return d;
+}
+
 // Partial sums cross workgroups (other CUs, other XCDs) inside a launch.  They are written and read with agent-scope relaxed atomic
 // accesses (global_store / global_load ... sc1: through to / from the level the XCDs share), and a workgroup waits for its stores
 // (s_waitcnt vmcnt(0)) before its thread 0 bumps the counter: no cache maintenance.  (The generic release / acquire fences of
@@ -125,8 +154,10 @@ __device__ __forceinline__ double ff_wave_sum(double v) {
     return v;
 }
 
-template <int KL1, int K2P, bool GENERAL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ? 4 : 2, KL1 <= 16 ? 4 : 2))) void ff_eval_kernel(const ff_params p, const double* __restrict__ Psi) {
+// F32: the element loop (product, element-wise terms, Y update) in fp32 like the reference's; everything around it -- E2 = Phi2 C, the unit
+// epilogue, partial sums, the quadratic and sum-to-one terms, the optimiser -- stays float64.
+template <int KL1, int K2P, bool GENERAL, bool F32 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ? 4 : 2, KL1 <= 16 ? 4 : 2))) void ff_eval_kernel(const ff_params p, const double* __restrict__ Psi, const float* __restrict__ Psi32) {
     constexpr int KT1 = (KL1 + 15) / 16 * 16, T1 = KT1 / 16, T2 = K2P / 16;
     extern __shared__ __attribute__((aligned(16))) double ff_sm[];
     double* Ltab = ff_sm;                            // [128][2]        (u_i, -log u_i) of the in-line logarithm
@@ -203,8 +234,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
         }
         // ---- the unit's entries: 32 columns per wave, Psi rows through the scalar cache
         double Y[KL1];
-#pragma unroll
-        for (int c = 0; c < KL1; ++c) Y[c] = 0.0;
         double eacc = 0.0;
         asm volatile("" :: "v"(touch0), "v"(touch1));
 #ifdef DM_EXPERIMENTS
@@ -212,6 +241,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #else
         constexpr int jmul = KL1;
 #endif
+        if constexpr (F32) {
+            // fp32: two entries of the 16-deep products per v_pk_fma_f32 (the row of the other factor is an aligned pair of scalar
+            // registers), the element-wise terms on v_log_f32 / v_rcp_f32, Y in fp32 for the wave's 32 columns of this unit
+            const float* psf = Psi32 + ((long long)b * p.N1pad + cc * FF_COLS + wave * FF_WCOLS) * KL1;
+            ff_f32x2 E2f[KL1 / 2], Yf[KL1 / 2];
+#pragma unroll
+            for (int c = 0; c < KL1 / 2; ++c) { E2f[c] = ff_f32x2{(float)E2[2 * c], (float)E2[2 * c + 1]}; Yf[c] = ff_f32x2{0.f, 0.f}; }
+            const float w_ent = (float)p.w_ent, w_p2p = (float)p.w_p2p, w_r01 = (float)p.w_r01;
+            float eaf = 0.f;
+#pragma unroll 2
+            for (int jj = 0; jj < FF_WCOLS; ++jj) {
+                ff_f32x2 ps[KL1 / 2];
+#pragma unroll
+                for (int c = 0; c < KL1 / 2; ++c) ps[c] = *reinterpret_cast<const ff_f32x2*>(psf + jj * jmul + 2 * c);
+                ff_f32x2 m2 = E2f[0] * ps[0], m2b = E2f[1] * ps[1];             // (two chains: a dependent v_pk_fma_f32 waits for its predecessor)
+#pragma unroll
+                for (int c = 2; c < KL1 / 2; c += 2) { m2 = __builtin_elementwise_fma(E2f[c], ps[c], m2); m2b = __builtin_elementwise_fma(E2f[c + 1], ps[c + 1], m2b); }
+                m2 = m2 + m2b;
+                const float m = m2[0] + m2[1];
+#ifdef DM_EXPERIMENTS
+                const float d = (p.dbg_mode & 4) ? m : ff_element_f32<GENERAL>(m, w_ent, w_p2p, w_r01, eaf);
+#else
+                const float d = ff_element_f32<GENERAL>(m, w_ent, w_p2p, w_r01, eaf);
+#endif
+                const ff_f32x2 d2 = ff_f32x2{d, d};
+#pragma unroll
+                for (int c = 0; c < KL1 / 2; ++c) Yf[c] = __builtin_elementwise_fma(d2, ps[c], Yf[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < KL1 / 2; ++c) { Y[2 * c] = (double)Yf[c][0]; Y[2 * c + 1] = (double)Yf[c][1]; }
+            eacc = (double)eaf;
+        } else {
+#pragma unroll
+        for (int c = 0; c < KL1; ++c) Y[c] = 0.0;
 #pragma unroll 2
         for (int jj = 0; jj < FF_WCOLS; ++jj) {
             double ps[KL1];
@@ -227,6 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #endif
 #pragma unroll
             for (int c = 0; c < KL1; ++c) Y[c] = fma(d, ps[c], Y[c]);
+        }
         }
 #ifdef DM_EXPERIMENTS
         if (p.dbg_mode & 1) { asm volatile("" :: "v"(Y[0]), "v"(Y[KL1 - 1]), "v"(eacc)); continue; }
@@ -468,14 +532,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 
 // Psi[b][j][c] = a1_j Phi1[j][c]  (float64; zero for j >= N1 and c >= k1)
 __global__ __launch_bounds__(256) void ff_psi_kernel(const float* __restrict__ Phi1, int ld1, const float* __restrict__ mass1, int N1, int N1pad,
-                                                     int k1, int KL1, long long total, double* __restrict__ Psi) {
+                                                     int k1, int KL1, long long total, double* __restrict__ Psi, float* __restrict__ Psi32) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int c = (int)(e % KL1);
     const long long r = e / KL1;
     const int j = (int)(r % N1pad);
     const long long b = r / N1pad;
-    Psi[e] = (j < N1 && c < k1) ? (double)mass1[b * N1 + j] * (double)Phi1[(b * N1 + j) * ld1 + c] : 0.0;
+    const double v = (j < N1 && c < k1) ? (double)mass1[b * N1 + j] * (double)Phi1[(b * N1 + j) * ld1 + c] : 0.0;
+    Psi[e] = v;
+    if (Psi32) Psi32[e] = (float)v;           // (the fp32 product of two fp32 numbers the reference forms, base_functions.py:296: one rounding)
 }
 
 // Column sums and centred Gram matrix of the rows X_i (i < N) of one factor: blockIdx.y = 0: X = Psi (-> p, G1c), 1: X = Phi2 (-> s2, G2c).
@@ -562,6 +628,13 @@ static size_t ff_lds_bytes() {
     return (256 + (size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8;
 }
 
+template <int KL1, int K2P, bool GENERAL, bool F32>
+static int ff_launch1(dm_ctx* ctx, const ff_params& p, const double* Psi, size_t lds, dim3 grid) {
+    int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, GENERAL, F32>, lds);
+    if (rc) return rc;
+    DM_LAUNCH(ctx, "fit_fused_eval", (ff_eval_kernel<KL1, K2P, GENERAL, F32>), grid, dim3(256), lds, p, Psi, p.Psi32);
+    return DM_OK;
+}
 template <int KL1, int K2P>
 static int ff_launch(dm_ctx* ctx, const ff_params& p, const double* Psi, bool general) {
     const size_t lds = ff_lds_bytes<KL1, K2P>();
@@ -571,16 +644,8 @@ static int ff_launch(dm_ctx* ctx, const ff_params& p, const double* Psi, bool ge
         hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ff_eval_kernel<KL1, K2P, false>, 256, lds);
         fprintf(stderr, "fit_fused: occupancy %d workgroups per CU (%s), dynamic LDS %zu bytes, grid %u, W = %d\n", nb, hipGetErrorString(e_), lds, grid.x, p.W);
     }
-    if (general) {
-        int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, true>, lds);
-        if (rc) return rc;
-        DM_LAUNCH(ctx, "fit_fused_eval", (ff_eval_kernel<KL1, K2P, true>), grid, dim3(256), lds, p, Psi);
-    } else {
-        int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, false>, lds);
-        if (rc) return rc;
-        DM_LAUNCH(ctx, "fit_fused_eval", (ff_eval_kernel<KL1, K2P, false>), grid, dim3(256), lds, p, Psi);
-    }
-    return DM_OK;
+    if (p.Psi32) return general ? ff_launch1<KL1, K2P, true, true>(ctx, p, Psi, lds, grid) : ff_launch1<KL1, K2P, false, true>(ctx, p, Psi, lds, grid);
+    return general ? ff_launch1<KL1, K2P, true, false>(ctx, p, Psi, lds, grid) : ff_launch1<KL1, K2P, false, false>(ctx, p, Psi, lds, grid);
 }
 static int ff_dispatch(dm_ctx* ctx, const ff_params& p, const double* Psi, int KL1, int K2P, bool general) {
 #define FF_CASE(A_, B_) if (KL1 == A_ && K2P == B_) return ff_launch<A_, B_>(ctx, p, Psi, general);
@@ -645,13 +710,17 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     choose(B);
     p.n_active = B;
     DM_REQUIRE(ctx, (long long)B * p.nU < (1ll << 31), "batch too large for one launch");
+    const bool f32 = ctx->opt_fit_f32 != 0;                    // dm_set_option("fit_f32"): the element loop in the reference's precision
+    const size_t bPsi32 = f32 ? (size_t)B * p.N1pad * KL1 * 4 : 0;
     const size_t bPsi = (size_t)B * p.N1pad * KL1 * 8, bSums = (size_t)B * FF_SUMS * 8, bPQ = (size_t)B * (k1 + k2) * k1 * 8;
     const size_t bUnit = (size_t)B * p.nU * np1 * 8, bChunk = (size_t)B * p.nchunks * np1 * 8;
     const size_t bCnt = (size_t)B * (p.nchunks + 1) * 4, bState = eval_only ? 0 : lb_state_bytes(B, n, m);
-    int rc = dm_ws_reserve(ctx, dm_align_up(bPsi) + dm_align_up(bSums) + dm_align_up(bPQ) + dm_align_up(bUnit) + dm_align_up(bChunk) + dm_align_up(bCnt) +
+    int rc = dm_ws_reserve(ctx, dm_align_up(bPsi) + dm_align_up(bPsi32) + dm_align_up(bSums) + dm_align_up(bPQ) + dm_align_up(bUnit) + dm_align_up(bChunk) + dm_align_up(bCnt) +
                                     dm_align_up(bState) + 3 * dm_align_up((size_t)B * n * 8) + 3 * dm_align_up((size_t)B * 8) + 65536);
     if (rc) return rc;
     double* Psi = (double*)dm_ws_take(ctx, bPsi);
+    float* Psi32 = f32 ? (float*)dm_ws_take(ctx, bPsi32) : nullptr;
+    if (f32 && !Psi32) return dm_fail(ctx, DM_ENOMEM, "fit_fused: workspace not reserved");
     double* sums = (double*)dm_ws_take(ctx, bSums);
     double* PQ = (double*)dm_ws_take(ctx, bPQ);
     double* unit_part = (double*)dm_ws_take(ctx, bUnit);       // (unit mode may come later, when few pairs are left)
@@ -667,7 +736,7 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     // ---- once per fit: Psi, the basis sums and centred Gram matrices, P = A A^T, Q = Bm A^T
     {
         const long long total = (long long)B * p.N1pad * KL1;
-        DM_LAUNCH(ctx, "fit_fused_psi", ff_psi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, Phi1, ld1, mass1, N1, p.N1pad, k1, KL1, total, Psi);
+        DM_LAUNCH(ctx, "fit_fused_psi", ff_psi_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, Phi1, ld1, mass1, N1, p.N1pad, k1, KL1, total, Psi, Psi32);
         DM_LAUNCH(ctx, "fit_fused_sums", ff_sums_kernel, dim3(B, 2), dim3(256), 0, (const double*)Psi, p.N1pad, KL1, N1, k1, Phi2, ld2, N2, k2, sums, lam1, lam2, Bm, D);
         KRowsStackedF32 opa{A, Bm, k1, k2, D};
         KRowsF32 opb{A, (long long)k1 * D, D, k1, D};
@@ -682,7 +751,7 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     DM_CHECK_HIP(ctx, hipMemcpyAsync(active, host_active.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
     DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));         // (the host vector is rewritten below)
     p.active = active;
-    p.Phi2 = Phi2; p.ld2 = ld2; p.xt = xt; p.unit_part = unit_part; p.chunk_part = chunk_part;
+    p.Phi2 = Phi2; p.ld2 = ld2; p.Psi32 = Psi32; p.xt = xt; p.unit_part = unit_part; p.chunk_part = chunk_part;
     p.chunk_cnt = cnt; p.pair_cnt = cnt + (size_t)B * p.nchunks;
     p.w_p2p = weights[3]; p.w_ent = weights[5]; p.w_r01 = weights[6]; p.w_sum = weights[7];
     p.qa = quad_args{xt, nullptr, PQ, Bm, lam1, lam2, D, weights[0], weights[1]};

@@ -888,11 +888,6 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
 #endif
         simnn_tail<full, TT, ((dbg & 7) == 4 || (dbg & 7) == 6) ? 4 : 0, (DUAL == 3 ? 1 : DUAL), TB>(
             p, acc, nrm_t, nrm_s, do_tn, do_sn, b, i0, j0, ts_, lane, wsrc, wtgt, bias_lds + (n & 1) * BSLOT);
-#ifdef DM_EXPERIMENTS
-        if (DUAL == 3 && (p.dbg & 0x2000)) {             // ablation (wrong results): no column-direction reduction
-            if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
-        } else
-#endif
         if constexpr (TRACE) {
             if (tr_on) {
                 unsigned long long te;
@@ -902,6 +897,13 @@ __global__ __launch_bounds__(2 * 64 * (2 * WT / TB), TB == 4 ? 1 : 2) void simnn
                 for (int q = lane; q < 256; q += 64) p.trace[wave * 256 + q] = (q <= tr_n) ? tr_lds[q] : 0ull;
             }
         }
+#ifdef DM_EXPERIMENTS
+        // ablation (wrong results): no column-direction reduction.  (r04 - r05 this test sat in front of the TRACE block above and
+        // its `else` bound to THAT: the flag did nothing, "no column reductions" timed the full kernel; found in r06.)
+        if (DUAL == 3 && (p.dbg & 0x2000)) {
+            if (acc[0][0][0] == 1.2345f) p.pb[0] = acc[1][1][1];
+        } else
+#endif
         if (DUAL == 3) {
             // transposes go through the free slot (8 waves: seven of them, the eighth has its own buffer)
             float* tb = (NW == 8 && wave == 7) ? tb_extra : free_slot + wave * (32 * 36);

@@ -87,7 +87,7 @@ class MatchEngine:
         self.stream.synchronize()
 
     OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0, "solve_reg": 1, "simnn_band": 4, "lsa_reg": 2, "simnn_big": 0, "energy_keep_gram": 0,
-                       "p2pfm_direct": 1, "zoomout_fused": 1, "proj_onepass": 1}
+                       "p2pfm_direct": 1, "zoomout_fused": 1, "proj_onepass": 1, "fit_f32": 0}
 
     def set_option(self, name, value):
         """Choose between equivalent code paths of the library (include/densematch.h: dm_set_option); every setting
@@ -360,10 +360,19 @@ class MatchEngine:
         w = self._weight_array(weights)
         return bool(self.lib.dm_fmap_fit_fused_ok(int(k1), int(k2), C.cast(w, C.c_void_p), 0 if ops1 is None else int(ops1.shape[1])))
 
-    def _fit_fused(self, A, Bm, lam1, lam2, weights, P1, P2, a1, x0, opts, maxiter):
-        """the whole fit in one library call (dm_fmap_fit_fused: one launch per evaluation, the optimiser inside the kernel)"""
+    def _fit_fused(self, A, Bm, lam1, lam2, weights, P1, P2, a1, x0, opts, maxiter, precision="auto"):
+        """the whole fit in one library call (dm_fmap_fit_fused: one launch per evaluation, the optimiser inside the kernel).
+        precision: the element loop over the N2 x N1 entries of the mapped indicator (product, entropy / range terms, back-product):
+        "f32" = the reference's precision (pyFM/functional.py:379-383 moves every tensor to float32), "f64", or "auto" (default): fp32
+        under SciPy's stopping rule -- what the reference runs: the same iterations, the map within 3e-6 of the float64 loop's, 1.7 x
+        faster per evaluation -- and float64 when the caller asks for a tighter one (ftol < 1e-10 is below the fp32 noise floor of the
+        energy: the line search then ends in ABNORMAL_TERMINATION, like SciPy's does on a noisy function).  Everything around the
+        element loop (Phi2 C, partial sums, quadratic and sum-to-one terms, L-BFGS) is float64 either way."""
         import types
         import numpy as np
+        if precision not in ("auto", "f32", "f64"):
+            raise ValueError("precision must be 'auto', 'f32' or 'f64'")
+        f32 = precision == "f32" or (precision == "auto" and float(opts["ftol"]) >= 1e-10)
         B, k1, D = A.shape
         k2 = Bm.shape[1]
         _, N1, ld1 = P1.shape
@@ -374,20 +383,25 @@ class MatchEngine:
         fo = torch.empty((B,), dtype=torch.float64, device=self.device)
         info = torch.empty((B, 4), dtype=torch.int32, device=self.device)
         nev = C.c_int(0)
-        self._chk(self.lib.dm_fmap_fit_fused(self.ctx, B, N1, N2, k1, k2, D, _ptr(P1), ld1, _ptr(P2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1),
-                                             _ptr(lam2), C.cast(w, C.c_void_p), int(opts["maxcor"]), _ptr(x0d), float(opts["ftol"]), float(opts["gtol"]),
-                                             int(maxiter), int(opts["maxfun"]), int(opts["maxls"]), _ptr(xo), _ptr(fo), _ptr(info), C.c_void_p(0),
-                                             C.byref(nev)))
+        self.set_option("fit_f32", 1 if f32 else 0)
+        try:
+            self._chk(self.lib.dm_fmap_fit_fused(self.ctx, B, N1, N2, k1, k2, D, _ptr(P1), ld1, _ptr(P2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1),
+                                                 _ptr(lam2), C.cast(w, C.c_void_p), int(opts["maxcor"]), _ptr(x0d), float(opts["ftol"]), float(opts["gtol"]),
+                                                 int(maxiter), int(opts["maxfun"]), int(opts["maxls"]), _ptr(xo), _ptr(fo), _ptr(info), C.c_void_p(0),
+                                                 C.byref(nev)))
+        finally:
+            self.set_option("fit_f32", 0)
         info = info.cpu().numpy()
         info[:, 0] = np.where(info[:, 0] == 0, 4, info[:, 0])
         res = types.SimpleNamespace(x=xo.cpu().numpy(), fun=fo.cpu().numpy(), status=info[:, 0].copy(), nit=info[:, 1].copy(),
                                     nfev=info[:, 2].copy(), message=[self.LBFGS_STATUS.get(int(q), "?") for q in info[:, 0]],
-                                    success=bool(np.all((info[:, 0] == 1) | (info[:, 0] == 2))), evaluations=int(nev.value), path="fused")
+                                    success=bool(np.all((info[:, 0] == 1) | (info[:, 0] == 2))), evaluations=int(nev.value), path="fused",
+                                    element_loop="f32" if f32 else "f64")
         return res.x, res
 
-    def energy_grad_fused(self, Cm, A, Bm, lam1, lam2, weights, Phi1, Phi2, a1):
+    def energy_grad_fused(self, Cm, A, Bm, lam1, lam2, weights, Phi1, Phi2, a1, precision="f64"):
         """energy (B,) and gradient (B,k2,k1) at the maps Cm through the arithmetic of dm_fmap_fit_fused (its single-evaluation mode):
-        what the fused fit minimises, for tests and diagnostics"""
+        what the fused fit minimises, for tests and diagnostics.  precision "f64" | "f32": the element loop's (see _fit_fused)"""
         Cm = self._dev(Cm, torch.float64, "C")
         A = self._dev(A, torch.float32, "A")
         Bm = self._dev(Bm, torch.float32, "Bm")
@@ -403,12 +417,17 @@ class MatchEngine:
         w = self._weight_array(dict(weights, w_dcomm=0.0))
         energy = torch.empty((B,), dtype=torch.float64, device=self.device)
         grad = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)
-        self._chk(self.lib.dm_fmap_fit_fused(self.ctx, B, N1, N2, k1, k2, D, _ptr(P1), ld1, _ptr(P2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1),
-                                             _ptr(lam2), C.cast(w, C.c_void_p), 0, _ptr(Cm), 0.0, 0.0, 0, 0, 0, C.c_void_p(0), _ptr(energy), C.c_void_p(0),
-                                             _ptr(grad), None))
+        self.set_option("fit_f32", 1 if precision == "f32" else 0)
+        try:
+            self._chk(self.lib.dm_fmap_fit_fused(self.ctx, B, N1, N2, k1, k2, D, _ptr(P1), ld1, _ptr(P2), ld2, _ptr(a1), _ptr(A), _ptr(Bm), _ptr(lam1),
+                                                 _ptr(lam2), C.cast(w, C.c_void_p), 0, _ptr(Cm), 0.0, 0.0, 0, 0, 0, C.c_void_p(0), _ptr(energy), C.c_void_p(0),
+                                                 _ptr(grad), None))
+        finally:
+            self.set_option("fit_f32", 0)
         return energy, grad
 
-    def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4, orient_ops=None, fused=True):
+    def fit_general(self, batch, weights, x0, k=None, maxiter=15000, lbfgs_options=None, driver="device", check_every=4, orient_ops=None, fused=True,
+                    precision="auto"):
         """FunctionalMapping.fit for any of the implemented energy terms, a whole batch at once (reference: L-BFGS-B through
         scipy.optimize.minimize, one pair per call, functional.py:477).  Every pair runs its OWN limited-memory BFGS iteration --
         history, step length, stopping test -- so a pair's result does not depend on the batch it is in; the optimiser state
@@ -443,7 +462,7 @@ class MatchEngine:
             return res.x.reshape(B, k2, k1), res
         n, m = k2 * k1, int(opts["maxcor"])
         if self.fit_fused_ok(k1, k2, weights, ops1) and fused:
-            return self._fit_fused(A, Bm, lam1, lam2, weights, P1, P2, a1, x0, opts, maxiter)
+            return self._fit_fused(A, Bm, lam1, lam2, weights, P1, P2, a1, x0, opts, maxiter, precision=precision)
         nbytes = int(self.lib.dm_lbfgs_state_bytes(B, n, m))
         state = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=self.device)
         xt = torch.empty((B, k2, k1), dtype=torch.float64, device=self.device)

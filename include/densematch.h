@@ -86,6 +86,10 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *   "p2pfm_direct"  1 | 0   dm_p2p_to_fm (and the p2p_to_FM steps of dm_zoomout / dm_icp): register-resident tiles, operands straight
  *                           from global memory, fixed-order in-workgroup reduction | LDS-staged 64 x 64 tiles + split-K partials + reduce
  *   "simnn1_wt"     4 | 2   tile shape of the fused ZoomOut search: 8 waves, 256 x 256 | 4 waves, 128 x 256 (two workgroups per CU)
+ *   "fit_f32"       0 | 1   dm_fmap_fit_fused: the element loop over the N2 x N1 entries of the mapped indicator in float64 | in fp32,
+ *                           the precision the reference evaluates these terms in (pyFM/functional.py:379-383).  The ONE option whose two
+ *                           settings differ in the result: energy / gradient within 1e-6 relative, the fitted map within 3e-6 under
+ *                           SciPy's stopping rule.  The Python layer chooses it from the stopping rule (engine.py: _fit_fused).
  * Unknown names return DM_EINVAL.  The library never reads environment variables. */
 int dm_set_option(dm_ctx* ctx, const char* name, int value);
 /* Diagnostics of the LAST dm_fm_to_p2p[_f64] / dm_simnn_f16 call on ctx (synchronises the stream): out[q] = rows of reduction q

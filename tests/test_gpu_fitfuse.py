@@ -132,3 +132,55 @@ def test_fused_fit_k30_against_oracle(fx_cfg1, oracle_cfg1_fits):
     assert r1.path == "fused"
     print("k = 30 fused fit: iterations", r1.nit, "evaluations", r1.nfev, "|C - C_oracle| =", np.abs(C1[0] - oracle_cfg1_fits["C_nb"]).max())
     assert np.abs(C1[0] - oracle_cfg1_fits["C_nb"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("N1,N2,k1,k2", [(300, 517, 15, 13), (1000, 777, 20, 30), (2048, 2048, 15, 15)])
+def test_fused_fp32_element_loop_against_oracle(N1, N2, k1, k2):
+    """r06: the element loop of the fused evaluation in the REFERENCE's precision (fp32: pyFM/functional.py:379-383 moves every tensor
+    to float32; products on v_pk_fma_f32, v_log_f32 / v_rcp_f32) -- energy and gradient within 1e-6 (relative to |E|, max |G|) of the
+    oracle's float64 values on meshes of the path's sizes.  (On a 65-vertex mesh with a 32 x 32 map the bound is not met -- 1e-5,
+    tools/fit_f32_gate.py: an entry within fp32 rounding of the clamp's corner m = 0 flips the derivative's 23 w jump, and 8 k entries do
+    not average one flip away; the reference's fp32 evaluation has the same corner.)"""
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(N1 + 3 * N2 + k1)
+    B = 2
+    e1, e2, a1, C, A, Bm, lam1, lam2 = _random_problem(rng, B, N1, N2, k1, k2)
+    C[1] *= 40.0
+    for w in ({"w_ent": 0.3}, dict(NOTEBOOK_W), {"w_p2p": 0.5, "w_ent": 0.3, "w_range01": 1.5, "w_sumto1": 2.0, "w_descr": 1.0, "w_lap": 0.1}):
+        E, G = eng.energy_grad_fused(C, A, Bm, lam1, lam2, w, e1, e2, a1, precision="f32")
+        for b in range(B):
+            ev = orc.ev_sqdiff(lam1[b], lam2[b])
+            Eo, Go = orc.energy_grad_general(C[b], A[b].astype(np.float64), Bm[b].astype(np.float64), ev, e1[b], e2[b], a1[b], w)
+            assert abs(float(E[b]) - Eo) <= 1e-6 * abs(Eo), (w, b, float(E[b]), Eo)
+            assert np.abs(G[b].cpu().numpy() - Go).max() <= 1e-6 * np.abs(Go).max(), (w, b)
+
+
+def test_fused_fit_precision_follows_the_stopping_rule(fx_cfg1):
+    """SciPy's stopping rule (the reference's call, the default) runs the element loop in fp32 like the reference: the same iterations as
+    the float64 loop, the map within 1e-4 of it (measured 3e-6), bit-identical in batches of 1, 3 and 140; a tighter rule (ftol 1e-12 is
+    below the fp32 noise floor of the energy) keeps float64"""
+    from densematcher_amd.engine import default_engine
+    from densematcher_amd.pyFM.functional import LBFGS_OPTIONS
+    eng = default_engine()
+    fx = fx_cfg1
+    k = 15
+    x0 = orc.get_x0(k, k, float(fx["Phi1"][0, 0]), float(fx["Phi2"][0, 0]), float(fx["a1"].astype(np.float64).sum()),
+                    float(fx["a2"].astype(np.float64).sum()))
+    b3 = _fit_batch(fx, k, 3, None)
+    C3, r3 = eng.fit_general(b3, NOTEBOOK_W, np.stack([x0] * 3))
+    assert r3.path == "fused" and r3.element_loop == "f32"
+    C64, r64 = eng.fit_general(b3, NOTEBOOK_W, np.stack([x0] * 3), precision="f64")
+    assert r64.element_loop == "f64"
+    print("reference stopping: fp32 loop nit", r3.nit, "nfev", r3.nfev, "| f64 loop nit", r64.nit, "nfev", r64.nfev, "| max |C_f32 - C_f64| =", np.abs(C3 - C64).max())
+    assert np.all((r3.status == 1) | (r3.status == 2))
+    assert np.abs(C3 - C64).max() <= 1e-4
+    assert np.all(np.abs(r3.nit.astype(int) - r64.nit.astype(int)) <= 5)
+    C1, r1 = eng.fit_general({n: v[:1] for n, v in b3.items()}, NOTEBOOK_W, x0[None])
+    assert np.array_equal(C1[0], C3[0]) and r1.nit[0] == r3.nit[0]
+    big = _fit_batch(fx, k, 140, None)
+    Cb, rb = eng.fit_general(big, NOTEBOOK_W, np.stack([x0] * 140))
+    for b in (0, 1, 2, 137, 139):
+        assert np.array_equal(Cb[b], C3[b % 3]), b
+    Ct, rt = eng.fit_general({n: v[:1] for n, v in b3.items()}, NOTEBOOK_W, x0[None], lbfgs_options=dict(LBFGS_OPTIONS))
+    assert rt.element_loop == "f64"
