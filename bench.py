@@ -859,7 +859,7 @@ def surface_map_batch_rate(B):
             r = fmod.compute_surface_map_batch(m1, m2, F1s, F2s, n_ev=k, compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(NOTEBOOK_FIT), **kw)
         torch.cuda.synchronize()
         return r, time.perf_counter() - t0
-    # the figure: the call as a user makes it (its default: two chunk streams), no instrumentation; six warm-ups (the first call of a
+    # the figure: the call as a user makes it (its default: one chunk stream per 64 pairs), no instrumentation; six warm-ups (the first call of a
     # process creates the chunk streams' engines and their workspaces, and the caching allocator takes a few calls to hold every block a
     # call needs: until then calls alternate between 305 and 340-375 ms), then the median of seven
     for _ in range(6):
@@ -885,7 +885,7 @@ def surface_map_batch_rate(B):
             setattr(o, n, fn)
     fr = res[0][7].fit_result
     return {"value": round(B / t_call, 2), "unit": "mesh-pairs/s", "pairs_per_call": B, "s_per_call": round(t_call, 3),
-            "calls_s": [round(t, 3) for t in times], "streams": 2 if B >= 16 else 1,
+            "calls_s": [round(t, 3) for t in times], "streams": min(4, -(-B // 64)),
             "one_stream_instrumented_s_per_call": round(t_one, 3),
             "stages_ms_one_stream": {n: round(1e3 * v, 1) for n, v in stages.items()},
             "fit_evaluations_of_pair_0": int(getattr(fr, "nfev", [0])[0]),

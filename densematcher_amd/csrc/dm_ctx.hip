@@ -55,6 +55,7 @@ extern "C" int dm_destroy(dm_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->gram_keep) (void)hipFree(ctx->gram_keep);
+    for (auto& e : ctx->stats) { if (e.buf[0]) (void)hipFree(e.buf[0]); }
     if (ctx->pinned_words) (void)hipHostFree(ctx->pinned_words);
     if (ctx->pinned_event) (void)hipEventDestroy(ctx->pinned_event);
     delete ctx;
@@ -87,6 +88,7 @@ extern "C" int dm_set_option(dm_ctx* ctx, const char* name, int value) {
     else if (n == "simnn_big") ctx->opt_simnn_big = value;
     else if (n == "simnn_prio") ctx->opt_simnn_prio = value;
     else if (n == "fit_f32") ctx->opt_fit_f32 = value;
+    else if (n == "basis_stats") { ctx->opt_basis_stats = value; for (auto& e : ctx->stats) e.valid = false; }
     else if (n == "lsa_reg") ctx->opt_lsa_reg = value;
     else if (n == "p2p_split") ctx->opt_p2p_split = value;
     else if (n == "simnn_persist") ctx->opt_simnn_persist = value;
@@ -102,6 +104,27 @@ extern "C" int dm_set_option(dm_ctx* ctx, const char* name, int value) {
 extern "C" const char* dm_last_error(const dm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 extern "C" const char* dm_version(void) { return DM_VERSION_STRING; }
 extern "C" size_t dm_workspace_bytes(const dm_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+// the statistics entry of a basis (dm_ctx::basis_stat), created on first sight; the oldest entry makes room.  Null when the two small
+// buffers cannot be allocated (the caller then runs without hints).
+dm_ctx::basis_stat* dm_stat_entry(dm_ctx* ctx, const void* ptr, int B, int N, int k, int ld, int esz, int n) {
+    for (auto& e : ctx->stats)
+        if (e.ptr == ptr && e.B == B && e.N == N && e.k == k && e.ld == ld && e.esz == esz && e.n == n && e.buf[0]) return &e;
+    dm_ctx::basis_stat& e = ctx->stats[ctx->stats_next];
+    ctx->stats_next = (ctx->stats_next + 1) % 4;
+    const size_t need = (size_t)B * n * 8;
+    if (!e.buf[0] || (size_t)e.B * e.n * 8 < need) {
+        if (e.buf[0]) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(e.buf[0]); e.buf[0] = e.buf[1] = nullptr; }
+        void* p = nullptr;
+        if (hipMalloc(&p, 2 * dm_align_up(need)) != hipSuccess) { e.ptr = nullptr; return nullptr; }
+        e.buf[0] = (double*)p;
+        e.buf[1] = (double*)((char*)p + dm_align_up(need));
+    } else {
+        e.buf[1] = (double*)((char*)e.buf[0] + dm_align_up(need));
+    }
+    e.ptr = ptr; e.B = B; e.N = N; e.k = k; e.ld = ld; e.esz = esz; e.n = n; e.cur = 0; e.valid = false;
+    return &e;
+}
 
 int dm_ws_reserve(dm_ctx* ctx, size_t total_bytes) {
     ctx->ws_off = 0;

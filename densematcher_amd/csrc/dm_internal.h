@@ -66,6 +66,15 @@ struct dm_ctx {
     int n_cu = 0;                // multiProcessorCount of the device
     int32_t* pinned_words = nullptr;   // 64 ints of page-locked host memory + an event: small device -> host reads that must not stall the
     hipEvent_t pinned_event = nullptr; // launch queue (dm_pinned_words; the ICP's "have all polar iterations converged?")
+    // Per-basis statistics kept between calls (dm_fm_to_p2p: the per-64-vertex maxima of |Phi2|, from which the power-of-two scale of
+    // the target rows follows -- a property of the MESH, not of the map).  Keyed on (pointer, sizes), two buffers per
+    // entry: a call reads the maxima the previous call on this basis left and writes its own into the other buffer.  The hint only
+    // saves a pass over the basis: a call whose data turn out to have another scale than the hint's (a tensor rewritten in place, or
+    // another one at the same address) re-evaluates that pair's rows exactly -- slower, never wrong.
+    struct basis_stat { const void* ptr = nullptr; int B = 0, N = 0, k = 0, ld = 0, esz = 0, n = 0; double* buf[2] = {nullptr, nullptr}; int cur = 0; bool valid = false; };
+    basis_stat stats[4];
+    int stats_next = 0;
+    int opt_basis_stats = 1;     // 0: no hints, every call takes its own pass over the basis for the target rows (fs_build_rows)
     const int32_t* last_flag_counts = nullptr;   // device: the four queue counters (64 ints apart) of the last tile pass with its own merge; null: none
     int last_flag_sets = 0;
 };
@@ -150,8 +159,14 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, in
                     const double* Cm, int ldc, long long strideC, int transC,
                     double* embT, int krpad, int Npad, double* nrm, int zero_first,
                     double* amax_part = nullptr,    // amax_part: (B, ceil(Npad / DM_EMB_COLS)) max |embT| per block of columns (nullable)
-                    double* amax_in_part = nullptr);   // same shape: max |Phi[:, :km]| over the block's vertices (nullable)
+                    double* amax_in_part = nullptr,   // same shape: max |Phi[:, :km]| over the block's vertices (nullable)
+                    const struct dm_embed_fx* fx = nullptr);
 constexpr int DM_EMB_COLS = 64;
+// The basis rows a norms-only embedding streams anyway can leave it as SPLIT fp16 rows of the tile kernels (what fs_build_rows_kernel
+// writes in a pass of its own), when the power-of-two scale is known up front: `hint` = the per-block maxima a previous call on the
+// same basis left (dm_ctx::basis_stat).  amax_copy (nullable): a second copy of amax_in_part, the next call's hint.
+struct dm_embed_fx { _Float16* F; int D, rows_out; const double* hint /* (B) hinted max |Phi| per pair */; int n_hint; double* amax_copy; };
+dm_ctx::basis_stat* dm_stat_entry(dm_ctx* ctx, const void* ptr, int B, int N, int k, int ld, int esz, int n);
 
 // Fused G = A^T B tile kernel with the arg-reductions (see dm_p2p.hip).
 struct dm_gred_args {
@@ -247,9 +262,14 @@ int dm_launch_knn21(dm_ctx* ctx, const dm_gred_args& a, const dm_knn_split_state
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K);
 size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K);
 size_t dm_fm_split_zero_bytes(int B);      // block the caller zeroes: the per-pair bounds (max |bias|, max mass) the pass accumulates with atomicMax
+// pre (nullable): the target rows Fx taken from the arena by the caller (the FIRST dm_fm_split_ws_bytes piece) and -- built = true --
+// already written by the second embedding with the scale of `hint`; the pass then checks the hint against the maxima the embedding
+// measured and re-evaluates a pair exactly where they give different scales
+struct dm_fm_split_pre { _Float16* Fx; bool built; const double* hint /* (B) pair maxima the rows were scaled with */; double* pair_out /* (B) nullable: this call's pair maxima */; };
 template <typename TR>
 int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, const double* amaxT, int nT, void* zeroed,
-                       const TR* Phi2, int ld2);
+                       const TR* Phi2, int ld2, const dm_fm_split_pre* pre = nullptr);
+_Float16* dm_fm_split_take_fx(dm_ctx* ctx, int B, int N2, int K, int* D_out, int* rows_out);
 
 template <typename TR>
 int dm_fm_split_build_rows(dm_ctx* ctx, int B, int N, int K, const TR* Phi, int ld, const double* amaxT, int nT, int D, _Float16* F, int rows_out);

@@ -52,13 +52,21 @@ __global__ __launch_bounds__(256) void ks_absmax_kernel(const double* __restrict
 struct fs_bias_set {
     const double* nrm; int N, Npad; const double* mass; float* bias; unsigned int* bmax; unsigned int* mmax; float* scale32;
     int rows_out;                                            // entries per pair of bias / scale32 (>= N: padded to whole tiles)
+    const double* hint; int32_t* force;                      // (nullable) (B) the pair maxima the target rows were scaled with: a pair whose
+                                                             // measured maxima give another scale is re-evaluated exactly as a whole (force[b] = 1)
+    double* pair_out;                                        // (nullable) (B) the measured pair maximum: the next call's hint
 };
 __device__ __forceinline__ void fs_bias_body(const fs_bias_set& s, int b, int chunk, const double* __restrict__ amaxT, int nT,
                                              const double* __restrict__ amaxS, int nS) {
     __shared__ float wb[4], wm[4];
     const int j = chunk * 256 + threadIdx.x;
     if (chunk * 256 >= s.N) return;                          // uniform
-    const double sxy = ks_scale(amaxT + b * nT, nT) * ks_scale(amaxS + b * nS, nS);
+    const double sx_ = ks_scale(amaxT + b * nT, nT);
+    const double sxy = sx_ * ks_scale(amaxS + b * nS, nS);
+    if (chunk == 0 && threadIdx.x == 0) {
+        if (s.hint && ks_scale(s.hint + b, 1) != sx_) s.force[b] = 1;
+        if (s.pair_out) { double m_ = 0.0; for (int q = 0; q < nT; ++q) m_ = fmax(m_, amaxT[b * nT + q]); s.pair_out[b] = m_; }
+    }
     float bb = 0.f, mm = 0.f;
     if (j < s.N) {
         const float v = (float)(-0.5 * s.nrm[(long long)b * s.Npad + j] * sxy);
@@ -319,12 +327,7 @@ __global__ __launch_bounds__(256) void fs_build_rows_kernel(const TR* __restrict
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         _Float16 h, l;
-        if constexpr (sizeof(TR) == 4) {
-            const float x = (float)((double)xin[u] * sx);             // exact (sx is a power of two); 0 beyond K
-            h = (_Float16)x; l = (_Float16)(x - (float)h);
-        } else {
-            split2_hw((double)xin[u] * sx, h, l);
-        }
+        fs_split_entry<TR>(xin[u], sx, h, l);                         // exact scaling (sx is a power of two); 0 beyond K
         hv[u] = h; lv[u] = l;
     }
     *reinterpret_cast<f16x8*>(dst) = hv;
@@ -344,7 +347,7 @@ template int dm_fm_split_build_rows<float>(dm_ctx*, int, int, int, const float*,
 template int dm_fm_split_build_rows<double>(dm_ctx*, int, int, int, const double*, int, const double*, int, int, _Float16*, int);
 
 static inline int fs_depth(int K) { return 32 * ((K + 15) / 16); }    // halves per split row
-size_t dm_fm_split_zero_bytes(int B) { return 3 * dm_align_up((size_t)B * 4); }
+size_t dm_fm_split_zero_bytes(int B) { return 4 * dm_align_up((size_t)B * 4); }   // max |bias A|, max mass, max |bias B|, the pairs' force flags
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K) {
     return ctx->opt_p2p_split != 0 && dm_simnn_dual_ok(ctx, N2, N1, fs_depth(K), true) && N1 >= 256 && N2 >= 256;
 }
@@ -356,24 +359,35 @@ size_t dm_fm_split_ws_bytes(int B, int N2, int N1, int K) {
 }
 // a: AT, BT (K-major f64), n1, n2, mass1 and all four outputs; amaxS: per-256-column maxima of |BT| (colnorm_kernel);
 // zeroed: dm_fm_split_zero_bytes block, zeroed before dm_launch_phiT(Phi2) filled its first part
+// the target rows' buffer: the first piece dm_launch_fm_split takes from the arena (the caller takes it early when the second
+// embedding is to write the rows); padding rows are zeroed here
+_Float16* dm_fm_split_take_fx(dm_ctx* ctx, int B, int N2, int K, int* D_out, int* rows_out) {
+    const int D = fs_depth(K), R2 = pad_to(N2, 256);
+    _Float16* Fx = (_Float16*)dm_ws_take(ctx, (size_t)B * R2 * D * 2);
+    if (!Fx) return nullptr;
+    if (R2 != N2 && hipMemsetAsync(Fx, 0, (size_t)B * R2 * D * 2, ctx->stream) != hipSuccess) return nullptr;
+    *D_out = D; *rows_out = R2;
+    return Fx;
+}
+
 template <typename TR>
 int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, int nS, const double* amaxT, int nT, void* zeroed,
-                       const TR* Phi2, int ld2) {
+                       const TR* Phi2, int ld2, const dm_fm_split_pre* pre) {
     const int B = a.B, N1 = a.N1, N2 = a.N2;
     const int K = a.Ktrue > 0 ? a.Ktrue : a.Kloop;
     if (!a.BT || !a.n1 || !a.n2 || !a.mass1 || !a.knn21 || !a.knn12 || !a.ind21 || !a.ind12 || !amaxS || !amaxT || !zeroed || !Phi2)
         return dm_fail(ctx, DM_EINVAL, "fm_split: missing operand");
-    const int D = fs_depth(K);
+    int D = fs_depth(K);
     // Any N2, N1: the split rows and the per-row terms are padded to whole 256-tiles (zero rows; the tiles that reach into the
     // padding mask it in their reductions), so a mesh with 2000 vertices takes the same path as one with 2048.
-    const int R2 = pad_to(N2, 256), R1 = pad_to(N1, 256);
-    _Float16* Fx = (_Float16*)dm_ws_take(ctx, (size_t)B * R2 * D * 2);
+    int R2 = pad_to(N2, 256);
+    const int R1 = pad_to(N1, 256);
+    _Float16* Fx = pre ? pre->Fx : dm_fm_split_take_fx(ctx, B, N2, K, &D, &R2);
     _Float16* Fy = (_Float16*)dm_ws_take(ctx, (size_t)B * R1 * D * 2);
     float* biasA = (float*)dm_ws_take(ctx, (size_t)B * R1 * 4);
     float* biasB = (float*)dm_ws_take(ctx, (size_t)B * R2 * 4);
     float* scale32 = (float*)dm_ws_take(ctx, (size_t)B * R1 * 4);       // fp32 rounding of mass1: key B of the tile kernel
     if (!Fx || !Fy || !biasA || !biasB || !scale32) return dm_fail(ctx, DM_ENOMEM, "fm_split: workspace not reserved");
-    if (R2 != N2) DM_CHECK_HIP(ctx, hipMemsetAsync(Fx, 0, (size_t)B * R2 * D * 2, ctx->stream));
     if (R1 != N1) DM_CHECK_HIP(ctx, hipMemsetAsync(Fy, 0, (size_t)B * R1 * D * 2, ctx->stream));
     if (R1 != N1) {                                           // (padded terms reach LDS and masked lanes: keep them finite)
         DM_CHECK_HIP(ctx, hipMemsetAsync(biasA, 0, (size_t)B * R1 * 4, ctx->stream));
@@ -383,7 +397,9 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     const size_t mstride = dm_align_up((size_t)B * 4) / 4;
     unsigned int* bmaxA = reinterpret_cast<unsigned int*>(zeroed);
     unsigned int* mmax = bmaxA + mstride; unsigned int* bmaxB = bmaxA + 2 * mstride;
-    {
+    // pairs whose target rows were written with a hinted scale that is not their data's: every row takes the exact path
+    int32_t* force = (pre && pre->built) ? reinterpret_cast<int32_t*>(bmaxA + 3 * mstride) : nullptr;
+    if (!(pre && pre->built)) {
         const long long n = (long long)N2 * (D / 16);
         DM_LAUNCH(ctx, "fm_split_build_rows", fs_build_rows_kernel<TR>, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, Phi2, N2, K, ld2,
                   amaxT, nT, D, Fx, R2);
@@ -392,8 +408,8 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     if (rcb) return rcb;
     {
         // (the same launch writes the per-row terms of the pass: 2 x ceil(N / 256) extra workgroups per pair)
-        const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32, R1};
-        const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr, R2};
+        const fs_bias_set sA{a.n1, N1, a.N1pad, a.mass1, biasA, bmaxA, mmax, scale32, R1, force ? pre->hint : nullptr, force, pre ? pre->pair_out : nullptr};
+        const fs_bias_set sB{a.n2, N2, a.N2pad, nullptr, biasB, bmaxB, nullptr, nullptr, R2, nullptr, nullptr, nullptr};
         const int nbuild = dm_cdiv(N1, 64), nbb = dm_cdiv(N1 > N2 ? N1 : N2, 256);
         DM_LAUNCH(ctx, "knn_split_build", ks_build_kernel<true>, dim3(nbuild + 2 * nbb, B), dim3(256), ks_build_lds(D), a.BT,
                   a.n1, amaxT, amaxS, nS, K, N1, a.N1pad, a.Kpad, D, D, 0, Fy, (int32_t*)nullptr, 1, nT, R1, nbuild, sA, sB, nbb);
@@ -407,7 +423,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         // (ind12[j] = 0 where mass1[j] = 0: the whole indicator column is 0 and np.argmax returns the first index)
         dm_simnn_cols cols{biasB, reinterpret_cast<const float*>(bmaxB), a.knn12, a.ind12, &qc, &qd, a.mass1};
         dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols, true};
-        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
+        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, force, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         // (Phi2 is read where the caller keeps it: targets of e0 / e1, candidates of f0 / f1)
         ks_exact_args e0{nullptr, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21, Phi2, nullptr, ld2};
@@ -423,7 +439,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     {
         dm_simnn_queue qa, qb;
         dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, nullptr, true};
-        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, nullptr, a.knn21, nullptr, nullptr, &qa, &dual);
+        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, force, a.knn21, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         ks_exact_args e0{nullptr, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21, Phi2, nullptr, ld2};
         ks_exact_args e1 = e0;
@@ -434,7 +450,7 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     {
         dm_simnn_queue qa, qb;
         dm_simnn_dual dual{biasB, nullptr, reinterpret_cast<const float*>(bmaxB), nullptr, a.ind12, &qb, nullptr, true};
-        int rc = dm_simnn_core(ctx, B, N1, N2, D, Fy, D, Fx, D, rel_extra, nullptr, a.knn12, nullptr, nullptr, &qa, &dual);
+        int rc = dm_simnn_core(ctx, B, N1, N2, D, Fy, D, Fx, D, rel_extra, force, a.knn12, nullptr, nullptr, &qa, &dual);
         if (rc) return rc;
         ks_exact_args e0{a.BT, nullptr, a.n2, nullptr, nullptr, K, N1, a.N1pad, N2, a.N2pad, a.Kpad, qa, a.knn12, nullptr, Phi2, ld2};
         ks_exact_args e1 = e0;
@@ -445,5 +461,5 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
     }
     return DM_OK;
 }
-template int dm_launch_fm_split<float>(dm_ctx*, const dm_gred_args&, const double*, int, const double*, int, void*, const float*, int);
-template int dm_launch_fm_split<double>(dm_ctx*, const dm_gred_args&, const double*, int, const double*, int, void*, const double*, int);
+template int dm_launch_fm_split<float>(dm_ctx*, const dm_gred_args&, const double*, int, const double*, int, void*, const float*, int, const dm_fm_split_pre*);
+template int dm_launch_fm_split<double>(dm_ctx*, const dm_gred_args&, const double*, int, const double*, int, void*, const double*, int, const dm_fm_split_pre*);

@@ -16,6 +16,7 @@
 
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
+#include "dm_split.h"
 #include "dm_indicator_dev.h"
 
 static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
@@ -137,12 +138,15 @@ constexpr int EB_BK = 16;     // contraction per stage
 constexpr int EB_LD = 18;     // LDS row stride (f64): 36 dwords -> the 16 rows of a fragment read start on distinct 4-bank groups
 static inline size_t embed_lds(int RT) { return ((size_t)2 * (64 * RT + 64) * EB_LD + 3 * 64 + 8) * sizeof(double); }
 
-template <int RT, bool STORE, typename TR>
+// FX: the basis rows that stream by also leave the kernel as split fp16 rows of the tile kernels (dm_embed_fx: what fs_build_rows_kernel
+// writes in a pass of its own), scaled with the power of two the HINTED maxima give; the thread that stages entries k .. k + 3 of a
+// vertex's row for the matrix cores splits them and stores 8 + 8 bytes (four threads = one vertex's 64 bytes of a 16-index group)
+template <int RT, bool STORE, typename TR, bool FX = false>
 __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __restrict__ Cm, long long strideC, int ldc, int transC,
                                                          const TR* __restrict__ Phi, long long stridePhi, int ld,
                                                          double* __restrict__ embT, int krpad, int Npad, int kr, int N, int K,
                                                          double* __restrict__ nrm, double* __restrict__ amax_part, int ntile_j,
-                                                         int total, int nrg, double* __restrict__ amax_in_part) {
+                                                         int total, int nrg, double* __restrict__ amax_in_part, dm_embed_fx fx) {
     extern __shared__ __attribute__((aligned(16))) double eb_sm[];
     constexpr int RA = 64 * RT;
     double* Abuf = eb_sm;                                   // [2][RA][EB_LD]
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
     // completely inside the contraction (wave-uniform test) is then branch-free.  The generic path handles a ragged last
     // stage and unaligned operands.
     int f_tile = blockIdx.x, f_s = 0, f_rg = 0;           // fetch stream position: tile, row group of the tile, stage
+    double fx_hint_next = 0.0;
     gdouble* fa[RT];
     gfloat* fb = nullptr;
     const long long a_step = transC ? (long long)EB_BK * ldc : EB_BK;
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
         }                                                                                                              \
         fb = (gfloat*)Phi + (long long)b_ * stridePhi + (long long)min(j0_ + srow, N - 1) * ld + sk;                   \
         f_s = 0;                                                                                                       \
+        if constexpr (FX) fx_hint_next = fx.hint[b_];      /* the pair's hinted maximum, a tile ahead of its use */     \
     }
 #define EB_FETCH()                                                                                                     \
     {                                                                                                                  \
@@ -230,6 +236,14 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
         const int b = tile / ntile_j, j0 = (tile - b * ntile_j) * 64;
         double* E = STORE ? embT + (long long)b * krpad * Npad : nullptr;
         double csum[4] = {0.0, 0.0, 0.0, 0.0}, amax = 0.0, inmax = 0.0;   // inmax: max |Phi| over the tile's vertex slab
+        double fx_sx = 1.0;
+        _Float16* fx_row = nullptr;
+        if constexpr (FX) {
+            // (the fetch stream's last EB_SET_TILE before this point was the one for THIS tile -- it ran during the previous tile's last
+            //  stage --; the next one comes during this tile's last stage, after the value has been used)
+            fx_sx = ks_scale(&fx_hint_next, 1);
+            if (j0 + srow < N) fx_row = fx.F + ((long long)b * fx.rows_out + j0 + srow) * fx.D + sk;
+        }
         // more than 64 RT rows: the tile is walked in row groups (the vertex slab is streamed again from L2 for each), the
         // column sums run on across the groups
         for (int rg = 0; rg < nrg; ++rg) {
@@ -250,6 +264,16 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
                 *reinterpret_cast<f64x2*>(Bs + srow * EB_LD + sk + 2) = f64x2{(double)rb[2], (double)rb[3]};
                 if (amax_in_part)                           // (uniform) the basis entries this stage consumes, as they pass by
                     inmax = fmax(fmax(inmax, fmax(fabs((double)rb[0]), fabs((double)rb[1]))), fmax(fabs((double)rb[2]), fabs((double)rb[3])));
+                if constexpr (FX) {
+                    if (rg == 0 && fx_row) {                // (entries beyond K were fetched as 0: zero halves, like the row builder's)
+                        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+                        f16x4_t hv, lv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { _Float16 h_, l_; fs_split_entry<TR>(rb[e], fx_sx, h_, l_); hv[e] = h_; lv[e] = l_; }
+                        *reinterpret_cast<f16x4_t*>(fx_row + 32 * s) = hv;
+                        *reinterpret_cast<f16x4_t*>(fx_row + 32 * s + 16) = lv;
+                    }
+                }
                 __syncthreads();
                 // the buffer written above was last read two stages ago, and every wave has passed a barrier since
                 if (f_tile < total) EB_FETCH()
@@ -311,7 +335,11 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
             }
         }
         if (t == 0 && amax_part) amax_part[(long long)b * ntile_j + (j0 >> 6)] = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
-        if (t == 0 && amax_in_part) amax_in_part[(long long)b * ntile_j + (j0 >> 6)] = fmax(fmax(wmax[4], wmax[5]), fmax(wmax[6], wmax[7]));
+        if (t == 0 && amax_in_part) {
+            const double im = fmax(fmax(wmax[4], wmax[5]), fmax(wmax[6], wmax[7]));
+            amax_in_part[(long long)b * ntile_j + (j0 >> 6)] = im;
+            if (fx.amax_copy) fx.amax_copy[(long long)b * ntile_j + (j0 >> 6)] = im;         // (the next call's hint)
+        }
         // (xs / wmax are rewritten only after the next tile's stage barriers)
         tile += (int)gridDim.x;
     }
@@ -322,7 +350,10 @@ __global__ __launch_bounds__(256, 2) void embed_tile_kernel(const double* __rest
 template <typename TR>
 int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, int ld, const double* Cm, int ldc,
                     long long strideC, int transC, double* embT, int krpad, int Npad, double* nrm, int zero_first,
-                    double* amax_part, double* amax_in_part) {
+                    double* amax_part, double* amax_in_part, const dm_embed_fx* fxp) {
+    dm_embed_fx fx{nullptr, 0, 0, nullptr, 0, nullptr};
+    if (fxp) fx = *fxp;
+    if (fx.F && (embT || !amax_in_part || !fx.hint)) return dm_fail(ctx, DM_EINVAL, "embed: the split-row output rides on the norms-only embedding");
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
     if (embT && zero_first && (kr != krpad || N != Npad))
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
@@ -335,28 +366,28 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, in
     const int by_regs = RT == 1 ? 3 : 2, by_lds = (int)((size_t)160 * 1024 / lds);
     const int per_cu = by_regs < by_lds ? by_regs : by_lds;
     const int grid = total < ncu * per_cu ? total : ncu * per_cu;
+#define EB_LAUNCH1(RT_, ST_, FX_)                                                                                      \
+    {                                                                                                                  \
+        int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, ST_, TR, FX_>, lds);                            \
+        if (rc) return rc;                                                                                             \
+        DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, ST_, TR, FX_>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
+                  (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg, amax_in_part, fx); \
+    }
 #define EB_LAUNCH(RT_)                                                                                                 \
     {                                                                                                                  \
-        if (embT) {                                                                                                    \
-            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, true, TR>, lds);                                \
-            if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, true, TR>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
-                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg, amax_in_part); \
-        } else {                                                                                                       \
-            int rc = dm_grant_lds(ctx, (const void*)embed_tile_kernel<RT_, false, TR>, lds);                               \
-            if (rc) return rc;                                                                                         \
-            DM_LAUNCH(ctx, "embed_nt_f64", (embed_tile_kernel<RT_, false, TR>), dim3(grid), dim3(256), lds, Cm, strideC, ldc, transC, Phi, \
-                      (long long)N * ld, ld, embT, krpad, Npad, kr, N, km, nrm, amax_part, ntile_j, total, nrg, amax_in_part); \
-        }                                                                                                              \
+        if (embT) EB_LAUNCH1(RT_, true, false)                                                                         \
+        else if (fx.F) EB_LAUNCH1(RT_, false, true)                                                                    \
+        else EB_LAUNCH1(RT_, false, false)                                                                             \
     }
     if (RT == 1) EB_LAUNCH(1) else EB_LAUNCH(2)
 #undef EB_LAUNCH
+#undef EB_LAUNCH1
     return DM_OK;
 }
 template int dm_launch_embed<float>(dm_ctx*, int, int, int, int, const float*, int, const double*, int, long long, int, double*, int, int,
-                                    double*, int, double*, double*);
+                                    double*, int, double*, double*, const dm_embed_fx*);
 template int dm_launch_embed<double>(dm_ctx*, int, int, int, int, const double*, int, const double*, int, long long, int, double*, int,
-                                     int, double*, int, double*, double*);
+                                     int, double*, int, double*, double*, const dm_embed_fx*);
 
 // =================================================================================================
 // fused G tile + arg-reductions
@@ -822,11 +853,29 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
     // BT = emb1^T, emb1 = Phi1[:, :k1] C^T (N1 x k2): emb1T[c][j] = sum_m C[c][m] Phi1[j][m];  n1_j = |emb1_j|^2
     rc = dm_launch_embed(ctx, B, N1, k2, k1, Phi1, ld1, C, k1, (long long)k2 * k1, 0, BT, Kpad, N1pad, n1, 1, amaxS);
     if (rc) return rc;
+    // The four-map path's target rows (split fp16 rows of Phi2) need the power-of-two scale of max |Phi2| before the first row is
+    // written: a property of the mesh, not of the map.  The second embedding measures those maxima anyway; a call that finds the
+    // maxima a previous call on the same basis left (dm_ctx::basis_stat) lets the embedding write the rows as the basis streams by
+    // and skips the row builder's pass (134 MB of reads at config 2).  The pass checks the hint against what was measured.
+    dm_ctx::basis_stat* st = (split && ctx->opt_basis_stats) ? dm_stat_entry(ctx, Phi2, B, N2, k2, ld2, (int)sizeof(TR), 1) : nullptr;
+    dm_fm_split_pre pre{nullptr, false, nullptr, nullptr};
+    dm_embed_fx fx{nullptr, 0, 0, nullptr, 0, nullptr};
+    if (split) {
+        int D_ = 0, R2_ = 0;
+        pre.Fx = dm_fm_split_take_fx(ctx, B, N2, k2, &D_, &R2_);
+        if (!pre.Fx) return dm_fail(ctx, DM_ENOMEM, "fm_to_p2p: workspace not reserved");
+        if (st) {
+            // (a buffer = the pairs' maxima of |Phi2|, reduced from the embedding's per-block maxima by the pass's per-row-term workgroups)
+            if (st->valid) { fx.F = pre.Fx; fx.D = D_; fx.rows_out = R2_; fx.hint = st->buf[st->cur]; fx.n_hint = 1; pre.built = true; pre.hint = fx.hint; }
+            pre.pair_out = st->buf[st->cur ^ 1];
+        }
+    }
     if (all) {
         // emb2 = Phi2[:, :k2] C (N2 x k1): emb2T[m][i] = sum_c C[c][m] Phi2[i][c];  only n2_i = |emb2_i|^2 is used
         rc = dm_launch_embed(ctx, B, N2, k1, k2, Phi2, ld2, C, k1, (long long)k2 * k1, 1, (double*)nullptr, K1pad, N2pad, n2, 1,
-                             (double*)nullptr, split ? amaxT : nullptr);
+                             (double*)nullptr, split ? amaxT : nullptr, (split && st) ? &fx : nullptr);
         if (rc) return rc;
+        if (st) { st->cur ^= 1; st->valid = true; }          // (stream order: the next call reads what this launch wrote)
     }
     dm_gred_args a;
     a.B = B; a.N2 = N2; a.N1 = N1; a.Kloop = Kpad;
@@ -839,7 +888,7 @@ static int fm_to_p2p_impl(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, co
     }
     a.knn21 = knn21; a.knn12 = knn12; a.ind21 = ind21; a.ind12 = ind12;
     ctx->last_flag_counts = nullptr;
-    if (split) { a.Ktrue = k2; return dm_launch_fm_split<TR>(ctx, a, amaxS, nS, amaxT, nT, zeroed, Phi2, ld2); }
+    if (split) { a.Ktrue = k2; return dm_launch_fm_split<TR>(ctx, a, amaxS, nS, amaxT, nT, zeroed, Phi2, ld2, &pre); }
     return dm_launch_gred(ctx, a);
 }
 extern "C" int dm_fm_to_p2p(dm_ctx* ctx, int B, int N1, int N2, int k1, int k2, const float* Phi1, int ld1,

@@ -36,3 +36,17 @@ __device__ __forceinline__ void split2_hw(double v, _Float16& hi, _Float16& lo) 
     hi = (_Float16)cvt_f32_f64_hw(v);
     lo = (_Float16)cvt_f32_f64_hw(v - (double)(float)hi);
 }
+
+// one entry of a basis row scaled by the power of two sx and split for the tile kernels (fs_build_rows_kernel and the embedding that
+// writes the same rows on the fly: the same bits).  fp32 basis: x sx, |.| < 2, is exact in fp32 and so is x sx - h: the pieces equal
+// those of the float64 split; fp64 basis: the split runs in float64 (split2_hw)
+template <typename TR>
+__device__ __forceinline__ void fs_split_entry(TR xin, double sx, _Float16& h, _Float16& l) {
+    if constexpr (sizeof(TR) == 4) {
+        const float x = (float)((double)xin * sx);
+        h = (_Float16)x; l = (_Float16)(x - (float)h);
+    } else {
+        split2_hw((double)xin * sx, h, l);
+    }
+}
+

@@ -282,10 +282,10 @@ def _batch_chunk(models, idx, out, n_ev, compute_extra, fit_params, after_eigenb
         from .pyFM.functional import CLOSED_FORM_MAX_K1
         wide = n_ev > CLOSED_FORM_MAX_K1              # (FunctionalMapping.fit: maps wider than the closed form's solvers take the iterative scheme, tight)
         if any(v > 0 for v in general.values()) or wide:
-            from .pyFM.functional import LBFGS_OPTIONS
+            from .pyFM.functional import LBFGS_OPTIONS, LBFGS_WIDE
             x0 = np.stack([m.get_x0(optinit=fp["optinit"]) for m in g])
             C0, res = eng.fit_general(dev, dict(w_descr=fp["w_descr"], w_lap=fp["w_lap"], **general), x0, maxiter=fp["maxiter"],
-                                      lbfgs_options=LBFGS_OPTIONS if (fp["stopping"] == "tight" or wide) else None)
+                                      lbfgs_options=LBFGS_WIDE if wide else (LBFGS_OPTIONS if fp["stopping"] == "tight" else None))
             C0 = np.asarray(C0, dtype=np.float64)
         else:
             res = None
@@ -398,8 +398,7 @@ def compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev=50, compute_e
     streams: the batch is cut into that many contiguous chunks, each run by its own host thread on its own HIP stream (its own
     MatchEngine: context, workspace).  The stages of a chunk depend on each other, the chunks do not: while one chunk's iterative fit
     fills the vector ALUs, another's eigensolver (a chain of a thousand small launches), linear assignments (a workgroup per matrix,
-    latency bound) and host-side bookkeeping run beside it.  Default: 2 chunks from 16 pairs (measured at 64 pairs: 500 ms on one stream, 455 on two, 495 on three, 580 on four -- a
-    chunk's thousand small launches wait for register space behind the other chunks' fit kernels).  A pair's results do
+    latency bound) and host-side bookkeeping run beside it.  Default: one chunk per 64 pairs, at most four (r05, float64 fit: 500 ms on one stream, 455 on two, 495 on three, 580 on four; r06, fp32 element loop and a one-chunk call's assignments started early: 260 / 255-297 / 267-308 ms on one / two / three).  A pair's results do
     not depend on the chunking.
     robust_backend: as for compute_surface_map.  Two host threads may call concurrently when each calls on its own HIP stream."""
     with _robust_backend_for_call(robust_backend):
@@ -444,7 +443,9 @@ def _compute_surface_map_batch(meshes1_t, meshes2_t, c1s, c2s, n_ev, compute_ext
         models.append(model)
     out = [None] * B
     if streams is None:
-        streams = 2 if B >= 16 else 1
+        # r06 (the fit's element loop in fp32: 1.7 x faster): at 64 pairs one chunk -- its assignments started early on side streams --
+        # takes 259-264 ms, two chunks 255-297, three 267-308 (tools/batch_stage_times.py --streams=N): a chunk per 64 pairs
+        streams = min(4, -(-B // 64))
     streams = max(1, min(int(streams), B))
     dev_index = torch.cuda.current_device()
     if streams == 1:

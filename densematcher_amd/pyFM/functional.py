@@ -21,6 +21,8 @@ _OPTIMIZERS = ("L-BFGS-B", "fmin_l_bfgs_b", "l-bfgs-b")
 # 1e-12 332 9e-6, 1e-11 261 4e-5, 1e-10 224 1.3e-4.  1e-12 keeps a factor ten under the 1e-4 bar on C.
 CLOSED_FORM_MAX_K1 = 200          # dm_fmap_solve / dm_fmap_fit: the in-LDS solvers take systems of order <= 199
 LBFGS_OPTIONS = {"ftol": 1e-12, "gtol": 1e-9, "maxcor": 30, "maxfun": 15000}
+# maps wider than the closed form takes (quadratic energy, k^2 > 40 000 unknowns): run until the gradient test or the line search's noise floor
+LBFGS_WIDE = {"ftol": 1e-15, "gtol": 1e-11, "maxcor": 30, "maxfun": 50000}
 
 
 class FunctionalMapping:
@@ -207,7 +209,8 @@ class FunctionalMapping:
                 orient_ops = (np.stack([a for a, _ in fit_ops])[None], np.stack([b for _, b in fit_ops])[None])
             self._verbose_terms(eng, dev, weights, x0, orient_ops, "x0")
             C, res = eng.fit_general(dev, weights, x0[None], maxiter=maxiter,
-                                     lbfgs_options=LBFGS_OPTIONS if stopping == "tight" else None, driver=driver, orient_ops=orient_ops)
+                                     lbfgs_options=(LBFGS_WIDE if wide else LBFGS_OPTIONS) if stopping == "tight" else None, driver=driver,
+                                     orient_ops=orient_ops)
             self.FM = np.asarray(C[0], dtype=np.float64)
             self.fit_result = res
             self._verbose_terms(eng, dev, weights, self.FM, orient_ops, "solution")

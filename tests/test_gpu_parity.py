@@ -925,9 +925,10 @@ def test_eigenbasis_small_mesh_beside_a_large_one(eng):
         w = scipy.linalg.eigh(m.W.toarray(), np.diag(a), eigvals_only=True)
         assert m.eigenvectors.shape == (m.n_vertices, k)
         assert np.abs(m.eigenvalues - w[:k]).max() <= 1e-6 * w[k - 1], m.n_vertices
-    # beyond the dense route's size the refusal stays (k + guard vectors cannot sit in the lower half of 600 eigenvalues)
+    # r06: the dense route takes meshes up to 2048 vertices (600 vertices, k = 290: test_small_meshes_take_the_dense_route); beyond
+    # that the refusal stays (k + guard vectors cannot sit in the lower half of the spectrum)
     with pytest.raises(ValueError, match="dense route"):
-        TriMesh(*synth.torus_mesh(30, 20)).process(k=290)
+        TriMesh(*synth.torus_mesh(60, 40)).process(k=1190)
 
 
 def test_maps_on_gpu_eigenbasis_match_maps_on_host_eigenbasis(eng):
@@ -1019,3 +1020,46 @@ def test_eigenbasis_of_meshes_of_different_sizes_in_one_call(eng):
 
 
 
+
+
+def test_fm_to_p2p_basis_hint_is_checked_not_trusted(eng, fx_cfg2):
+    """r06: the four-map path keeps, per basis tensor, the maxima of |Phi2| a call measured; the next call on the same
+    tensor lets the second embedding write the split target rows as the basis streams by (no fm_split_build_rows pass).  The hint is
+    CHECKED against what the call measures: a tensor rewritten in place with another scale (or another tensor at the same address)
+    sends that pair's rows to the exact path -- the maps stay the float64 arg-reductions either way, and equal the hint-less path's."""
+    fx = fx_cfg2
+    k = int(fx["k"])
+    P1 = torch.as_tensor(np.stack([fx["Phi1"][:, :k]] * 2)).to(eng.device)
+    P2 = torch.as_tensor(np.stack([fx["Phi2"][:, :k]] * 2)).to(eng.device)
+    a1 = torch.as_tensor(np.stack([fx["a1"]] * 2)).to(eng.device)
+    C = torch.as_tensor(np.stack([fx["C_f64"], fx["C_f64"].T.copy()])).to(eng.device)
+    names = ("knn21", "knn12", "ind21", "ind12")
+    eng.set_option("basis_stats", 0)
+    ref = {n: v.cpu().numpy() for n, v in eng.fm_to_p2p(P1, P2, a1, C).items()}
+    eng.set_option("basis_stats", 1)                       # (also forgets every stored hint)
+    launches = []
+    for rep in range(3):
+        eng.profile_kernel("*")
+        out = eng.fm_to_p2p(P1, P2, a1, C)
+        torch.cuda.synchronize()
+        launches.append({n: v[0] for n, v in eng.profile_report().items()})
+        eng.profile_kernel("")
+        for n in names:
+            assert np.array_equal(out[n].cpu().numpy(), ref[n]), (rep, n)
+    assert launches[0].get("fm_split_build_rows", 0) == 1 and launches[1].get("fm_split_build_rows", 0) == 0 and launches[2].get("fm_split_build_rows", 0) == 0
+    flagged_ok = eng.last_requeued_rows()
+    # the same tensor, rewritten in place: pair 1's basis scaled by 2^-7 (another binade: the hint is wrong for it), pair 0 untouched
+    P2[1] *= 2.0 ** -7
+    out = eng.fm_to_p2p(P1, P2, a1, C)
+    flagged_bad = eng.last_requeued_rows()
+    eng.set_option("basis_stats", 0)
+    want = {n: v.cpu().numpy() for n, v in eng.fm_to_p2p(P1, P2, a1, C).items()}
+    eng.set_option("basis_stats", 1)
+    for n in names:
+        assert np.array_equal(out[n].cpu().numpy(), want[n]), n
+    assert flagged_bad[0] >= P2.shape[1] and flagged_ok[0] < P2.shape[1] // 4          # pair 1 went through the exact path whole
+    # ... and the call after that has the right hint again
+    out = eng.fm_to_p2p(P1, P2, a1, C)
+    assert eng.last_requeued_rows()[0] < P2.shape[1] // 4
+    for n in names:
+        assert np.array_equal(out[n].cpu().numpy(), want[n]), n

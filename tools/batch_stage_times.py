@@ -28,6 +28,9 @@ for i in range(B):
     F1, F2, _ = synth.feature_pair(nu * nv, nu * nv, D, 1000 + i, 2000 + i, sigma=0.5, perm="identity")
     m1.append(bench._Duck(v1, f1)); m2.append(bench._Duck(v2, f2)); F1s.append(F1); F2s.append(F2)
 log, t_call = [], [0.0]
+STREAMS = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--streams=")), None)     # (None: the call's default)
+REPS = next((int(a) for a in sys.argv[1:] if a.isdigit()), 8)
+print("streams =", STREAMS if STREAMS else "default", flush=True)
 
 
 def stamp(label, fn):
@@ -45,10 +48,10 @@ for name in ("fit_general", "icp", "precise_map", "lsa_indicator"):
     setattr(MatchEngine, name, stamp(name, getattr(MatchEngine, name)))
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
-    for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
+    for rep in range(REPS):
         log.clear()
         torch.cuda.synchronize(); t_call[0] = time.perf_counter()
-        fmod.compute_surface_map_batch(m1, m2, F1s, F2s, n_ev=k, compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(bench.NOTEBOOK_FIT))
+        fmod.compute_surface_map_batch(m1, m2, F1s, F2s, n_ev=k, compute_extra=True, optimizer="L-BFGS-B", fit_params=dict(bench.NOTEBOOK_FIT), streams=STREAMS)
         torch.cuda.synchronize(); total = 1e3 * (time.perf_counter() - t_call[0])
         tids = sorted({t for t, *_ in log}, key=lambda t: min(x[2] for x in log if x[0] == t))
         line = f"call {rep}: {total:6.1f} ms |"
