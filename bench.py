@@ -129,6 +129,12 @@ def kernel_models(N, D, k, B, eng):
     return {
         "fmap_solve_chol": dict(dtype="f64", bound="mfma", what="k2 SPD solves of order k1-1 per pair: k (n^3/3 + 2 n^2)",
                                 flops=B * k * (n ** 3 / 3.0 + 2.0 * n * n)),
+        # r06: the same k2 solves by the batched Jacobi-preconditioned conjugate-gradient iteration (csrc/dm_pcg.h).  `flops` stays SURVEY
+        # 8(d)'s algorithmic count of the solves (what a direct method spends); the iteration issues 2 n^2 k per step and pair on the
+        # matrix cores (about 24 steps to its tolerance: 0.8 of the algorithmic count at n = 127) -- not quoted as `executed` because the
+        # step count is data dependent
+        "fmap_solve_pcg": dict(dtype="f64", bound="mfma", what="k2 SPD solves of order k1-1 per pair (batched PCG on the matrix cores): k (n^3/3 + 2 n^2)",
+                               flops=B * k * (n ** 3 / 3.0 + 2.0 * n * n)),
         "simnn4_f16_mfma": dict(dtype="f16", bound="mfma", what="G = Phi2 C Phi1^T and its four arg-reductions: 2 N^2 k (float64 flops of the reference)",
                                 flops=2.0 * N * N * k * B, executed=2.0 * N * N * kd * B),
         "simnn2_f16_mfma": dict(dtype="f16", bound="mfma", what="one direction of G: 2 N^2 k", flops=2.0 * N * N * k * B, executed=2.0 * N * N * kd * B),
@@ -1025,7 +1031,8 @@ def pmc_traffic_bytes(kernel, workload):
         mt = re.search(r"simnn_pipe_kernel<\d+, \d+, (\d+)", name)
         return int(mt.group(1)) if mt else None
     match = {"gred_f64": lambda n: "gred_kernel" in n,
-             "fmap_solve_chol": lambda n: "fmap_solve" in n,
+             "fmap_solve_chol": lambda n: "fmap_solve" in n and "pcg" not in n,
+             "fmap_solve_pcg": lambda n: "fmap_solve_pcg" in n,
              "embed_nt_f64": lambda n: "embed_tile_kernel" in n,
              "project_f16split_mfma": lambda n: "proj_f16split_kernel" in n,
              "gram_nt_f64": lambda n: "gemm_nt_f64" in n and "OutScaled" in n,

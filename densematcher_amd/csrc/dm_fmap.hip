@@ -444,6 +444,7 @@ extern "C" int dm_debug_solve_timing(long long* out16) {
 #endif
 
 #include "dm_chol.h"
+#include "dm_pcg.h"
 
 // =================================================================================================
 // Blocked variant (n <= 176): the matrix lives in LDS as 16x16 blocks, lower block triangle, each
@@ -459,7 +460,8 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
                                                                  const double* __restrict__ lam1,
                                                                  const double* __restrict__ lam2, const double* __restrict__ c00,
                                                                  double w_lap, int k1, int k2, int NB, double* __restrict__ C,
-                                                                 int32_t* __restrict__ info) {
+                                                                 int32_t* __restrict__ info, const int32_t* __restrict__ only_if) {
+    if (only_if && only_if[blockIdx.y] == 0) return;       // (the fall-back launch of the batched iteration: flagged pairs only)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = k1 - 1;
     const int nblk = NB * (NB + 1) / 2;
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256) void fmap_solve_2phase_kernel(const double* __
                                                                 const double* __restrict__ lam1, const double* __restrict__ lam2,
                                                                 const double* __restrict__ c00, double w_lap, int k1, int k2,
                                                                 int NB, int B, double* __restrict__ spill, double* __restrict__ C,
-                                                                int32_t* __restrict__ info) {
+                                                                int32_t* __restrict__ info, const int32_t* __restrict__ only_if) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = k1 - 1;
     const int NA = (NB + 1) / 2, NBr = NB - NA;
@@ -600,6 +602,7 @@ __global__ __launch_bounds__(256) void fmap_solve_2phase_kernel(const double* __
 
     for (long long sys = blockIdx.x; sys < (long long)B * k2; sys += gridDim.x) {
         const int b = (int)(sys / k2), i = (int)(sys - (long long)b * k2);
+        if (only_if && only_if[b] == 0) continue;           // (uniform: the fall-back launch of the batched iteration, flagged pairs only)
         const double* P = PQ + (long long)b * (k1 + k2) * k1;
         const double* Q = P + (long long)k1 * k1;
         const double* l1 = lam1 + (long long)b * k1;
@@ -735,9 +738,12 @@ template <int NBT>
 __global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __restrict__ PQ, const double* __restrict__ Timg,
                                                                 const double* __restrict__ lam1, const double* __restrict__ lam2,
                                                                 const double* __restrict__ c00, double w_lap, int k1, int k2, int NBimg,
-                                                                long long nsys, double* __restrict__ C, int32_t* __restrict__ info) {
+                                                                long long nsys, double* __restrict__ C, int32_t* __restrict__ info,
+                                                                const int32_t* __restrict__ only_if) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long sys0 = (long long)blockIdx.x * 4;
+    // only_if (nullable): the direct solver as the fall-back of the batched iteration (dm_pcg.h) -- only the pairs it flagged
+    if (only_if && only_if[(int)(sys0 / k2)] == 0 && only_if[(int)(min(sys0 + 3, nsys - 1) / k2)] == 0) return;
     const long long sys = min(sys0 + wave, nsys - 1);        // (a wave past the end repeats the last system: it takes part in the barriers)
     const int b = (int)(sys / k2), i = (int)(sys - (long long)b * k2);
     const int n = k1 - 1, c = lane & 15, g = lane >> 4;
@@ -849,7 +855,15 @@ static size_t fmap_solve_ws(const dm_ctx* ctx, int B, int k1, int k2) {
     const size_t img_bytes = blocked ? (size_t)B * (NB * (NB + 1) / 2) * 256 * 8 : 0;
     const int NA = (NB + 1) / 2, grid2 = ctx->n_cu > 0 ? ctx->n_cu : 256;
     const size_t spill_bytes = two_phase ? (size_t)grid2 * (NA * (NA + 1) / 2) * 256 * 8 : 0;
-    return dm_align_up(pq_bytes) + dm_align_up(img_bytes) + dm_align_up(spill_bytes) + 4096;
+    const size_t pcgs_bytes = (ctx->opt_solve_pcg && n > 128 && n <= 256) ? pcgs_image_bytes(B, n) : 0;
+    return dm_align_up(pq_bytes) + dm_align_up(img_bytes) + dm_align_up(spill_bytes) + dm_align_up((size_t)B * 4) + dm_align_up(pcgs_bytes) + 4096;
+}
+
+// the batched iteration (dm_pcg.h) takes the systems of order 65 .. 128 (one instantiation: eight row tiles on four waves); whole
+// workgroups of the direct solver must belong to one pair for its fall-back launch (k2 % 4 == 0)
+static inline bool fmap_solve_pcg_ok(const dm_ctx* ctx, int k1, int k2) {
+    const int n = k1 - 1;
+    return ctx->opt_solve_pcg && ctx->opt_solve_reg && !ctx->opt_solve_packed && n >= 65 && n <= 128 && k2 % 4 == 0;
 }
 
 // Gram matrices + the k2 solves per pair; OPA = the stacked rows [A; Bm], OPB = the rows of A (fp32 arrays, or the split-K
@@ -884,6 +898,23 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         default: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 2>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
     }
 
+    const int32_t* only_if_big = nullptr;
+    if ((two_phase || (blocked && NB >= 9)) && ctx->opt_solve_pcg && !ctx->opt_solve_packed) {
+        // r06: systems of order 129 .. 208 by the batched iteration with STREAMED matrix fragments (dm_pcg.h: fmap_solve_pcgs_kernel); the
+        // LDS solvers below then only run the pairs it flagged
+        int32_t* fb = (int32_t*)dm_ws_take(ctx, (size_t)B * 4);
+        double* img = (double*)dm_ws_take(ctx, pcgs_image_bytes(B, n));
+        if (!fb || !img) return dm_fail(ctx, DM_ENOMEM, "fmap_solve: workspace not reserved");
+        DM_CHECK_HIP(ctx, hipMemsetAsync(fb, 0, (size_t)B * 4, ctx->stream));
+        const int NTp = (n + 15) / 16, KSP = pcgs_ksp(n), ngroups = dm_cdiv(k2, PCG_NS);
+        DM_LAUNCH(ctx, "fmap_solve_pcg_pack", pcgs_pack_kernel, dim3(64, B), dim3(256), 0, (const double*)PQ, k1, k2, NTp, KSP, img);
+        const size_t lds_pcg = pcg_lds_bytes(PCGS_NT, PCGS_NW);
+        rc = dm_grant_lds(ctx, (const void*)fmap_solve_pcgs_kernel, lds_pcg);
+        if (rc) return rc;
+        DM_LAUNCH(ctx, "fmap_solve_pcg", fmap_solve_pcgs_kernel, dim3((unsigned)(B * ngroups)), dim3(64 * PCGS_NW), lds_pcg, (const double*)PQ,
+                  (const double*)img, lam1, lam2, c00, w_lap, k1, k2, ngroups, NTp, KSP, 1e-22, 48, 16, 1e-8, C, fb);
+        only_if_big = fb;
+    }
     if (two_phase) {
         const int NBr = NB - NA;
         const size_t lds = ((size_t)(NA * (NA + 1) / 2 + NBr * NA + 2) * 256 + 2 * NB * 16 + 8) * sizeof(double) + (96 + 16 + 128) * sizeof(int);
@@ -891,19 +922,38 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         if (rc) return rc;
         const long long nsys = (long long)B * k2;
         DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_2phase_kernel, dim3((unsigned)(nsys < grid2 ? nsys : grid2)), dim3(256), lds, PQ, Timg,
-                  lam1, lam2, c00, w_lap, k1, k2, NB, B, spill, C, info);
+                  lam1, lam2, c00, w_lap, k1, k2, NB, B, spill, C, info, only_if_big);
         return DM_OK;
     }
     if (blocked && !two_phase && NB <= 8 && ctx->opt_solve_reg) {
         // register-resident solver: one wave per system, four systems per CU (dm_chol_reg.h)
         const long long nsys = (long long)B * k2;
         const dim3 grid((unsigned)((nsys + 3) / 4));
+        const int32_t* only_if = nullptr;
+        if (fmap_solve_pcg_ok(ctx, k1, k2)) {
+            // r06: the batched Jacobi-preconditioned conjugate-gradient iteration first (dm_pcg.h); the direct solver below then only
+            // runs the pairs whose iteration did not converge or met a non-positive curvature (its workgroups of the other pairs leave
+            // at once)
+            int32_t* fb = (int32_t*)dm_ws_take(ctx, (size_t)B * 4);
+            if (!fb) return dm_fail(ctx, DM_ENOMEM, "fmap_solve: workspace not reserved");
+            DM_CHECK_HIP(ctx, hipMemsetAsync(fb, 0, (size_t)B * 4, ctx->stream));
+            const int ngroups = dm_cdiv(k2, PCG_NS);
+            const size_t lds_pcg = pcg_lds_bytes(8, 4);
+            rc = dm_grant_lds(ctx, (const void*)fmap_solve_pcg_kernel<8, 4>, lds_pcg);
+            if (rc) return rc;
+            // stop at a relative reduction of 1e-22 of r^T M^-1 r (1e-11 in that norm: the iterate is within ~1e-10 of the direct
+            // solution at cond = 1e2; the bar on C is 1e-4, the closed form's own distance to the float64 minimiser 6e-8); at most 48
+            // steps, and a pair whose reduction is still above 1e-8 after 16 goes to the direct solver at once
+            DM_LAUNCH(ctx, "fmap_solve_pcg", (fmap_solve_pcg_kernel<8, 4>), dim3((unsigned)(B * ngroups)), dim3(256), lds_pcg, PQ, lam1, lam2, c00,
+                      w_lap, k1, k2, ngroups, 1e-22, 48, 16, 1e-8, C, fb);
+            only_if = fb;
+        }
 #define DM_SOLVE_REG(NBT_)                                                                                             \
         {                                                                                                              \
             rc = dm_grant_lds(ctx, (const void*)fmap_solve_reg_kernel<NBT_>, solve_reg_lds(NBT_));                     \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_reg_kernel<NBT_>, grid, dim3(256), solve_reg_lds(NBT_), PQ, Timg, lam1, lam2, \
-                      c00, w_lap, k1, k2, NB, nsys, C, info);                                                          \
+                      c00, w_lap, k1, k2, NB, nsys, C, info, only_if);                                                 \
         }
         if (NB <= 2) DM_SOLVE_REG(2)
         else if (NB <= 4) DM_SOLVE_REG(4)
@@ -918,7 +968,7 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         rc = dm_grant_lds(ctx, (const void*)fmap_solve_blocked_kernel, lds);
         if (rc) return rc;
         DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_blocked_kernel, dim3(k2, B), dim3(256), lds, PQ, Timg, lam1, lam2, c00,
-                  w_lap, k1, k2, NB, C, info);
+                  w_lap, k1, k2, NB, C, info, only_if_big);
         return DM_OK;
     }
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 16 ? 16 : n + 1) + 4) * sizeof(double);

@@ -1063,3 +1063,47 @@ def test_fm_to_p2p_basis_hint_is_checked_not_trusted(eng, fx_cfg2):
     assert eng.last_requeued_rows()[0] < P2.shape[1] // 4
     for n in names:
         assert np.array_equal(out[n].cpu().numpy(), want[n]), n
+
+
+@pytest.mark.parametrize("k,N", [(128, 640), (100, 512), (68, 400), (200, 900), (150, 700)])
+def test_solver_batched_pcg_equals_direct(eng, k, N):
+    """r06: the k2 systems of a pair by the batched Jacobi-preconditioned conjugate-gradient iteration on the float64 matrix cores
+    (csrc/dm_pcg.h; orders 65 .. 128 with the matrix in registers, 129 .. 199 with streamed fragments) against the direct solvers
+    (dm_set_option solve_pcg = 0): the maps agree to 1e-9, the iteration's kernel ran, and rank-deficient descriptors -- which it cannot
+    finish in its step budget -- come back from the direct solver bit for bit (the fall-back launch)"""
+    from densematcher_amd import synth
+    B, D = 3, 96
+    bases = [synth.random_basis(N, k, 40 + q) for q in range(2 * B)]
+    st = lambda q0, j: np.stack([bases[2 * b + q0][j] for b in range(B)])
+    lam1, lam2, P1, P2, a1, a2 = st(0, 0), st(1, 0), st(0, 1).astype(np.float32), st(1, 1).astype(np.float32), st(0, 2).astype(np.float32), st(1, 2).astype(np.float32)
+    F = [synth.feature_pair(N, N, D, 70 + b, 80 + b, sigma=0.3, perm="identity") for b in range(B)]
+    F1, F2 = np.stack([f[0] for f in F]), np.stack([f[1] for f in F])
+
+    def fit(pcg, F1_, F2_):
+        eng.set_option("solve_pcg", pcg)
+        eng.profile_kernel("*")
+        C = eng.fmap_fit(P1, P2, a1, a2, F1_, F2_, lam1, lam2, 1e4, 1e3, k1=k, k2=k).cpu().numpy()
+        names = set(eng.profile_report())
+        eng.profile_kernel("")
+        return C, names
+    try:
+        Cd, nd = fit(0, F1, F2)
+        Cp, npcg = fit(1, F1, F2)
+        assert "fmap_solve_pcg" in npcg and "fmap_solve_pcg" not in nd
+        err = np.abs(Cp - Cd).max()
+        print(f"k = {k}: max |C_pcg - C_direct| = {err:.2e}")
+        assert err <= 1e-9 * max(1.0, np.abs(Cd).max())
+        for b in range(B):
+            Co = orc.fit(P1[b], P2[b], lam1[b], lam2[b], a1[b], a2[b], F1[b], F2[b], 1e4, 1e3)
+            assert np.abs(Cp[b] - Co).max() <= 1e-4
+        # 20 distinct channels: P = A A^T has rank 20 < k - 1, the systems are held up by the Laplacian term alone (cond ~ 1e6)
+        Fr1 = np.tile(F1[:, :, :20], (1, 1, 5))[:, :, :D].copy()
+        Fr2 = np.tile(F2[:, :, :20], (1, 1, 5))[:, :, :D].copy()
+        Cd, _ = fit(0, Fr1, Fr2)
+        Cp, npcg = fit(1, Fr1, Fr2)
+        same = np.array_equal(Cp, Cd)
+        print(f"k = {k}, rank-20 descriptors: bit-identical to the direct solver (fall-back): {same}; max diff {np.abs(Cp - Cd).max():.2e}")
+        assert "fmap_solve_chol" in npcg                                    # the fall-back launch is always there
+        assert same or np.abs(Cp - Cd).max() <= 1e-7 * max(1.0, np.abs(Cd).max())
+    finally:
+        eng.set_option("solve_pcg", 1)
