@@ -921,7 +921,7 @@ def roofline_block(kernel, model, launches, avg_ms, workload, table, kernel_ms_p
     out["traffic"] = traffic
     out["traffic_source"] = (f"HBM bytes per launch from the rocprofv3 PMC passes of this command on this code (profiles/{traffic_file}, "
                              f"csrc_sha16 {_SHA[0] if _SHA else None}: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)") if traffic else \
-        "no PMC summary of this code under profiles/ (tools/prof_all_r05.sh writes one): not quoted"
+        "no PMC summary of this code under profiles/ (tools/prof_all_r06.sh writes one): not quoted"
     out["peak_measured"] = measured_peaks(eng)
     if out.get("achieved") and model["dtype"] == "f16":
         out["frac_of_measured_peak_random_operands"] = round(out["achieved"] / out["peak_measured"]["mfma_f16_random_operands_tflops"], 4)
@@ -1002,7 +1002,7 @@ def parity_block(eng):
         return {"error": repr(e)}
 
 
-ROUND = "r05"
+ROUND = "r06"
 
 
 def csrc_sha16():
@@ -1021,7 +1021,7 @@ _SHA = []
 
 def pmc_traffic_bytes(kernel, workload):
     """HBM bytes per launch of a kernel, measured in separate rocprofv3 --pmc passes of this same command (PMC collection cannot
-    run inside the timed region; tools/prof_all_r05.sh), summaries committed under profiles/.  Only THIS round's summary is read,
+    run inside the timed region; tools/prof_all_r06.sh), summaries committed under profiles/.  Only THIS round's summary is read,
     and only when its `# csrc_sha16:` line equals the hash of the kernel sources now in the tree: a number measured on other code
     is not quoted -- the caller then reports traffic = null."""
     import csv
