@@ -912,7 +912,7 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         rc = dm_grant_lds(ctx, (const void*)fmap_solve_pcgs_kernel, lds_pcg);
         if (rc) return rc;
         DM_LAUNCH(ctx, "fmap_solve_pcg", fmap_solve_pcgs_kernel, dim3((unsigned)(B * ngroups)), dim3(64 * PCGS_NW), lds_pcg, (const double*)PQ,
-                  (const double*)img, lam1, lam2, c00, w_lap, k1, k2, ngroups, NTp, KSP, 1e-22, 48, 16, 1e-8, C, fb);
+                  (const double*)img, lam1, lam2, c00, w_lap, k1, k2, ngroups, NTp, KSP, 1e-22, 48, 6, 3e-4, C, fb);
         only_if_big = fb;
     }
     if (two_phase) {
@@ -943,9 +943,11 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
             if (rc) return rc;
             // stop at a relative reduction of 1e-22 of r^T M^-1 r (1e-11 in that norm: the iterate is within ~1e-10 of the direct
             // solution at cond = 1e2; the bar on C is 1e-4, the closed form's own distance to the float64 minimiser 6e-8); at most 48
-            // steps, and a pair whose reduction is still above 1e-8 after 16 goes to the direct solver at once
+            // steps, and a pair whose reduction is still above 3e-4 after 6 goes to the direct solver at once (measured on three
+            // descriptor families x three weightings, profiles/r06_solver_jacobi_pcg_experiment.txt: <= 4.7e-5 after six steps where
+            // the iteration finishes in 20 - 29, >= 2.4e-3 for rank-deficient descriptors, which would need more than 48)
             DM_LAUNCH(ctx, "fmap_solve_pcg", (fmap_solve_pcg_kernel<8, 4>), dim3((unsigned)(B * ngroups)), dim3(256), lds_pcg, PQ, lam1, lam2, c00,
-                      w_lap, k1, k2, ngroups, 1e-22, 48, 16, 1e-8, C, fb);
+                      w_lap, k1, k2, ngroups, 1e-22, 48, 6, 3e-4, C, fb);
             only_if = fb;
         }
 #define DM_SOLVE_REG(NBT_)                                                                                             \

@@ -12,7 +12,7 @@
 //     v_mfma_f64_16x16x4_f64 for the whole iteration (128 doubles per lane at k = 128; one wave per SIMD);
 //   * the direction block lives in the LDS (the B operand: one ds_read_b64 per two matrix instructions), x / r / p in registers in
 //     the accumulator layout, so every vector update is in-lane;
-//   * the two inner products per step are column sums: in-lane, two DPP-free shuffles across the four row groups of a lane's column,
+//   * the two inner products per step are column sums: in-lane, two lane swaps across the four row groups of a lane's column,
 //     four partials per column through the LDS, added in wave order by everybody (every wave holds every column's total: the
 //     stopping test is wave-uniform without a flag).
 // Arithmetic per step and pair: 2 n^2 k2 flops against (n^3 / 3 + 2 n^2) k2 of the factorisations: 17 steps = 0.27 of the flops at
@@ -29,13 +29,24 @@ static inline size_t pcg_lds_bytes(int NT, int NW) { return ((size_t)NT * 16 * P
 
 // sum over the rows of a column (= over a system's unknowns) of the per-lane partials v[ct]: across the lane's four row groups by
 // shuffles, across the waves through `red` (NW x 32 doubles), every lane ends with the totals of its two columns, added in wave order
+// sum over the four 16-lane rows of a wave, the same total (and the same order of additions) in every row: (row 0 + row 1) + (row 2 + row 3).
+// Two swaps on the vector ALU per step and half -- v_permlane16_swap: odd rows of the first operand <-> even rows of the second;
+// v_permlane32_swap: the halves -- instead of two dependent ds_bpermute round trips (__shfl_xor).
+__device__ __forceinline__ double pcg_rows4_sum(double v) {
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double e = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    lo = (unsigned)__double2loint(e); hi = (unsigned)__double2hiint(e);
+    const auto c = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)d[0], (int)c[0]) + __hiloint2double((int)d[1], (int)c[1]);
+}
+
 template <int NW>
 __device__ __forceinline__ void pcg_colsum(double (&v)[2], double* red, int wave, int lane) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        v[ct] += __shfl_xor(v[ct], 16);
-        v[ct] += __shfl_xor(v[ct], 32);
-    }
+    for (int ct = 0; ct < 2; ++ct) v[ct] = pcg_rows4_sum(v[ct]);
     if (lane < 16) { red[wave * PCG_NS + lane] = v[0]; red[wave * PCG_NS + 16 + lane] = v[1]; }
     __syncthreads();
     const int l15 = lane & 15;
@@ -147,14 +158,35 @@ __global__ __launch_bounds__(64 * NW, 1) void fmap_solve_pcg_kernel(const double
         for (int rt = 0; rt < RTW; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = f64x4{0.0, 0.0, 0.0, 0.0};
+        // the B operands of a group of four k-steps are requested a whole group (16 matrix instructions) ahead of their use: with one wave
+        // per SIMD nothing else covers an LDS round trip (the compiler's own schedule asked for a k-step's pair two instructions ahead and
+        // waited lgkmcnt(0) in front of every fourth one)
+        constexpr int G = 4, NG = KS / G;
+        static_assert(KS % G == 0, "whole groups of k-steps");
+        double bq[2][G][2];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const double b0 = pL[(4 * s + lg) * PCG_LDP + l15], b1 = pL[(4 * s + lg) * PCG_LDP + 16 + l15];
+        for (int u = 0; u < G; ++u) { bq[0][u][0] = pL[(4 * u + lg) * PCG_LDP + l15]; bq[0][u][1] = pL[(4 * u + lg) * PCG_LDP + 16 + l15]; }
 #pragma unroll
-            for (int rt = 0; rt < RTW; ++rt) {
-                acc[rt][0] = mfma_f64_16x16x4(Pf[rt][s], b0, acc[rt][0]);
-                acc[rt][1] = mfma_f64_16x16x4(Pf[rt][s], b1, acc[rt][1]);
+        for (int gq = 0; gq < NG; ++gq) {
+            if (gq + 1 < NG) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int sn = (gq + 1) * G + u;
+                    bq[(gq + 1) & 1][u][0] = pL[(4 * sn + lg) * PCG_LDP + l15];
+                    bq[(gq + 1) & 1][u][1] = pL[(4 * sn + lg) * PCG_LDP + 16 + l15];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int s = gq * G + u;
+#pragma unroll
+                for (int rt = 0; rt < RTW; ++rt) {
+                    acc[rt][0] = mfma_f64_16x16x4(Pf[rt][s], bq[gq & 1][u][0], acc[rt][0]);
+                    acc[rt][1] = mfma_f64_16x16x4(Pf[rt][s], bq[gq & 1][u][1], acc[rt][1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // + diag(dd) p;  p . Ap
         part[0] = part[1] = 0.0;
@@ -365,6 +397,8 @@ __global__ __launch_bounds__(64 * PCGS_NW, 1) void fmap_solve_pcgs_kernel(const 
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int rt = 0; rt < RTW; ++rt) a_nxt[u][rt] = has[rt] ? ap[rt][(long long)(sn + u) * 64] : 0.0;
+            // (the B operands are read where they are used: requested a group ahead like the n <= 128 kernel's they cost 27 more spilled
+            //  registers here -- 256 per wave -- and 5 % of the kernel, measured)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int s = s0 + u;
