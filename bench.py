@@ -568,6 +568,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, host, k)
     out["summary"] = compact_summary(summary, pcie)
+    # (the headline's own figures once more, so that the kept tail of the line stands alone)
+    out["summary"]["headline"] = {"pairs_s": out["value"], "step_ms": out["ms_per_step"], "kernel": roof.get("kernel"),
+                                  "kernel_ms": roof.get("avg_launch_ms"), "frac": roof.get("frac"), "frac_executed": roof.get("frac_executed"),
+                                  "traffic_B": roof.get("traffic"), "cpu_pairs_s": (out.get("cpu_baseline") or {}).get("value")}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
