@@ -91,3 +91,46 @@ def test_bench_rccl_branch_on_one_device():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["config"]["process_group"] == "nccl" and out["value"] > 0
+
+
+def _worker_refine(rank, world, port, B, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from densematcher_amd import shard
+    from densematcher_amd.engine import MatchEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = _batch(B)
+    C0 = np.stack([np.eye(10)] * B)
+    fac = lambda: MatchEngine(0)
+    z = shard.run_sharded("zoomout", {"Phi1": b["Phi1"], "Phi2": b["Phi2"], "a2": b["a2"], "C0": C0}, fac, rank, world, nit=4, step=2)
+    i = shard.run_sharded("icp", {"Phi1": b["Phi1"][:, :, :18], "Phi2": b["Phi2"][:, :, :18], "C0": np.stack([np.eye(18)] * B)}, fac, rank, world, nit=3)
+    n = shard.run_sharded("simnn", {"F1": b["F1"], "F2": b["F2"]}, fac, rank, world)
+    dist.barrier()
+    if rank == 0:
+        q.put({"zC": z["C"].cpu().numpy(), "zp": z["p2p21"].cpu().numpy(), "iC": i["C"].cpu().numpy(), "nn": n["nn21"].cpu().numpy()})
+    dist.destroy_process_group()
+
+
+def test_run_sharded_refinements_real_engine_two_ranks():
+    """r06: ZoomOut, ICP and the feature NN through shard.run_sharded on two ranks (one device) equal the un-sharded
+    engine calls bit for bit -- a pair's result does not depend on the rank that computed it"""
+    B = 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_refine, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    from densematcher_amd.engine import MatchEngine
+    eng = MatchEngine(0)
+    b = _batch(B)
+    C, p21 = eng.zoomout(b["Phi1"], b["Phi2"], b["a2"], np.stack([np.eye(10)] * B), nit=4, step=2, return_p2p=True)
+    assert np.array_equal(got["zC"], C.cpu().numpy()) and np.array_equal(got["zp"], p21.cpu().numpy())
+    Ci = eng.icp(b["Phi1"][:, :, :18], b["Phi2"][:, :, :18], np.stack([np.eye(18)] * B), nit=3)
+    assert np.array_equal(got["iC"], Ci.cpu().numpy())
+    assert np.array_equal(got["nn"], eng.simnn(b["F2"], b["F1"]).cpu().numpy())
