@@ -86,6 +86,13 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *   "p2pfm_direct"  1 | 0   dm_p2p_to_fm (and the p2p_to_FM steps of dm_zoomout / dm_icp): register-resident tiles, operands straight
  *                           from global memory, fixed-order in-workgroup reduction | LDS-staged 64 x 64 tiles + split-K partials + reduce
  *   "simnn1_wt"     4 | 2   tile shape of the fused ZoomOut search: 8 waves, 256 x 256 | 4 waves, 128 x 256 (two workgroups per CU)
+ *   "solve_pcg"     1 | 0   dm_fmap_solve / dm_fmap_fit, 66 <= k1 <= 200: the k2 systems of a pair by a batched Jacobi-preconditioned
+ *                           conjugate-gradient iteration on the float64 matrix cores (stops at a 1e-11 relative reduction: C within 1e-9 of
+ *                           the direct solution; ill-conditioned pairs leave it after six steps and take the direct solver) | direct
+ *                           solvers only.  The two settings agree to 1e-9, not bit for bit.
+ *   "basis_stats"   1 | 0   dm_fm_to_p2p: keep the maximum of |Phi2| per basis tensor between calls (a checked hint: the target operand's
+ *                           fp16 rows are then written while the basis streams through the second embedding) | every call takes its own
+ *                           pass over the basis.  Same results.
  *   "fit_f32"       0 | 1   dm_fmap_fit_fused: the element loop over the N2 x N1 entries of the mapped indicator in float64 | in fp32,
  *                           the precision the reference evaluates these terms in (pyFM/functional.py:379-383).  The ONE option whose two
  *                           settings differ in the result: energy / gradient within 1e-6 relative, the fitted map within 3e-6 under
