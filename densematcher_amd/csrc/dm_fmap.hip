@@ -895,7 +895,7 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         case 1: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 1>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
         case 4: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 4>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
         case 3: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 3>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
-        default: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 2>), grid, dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
+        default: DM_LAUNCH(ctx, "gram_nt_f64", (gemm_nt_f64<OPA, OPB, OutScaled, 2, true>), dim3(grid.x * (unsigned)B), dim3(256), 0, opa, opb, out, k1 + k2, k1, D); break;
     }
 
     const int32_t* only_if_big = nullptr;

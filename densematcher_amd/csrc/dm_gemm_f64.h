@@ -147,13 +147,19 @@ __device__ __forceinline__ void gemm_nt_body(const OpA& opa, const OpB& opb, int
 // a stage is 32 matrix instructions per wave (~1 us), a global round trip ~2 us, so short products (K = 128: four stages) wait
 // for their operands every stage; NPRE = 2 - 4 keeps that many stages in flight (the loads past the last stage re-read it:
 // unconditional, so the compiler counts them instead of waiting for all).  Same sums in the same order.
-template <class OpA, class OpB, class Out, int NPRE = 1>
+// XCD: a one-dimensional grid of (pairs x tiles) workgroups in an XCD-aware order -- the tiles of a pair run on ONE XCD, so the operand
+// panels they share are fetched into one L2 instead of eight (the headline's Gram product: 8 tiles per pair, 351 MB fetched for 100 MB
+// of operands when its tiles were dealt round-robin over the XCDs)
+template <class OpA, class OpB, class Out, int NPRE = 1, bool XCD = false>
 __global__ __launch_bounds__(256) void gemm_nt_f64(OpA opa, OpB opb, Out out, int M, int N, int K) {
     __shared__ double As[NT_T * NT_LD];
     __shared__ double Bs[NT_T * NT_LD];
     const int tiles_j = (N + NT_T - 1) / NT_T;
-    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
-    const int b = blockIdx.z;
+    const int tiles_all = ((M + NT_T - 1) / NT_T) * tiles_j;
+    const int vid = XCD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int tile_id = XCD ? vid % tiles_all : vid;
+    const int ti = tile_id / tiles_j, tj = tile_id % tiles_j;
+    const int b = XCD ? vid / tiles_all : (int)blockIdx.z;
     const int i0 = ti * NT_T, j0 = tj * NT_T;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
