@@ -1048,6 +1048,20 @@ def test_fm_to_p2p_basis_hint_is_checked_not_trusted(eng, fx_cfg2):
             assert np.array_equal(out[n].cpu().numpy(), ref[n]), (rep, n)
     assert launches[0].get("fm_split_build_rows", 0) == 1 and launches[1].get("fm_split_build_rows", 0) == 0 and launches[2].get("fm_split_build_rows", 0) == 0
     flagged_ok = eng.last_requeued_rows()
+    # the SOURCE rows ride on the first embedding with the scale of max |Phi1 C^T| of the previous call on the same Phi1 tensor; a map of
+    # another magnitude (pair 1: C x 64, another binade) gets that pair's rows rebuilt by knn_split_build -- same results as without hints
+    C2 = C.clone()
+    C2[1] *= 64.0
+    out2 = eng.fm_to_p2p(P1, P2, a1, C2)
+    eng.set_option("basis_stats", 0)
+    want2 = {n: v.cpu().numpy() for n, v in eng.fm_to_p2p(P1, P2, a1, C2).items()}
+    eng.set_option("basis_stats", 1)
+    for n in names:
+        assert np.array_equal(out2[n].cpu().numpy(), want2[n]), n
+    for rep in range(2):                                   # (refill the hints for the part below)
+        out = eng.fm_to_p2p(P1, P2, a1, C)
+        for n in names:
+            assert np.array_equal(out[n].cpu().numpy(), ref[n]), n
     # the same tensor, rewritten in place: pair 1's basis scaled by 2^-7 (another binade: the hint is wrong for it), pair 0 untouched
     P2[1] *= 2.0 ** -7
     out = eng.fm_to_p2p(P1, P2, a1, C)
