@@ -10,6 +10,7 @@
 
 #include "dm_gemm_f64.h"
 #include "dm_internal.h"
+#include "dm_pcg.h"
 
 // =================================================================================================
 // dm_project:  Ared[b] = Phi[b][:, :k]^T (mass[b] * F[b])
@@ -444,7 +445,6 @@ extern "C" int dm_debug_solve_timing(long long* out16) {
 #endif
 
 #include "dm_chol.h"
-#include "dm_pcg.h"
 
 // =================================================================================================
 // Blocked variant (n <= 176): the matrix lives in LDS as 16x16 blocks, lower block triangle, each
@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256) void fmap_solve_blocked_kernel(const double* _
                                                                  const double* __restrict__ lam1,
                                                                  const double* __restrict__ lam2, const double* __restrict__ c00,
                                                                  double w_lap, int k1, int k2, int NB, double* __restrict__ C,
-                                                                 int32_t* __restrict__ info, const int32_t* __restrict__ only_if) {
-    if (only_if && only_if[blockIdx.y] == 0) return;       // (the fall-back launch of the batched iteration: flagged pairs only)
+                                                                 int32_t* __restrict__ info, const int32_t* __restrict__ only_if, int only_ng) {
+    if (only_if && !pcg_flagged(only_if, only_ng, (int)blockIdx.y)) return;       // (the fall-back launch of the batched iteration: flagged pairs only)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = k1 - 1;
     const int nblk = NB * (NB + 1) / 2;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void fmap_solve_2phase_kernel(const double* __
                                                                 const double* __restrict__ lam1, const double* __restrict__ lam2,
                                                                 const double* __restrict__ c00, double w_lap, int k1, int k2,
                                                                 int NB, int B, double* __restrict__ spill, double* __restrict__ C,
-                                                                int32_t* __restrict__ info, const int32_t* __restrict__ only_if) {
+                                                                int32_t* __restrict__ info, const int32_t* __restrict__ only_if, int only_ng) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int n = k1 - 1;
     const int NA = (NB + 1) / 2, NBr = NB - NA;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void fmap_solve_2phase_kernel(const double* __
 
     for (long long sys = blockIdx.x; sys < (long long)B * k2; sys += gridDim.x) {
         const int b = (int)(sys / k2), i = (int)(sys - (long long)b * k2);
-        if (only_if && only_if[b] == 0) continue;           // (uniform: the fall-back launch of the batched iteration, flagged pairs only)
+        if (only_if && !pcg_flagged(only_if, only_ng, b)) continue;   // (uniform: the fall-back launch of the batched iteration, flagged pairs only)
         const double* P = PQ + (long long)b * (k1 + k2) * k1;
         const double* Q = P + (long long)k1 * k1;
         const double* l1 = lam1 + (long long)b * k1;
@@ -739,11 +739,11 @@ __global__ __launch_bounds__(256, 1) void fmap_solve_reg_kernel(const double* __
                                                                 const double* __restrict__ lam1, const double* __restrict__ lam2,
                                                                 const double* __restrict__ c00, double w_lap, int k1, int k2, int NBimg,
                                                                 long long nsys, double* __restrict__ C, int32_t* __restrict__ info,
-                                                                const int32_t* __restrict__ only_if) {
+                                                                const int32_t* __restrict__ only_if, int only_ng) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long sys0 = (long long)blockIdx.x * 4;
     // only_if (nullable): the direct solver as the fall-back of the batched iteration (dm_pcg.h) -- only the pairs it flagged
-    if (only_if && only_if[(int)(sys0 / k2)] == 0 && only_if[(int)(min(sys0 + 3, nsys - 1) / k2)] == 0) return;
+    if (only_if && !pcg_flagged(only_if, only_ng, (int)(sys0 / k2)) && !pcg_flagged(only_if, only_ng, (int)(min(sys0 + 3, nsys - 1) / k2))) return;
     const long long sys = min(sys0 + wave, nsys - 1);        // (a wave past the end repeats the last system: it takes part in the barriers)
     const int b = (int)(sys / k2), i = (int)(sys - (long long)b * k2);
     const int n = k1 - 1, c = lane & 15, g = lane >> 4;
@@ -856,7 +856,7 @@ static size_t fmap_solve_ws(const dm_ctx* ctx, int B, int k1, int k2) {
     const int NA = (NB + 1) / 2, grid2 = ctx->n_cu > 0 ? ctx->n_cu : 256;
     const size_t spill_bytes = two_phase ? (size_t)grid2 * (NA * (NA + 1) / 2) * 256 * 8 : 0;
     const size_t pcgs_bytes = (ctx->opt_solve_pcg && n > 128 && n <= 256) ? pcgs_image_bytes(B, n) : 0;
-    return dm_align_up(pq_bytes) + dm_align_up(img_bytes) + dm_align_up(spill_bytes) + dm_align_up((size_t)B * 4) + dm_align_up(pcgs_bytes) + 4096;
+    return dm_align_up(pq_bytes) + dm_align_up(img_bytes) + dm_align_up(spill_bytes) + dm_align_up((size_t)B * dm_cdiv(k2, 32) * 4) + dm_align_up(pcgs_bytes) + 4096;
 }
 
 // the batched iteration (dm_pcg.h) takes the systems of order 65 .. 128 (one instantiation: eight row tiles on four waves); whole
@@ -887,7 +887,10 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
     double* spill = two_phase ? (double*)dm_ws_take(ctx, spill_bytes) : nullptr;
     if (!PQ || (blocked && !Timg) || (two_phase && !spill)) return dm_fail(ctx, DM_ENOMEM, "fmap_solve: workspace not reserved");
     if (blocked) DM_CHECK_HIP(ctx, hipMemsetAsync(Timg, 0, img_bytes, ctx->stream));
-    DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
+    const bool pcg_small = blocked && !two_phase && NB <= 8 && ctx->opt_solve_reg && fmap_solve_pcg_ok(ctx, k1, k2);
+    const bool pcg_big = (two_phase || (blocked && NB >= 9)) && ctx->opt_solve_pcg && !ctx->opt_solve_packed;
+    // (with the batched iteration in front, its group-0 workgroups clear the status words: one memset launch less per call)
+    if (!pcg_small && !pcg_big) DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
 
     OutScaled out{PQ, (long long)(k1 + k2) * k1, k1, w_descr, Timg, (long long)(NB * (NB + 1) / 2) * 256, k1};
     dim3 grid(dm_cdiv(k1 + k2, NT_T) * dm_cdiv(k1, NT_T), 1, B);
@@ -899,20 +902,20 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
     }
 
     const int32_t* only_if_big = nullptr;
-    if ((two_phase || (blocked && NB >= 9)) && ctx->opt_solve_pcg && !ctx->opt_solve_packed) {
+    const int only_ng = dm_cdiv(k2, PCG_NS);
+    if (pcg_big) {
         // r06: systems of order 129 .. 208 by the batched iteration with STREAMED matrix fragments (dm_pcg.h: fmap_solve_pcgs_kernel); the
         // LDS solvers below then only run the pairs it flagged
-        int32_t* fb = (int32_t*)dm_ws_take(ctx, (size_t)B * 4);
+        int32_t* fb = (int32_t*)dm_ws_take(ctx, (size_t)B * only_ng * 4);
         double* img = (double*)dm_ws_take(ctx, pcgs_image_bytes(B, n));
         if (!fb || !img) return dm_fail(ctx, DM_ENOMEM, "fmap_solve: workspace not reserved");
-        DM_CHECK_HIP(ctx, hipMemsetAsync(fb, 0, (size_t)B * 4, ctx->stream));
         const int NTp = (n + 15) / 16, KSP = pcgs_ksp(n), ngroups = dm_cdiv(k2, PCG_NS);
         DM_LAUNCH(ctx, "fmap_solve_pcg_pack", pcgs_pack_kernel, dim3(64, B), dim3(256), 0, (const double*)PQ, k1, k2, NTp, KSP, img);
         const size_t lds_pcg = pcg_lds_bytes(PCGS_NT, PCGS_NW);
         rc = dm_grant_lds(ctx, (const void*)fmap_solve_pcgs_kernel, lds_pcg);
         if (rc) return rc;
         DM_LAUNCH(ctx, "fmap_solve_pcg", fmap_solve_pcgs_kernel, dim3((unsigned)(B * ngroups)), dim3(64 * PCGS_NW), lds_pcg, (const double*)PQ,
-                  (const double*)img, lam1, lam2, c00, w_lap, k1, k2, ngroups, NTp, KSP, 1e-22, 48, 6, 3e-4, C, fb);
+                  (const double*)img, lam1, lam2, c00, w_lap, k1, k2, ngroups, NTp, KSP, 1e-22, 48, 6, 3e-4, C, fb, info);
         only_if_big = fb;
     }
     if (two_phase) {
@@ -922,7 +925,7 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         if (rc) return rc;
         const long long nsys = (long long)B * k2;
         DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_2phase_kernel, dim3((unsigned)(nsys < grid2 ? nsys : grid2)), dim3(256), lds, PQ, Timg,
-                  lam1, lam2, c00, w_lap, k1, k2, NB, B, spill, C, info, only_if_big);
+                  lam1, lam2, c00, w_lap, k1, k2, NB, B, spill, C, info, only_if_big, only_ng);
         return DM_OK;
     }
     if (blocked && !two_phase && NB <= 8 && ctx->opt_solve_reg) {
@@ -930,13 +933,12 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         const long long nsys = (long long)B * k2;
         const dim3 grid((unsigned)((nsys + 3) / 4));
         const int32_t* only_if = nullptr;
-        if (fmap_solve_pcg_ok(ctx, k1, k2)) {
+        if (pcg_small) {
             // r06: the batched Jacobi-preconditioned conjugate-gradient iteration first (dm_pcg.h); the direct solver below then only
             // runs the pairs whose iteration did not converge or met a non-positive curvature (its workgroups of the other pairs leave
             // at once)
-            int32_t* fb = (int32_t*)dm_ws_take(ctx, (size_t)B * 4);
+            int32_t* fb = (int32_t*)dm_ws_take(ctx, (size_t)B * only_ng * 4);
             if (!fb) return dm_fail(ctx, DM_ENOMEM, "fmap_solve: workspace not reserved");
-            DM_CHECK_HIP(ctx, hipMemsetAsync(fb, 0, (size_t)B * 4, ctx->stream));
             const int ngroups = dm_cdiv(k2, PCG_NS);
             const size_t lds_pcg = pcg_lds_bytes(8, 4);
             rc = dm_grant_lds(ctx, (const void*)fmap_solve_pcg_kernel<8, 4>, lds_pcg);
@@ -947,7 +949,7 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
             // descriptor families x three weightings, profiles/r06_solver_jacobi_pcg_experiment.txt: <= 4.7e-5 after six steps where
             // the iteration finishes in 20 - 29, >= 2.4e-3 for rank-deficient descriptors, which would need more than 48)
             DM_LAUNCH(ctx, "fmap_solve_pcg", (fmap_solve_pcg_kernel<8, 4>), dim3((unsigned)(B * ngroups)), dim3(256), lds_pcg, PQ, lam1, lam2, c00,
-                      w_lap, k1, k2, ngroups, 1e-22, 48, 6, 3e-4, C, fb);
+                      w_lap, k1, k2, ngroups, 1e-22, 48, 6, 3e-4, C, fb, info);
             only_if = fb;
         }
 #define DM_SOLVE_REG(NBT_)                                                                                             \
@@ -955,7 +957,7 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
             rc = dm_grant_lds(ctx, (const void*)fmap_solve_reg_kernel<NBT_>, solve_reg_lds(NBT_));                     \
             if (rc) return rc;                                                                                         \
             DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_reg_kernel<NBT_>, grid, dim3(256), solve_reg_lds(NBT_), PQ, Timg, lam1, lam2, \
-                      c00, w_lap, k1, k2, NB, nsys, C, info, only_if);                                                 \
+                      c00, w_lap, k1, k2, NB, nsys, C, info, only_if, only_ng);                                        \
         }
         if (NB <= 2) DM_SOLVE_REG(2)
         else if (NB <= 4) DM_SOLVE_REG(4)
@@ -970,7 +972,7 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
         rc = dm_grant_lds(ctx, (const void*)fmap_solve_blocked_kernel, lds);
         if (rc) return rc;
         DM_LAUNCH(ctx, "fmap_solve_chol", fmap_solve_blocked_kernel, dim3(k2, B), dim3(256), lds, PQ, Timg, lam1, lam2, c00,
-                  w_lap, k1, k2, NB, C, info, only_if_big);
+                  w_lap, k1, k2, NB, C, info, only_if_big, only_ng);
         return DM_OK;
     }
     const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (n + 1 < 16 ? 16 : n + 1) + 4) * sizeof(double);

@@ -347,7 +347,7 @@ template int dm_fm_split_build_rows<float>(dm_ctx*, int, int, int, const float*,
 template int dm_fm_split_build_rows<double>(dm_ctx*, int, int, int, const double*, int, const double*, int, int, _Float16*, int);
 
 static inline int fs_depth(int K) { return 32 * ((K + 15) / 16); }    // halves per split row
-size_t dm_fm_split_zero_bytes(int B) { return 4 * dm_align_up((size_t)B * 4); }   // max |bias A|, max mass, max |bias B|, the pairs' force flags
+size_t dm_fm_split_zero_bytes(int B) { return 4 * dm_align_up((size_t)B * 4) + dm_align_up(dm_simnn_ctl_bytes(B)); }   // max |bias A|, max mass, max |bias B|, the pairs' force flags, the tile pass's control block (its own memset saved)
 bool dm_fm_split_ok(const dm_ctx* ctx, int N2, int N1, int K) {
     return ctx->opt_p2p_split != 0 && dm_simnn_dual_ok(ctx, N2, N1, fs_depth(K), true) && N1 >= 256 && N2 >= 256;
 }
@@ -423,7 +423,9 @@ int dm_launch_fm_split(dm_ctx* ctx, const dm_gred_args& a, const double* amaxS, 
         // (ind12[j] = 0 where mass1[j] = 0: the whole indicator column is 0 and np.argmax returns the first index)
         dm_simnn_cols cols{biasB, reinterpret_cast<const float*>(bmaxB), a.knn12, a.ind12, &qc, &qd, a.mass1};
         dm_simnn_dual dual{biasA, scale32, reinterpret_cast<const float*>(bmaxA), reinterpret_cast<const float*>(mmax), a.ind21, &qb, &cols, true};
-        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, force, a.knn21, nullptr, nullptr, &qa, &dual);
+        dm_simnn_ext ext;                                   // (the pass's per-pair maxima and queue counters live in the caller's zeroed block)
+        ext.ctl = reinterpret_cast<char*>(zeroed) + 4 * dm_align_up((size_t)B * 4);
+        int rc = dm_simnn_core(ctx, B, N2, N1, D, Fx, D, Fy, D, rel_extra, force, a.knn21, nullptr, nullptr, &qa, &dual, &ext);
         if (rc) return rc;
         // (Phi2 is read where the caller keeps it: targets of e0 / e1, candidates of f0 / f1)
         ks_exact_args e0{nullptr, a.BT, a.n1, nullptr, nullptr, K, N2, a.N2pad, N1, a.N1pad, a.Kpad, qa, a.knn21, Phi2, nullptr, ld2};

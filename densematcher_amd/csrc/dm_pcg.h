@@ -23,6 +23,13 @@
 #include "dm_device.h"
 
 constexpr int PCG_NS = 32;        // systems per workgroup: two 16-column tiles
+
+// did the iteration flag pair b (any of its `ng` workgroups)?  -- the direct solvers' fall-back launch
+__device__ __forceinline__ bool pcg_flagged(const int32_t* __restrict__ flags, int ng, int b) {
+    int f = 0;
+    for (int q = 0; q < ng; ++q) f |= flags[(long long)b * ng + q];
+    return f != 0;
+}
 constexpr int PCG_LDP = 48;       // LDS row stride (doubles) of the direction block: the four k-rows of a ds_read_b64 hit disjoint bank halves
 
 static inline size_t pcg_lds_bytes(int NT, int NW) { return ((size_t)NT * 16 * PCG_LDP + 2 * NW * PCG_NS + 64) * sizeof(double); }
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(64 * NW, 1) void fmap_solve_pcg_kernel(const double
                                                                     const double* __restrict__ lam2, const double* __restrict__ c00,
                                                                     double w_lap, int k1, int k2, int ngroups, double tol2, int maxit,
                                                                     int slow_it, double slow_tol2,
-                                                                    double* __restrict__ C, int32_t* __restrict__ fallback) {
+                                                                    double* __restrict__ C, int32_t* __restrict__ fallback, int32_t* __restrict__ info) {
     static_assert(NT % NW == 0, "whole tiles per wave");
     constexpr int RTW = NT / NW, KS = NT * 4;
     extern __shared__ __attribute__((aligned(16))) double pcg_sm[];
@@ -247,7 +254,9 @@ __global__ __launch_bounds__(64 * NW, 1) void fmap_solve_pcg_kernel(const double
         }
     }
     // the last direction block may still be read by a slower wave: nothing below writes the LDS
-    if (!done || notpd) { if (t == 0) fallback[b] = 1; }
+    // one flag per (pair, group), written by every workgroup: nothing to clear before the launch; group 0 also clears the pair's status word
+    // for the direct solver behind (which reports singular systems there)
+    if (t == 0) { fallback[(long long)b * ngroups + g] = (!done || notpd) ? 1 : 0; if (g == 0) info[b] = 0; }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int i = g * PCG_NS + ct * 16 + l15;
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(64 * PCGS_NW, 1) void fmap_solve_pcgs_kernel(const 
                                                                           const double* __restrict__ lam1, const double* __restrict__ lam2,
                                                                           const double* __restrict__ c00, double w_lap, int k1, int k2, int ngroups,
                                                                           int NT, int KSP, double tol2, int maxit, int slow_it, double slow_tol2,
-                                                                          double* __restrict__ C, int32_t* __restrict__ fallback) {
+                                                                          double* __restrict__ C, int32_t* __restrict__ fallback, int32_t* __restrict__ info) {
     constexpr int NW = PCGS_NW, RTW = 2, U = PCGS_U;
     extern __shared__ __attribute__((aligned(16))) double pcg_sm[];
     double* pL = pcg_sm;                                  // [16 PCGS_NT][PCG_LDP]
@@ -470,7 +479,9 @@ __global__ __launch_bounds__(64 * PCGS_NW, 1) void fmap_solve_pcgs_kernel(const 
             if (__any(slow)) break;
         }
     }
-    if (!done || notpd) { if (t == 0) fallback[b] = 1; }
+    // one flag per (pair, group), written by every workgroup: nothing to clear before the launch; group 0 also clears the pair's status word
+    // for the direct solver behind (which reports singular systems there)
+    if (t == 0) { fallback[(long long)b * ngroups + g] = (!done || notpd) ? 1 : 0; if (g == 0) info[b] = 0; }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int i = g * PCG_NS + ct * 16 + l15;
