@@ -355,8 +355,14 @@ int dm_launch_embed(dm_ctx* ctx, int B, int N, int kr, int km, const TR* Phi, in
     if (fxp) fx = *fxp;
     if (fx.F && (embT || !amax_in_part || !fx.hint)) return dm_fail(ctx, DM_EINVAL, "embed: the split-row output rides on the norms-only embedding");
     // the K-major buffer is zero padded: rows >= kr and columns >= N must be 0 for the tile kernels
-    if (embT && zero_first && (kr != krpad || N != Npad))
+    if (embT && zero_first && N == Npad && kr != krpad) {
+        // only the padding ROWS kr .. krpad - 1 of every pair (config 5: k = 200 in a 208-row buffer -- the whole buffer is 872 MB, a
+        // 150 us memset per call; its padding 33 MB)
+        DM_CHECK_HIP(ctx, hipMemset2DAsync(embT + (size_t)kr * Npad, (size_t)krpad * Npad * sizeof(double), 0, (size_t)(krpad - kr) * Npad * sizeof(double),
+                                           (size_t)B, ctx->stream));
+    } else if (embT && zero_first && (kr != krpad || N != Npad)) {
         DM_CHECK_HIP(ctx, hipMemsetAsync(embT, 0, (size_t)B * krpad * Npad * sizeof(double), ctx->stream));
+    }
     const int RT = kr <= 64 ? 1 : 2;                        // 64 RT rows per row group: two workgroups per CU at RT = 2
     const int nrg = dm_cdiv(kr, 64 * RT);
     const int ntile_j = dm_cdiv(Npad, DM_EMB_COLS), total = B * ntile_j;
