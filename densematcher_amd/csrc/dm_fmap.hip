@@ -887,15 +887,12 @@ static int fmap_solve_core(dm_ctx* ctx, int B, int k1, int k2, int D, const OPA&
     double* spill = two_phase ? (double*)dm_ws_take(ctx, spill_bytes) : nullptr;
     if (!PQ || (blocked && !Timg) || (two_phase && !spill)) return dm_fail(ctx, DM_ENOMEM, "fmap_solve: workspace not reserved");
     if (blocked) DM_CHECK_HIP(ctx, hipMemsetAsync(Timg, 0, img_bytes, ctx->stream));
-    // The iteration's time does not depend on the batch while its workgroups fit the chip (~125 us at n = 127, ~320 us at n = 199: ~24
-    // dependent steps), the direct solvers' grows with it (46 us per round of 4 systems per CU at n <= 128, 80 us per round of one system
-    // per CU above): small batches stay direct.  opt_solve_pcg = 2 forces the iteration (tests).
-    const long long nsys_all = (long long)B * k2;
-    const int ncu_ = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    const bool force_pcg = ctx->opt_solve_pcg == 2;
-    const bool pcg_small = blocked && !two_phase && NB <= 8 && ctx->opt_solve_reg && fmap_solve_pcg_ok(ctx, k1, k2) &&
-                           (force_pcg || nsys_all >= 12LL * ncu_);
-    const bool pcg_big = (two_phase || (blocked && NB >= 9)) && ctx->opt_solve_pcg && !ctx->opt_solve_packed && (force_pcg || nsys_all >= 4LL * ncu_);
+    // The solver is chosen by the SIZES alone, never by the batch: a pair's bits do not depend on the batch it is in.  (Measured and not
+    // adopted: the iteration costs ~125 us at n = 127 / ~330 us at n = 199 whatever the batch, the direct solvers 52 / 98 us for ONE pair --
+    // they win below 16-24 pairs of k = 128 and below 4 pairs of k = 200, profiles/r06_solve_pcg_crossover.txt -- but a switch on B k2
+    // makes the map of a pair solved alone differ by 5e-12 from the same pair in a batch of 64.)
+    const bool pcg_small = blocked && !two_phase && NB <= 8 && ctx->opt_solve_reg && fmap_solve_pcg_ok(ctx, k1, k2);
+    const bool pcg_big = (two_phase || (blocked && NB >= 9)) && ctx->opt_solve_pcg && !ctx->opt_solve_packed;
     // (with the batched iteration in front, its group-0 workgroups clear the status words: one memset launch less per call)
     if (!pcg_small && !pcg_big) DM_CHECK_HIP(ctx, hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), ctx->stream));
 

@@ -48,7 +48,7 @@ struct dm_ctx {
                                  // N = 8192 (tools/simnn_band_sweep.py: 8.93 / 8.62 / 8.44 / 8.57 / 8.82 ms for 0 / 2 / 4 / 8 / 16), neutral at N = 2048
     int opt_lsa_reg = 2;         // linear assignment: 0 the LDS-state kernel, 1 the register-state kernel in SciPy's order, 2 the same
                                  // from a column-reduction start, kept where the optimum is provably unique, else redone in order
-    int opt_solve_pcg = 1;       // 1: systems of order 65 .. 199 by the batched preconditioned conjugate-gradient iteration (dm_pcg.h) where the batch is large enough for it to win, the direct solver as its fall-back; 2: always; 0: direct
+    int opt_solve_pcg = 1;       // 1: systems of order 65 .. 199 by the batched preconditioned conjugate-gradient iteration (dm_pcg.h), the direct solver as its fall-back; 0: direct
     int opt_solve_reg = 1;       // 0: the LDS-resident blocked solver also where the register-resident one (n <= 128) would run
     int opt_p2p_split = 2;       // four maps: 0 the float64 G kernel, 1 two passes of the two-key fp16 tile kernel, 2 one pass reducing in both directions (3: 4-wave shape)
     int opt_simnn_persist = 1;   // 0: one workgroup per similarity tile instead of one persistent workgroup per CU

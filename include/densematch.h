@@ -86,8 +86,8 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *   "p2pfm_direct"  1 | 0   dm_p2p_to_fm (and the p2p_to_FM steps of dm_zoomout / dm_icp): register-resident tiles, operands straight
  *                           from global memory, fixed-order in-workgroup reduction | LDS-staged 64 x 64 tiles + split-K partials + reduce
  *   "simnn1_wt"     4 | 2   tile shape of the fused ZoomOut search: 8 waves, 256 x 256 | 4 waves, 128 x 256 (two workgroups per CU)
- *   "solve_pcg"     1 | 0 | 2   dm_fmap_solve / dm_fmap_fit, 66 <= k1 <= 200, batches of at least 12 (k1 <= 129) / 4 (above) systems per
- *                           compute unit (2: any batch): the k2 systems of a pair by a batched Jacobi-preconditioned
+ *   "solve_pcg"     1 | 0   dm_fmap_solve / dm_fmap_fit, 66 <= k1 <= 200 (any batch: the choice follows the sizes only, a pair's result
+ *                           does not depend on its batch): the k2 systems of a pair by a batched Jacobi-preconditioned
  *                           conjugate-gradient iteration on the float64 matrix cores (stops at a 1e-11 relative reduction: C within 1e-9 of
  *                           the direct solution; ill-conditioned pairs leave it after six steps and take the direct solver) | direct
  *                           solvers only.  The two settings agree to 1e-9, not bit for bit.

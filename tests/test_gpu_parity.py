@@ -1094,7 +1094,7 @@ def test_solver_batched_pcg_equals_direct(eng, k, N):
     F1, F2 = np.stack([f[0] for f in F]), np.stack([f[1] for f in F])
 
     def fit(pcg, F1_, F2_):
-        eng.set_option("solve_pcg", 2 * pcg)               # (2: the iteration whatever the batch size; 1 leaves small batches to the direct solvers)
+        eng.set_option("solve_pcg", pcg)               # (2: the iteration whatever the batch size; 1 leaves small batches to the direct solvers)
         eng.profile_kernel("*")
         C = eng.fmap_fit(P1, P2, a1, a2, F1_, F2_, lam1, lam2, 1e4, 1e3, k1=k, k2=k).cpu().numpy()
         names = set(eng.profile_report())

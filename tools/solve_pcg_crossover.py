@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""r06: where does the batched iteration (solve_pcg = 2: forced) beat the direct solvers (0) as the batch grows?  Solver kernel time per call (us).
+"""r06: where does the batched iteration (solve_pcg = 1) beat the direct solvers (0) as the batch grows?  Solver kernel time per call (us).
 usage: python tools/solve_pcg_crossover.py"""
 import os
 import sys
@@ -18,7 +18,7 @@ for wl, Bs in (("fmap", (1, 4, 8, 16, 24, 32, 64)), ("stress", (1, 2, 4, 8, 16))
     for B in Bs:
         dev = {q: torch.as_tensor(v[:B]).to(eng.device) for q, v in host.items()}
         row = []
-        for mode in (0, 2):
+        for mode in (0, 1):
             eng.set_option("solve_pcg", mode)
             for _ in range(3):
                 eng.fmap_fit(dev["Phi1"], dev["Phi2"], dev["a1"], dev["a2"], dev["F1"], dev["F2"], dev["lam1"], dev["lam2"], 1e4, 1e3, k1=k, k2=k)
