@@ -527,7 +527,7 @@ def main():
                 for key, which in (("config4_zoomout", "zoomout"), ("icp", "icp")):
                     blk = secondary_refine(eng, rank, barrier, which)
                     details[key] = blk
-                    summary[key] = {q: blk[q] for q in ("value", "unit", "ms_per_step", "launches_per_step")}
+                    summary[key] = {q: blk[q] for q in ("value", "unit", "ms_per_step", "launches_per_step", "step10_nit15") if q in blk}
                 blk = secondary_stress(eng, rank, barrier)
                 details["config5_stress"] = blk
                 summary["config5_stress"] = {q: blk[q] for q in ("value", "unit", "ms_per_step", "launches_per_step", "workspace_bytes")}
@@ -593,6 +593,8 @@ def compact_summary(summary, pcie):
         blk = summary.get(key)
         if blk:
             s[short] = {"pairs_s": rnd(blk.get("value"), 1), "step_ms": rnd(blk.get("ms_per_step"), 3), "launches": blk.get("launches_per_step")}
+            if blk.get("step10_nit15"):
+                s[short]["step10_pairs_s"] = rnd(blk["step10_nit15"].get("value"), 1)
     sm = summary.get("surface_map")
     if sm:
         s["sm"] = {"single_ms": rnd(sm.get("single_call_ms"), 2), "batch_pairs_s": rnd(sm.get("batched_pairs_per_s"), 1),
@@ -764,6 +766,13 @@ def secondary_refine(eng, rank, barrier, which):
            "config": {"workload": w["cfg"], "pairs_per_gpu": B, "N": N, "k": k, "basis_dtype": str(host["Phi1"].dtype)},
            "kernel_ms_per_step": round(kms, 3), "launches_per_step": round(nl, 1),
            "launches_per_iteration": round(nl / (150 if which == "zoomout" else 10), 2), "kernels": table}
+    if which == "zoomout":
+        # the same refinement in steps of ten (15 iterations: the maps of sizes 50, 60, ... 200), reported beside step 1
+        def step10():
+            return eng.zoomout(dev["Phi1"], dev["Phi2"], dev["a2"], C0, nit=15, step=10)
+        el10, _, _, bl10 = timed_kernel(eng, step10, "simnn1_f16_mfma", 10, 2, barrier, n_blocks=3)
+        out["step10_nit15"] = {"value": round(B * 10 / el10, 1), "unit": "mesh-pairs/s", "ms_per_step": round(1e3 * el10 / 10, 3), "steps": 10,
+                               "blocks_ms_per_step": [round(1e3 * b_ / 10, 3) for b_ in bl10]}
     del dev
     torch.cuda.empty_cache()
     return out
