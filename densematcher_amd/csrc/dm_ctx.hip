@@ -88,6 +88,7 @@ extern "C" int dm_set_option(dm_ctx* ctx, const char* name, int value) {
     else if (n == "simnn_big") ctx->opt_simnn_big = value;
     else if (n == "simnn_prio") ctx->opt_simnn_prio = value;
     else if (n == "fit_f32") ctx->opt_fit_f32 = value;
+    else if (n == "fit_mfma") ctx->opt_fit_mfma = value;
     else if (n == "solve_pcg") ctx->opt_solve_pcg = value;
     else if (n == "basis_stats") { ctx->opt_basis_stats = value; for (auto& e : ctx->stats) e.valid = false; }
     else if (n == "lsa_reg") ctx->opt_lsa_reg = value;

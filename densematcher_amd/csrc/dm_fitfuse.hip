@@ -55,6 +55,7 @@ struct ff_params {
     const double* sums;
     double* energy; double* grad;
     int advance; lbfgs_opts lo; lb_layout L;
+    int use_mfma;                               // fp32 element loop, k1 <= 16: the two 16-deep products of an entry on v_mfma_f32_16x16x4_f32 (dm_set_option fit_mfma)
     int dbg_mode;                               // experiments build (WRONG results): 1 no unit epilogue, 2 every column reads Psi row 0, 4 no element-wise terms
     long long* dbg;                             // experiments build: 16 time stamps (100 MHz counter) of the pair-0 chain of the last launch; else null
 };
@@ -156,9 +157,11 @@ __device__ __forceinline__ double ff_wave_sum(double v) {
 
 // F32: the element loop (product, element-wise terms, Y update) in fp32 like the reference's; everything around it -- E2 = Phi2 C, the unit
 // epilogue, partial sums, the quadratic and sum-to-one terms, the optimiser -- stays float64.
-template <int KL1, int K2P, bool GENERAL, bool F32 = false>
+// MF (F32, KL1 = 16): the two 16-deep products of an entry on v_mfma_f32_16x16x4_f32 instead of the packed vector FMA.
+template <int KL1, int K2P, bool GENERAL, bool F32 = false, bool MF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ? 4 : 2, KL1 <= 16 ? 4 : 2))) void ff_eval_kernel(const ff_params p, const double* __restrict__ Psi, const float* __restrict__ Psi32) {
     constexpr int KT1 = (KL1 + 15) / 16 * 16, T1 = KT1 / 16, T2 = K2P / 16;
+    constexpr bool USE_MF = F32 && MF && KL1 == 16;
     extern __shared__ __attribute__((aligned(16))) double ff_sm[];
     double* Ltab = ff_sm;                            // [128][2]        (u_i, -log u_i) of the in-line logarithm
     double* Cs = Ltab + 256;                         // [K2P][KL1]      the trial map, zero padded
@@ -197,7 +200,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #pragma unroll
         for (int tc = 0; tc < T1; ++tc) acc[ta][tc] = 0.0;
     double eacc_chunk = 0.0;                           // (thread 0)
-    double E2[KL1];
+    double E2[USE_MF ? 1 : KL1];
+    float e2b[4][4];                                   // (MF) E2 of the wave's rows in the matrix instruction's B distribution: [16 ib + l15][4 s + g]
     int rb_prev = -1;
     for (int u = u_begin; u < u_end; ++u) {
         const int rb = u / p.ncc, cc = u - rb * p.ncc;
@@ -222,13 +226,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #pragma unroll
             for (int a = 0; a < K2P; ++a)
                 if (a / (K2P / 4) == wave) P2s[a * FF_LDT + lane] = (double)x[a];
+            double E2n[KL1];
 #pragma unroll
-            for (int c = 0; c < KL1; ++c) E2[c] = 0.0;
+            for (int c = 0; c < KL1; ++c) E2n[c] = 0.0;
 #pragma unroll
             for (int a = 0; a < K2P; ++a) {
                 const double xa = (double)x[a];
 #pragma unroll
-                for (int c = 0; c < KL1; ++c) E2[c] = fma(xa, Cs[a * KL1 + c], E2[c]);
+                for (int c = 0; c < KL1; ++c) E2n[c] = fma(xa, Cs[a * KL1 + c], E2n[c]);
+            }
+            if constexpr (USE_MF) {
+                // (Ysh is free here: the previous unit's epilogue ended with a barrier)
+                float* wbuf = reinterpret_cast<float*>(Ysh) + wave * 1024;          // wave-private [64][16] floats
+                const int l15 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) wbuf[lane * 16 + ((c + lane) & 15)] = (float)E2n[c];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) { const int row = 16 * ib + l15; e2b[ib][s4] = wbuf[row * 16 + ((4 * s4 + g4 + row) & 15)]; }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int c = 0; c < KL1; ++c) E2[c] = E2n[c];
             }
             rb_prev = rb;
         }
@@ -245,6 +266,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
             // fp32: two entries of the 16-deep products per v_pk_fma_f32 (the row of the other factor is an aligned pair of scalar
             // registers), the element-wise terms on v_log_f32 / v_rcp_f32, Y in fp32 for the wave's 32 columns of this unit
             const float* psf = Psi32 + ((long long)b * p.N1pad + cc * FF_COLS + wave * FF_WCOLS) * KL1;
+            if constexpr (USE_MF) {
+                // The wave's 64 rows x 32 columns as 4 x 2 blocks of 16 x 16, TRANSPOSED (block entry [j][i]): the product on four
+                // v_mfma_f32_16x16x4_f32 (A = 16 rows of Psi, B = the rows' E2 for 16 vertices i: e2b), the element-wise terms on the four
+                // results a lane holds (j = 4 g + r, i = lane & 15), and those four registers ARE the B operand of the back-product
+                // Y^T[c][i] += sum_j Psi[j][c] d[j][i] (contraction index j = 4 g + r of instruction r): no exchange between the two
+                // products.  The vector ALU keeps the element-wise terms only; the matrix pipe runs beside it.
+                float* wbuf = reinterpret_cast<float*>(Ysh) + wave * 1024;          // wave-private [64][16] floats (Ysh is free inside the loop)
+                const int l15 = lane & 15, g4 = lane >> 4;
+                f32x4 Yt[4];
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) Yt[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const float w_ent = (float)p.w_ent, w_p2p = (float)p.w_p2p, w_r01 = (float)p.w_r01;
+                float eaf = 0.f;
+                // (both column blocks' operands requested up front: the second block's loads fly under the first block's work)
+                float pa2[2][4], pb2[2][4];                                       // Psi[16 jb + l15][4 s + g], Psi[16 jb + 4 g + r][l15]
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) pa2[jb][s4] = psf[(16 * jb + l15) * jmul + 4 * s4 + g4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pb2[jb][r] = psf[(16 * jb + 4 * g4 + r) * jmul + l15];
+                }
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    const float (&pa)[4] = pa2[jb];
+                    const float (&pb)[4] = pb2[jb];
+                    // (the four row blocks side by side: four independent accumulator chains per product, not one)
+                    f32x4 Dv[4];
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) Dv[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                        for (int ib = 0; ib < 4; ++ib) Dv[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s4], e2b[ib][s4], Dv[ib], 0, 0, 0);
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+#ifdef DM_EXPERIMENTS
+                            if (p.dbg_mode & 4) continue;
+#endif
+                            Dv[ib][r] = ff_element_f32<GENERAL>(Dv[ib][r], w_ent, w_p2p, w_r01, eaf);
+                        }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ib = 0; ib < 4; ++ib) Yt[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[r], Dv[ib][r], Yt[ib], 0, 0, 0);
+                }
+                // Y^T[c = 4 g + r][i = 16 ib + l15] -> the lane that owns row i
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int row = 16 * ib + l15; wbuf[row * 16 + ((4 * g4 + r + row) & 15)] = Yt[ib][r]; }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) Y[c] = (double)wbuf[lane * 16 + ((c + lane) & 15)];
+                eacc = (double)eaf;
+            } else {
             ff_f32x2 E2f[KL1 / 2], Yf[KL1 / 2];
 #pragma unroll
             for (int c = 0; c < KL1 / 2; ++c) { E2f[c] = ff_f32x2{(float)E2[2 * c], (float)E2[2 * c + 1]}; Yf[c] = ff_f32x2{0.f, 0.f}; }
@@ -272,6 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
 #pragma unroll
             for (int c = 0; c < KL1 / 2; ++c) { Y[2 * c] = (double)Yf[c][0]; Y[2 * c + 1] = (double)Yf[c][1]; }
             eacc = (double)eaf;
+            }
         } else {
 #pragma unroll
         for (int c = 0; c < KL1; ++c) Y[c] = 0.0;
@@ -301,6 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KL1 <= 16 ?
             const double es = ff_wave_sum(eacc);
             if (lane == 0) esh[wave] = es;
         }
+        if constexpr (USE_MF) __syncthreads();                   // (the waves' private pieces of Ysh are read: the panels below may be written)
         if (wave & 1) {
 #pragma unroll
             for (int c = 0; c < KL1; ++c) Ysh[((wave >> 1) * KT1 + c) * 64 + lane] = Y[c];
@@ -628,11 +709,11 @@ static size_t ff_lds_bytes() {
     return (256 + (size_t)K2P * KL1 + (size_t)K2P * FF_LDT + (size_t)KT1 * FF_LDT + (panels > dsh ? panels : dsh)) * 8;
 }
 
-template <int KL1, int K2P, bool GENERAL, bool F32>
+template <int KL1, int K2P, bool GENERAL, bool F32, bool MF = false>
 static int ff_launch1(dm_ctx* ctx, const ff_params& p, const double* Psi, size_t lds, dim3 grid) {
-    int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, GENERAL, F32>, lds);
+    int rc = dm_grant_lds(ctx, (const void*)ff_eval_kernel<KL1, K2P, GENERAL, F32, MF>, lds);
     if (rc) return rc;
-    DM_LAUNCH(ctx, "fit_fused_eval", (ff_eval_kernel<KL1, K2P, GENERAL, F32>), grid, dim3(256), lds, p, Psi, p.Psi32);
+    DM_LAUNCH(ctx, "fit_fused_eval", (ff_eval_kernel<KL1, K2P, GENERAL, F32, MF>), grid, dim3(256), lds, p, Psi, p.Psi32);
     return DM_OK;
 }
 template <int KL1, int K2P>
@@ -643,6 +724,10 @@ static int ff_launch(dm_ctx* ctx, const ff_params& p, const double* Psi, bool ge
         int nb = -1;
         hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ff_eval_kernel<KL1, K2P, false>, 256, lds);
         fprintf(stderr, "fit_fused: occupancy %d workgroups per CU (%s), dynamic LDS %zu bytes, grid %u, W = %d\n", nb, hipGetErrorString(e_), lds, grid.x, p.W);
+    }
+    if constexpr (KL1 == 16 && K2P == 16) {             // (maps up to 16 x 16: the 32-row form would spill under four waves per SIMD)
+        if (p.Psi32 && p.use_mfma)
+            return general ? ff_launch1<KL1, K2P, true, true, true>(ctx, p, Psi, lds, grid) : ff_launch1<KL1, K2P, false, true, true>(ctx, p, Psi, lds, grid);
     }
     if (p.Psi32) return general ? ff_launch1<KL1, K2P, true, true>(ctx, p, Psi, lds, grid) : ff_launch1<KL1, K2P, false, true>(ctx, p, Psi, lds, grid);
     return general ? ff_launch1<KL1, K2P, true, false>(ctx, p, Psi, lds, grid) : ff_launch1<KL1, K2P, false, false>(ctx, p, Psi, lds, grid);
@@ -751,6 +836,7 @@ extern "C" int dm_fmap_fit_fused(dm_ctx* ctx, int B, int N1, int N2, int k1, int
     DM_CHECK_HIP(ctx, hipMemcpyAsync(active, host_active.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
     DM_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));         // (the host vector is rewritten below)
     p.active = active;
+    p.use_mfma = ctx->opt_fit_mfma != 0;
     p.Phi2 = Phi2; p.ld2 = ld2; p.Psi32 = Psi32; p.xt = xt; p.unit_part = unit_part; p.chunk_part = chunk_part;
     p.chunk_cnt = cnt; p.pair_cnt = cnt + (size_t)B * p.nchunks;
     p.w_p2p = weights[3]; p.w_ent = weights[5]; p.w_r01 = weights[6]; p.w_sum = weights[7];

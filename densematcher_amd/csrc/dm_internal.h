@@ -41,6 +41,7 @@ struct dm_ctx {
     int opt_knn_split = 1;       // 0: knn21 (ZoomOut, ICP, knn_query) on the float64 G kernel instead of the fp16 split
     int opt_solve_packed = 0;    // 1: the packed-storage solver for every system size it supports
     int opt_proj_onepass = 1;    // 1: the fp16-split projection reads the basis once (running scale per workgroup); 0: maxima pass + fp32 copy + r03 tile kernel
+    int opt_fit_mfma = 1;        // fp32 element loop of dm_fmap_fit_fused, maps up to 16 x 16: the two products of an entry on v_mfma_f32_16x16x4_f32 (1) or on the packed vector FMA (0); both agree with the oracle to the same 1e-7
     int opt_fit_f32 = 0;         // 1: dm_fmap_fit_fused runs its element loop in fp32 (the reference's precision), 0: float64
     int opt_simnn_prio = 0;      // 1: the tile kernels raise their wave priority around the matrix instructions (s_setprio)
     int opt_simnn_big = 0;       // 1: the tile kernels run four waves of 128 x 128 (accumulators in AGPRs) instead of eight of 128 x 64

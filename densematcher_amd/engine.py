@@ -87,7 +87,7 @@ class MatchEngine:
         self.stream.synchronize()
 
     OPTION_DEFAULTS = {"simnn_pipe": 1, "simnn_persist": 1, "knn_split": 1, "p2p_split": 2, "solve_packed": 0, "solve_reg": 1, "simnn_band": 4, "lsa_reg": 2, "simnn_big": 0, "energy_keep_gram": 0,
-                       "p2pfm_direct": 1, "zoomout_fused": 1, "proj_onepass": 1, "fit_f32": 0, "basis_stats": 1, "solve_pcg": 1}
+                       "p2pfm_direct": 1, "zoomout_fused": 1, "proj_onepass": 1, "fit_f32": 0, "fit_mfma": 1, "basis_stats": 1, "solve_pcg": 1}
 
     def set_option(self, name, value):
         """Choose between equivalent code paths of the library (include/densematch.h: dm_set_option); every setting

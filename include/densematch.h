@@ -98,6 +98,10 @@ size_t dm_workspace_bytes(const dm_ctx* ctx);
  *                           the precision the reference evaluates these terms in (pyFM/functional.py:379-383).  The ONE option whose two
  *                           settings differ in the result: energy / gradient within 1e-6 relative, the fitted map within 3e-6 under
  *                           SciPy's stopping rule.  The Python layer chooses it from the stopping rule (engine.py: _fit_fused).
+ *   "fit_mfma"      1 | 0   the fp32 element loop for maps up to 16 x 16: the two 16-deep products of an entry (the entry itself and the
+ *                           back-product of its derivative) on v_mfma_f32_16x16x4_f32, the element-wise terms alone on the vector ALU | both
+ *                           on the packed vector FMA.  Different summation orders of the same fp32 arithmetic: both within 1e-7 (energy) /
+ *                           1e-6 (gradient) of the float64 oracle, fitted maps within 1e-6 of each other.
  * Unknown names return DM_EINVAL.  The library never reads environment variables. */
 int dm_set_option(dm_ctx* ctx, const char* name, int value);
 /* Diagnostics of the LAST dm_fm_to_p2p[_f64] / dm_simnn_f16 call on ctx (synchronises the stream): out[q] = rows of reduction q

@@ -156,6 +156,59 @@ def test_fused_fp32_element_loop_against_oracle(N1, N2, k1, k2):
             assert np.abs(G[b].cpu().numpy() - Go).max() <= 1e-6 * np.abs(Go).max(), (w, b)
 
 
+@pytest.mark.parametrize("N1,N2,k1,k2", [(300, 517, 15, 13), (1000, 777, 16, 16), (129, 65, 7, 9), (200, 4100, 12, 16)])
+def test_fused_fp32_loop_matrix_and_vector_forms(N1, N2, k1, k2):
+    """r06: maps up to 16 x 16 run the fp32 element loop's two 16-deep products on v_mfma_f32_16x16x4_f32 (dm_set_option fit_mfma = 1, the
+    default); the packed-vector form (0) stays for wider maps.  Same fp32 arithmetic in another summation order: both forms within 2e-6
+    (relative to |E|, max |G|) of the oracle's float64 values, on ragged sizes (rows and columns past the last 64 x 128 unit) too."""
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(N1 + 3 * N2 + k1)
+    e1, e2, a1, C, A, Bm, lam1, lam2 = _random_problem(rng, 2, N1, N2, k1, k2)
+    C[1] *= 40.0
+    try:
+        for w in ({"w_ent": 0.3}, dict(NOTEBOOK_W), {"w_p2p": 0.5, "w_ent": 0.3, "w_range01": 1.5, "w_sumto1": 2.0, "w_descr": 1.0, "w_lap": 0.1}):
+            for mf in (0, 1):
+                eng.set_option("fit_mfma", mf)
+                E, G = eng.energy_grad_fused(C, A, Bm, lam1, lam2, w, e1, e2, a1, precision="f32")
+                for b in range(2):
+                    ev = orc.ev_sqdiff(lam1[b], lam2[b])
+                    Eo, Go = orc.energy_grad_general(C[b], A[b].astype(np.float64), Bm[b].astype(np.float64), ev, e1[b], e2[b], a1[b], w)
+                    assert abs(float(E[b]) - Eo) <= 2e-6 * abs(Eo), (w, mf, b, float(E[b]), Eo)
+                    assert np.abs(G[b].cpu().numpy() - Go).max() <= 2e-6 * np.abs(Go).max(), (w, mf, b)
+    finally:
+        eng.set_option("fit_mfma", 1)
+
+
+def test_fused_fit_matrix_form_same_iterations_batch_invariant(fx_cfg1):
+    """the notebook's fit (15 x 15, SciPy's stopping rule: fp32 loop) with the products on the matrix instruction: the iteration count of the vector
+    form to within a step (the rule stops on an energy at its fp32 noise floor), the map within 1e-4 of it (7e-7 where the counts agree), a
+    pair's bits independent of its batch (1, 3, 140)"""
+    from densematcher_amd.engine import default_engine
+    eng = default_engine()
+    fx = fx_cfg1
+    k = 15
+    x0 = orc.get_x0(k, k, float(fx["Phi1"][0, 0]), float(fx["Phi2"][0, 0]), float(fx["a1"].astype(np.float64).sum()),
+                    float(fx["a2"].astype(np.float64).sum()))
+    b3 = _fit_batch(fx, k, 3, None)
+    try:
+        eng.set_option("fit_mfma", 0)
+        Cv, rv = eng.fit_general(b3, NOTEBOOK_W, np.stack([x0] * 3))
+        eng.set_option("fit_mfma", 1)
+        Cm, rm = eng.fit_general(b3, NOTEBOOK_W, np.stack([x0] * 3))
+        assert rm.element_loop == "f32" and rv.element_loop == "f32"
+        assert np.abs(rm.nit.astype(int) - rv.nit.astype(int)).max() <= 2          # (SciPy's rule stops on an fp32-noisy energy: 39 / 40 / 37 against 39 / 39 / 37)
+        print("fused fit, matrix against vector form: |C_m - C_v| =", np.abs(Cm - Cv).max(), "iterations", rm.nit, rv.nit)
+        assert np.abs(Cm - Cv).max() < 1e-4                                         # (one more step of a fit that stops ~5e-4 short of the minimiser)
+        C1, _ = eng.fit_general({n: v[:1] for n, v in b3.items()}, NOTEBOOK_W, x0[None])
+        assert np.array_equal(C1[0], Cm[0])
+        big = _fit_batch(fx, k, 140, None)
+        Cb, _ = eng.fit_general(big, NOTEBOOK_W, np.stack([x0] * 140))
+        assert all(np.array_equal(Cb[b], Cm[b % 3]) for b in (0, 1, 2, 137, 139))
+    finally:
+        eng.set_option("fit_mfma", 1)
+
+
 def test_fused_fit_precision_follows_the_stopping_rule(fx_cfg1):
     """SciPy's stopping rule (the reference's call, the default) runs the element loop in fp32 like the reference: the same iterations as
     the float64 loop, the map within 1e-4 of it (measured 3e-6), bit-identical in batches of 1, 3 and 140; a tighter rule (ftol 1e-12 is

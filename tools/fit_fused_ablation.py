@@ -13,6 +13,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     from densematcher_amd import _build, synth
     from densematcher_amd.engine import MatchEngine
     eng = MatchEngine(0, lib_path=_build.LIB_EXP)
+    eng.set_option("fit_mfma", int(os.environ.get("DM_FIT_MFMA", "0")))      # (the element loop's products on the fp32 matrix instruction)
     B, k = 64, 15
     host = synth.make_pair_batch(B, 64, 32, 64, k, sigma=0.5, n_distinct_meshes=1, basis="random")
     dev = {n: torch.as_tensor(v).to(eng.device) for n, v in host.items()}
@@ -27,7 +28,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
             print("  (fit ended with", type(e).__name__, ")")
     nl, ms = eng.profile_read()
     ne = int(res.nfev.max())
-    print(f"  DM_FF_MODE={os.environ.get('DM_FF_MODE', '0')}: {nl} launches, evaluations min {int(res.nfev.min())} max {ne}; {1e3 * ms / ne:.1f} us per evaluation "
+    print(f"  fit_mfma={os.environ.get('DM_FIT_MFMA', '0')} DM_FF_MODE={os.environ.get('DM_FF_MODE', '0')}: {nl} launches, evaluations min {int(res.nfev.min())} max {ne}; {1e3 * ms / ne:.1f} us per evaluation "
           f"(empty launches behind the last evaluation included: a few us each)", flush=True)
 else:
     for mode, label in ((0, "product"), (1, "no unit epilogue"), (2, "every column reads Psi row 0 (scalar-cache hits)"), (4, "no element-wise terms (products only)"),
